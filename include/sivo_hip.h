@@ -1,0 +1,224 @@
+/*
+ * sivo_hip.h — C ABI of libsivo_hip.so: the MI355X (gfx950) implementation of
+ * navganti/SIVO's per-frame perception hot path.
+ *
+ * The reference has no FFI layer: its seam is the C++ class API of three
+ * shared libraries (reference CMakeLists.txt:74-123).  Every entry point below
+ * names the reference interface it stands behind; the C++ classes with the
+ * reference's own signatures (sivo_amd/api/) are thin callers of this ABI, and
+ * INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only; `int` status (0 = ok); no
+ * exceptions cross the boundary; `*_dev` entry points take DEVICE pointers and
+ * a hipStream_t passed as void* (NULL = the default stream) and never
+ * synchronise; the others take HOST pointers and return when the result is
+ * ready.  Handles are not re-entrant (reference BayesianSegNet::segmentImage
+ * mutates a shared input blob too); distinct handles may be used from
+ * distinct host threads (reference Frame.cc:126-129 runs two ORBextractors
+ * concurrently).
+ */
+#ifndef SIVO_HIP_H
+#define SIVO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIVO_OK 0
+#define SIVO_ERR_INVALID_ARGUMENT 1 /* the C++ classes rethrow this as std::invalid_argument
+                                       (reference bayesian_segnet.cpp:65-70,80-89) */
+#define SIVO_ERR_RUNTIME 2          /* HIP error / no device */
+#define SIVO_ERR_UNSUPPORTED 3      /* layer type or shape outside the two reference nets' vocabulary */
+#define SIVO_ERR_IMAGE_TOO_SMALL 4  /* reference resizeImage returns an empty Mat (bayesian_segnet.cpp:142-162) */
+#define SIVO_ERR_CAPACITY 5         /* caller buffer too small */
+
+/* Thread-local text of the last failure on this thread. */
+const char *sivo_last_error(void);
+int sivo_version(void);
+/* Number of visible HIP devices (0 when there is none; never fails). */
+int sivo_device_count(void);
+
+/* ===========================================================================
+ * Bayesian SegNet — stands behind SIVO::BayesianSegNet
+ * (reference include/bayesian_segnet/bayesian_segnet.hpp:108-170,
+ *  src/bayesian_segnet/bayesian_segnet.cpp:46-78, 299-318).
+ * ======================================================================== */
+typedef struct sivo_segnet *sivo_segnet_t;
+
+/* BayesianSegNet::BayesianSegNet (bayesian_segnet.cpp:46-78): parse the Caffe
+ * prototxt text, take T,C,H,W from the input blob, upload the parameters.
+ * `weights` is the flat fp32 parameter array in prototxt layer order
+ * (Convolution: W[Cout][Cin][k][k] then bias[Cout]; BN: scale[C] then
+ * shift[C]).  t_override > 0 replaces the prototxt batch size (the standard
+ * prototxt ships with it blank).  Errors: empty text / C != 3 / T <= 1 ->
+ * SIVO_ERR_INVALID_ARGUMENT, as the reference constructor throws. */
+int sivo_segnet_create(const char *prototxt_text, size_t prototxt_len, int t_override,
+                       const float *weights, size_t n_weights, int device, sivo_segnet_t *out);
+/* Same from files: model_file = prototxt, weights_file = .sivow container
+ * (sivo_amd/weights.py).  Empty paths -> SIVO_ERR_INVALID_ARGUMENT
+ * (bayesian_segnet.cpp:80-89, pinned by tests/test_bayesian_segnet.cpp:138-150). */
+int sivo_segnet_create_from_files(const char *model_file, const char *weights_file, int t_override,
+                                  int device, sivo_segnet_t *out);
+int sivo_segnet_destroy(sivo_segnet_t h);
+/* getInputGeometry (bayesian_segnet.hpp) and the blob shapes: T, C(=3), H, W, classes. */
+int sivo_segnet_shape(sivo_segnet_t h, int32_t *T, int32_t *C, int32_t *H, int32_t *W, int32_t *classes);
+/* Number of fp32 parameters the prototxt implies (size of `weights`). */
+int sivo_segnet_num_params(const char *prototxt_text, size_t prototxt_len, size_t *n_params);
+
+/* network->Forward() (bayesian_segnet.cpp:310) for `n_samples` Monte-Carlo
+ * samples with global indices sample0 .. sample0+n_samples-1 (the T samples
+ * of one frame are sharded over ranks this way; n_samples <= T).
+ *   d_bgr       device, H*W*3 u8, BGR interleaved, already cropped to H x W
+ *               (preprocessImage, :164-178: no scaling, no mean)
+ *   d_prob_sum  device, classes*H*W fp32: sum over the n_samples of the
+ *               per-pixel softmax (the tensor the all-reduce carries); the mean
+ *               of extractMeanConfidence (:278-297) is this / T_total
+ *   d_logits    device or NULL, n_samples*classes*H*W fp32 pre-softmax scores
+ *   d_prob      device or NULL, n_samples*classes*H*W fp32 softmax ("prob" blob)
+ * Dropout masks: Philox4x32-10 keyed on (seed; site, global sample, element). */
+int sivo_segnet_forward_dev(sivo_segnet_t h, const uint8_t *d_bgr, int n_samples, int sample0,
+                            uint64_t seed, float *d_prob_sum, float *d_logits, float *d_prob,
+                            void *stream);
+
+/* computeClasses / computeMaxConfidence / computeClassificationEntropy
+ * (bayesian_segnet.cpp:180-203, 262-276) from the probability sum:
+ * mean = sum / t_total in f64; argmax (first maximum wins), max, and
+ * sum_c (p == 0 ? 0 : -p*log2 p). */
+int sivo_mc_finalize_dev(const float *d_prob_sum, int classes, int64_t hw, int t_total,
+                         uint8_t *d_classes, double *d_confidence, double *d_entropy, void *stream);
+
+/* Softmax over the class axis of (n, classes, hw) logits and sum over n
+ * (Softmax layer + the sum half of extractMeanConfidence).  accumulate != 0
+ * adds to d_prob_sum instead of overwriting it. */
+int sivo_mc_reduce_dev(const float *d_logits, int n, int classes, int64_t hw, float *d_prob_sum,
+                       float *d_prob, int accumulate, void *stream);
+
+/* computeVariance (bayesian_segnet.cpp:205-260; private and unused in the
+ * reference): sample variance over T of the winning class's probability. */
+int sivo_mc_variance_dev(const float *d_prob, int T, int classes, int64_t hw, const uint8_t *d_classes,
+                         double *d_variance, void *stream);
+
+/* BayesianSegNet::segmentImage (bayesian_segnet.cpp:299-318), host buffers:
+ * centre-crop (resizeImage :142-162), upload, T samples, finalize, download.
+ * classes: H*W u8, confidence / entropy: H*W f64 (row-major, like MatXu/MatXd). */
+int sivo_segnet_segment(sivo_segnet_t h, const uint8_t *bgr_hwc, int rows, int cols, uint64_t seed,
+                        uint8_t *classes, double *confidence, double *entropy);
+
+/* Copy a named blob of the last forward to the host (fp32; pooling masks are
+ * returned as the flat input-plane index Caffe stores, as fp32).  shape =
+ * {N, C, H, W}.  Test/diagnostic entry point. */
+int sivo_segnet_blob(sivo_segnet_t h, const char *name, float *host_out, size_t capacity, int32_t shape[4]);
+
+/* Algorithmic FLOPs of one forward (2*k*k*Cin*Cout*H*W per conv): shared =
+ * the sample-invariant prefix, per_sample = the rest. */
+int sivo_segnet_flops(sivo_segnet_t h, double *shared, double *per_sample);
+
+/* ===========================================================================
+ * ORB extractor — stands behind SIVO::ORBextractor
+ * (reference include/orbslam/ORBextractor.h:46-123, src/orbslam/ORBextractor.cc).
+ * ======================================================================== */
+typedef struct {  /* == cv::KeyPoint (28 bytes) */
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} SivoKeyPoint;
+
+typedef struct sivo_orb *sivo_orb_t;
+
+/* ORBextractor::ORBextractor (ORBextractor.cc:412-475). */
+int sivo_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast,
+                    int device, sivo_orb_t *out);
+int sivo_orb_destroy(sivo_orb_t h);
+/* GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares + mnFeaturesPerLevel; arrays of nlevels. */
+int sivo_orb_tables(sivo_orb_t h, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,
+                    int32_t *features_per_level);
+/* ORBextractor::operator() (ORBextractor.cc:1019-1083): 8UC1 host image in,
+ * keypoints (level 0 .. n-1 concatenated, pt scaled by the level factor) and
+ * 32-byte descriptors out.  *n_out > capacity -> SIVO_ERR_CAPACITY. */
+int sivo_orb_extract(sivo_orb_t h, const uint8_t *gray, int rows, int cols, int step,
+                     SivoKeyPoint *keypoints, uint8_t *descriptors, int capacity, int *n_out);
+/* Same with the image already resident in HBM (outputs still host). */
+int sivo_orb_extract_dev(sivo_orb_t h, const uint8_t *d_gray, int rows, int cols, int step,
+                         SivoKeyPoint *keypoints, uint8_t *descriptors, int capacity, int *n_out,
+                         void *stream);
+/* mvImagePyramid[level] (ORBextractor.h:83) of the last extraction: the level
+ * image WITH its 19-pixel reflect-101 border, (rows+38) x (cols+38), tightly
+ * packed; rows/cols report the interior size. */
+int sivo_orb_level(sivo_orb_t h, int level, uint8_t *host_out, size_t capacity, int32_t *rows, int32_t *cols);
+/* FAST candidates of one level of the last extraction (vToDistributeKeys,
+ * ORBextractor.cc:765-819; coordinates relative to the 16-px border), in the
+ * reference's emission order.  Test/diagnostic entry point. */
+int sivo_orb_candidates(sivo_orb_t h, int level, SivoKeyPoint *out, int capacity, int *n_out);
+/* DistributeOctTree (ORBextractor.cc:544-750), host only (sequential list surgery). */
+int sivo_orb_distribute(const SivoKeyPoint *keys, int n, int min_x, int max_x, int min_y, int max_y,
+                        int n_features, SivoKeyPoint *out, int capacity, int *n_out);
+
+/* ===========================================================================
+ * Hamming matching — stands behind SIVO::ORBmatcher
+ * (reference include/orbslam/ORBmatcher.h:36-142, src/orbslam/ORBmatcher.cc).
+ * Descriptors are rows of 32 bytes.
+ * ======================================================================== */
+/* ORBmatcher::DescriptorDistance (ORBmatcher.cc:1582-1596), dense nA x nB. */
+int sivo_hamming_matrix_dev(const uint8_t *d_a, int n_a, const uint8_t *d_b, int n_b, int32_t *d_out,
+                            void *stream);
+int sivo_hamming_matrix(const uint8_t *a, int n_a, const uint8_t *b, int n_b, int32_t *out);
+/* Candidate-list argmin with best / second best (the inner loop of every
+ * Search* routine, e.g. ORBmatcher.cc:78-104): for query i the candidates are
+ * rows cand_idx[cand_off[i] .. cand_off[i+1]) of b, visited in order; ties keep
+ * the earlier candidate; empty list -> idx -1, dist 256. */
+int sivo_hamming_argmin2_dev(const uint8_t *d_a, int n_a, const uint8_t *d_b, const int32_t *d_cand_off,
+                             const int32_t *d_cand_idx, int32_t *d_best_idx, int32_t *d_best_dist,
+                             int32_t *d_second_dist, void *stream);
+int sivo_hamming_argmin2(const uint8_t *a, int n_a, const uint8_t *b, int n_b, const int32_t *cand_off,
+                         const int32_t *cand_idx, int32_t *best_idx, int32_t *best_dist,
+                         int32_t *second_dist);
+/* Brute-force argmin over ALL rows of b for every row of a (best, second). */
+int sivo_hamming_bruteforce_dev(const uint8_t *d_a, int n_a, const uint8_t *d_b, int n_b,
+                                int32_t *d_best_idx, int32_t *d_best_dist, int32_t *d_second_dist,
+                                void *stream);
+
+/* Frame::ComputeStereoMatches (reference src/orbslam/Frame.cc:444-629):
+ * row-band candidates, octave +-1, disparity window, best Hamming < 100,
+ * accept < 75, 11x11 SAD slide +-5 on the pyramid level, parabola, median
+ * cull.  Left/right keypoints and descriptors are host arrays; the pyramids
+ * are those of two sivo_orb handles' last extraction (still in HBM).
+ * u_right / depth: n_left floats, -1 where unmatched. */
+int sivo_stereo_match(sivo_orb_t left, sivo_orb_t right, const SivoKeyPoint *kp_left, const uint8_t *desc_left,
+                      int n_left, const SivoKeyPoint *kp_right, const uint8_t *desc_right, int n_right,
+                      float bf, float b, float *u_right, float *depth, int32_t *best_right);
+
+/* ===========================================================================
+ * Bundle-adjustment edges — stands behind the g2o edges SIVO::Optimizer
+ * builds (reference src/orbslam/Optimizer.cc:318-409, 651-755):
+ * EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ (+OnlyPose) computeError and
+ * linearizeOplus, chi2 and the Huber kernel.
+ * ======================================================================== */
+typedef struct {
+    int32_t pose;   /* index into poses: 12 doubles each, R row-major then t (world -> camera) */
+    int32_t point;  /* index into points: 3 doubles each */
+    int32_t stereo; /* 0 = (u,v), 1 = (u,v,uR) */
+    int32_t pad_;
+    double obs[3];
+    double inv_sigma2; /* information = inv_sigma2 * I (Optimizer.cc:691-692, 730-733) */
+} SivoEdge;
+
+/* Per edge e: err[3e..] (err[2] = 0 for mono), Jx[9e..] 3x3 row-major
+ * d err/d point, Jp[18e..] 3x6 row-major d err/d pose (rotation columns
+ * first), chi2, rho (Huber-robustified chi2), w (Huber weight), depth_ok (z>0).
+ * intr = {fx, fy, cx, cy, bf}. Any output pointer may be NULL. */
+int sivo_ba_linearize_dev(const double *d_poses, const double *d_points, const SivoEdge *d_edges,
+                          int64_t n_edges, const double intr[5], double delta_mono, double delta_stereo,
+                          double *d_err, double *d_jx, double *d_jp, double *d_chi2, double *d_rho,
+                          double *d_w, uint8_t *d_depth_ok, void *stream);
+int sivo_ba_linearize(const double *poses, int n_poses, const double *points, int n_points,
+                      const SivoEdge *edges, int64_t n_edges, const double intr[5], double delta_mono,
+                      double delta_stereo, double *err, double *jx, double *jp, double *chi2, double *rho,
+                      double *w, uint8_t *depth_ok);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIVO_HIP_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of libsivo_hip.so (the C ABI declared in include/sivo_hip.h).
+
+There is no CPU fallback: if the HIP library is missing, or no HIP device is
+visible when a compute entry point is called, the call fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsivo_hip.so")
+
+OK = 0
+ERR_INVALID_ARGUMENT = 1
+ERR_RUNTIME = 2
+ERR_UNSUPPORTED = 3
+ERR_IMAGE_TOO_SMALL = 4
+ERR_CAPACITY = 5
+
+
+class SivoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsivo_hip error {code}: {msg}")
+        self.code = code
+
+
+class KeyPoint(C.Structure):  # == cv::KeyPoint / SivoKeyPoint (28 bytes)
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),
+                ("response", C.c_float), ("octave", C.c_int32), ("class_id", C.c_int32)]
+
+
+class Edge(C.Structure):      # == SivoEdge (48 bytes)
+    _fields_ = [("pose", C.c_int32), ("point", C.c_int32), ("stereo", C.c_int32), ("pad_", C.c_int32),
+                ("obs", C.c_double * 3), ("inv_sigma2", C.c_double)]
+
+
+_vp, _i, _i64, _u64, _sz, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_size_t, C.c_float, C.c_double
+_pi32 = C.POINTER(C.c_int32)
+
+# name -> argtypes; every function returns int status unless listed in _RESTYPE
+SIGNATURES = {
+    "sivo_version": [],
+    "sivo_device_count": [],
+    "sivo_segnet_create": [C.c_char_p, _sz, _i, _vp, _sz, _i, C.POINTER(_vp)],
+    "sivo_segnet_create_from_files": [C.c_char_p, C.c_char_p, _i, _i, C.POINTER(_vp)],
+    "sivo_segnet_destroy": [_vp],
+    "sivo_segnet_shape": [_vp, _pi32, _pi32, _pi32, _pi32, _pi32],
+    "sivo_segnet_num_params": [C.c_char_p, _sz, C.POINTER(_sz)],
+    "sivo_segnet_forward_dev": [_vp, _vp, _i, _i, _u64, _vp, _vp, _vp, _vp],
+    "sivo_mc_finalize_dev": [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp],
+    "sivo_mc_reduce_dev": [_vp, _i, _i, _i64, _vp, _vp, _i, _vp],
+    "sivo_mc_variance_dev": [_vp, _i, _i, _i64, _vp, _vp, _vp],
+    "sivo_segnet_segment": [_vp, _vp, _i, _i, _u64, _vp, _vp, _vp],
+    "sivo_segnet_blob": [_vp, C.c_char_p, _vp, _sz, _pi32],
+    "sivo_segnet_flops": [_vp, C.POINTER(_d), C.POINTER(_d)],
+    "sivo_orb_create": [_i, _f, _i, _i, _i, _i, C.POINTER(_vp)],
+    "sivo_orb_destroy": [_vp],
+    "sivo_orb_tables": [_vp, _vp, _vp, _vp, _vp, _vp],
+    "sivo_orb_extract": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _pi32],
+    "sivo_orb_extract_dev": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _pi32, _vp],
+    "sivo_orb_level": [_vp, _i, _vp, _sz, _pi32, _pi32],
+    "sivo_orb_candidates": [_vp, _i, _vp, _i, _pi32],
+    "sivo_orb_distribute": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _pi32],
+    "sivo_hamming_matrix_dev": [_vp, _i, _vp, _i, _vp, _vp],
+    "sivo_hamming_matrix": [_vp, _i, _vp, _i, _vp],
+    "sivo_hamming_argmin2_dev": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sivo_hamming_argmin2": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "sivo_hamming_bruteforce_dev": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
+    "sivo_stereo_match": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp],
+    "sivo_ba_linearize_dev": [_vp, _vp, _vp, _i64, C.POINTER(_d), _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sivo_ba_linearize": [_vp, _i, _vp, _i, _vp, _i64, C.POINTER(_d), _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+}
+
+_lib = None
+
+
+def lib():
+    """Load libsivo_hip.so (build it with `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first (make -C sivo_amd/csrc); "
+                              "sivo_amd has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.sivo_last_error.restype = C.c_char_p
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise SivoError(rc, lib().sivo_last_error().decode(errors="replace"))
+
+
+def require_gpu():
+    if lib().sivo_device_count() < 1:
+        raise SivoError(ERR_RUNTIME, "no HIP device visible: sivo_amd has no CPU fallback")

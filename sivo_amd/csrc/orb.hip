@@ -1,0 +1,905 @@
+// orb.hip — ORB extraction pipeline on CDNA4; stands behind SIVO::ORBextractor
+// (reference src/orbslam/ORBextractor.cc: ComputePyramid :1085-1122,
+// ComputeKeyPointsOctTree :752-847, IC_Angle :75-100, GaussianBlur + computeOrbDescriptor
+// :1060-1066,104-150, operator() :1019-1083) and behind the pixel work of
+// Frame::ComputeStereoMatches (reference src/orbslam/Frame.cc:444-629).
+//
+// All kernels are integer / byte kernels bound by HBM latency and launch overhead
+// (~6.6 MB touched per image): one launch covers all 8 pyramid levels wherever the
+// data dependence allows (border, FAST cells, blur), coalesced row-major byte
+// accesses, wave ballot + popcount for the ordered compaction of FAST corners.
+// The OpenCV primitives are restated bit-exactly (fixed-point resize, reflect-101,
+// FAST-9/16 score ladder in closed form, 8-bit fixed-point Gaussian, fastAtan2
+// polynomial with explicitly unfused float ops) — see oracle/orb_oracle.c for the
+// same definitions on the CPU.
+//
+// Per image:  pyramid (1 copy + 7 resize launches, level l needs l-1) -> border (1) ->
+// FAST per 30-px cell incl. the iniTh/minTh fallback and per-cell NMS (1) -> scan +
+// ordered compaction (2) -> D2H candidates -> host quadtree (orb_host.cpp)
+//            blur of all levels (1 launch, overlaps the host quadtree)
+// -> H2D kept keypoints -> IC angle (1) -> rBRIEF (1) -> D2H.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "common.hpp"
+#include "orb.hpp"
+
+namespace sivo {
+
+constexpr int EDGE_THRESHOLD = 19, HALF_PATCH = 15, PATCH_SIZE = 31;
+constexpr int MAX_LEVELS = 16;
+
+static const int8_t h_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+__constant__ int8_t c_pattern[1024];
+__constant__ int c_umax[16];
+
+struct LevelInfo {
+    int rows, cols, step;    // interior size; step = cols + 2*EDGE (bytes)
+    int pad_;
+    int64_t off;             // byte offset of the padded buffer inside the pyramid arena
+    int64_t blur_off;        // byte offset of the (rows x cols, tight) blurred image
+};
+struct LevelTable { LevelInfo lv[MAX_LEVELS]; int n; };
+
+struct CellInfo { int level, x0, y0, w, h; };   // tested region (absolute level coordinates)
+
+struct XTab { int sx; short a0, a1; };
+struct YTab { int sy0, sy1; short b0, b1; };
+
+// ---------------------------------------------------------------- pyramid
+__global__ void copy_level0_kernel(const uint8_t *src, int sstep, uint8_t *dst, int dstep, int rows, int cols) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x < cols) dst[(int64_t)y * dstep + x] = src[(int64_t)y * sstep + x];
+}
+
+// cv::resize INTER_LINEAR on 8UC1: horizontal 11-bit fixed point into int, vertical
+// (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.  Coefficient tables come from the host.
+__global__ void resize_kernel(const uint8_t *src, int sstep, int sw, uint8_t *dst, int dstep, int dh, int dw,
+                              const XTab *xt, const YTab *yt) {
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
+    if (dx >= dw) return;
+    const XTab X = xt[dx];
+    const YTab Y = yt[dy];
+    const int sx1 = X.sx + 1 < sw ? X.sx + 1 : X.sx;
+    const uint8_t *S0 = src + (int64_t)Y.sy0 * sstep, *S1 = src + (int64_t)Y.sy1 * sstep;
+    const int r0 = S0[X.sx] * X.a0 + S0[sx1] * X.a1;
+    const int r1 = S1[X.sx] * X.a0 + S1[sx1] * X.a1;
+    int v = (((Y.b0 * (r0 >> 4)) >> 16) + ((Y.b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    dst[(int64_t)dy * dstep + dx] = (uint8_t)v;
+}
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+// copyMakeBorder(BORDER_REFLECT_101) of every level in one launch (blockIdx.y = level).
+__global__ void border_kernel(uint8_t *pyr, LevelTable T) {
+    const LevelInfo L = T.lv[blockIdx.y];
+    const int PW = L.cols + 2 * EDGE_THRESHOLD, PH = L.rows + 2 * EDGE_THRESHOLD;
+    uint8_t *base = pyr + L.off;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)PW * PH;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int px = (int)(i % PW), py = (int)(i / PW);
+        const int x = px - EDGE_THRESHOLD, y = py - EDGE_THRESHOLD;
+        if (x >= 0 && x < L.cols && y >= 0 && y < L.rows) continue;
+        const int sx = reflect101(x, L.cols), sy = reflect101(y, L.rows);
+        base[(int64_t)py * L.step + px] = base[(int64_t)(sy + EDGE_THRESHOLD) * L.step + sx + EDGE_THRESHOLD];
+    }
+}
+
+// ---------------------------------------------------------------- FAST-9/16
+// Closed form of cv::FAST's cornerScore<16>: with d[k] = v - ring[k],
+//   A = max over the 16 arcs of 9 contiguous ring pixels of min(d),  B = the same on -d,
+//   pixel is a corner at threshold t  <=>  max(A,B) > t,   score = max(A,B) - 1.
+__device__ __forceinline__ int fast_score(const uint8_t *p, int step) {
+    const int v = p[0];
+    int d[16];
+    d[0] = v - p[3 * step];      d[1] = v - p[3 * step + 1];   d[2] = v - p[2 * step + 2];   d[3] = v - p[step + 3];
+    d[4] = v - p[3];             d[5] = v - p[-step + 3];      d[6] = v - p[-2 * step + 2];  d[7] = v - p[-3 * step + 1];
+    d[8] = v - p[-3 * step];     d[9] = v - p[-3 * step - 1];  d[10] = v - p[-2 * step - 2]; d[11] = v - p[-step - 3];
+    d[12] = v - p[-3];           d[13] = v - p[step - 3];      d[14] = v - p[2 * step - 2];  d[15] = v - p[3 * step - 1];
+    int lo2[16], hi2[16], lo4[16], hi4[16], lo8[16], hi8[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { lo8[k] = min(lo4[k], lo4[(k + 4) & 15]); hi8[k] = max(hi4[k], hi4[(k + 4) & 15]); }
+    int A = -256, Bn = 256;   // A = max arc-min(d); Bn = min arc-max(d)  (B = -Bn)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        A = max(A, min(lo8[k], d[(k + 8) & 15]));
+        Bn = min(Bn, max(hi8[k], d[(k + 8) & 15]));
+    }
+    return max(A, -Bn) - 1;
+}
+
+constexpr int CELL_MAX = 64;                       // tested region is at most 64 x 64
+__device__ __forceinline__ bool nms_keep(const uint8_t *s, int sw, int th) {
+    const int c = s[0];
+    if (c < th) return false;
+#define NB(o) ((s[o] >= th ? s[o] : 0) < c)
+    return NB(-1) && NB(1) && NB(-sw - 1) && NB(-sw) && NB(-sw + 1) && NB(sw - 1) && NB(sw) && NB(sw + 1);
+#undef NB
+}
+
+// One wave per 30-px cell (ORBextractor.cc:775-819): scores of the cell's tested region in
+// LDS, per-cell 3x3 NMS at iniTh, fall back to minTh when that leaves nothing, raster-order
+// emission through ballot/popcount.  Slot word = x | y << 12 | score << 24 with (x, y)
+// relative to the FAST border (level coordinate - 16), as vToDistributeKeys holds them.
+__global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *pyr, LevelTable T, const CellInfo *cells,
+                                                       int ini_th, int min_th, uint32_t *slots, int cap,
+                                                       int *counts) {
+    __shared__ uint8_t s_score[(CELL_MAX + 2) * (CELL_MAX + 2)];
+    const CellInfo C = cells[blockIdx.x];
+    const LevelInfo L = T.lv[C.level];
+    const int lane = threadIdx.x;
+    const uint8_t *img = pyr + L.off + (int64_t)EDGE_THRESHOLD * L.step + EDGE_THRESHOLD;
+    const int sw = C.w + 2, npx = C.w * C.h;
+    for (int i = lane; i < sw * (C.h + 2); i += 64) s_score[i] = 0;
+    __syncthreads();
+    const int lowest = min(ini_th, min_th);
+    for (int i = lane; i < npx; i += 64) {
+        const int ix = i % C.w, iy = i / C.w;
+        const int sc = fast_score(img + (int64_t)(C.y0 + iy) * L.step + C.x0 + ix, L.step);
+        s_score[(iy + 1) * sw + ix + 1] = (uint8_t)(sc >= lowest ? sc : 0);
+    }
+    __syncthreads();
+    int th = ini_th, total = 0;
+    for (int i0 = 0; i0 < npx; i0 += 64) {
+        const int i = i0 + lane;
+        const bool keep = i < npx && nms_keep(s_score + (i / C.w + 1) * sw + i % C.w + 1, sw, th);
+        total += __popcll(__ballot(keep));
+    }
+    if (total == 0) th = min_th;   // vKeysCell.empty() -> FAST(minThFAST)
+    uint32_t *out = slots + (int64_t)blockIdx.x * cap;
+    int base = 0;
+    for (int i0 = 0; i0 < npx; i0 += 64) {
+        const int i = i0 + lane;
+        const int ix = i % C.w, iy = i / C.w;
+        const bool keep = i < npx && nms_keep(s_score + (iy + 1) * sw + ix + 1, sw, th);
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            const int k = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (k < cap)
+                out[k] = (uint32_t)(C.x0 + ix - 16) | ((uint32_t)(C.y0 + iy - 16) << 12) |
+                         ((uint32_t)s_score[(iy + 1) * sw + ix + 1] << 24);
+        }
+        base += __popcll(m);
+    }
+    if (lane == 0) counts[blockIdx.x] = base < cap ? base : cap;
+}
+
+// Exclusive scan of the per-cell counts (single workgroup; cells are few thousand at most).
+__global__ __launch_bounds__(256) void scan_counts_kernel(const int *counts, int n, int *offsets, int *total) {
+    __shared__ int s[256];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int b = 0; b < n; b += 256) {
+        const int i = b + threadIdx.x;
+        const int v = i < n ? counts[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int t = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) offsets[i] = carry + s[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += s[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { offsets[n] = carry; *total = carry; }
+}
+
+__global__ __launch_bounds__(64) void compact_kernel(const uint32_t *slots, int cap, const int *counts,
+                                                    const int *offsets, uint32_t *dense) {
+    const int c = blockIdx.x, n = counts[c], o = offsets[c];
+    for (int k = threadIdx.x; k < n; k += 64) dense[o + k] = slots[(int64_t)c * cap + k];
+}
+
+// ---------------------------------------------------------------- Gaussian blur
+// GaussianBlur(7x7, sigma 2, REFLECT_101) on 8U: 8-bit fixed-point kernel (sum 257), row
+// pass in int, column pass (sum + 2^15) >> 16.  32x32 output tile per workgroup, all levels
+// in one launch (blockIdx.y = level).
+__global__ __launch_bounds__(256) void blur_kernel(const uint8_t *pyr, uint8_t *blur, LevelTable T, int k0, int k1,
+                                                  int k2, int k3) {
+    const LevelInfo L = T.lv[blockIdx.y];
+    const int tiles_x = (L.cols + 31) / 32, tiles_y = (L.rows + 31) / 32;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int x0 = (blockIdx.x % tiles_x) * 32, y0 = (blockIdx.x / tiles_x) * 32;
+    __shared__ uint8_t s_in[38][40];
+    __shared__ int s_row[38][33];
+    const uint8_t *img = pyr + L.off + (int64_t)EDGE_THRESHOLD * L.step + EDGE_THRESHOLD;
+    for (int i = threadIdx.x; i < 38 * 38; i += 256) {
+        const int px = i % 38, py = i / 38;
+        const int gx = reflect101(min(x0 + px - 3, L.cols + 2), L.cols), gy = reflect101(min(y0 + py - 3, L.rows + 2), L.rows);
+        s_in[py][px] = img[(int64_t)gy * L.step + gx];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 38 * 32; i += 256) {
+        const int x = i % 32, y = i / 32;
+        const uint8_t *r = &s_in[y][x];
+        s_row[y][x] = k0 * (r[0] + r[6]) + k1 * (r[1] + r[5]) + k2 * (r[2] + r[4]) + k3 * r[3];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+        const int x = i % 32, y = i / 32;
+        if (x0 + x >= L.cols || y0 + y >= L.rows) continue;
+        const int s = k0 * (s_row[y][x] + s_row[y + 6][x]) + k1 * (s_row[y + 1][x] + s_row[y + 5][x]) +
+                      k2 * (s_row[y + 2][x] + s_row[y + 4][x]) + k3 * s_row[y + 3][x];
+        const int v = (s + (1 << 15)) >> 16;
+        blur[L.blur_off + (int64_t)(y0 + y) * L.cols + x0 + x] = (uint8_t)(v > 255 ? 255 : v);
+    }
+}
+
+// ---------------------------------------------------------------- orientation + descriptor
+struct DevKp { float x, y; int level; };
+
+// cv::fastAtan2 (7th-order polynomial, degrees); every operation individually rounded.
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.141592653589793238462643383279502884);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.141592653589793238462643383279502884);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.141592653589793238462643383279502884);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.141592653589793238462643383279502884);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, (float)DBL_EPSILON));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, (float)DBL_EPSILON));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// IC_Angle (ORBextractor.cc:75-100): one wave per keypoint, lane = patch row v in [-15,15];
+// integer moments are order independent, so the wave reduction is exact.
+__global__ __launch_bounds__(256) void angle_kernel(const uint8_t *pyr, LevelTable T, const DevKp *kps, int n,
+                                                   float *angles) {
+    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n) return;
+    const DevKp kp = kps[k];
+    const LevelInfo L = T.lv[kp.level];
+    const uint8_t *center = pyr + L.off + (int64_t)(EDGE_THRESHOLD + __float2int_rn(kp.y)) * L.step + EDGE_THRESHOLD +
+                            __float2int_rn(kp.x);
+    int m10 = 0, m01 = 0;
+    if (lane < 2 * HALF_PATCH + 1) {
+        const int v = lane - HALF_PATCH;
+        const int d = c_umax[v < 0 ? -v : v];
+        const uint8_t *row = center + (int64_t)v * L.step;
+        int s = 0;
+        for (int u = -d; u <= d; ++u) { const int val = row[u]; m10 += u * val; s += val; }
+        m01 = v * s;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    if (lane == 0) angles[k] = fast_atan2_deg((float)m01, (float)m10);
+}
+
+// computeOrbDescriptor (ORBextractor.cc:104-150) on the blurred level image: one wave per
+// keypoint, lane l evaluates tests 4l..4l+3 (a nibble); lanes pair up into bytes.
+__global__ __launch_bounds__(256) void descriptor_kernel(const uint8_t *blur, LevelTable T, const DevKp *kps,
+                                                        const float *angles, int n, uint8_t *desc) {
+    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n) return;
+    const DevKp kp = kps[k];
+    const LevelInfo L = T.lv[kp.level];
+    const float factorPI = (float)(3.141592653589793238462643383279502884 / 180.f);
+    const float angle = __fmul_rn(angles[k], factorPI);
+    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    const int step = L.cols;
+    const uint8_t *center = blur + L.blur_off + (int64_t)__float2int_rn(kp.y) * step + __float2int_rn(kp.x);
+    int nib = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int8_t *p = c_pattern + 4 * (4 * lane + t);
+        const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = center[r0 * step + c0], t1 = center[r1 * step + c1];
+        nib |= (t0 < t1) << t;
+    }
+    const int hi = __shfl_down(nib, 1);
+    if ((lane & 1) == 0) desc[(int64_t)k * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+}
+
+// ---------------------------------------------------------------- stereo SAD (Frame.cc:543-583)
+struct SadJob { int level, cy, cxl, cxr0; };
+// One wave per job: 11 L1 distances between the centre-subtracted 11x11 windows of the left
+// level image at (cxl, cy) and of the right one at (cxr0 + inc, cy), inc = -5..5.
+__global__ __launch_bounds__(256) void stereo_sad_kernel(const uint8_t *pyrL, LevelTable TL, const uint8_t *pyrR,
+                                                        LevelTable TR, const SadJob *jobs, int n, int *dists) {
+    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n) return;
+    const SadJob J = jobs[k];
+    const LevelInfo LL = TL.lv[J.level], LR = TR.lv[J.level];
+    const uint8_t *iL = pyrL + LL.off + (int64_t)(EDGE_THRESHOLD + J.cy) * LL.step + EDGE_THRESHOLD + J.cxl;
+    const uint8_t *iR = pyrR + LR.off + (int64_t)(EDGE_THRESHOLD + J.cy) * LR.step + EDGE_THRESHOLD + J.cxr0;
+    const int cL = iL[0];
+    int acc[11];
+#pragma unroll
+    for (int s = 0; s < 11; ++s) acc[s] = 0;
+    for (int i = lane; i < 121; i += 64) {
+        const int dy = i / 11 - 5, dx = i % 11 - 5;
+        const int l = (int)iL[(int64_t)dy * LL.step + dx] - cL;
+#pragma unroll
+        for (int s = 0; s < 11; ++s) {
+            const int inc = s - 5;
+            const int r = (int)iR[(int64_t)dy * LR.step + dx + inc] - (int)iR[inc];
+            const int d = l - r;
+            acc[s] += d < 0 ? -d : d;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 11; ++s) {
+        int v = acc[s];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) dists[k * 11 + s] = v;
+    }
+}
+
+}  // namespace sivo
+
+// ================================================================== host side
+using namespace sivo;
+
+struct sivo_orb {
+    int device = 0;
+    int nfeatures, nlevels, ini_th, min_th;
+    double scale_factor;
+    float scale[MAX_LEVELS], inv_scale[MAX_LEVELS], sigma2[MAX_LEVELS], inv_sigma2[MAX_LEVELS];
+    int feat_per_level[MAX_LEVELS];
+    int umax[16];
+    int gk[4];                       // fixed-point Gaussian taps k0..k3 (k3 = centre)
+    // geometry-dependent state
+    int rows = 0, cols = 0;
+    LevelTable table{};
+    std::vector<CellInfo> cells;
+    std::vector<int> level_cell_begin;   // nlevels + 1
+    int cap = 0;
+    uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_src = nullptr;
+    size_t pyr_bytes = 0, blur_bytes = 0, src_bytes = 0;
+    XTab *d_xt[MAX_LEVELS] = {};
+    YTab *d_yt[MAX_LEVELS] = {};
+    CellInfo *d_cells = nullptr;
+    uint32_t *d_slots = nullptr, *d_dense = nullptr;
+    int *d_counts = nullptr, *d_offsets = nullptr, *d_total = nullptr;
+    int *h_counts = nullptr;          // pinned: ncells + 1 (total at the end)
+    uint32_t *h_dense = nullptr;      // pinned
+    size_t dense_cap = 0;
+    DevKp *d_kps = nullptr, *h_kps = nullptr;
+    float *d_angles = nullptr, *h_angles = nullptr;
+    uint8_t *d_desc = nullptr, *h_desc = nullptr;
+    int kp_cap = 0;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
+    std::vector<std::vector<SivoKeyPoint>> last_candidates;
+    bool have_pyramid = false;
+
+    void free_geometry() {
+        for (void *p : {(void *)d_pyr, (void *)d_blur, (void *)d_src, (void *)d_cells, (void *)d_slots, (void *)d_dense,
+                        (void *)d_counts, (void *)d_offsets, (void *)d_total})
+            if (p) (void)hipFree(p);
+        for (int l = 0; l < MAX_LEVELS; ++l) {
+            if (d_xt[l]) (void)hipFree(d_xt[l]);
+            if (d_yt[l]) (void)hipFree(d_yt[l]);
+            d_xt[l] = nullptr; d_yt[l] = nullptr;
+        }
+        if (h_counts) (void)hipHostFree(h_counts);
+        if (h_dense) (void)hipHostFree(h_dense);
+        d_pyr = d_blur = d_src = nullptr; d_cells = nullptr; d_slots = d_dense = nullptr;
+        d_counts = d_offsets = d_total = nullptr; h_counts = nullptr; h_dense = nullptr;
+        src_bytes = 0;
+    }
+    ~sivo_orb() {
+        free_geometry();
+        if (d_kps) (void)hipFree(d_kps);
+        if (d_angles) (void)hipFree(d_angles);
+        if (d_desc) (void)hipFree(d_desc);
+        if (h_kps) (void)hipHostFree(h_kps);
+        if (h_angles) (void)hipHostFree(h_angles);
+        if (h_desc) (void)hipHostFree(h_desc);
+        if (ev_pyr) (void)hipEventDestroy(ev_pyr);
+        if (ev_blur) (void)hipEventDestroy(ev_blur);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (stream2) (void)hipStreamDestroy(stream2);
+    }
+};
+
+namespace {
+
+inline int cv_round(double v) { return (int)std::lrint(v); }
+inline int cv_roundf(float v) { return (int)std::lrintf(v); }
+inline int cv_floor(double v) { int i = (int)v; return i - (i > v); }
+inline int cv_ceil(double v) { int i = (int)v; return i + (i < v); }
+
+// ORBextractor::ORBextractor (ORBextractor.cc:412-475): scale chain, features per level, umax.
+void init_tables(sivo_orb &o, int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th) {
+    o.nfeatures = nfeatures; o.nlevels = nlevels; o.ini_th = ini_th; o.min_th = min_th;
+    o.scale_factor = scale_factor;   // the reference keeps it in a double member
+    o.scale[0] = 1.0f; o.sigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; ++i) {
+        o.scale[i] = (float)(o.scale[i - 1] * o.scale_factor);
+        o.sigma2[i] = o.scale[i] * o.scale[i];
+    }
+    for (int i = 0; i < nlevels; ++i) { o.inv_scale[i] = 1.0f / o.scale[i]; o.inv_sigma2[i] = 1.0f / o.sigma2[i]; }
+    const float factor = (float)(1.0f / o.scale_factor);
+    float desired = (float)(nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels)));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; ++l) {
+        o.feat_per_level[l] = cv_roundf(desired);
+        sum += o.feat_per_level[l];
+        desired *= factor;
+    }
+    o.feat_per_level[nlevels - 1] = std::max(nfeatures - sum, 0);
+    const int vmax = cv_floor(HALF_PATCH * std::sqrt(2.f) / 2 + 1), vmin = cv_ceil(HALF_PATCH * std::sqrt(2.f) / 2);
+    const double hp2 = HALF_PATCH * HALF_PATCH;
+    for (int v = 0; v <= vmax; ++v) o.umax[v] = cv_round(std::sqrt(hp2 - v * v));
+    for (int v = HALF_PATCH, v0 = 0; v >= vmin; --v) {
+        while (o.umax[v0] == o.umax[v0 + 1]) ++v0;
+        o.umax[v] = v0;
+        ++v0;
+    }
+    // getGaussianKernel(7, 2, CV_32F) quantised by convertTo(CV_32S, 256)
+    float cf[7]; double s = 0;
+    for (int i = 0; i < 7; ++i) { const double x = i - 3.0; cf[i] = (float)std::exp(-0.5 / 4.0 * x * x); s += cf[i]; }
+    s = 1. / s;
+    for (int i = 0; i < 4; ++i) o.gk[i] = cv_round((double)(float)(cf[i] * s) * 256.0);
+}
+
+// Everything that depends on the image size: level buffers, resize tables, FAST cell list.
+void setup_geometry(sivo_orb &o, int rows, int cols) {
+    if (rows == o.rows && cols == o.cols) return;
+    if (rows >= 4096 || cols >= 4096) throw std::invalid_argument("images up to 4095 x 4095 are supported");
+    o.free_geometry();
+    o.rows = rows; o.cols = cols;
+    o.table.n = o.nlevels;
+    size_t poff = 0, boff = 0;
+    for (int l = 0; l < o.nlevels; ++l) {
+        LevelInfo &L = o.table.lv[l];
+        L.cols = cv_roundf((float)cols * o.inv_scale[l]);
+        L.rows = cv_roundf((float)rows * o.inv_scale[l]);
+        L.step = L.cols + 2 * EDGE_THRESHOLD;
+        L.off = (int64_t)poff; L.blur_off = (int64_t)boff;
+        poff += ((size_t)L.step * (L.rows + 2 * EDGE_THRESHOLD) + 255) & ~(size_t)255;
+        boff += ((size_t)L.cols * L.rows + 255) & ~(size_t)255;
+        if (L.cols < 2 * EDGE_THRESHOLD + 1 || L.rows < 2 * EDGE_THRESHOLD + 1)
+            throw std::invalid_argument("image too small for the requested number of pyramid levels");
+    }
+    o.pyr_bytes = poff; o.blur_bytes = boff;
+    o.d_pyr = dev_alloc<uint8_t>(poff);
+    o.d_blur = dev_alloc<uint8_t>(boff);
+    SIVO_HIP(hipMemset(o.d_pyr, 0, poff));
+    // cv::resize coefficient tables (level l from level l-1)
+    for (int l = 1; l < o.nlevels; ++l) {
+        const LevelInfo &S = o.table.lv[l - 1], &D = o.table.lv[l];
+        const double scale_x = 1. / ((double)D.cols / S.cols), scale_y = 1. / ((double)D.rows / S.rows);
+        std::vector<XTab> xt(D.cols);
+        std::vector<YTab> yt(D.rows);
+        for (int dx = 0; dx < D.cols; ++dx) {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5);
+            int sx = cv_floor(fx);
+            fx -= sx;
+            if (sx < 0) { fx = 0; sx = 0; }
+            if (sx >= S.cols - 1) { fx = 0; sx = S.cols - 1; }
+            xt[dx] = XTab{sx, (short)cv_roundf((1.f - fx) * 2048), (short)cv_roundf(fx * 2048)};
+        }
+        for (int dy = 0; dy < D.rows; ++dy) {
+            float fy = (float)((dy + 0.5) * scale_y - 0.5);
+            int sy = cv_floor(fy);
+            fy -= sy;
+            const int sy0 = std::min(std::max(sy, 0), S.rows - 1), sy1 = std::min(std::max(sy + 1, 0), S.rows - 1);
+            yt[dy] = YTab{sy0, sy1, (short)cv_roundf((1.f - fy) * 2048), (short)cv_roundf(fy * 2048)};
+        }
+        o.d_xt[l] = dev_alloc<XTab>(xt.size());
+        o.d_yt[l] = dev_alloc<YTab>(yt.size());
+        SIVO_HIP(hipMemcpy(o.d_xt[l], xt.data(), xt.size() * sizeof(XTab), hipMemcpyHostToDevice));
+        SIVO_HIP(hipMemcpy(o.d_yt[l], yt.data(), yt.size() * sizeof(YTab), hipMemcpyHostToDevice));
+    }
+    // FAST cells (ORBextractor.cc:752-819)
+    o.cells.clear();
+    o.level_cell_begin.assign(o.nlevels + 1, 0);
+    int cap = 1;
+    for (int l = 0; l < o.nlevels; ++l) {
+        o.level_cell_begin[l] = (int)o.cells.size();
+        const LevelInfo &L = o.table.lv[l];
+        const float W = 30;
+        const int minBX = EDGE_THRESHOLD - 3, minBY = minBX;
+        const int maxBX = L.cols - EDGE_THRESHOLD + 3, maxBY = L.rows - EDGE_THRESHOLD + 3;
+        const float width = (float)(maxBX - minBX), height = (float)(maxBY - minBY);
+        const int nCols = (int)(width / W), nRows = (int)(height / W);
+        if (nCols < 1 || nRows < 1) continue;
+        const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+        for (int i = 0; i < nRows; ++i) {
+            const float iniY = (float)(minBY + i * hCell);
+            float maxY = iniY + hCell + 6;
+            if (iniY >= maxBY - 3) continue;
+            if (maxY > maxBY) maxY = (float)maxBY;
+            for (int j = 0; j < nCols; ++j) {
+                const float iniX = (float)(minBX + j * wCell);
+                float maxX = iniX + wCell + 6;
+                if (iniX >= maxBX - 6) continue;
+                if (maxX > maxBX) maxX = (float)maxBX;
+                CellInfo c;
+                c.level = l; c.x0 = (int)iniX + 3; c.y0 = (int)iniY + 3;
+                c.w = (int)maxX - (int)iniX - 6; c.h = (int)maxY - (int)iniY - 6;
+                if (c.w <= 0 || c.h <= 0) continue;   // cv::FAST on a view narrower than 7 finds nothing
+                if (c.w > CELL_MAX || c.h > CELL_MAX) throw std::runtime_error("FAST cell larger than 64 px");
+                cap = std::max(cap, ((c.w + 1) / 2) * ((c.h + 1) / 2));
+                o.cells.push_back(c);
+            }
+        }
+    }
+    o.level_cell_begin[o.nlevels] = (int)o.cells.size();
+    o.cap = cap;
+    const size_t nc = o.cells.size();
+    o.d_cells = dev_alloc<CellInfo>(nc);
+    if (nc) SIVO_HIP(hipMemcpy(o.d_cells, o.cells.data(), nc * sizeof(CellInfo), hipMemcpyHostToDevice));
+    o.d_slots = dev_alloc<uint32_t>(nc * cap);
+    o.dense_cap = nc * cap;
+    o.d_dense = dev_alloc<uint32_t>(o.dense_cap);
+    o.d_counts = dev_alloc<int>(nc + 1);
+    o.d_offsets = dev_alloc<int>(nc + 1);
+    o.d_total = dev_alloc<int>(1);
+    SIVO_HIP(hipHostMalloc((void **)&o.h_counts, (nc + 2) * sizeof(int), hipHostMallocDefault));
+    SIVO_HIP(hipHostMalloc((void **)&o.h_dense, std::max<size_t>(o.dense_cap, 1) * sizeof(uint32_t), hipHostMallocDefault));
+    o.have_pyramid = false;
+}
+
+void ensure_kp_capacity(sivo_orb &o, int n) {
+    if (n <= o.kp_cap) return;
+    if (o.d_kps) { (void)hipFree(o.d_kps); (void)hipFree(o.d_angles); (void)hipFree(o.d_desc); (void)hipHostFree(o.h_kps); (void)hipHostFree(o.h_angles); (void)hipHostFree(o.h_desc); }
+    const int cap = std::max(n, 4096);
+    o.d_kps = dev_alloc<DevKp>(cap); o.d_angles = dev_alloc<float>(cap); o.d_desc = dev_alloc<uint8_t>((size_t)cap * 32);
+    SIVO_HIP(hipHostMalloc((void **)&o.h_kps, cap * sizeof(DevKp), hipHostMallocDefault));
+    SIVO_HIP(hipHostMalloc((void **)&o.h_angles, cap * sizeof(float), hipHostMallocDefault));
+    SIVO_HIP(hipHostMalloc((void **)&o.h_desc, (size_t)cap * 32, hipHostMallocDefault));
+    o.kp_cap = cap;
+}
+
+// The whole operator(): d_src is a device image (rows x cols, stride step).
+int extract(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, SivoKeyPoint *keypoints,
+            uint8_t *descriptors, int capacity, int *n_out, hipStream_t user_stream) {
+    setup_geometry(o, rows, cols);
+    hipStream_t st = o.stream;
+    if (user_stream) {   // order after the producer of d_src
+        SIVO_HIP(hipEventRecord(o.ev_pyr, user_stream));
+        SIVO_HIP(hipStreamWaitEvent(st, o.ev_pyr, 0));
+    }
+    const LevelTable &T = o.table;
+    // ---- pyramid
+    {
+        const LevelInfo &L0 = T.lv[0];
+        uint8_t *dst = o.d_pyr + L0.off + (size_t)EDGE_THRESHOLD * L0.step + EDGE_THRESHOLD;
+        hipLaunchKernelGGL(copy_level0_kernel, dim3(cdiv(cols, 256), rows), dim3(256), 0, st, d_src, step, dst, L0.step, rows, cols);
+        for (int l = 1; l < o.nlevels; ++l) {
+            const LevelInfo &S = T.lv[l - 1], &D = T.lv[l];
+            const uint8_t *src = o.d_pyr + S.off + (size_t)EDGE_THRESHOLD * S.step + EDGE_THRESHOLD;
+            uint8_t *d = o.d_pyr + D.off + (size_t)EDGE_THRESHOLD * D.step + EDGE_THRESHOLD;
+            hipLaunchKernelGGL(resize_kernel, dim3(cdiv(D.cols, 256), D.rows), dim3(256), 0, st, src, S.step, S.cols, d, D.step,
+                               D.rows, D.cols, o.d_xt[l], o.d_yt[l]);
+        }
+    }
+    SIVO_HIP(hipEventRecord(o.ev_pyr, st));
+    // ---- blur on the second stream (needs interiors only), overlapping FAST + the host quadtree
+    SIVO_HIP(hipStreamWaitEvent(o.stream2, o.ev_pyr, 0));
+    {
+        int max_tiles = 0;
+        for (int l = 0; l < o.nlevels; ++l) max_tiles = std::max(max_tiles, cdiv(T.lv[l].cols, 32) * cdiv(T.lv[l].rows, 32));
+        hipLaunchKernelGGL(blur_kernel, dim3(max_tiles, o.nlevels), dim3(256), 0, o.stream2, o.d_pyr, o.d_blur, T, o.gk[0], o.gk[1],
+                           o.gk[2], o.gk[3]);
+        hipLaunchKernelGGL(border_kernel, dim3(64, o.nlevels), dim3(256), 0, o.stream2, o.d_pyr, T);
+        SIVO_HIP(hipEventRecord(o.ev_blur, o.stream2));
+    }
+    // ---- FAST cells -> ordered candidate list
+    const int nc = (int)o.cells.size();
+    int total = 0;
+    if (nc) {
+        hipLaunchKernelGGL(fast_cells_kernel, dim3(nc), dim3(64), 0, st, o.d_pyr, T, o.d_cells, o.ini_th, o.min_th, o.d_slots,
+                           o.cap, o.d_counts);
+        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(256), 0, st, o.d_counts, nc, o.d_offsets, o.d_total);
+        hipLaunchKernelGGL(compact_kernel, dim3(nc), dim3(64), 0, st, o.d_slots, o.cap, o.d_counts, o.d_offsets, o.d_dense);
+        SIVO_HIP(hipMemcpyAsync(o.h_counts, o.d_offsets, (size_t)(nc + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+        SIVO_HIP(hipStreamSynchronize(st));
+        total = o.h_counts[nc];
+        if (total) {
+            SIVO_HIP(hipMemcpyAsync(o.h_dense, o.d_dense, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            SIVO_HIP(hipStreamSynchronize(st));
+        }
+    }
+    o.have_pyramid = true;
+    // ---- host: quadtree per level (ORBextractor.cc:821-841)
+    o.last_candidates.assign(o.nlevels, {});
+    std::vector<SivoKeyPoint> kept, all;
+    std::vector<int> level_count(o.nlevels, 0);
+    for (int l = 0; l < o.nlevels; ++l) {
+        const int c0 = o.level_cell_begin[l], c1 = o.level_cell_begin[l + 1];
+        if (c0 == c1) continue;
+        const int b = o.h_counts[c0], e = o.h_counts[c1];
+        std::vector<SivoKeyPoint> &cand = o.last_candidates[l];
+        cand.resize(e - b);
+        for (int i = b; i < e; ++i) {
+            const uint32_t w = o.h_dense[i];
+            SivoKeyPoint &k = cand[i - b];
+            k.x = (float)(w & 0xfff); k.y = (float)((w >> 12) & 0xfff);
+            k.size = 7.f; k.angle = -1.f; k.response = (float)(w >> 24); k.octave = 0; k.class_id = -1;
+        }
+        if (cand.empty()) continue;
+        const LevelInfo &L = T.lv[l];
+        const int minB = EDGE_THRESHOLD - 3;
+        distribute_quadtree(cand.data(), (int)cand.size(), minB, L.cols - EDGE_THRESHOLD + 3, minB, L.rows - EDGE_THRESHOLD + 3,
+                            o.feat_per_level[l], kept);
+        const int scaled_patch = (int)(PATCH_SIZE * o.scale[l]);
+        for (SivoKeyPoint &k : kept) {
+            k.x += minB; k.y += minB; k.octave = l; k.size = (float)scaled_patch;
+            all.push_back(k);
+        }
+        level_count[l] = (int)kept.size();
+    }
+    const int n = (int)all.size();
+    *n_out = n;
+    if (n == 0) { SIVO_HIP(hipStreamSynchronize(o.stream2)); return SIVO_OK; }
+    if (n > capacity) { SIVO_HIP(hipStreamSynchronize(o.stream2)); return fail(SIVO_ERR_CAPACITY, "%d keypoints, capacity %d", n, capacity); }
+    // ---- device: orientation + descriptors
+    ensure_kp_capacity(o, n);
+    for (int i = 0; i < n; ++i) o.h_kps[i] = DevKp{all[i].x, all[i].y, all[i].octave};
+    SIVO_HIP(hipMemcpyAsync(o.d_kps, o.h_kps, (size_t)n * sizeof(DevKp), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(angle_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, o.d_pyr, T, o.d_kps, n, o.d_angles);
+    SIVO_HIP(hipStreamWaitEvent(st, o.ev_blur, 0));
+    hipLaunchKernelGGL(descriptor_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, o.d_blur, T, o.d_kps, o.d_angles, n, o.d_desc);
+    SIVO_HIP(hipMemcpyAsync(o.h_angles, o.d_angles, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+    SIVO_HIP(hipMemcpyAsync(o.h_desc, o.d_desc, (size_t)n * 32, hipMemcpyDeviceToHost, st));
+    SIVO_HIP(hipStreamSynchronize(st));
+    SIVO_HIP(hipGetLastError());
+    // ---- assemble (ORBextractor.cc:1068-1081): pt *= scale for level > 0
+    for (int i = 0; i < n; ++i) {
+        SivoKeyPoint k = all[i];
+        k.angle = o.h_angles[i];
+        if (k.octave != 0) { const float s = o.scale[k.octave]; k.x *= s; k.y *= s; }
+        keypoints[i] = k;
+    }
+    if (descriptors) std::memcpy(descriptors, o.h_desc, (size_t)n * 32);
+    return SIVO_OK;
+}
+
+}  // namespace
+
+extern "C" int sivo_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast,
+                               int device, sivo_orb_t *out) {
+    return guarded([&] {
+        if (!out) throw std::invalid_argument("out is NULL");
+        *out = nullptr;
+        if (nfeatures < 1 || nlevels < 1 || nlevels > MAX_LEVELS || scale_factor <= 1.0f || ini_th_fast < 0 || min_th_fast < 0)
+            throw std::invalid_argument("bad ORB parameters (nlevels <= 16, scale_factor > 1)");
+        if (device < 0 || sivo_device_count() <= device)
+            return fail(SIVO_ERR_RUNTIME, "HIP device %d is not available (%d visible): libsivo_hip has no CPU fallback", device,
+                        sivo_device_count());
+        std::unique_ptr<sivo_orb> o(new sivo_orb);
+        o->device = device;
+        init_tables(*o, nfeatures, scale_factor, nlevels, std::min(std::max(ini_th_fast, 0), 255), std::min(std::max(min_th_fast, 0), 255));
+        DeviceGuard dg(device);
+        SIVO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), h_pattern, sizeof h_pattern));
+        SIVO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), o->umax, sizeof(int) * 16));
+        SIVO_HIP(hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking));
+        SIVO_HIP(hipStreamCreateWithFlags(&o->stream2, hipStreamNonBlocking));
+        SIVO_HIP(hipEventCreateWithFlags(&o->ev_pyr, hipEventDisableTiming));
+        SIVO_HIP(hipEventCreateWithFlags(&o->ev_blur, hipEventDisableTiming));
+        *out = o.release();
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_orb_destroy(sivo_orb_t h) {
+    return guarded([&] {
+        if (h) { DeviceGuard dg(h->device); delete h; }
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_orb_tables(sivo_orb_t h, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,
+                               int32_t *features_per_level) {
+    if (!h) return fail(SIVO_ERR_INVALID_ARGUMENT, "null handle");
+    for (int l = 0; l < h->nlevels; ++l) {
+        if (scale) scale[l] = h->scale[l];
+        if (inv_scale) inv_scale[l] = h->inv_scale[l];
+        if (sigma2) sigma2[l] = h->sigma2[l];
+        if (inv_sigma2) inv_sigma2[l] = h->inv_sigma2[l];
+        if (features_per_level) features_per_level[l] = h->feat_per_level[l];
+    }
+    return SIVO_OK;
+}
+
+extern "C" int sivo_orb_extract_dev(sivo_orb_t h, const uint8_t *d_gray, int rows, int cols, int step,
+                                    SivoKeyPoint *keypoints, uint8_t *descriptors, int capacity, int *n_out,
+                                    void *stream) {
+    return guarded([&] {
+        if (!h || !n_out) throw std::invalid_argument("null argument");
+        *n_out = 0;
+        if (!d_gray || rows <= 0 || cols <= 0) return SIVO_OK;   // _image.empty(): return silently (:1023-1024)
+        if (step < cols || !keypoints) throw std::invalid_argument("bad step / null keypoints");
+        DeviceGuard dg(h->device);
+        return extract(*h, d_gray, rows, cols, step, keypoints, descriptors, capacity, n_out, (hipStream_t)stream);
+    });
+}
+
+extern "C" int sivo_orb_extract(sivo_orb_t h, const uint8_t *gray, int rows, int cols, int step,
+                                SivoKeyPoint *keypoints, uint8_t *descriptors, int capacity, int *n_out) {
+    return guarded([&] {
+        if (!h || !n_out) throw std::invalid_argument("null argument");
+        *n_out = 0;
+        if (!gray || rows <= 0 || cols <= 0) return SIVO_OK;
+        if (step < cols || !keypoints) throw std::invalid_argument("bad step / null keypoints");
+        DeviceGuard dg(h->device);
+        const size_t need = (size_t)rows * cols;
+        if (h->src_bytes < need || h->rows != rows || h->cols != cols) {
+            setup_geometry(*h, rows, cols);
+            if (h->d_src) (void)hipFree(h->d_src);
+            h->d_src = dev_alloc<uint8_t>(need);
+            h->src_bytes = need;
+        }
+        SIVO_HIP(hipMemcpy2DAsync(h->d_src, cols, gray, step, cols, rows, hipMemcpyHostToDevice, h->stream));
+        return extract(*h, h->d_src, rows, cols, cols, keypoints, descriptors, capacity, n_out, nullptr);
+    });
+}
+
+extern "C" int sivo_orb_level(sivo_orb_t h, int level, uint8_t *host_out, size_t capacity, int32_t *rows, int32_t *cols) {
+    return guarded([&] {
+        if (!h || level < 0 || level >= h->nlevels) throw std::invalid_argument("bad level");
+        if (!h->have_pyramid) throw std::invalid_argument("no image has been extracted yet");
+        const LevelInfo &L = h->table.lv[level];
+        if (rows) *rows = L.rows;
+        if (cols) *cols = L.cols;
+        const size_t n = (size_t)L.step * (L.rows + 2 * EDGE_THRESHOLD);
+        if (!host_out) return SIVO_OK;
+        if (capacity < n) return fail(SIVO_ERR_CAPACITY, "level needs %zu bytes, capacity %zu", n, capacity);
+        DeviceGuard dg(h->device);
+        SIVO_HIP(hipStreamSynchronize(h->stream2));
+        SIVO_HIP(hipMemcpy(host_out, h->d_pyr + L.off, n, hipMemcpyDeviceToHost));
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_orb_candidates(sivo_orb_t h, int level, SivoKeyPoint *out, int capacity, int *n_out) {
+    return guarded([&] {
+        if (!h || level < 0 || level >= h->nlevels || !n_out) throw std::invalid_argument("bad argument");
+        if ((int)h->last_candidates.size() <= level) { *n_out = 0; return SIVO_OK; }
+        const std::vector<SivoKeyPoint> &c = h->last_candidates[level];
+        *n_out = (int)c.size();
+        if (!out) return SIVO_OK;
+        if ((int)c.size() > capacity) return fail(SIVO_ERR_CAPACITY, "%zu candidates, capacity %d", c.size(), capacity);
+        std::copy(c.begin(), c.end(), out);
+        return SIVO_OK;
+    });
+}
+
+// Frame::ComputeStereoMatches (Frame.cc:444-629).  Host: row table, candidate lists and the
+// float decision logic exactly as the reference orders it; device: Hamming argmin over the
+// candidate lists and the 11 SAD windows per match on the two resident pyramids.
+extern "C" int sivo_stereo_match(sivo_orb_t left, sivo_orb_t right, const SivoKeyPoint *kpL, const uint8_t *descL,
+                                 int nL, const SivoKeyPoint *kpR, const uint8_t *descR, int nR, float bf, float b,
+                                 float *u_right, float *depth, int32_t *best_right) {
+    return guarded([&] {
+        if (!left || !right || nL < 0 || nR < 0 || (nL && (!kpL || !descL || !u_right || !depth)) || (nR && (!kpR || !descR)))
+            throw std::invalid_argument("bad argument");
+        if (!left->have_pyramid || !right->have_pyramid) throw std::invalid_argument("both extractors must hold a pyramid");
+        if (left->nlevels != right->nlevels || left->rows != right->rows || left->cols != right->cols)
+            throw std::invalid_argument("left/right extractors differ in geometry");
+        for (int i = 0; i < nL; ++i) { u_right[i] = -1.f; depth[i] = -1.f; if (best_right) best_right[i] = -1; }
+        if (nL == 0 || nR == 0) return SIVO_OK;
+        DeviceGuard dg(left->device);
+        const int TH_HIGH = 100, TH_LOW = 50, thOrbDist = (TH_HIGH + TH_LOW) / 2;
+        const int nRows = left->table.lv[0].rows;
+        // row table (:454-477); the reference indexes rows unchecked — clamped here
+        std::vector<std::vector<int>> rowIdx(nRows);
+        for (int iR = 0; iR < nR; ++iR) {
+            const float r = 2.0f * left->scale[kpR[iR].octave];
+            const int maxr = (int)std::ceil(kpR[iR].y + r), minr = (int)std::floor(kpR[iR].y - r);
+            for (int yi = minr; yi <= maxr; ++yi)
+                if (yi >= 0 && yi < nRows) rowIdx[yi].push_back(iR);
+        }
+        const float minZ = b, minD = 0, maxD = bf / minZ;
+        std::vector<int> off(nL + 1, 0), idx;
+        for (int iL = 0; iL < nL; ++iL) {
+            off[iL] = (int)idx.size();
+            const int row = (int)kpL[iL].y;
+            if (row < 0 || row >= nRows) continue;
+            const float uL = kpL[iL].x, minU = uL - maxD, maxU = uL - minD;
+            if (rowIdx[row].empty() || maxU < 0) continue;
+            for (int iR : rowIdx[row]) {
+                if (kpR[iR].octave < kpL[iL].octave - 1 || kpR[iR].octave > kpL[iL].octave + 1) continue;
+                if (kpR[iR].x >= minU && kpR[iR].x <= maxU) idx.push_back(iR);
+            }
+        }
+        off[nL] = (int)idx.size();
+        std::vector<int> bi(nL), bd(nL), sd(nL);
+        int rc = sivo_hamming_argmin2(descL, nL, descR, nR, off.data(), idx.data(), bi.data(), bd.data(), sd.data());
+        if (rc) return rc;
+        // SAD jobs (:538-565)
+        std::vector<SadJob> jobs;
+        std::vector<int> jobL;
+        const int w = 5, Lw = 5;
+        for (int iL = 0; iL < nL; ++iL) {
+            if (bd[iL] >= TH_HIGH || bi[iL] < 0) continue;   // bestDist starts at TH_HIGH
+            if (best_right) best_right[iL] = bi[iL];
+            if (bd[iL] >= thOrbDist) continue;
+            const int lvl = kpL[iL].octave;
+            const float sf = left->inv_scale[lvl];
+            const float suL = std::round(kpL[iL].x * sf), svL = std::round(kpL[iL].y * sf), suR0 = std::round(kpR[bi[iL]].x * sf);
+            const float iniu = suR0 + Lw - w, endu = suR0 + Lw + w + 1;
+            if (iniu < 0 || endu >= right->table.lv[lvl].cols) continue;
+            jobs.push_back(SadJob{lvl, (int)svL, (int)suL, (int)suR0});
+            jobL.push_back(iL);
+        }
+        std::vector<int> dists(jobs.size() * 11);
+        if (!jobs.empty()) {
+            SadJob *dj = dev_alloc<SadJob>(jobs.size());
+            int *dd = dev_alloc<int>(dists.size());
+            SIVO_HIP(hipMemcpy(dj, jobs.data(), jobs.size() * sizeof(SadJob), hipMemcpyHostToDevice));
+            SIVO_HIP(hipStreamSynchronize(left->stream2));
+            SIVO_HIP(hipStreamSynchronize(right->stream2));
+            hipLaunchKernelGGL(stereo_sad_kernel, dim3(cdiv((int)jobs.size(), 4)), dim3(256), 0, nullptr, left->d_pyr, left->table,
+                               right->d_pyr, right->table, dj, (int)jobs.size(), dd);
+            SIVO_HIP(hipMemcpy(dists.data(), dd, dists.size() * sizeof(int), hipMemcpyDeviceToHost));
+            (void)hipFree(dj); (void)hipFree(dd);
+        }
+        // decision logic (:567-628)
+        std::vector<std::pair<int, int>> vDistIdx;
+        for (size_t j = 0; j < jobs.size(); ++j) {
+            const int iL = jobL[j], lvl = jobs[j].level;
+            int bestDist = INT32_MAX, bestinc = 0;
+            float vD[11];
+            for (int inc = -Lw; inc <= Lw; ++inc) {
+                const float dist = (float)dists[j * 11 + inc + Lw];
+                if (dist < (float)bestDist) { bestDist = (int)dist; bestinc = inc; }
+                vD[Lw + inc] = dist;
+            }
+            if (bestinc == -Lw || bestinc == Lw) continue;
+            const float d1 = vD[Lw + bestinc - 1], d2 = vD[Lw + bestinc], d3 = vD[Lw + bestinc + 1];
+            const float deltaR = (d1 - d3) / (2.0f * (d1 + d3 - 2.0f * d2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = left->scale[lvl] * ((float)jobs[j].cxr0 + (float)bestinc + deltaR);
+            const float uL = kpL[iL].x;
+            float disparity = uL - bestuR;
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) { disparity = 0.01f; bestuR = (float)(uL - 0.01); }
+                depth[iL] = bf / disparity;
+                u_right[iL] = bestuR;
+                vDistIdx.emplace_back(bestDist, iL);
+            }
+        }
+        if (!vDistIdx.empty()) {
+            std::sort(vDistIdx.begin(), vDistIdx.end());
+            const float median = (float)vDistIdx[vDistIdx.size() / 2].first;
+            const float thDist = 1.5f * 1.4f * median;
+            for (int i = (int)vDistIdx.size() - 1; i >= 0; --i) {
+                if ((float)vDistIdx[i].first < thDist) break;
+                u_right[vDistIdx[i].second] = -1;
+                depth[vDistIdx[i].second] = -1;
+            }
+        }
+        return SIVO_OK;
+    });
+}

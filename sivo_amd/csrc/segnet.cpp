@@ -1,0 +1,533 @@
+// segnet.cpp — host runtime of the Bayesian SegNet path: prototxt -> fused launch
+// plan -> per-frame forward.  Stands behind SIVO::BayesianSegNet
+// (reference src/bayesian_segnet/bayesian_segnet.cpp:46-78 constructor,
+// :299-318 segmentImage).
+//
+// Plan construction ("what Caffe runs layer by layer, regrouped for the GPU"):
+//   * BN(INFERENCE), ReLU and Dropout that follow a Convolution in place are folded
+//     into the convolution's epilogue; Dropout that follows a Pooling in place is
+//     folded into the pooling kernel.
+//   * Everything upstream of the first Dropout does not depend on the Monte-Carlo
+//     sample: those blobs are "shared" (N = 1, computed once per frame instead of
+//     T times — 134.1 of 446.0 GFLOP per sample for SegNet-Standard) and are
+//     broadcast with a zero sample stride into the first sample-dependent op.
+//   * Softmax is not a kernel of its own: the plan ends at the logits and
+//     sivo_mc_reduce fuses softmax with the sum over samples.
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <vector>
+
+#include "common.hpp"
+#include "prototxt.hpp"
+#include "segnet_kernels.hpp"
+
+namespace sivo {
+namespace {
+
+struct Blob {
+    std::string name;
+    int C = 0, H = 0, W = 0;
+    bool shared = true;    // independent of the MC sample (stored once)
+    bool is_mask = false;  // pooling argmax codes (u8)
+    int src_W = 0;         // masks: width of the pooled input plane (for index reconstruction)
+    void *d = nullptr;
+    int64_t chw() const { return (int64_t)C * H * W; }
+};
+
+enum OpKind { OP_CONV, OP_POOL, OP_UNPOOL, OP_DROPOUT, OP_LRN };
+
+struct Op {
+    OpKind kind;
+    int in = -1, in2 = -1, out = -1, out2 = -1;
+    // conv
+    int ks = 0, cin = 0, cout = 0, cout_pad = 0;
+    float *d_w = nullptr, *d_scale = nullptr, *d_shift = nullptr;
+    bool relu = false;
+    int drop_site = -1;
+    // lrn
+    int local_size = 5;
+    float alpha = 0.f, beta = 0.f;
+    double flops = 0.0;
+};
+
+}  // namespace
+}  // namespace sivo
+
+struct sivo_segnet {
+    int device = 0;
+    int T = 0, C = 3, H = 0, W = 0, classes = 0;
+    std::vector<sivo::Blob> blobs;
+    std::vector<sivo::Op> ops;
+    std::map<std::string, int> blob_id;
+    int input_blob = -1, logits_blob = -1;
+    bool has_softmax = false;
+    uint8_t *d_image = nullptr;     // H*W*3 staging for the host entry point
+    float *d_prob_sum = nullptr;    // classes*H*W
+    uint8_t *d_classes = nullptr;
+    double *d_conf = nullptr, *d_ent = nullptr;
+    hipStream_t stream = nullptr;   // for the host-level entry point
+    double flops_shared = 0.0, flops_sample = 0.0;
+    std::vector<void *> owned;
+    ~sivo_segnet() {
+        for (void *p : owned) (void)hipFree(p);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace sivo {
+namespace {
+
+size_t count_params(const ProtoNet &net) {
+    std::map<std::string, int> ch;
+    ch[net.input] = net.shape[1];
+    size_t n = 0;
+    for (const ProtoLayer &L : net.layers) {
+        const int cin = L.bottom.empty() ? net.shape[1] : ch[L.bottom[0]];
+        if (L.type == "Convolution") {
+            n += (size_t)L.num_output * cin * L.kernel_size * L.kernel_size + (size_t)L.num_output;
+            ch[L.top[0]] = L.num_output;
+        } else if (L.type == "BN") {
+            n += 2 * (size_t)cin;
+            ch[L.top[0]] = cin;
+        } else {
+            for (auto &t : L.top) ch[t] = cin;
+        }
+    }
+    return n;
+}
+
+int new_blob(sivo_segnet &S, const std::string &name, int C, int H, int W, bool shared, bool is_mask = false) {
+    Blob b;
+    b.name = name; b.C = C; b.H = H; b.W = W; b.shared = shared; b.is_mask = is_mask;
+    S.blobs.push_back(b);
+    S.blob_id[name] = (int)S.blobs.size() - 1;
+    return (int)S.blobs.size() - 1;
+}
+
+// Re-layout Caffe (Cout,Cin,k,k) weights to [ceil(Cin/KC)][k*k][KC][CoutPad] and fold
+// bias (+ BN scale/shift) into the epilogue's per-channel affine.
+void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias) {
+    const int ks = op.ks, cin = op.cin, cout = op.cout;
+    const int KC = conv_k_chunk(ks, cin), BN = conv_cout_tile(ks, cout);
+    op.cout_pad = cdiv(cout, BN) * BN;
+    const int nchunks = cdiv(cin, KC), taps = ks * ks;
+    std::vector<float> wt((size_t)nchunks * taps * KC * op.cout_pad, 0.f);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < taps; ++t) {
+                const size_t dst = (((size_t)(ci / KC) * taps + t) * KC + (ci % KC)) * op.cout_pad + co;
+                wt[dst] = W[((size_t)co * cin + ci) * taps + t];
+            }
+    op.d_w = dev_alloc<float>(wt.size());
+    S.owned.push_back(op.d_w);
+    SIVO_HIP(hipMemcpy(op.d_w, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<float> sc(cout, 1.f), sh(bias, bias + cout);
+    op.d_scale = dev_alloc<float>(cout);
+    op.d_shift = dev_alloc<float>(cout);
+    S.owned.push_back(op.d_scale);
+    S.owned.push_back(op.d_shift);
+    SIVO_HIP(hipMemcpy(op.d_scale, sc.data(), cout * sizeof(float), hipMemcpyHostToDevice));
+    SIVO_HIP(hipMemcpy(op.d_shift, sh.data(), cout * sizeof(float), hipMemcpyHostToDevice));
+}
+
+void fold_bn(Op &op, const float *scale, const float *shift) {
+    // y = scale*(acc*s0 + b0) + shift = (scale*s0)*acc + (scale*b0 + shift)
+    std::vector<float> s0(op.cout), b0(op.cout);
+    SIVO_HIP(hipMemcpy(s0.data(), op.d_scale, op.cout * sizeof(float), hipMemcpyDeviceToHost));
+    SIVO_HIP(hipMemcpy(b0.data(), op.d_shift, op.cout * sizeof(float), hipMemcpyDeviceToHost));
+    for (int c = 0; c < op.cout; ++c) {
+        b0[c] = scale[c] * b0[c] + shift[c];
+        s0[c] = scale[c] * s0[c];
+    }
+    SIVO_HIP(hipMemcpy(op.d_scale, s0.data(), op.cout * sizeof(float), hipMemcpyHostToDevice));
+    SIVO_HIP(hipMemcpy(op.d_shift, b0.data(), op.cout * sizeof(float), hipMemcpyHostToDevice));
+}
+
+std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const float *weights, size_t n_weights,
+                                   int device) {
+    std::unique_ptr<sivo_segnet> Sp(new sivo_segnet);
+    sivo_segnet &S = *Sp;
+    S.device = device;
+    S.T = t_override > 0 ? t_override : net.shape[0];
+    S.C = net.shape[1]; S.H = net.shape[2]; S.W = net.shape[3];
+    // reference constructor checks (bayesian_segnet.cpp:64-70)
+    if (S.C != 3) throw std::invalid_argument("Input layer must have 3 channels!");
+    if (S.T <= 1) throw std::invalid_argument("Input layer must have a batch size greater than 1!");
+    if (S.H <= 0 || S.W <= 0) throw std::invalid_argument("Input layer must have a positive geometry!");
+    if (count_params(net) != n_weights) {
+        std::ostringstream m;
+        m << "weights hold " << n_weights << " values but the prototxt implies " << count_params(net);
+        throw std::invalid_argument(m.str());
+    }
+
+    DeviceGuard dg(device);
+    S.input_blob = new_blob(S, net.input, S.C, S.H, S.W, true);
+    size_t woff = 0;
+    int site = 0;
+    // producer[blob] = index of the op that can still absorb in-place BN/ReLU/Dropout
+    std::map<int, int> absorber;
+    for (const ProtoLayer &L : net.layers) {
+        auto bottom = [&](size_t i) -> int {
+            auto it = S.blob_id.find(L.bottom.at(i));
+            if (it == S.blob_id.end()) throw std::invalid_argument("layer '" + L.name + "': unknown bottom '" + L.bottom[i] + "'");
+            return it->second;
+        };
+        const bool inplace = !L.top.empty() && !L.bottom.empty() && L.top[0] == L.bottom[0];
+        if (L.type == "Convolution") {
+            if (L.stride != 1 || (L.kernel_size != 1 && L.kernel_size != 3 && L.kernel_size != 7) ||
+                L.pad != L.kernel_size / 2)
+                throw std::runtime_error("Convolution '" + L.name + "': only stride-1 'same' 1x1/3x3/7x7 kernels are supported");
+            const int bi = bottom(0);
+            const Blob b = S.blobs[bi];
+            Op op;
+            op.kind = OP_CONV; op.in = bi; op.ks = L.kernel_size; op.cin = b.C; op.cout = L.num_output;
+            op.out = new_blob(S, L.top[0], L.num_output, b.H, b.W, b.shared);
+            const size_t nw = (size_t)op.cout * op.cin * op.ks * op.ks;
+            upload_conv(S, op, weights + woff, weights + woff + nw);
+            woff += nw + op.cout;
+            op.flops = 2.0 * op.ks * op.ks * op.cin * op.cout * (double)b.H * b.W;
+            S.ops.push_back(op);
+            absorber[op.out] = (int)S.ops.size() - 1;
+        } else if (L.type == "BN") {
+            if (L.bn_mode != "INFERENCE") throw std::runtime_error("BN '" + L.name + "': only bn_mode INFERENCE is supported");
+            const int bi = bottom(0);
+            auto it = absorber.find(bi);
+            if (!inplace || it == absorber.end() || S.ops[it->second].kind != OP_CONV || S.ops[it->second].relu ||
+                S.ops[it->second].drop_site >= 0)
+                throw std::runtime_error("BN '" + L.name + "' must follow a Convolution in place");
+            const int C = S.blobs[bi].C;
+            fold_bn(S.ops[it->second], weights + woff, weights + woff + C);
+            woff += 2 * (size_t)C;
+        } else if (L.type == "ReLU") {
+            const int bi = bottom(0);
+            auto it = absorber.find(bi);
+            if (!inplace || it == absorber.end() || S.ops[it->second].kind != OP_CONV || S.ops[it->second].drop_site >= 0)
+                throw std::runtime_error("ReLU '" + L.name + "' must follow a Convolution in place");
+            S.ops[it->second].relu = true;
+        } else if (L.type == "Pooling") {
+            if (L.pool != "MAX" || L.kernel_size != 2 || L.stride != 2 || L.top.size() != 2)
+                throw std::runtime_error("Pooling '" + L.name + "': only MAX 2x2 stride 2 with a mask top is supported");
+            const int bi = bottom(0);
+            const Blob b = S.blobs[bi];
+            Op op;
+            op.kind = OP_POOL; op.in = bi;
+            const int Ho = (b.H - 2 + 1) / 2 + 1, Wo = (b.W - 2 + 1) / 2 + 1;   // ceil((H-k)/s)+1
+            op.out = new_blob(S, L.top[0], b.C, Ho, Wo, b.shared);
+            op.out2 = new_blob(S, L.top[1], b.C, Ho, Wo, b.shared, true);
+            S.blobs[op.out2].src_W = b.W;
+            S.ops.push_back(op);
+            absorber.erase(bi);
+            absorber[op.out] = (int)S.ops.size() - 1;
+        } else if (L.type == "Dropout") {
+            const int my_site = site++;
+            if (!L.sample_weights_test) continue;  // plain Caffe dropout is the identity at test time
+            if (std::fabs(L.dropout_ratio - 0.5f) > 1e-6f)
+                throw std::runtime_error("Dropout '" + L.name + "': only dropout_ratio 0.5 is supported");
+            const int bi = bottom(0);
+            auto it = absorber.find(bi);
+            if (inplace && it != absorber.end() && S.ops[it->second].drop_site < 0 && !S.blobs[bi].shared) {
+                S.ops[it->second].drop_site = my_site;       // conv / pool epilogue
+            } else if (inplace && it != absorber.end() && S.ops[it->second].kind == OP_POOL && S.blobs[bi].shared) {
+                // pooled output of a shared blob becomes per-sample: pool kernel broadcasts + drops
+                S.ops[it->second].drop_site = my_site;
+                S.blobs[bi].shared = false;
+            } else {
+                // general case: separate kernel, out of place into a per-sample blob that takes over the name
+                Op op;
+                op.kind = OP_DROPOUT; op.in = bi; op.drop_site = my_site;
+                const Blob b = S.blobs[bi];
+                op.out = new_blob(S, L.top[0], b.C, b.H, b.W, false);
+                S.ops.push_back(op);
+            }
+            absorber.erase(bi);
+        } else if (L.type == "Upsample") {
+            if (L.scale != 2 || L.bottom.size() != 2) throw std::runtime_error("Upsample '" + L.name + "': only scale 2 with a mask bottom");
+            const int bi = bottom(0), mi = bottom(1);
+            const Blob b = S.blobs[bi], m = S.blobs[mi];
+            if (!m.is_mask || m.C != b.C || m.H != b.H || m.W != b.W)
+                throw std::runtime_error("Upsample '" + L.name + "': mask does not match the bottom");
+            Op op;
+            op.kind = OP_UNPOOL; op.in = bi; op.in2 = mi;
+            op.out = new_blob(S, L.top[0], b.C, b.H * 2, b.W * 2, b.shared && m.shared);
+            S.ops.push_back(op);
+            absorber.erase(bi);
+        } else if (L.type == "LRN") {
+            const int bi = bottom(0);
+            const Blob b = S.blobs[bi];
+            Op op;
+            op.kind = OP_LRN; op.in = bi; op.local_size = L.local_size; op.alpha = L.alpha; op.beta = L.beta;
+            op.out = new_blob(S, L.top[0], b.C, b.H, b.W, b.shared);
+            S.ops.push_back(op);
+        } else if (L.type == "Softmax") {
+            S.has_softmax = true;
+            S.logits_blob = bottom(0);
+        } else {
+            throw std::runtime_error("layer '" + L.name + "': unsupported type '" + L.type + "'");
+        }
+    }
+    if (!S.has_softmax) throw std::runtime_error("the network must end in a Softmax layer");
+    S.classes = S.blobs[S.logits_blob].C;
+    if (S.classes > 16) throw std::runtime_error("at most 16 classes are supported");
+
+    // sharedness must propagate forward through ops built before a later flip (pool+dropout flips its output)
+    for (Op &op : S.ops) {
+        bool sh = S.blobs[op.in].shared && (op.in2 < 0 || S.blobs[op.in2].shared) && op.drop_site < 0;
+        if (op.kind == OP_DROPOUT) sh = false;
+        S.blobs[op.out].shared = sh;
+        if (op.out2 >= 0) S.blobs[op.out2].shared = S.blobs[op.in].shared;   // the argmax only depends on the input
+        (sh ? S.flops_shared : S.flops_sample) += op.flops;
+    }
+    // allocate
+    for (Blob &b : S.blobs) {
+        const size_t n = (size_t)(b.shared ? 1 : S.T) * b.chw();
+        b.d = b.is_mask ? (void *)dev_alloc<uint8_t>(n) : (void *)dev_alloc<float>(n);
+        S.owned.push_back(b.d);
+    }
+    const int64_t hw = (int64_t)S.H * S.W;
+    S.d_image = dev_alloc<uint8_t>(hw * 3);
+    S.d_prob_sum = dev_alloc<float>(S.classes * hw);
+    S.d_classes = dev_alloc<uint8_t>(hw);
+    S.d_conf = dev_alloc<double>(hw);
+    S.d_ent = dev_alloc<double>(hw);
+    for (void *p : {(void *)S.d_image, (void *)S.d_prob_sum, (void *)S.d_classes, (void *)S.d_conf, (void *)S.d_ent})
+        S.owned.push_back(p);
+    SIVO_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    return Sp;
+}
+
+void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t seed, float *d_prob_sum,
+             float *d_logits, float *d_prob, hipStream_t st) {
+    const int64_t hw = (int64_t)S.H * S.W;
+    launch_preprocess(d_bgr, (float *)S.blobs[S.input_blob].d, hw, st);
+    for (const Op &op : S.ops) {
+        const Blob &bi = S.blobs[op.in];
+        const Blob &bo = S.blobs[op.out];
+        const int N = bo.shared ? 1 : n;
+        switch (op.kind) {
+            case OP_CONV: {
+                ConvArgs a{};
+                a.in = (const float *)bi.d; a.in_sample_stride = bi.shared ? 0 : bi.chw();
+                a.wt = op.d_w; a.ep_scale = op.d_scale; a.ep_shift = op.d_shift;
+                a.out = (float *)bo.d;
+                a.N = N; a.Cin = op.cin; a.H = bi.H; a.W = bi.W; a.Cout = op.cout; a.CoutPad = op.cout_pad;
+                a.relu = op.relu; a.drop_site = op.drop_site; a.sample0 = sample0; a.seed = seed;
+                launch_conv(a, op.ks, st);
+                break;
+            }
+            case OP_POOL: {
+                PoolArgs a{};
+                a.in = (const float *)bi.d; a.in_sample_stride = bi.shared ? 0 : bi.chw();
+                a.out = (float *)bo.d; a.mask = (uint8_t *)S.blobs[op.out2].d;
+                a.mask_N = S.blobs[op.out2].shared ? 1 : n;
+                a.N = N; a.C = bi.C; a.H = bi.H; a.W = bi.W; a.Ho = bo.H; a.Wo = bo.W;
+                a.drop_site = op.drop_site; a.sample0 = sample0; a.seed = seed;
+                launch_maxpool2(a, st);
+                break;
+            }
+            case OP_UNPOOL: {
+                UnpoolArgs a{};
+                const Blob &bm = S.blobs[op.in2];
+                a.in = (const float *)bi.d; a.mask = (const uint8_t *)bm.d;
+                a.mask_sample_stride = bm.shared ? 0 : bm.chw();
+                a.out = (float *)bo.d; a.N = N; a.C = bi.C; a.H = bi.H; a.W = bi.W;
+                if (bi.shared && !bo.shared) throw std::runtime_error("unpool of a shared blob with a per-sample mask is not supported");
+                launch_unpool2(a, st);
+                break;
+            }
+            case OP_DROPOUT:
+                launch_dropout((const float *)bi.d, bi.shared ? 0 : bi.chw(), (float *)bo.d, n, bi.chw(), op.drop_site,
+                               sample0, seed, st);
+                break;
+            case OP_LRN:
+                launch_lrn((const float *)bi.d, (float *)bo.d, N, bi.C, (int64_t)bi.H * bi.W, op.local_size, op.alpha,
+                           op.beta, st);
+                break;
+        }
+    }
+    const Blob &lg = S.blobs[S.logits_blob];
+    if (lg.shared) throw std::runtime_error("the network has no test-time dropout: nothing to sample");
+    launch_mc_reduce((const float *)lg.d, n, S.classes, hw, d_prob_sum, d_prob, 0, st);
+    if (d_logits)
+        SIVO_HIP(hipMemcpyAsync(d_logits, lg.d, (size_t)n * lg.chw() * sizeof(float), hipMemcpyDeviceToDevice, st));
+    SIVO_HIP(hipGetLastError());
+}
+
+std::string read_file(const char *path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::invalid_argument(std::string("cannot open '") + path + "'");
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+}  // namespace
+}  // namespace sivo
+
+using namespace sivo;
+
+extern "C" int sivo_segnet_num_params(const char *text, size_t len, size_t *n_params) {
+    return guarded([&] {
+        if (!text || !len) throw std::invalid_argument("model_file (.prototxt file) is empty!");
+        *n_params = count_params(parse_prototxt(std::string(text, len)));
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_segnet_create(const char *text, size_t len, int t_override, const float *weights,
+                                  size_t n_weights, int device, sivo_segnet_t *out) {
+    return guarded([&] {
+        if (!out) throw std::invalid_argument("out is NULL");
+        *out = nullptr;
+        if (!text || !len) throw std::invalid_argument("model_file (.prototxt file) is empty!");
+        if (!weights || !n_weights) throw std::invalid_argument("weights_file (.caffemodel file) is empty!");
+        if (sivo_device_count() <= device || device < 0)
+            return fail(SIVO_ERR_RUNTIME, "HIP device %d is not available (%d visible): libsivo_hip has no CPU fallback",
+                        device, sivo_device_count());
+        ProtoNet net = parse_prototxt(std::string(text, len));
+        *out = build(net, t_override, weights, n_weights, device).release();
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_segnet_create_from_files(const char *model_file, const char *weights_file, int t_override,
+                                             int device, sivo_segnet_t *out) {
+    return guarded([&] {
+        if (!model_file || !*model_file) throw std::invalid_argument("model_file (.prototxt file) is empty!");
+        if (!weights_file || !*weights_file) throw std::invalid_argument("weights_file (.caffemodel file) is empty!");
+        const std::string text = read_file(model_file);
+        const std::string wb = read_file(weights_file);
+        if (wb.size() < 16 || std::memcmp(wb.data(), "SIVOW001", 8) != 0)
+            throw std::invalid_argument("weights_file is not a .sivow container (see sivo_amd/weights.py)");
+        uint64_t n = 0;
+        std::memcpy(&n, wb.data() + 8, 8);
+        if (wb.size() != 16 + 4 * n) throw std::invalid_argument("weights_file is truncated");
+        std::vector<float> w(n);
+        std::memcpy(w.data(), wb.data() + 16, 4 * n);
+        return sivo_segnet_create(text.data(), text.size(), t_override, w.data(), w.size(), device, out);
+    });
+}
+
+extern "C" int sivo_segnet_destroy(sivo_segnet_t h) {
+    return guarded([&] {
+        if (h) {
+            DeviceGuard dg(h->device);
+            delete h;
+        }
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_segnet_shape(sivo_segnet_t h, int32_t *T, int32_t *C, int32_t *H, int32_t *W, int32_t *classes) {
+    if (!h) return fail(SIVO_ERR_INVALID_ARGUMENT, "null handle");
+    if (T) *T = h->T;
+    if (C) *C = h->C;
+    if (H) *H = h->H;
+    if (W) *W = h->W;
+    if (classes) *classes = h->classes;
+    return SIVO_OK;
+}
+
+extern "C" int sivo_segnet_flops(sivo_segnet_t h, double *shared, double *per_sample) {
+    if (!h) return fail(SIVO_ERR_INVALID_ARGUMENT, "null handle");
+    if (shared) *shared = h->flops_shared;
+    if (per_sample) *per_sample = h->flops_sample;
+    return SIVO_OK;
+}
+
+extern "C" int sivo_segnet_forward_dev(sivo_segnet_t h, const uint8_t *d_bgr, int n_samples, int sample0,
+                                       uint64_t seed, float *d_prob_sum, float *d_logits, float *d_prob,
+                                       void *stream) {
+    return guarded([&] {
+        if (!h || !d_bgr || !d_prob_sum) throw std::invalid_argument("null argument");
+        if (n_samples < 1 || n_samples > h->T) throw std::invalid_argument("n_samples must be in [1, T]");
+        DeviceGuard dg(h->device);
+        forward(*h, d_bgr, n_samples, sample0, seed, d_prob_sum, d_logits, d_prob, (hipStream_t)stream);
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_mc_reduce_dev(const float *d_logits, int n, int classes, int64_t hw, float *d_prob_sum,
+                                  float *d_prob, int accumulate, void *stream) {
+    return guarded([&] {
+        if (!d_logits || !d_prob_sum || n < 1 || classes < 1 || classes > 16 || hw < 1)
+            throw std::invalid_argument("bad argument (1 <= classes <= 16)");
+        launch_mc_reduce(d_logits, n, classes, hw, d_prob_sum, d_prob, accumulate, (hipStream_t)stream);
+        SIVO_HIP(hipGetLastError());
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_mc_finalize_dev(const float *d_prob_sum, int classes, int64_t hw, int t_total,
+                                    uint8_t *d_classes, double *d_confidence, double *d_entropy, void *stream) {
+    return guarded([&] {
+        if (!d_prob_sum || classes < 1 || hw < 1 || t_total < 1) throw std::invalid_argument("bad argument");
+        launch_mc_finalize(d_prob_sum, classes, hw, t_total, d_classes, d_confidence, d_entropy, (hipStream_t)stream);
+        SIVO_HIP(hipGetLastError());
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_mc_variance_dev(const float *d_prob, int T, int classes, int64_t hw, const uint8_t *d_classes,
+                                    double *d_variance, void *stream) {
+    return guarded([&] {
+        if (!d_prob || !d_classes || !d_variance || T < 2) throw std::invalid_argument("bad argument (T >= 2)");
+        launch_mc_variance(d_prob, T, classes, hw, d_classes, d_variance, (hipStream_t)stream);
+        SIVO_HIP(hipGetLastError());
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_segnet_segment(sivo_segnet_t h, const uint8_t *bgr, int rows, int cols, uint64_t seed,
+                                   uint8_t *classes, double *confidence, double *entropy) {
+    return guarded([&] {
+        if (!h || !bgr) throw std::invalid_argument("null argument");
+        // resizeImage (bayesian_segnet.cpp:142-162): exact size -> as is; larger -> centre crop; smaller -> empty
+        if (rows < h->H || cols < h->W)
+            return fail(SIVO_ERR_IMAGE_TOO_SMALL, "image %dx%d is smaller than the network geometry %dx%d", cols, rows, h->W, h->H);
+        DeviceGuard dg(h->device);
+        const int x_tl = (rows == h->H && cols == h->W) ? 0 : cols / 2 - h->W / 2;
+        const int y_tl = (rows == h->H && cols == h->W) ? 0 : rows / 2 - h->H / 2;
+        hipStream_t st = h->stream;
+        SIVO_HIP(hipMemcpy2DAsync(h->d_image, (size_t)h->W * 3, bgr + ((size_t)y_tl * cols + x_tl) * 3, (size_t)cols * 3,
+                                  (size_t)h->W * 3, (size_t)h->H, hipMemcpyHostToDevice, st));
+        forward(*h, h->d_image, h->T, 0, seed, h->d_prob_sum, nullptr, nullptr, st);
+        const int64_t hw = (int64_t)h->H * h->W;
+        launch_mc_finalize(h->d_prob_sum, h->classes, hw, h->T, h->d_classes, h->d_conf, h->d_ent, st);
+        if (classes) SIVO_HIP(hipMemcpyAsync(classes, h->d_classes, hw, hipMemcpyDeviceToHost, st));
+        if (confidence) SIVO_HIP(hipMemcpyAsync(confidence, h->d_conf, hw * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (entropy) SIVO_HIP(hipMemcpyAsync(entropy, h->d_ent, hw * sizeof(double), hipMemcpyDeviceToHost, st));
+        SIVO_HIP(hipStreamSynchronize(st));
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_segnet_blob(sivo_segnet_t h, const char *name, float *host_out, size_t capacity,
+                                int32_t shape[4]) {
+    return guarded([&] {
+        if (!h || !name) throw std::invalid_argument("null argument");
+        auto it = h->blob_id.find(name);
+        if (it == h->blob_id.end()) throw std::invalid_argument(std::string("no blob named '") + name + "'");
+        const Blob &b = h->blobs[it->second];
+        const int N = b.shared ? 1 : h->T;
+        if (shape) { shape[0] = N; shape[1] = b.C; shape[2] = b.H; shape[3] = b.W; }
+        const size_t n = (size_t)N * b.chw();
+        if (!host_out) return SIVO_OK;
+        if (capacity < n) return fail(SIVO_ERR_CAPACITY, "blob '%s' holds %zu values, capacity %zu", name, n, capacity);
+        DeviceGuard dg(h->device);
+        SIVO_HIP(hipDeviceSynchronize());
+        if (b.is_mask) {
+            float *tmp = dev_alloc<float>(n);
+            launch_mask_to_index((const uint8_t *)b.d, tmp, (int64_t)n, b.H, b.W, b.src_W, nullptr);
+            SIVO_HIP(hipMemcpy(host_out, tmp, n * sizeof(float), hipMemcpyDeviceToHost));
+            SIVO_HIP(hipFree(tmp));
+        } else {
+            SIVO_HIP(hipMemcpy(host_out, b.d, n * sizeof(float), hipMemcpyDeviceToHost));
+        }
+        return SIVO_OK;
+    });
+}

@@ -1,0 +1,60 @@
+// segnet_kernels.hpp — launch interface of segnet_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sivo {
+
+struct ConvArgs {
+    const float *in;           // (N or 1, Cin, H, W)
+    int64_t in_sample_stride;  // Cin*H*W, or 0 when the input is shared by all samples
+    const float *wt;           // [ceil(Cin/KC)][k*k][KC][CoutPad], zero padded
+    const float *ep_scale;     // [Cout]  y = ep_scale*acc + ep_shift   (bias + BN folded)
+    const float *ep_shift;     // [Cout]
+    float *out;                // (N, Cout, H, W)
+    int N, Cin, H, W, Cout, CoutPad;
+    int tiles_x, tiles_y;      // filled by the launcher
+    int relu;
+    int drop_site;             // < 0: no dropout in the epilogue
+    int sample0;
+    uint64_t seed;
+};
+int conv_cout_tile(int ks, int cout);  // BN the launcher will pick (CoutPad must be a multiple)
+int conv_k_chunk(int ks, int cin);     // KC the launcher will pick (defines the weight layout)
+void launch_conv(const ConvArgs &a, int ks, hipStream_t s);
+
+struct PoolArgs {
+    const float *in;
+    int64_t in_sample_stride;
+    float *out;
+    uint8_t *mask;  // window code dy*2+dx
+    int mask_N;     // how many samples' masks to write (1 when the input is shared)
+    int N, C, H, W, Ho, Wo;
+    int drop_site, sample0;
+    uint64_t seed;
+};
+void launch_maxpool2(const PoolArgs &a, hipStream_t s);
+
+struct UnpoolArgs {
+    const float *in;
+    const uint8_t *mask;
+    int64_t mask_sample_stride;  // 0 when the mask is shared
+    float *out;
+    int N, C, H, W;              // input dims; output is (2H, 2W)
+};
+void launch_unpool2(const UnpoolArgs &a, hipStream_t s);
+
+void launch_preprocess(const uint8_t *bgr, float *out, int64_t hw, hipStream_t s);
+void launch_dropout(const float *in, int64_t in_sample_stride, float *out, int N, int64_t chw, int site,
+                    int sample0, uint64_t seed, hipStream_t s);
+void launch_lrn(const float *in, float *out, int N, int C, int64_t hw, int local_size, float alpha, float beta,
+                hipStream_t s);
+int launch_mc_reduce(const float *logits, int n, int C, int64_t hw, float *prob_sum, float *prob, int accumulate,
+                     hipStream_t s);
+void launch_mc_finalize(const float *prob_sum, int C, int64_t hw, int T, uint8_t *classes, double *confidence,
+                        double *entropy, hipStream_t s);
+void launch_mc_variance(const float *prob, int T, int C, int64_t hw, const uint8_t *classes, double *variance,
+                        hipStream_t s);
+void launch_mask_to_index(const uint8_t *mask, float *out, int64_t total, int Ho, int Wo, int Win, hipStream_t s);
+
+}  // namespace sivo

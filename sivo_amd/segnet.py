@@ -1,0 +1,145 @@
+"""Python mirror of SIVO::BayesianSegNet (reference include/bayesian_segnet/bayesian_segnet.hpp:85-170,
+src/bayesian_segnet/bayesian_segnet.cpp) over the C ABI.  torch is used for device
+memory, streams and torch.distributed only."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+# bayesian_segnet.hpp:67-83
+CLASSES = ["ROAD", "SIDEWALK", "BUILDING", "WALL", "POLE", "TRAFFIC_LIGHT", "TRAFFIC_SIGN", "VEGETATION",
+           "TERRAIN", "SKY", "PERSON", "CAR", "COMMERCIAL_VEHICLE", "BIKE"]
+VOID = 255
+
+
+class BayesianSegNetParams:
+    """bayesian_segnet.hpp:85-105."""
+
+    def __init__(self, model_file="", weights_file="", use_gpu=True):
+        self.model_file, self.weights_file, self.use_gpu = model_file, weights_file, use_gpu
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class BayesianSegNet:
+    """Constructor from a params object (files) like the reference, or from prototxt text + flat weights."""
+
+    def __init__(self, params=None, prototxt=None, weights=None, T=0, device=0):
+        h = C.c_void_p()
+        if params is not None:
+            if not params.model_file:
+                raise ValueError("model_file (.prototxt file) is empty!")       # bayesian_segnet.cpp:80-89
+            if not params.weights_file:
+                raise ValueError("weights_file (.caffemodel file) is empty!")
+            if not params.use_gpu:
+                raise _lib.SivoError(_lib.ERR_UNSUPPORTED, "use_gpu=false: this library has no CPU path")
+            rc = lib().sivo_segnet_create_from_files(params.model_file.encode(), params.weights_file.encode(), T,
+                                                     device, C.byref(h))
+        else:
+            text = prototxt.encode() if isinstance(prototxt, str) else (prototxt or b"")
+            w = np.ascontiguousarray(weights if weights is not None else np.zeros(0), np.float32)
+            rc = lib().sivo_segnet_create(text, len(text), T, w.ctypes.data_as(C.c_void_p), w.size, device, C.byref(h))
+        if rc == _lib.ERR_INVALID_ARGUMENT:
+            raise ValueError(lib().sivo_last_error().decode())                     # std::invalid_argument
+        check(rc)
+        self._h = h
+        self.device = device
+        T_, C_, H_, W_, K_ = (C.c_int32() for _ in range(5))
+        check(lib().sivo_segnet_shape(h, T_, C_, H_, W_, K_))
+        self.T, self.C, self.H, self.W, self.classes = T_.value, C_.value, H_.value, W_.value, K_.value
+        a, b = C.c_double(), C.c_double()
+        check(lib().sivo_segnet_flops(h, C.byref(a), C.byref(b)))
+        self.flops_shared, self.flops_per_sample = a.value, b.value
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().sivo_segnet_destroy(h)
+            self._h = None
+
+    def get_input_geometry(self):
+        """getInputGeometry(): (width, height) like cv::Size."""
+        return (self.W, self.H)
+
+    # -- device-resident path -------------------------------------------------------------
+    def forward(self, d_bgr, seed, n_samples=None, sample0=0, want_logits=False, want_prob=False):
+        """d_bgr: cuda uint8 tensor (H, W, 3) BGR.  Returns (prob_sum[classes,H,W] f32, logits|None, prob|None)."""
+        n = self.T if n_samples is None else n_samples
+        dev = d_bgr.device
+        assert d_bgr.is_cuda and d_bgr.dtype == torch.uint8 and d_bgr.is_contiguous() and tuple(d_bgr.shape) == (self.H, self.W, 3)
+        prob_sum = torch.empty((self.classes, self.H, self.W), dtype=torch.float32, device=dev)
+        logits = torch.empty((n, self.classes, self.H, self.W), dtype=torch.float32, device=dev) if want_logits else None
+        prob = torch.empty((n, self.classes, self.H, self.W), dtype=torch.float32, device=dev) if want_prob else None
+        check(lib().sivo_segnet_forward_dev(self._h, d_bgr.data_ptr(), n, sample0, C.c_uint64(seed), prob_sum.data_ptr(),
+                                            logits.data_ptr() if want_logits else None,
+                                            prob.data_ptr() if want_prob else None, _stream()))
+        return prob_sum, logits, prob
+
+    def forward_into(self, d_bgr, seed, prob_sum, n_samples=None, sample0=0):
+        n = self.T if n_samples is None else n_samples
+        check(lib().sivo_segnet_forward_dev(self._h, d_bgr.data_ptr(), n, sample0, C.c_uint64(seed), prob_sum.data_ptr(),
+                                            None, None, _stream()))
+
+    def finalize(self, prob_sum, t_total=None, out=None):
+        """classes (u8), confidence (f64), entropy (f64) maps from the probability sum."""
+        t_total = self.T if t_total is None else t_total
+        dev = prob_sum.device
+        if out is None:
+            out = (torch.empty((self.H, self.W), dtype=torch.uint8, device=dev),
+                   torch.empty((self.H, self.W), dtype=torch.float64, device=dev),
+                   torch.empty((self.H, self.W), dtype=torch.float64, device=dev))
+        check(lib().sivo_mc_finalize_dev(prob_sum.data_ptr(), self.classes, self.H * self.W, t_total,
+                                         out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), _stream()))
+        return out
+
+    # -- host path == segmentImage --------------------------------------------------------
+    def segment_image(self, image_bgr, seed=0):
+        """segmentImage(const cv::Mat&, MatXu&, MatXd&, MatXd&) (bayesian_segnet.cpp:299-318)."""
+        img = np.ascontiguousarray(image_bgr, np.uint8)
+        classes = np.empty((self.H, self.W), np.uint8)
+        conf = np.empty((self.H, self.W), np.float64)
+        ent = np.empty((self.H, self.W), np.float64)
+        check(lib().sivo_segnet_segment(self._h, img.ctypes.data_as(C.c_void_p), img.shape[0], img.shape[1],
+                                        C.c_uint64(seed), classes.ctypes.data_as(C.c_void_p),
+                                        conf.ctypes.data_as(C.c_void_p), ent.ctypes.data_as(C.c_void_p)))
+        return classes, conf, ent
+
+    def blob(self, name):
+        shape = (C.c_int32 * 4)()
+        check(lib().sivo_segnet_blob(self._h, name.encode(), None, 0, shape))
+        out = np.empty(tuple(shape), np.float32)
+        check(lib().sivo_segnet_blob(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), out.size, shape))
+        return out
+
+
+def mc_reduce(logits, prob_sum=None, want_prob=False, accumulate=False):
+    n, K, H, W = logits.shape
+    if prob_sum is None:
+        prob_sum = torch.zeros((K, H, W), dtype=torch.float32, device=logits.device)
+    prob = torch.empty_like(logits) if want_prob else None
+    check(lib().sivo_mc_reduce_dev(logits.data_ptr(), n, K, H * W, prob_sum.data_ptr(),
+                                   prob.data_ptr() if want_prob else None, int(accumulate), _stream()))
+    return prob_sum, prob
+
+
+def mc_finalize(prob_sum, t_total):
+    K, H, W = prob_sum.shape
+    dev = prob_sum.device
+    cls = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    conf = torch.empty((H, W), dtype=torch.float64, device=dev)
+    ent = torch.empty((H, W), dtype=torch.float64, device=dev)
+    check(lib().sivo_mc_finalize_dev(prob_sum.data_ptr(), K, H * W, t_total, cls.data_ptr(), conf.data_ptr(),
+                                     ent.data_ptr(), _stream()))
+    return cls, conf, ent
+
+
+def mc_variance(prob, classes):
+    T, K, H, W = prob.shape
+    var = torch.empty((H, W), dtype=torch.float64, device=prob.device)
+    check(lib().sivo_mc_variance_dev(prob.data_ptr(), T, K, H * W, classes.data_ptr(), var.data_ptr(), _stream()))
+    return var

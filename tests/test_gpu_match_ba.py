@@ -1,0 +1,104 @@
+"""GPU parity (bit-exact) of Hamming matching and BA edge linearisation vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from sivo_amd import matcher, optimizer
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("nA,nB", [(1, 1), (3, 300), (257, 255), (2000, 2000), (33, 1)])
+def test_hamming_matrix_bit_exact(oracle, nA, nB):
+    rng = np.random.default_rng(nA + nB)
+    A = rng.integers(0, 256, (nA, 32), dtype=np.uint8); B = rng.integers(0, 256, (nB, 32), dtype=np.uint8)
+    B[0] = A[0]                       # a zero distance
+    if nB > 1: B[1] = ~A[0]           # a 256 distance
+    ref = oracle.hamming_matrix(A, B)
+    assert np.array_equal(matcher.descriptor_distance_matrix(A, B), ref)
+    out = matcher.descriptor_distance_matrix(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda())
+    assert np.array_equal(out.cpu().numpy(), ref)
+    assert ref[0, 0] == 0 and (nB < 2 or ref[0, 1] == 256)
+
+
+def test_hamming_empty():
+    out = matcher.descriptor_distance_matrix(np.zeros((0, 32), np.uint8), np.zeros((5, 32), np.uint8))
+    assert out.shape == (0, 5)
+
+
+def test_argmin2_candidate_lists(oracle):
+    rng = np.random.default_rng(5)
+    nA, nB = 700, 900
+    A = rng.integers(0, 256, (nA, 32), dtype=np.uint8); B = rng.integers(0, 256, (nB, 32), dtype=np.uint8)
+    B[10:40] = B[5]                     # duplicates: ties must keep the earlier candidate
+    lens = rng.integers(0, 200, nA); lens[::7] = 0; lens[3] = 1
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = rng.integers(0, nB, off[-1]).astype(np.int32)
+    bi, bd, sd = matcher.argmin2(A, B, off, idx)
+    obi, obd, osd = oracle.hamming_argmin2(A, B, off, idx)
+    assert np.array_equal(bi, obi) and np.array_equal(bd, obd) and np.array_equal(sd, osd)
+    assert (bi[lens == 0] == -1).all() and (bd[lens == 0] == 256).all()
+
+
+def test_bruteforce_matches_matrix(oracle):
+    rng = np.random.default_rng(6)
+    A = rng.integers(0, 256, (500, 32), dtype=np.uint8); B = rng.integers(0, 256, (333, 32), dtype=np.uint8)
+    bi, bd, sd = matcher.bruteforce(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda())
+    D = oracle.hamming_matrix(A, B)
+    assert np.array_equal(bd.cpu().numpy(), D.min(1)) and np.array_equal(bi.cpu().numpy(), D.argmin(1))
+    assert np.array_equal(sd.cpu().numpy(), np.sort(D, 1)[:, 1])
+
+
+def make_ba_scene(seed=99, n_kf=20, n_pts=3000, stereo_frac=0.8):
+    """forward trajectory, frustum box of points, KITTI-00 intrinsics."""
+    rng = np.random.default_rng(seed)
+    fx = fy = 718.856; cx, cy, bf = 498.692, 173.215, 386.1448
+    poses = np.zeros((n_kf, 12))
+    for k in range(n_kf):
+        yaw = np.deg2rad(rng.uniform(-2, 2))
+        Rwc = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+        twc = np.array([rng.normal(0, 0.05), rng.normal(0, 0.02), 1.0 * k])
+        Rcw = Rwc.T; tcw = -Rcw @ twc
+        poses[k, :9] = Rcw.ravel(); poses[k, 9:] = tcw
+    pts = np.stack([rng.uniform(-20, 20, n_pts), rng.uniform(-5, 5, n_pts), rng.uniform(2, 62, n_pts)], 1)
+    edges = []
+    for k in range(n_kf):
+        R = poses[k, :9].reshape(3, 3); t = poses[k, 9:]
+        pc = pts @ R.T + t
+        z = pc[:, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u = fx * pc[:, 0] / z + cx; v = fy * pc[:, 1] / z + cy
+        vis = (z > 0.5) & (z < 80) & (u >= 0) & (u < 1024) & (v >= 0) & (v < 352)
+        for i in np.nonzero(vis)[0]:
+            lvl = rng.integers(0, 8); sig = 1.2 ** lvl
+            st = rng.random() < stereo_frac
+            obs = [u[i] + rng.normal(0, sig), v[i] + rng.normal(0, sig), u[i] - bf / z[i] + rng.normal(0, sig)]
+            if rng.random() < 0.02: obs[0] += 30          # outliers exercise the Huber branch
+            edges.append((k, i, int(st), 0, obs, 1.0 / (sig * sig)))
+    return poses, pts, np.array(edges, dtype=optimizer.EDGE_DTYPE), (fx, fy, cx, cy, bf)
+
+
+def test_ba_linearize_bit_exact(oracle):
+    poses, pts, edges, intr = make_ba_scene()
+    assert 20000 < len(edges) < 70000
+    g = optimizer.linearize(poses, pts, edges, intr)
+    o = oracle.ba_linearize(poses, pts, edges, intr)
+    for k in ("err", "Jx", "Jp", "chi2", "rho", "w", "depth_ok"):
+        assert np.array_equal(g[k], o[k]), k
+    assert (o["w"] < 1).any() and (o["w"] == 1).any()
+    assert (edges["stereo"] == 0).any() and (edges["stereo"] == 1).any()
+
+
+def test_ba_edge_cases(oracle):
+    poses, pts, edges, intr = make_ba_scene(seed=3, n_kf=2, n_pts=50)
+    # a point behind the camera (depth_ok = 0) and an empty batch
+    pts[0] = [0, 0, -5]
+    g = optimizer.linearize(poses, pts, edges, intr); o = oracle.ba_linearize(poses, pts, edges, intr)
+    assert np.array_equal(g["depth_ok"], o["depth_ok"]) and (o["depth_ok"] == 0).any()
+    assert np.array_equal(g["Jp"], o["Jp"])
+    e0 = optimizer.linearize(poses, pts, edges[:0], intr)
+    assert e0["err"].shape == (0, 3)
+    from sivo_amd._lib import SivoError
+    bad = edges[:1].copy(); bad["point"] = 10 ** 6
+    with pytest.raises(SivoError):
+        optimizer.linearize(poses, pts, bad, intr)

@@ -1,0 +1,83 @@
+"""GPU parity (bit-exact) of the ORB extractor and stereo matching vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import synthetic_frame, synthetic_stereo
+from sivo_amd import orb
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(oracle, gray, **kw):
+    ex_o = oracle.OrbExtractor(**{k: v for k, v in kw.items()})
+    names = {"nfeatures": "nfeatures", "scale_factor": "scale_factor", "nlevels": "nlevels", "ini_th": "ini_th_fast", "min_th": "min_th_fast"}
+    ex_g = orb.ORBextractor(**{names[k]: v for k, v in kw.items()})
+    kp_o, d_o = ex_o(gray)
+    kp_g, d_g = ex_g(gray)
+    for l in range(ex_o.nlevels):
+        assert np.array_equal(ex_g.image_pyramid(l, with_border=True), ex_o.level(l, with_border=True)), f"pyramid level {l}"
+        co, cg = ex_o.candidates(l), ex_g.candidates(l)
+        assert len(co) == len(cg) and co.tobytes() == cg.tobytes(), f"FAST candidates level {l}"
+    assert len(kp_o) == len(kp_g)
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        assert np.array_equal(kp_o[f], kp_g[f]), f
+    assert np.array_equal(kp_o["angle"].view(np.uint32), kp_g["angle"].view(np.uint32)), "angle bits"
+    assert np.array_equal(d_o, d_g), "descriptors"
+    return ex_o, ex_g, kp_g, d_g
+
+
+def test_orb_kitti_frame_bit_exact(oracle, kitti_like_bgr):
+    """BASELINE config 1: 2000 features / 8 levels on the KITTI frame."""
+    gray = oracle.bgr2gray(kitti_like_bgr)
+    ex_o, ex_g, kp, d = _compare(oracle, gray)
+    assert 1900 <= len(kp) <= 2100
+    assert list(ex_g.features_per_level) == [434, 362, 302, 251, 209, 175, 145, 122]
+
+
+def test_orb_synthetic_bit_exact(oracle):
+    _compare(oracle, synthetic_frame(1234))
+
+
+def test_orb_device_resident_input(oracle):
+    gray = synthetic_frame(77)
+    ex = orb.ORBextractor()
+    kp_h, d_h = ex(gray)
+    kp_d, d_d = ex(torch.from_numpy(gray).cuda())
+    assert kp_h.tobytes() == kp_d.tobytes() and np.array_equal(d_h, d_d)
+
+
+@pytest.mark.parametrize("shape,kw", [((120, 160), dict(nfeatures=300, nlevels=4)),
+                                       ((375, 1242), dict(nfeatures=1000, ini_th=12)),
+                                       ((97, 131), dict(nfeatures=50, nlevels=3, scale_factor=1.5))])
+def test_orb_other_geometries(oracle, shape, kw):
+    _compare(oracle, synthetic_frame(5, *shape), **kw)
+
+
+def test_orb_flat_and_low_contrast_images(oracle):
+    """No corners anywhere -> zero keypoints; low contrast -> the minThFAST fallback path."""
+    ex = orb.ORBextractor()
+    kp, d = ex(np.full((352, 1024), 128, np.uint8))
+    assert len(kp) == 0 and d.shape == (0, 32)
+    rng = np.random.default_rng(0)
+    low = (128 + rng.integers(-9, 10, (352, 1024))).astype(np.uint8)
+    _compare(oracle, low)
+    kp, d = ex(np.zeros((0, 0), np.uint8))
+    assert len(kp) == 0
+
+
+def test_stereo_matches(oracle):
+    L, R = synthetic_stereo(21, disparity=8)
+    eo_l, eo_r = oracle.OrbExtractor(), oracle.OrbExtractor()
+    kl, dl = eo_l(L); kr, dr = eo_r(R)
+    bf, b = 386.1448, 386.1448 / 718.856
+    pyrL = [eo_l.level(l) for l in range(8)]; pyrR = [eo_r.level(l) for l in range(8)]
+    uR_o, depth_o, best_o, kept = oracle.stereo_matches(kl, dl, kr, dr, eo_l.scale, eo_l.inv_scale, pyrL, pyrR, bf, b)
+    eg_l, eg_r = orb.ORBextractor(), orb.ORBextractor()
+    kgl, dgl = eg_l(L); kgr, dgr = eg_r(R)
+    assert kgl.tobytes() == kl.tobytes() and kgr.tobytes() == kr.tobytes()
+    uR, depth, best = orb.stereo_match(eg_l, eg_r, kgl, dgl, kgr, dgr, bf, b)
+    assert np.array_equal(best, best_o)
+    assert np.array_equal(uR.view(np.uint32), uR_o.view(np.uint32))
+    assert np.array_equal(depth.view(np.uint32), depth_o.view(np.uint32))
+    assert kept > 200 and abs(np.median((kl["x"] - uR)[uR >= 0]) - 8) < 0.5

@@ -1,0 +1,175 @@
+"""GPU parity of the Bayesian SegNet path against the CPU oracle (through the C ABI).
+
+Tolerances: logits max-abs 1e-3 (BASELINE.json north_star: "segmentation logits within
+1e-3 fp32"); probabilities / confidence / entropy 1e-5 (fp32 softmax, expf 1-ulp
+differences between libm and the device); classes exact except where the top-2 mean
+probabilities are closer than 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import prototxt as oproto
+from sivo_amd import netspec, weights as wts
+from sivo_amd.segnet import BayesianSegNet, mc_finalize, mc_reduce, mc_variance
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-3
+
+
+def _make(text, T, seed=42):
+    net = oproto.parse(text)
+    w = wts.synth_weights(net["layers"], seed)
+    flat = wts.pack(net["layers"], w)
+    return net, w, BayesianSegNet(prototxt=text, weights=flat, T=T)
+
+
+def _image(rng, H, W):
+    return rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+
+
+def _check_outputs(oracle, res, cls, conf, ent, prob_sum, T):
+    mean = res["mean"]
+    np.testing.assert_allclose(prob_sum / T, mean, atol=1e-5, rtol=0)
+    np.testing.assert_allclose(conf, res["confidence"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(ent, res["entropy"], atol=2e-4, rtol=0)
+    srt = np.sort(mean, axis=0)
+    decided = (srt[-1] - srt[-2]) > 1e-5
+    assert (cls[decided] == res["classes"][decided]).all()
+    assert decided.mean() > 0.99
+
+
+def test_tiny_net_every_blob(oracle):
+    T, H, W = 3, 32, 64
+    text = netspec.tiny_prototxt(T, H, W)
+    net, w, sn = _make(text, T)
+    rng = np.random.default_rng(0)
+    img = _image(rng, H, W)
+    seed = 7
+    blob = oracle.preprocess(img, T, H, W)
+    ob = oracle.run_net(net, w, blob, seed)
+    d_img = torch.from_numpy(img).cuda()
+    prob_sum, logits, prob = sn.forward(d_img, seed, want_logits=True, want_prob=True)
+    torch.cuda.synchronize()
+    # intermediate blobs (shared ones are stored once on the device)
+    for name in ["norm", "c1", "p1", "p1_mask", "c2", "p2", "p2_mask", "p2_D", "d2", "p1_D", "d1", "cls"]:
+        g = sn.blob(name)
+        o = ob[name].astype(np.float32)
+        if g.shape[0] == 1 and o.shape[0] > 1:
+            assert np.array_equal(o[0], o[1]) or name in ("p2",), name
+            o = o[:1]
+        if name.endswith("_mask"):
+            assert np.array_equal(g, o), name
+        else:
+            np.testing.assert_allclose(g, o, atol=LOGIT_TOL, rtol=0, err_msg=name)
+    np.testing.assert_allclose(logits.cpu().numpy(), ob["cls"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(prob.cpu().numpy(), ob["__last__"], atol=1e-5, rtol=0)
+    cls, conf, ent = sn.finalize(prob_sum)
+    res = {"mean": oracle.mc_mean(ob["__last__"])}
+    res["classes"], res["confidence"], res["entropy"] = oracle.mc_finalize(res["mean"])
+    _check_outputs(oracle, res, cls.cpu().numpy(), conf.cpu().numpy(), ent.cpu().numpy(), prob_sum.cpu().numpy(), T)
+
+
+def test_dropout_masks_bit_exact(oracle):
+    """Every dropout site: the zero pattern of the device blob equals the oracle's Philox mask."""
+    T, H, W = 4, 32, 64
+    text = netspec.tiny_prototxt(T, H, W)
+    net, w, sn = _make(text, T)
+    img = _image(np.random.default_rng(1), H, W)
+    ob = oracle.run_net(net, w, oracle.preprocess(img, T, H, W), 1234567890123, sample0=5)
+    sn.forward(torch.from_numpy(img).cuda(), 1234567890123, sample0=5)
+    torch.cuda.synchronize()
+    for name in ["p2", "d2"]:
+        g, o = sn.blob(name), ob[name]
+        assert np.array_equal(g == 0, o == 0), name
+        assert 0.3 < (o == 0).mean() < 0.9
+
+
+@pytest.mark.parametrize("kind", ["basic", "standard"])
+def test_reference_nets_reduced_geometry(oracle, kind):
+    """The two reference architectures at full width, reduced image size (oracle runs in seconds)."""
+    T, H, W = 2, 32, 64
+    text = netspec.basic_prototxt(T, H, W) if kind == "basic" else netspec.standard_prototxt(T, H, W)
+    net, w, sn = _make(text, T)
+    img = _image(np.random.default_rng(2), H, W)
+    seed = 99
+    logits_name = "dense_softmax_inner_prod" if kind == "basic" else "conv1_1_D"
+    res = oracle.segment(net, w, img, seed, logits_name=logits_name)
+    prob_sum, logits, _ = sn.forward(torch.from_numpy(img).cuda(), seed, want_logits=True)
+    cls, conf, ent = sn.finalize(prob_sum)
+    torch.cuda.synchronize()
+    lg = logits.cpu().numpy()
+    assert np.abs(res["logits"]).max() > 0.1            # the comparison is not vacuous
+    np.testing.assert_allclose(lg, res["logits"], atol=LOGIT_TOL, rtol=0)
+    _check_outputs(oracle, res, cls.cpu().numpy(), conf.cpu().numpy(), ent.cpu().numpy(), prob_sum.cpu().numpy(), T)
+
+
+def test_sample_sharding_matches_single_pass(oracle):
+    """Samples {0,1} + {2,3} computed separately sum to the 4-sample pass (multi-GPU partitioning)."""
+    T, H, W = 4, 32, 64
+    text = netspec.tiny_prototxt(T, H, W)
+    net, w, sn = _make(text, T)
+    d_img = torch.from_numpy(_image(np.random.default_rng(3), H, W)).cuda()
+    full, lg_full, _ = sn.forward(d_img, 11, want_logits=True)
+    a, lg_a, _ = sn.forward(d_img, 11, n_samples=2, sample0=0, want_logits=True)
+    b, lg_b, _ = sn.forward(d_img, 11, n_samples=2, sample0=2, want_logits=True)
+    torch.cuda.synchronize()
+    assert torch.equal(lg_full[:2], lg_a) and torch.equal(lg_full[2:], lg_b)
+    np.testing.assert_allclose((a + b).cpu().numpy(), full.cpu().numpy(), atol=1e-6, rtol=0)
+
+
+def test_segment_image_host_entry_and_crop(oracle, kitti_like_bgr):
+    """segmentImage on a larger frame: centre crop (resizeImage) then the full path."""
+    T, H, W = 2, 32, 64
+    text = netspec.tiny_prototxt(T, H, W)
+    net, w, sn = _make(text, T)
+    big = np.ascontiguousarray(kitti_like_bgr[:100, :200])
+    cls, conf, ent = sn.segment_image(big, seed=5)
+    res = oracle.segment(net, w, big, 5)
+    np.testing.assert_allclose(conf, res["confidence"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(ent, res["entropy"], atol=2e-4, rtol=0)
+    assert (cls == res["classes"]).mean() > 0.99
+    from sivo_amd._lib import SivoError
+    with pytest.raises(SivoError):
+        sn.segment_image(big[:16, :16], seed=5)          # smaller than the net geometry
+
+
+def test_mc_reduce_finalize_known_answers(oracle):
+    K, H, W = 15, 8, 16
+    # uniform logits -> p = 1/15 everywhere -> entropy log2(15) bits, class 0 (first index wins ties)
+    lg = torch.zeros((2, K, H, W), device="cuda")
+    ps, _ = mc_reduce(lg)
+    cls, conf, ent = mc_finalize(ps, 2)
+    assert (cls == 0).all()
+    np.testing.assert_allclose(conf.cpu().numpy(), 1 / 15, atol=1e-7)
+    np.testing.assert_allclose(ent.cpu().numpy(), np.log2(15), atol=1e-6)
+    # one-hot (huge margin) -> entropy 0 with the exact-zero guard, confidence 1
+    lg = torch.full((3, K, H, W), -1000.0, device="cuda"); lg[:, 4] = 1000.0
+    ps, _ = mc_reduce(lg)
+    cls, conf, ent = mc_finalize(ps, 3)
+    assert (cls == 4).all() and (conf == 1).all() and (ent == 0).all()
+
+
+@pytest.mark.parametrize("T,K,H,W", [(2, 15, 5, 7), (6, 15, 16, 32), (12, 15, 44, 128), (3, 11, 9, 10)])
+def test_mc_reduce_random(oracle, T, K, H, W):
+    rng = np.random.default_rng(T * 100 + K)
+    lg = (rng.standard_normal((T, K, H, W)) * 4).astype(np.float32)
+    prob_o = oracle.softmax(lg)
+    mean_o = oracle.mc_mean(prob_o)
+    cls_o, conf_o, ent_o = oracle.mc_finalize(mean_o)
+    d = torch.from_numpy(lg).cuda()
+    ps, prob = mc_reduce(d, want_prob=True)
+    cls, conf, ent = mc_finalize(ps, T)
+    np.testing.assert_allclose(prob.cpu().numpy(), prob_o, atol=2e-7, rtol=0)
+    np.testing.assert_allclose(ps.cpu().numpy() / T, mean_o, atol=1e-6, rtol=0)
+    np.testing.assert_allclose(conf.cpu().numpy(), conf_o, atol=1e-6, rtol=0)
+    np.testing.assert_allclose(ent.cpu().numpy(), ent_o, atol=2e-5, rtol=0)
+    srt = np.sort(mean_o, axis=0)
+    decided = (srt[-1] - srt[-2]) > 1e-6
+    assert (cls.cpu().numpy()[decided] == cls_o[decided]).all()
+    # accumulate flag: two halves add up
+    if T % 2 == 0:
+        ps2, _ = mc_reduce(d[:T // 2])
+        mc_reduce(d[T // 2:], prob_sum=ps2, accumulate=True)
+        np.testing.assert_allclose(ps2.cpu().numpy(), ps.cpu().numpy(), atol=1e-6, rtol=0)
+    var = mc_variance(prob, cls)
+    np.testing.assert_allclose(var.cpu().numpy(), oracle.mc_variance(prob_o, cls.cpu().numpy()), atol=1e-7, rtol=0)
