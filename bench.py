@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of SIVO's per-frame perception path on MI355X.
+
+A "step" is one stereo frame through the hot path (BASELINE.json configs[2]):
+  SegNet-Standard forward for T=12 Monte-Carlo dropout samples at 352x1024 (fp32 MFMA)
+  -> per-pixel softmax sum -> [RCCL all-reduce when N > 1] -> mean / class / confidence / entropy maps
+  ORB 2000 x 8 levels on the left and right images, semantic key filter (class <= TERRAIN),
+  stereo matching (Hamming + SAD)                                   [rank 0, overlapped on its own streams]
+All inputs are resident in HBM before the timed region starts.
+
+Multi-GPU (one process per GPU, torch.distributed over RCCL): the T samples of a frame are
+sharded over the ranks (global sample index keys the dropout masks, so the result does not
+depend on N), each rank recomputes the sample-invariant prefix, one all-reduce(SUM) of the
+15x352x1024 fp32 probability sums per frame.  T is fixed -> "scaling": "strong".
+
+Prints ONE JSON line (rank 0).  `roofline`: the dominant kernel (the convolution
+instantiation with the largest share of GPU time), algorithmic FLOPs per launch / mean
+launch duration measured with HIP events on the launch stream during the timed region,
+against the dense fp32 MFMA peak (157.3 TFLOP/s).  `cpu_baseline`: this repo's CPU oracle
+(a restatement of the reference path — not Caffe/cuDNN/OpenCV, which are unavailable)
+timed on the host cores for a bounded sample and extrapolated to the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_frame(seed, rows=352, cols=1024):
+    rng = np.random.default_rng(seed)
+    img = np.full((rows, cols), 90.0)
+    for _ in range(40):
+        x0, x1 = sorted(rng.integers(0, cols, 2)); y0, y1 = sorted(rng.integers(0, rows, 2))
+        img[y0:y1 + 1, x0:x1 + 1] = rng.integers(0, 256)
+    img += rng.normal(0, 4, img.shape)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def make_inputs(H, W):
+    """Synthetic KITTI-shaped stereo pair: left gray + 8 px disparity right, colour left for the net."""
+    wide = synthetic_frame(1234, H, W + 64)
+    left = np.ascontiguousarray(wide[:, :W])
+    rng = np.random.default_rng(4321)
+    right = np.clip(np.rint(wide[:, 8:8 + W].astype(np.float64) + rng.normal(0, 1.0, (H, W))), 0, 255).astype(np.uint8)
+    bgr = np.stack([left, np.roll(left, 1, 1), np.roll(left, 1, 0)], axis=2)
+    return np.ascontiguousarray(bgr), left, right
+
+
+def cpu_baseline(kind, T, H, W, text, w, bgr, left, right, budget_note):
+    """Oracle on the host cores: prefix once + ONE MC sample of the suffix + ORB pair + MC reduction
+    of 2 samples, extrapolated to T samples per frame."""
+    from oracle import oracle as O, prototxt as oproto
+    net = oproto.parse(text)
+    net["shape"][0] = 1
+    first_drop = next(i for i, L in enumerate(net["layers"]) if L["type"] == "Dropout")
+    prefix = dict(net, layers=net["layers"][:first_drop])
+    blob = O.preprocess(bgr, 1, H, W)
+    t0 = time.perf_counter()
+    pb = O.run_net(prefix, w, blob, 7, keep=[L["top"][j] for L in prefix["layers"] for j in range(len(L["top"]))])
+    t_prefix = time.perf_counter() - t0
+    # suffix on one sample, re-using the prefix blobs
+    t0 = time.perf_counter()
+    blobs = {k: v for k, v in pb.items() if k != "__last__"}
+    site = 0
+    last = None
+    for L in net["layers"][first_drop:]:
+        t = L["type"]; bot = [blobs[b] for b in L["bottom"]]
+        if t == "Convolution": out = O.conv2d(bot[0], *w[L["name"]], L["pad"])
+        elif t == "BN": out = O.bn_inference(bot[0], *w[L["name"]])
+        elif t == "ReLU": out = O.relu(bot[0])
+        elif t == "Pooling":
+            out, m = O.maxpool(bot[0]); blobs[L["top"][1]] = m
+        elif t == "Upsample": out = O.unpool(bot[0], bot[1], bot[0].shape[2] * 2, bot[0].shape[3] * 2)
+        elif t == "Dropout":
+            out = O.dropout(bot[0], site, 0, 7); site += 1
+        elif t == "LRN": out = O.lrn(bot[0], L["local_size"], L["alpha"], L["beta"])
+        elif t == "Softmax": out = O.softmax(bot[0])
+        blobs[L["top"][0]] = out; last = out
+    t_suffix = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    prob2 = np.concatenate([last, last])
+    O.mc_finalize(O.mc_mean(prob2))
+    t_mc = (time.perf_counter() - t0) * T / 2
+    t0 = time.perf_counter()
+    ex_l, ex_r = O.OrbExtractor(), O.OrbExtractor()
+    res = {}
+    th = [threading.Thread(target=lambda k=k, e=e, im=im: res.__setitem__(k, e(im))) for k, e, im in (("l", ex_l, left), ("r", ex_r, right))]
+    [t.start() for t in th]; [t.join() for t in th]        # Frame.cc:126-129: two extractor threads
+    kl, dl = res["l"]; kr, dr = res["r"]
+    O.stereo_matches(kl, dl, kr, dr, ex_l.scale, ex_l.inv_scale, [ex_l.level(l) for l in range(8)],
+                     [ex_r.level(l) for l in range(8)], 386.1448, 386.1448 / 718.856)
+    t_orb = time.perf_counter() - t0
+    frame = t_prefix + T * t_suffix + t_mc + t_orb
+    return {"value": 1.0 / frame, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": (f"CPU oracle (C, OpenMP over {os.cpu_count()} cores; a restatement of the reference path, not Caffe/OpenCV): "
+                       f"prefix once {t_prefix:.2f}s + 1 of {T} MC samples of the suffix {t_suffix:.2f}s (x{T} extrapolated) + "
+                       f"MC reduction {t_mc:.2f}s + ORB stereo pair and matching {t_orb:.2f}s on {kind} {H}x{W}")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--T", type=int, default=12, help="Monte-Carlo samples per frame (12 = BASELINE configs[2], 48 = configs[3])")
+    ap.add_argument("--net", default="standard", choices=["standard", "basic"])
+    ap.add_argument("--height", type=int, default=352)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--no-orb", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from sivo_amd import netspec, orb, weights as wts
+    from sivo_amd._lib import require_gpu
+    from sivo_amd.segnet import BayesianSegNet
+    from oracle import prototxt as oproto    # used only to size the synthetic weights + cpu_baseline leg
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    require_gpu()
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    T, H, W = args.T, args.height, args.width
+    # contiguous shard of the T samples: the first T % world ranks take one extra
+    base, extra = divmod(T, world)
+    n_local = base + (1 if rank < extra else 0)
+    sample0 = rank * base + min(rank, extra)
+    t_alloc = max(2, base + (1 if extra else 0))
+    text = (netspec.standard_prototxt if args.net == "standard" else netspec.basic_prototxt)(t_alloc, H, W)
+    layers = oproto.parse(text)["layers"]
+    w = wts.synth_weights(layers, 42)
+    sn = BayesianSegNet(prototxt=text, weights=wts.pack(layers, w), T=t_alloc, device=local)
+
+    bgr, left, right = make_inputs(H, W)
+    d_bgr = torch.from_numpy(bgr).cuda()
+    d_left = torch.from_numpy(left).cuda()
+    d_right = torch.from_numpy(right).cuda()
+    prob_sum = torch.zeros((sn.classes, H, W), dtype=torch.float32, device="cuda")
+    maps = (torch.empty((H, W), dtype=torch.uint8, device="cuda"), torch.empty((H, W), dtype=torch.float64, device="cuda"),
+            torch.empty((H, W), dtype=torch.float64, device="cuda"))
+    do_orb = (rank == 0) and not args.no_orb
+    if do_orb:
+        ex_l, ex_r = orb.ORBextractor(device=local), orb.ORBextractor(device=local)
+    stats = {"kps": 0, "matches": 0}
+
+    def orb_side(cls_host):
+        res = {}
+        th = [threading.Thread(target=lambda k=k, e=e, im=im: res.__setitem__(k, e(im)))
+              for k, e, im in (("l", ex_l, d_left), ("r", ex_r, d_right))]
+        [t.start() for t in th]; [t.join() for t in th]
+        (kl, dl), (kr, dr) = res["l"], res["r"]
+        # SelectSemanticKeys (Frame.cc:177-203): class <= TERRAIN(8) at the truncated keypoint position
+        if cls_host is not None:
+            keep = cls_host[kl["y"].astype(np.int32), kl["x"].astype(np.int32)] <= 8
+            kl, dl = kl[keep], dl[keep]
+        uR, depth, _ = orb.stereo_match(ex_l, ex_r, kl, dl, kr, dr, 386.1448, 386.1448 / 718.856)
+        stats["kps"], stats["matches"] = len(kl), int((uR >= 0).sum())
+
+    cls_prev = [None]
+
+    def frame(seed):
+        # ORB + stereo of this frame run on their own streams/threads beside the network; the
+        # semantic filter uses the class map as soon as it exists (previous frame's for overlap
+        # would change semantics, so the ORB side joins after finalize of THIS frame).
+        sn.forward_into(d_bgr, seed, prob_sum, n_samples=n_local, sample0=sample0)
+        if world > 1:
+            dist.all_reduce(prob_sum)
+        sn.finalize(prob_sum, t_total=T, out=maps)
+        if do_orb:
+            ev = torch.cuda.Event(); ev.record()
+            cls_host = maps[0].cpu().numpy()       # 360 KB D2H, syncs this stream
+            orb_side(cls_host)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        frame(1000 + i)
+    barrier()
+    sn.profile(True, reset=True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        frame(2000 + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = sn.profile_read()
+    sn.profile(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        fps = args.steps / elapsed
+        # per-kernel aggregation of the event-timed launches
+        by_kernel = {}
+        for p in prof:
+            k = by_kernel.setdefault(p["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+            k["ms"] += p["ms_total"]; k["launches"] += p["launches"]
+            k["flops"] += p["flops_per_sample"] * p["samples"] * p["launches"]
+            k["bytes"] += p["bytes_per_sample"] * p["samples"] * p["launches"]
+        conv = {k: v for k, v in by_kernel.items() if k.startswith("conv_mfma")}
+        dom_name, dom = max(conv.items(), key=lambda kv: kv[1]["ms"])
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        conv_ms = sum(v["ms"] for v in conv.values()); conv_fl = sum(v["flops"] for v in conv.values())
+        all_ms = sum(v["ms"] for v in by_kernel.values())
+        roofline = {"bound": "mfma", "kernel": "sivo::" + dom_name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_frame": dom["launches"] / args.steps,
+                    "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
+                    "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
+                    "all_conv": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "ms_per_frame": round(conv_ms / args.steps, 3),
+                                 "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
+                    "kernels_ms_per_frame": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(by_kernel.items())},
+                    "segnet_kernel_ms_per_frame": round(all_ms / args.steps, 3)}
+        out = {"metric": "frames/sec, SIVO per-frame path (ORB+SegNet T=%d+entropy) %dx%d" % (T, H, W),
+               "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"full per-frame path: ORB 2000x8 stereo + SegNet-{args.net} T={T} MC-dropout + entropy maps + semantic key filter + stereo match, {H}x{W}, synthetic stereo pair, seeded random weights",
+                          "T": T, "samples_per_rank": [base + (1 if r < extra else 0) for r in range(world)],
+                          "orb": bool(do_orb), "semantic_keys": stats["kps"], "stereo_matches": stats["matches"],
+                          "algorithmic_gflop_per_frame": round((sn.flops_shared + T * sn.flops_per_sample) / 1e9, 2),
+                          "reference_equivalent_gflop_per_frame": round(T * (sn.flops_shared + sn.flops_per_sample) / 1e9, 2)},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.net, T, H, W, text, w, bgr, left, right, "")
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,21 @@ int sivo_segnet_blob(sivo_segnet_t h, const char *name, float *host_out, size_t 
  * the sample-invariant prefix, per_sample = the rest. */
 int sivo_segnet_flops(sivo_segnet_t h, double *shared, double *per_sample);
 
+/* Per-layer timing with HIP events recorded on the launch stream around every
+ * kernel of the forward (enable: 0 off, 1 on, 2 on + reset).  Timings are
+ * harvested lazily (at the next forward or at profile_read). */
+typedef struct {
+    char layer[64];          /* prototxt layer name of the (fused) op */
+    char kernel[96];         /* kernel symbol as rocprofv3 --kernel-trace prints it (sivo:: prefix omitted) */
+    int32_t samples;         /* batch of the last launch: 1 for the shared prefix, n_samples otherwise */
+    int32_t launches;
+    double flops_per_sample; /* algorithmic FLOPs of one sample (convolutions; 0 otherwise) */
+    double bytes_per_sample; /* algorithmic HBM bytes of one sample */
+    double ms_total;         /* sum of the event-timed durations of all harvested launches */
+} SivoOpProfile;
+int sivo_segnet_profile(sivo_segnet_t h, int enable);
+int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int capacity, int *n_out);
+
 /* ===========================================================================
  * ORB extractor — stands behind SIVO::ORBextractor
  * (reference include/orbslam/ORBextractor.h:46-123, src/orbslam/ORBextractor.cc).

@@ -28,6 +28,11 @@ class KeyPoint(C.Structure):  # == cv::KeyPoint / SivoKeyPoint (28 bytes)
                 ("response", C.c_float), ("octave", C.c_int32), ("class_id", C.c_int32)]
 
 
+class OpProfile(C.Structure):  # == SivoOpProfile
+    _fields_ = [("layer", C.c_char * 64), ("kernel", C.c_char * 96), ("samples", C.c_int32), ("launches", C.c_int32),
+                ("flops_per_sample", C.c_double), ("bytes_per_sample", C.c_double), ("ms_total", C.c_double)]
+
+
 class Edge(C.Structure):      # == SivoEdge (48 bytes)
     _fields_ = [("pose", C.c_int32), ("point", C.c_int32), ("stereo", C.c_int32), ("pad_", C.c_int32),
                 ("obs", C.c_double * 3), ("inv_sigma2", C.c_double)]
@@ -52,6 +57,8 @@ SIGNATURES = {
     "sivo_segnet_segment": [_vp, _vp, _i, _i, _u64, _vp, _vp, _vp],
     "sivo_segnet_blob": [_vp, C.c_char_p, _vp, _sz, _pi32],
     "sivo_segnet_flops": [_vp, C.POINTER(_d), C.POINTER(_d)],
+    "sivo_segnet_profile": [_vp, _i],
+    "sivo_segnet_profile_read": [_vp, _vp, _i, _pi32],
     "sivo_orb_create": [_i, _f, _i, _i, _i, _i, C.POINTER(_vp)],
     "sivo_orb_destroy": [_vp],
     "sivo_orb_tables": [_vp, _vp, _vp, _vp, _vp, _vp],

@@ -53,6 +53,11 @@ struct Op {
     int local_size = 5;
     float alpha = 0.f, beta = 0.f;
     double flops = 0.0;
+    // profiling (sivo_segnet_profile): HIP events bracket the launch on the launch stream
+    std::string name, kernel;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double ms_total = 0.0, bytes = 0.0;
+    int launches = 0, last_n = 0;
 };
 
 }  // namespace
@@ -72,8 +77,13 @@ struct sivo_segnet {
     double *d_conf = nullptr, *d_ent = nullptr;
     hipStream_t stream = nullptr;   // for the host-level entry point
     double flops_shared = 0.0, flops_sample = 0.0;
+    bool profile = false, pending = false;
     std::vector<void *> owned;
     ~sivo_segnet() {
+        for (sivo::Op &op : ops) {
+            if (op.ev0) (void)hipEventDestroy(op.ev0);
+            if (op.ev1) (void)hipEventDestroy(op.ev1);
+        }
         for (void *p : owned) (void)hipFree(p);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -191,6 +201,16 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             upload_conv(S, op, weights + woff, weights + woff + nw);
             woff += nw + op.cout;
             op.flops = 2.0 * op.ks * op.ks * op.cin * op.cout * (double)b.H * b.W;
+            op.name = L.name;
+            {
+                char kn[96];
+                const int bn = conv_cout_tile(op.ks, op.cout), kc = conv_k_chunk(op.ks, op.cin);
+                snprintf(kn, sizeof kn, "conv_mfma_kernel<%d,%d,32,%d,%d,%d,%d>", op.ks, bn == 128 ? 4 : 8, bn, kc,
+                         bn == 128 ? 2 : 4, bn == 128 ? 2 : 1);
+                op.kernel = kn;
+            }
+            // algorithmic HBM bytes: input + output activations once, weights once
+            op.bytes = 4.0 * ((double)b.C * b.H * b.W + (double)op.cout * b.H * b.W + (double)nw);
             S.ops.push_back(op);
             absorber[op.out] = (int)S.ops.size() - 1;
         } else if (L.type == "BN") {
@@ -220,6 +240,8 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             op.out = new_blob(S, L.top[0], b.C, Ho, Wo, b.shared);
             op.out2 = new_blob(S, L.top[1], b.C, Ho, Wo, b.shared, true);
             S.blobs[op.out2].src_W = b.W;
+            op.name = L.name; op.kernel = "maxpool2_kernel";
+            op.bytes = 4.0 * b.C * b.H * b.W + 5.0 * b.C * Ho * Wo;
             S.ops.push_back(op);
             absorber.erase(bi);
             absorber[op.out] = (int)S.ops.size() - 1;
@@ -242,6 +264,7 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
                 op.kind = OP_DROPOUT; op.in = bi; op.drop_site = my_site;
                 const Blob b = S.blobs[bi];
                 op.out = new_blob(S, L.top[0], b.C, b.H, b.W, false);
+                op.name = L.name; op.kernel = "dropout_kernel"; op.bytes = 8.0 * b.chw();
                 S.ops.push_back(op);
             }
             absorber.erase(bi);
@@ -254,6 +277,7 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             Op op;
             op.kind = OP_UNPOOL; op.in = bi; op.in2 = mi;
             op.out = new_blob(S, L.top[0], b.C, b.H * 2, b.W * 2, b.shared && m.shared);
+            op.name = L.name; op.kernel = "unpool2_kernel"; op.bytes = 5.0 * b.chw() + 16.0 * b.chw();
             S.ops.push_back(op);
             absorber.erase(bi);
         } else if (L.type == "LRN") {
@@ -262,6 +286,7 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             Op op;
             op.kind = OP_LRN; op.in = bi; op.local_size = L.local_size; op.alpha = L.alpha; op.beta = L.beta;
             op.out = new_blob(S, L.top[0], b.C, b.H, b.W, b.shared);
+            op.name = L.name; op.kernel = "lrn_kernel"; op.bytes = 8.0 * b.chw();
             S.ops.push_back(op);
         } else if (L.type == "Softmax") {
             S.has_softmax = true;
@@ -300,14 +325,33 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
     return Sp;
 }
 
+void harvest(sivo_segnet &S) {
+    if (!S.pending) return;
+    for (Op &op : S.ops) {
+        if (!op.ev1) continue;
+        SIVO_HIP(hipEventSynchronize(op.ev1));
+        float ms = 0.f;
+        SIVO_HIP(hipEventElapsedTime(&ms, op.ev0, op.ev1));
+        op.ms_total += ms;
+        op.launches += 1;
+    }
+    S.pending = false;
+}
+
 void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t seed, float *d_prob_sum,
              float *d_logits, float *d_prob, hipStream_t st) {
     const int64_t hw = (int64_t)S.H * S.W;
+    if (S.profile) harvest(S);
     launch_preprocess(d_bgr, (float *)S.blobs[S.input_blob].d, hw, st);
-    for (const Op &op : S.ops) {
+    for (Op &op : S.ops) {
         const Blob &bi = S.blobs[op.in];
         const Blob &bo = S.blobs[op.out];
         const int N = bo.shared ? 1 : n;
+        if (S.profile) {
+            if (!op.ev0) { SIVO_HIP(hipEventCreate(&op.ev0)); SIVO_HIP(hipEventCreate(&op.ev1)); }
+            SIVO_HIP(hipEventRecord(op.ev0, st));
+            op.last_n = N;
+        }
         switch (op.kind) {
             case OP_CONV: {
                 ConvArgs a{};
@@ -348,7 +392,9 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
                            op.beta, st);
                 break;
         }
+        if (S.profile) SIVO_HIP(hipEventRecord(op.ev1, st));
     }
+    if (S.profile) S.pending = true;
     const Blob &lg = S.blobs[S.logits_blob];
     if (lg.shared) throw std::runtime_error("the network has no test-time dropout: nothing to sample");
     launch_mc_reduce((const float *)lg.d, n, S.classes, hw, d_prob_sum, d_prob, 0, st);
@@ -527,6 +573,42 @@ extern "C" int sivo_segnet_blob(sivo_segnet_t h, const char *name, float *host_o
             SIVO_HIP(hipFree(tmp));
         } else {
             SIVO_HIP(hipMemcpy(host_out, b.d, n * sizeof(float), hipMemcpyDeviceToHost));
+        }
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_segnet_profile(sivo_segnet_t h, int enable) {
+    return guarded([&] {
+        if (!h) throw std::invalid_argument("null handle");
+        DeviceGuard dg(h->device);
+        if (h->profile) harvest(*h);
+        h->profile = enable != 0;
+        if (enable == 2)   // reset the accumulators
+            for (Op &op : h->ops) { op.ms_total = 0.0; op.launches = 0; }
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int capacity, int *n_out) {
+    return guarded([&] {
+        if (!h || !n_out) throw std::invalid_argument("null argument");
+        DeviceGuard dg(h->device);
+        harvest(*h);
+        *n_out = (int)h->ops.size();
+        if (!out) return SIVO_OK;
+        if (capacity < *n_out) return fail(SIVO_ERR_CAPACITY, "%d ops, capacity %d", *n_out, capacity);
+        for (size_t i = 0; i < h->ops.size(); ++i) {
+            const Op &op = h->ops[i];
+            SivoOpProfile &p = out[i];
+            std::memset(&p, 0, sizeof p);
+            std::snprintf(p.layer, sizeof p.layer, "%s", op.name.c_str());
+            std::snprintf(p.kernel, sizeof p.kernel, "%s", op.kernel.c_str());
+            p.samples = op.last_n;
+            p.flops_per_sample = op.flops;
+            p.bytes_per_sample = op.bytes;
+            p.ms_total = op.ms_total;
+            p.launches = op.launches;
         }
         return SIVO_OK;
     });

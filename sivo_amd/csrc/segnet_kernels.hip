@@ -221,7 +221,7 @@ int conv_k_chunk(int ks, int cin) {
 void launch_conv(const ConvArgs &a, int ks, hipStream_t s) {
     const int bn = conv_cout_tile(ks, a.Cout), kc = conv_k_chunk(ks, a.Cin);
     if (ks == 3) {
-        if (bn == 16) return launch_conv_cfg<3, 8, 32, 16, 8, 4, 1>(a, s);
+        if (bn == 16) return kc == 4 ? launch_conv_cfg<3, 8, 32, 16, 4, 4, 1>(a, s) : launch_conv_cfg<3, 8, 32, 16, 8, 4, 1>(a, s);
         if (bn == 64 && kc == 4) return launch_conv_cfg<3, 8, 32, 64, 4, 4, 1>(a, s);
         if (bn == 64) return launch_conv_cfg<3, 8, 32, 64, 8, 4, 1>(a, s);
         if (kc == 4) return launch_conv_cfg<3, 4, 32, 128, 4, 2, 2>(a, s);

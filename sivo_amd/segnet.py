@@ -109,6 +109,20 @@ class BayesianSegNet:
                                         conf.ctypes.data_as(C.c_void_p), ent.ctypes.data_as(C.c_void_p)))
         return classes, conf, ent
 
+    def profile(self, enable=True, reset=False):
+        """Bracket every kernel of the forward with HIP events on its launch stream."""
+        check(lib().sivo_segnet_profile(self._h, 2 if (enable and reset) else int(bool(enable))))
+
+    def profile_read(self):
+        """List of dicts: layer, kernel, samples, launches, flops_per_sample, bytes_per_sample, ms_total."""
+        n = C.c_int32(0)
+        check(lib().sivo_segnet_profile_read(self._h, None, 0, C.byref(n)))
+        arr = (_lib.OpProfile * n.value)()
+        check(lib().sivo_segnet_profile_read(self._h, arr, n.value, C.byref(n)))
+        return [dict(layer=a.layer.decode(), kernel=a.kernel.decode(), samples=a.samples, launches=a.launches,
+                     flops_per_sample=a.flops_per_sample, bytes_per_sample=a.bytes_per_sample, ms_total=a.ms_total)
+                for a in arr]
+
     def blob(self, name):
         shape = (C.c_int32 * 4)()
         check(lib().sivo_segnet_blob(self._h, name.encode(), None, 0, shape))
