@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--no-orb", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-layer", action="store_true", help="print the per-layer event timings to stderr")
     args = ap.parse_args()
 
     import torch
@@ -214,6 +215,12 @@ def main():
     if rank == 0:
         fps = args.steps / elapsed
         # per-kernel aggregation of the event-timed launches
+        if args.per_layer:
+            for p in prof:
+                ms = p["ms_total"] / max(p["launches"], 1)
+                fl = p["flops_per_sample"] * p["samples"]
+                print(f'{p["layer"]:14s} {p["kernel"]:42s} N={p["samples"]:2d} {ms:8.4f} ms  {fl / ms / 1e9 if ms else 0:7.1f} TFLOP/s  '
+                      f'{p["bytes_per_sample"] * p["samples"] / ms / 1e6 if ms else 0:8.1f} GB/s(alg)', file=sys.stderr)
         by_kernel = {}
         for p in prof:
             k = by_kernel.setdefault(p["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})

@@ -109,29 +109,62 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // ---- staging plan (chunk invariant): which global elements this thread brings in.
+    // Loads of chunk k+1 are issued into registers BEFORE the MFMA phase of chunk k and land in
+    // LDS after it (one LDS buffer, two barriers per chunk), so HBM/L2 latency hides under MFMA.
+    constexpr int NPATCH = KC * PH * PW, PITER = (NPATCH + 255) / 256;
+    constexpr int V = BN / 4, NWV = KROWS * V, WITER = (NWV + 255) / 256;
+    int p_goff[PITER], p_dst[PITER];   // p_dst = LDS dword offset | channel-in-chunk << 24, or -1
+#pragma unroll
+    for (int it = 0; it < PITER; ++it) {
+        const int idx = tid + it * 256;
+        const int c = idx / (PH * PW), r = idx % (PH * PW);
+        const int py = r / PW, px = r % PW;
+        const int gy = y0 + py - PADK, gx = x0 + px - PADK;
+        const bool inb = idx < NPATCH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        p_goff[it] = inb ? (int)(c * plane + (int64_t)gy * a.W + gx) : -1;
+        p_dst[it] = idx < NPATCH ? ((c * CS + py * PW + px) | (c << 24)) : -1;
+    }
+    float pv[PITER];
+    f32x4 wv[WITER];
     const int nchunks = (a.Cin + KC - 1) / KC;
+
+    auto issue_loads = [&](int chunk) {
+        const float *psrc = in_n + (int64_t)chunk * KC * plane;
+        const int cleft = a.Cin - chunk * KC;   // channels of this chunk that exist
+#pragma unroll
+        for (int it = 0; it < PITER; ++it) {
+            const bool ok = p_goff[it] >= 0 && (p_dst[it] >> 24) < cleft;
+            const float v = psrc[ok ? p_goff[it] : 0];
+            pv[it] = ok ? v : 0.f;
+        }
+        const float *wsrc = a.wt + (int64_t)chunk * KROWS * a.CoutPad + n0;
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) {
+            const int idx = tid + it * 256;
+            const int row = idx / V, c4 = idx % V;
+            const bool ok = (NWV % 256 == 0) || idx < NWV;
+            wv[it] = *reinterpret_cast<const f32x4 *>(wsrc + (ok ? (int64_t)row * a.CoutPad + c4 * 4 : 0));
+        }
+    };
+    auto commit_loads = [&]() {
+#pragma unroll
+        for (int it = 0; it < PITER; ++it)
+            if (p_dst[it] >= 0) s_patch[p_dst[it] & 0xffffff] = pv[it];
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) {
+            const int idx = tid + it * 256;
+            const int row = idx / V, c4 = idx % V;
+            if ((NWV % 256 == 0) || idx < NWV) *reinterpret_cast<f32x4 *>(s_w + row * BNP + c4 * 4) = wv[it];
+        }
+    };
+
+    issue_loads(0);
+    commit_loads();
+    __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int c0 = chunk * KC;
-        // ---- stage the input halo patch (zero padding at the image border / past Cin)
-        for (int idx = tid; idx < KC * PH * PW; idx += 256) {
-            const int c = idx / (PH * PW), r = idx % (PH * PW);
-            const int py = r / PW, px = r % PW;
-            const int gy = y0 + py - PADK, gx = x0 + px - PADK, ch = c0 + c;
-            float v = 0.f;
-            if (ch < a.Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = in_n[ch * plane + (int64_t)gy * a.W + gx];
-            s_patch[c * CS + py * PW + px] = v;
-        }
-        // ---- stage the weight slab [KROWS][BN] (global layout [chunk][KROWS][CoutPad])
-        {
-            const float *wsrc = a.wt + (int64_t)chunk * KROWS * a.CoutPad + n0;
-            constexpr int V = BN / 4;
-            for (int idx = tid; idx < KROWS * V; idx += 256) {
-                const int row = idx / V, c4 = idx % V;
-                const float4 v = *reinterpret_cast<const float4 *>(wsrc + (int64_t)row * a.CoutPad + c4 * 4);
-                *reinterpret_cast<float4 *>(s_w + row * BNP + c4 * 4) = v;
-            }
-        }
-        __syncthreads();
+        const bool more = chunk + 1 < nchunks;
+        issue_loads(more ? chunk + 1 : chunk);   // unconditional (re-reads the last chunk once): keeps the staging registers out of scratch
         // ---- k*k taps x KC/4 MFMA k-steps
 #pragma unroll
         for (int tap = 0; tap < KS * KS; ++tap) {
@@ -151,6 +184,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             }
         }
         __syncthreads();
+        if (more) {
+            commit_loads();
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: lane holds pixels x..x+3 (rows 4*(lane>>4)+r of the m-tile) of channel n0+..+(lane&15)
