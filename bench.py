@@ -162,33 +162,32 @@ def main():
         ex_l, ex_r = orb.ORBextractor(device=local), orb.ORBextractor(device=local)
     stats = {"kps": 0, "matches": 0}
 
-    def orb_side(cls_host):
-        res = {}
+    def orb_extract(res):
+        # Frame.cc:126-129: two extractor threads; here they also overlap the network on the GPU
         th = [threading.Thread(target=lambda k=k, e=e, im=im: res.__setitem__(k, e(im)))
               for k, e, im in (("l", ex_l, d_left), ("r", ex_r, d_right))]
-        [t.start() for t in th]; [t.join() for t in th]
+        [t.start() for t in th]
+        return th
+
+    def orb_finish(res, cls_host):
         (kl, dl), (kr, dr) = res["l"], res["r"]
         # SelectSemanticKeys (Frame.cc:177-203): class <= TERRAIN(8) at the truncated keypoint position
-        if cls_host is not None:
-            keep = cls_host[kl["y"].astype(np.int32), kl["x"].astype(np.int32)] <= 8
-            kl, dl = kl[keep], dl[keep]
+        keep = cls_host[kl["y"].astype(np.int32), kl["x"].astype(np.int32)] <= 8
+        kl, dl = kl[keep], dl[keep]
         uR, depth, _ = orb.stereo_match(ex_l, ex_r, kl, dl, kr, dr, 386.1448, 386.1448 / 718.856)
         stats["kps"], stats["matches"] = len(kl), int((uR >= 0).sum())
 
-    cls_prev = [None]
-
     def frame(seed):
-        # ORB + stereo of this frame run on their own streams/threads beside the network; the
-        # semantic filter uses the class map as soon as it exists (previous frame's for overlap
-        # would change semantics, so the ORB side joins after finalize of THIS frame).
+        res = {}
+        th = orb_extract(res) if do_orb else []          # ORB of this frame runs beside the network
         sn.forward_into(d_bgr, seed, prob_sum, n_samples=n_local, sample0=sample0)
         if world > 1:
             dist.all_reduce(prob_sum)
         sn.finalize(prob_sum, t_total=T, out=maps)
         if do_orb:
-            ev = torch.cuda.Event(); ev.record()
-            cls_host = maps[0].cpu().numpy()       # 360 KB D2H, syncs this stream
-            orb_side(cls_host)
+            cls_host = maps[0].cpu().numpy()              # 360 KB D2H; waits for this frame's class map
+            [t.join() for t in th]
+            orb_finish(res, cls_host)
 
     def barrier():
         torch.cuda.synchronize()
