@@ -123,7 +123,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from sivo_amd import netspec, orb, weights as wts
+    from sivo_amd import netspec, orb, parallel, weights as wts
     from sivo_amd._lib import require_gpu
     from sivo_amd.segnet import BayesianSegNet
     from oracle import prototxt as oproto    # used only to size the synthetic weights + cpu_baseline leg
@@ -141,10 +141,8 @@ def main():
 
     T, H, W = args.T, args.height, args.width
     # contiguous shard of the T samples: the first T % world ranks take one extra
-    base, extra = divmod(T, world)
-    n_local = base + (1 if rank < extra else 0)
-    sample0 = rank * base + min(rank, extra)
-    t_alloc = max(2, base + (1 if extra else 0))
+    sample0, n_local = parallel.shard_samples(T, world, rank)
+    t_alloc = max(2, parallel.max_shard(T, world))
     text = (netspec.standard_prototxt if args.net == "standard" else netspec.basic_prototxt)(t_alloc, H, W)
     layers = oproto.parse(text)["layers"]
     w = wts.synth_weights(layers, 42)
@@ -180,9 +178,11 @@ def main():
     def frame(seed):
         res = {}
         th = orb_extract(res) if do_orb else []          # ORB of this frame runs beside the network
-        sn.forward_into(d_bgr, seed, prob_sum, n_samples=n_local, sample0=sample0)
-        if world > 1:
-            dist.all_reduce(prob_sum)
+        if n_local:
+            sn.forward_into(d_bgr, seed, prob_sum, n_samples=n_local, sample0=sample0)
+        else:
+            prob_sum.zero_()                               # more ranks than samples: contribute nothing
+        parallel.all_reduce_prob_sum(prob_sum)
         sn.finalize(prob_sum, t_total=T, out=maps)
         if do_orb:
             cls_host = maps[0].cpu().numpy()              # 360 KB D2H; waits for this frame's class map
@@ -245,7 +245,7 @@ def main():
                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"full per-frame path: ORB 2000x8 stereo + SegNet-{args.net} T={T} MC-dropout + entropy maps + semantic key filter + stereo match, {H}x{W}, synthetic stereo pair, seeded random weights",
-                          "T": T, "samples_per_rank": [base + (1 if r < extra else 0) for r in range(world)],
+                          "T": T, "samples_per_rank": [parallel.shard_samples(T, world, r)[1] for r in range(world)],
                           "orb": bool(do_orb), "semantic_keys": stats["kps"], "stereo_matches": stats["matches"],
                           "algorithmic_gflop_per_frame": round((sn.flops_shared + T * sn.flops_per_sample) / 1e9, 2),
                           "reference_equivalent_gflop_per_frame": round(T * (sn.flops_shared + sn.flops_per_sample) / 1e9, 2)},

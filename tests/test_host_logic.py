@@ -1,0 +1,148 @@
+"""CPU: host-side logic of the product and the C ABI surface (no compute calls — there is no GPU here).
+Covers: the C++ prototxt reader vs the oracle's Python reader, netspec vs the reference layer graphs,
+the parameter container, the reference's constructor error conventions, the host quadtree vs the oracle,
+and that libsivo_hip.so exports every symbol include/sivo_hip.h declares and fails loudly without a GPU."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import prototxt as oproto
+from sivo_amd import _lib, netspec, orb, weights as wts
+
+
+def _graph(net):
+    keys = ("name", "type", "bottom", "top", "num_output", "pad", "kernel_size", "pool", "stride", "scale",
+            "dropout_ratio", "sample_weights_test", "local_size", "alpha", "beta", "bn_mode")
+    return [{k: L[k] for k in keys if k in L} for L in net["layers"]]
+
+
+@pytest.mark.parametrize("kind", ["standard", "basic"])
+def test_netspec_reproduces_reference_graph(kind):
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", f"netgraph_{kind}.json")))
+    gen = oproto.parse((netspec.standard_prototxt if kind == "standard" else netspec.basic_prototxt)(12))
+    assert _graph(gen) == gold["layers"]
+    assert gen["shape"][1:] == gold["shape"][1:] and gen["name"] == gold["name"]
+    ref_path = f"/root/reference/config/bayesian_segnet/{'standard/kitti/bayesian_segnet_kitti' if kind == 'standard' else 'basic/kitti/bayesian_segnet_basic_kitti'}.prototxt"
+    if os.path.exists(ref_path):          # build container only
+        assert _graph(oproto.parse(open(ref_path).read())) == gold["layers"]
+
+
+def test_parameter_counts_match_reference_weight_files():
+    """1,415,823 fp32 parameters for Basic (the 5,670,476-byte LFS object minus protobuf framing), SURVEY.md A.2."""
+    n = C.c_size_t()
+    text = netspec.basic_prototxt(6).encode()
+    _lib.check(_lib.lib().sivo_segnet_num_params(text, len(text), C.byref(n)))
+    assert n.value == 1415823
+    text = netspec.standard_prototxt(12).encode()
+    _lib.check(_lib.lib().sivo_segnet_num_params(text, len(text), C.byref(n)))
+    layers = oproto.parse(text.decode())["layers"]
+    assert n.value == sum(int(np.prod(s)) for _, shp in wts.param_shapes(layers) for s in shp) == 29451663
+
+
+def test_cpp_prototxt_reader_handles_reference_quirks():
+    """Blank batch dimension ("dim: # SET SAMPLE SIZE HERE", standard prototxt :3-8), comments, nested blocks."""
+    ref = "/root/reference/config/bayesian_segnet/standard/kitti/bayesian_segnet_kitti.prototxt"
+    n = C.c_size_t()
+    if os.path.exists(ref):
+        text = open(ref, "rb").read()
+        _lib.check(_lib.lib().sivo_segnet_num_params(text, len(text), C.byref(n)))
+        assert n.value == 29451663
+    text = b'name: "x"\ninput: "data"\ninput_shape {\n  dim: # blank\n  dim: 3\n  dim: 8\n  dim: 8\n}\n' \
+           b'layer { bottom: "data" top: "c" name: "c" type: "Convolution" param { lr_mult: 1 } ' \
+           b'convolution_param { weight_filler { type: "xavier" } num_output: 4 pad: 1 kernel_size: 3 } }\n'
+    _lib.check(_lib.lib().sivo_segnet_num_params(text, len(text), C.byref(n)))
+    assert n.value == 4 * 3 * 9 + 4
+    rc = _lib.lib().sivo_segnet_num_params(b"layer {", 7, C.byref(n))
+    assert rc == _lib.ERR_INVALID_ARGUMENT
+
+
+def test_constructor_error_conventions():
+    """Empty model / weights -> std::invalid_argument in the reference (bayesian_segnet.cpp:80-89, pinned by
+    tests/test_bayesian_segnet.cpp:138-150); C != 3 and T <= 1 likewise (:64-70)."""
+    from sivo_amd.segnet import BayesianSegNet, BayesianSegNetParams
+    with pytest.raises(ValueError, match="model_file"):
+        BayesianSegNet(BayesianSegNetParams("", "w.sivow"))
+    with pytest.raises(ValueError, match="weights_file"):
+        BayesianSegNet(BayesianSegNetParams("m.prototxt", ""))
+    with pytest.raises(ValueError, match="model_file"):
+        BayesianSegNet(prototxt="", weights=np.zeros(4, np.float32))
+    h = C.c_void_p()
+    lib = _lib.lib()
+    assert lib.sivo_segnet_create(b"", 0, 0, None, 0, 0, C.byref(h)) == _lib.ERR_INVALID_ARGUMENT
+    assert lib.sivo_segnet_create_from_files(b"", b"x", 0, 0, C.byref(h)) == _lib.ERR_INVALID_ARGUMENT
+
+
+def test_weight_container_roundtrip(tmp_path):
+    layers = oproto.parse(netspec.tiny_prototxt(2))["layers"]
+    w = wts.synth_weights(layers, 1)
+    flat = wts.pack(layers, w)
+    p = tmp_path / "w.sivow"
+    wts.save(str(p), flat)
+    assert np.array_equal(wts.load(str(p)), flat)
+    w2 = wts.synth_weights(layers, 1)
+    assert all(np.array_equal(a, b) for k in w for a, b in zip(w[k], w2[k]))      # seeded => reproducible
+
+
+def test_host_quadtree_matches_oracle(oracle, kitti_like_bgr):
+    ex = oracle.OrbExtractor()
+    ex(oracle.bgr2gray(kitti_like_bgr))
+    for l in range(8):
+        c = ex.candidates(l)
+        rows, cols = ex.level(l).shape
+        a = oracle.distribute_octtree(c, 16, cols - 16, 16, rows - 16, int(ex.features_per_level[l]))
+        b = orb.distribute_octtree(c, 16, cols - 16, 16, rows - 16, int(ex.features_per_level[l]))
+        assert a.tobytes() == b.tobytes(), f"level {l}"
+    rng = np.random.default_rng(0)
+    for n, N in ((1, 10), (5, 3), (400, 400), (2500, 100)):
+        k = np.zeros(n, oracle.KP_DTYPE)
+        k["x"] = rng.integers(0, 300, n); k["y"] = rng.integers(0, 100, n); k["response"] = rng.integers(7, 60, n)
+        assert oracle.distribute_octtree(k, 16, 316, 16, 116, N).tobytes() == orb.distribute_octtree(k, 16, 316, 16, 116, N).tobytes()
+    assert len(orb.distribute_octtree(np.zeros(0, oracle.KP_DTYPE), 16, 316, 16, 116, 10)) == 0
+
+
+def test_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "sivo_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(sivo_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 30
+    lib = C.CDLL(_lib.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared >= set(_lib.SIGNATURES)                 # the Python binding binds only declared symbols
+
+
+def test_struct_layouts_match_reference_types():
+    assert C.sizeof(_lib.KeyPoint) == 28 and orb.KP_DTYPE.itemsize == 28      # cv::KeyPoint
+    assert C.sizeof(_lib.Edge) == 48
+
+
+def test_no_gpu_fails_loudly():
+    """The product has no CPU fallback: compute entry points report SIVO_ERR_RUNTIME without a device."""
+    lib = _lib.lib()
+    if lib.sivo_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    h = C.c_void_p()
+    assert lib.sivo_orb_create(2000, C.c_float(1.2), 8, 20, 7, 0, C.byref(h)) == _lib.ERR_RUNTIME
+    a = np.zeros((2, 32), np.uint8); out = np.zeros((2, 2), np.int32)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    assert lib.sivo_hamming_matrix(p(a), 2, p(a), 2, p(out)) == _lib.ERR_RUNTIME
+    text = netspec.tiny_prototxt(2).encode()
+    w = np.zeros(10, np.float32)
+    assert lib.sivo_segnet_create(text, len(text), 0, p(w), 10, 0, C.byref(h)) == _lib.ERR_RUNTIME
+    assert b"no CPU fallback" in lib.sivo_last_error()
+    with pytest.raises(_lib.SivoError):
+        _lib.require_gpu()
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sivo_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "liboracle" not in src, f
