@@ -1,0 +1,160 @@
+// test_api.cpp — exercises the SIVO:: classes (sivo_amd/api) the way the reference's own
+// tests/test_bayesian_segnet.cpp does: InitializationTest (:138-150, exception convention),
+// SegmentationTest (:152-168, output sizes), plus the ORB / matcher / optimizer classes.
+//   test_api cpu                                 host-only checks (no GPU needed)
+//   test_api gpu <prototxt> <weights.sivow> <frame.bin> <outdir>
+//        frame.bin = int32 rows, int32 cols, then rows*cols*3 BGR bytes; writes the outputs for
+//        tests/test_gpu_cpp_api.py to compare with the Python binding (same library, bit-identical).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "bayesian_segnet/bayesian_segnet.hpp"
+#include "orbslam/ORBextractor.h"
+#include "orbslam/ORBmatcher.h"
+#include "orbslam/Optimizer.h"
+
+static int failures = 0;
+#define CHECK(cond)                                                              \
+    do {                                                                         \
+        if (!(cond)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); ++failures; } \
+    } while (0)
+
+template <class F>
+static bool throws_invalid_argument(F &&f) {
+    try { f(); } catch (const std::invalid_argument &) { return true; } catch (...) { return false; }
+    return false;
+}
+
+static void write_file(const std::string &path, const void *p, size_t n) {
+    std::ofstream f(path, std::ios::binary);
+    f.write(static_cast<const char *>(p), (std::streamsize)n);
+}
+
+static int run_cpu() {
+    // InitializationTest: empty model / weights path -> std::invalid_argument
+    CHECK(throws_invalid_argument([] { SIVO::BayesianSegNet s(SIVO::BayesianSegNetParams("", "weights")); }));
+    CHECK(throws_invalid_argument([] { SIVO::BayesianSegNet s(SIVO::BayesianSegNetParams("model", "")); }));
+    CHECK(SIVO::computeEntropy(0.0) == 0.0 && SIVO::computeEntropy(0.5) == 0.5);
+    CHECK(SIVO::ORBmatcher::TH_LOW == 50 && SIVO::ORBmatcher::TH_HIGH == 100 && SIVO::ORBmatcher::HISTO_LENGTH == 30);
+    cv::Mat a = cv::Mat::zeros(1, 32, CV_8UC1), b = cv::Mat::zeros(1, 32, CV_8UC1);
+    CHECK(SIVO::ORBmatcher::DescriptorDistance(a, b) == 0);
+    for (int i = 0; i < 32; ++i) b.data[i] = 0xff;
+    CHECK(SIVO::ORBmatcher::DescriptorDistance(a, b) == 256);
+    b.data[0] = 0x0f;
+    CHECK(SIVO::ORBmatcher::DescriptorDistance(a, b) == 252);
+    SIVO::ORBmatcher m;
+    std::vector<int> hist[30];
+    hist[3].assign(10, 0); hist[7].assign(5, 0); hist[9].assign(20, 0); hist[11].assign(1, 0);
+    int i1 = -1, i2 = -1, i3 = -1;
+    m.ComputeThreeMaxima(hist, 30, i1, i2, i3);
+    CHECK(i1 == 9 && i2 == 3 && i3 == 7);
+    hist[3].clear(); hist[7].clear();
+    i1 = i2 = i3 = -1;
+    m.ComputeThreeMaxima(hist, 30, i1, i2, i3);
+    CHECK(i1 == 9 && i2 == -1 && i3 == -1);                 // max2 < 0.1 * max1
+    std::printf(failures ? "cpu checks FAILED\n" : "cpu checks ok\n");
+    return failures;
+}
+
+static int run_gpu(int argc, char **argv) {
+    if (argc < 6) { std::printf("usage: test_api gpu prototxt weights frame.bin outdir\n"); return 2; }
+    const std::string proto = argv[2], weights = argv[3], frame = argv[4], out = argv[5];
+    std::ifstream f(frame, std::ios::binary);
+    int32_t rows = 0, cols = 0;
+    f.read(reinterpret_cast<char *>(&rows), 4); f.read(reinterpret_cast<char *>(&cols), 4);
+    cv::Mat bgr(rows, cols, CV_8UC3);
+    f.read(reinterpret_cast<char *>(bgr.data), (std::streamsize)rows * cols * 3);
+
+    // SegmentationTest (tests/test_bayesian_segnet.cpp:152-168)
+    SIVO::BayesianSegNetParams params(proto, weights);
+    params.seed = 7;
+    SIVO::BayesianSegNet segnet(params);
+    const cv::Size g = segnet.getInputGeometry();
+    SIVO::MatXu classes; SIVO::MatXd confidence, entropy;
+    segnet.segmentImage(bgr, classes, confidence, entropy);
+    const int output_size = g.height * g.width;
+    CHECK(classes.size() == output_size && confidence.size() == output_size && entropy.size() == output_size);
+    cv::Mat conf_img = segnet.generateConfidenceImage(confidence);
+    cv::Mat ent_img = segnet.generateEntropyImage(entropy);
+    cv::Mat seg_img = segnet.generateSegmentedImage(classes, bgr);
+    CHECK(conf_img.rows == g.height && ent_img.cols == g.width && seg_img.type() == CV_8UC3);
+    CHECK(entropy.minCoeff() >= 0.0 && entropy.maxCoeff() <= 3.91);
+    write_file(out + "/classes.bin", classes.data(), (size_t)output_size);
+    write_file(out + "/confidence.bin", confidence.data(), (size_t)output_size * 8);
+    write_file(out + "/entropy.bin", entropy.data(), (size_t)output_size * 8);
+    // smaller than the network: the reference yields an empty Mat; here a std::runtime_error
+    bool threw = false;
+    try { cv::Mat tiny(8, 8, CV_8UC3); segnet.segmentImage(tiny, classes, confidence, entropy); } catch (const std::exception &) { threw = true; }
+    CHECK(threw);
+
+    // ORB: two extractors on two threads (Frame.cc:126-129), gray = the blue plane (any 8UC1 image will do)
+    cv::Mat gray(rows, cols, CV_8UC1);
+    for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) gray.at<unsigned char>(r, c) = bgr.ptr(r)[3 * c];
+    SIVO::ORBextractor left(2000, 1.2f, 8, 20, 7), right(2000, 1.2f, 8, 20, 7);
+    std::vector<cv::KeyPoint> kl, kr; cv::Mat dl, dr, nomask;
+    std::thread t1([&] { left(gray, nomask, kl, dl); });
+    std::thread t2([&] { right(gray, nomask, kr, dr); });
+    t1.join(); t2.join();
+    CHECK(kl.size() == kr.size() && kl.size() > 100 && dl.rows == (int)kl.size() && dl.cols == 32);
+    CHECK(std::memcmp(dl.data, dr.data, (size_t)dl.rows * 32) == 0);
+    CHECK(left.GetLevels() == 8 && left.mvImagePyramid.size() == 8 && left.mvImagePyramid[0].rows == rows);
+    CHECK(std::memcmp(left.mvImagePyramid[0].ptr(5), gray.ptr(5), (size_t)cols) == 0);
+    CHECK(left.GetScaleFactors()[1] == 1.2f);
+    write_file(out + "/kps.bin", kl.data(), kl.size() * sizeof(cv::KeyPoint));
+    write_file(out + "/desc.bin", dl.data, (size_t)dl.rows * 32);
+    std::vector<cv::KeyPoint> none; cv::Mat nd, empty;
+    left(empty, nomask, none, nd);                         // empty image: returns silently
+    CHECK(none.empty());
+
+    // matcher: every descriptor against itself + neighbours -> best = itself at distance 0
+    SIVO::ORBmatcher matcher(0.9f, true);
+    const int n = dl.rows;
+    std::vector<int32_t> off(n + 1), idx;
+    std::vector<float> ang(n);
+    for (int i = 0; i < n; ++i) {
+        off[i] = (int32_t)idx.size();
+        for (int d = -2; d <= 2; ++d) if (i + d >= 0 && i + d < n) idx.push_back(i + d);
+        ang[i] = kl[i].angle;
+    }
+    off[n] = (int32_t)idx.size();
+    std::vector<int> matches;
+    const int nm = matcher.MatchCandidates(dl, ang, dr, ang, off, idx, SIVO::ORBmatcher::TH_LOW, true, matches);
+    int self = 0;
+    for (int i = 0; i < n; ++i) self += matches[i] == i;
+    CHECK(nm > n * 8 / 10 && self == nm);
+
+    // optimizer: one pose at identity, points in front, perfect observations -> zero error
+    std::vector<double> poses = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, points;
+    std::vector<SivoEdge> edges;
+    const double intr[5] = {718.856, 718.856, 498.692, 173.215, 386.1448};
+    for (int i = 0; i < 100; ++i) {
+        const double X = -5 + 0.1 * i, Y = 0.5, Z = 10 + i;
+        points.insert(points.end(), {X, Y, Z});
+        SivoEdge e{};
+        e.pose = 0; e.point = i; e.stereo = i & 1; e.inv_sigma2 = 1.0;
+        e.obs[0] = intr[0] * X / Z + intr[2]; e.obs[1] = intr[1] * Y / Z + intr[3]; e.obs[2] = e.obs[0] - intr[4] / Z;
+        if (i == 50) e.obs[0] += 10;                       // one outlier
+        edges.push_back(e);
+    }
+    SIVO::EdgeBatchResult lin;
+    SIVO::Optimizer::LinearizeEdges(poses, points, edges, intr, lin);
+    std::vector<uint8_t> outlier;
+    CHECK(SIVO::Optimizer::ClassifyOutliers(edges, lin, outlier) == 1 && outlier[50] == 1);
+    CHECK(lin.chi2[0] < 1e-20 && lin.weight[50] < 1.0 && lin.Jpose[3] == -1.0 / 10 * intr[0]);
+    std::printf(failures ? "gpu checks FAILED\n" : "gpu checks ok\n");
+    return failures;
+}
+
+int main(int argc, char **argv) {
+    if (argc >= 2 && std::string(argv[1]) == "cpu") return run_cpu();
+    if (argc >= 2 && std::string(argv[1]) == "gpu") return run_gpu(argc, argv);
+    std::printf("usage: test_api cpu | gpu ...\n");
+    return 2;
+}
