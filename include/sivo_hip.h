@@ -131,6 +131,10 @@ typedef struct {
 int sivo_segnet_profile(sivo_segnet_t h, int enable);
 int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int capacity, int *n_out);
 
+/* Diagnostic micro-benchmark of one convolution shape (random data); `variant` bit flags switch
+ * parts of the kernel off to attribute time (0 = the production kernel).  Mean launch ms out. */
+int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, int iters, int variant, double *ms_out);
+
 /* ===========================================================================
  * ORB extractor — stands behind SIVO::ORBextractor
  * (reference include/orbslam/ORBextractor.h:46-123, src/orbslam/ORBextractor.cc).

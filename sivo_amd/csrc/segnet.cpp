@@ -14,6 +14,7 @@
 //   * Softmax is not a kernel of its own: the plan ends at the logits and
 //     sivo_mc_reduce fuses softmax with the sum over samples.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -48,6 +49,7 @@ struct Op {
     int ks = 0, cin = 0, cout = 0, cout_pad = 0;
     float *d_w = nullptr, *d_scale = nullptr, *d_shift = nullptr;
     bool relu = false;
+    bool v2 = false;           // conv_v2.hip kernel + weight layout
     int drop_site = -1;
     // lrn
     int local_size = 5;
@@ -123,16 +125,23 @@ int new_blob(sivo_segnet &S, const std::string &name, int C, int H, int W, bool 
 // bias (+ BN scale/shift) into the epilogue's per-channel affine.
 void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias) {
     const int ks = op.ks, cin = op.cin, cout = op.cout;
-    const int KC = conv_k_chunk(ks, cin), BN = conv_cout_tile(ks, cout);
-    op.cout_pad = cdiv(cout, BN) * BN;
-    const int nchunks = cdiv(cin, KC), taps = ks * ks;
-    std::vector<float> wt((size_t)nchunks * taps * KC * op.cout_pad, 0.f);
-    for (int co = 0; co < cout; ++co)
-        for (int ci = 0; ci < cin; ++ci)
-            for (int t = 0; t < taps; ++t) {
-                const size_t dst = (((size_t)(ci / KC) * taps + t) * KC + (ci % KC)) * op.cout_pad + co;
-                wt[dst] = W[((size_t)co * cin + ci) * taps + t];
-            }
+    std::vector<float> wt;
+    static const bool force_v1 = std::getenv("SIVO_CONV_V1") != nullptr;
+    op.v2 = conv2_supported(ks) && !force_v1;
+    if (op.v2) {
+        conv2_pack_weights(W, ks, cin, cout, wt, &op.cout_pad);
+    } else {
+        const int KC = conv_k_chunk(ks, cin), BN = conv_cout_tile(ks, cout);
+        op.cout_pad = cdiv(cout, BN) * BN;
+        const int nchunks = cdiv(cin, KC), taps = ks * ks;
+        wt.assign((size_t)nchunks * taps * KC * op.cout_pad, 0.f);
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int t = 0; t < taps; ++t) {
+                    const size_t dst = (((size_t)(ci / KC) * taps + t) * KC + (ci % KC)) * op.cout_pad + co;
+                    wt[dst] = W[((size_t)co * cin + ci) * taps + t];
+                }
+    }
     op.d_w = dev_alloc<float>(wt.size());
     S.owned.push_back(op.d_w);
     SIVO_HIP(hipMemcpy(op.d_w, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -205,8 +214,12 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             {
                 char kn[96];
                 const int bn = conv_cout_tile(op.ks, op.cout), kc = conv_k_chunk(op.ks, op.cin);
-                snprintf(kn, sizeof kn, "conv_mfma_kernel<%d,%d,32,%d,%d,%d,%d>", op.ks, bn == 128 ? 4 : 8, bn, kc,
-                         bn == 128 ? 2 : 4, bn == 128 ? 2 : 1);
+                if (op.v2)
+                    snprintf(kn, sizeof kn, "conv_mfma2_kernel<%d,%d,32,%d,%d,%d>", op.ks, bn == 128 ? 4 : 8, bn, bn == 128 ? 2 : 4,
+                             bn == 128 ? 2 : 1);
+                else
+                    snprintf(kn, sizeof kn, "conv_mfma_kernel<%d,%d,32,%d,%d,%d,%d>", op.ks, bn == 128 ? 4 : 8, bn, kc,
+                             bn == 128 ? 2 : 4, bn == 128 ? 2 : 1);
                 op.kernel = kn;
             }
             // algorithmic HBM bytes: input + output activations once, weights once
@@ -360,7 +373,7 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
                 a.out = (float *)bo.d;
                 a.N = N; a.Cin = op.cin; a.H = bi.H; a.W = bi.W; a.Cout = op.cout; a.CoutPad = op.cout_pad;
                 a.relu = op.relu; a.drop_site = op.drop_site; a.sample0 = sample0; a.seed = seed;
-                launch_conv(a, op.ks, st);
+                if (op.v2) launch_conv2(a, op.ks, st); else launch_conv(a, op.ks, st);
                 break;
             }
             case OP_POOL: {
@@ -610,6 +623,44 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
             p.ms_total = op.ms_total;
             p.launches = op.launches;
         }
+        return SIVO_OK;
+    });
+}
+
+// Diagnostic: time one convolution shape in isolation (random data), `variant` switches parts of
+// the kernel off (see ConvArgs::variant).  Returns the mean launch time in ms.
+extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, int iters, int variant, double *ms_out) {
+    return guarded([&] {
+        if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device");
+        const bool v2 = (variant & 16) && conv2_supported(ks);
+        const int KC = v2 ? 4 : conv_k_chunk(ks, Cin), BN = conv_cout_tile(ks, Cout);
+        const int cout_pad = cdiv(Cout, BN) * BN, nchunks = cdiv(Cin, KC);
+        const size_t nin = (size_t)N * Cin * H * W, nout = (size_t)N * Cout * H * W;
+        const size_t nw = v2 ? (size_t)nchunks * (cout_pad / BN) * conv2_slab_floats(ks, Cout) : (size_t)nchunks * ks * ks * KC * cout_pad;
+        std::vector<float> hin(nin), hw(nw), hs(Cout, 1.f);
+        uint32_t st = 12345;
+        auto rnd = [&] { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
+        for (auto &v : hin) v = rnd();
+        for (auto &v : hw) v = rnd() * 0.05f;
+        float *din = dev_alloc<float>(nin), *dout = dev_alloc<float>(nout), *dw = dev_alloc<float>(nw), *ds = dev_alloc<float>(Cout);
+        SIVO_HIP(hipMemcpy(din, hin.data(), nin * 4, hipMemcpyHostToDevice));
+        SIVO_HIP(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
+        SIVO_HIP(hipMemcpy(ds, hs.data(), Cout * 4, hipMemcpyHostToDevice));
+        ConvArgs a{};
+        a.in = din; a.in_sample_stride = (int64_t)Cin * H * W; a.wt = dw; a.ep_scale = ds; a.ep_shift = ds; a.out = dout;
+        a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.CoutPad = cout_pad; a.relu = 1; a.drop_site = -1; a.variant = variant;
+        hipEvent_t e0, e1;
+        SIVO_HIP(hipEventCreate(&e0)); SIVO_HIP(hipEventCreate(&e1));
+        for (int i = 0; i < 2; ++i) { if (v2) launch_conv2(a, ks, nullptr); else launch_conv(a, ks, nullptr); }
+        SIVO_HIP(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) { if (v2) launch_conv2(a, ks, nullptr); else launch_conv(a, ks, nullptr); }
+        SIVO_HIP(hipEventRecord(e1, nullptr));
+        SIVO_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        SIVO_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *ms_out = ms / iters;
+        (void)hipFree(din); (void)hipFree(dout); (void)hipFree(dw); (void)hipFree(ds);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         return SIVO_OK;
     });
 }

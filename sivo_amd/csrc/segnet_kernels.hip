@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int nchunks = (a.Cin + KC - 1) / KC;
 
     auto issue_loads = [&](int chunk) {
+        if (a.variant & 4) return;
         const float *psrc = in_n + (int64_t)chunk * KC * plane;
         const int cleft = a.Cin - chunk * KC;   // channels of this chunk that exist
 #pragma unroll
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         }
     };
     auto commit_loads = [&]() {
+        if (a.variant & 2) return;
 #pragma unroll
         for (int it = 0; it < PITER; ++it)
             if (p_dst[it] >= 0) s_patch[p_dst[it] & 0xffffff] = pv[it];
@@ -224,6 +226,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 }
             }
             float *dst = out_n + (int64_t)co * plane + (int64_t)y * a.W + x;
+            if ((a.variant & 1) && v[0] != 12345.678f) continue;
             if (vec_ok) {
                 *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
@@ -538,3 +541,5 @@ void launch_mask_to_index(const uint8_t *mask, float *out, int64_t total, int Ho
 }
 
 }  // namespace sivo
+
+// ------------------------------------------------------------------ diagnostics

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace sivo {
 
 struct ConvArgs {
@@ -18,10 +20,16 @@ struct ConvArgs {
     int drop_site;             // < 0: no dropout in the epilogue
     int sample0;
     uint64_t seed;
+    int variant;               // diagnostics only (sivo_debug_conv): bit0 no epilogue stores, bit1 no LDS commit, bit2 no global loads
 };
 int conv_cout_tile(int ks, int cout);  // BN the launcher will pick (CoutPad must be a multiple)
 int conv_k_chunk(int ks, int cin);     // KC the launcher will pick (defines the weight layout)
 void launch_conv(const ConvArgs &a, int ks, hipStream_t s);
+// second-generation kernel (conv_v2.hip): KC = 4, double-buffered LDS, LDS-DMA weight slabs
+bool conv2_supported(int ks);
+int conv2_slab_floats(int ks, int cout);
+void conv2_pack_weights(const float *W, int ks, int cin, int cout, std::vector<float> &out, int *cout_pad);
+void launch_conv2(const ConvArgs &a, int ks, hipStream_t s);
 
 struct PoolArgs {
     const float *in;

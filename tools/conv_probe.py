@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Attribute time inside conv_mfma_kernel: runs sivo_debug_conv on the SegNet-Standard layer shapes
+with parts of the kernel switched off (variant bits).  GPU box only."""
+import ctypes as C
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sivo_amd._lib import lib, check
+
+SHAPES = {"conv4_2": (12, 512, 512, 44, 128), "conv5_2": (12, 512, 512, 22, 64), "conv3_2_D": (12, 256, 256, 88, 256),
+          "conv2_2_D": (12, 128, 128, 176, 512), "conv1_2_D": (12, 64, 64, 352, 1024), "conv3_2": (1, 256, 256, 88, 256)}
+VARIANTS = {16: "v2", 18: "v2 no-patch", 20: "v2 no-dma", 22: "v2 no-patch/dma", 24: "v2 dma-hot"}
+
+def run(name, variant, iters=10):
+    N, ci, co, H, W = SHAPES[name]
+    ms = C.c_double()
+    check(lib().sivo_debug_conv(N, ci, co, H, W, 3, iters, variant, C.byref(ms)))
+    fl = 2.0 * 9 * ci * co * H * W * N
+    return ms.value, fl / ms.value / 1e9
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(SHAPES)
+    for n in names:
+        row = []
+        for v, label in VARIANTS.items():
+            ms, tf = run(n, v)
+            row.append(f"{label}={ms:.3f}ms({tf:.0f}TF)")
+        print(n, " ".join(row))
