@@ -237,6 +237,28 @@ int sivo_ba_linearize(const double *poses, int n_poses, const double *points, in
                       double delta_stereo, double *err, double *jx, double *jp, double *chi2, double *rho,
                       double *w, uint8_t *depth_ok);
 
+/* ===========================================================================
+ * Entropy feature-selection gate — stands behind SIVO's sivo_helpers
+ * (reference src/sivo_helpers/sivo_helpers.cpp:64-88 computeStereoJacobianPose,
+ * :160-180 computeStereoCovariance, :201-219 computeStereoMutualInformation) as
+ * Tracking::CreateNewKeyFrame applies them per semantic keypoint
+ * (reference src/orbslam/Tracking.cc:934-1023).  SURVEY.md 8f-1.
+ * For keypoint i: skip unless depth[i] > 0; J = stereo pose Jacobian at
+ * xyz[3i..] (the coordinates the caller passes — the reference passes WORLD
+ * coordinates, Tracking.cc:963-977); S9 = [[Sx, Sx J'],[J Sx, J Sx J' + sigma2 I]];
+ * MI = 0.5 log2(det Sx * det Sz / det S9); reduction = MI - entropy(row, col) at
+ * the truncated keypoint position; accept iff reduction > th.
+ * state_cov: 6x6 row-major (Frame::mSigmacw); level_sigma2: mvLevelSigma2.
+ * ======================================================================== */
+int sivo_entropy_gate_dev(int n, const SivoKeyPoint *d_kps, const float *d_depth, const double *d_xyz,
+                          const double *d_entropy, int rows, int cols, const double state_cov[36], double fx,
+                          double fy, double bl, const float *level_sigma2, int nlevels, double th,
+                          double *d_mi, double *d_reduction, uint8_t *d_accept, void *stream);
+int sivo_entropy_gate(int n, const SivoKeyPoint *kps, const float *depth, const double *xyz,
+                      const double *entropy, int rows, int cols, const double state_cov[36], double fx,
+                      double fy, double bl, const float *level_sigma2, int nlevels, double th, double *mi,
+                      double *reduction, uint8_t *accept);
+
 #ifdef __cplusplus
 }
 #endif

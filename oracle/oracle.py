@@ -367,3 +367,24 @@ def bgr2gray(bgr):
     """cv::cvtColor BGR2GRAY on 8U (Tracking.cc:187-194): (B*1868 + G*9617 + R*4899 + 8192) >> 14."""
     b = bgr[..., 0].astype(np.int32); g = bgr[..., 1].astype(np.int32); r = bgr[..., 2].astype(np.int32)
     return ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
+
+
+# --------------------------------------------------------------------------- entropy feature-selection gate
+def stereo_mutual_information(Sx, fx, fy, bl, X, Y, Z, sigma2):
+    Sx = np.ascontiguousarray(Sx, np.float64)
+    f = lib().orc_stereo_mutual_information
+    f.restype = C.c_double
+    return f(_p(Sx, c_f64p), C.c_double(fx), C.c_double(fy), C.c_double(bl), C.c_double(X), C.c_double(Y), C.c_double(Z), C.c_double(sigma2))
+
+
+def entropy_gate(kps, depth, xyz, entropy, Sx, fx, fy, bl, level_sigma2, th):
+    """Tracking.cc:934-1023 over all keypoints: returns (mutual_information, entropy_reduction, accept)."""
+    kps = np.ascontiguousarray(kps, KP_DTYPE); depth = np.ascontiguousarray(depth, np.float32)
+    xyz = np.ascontiguousarray(xyz, np.float64); entropy = np.ascontiguousarray(entropy, np.float64)
+    Sx = np.ascontiguousarray(Sx, np.float64); ls2 = np.ascontiguousarray(level_sigma2, np.float32)
+    n = len(kps)
+    mi = np.empty(n); red = np.empty(n); acc = np.empty(n, np.uint8)
+    lib().orc_entropy_gate(n, kps.ctypes.data_as(C.c_void_p), _p(depth, c_f32p), _p(xyz, c_f64p), _p(entropy, c_f64p),
+                           entropy.shape[0], entropy.shape[1], _p(Sx, c_f64p), C.c_double(fx), C.c_double(fy), C.c_double(bl),
+                           _p(ls2, c_f32p), C.c_double(th), _p(mi, c_f64p), _p(red, c_f64p), _p(acc, c_u8p))
+    return mi, red, acc

@@ -1,0 +1,161 @@
+// select.hip — SIVO's information-theoretic map-point selection gate, batched over the semantic
+// keypoints of a frame.  Stands behind
+//   SIVO::computeStereoJacobianPose / computeStereoCovariance / computeStereoMutualInformation
+//   (reference src/sivo_helpers/sivo_helpers.cpp:64-88, 160-180, 201-219)
+// as they are applied in Tracking::CreateNewKeyFrame (reference src/orbslam/Tracking.cc:934-1023) and
+// LocalMapping::CheckSemantics: entropy lookup at the truncated keypoint position in the entropy map the
+// SegNet path left in HBM, depth > 0, accept iff MI - entropy > ThEntropyReduction.
+// One thread per keypoint, fp64, determinants as Eigen takes them (3x3 cofactors, 6x6 / 9x9 partial-
+// pivot LU); a few thousand independent 9x9 factorizations: latency bound, microseconds.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.hpp"
+
+namespace sivo {
+
+__device__ double det_lu(double *a, int n) {
+    double det = 1.0;
+    for (int k = 0; k < n; ++k) {
+        int piv = k;
+        double best = fabs(a[k * n + k]);
+        for (int i = k + 1; i < n; ++i)
+            if (fabs(a[i * n + k]) > best) { best = fabs(a[i * n + k]); piv = i; }
+        if (best == 0.0) return 0.0;
+        if (piv != k) {
+            for (int j = 0; j < n; ++j) { const double t = a[k * n + j]; a[k * n + j] = a[piv * n + j]; a[piv * n + j] = t; }
+            det = -det;
+        }
+        det *= a[k * n + k];
+        for (int i = k + 1; i < n; ++i) {
+            const double f = a[i * n + k] / a[k * n + k];
+            for (int j = k + 1; j < n; ++j) a[i * n + j] -= f * a[k * n + j];
+        }
+    }
+    return det;
+}
+
+struct GateArgs {
+    const SivoKeyPoint *kps;
+    const float *depth;
+    const double *xyz;
+    const double *entropy;
+    int rows, cols, n;
+    double Sx[36];
+    double fx, fy, bl, th;
+    float level_sigma2[16];
+    double *mi, *reduction;
+    uint8_t *accept;
+};
+
+__global__ void entropy_gate_kernel(GateArgs g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.n) return;
+    double m = 0.0, red = 0.0;
+    uint8_t acc = 0;
+    const SivoKeyPoint kp = g.kps[i];
+    const int col = (int)kp.x, row = (int)kp.y;
+    if (g.depth[i] > 0 && row >= 0 && row < g.rows && col >= 0 && col < g.cols) {
+        const double X = g.xyz[3 * i], Y = g.xyz[3 * i + 1], Z = g.xyz[3 * i + 2];
+        const double fx = g.fx, fy = g.fy, bl = g.bl;
+        double J[18];
+        for (int k = 0; k < 18; ++k) J[k] = 0.0;
+        if (Z != 0) {
+            J[0] = fx / Z; J[1] = 0.0; J[2] = -fx * X / (Z * Z);
+            J[3] = -fx * X * Y / (Z * Z); J[4] = fx * (1.0 + (X * X) / (Z * Z)); J[5] = -fx * Y / Z;
+            J[6] = 0.0; J[7] = fy / Z; J[8] = -fy * Y / (Z * Z);
+            J[9] = -fy * (1 + (Y * Y) / (Z * Z)); J[10] = fy * X * Y / (Z * Z); J[11] = fy * X / Z;
+            J[12] = fx / Z; J[13] = 0.0; J[14] = -fx * (X - bl) / (Z * Z);
+            J[15] = -fx * (X - bl) * Y / (Z * Z); J[16] = fx * (1.0 + (X * (X - bl)) / (Z * Z)); J[17] = -fx * Y / Z;
+        }
+        const double sigma2 = g.level_sigma2[kp.octave];
+        double S9[81], JS[18], Sz[9], Sxc[36];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 6; ++b) {
+                double s = 0.0;
+                for (int k = 0; k < 6; ++k) s += J[a * 6 + k] * g.Sx[k * 6 + b];
+                JS[a * 6 + b] = s;
+            }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                double s = 0.0;
+                for (int k = 0; k < 6; ++k) s += JS[a * 6 + k] * J[b * 6 + k];
+                Sz[a * 3 + b] = s + (a == b ? sigma2 : 0.0);
+            }
+        for (int a = 0; a < 6; ++a)
+            for (int b = 0; b < 6; ++b) { S9[a * 9 + b] = g.Sx[a * 6 + b]; Sxc[a * 6 + b] = g.Sx[a * 6 + b]; }
+        for (int a = 0; a < 6; ++a)
+            for (int b = 0; b < 3; ++b) {
+                double s = 0.0;
+                for (int k = 0; k < 6; ++k) s += g.Sx[a * 6 + k] * J[b * 6 + k];
+                S9[a * 9 + 6 + b] = s;
+            }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 6; ++b) S9[(6 + a) * 9 + b] = JS[a * 6 + b];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) S9[(6 + a) * 9 + 6 + b] = Sz[a * 3 + b];
+        const double state_det = det_lu(Sxc, 6);
+        const double meas_det = Sz[0] * (Sz[4] * Sz[8] - Sz[5] * Sz[7]) - Sz[1] * (Sz[3] * Sz[8] - Sz[5] * Sz[6]) +
+                                Sz[2] * (Sz[3] * Sz[7] - Sz[4] * Sz[6]);
+        const double cov_det = det_lu(S9, 9);
+        m = 0.5 * log2(state_det * meas_det / cov_det);
+        red = m - g.entropy[(int64_t)row * g.cols + col];
+        acc = red > g.th;
+    }
+    if (g.mi) g.mi[i] = m;
+    if (g.reduction) g.reduction[i] = red;
+    if (g.accept) g.accept[i] = acc;
+}
+
+}  // namespace sivo
+
+using namespace sivo;
+
+extern "C" int sivo_entropy_gate_dev(int n, const SivoKeyPoint *d_kps, const float *d_depth, const double *d_xyz,
+                                     const double *d_entropy, int rows, int cols, const double state_cov[36], double fx,
+                                     double fy, double bl, const float *level_sigma2, int nlevels, double th,
+                                     double *d_mi, double *d_reduction, uint8_t *d_accept, void *stream) {
+    return guarded([&] {
+        if (n < 0 || nlevels < 1 || nlevels > 16) throw std::invalid_argument("bad sizes (nlevels <= 16)");
+        if (n == 0) return SIVO_OK;
+        if (!d_kps || !d_depth || !d_xyz || !d_entropy || !state_cov || !level_sigma2) throw std::invalid_argument("null argument");
+        GateArgs g{};
+        g.kps = d_kps; g.depth = d_depth; g.xyz = d_xyz; g.entropy = d_entropy; g.rows = rows; g.cols = cols; g.n = n;
+        for (int i = 0; i < 36; ++i) g.Sx[i] = state_cov[i];
+        g.fx = fx; g.fy = fy; g.bl = bl; g.th = th;
+        for (int i = 0; i < nlevels; ++i) g.level_sigma2[i] = level_sigma2[i];
+        g.mi = d_mi; g.reduction = d_reduction; g.accept = d_accept;
+        hipLaunchKernelGGL(entropy_gate_kernel, dim3(cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, g);
+        SIVO_HIP(hipGetLastError());
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_entropy_gate(int n, const SivoKeyPoint *kps, const float *depth, const double *xyz,
+                                 const double *entropy, int rows, int cols, const double state_cov[36], double fx,
+                                 double fy, double bl, const float *level_sigma2, int nlevels, double th, double *mi,
+                                 double *reduction, uint8_t *accept) {
+    return guarded([&] {
+        if (n < 0) throw std::invalid_argument("negative size");
+        if (n == 0) return SIVO_OK;
+        if (!kps || !depth || !xyz || !entropy) throw std::invalid_argument("null argument");
+        if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device: libsivo_hip has no CPU fallback");
+        struct Buf { void *p = nullptr; ~Buf() { (void)hipFree(p); } };
+        auto up = [](Buf &b, const void *src, size_t bytes) {
+            SIVO_HIP(hipMalloc(&b.p, bytes ? bytes : 1));
+            if (src) SIVO_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+        };
+        Buf dk, dd, dx, de, dm, dr, da;
+        up(dk, kps, (size_t)n * sizeof(SivoKeyPoint)); up(dd, depth, (size_t)n * 4); up(dx, xyz, (size_t)n * 24);
+        up(de, entropy, (size_t)rows * cols * 8);
+        up(dm, nullptr, (size_t)n * 8); up(dr, nullptr, (size_t)n * 8); up(da, nullptr, (size_t)n);
+        const int rc = sivo_entropy_gate_dev(n, (const SivoKeyPoint *)dk.p, (const float *)dd.p, (const double *)dx.p,
+                                             (const double *)de.p, rows, cols, state_cov, fx, fy, bl, level_sigma2, nlevels, th,
+                                             (double *)dm.p, (double *)dr.p, (uint8_t *)da.p, nullptr);
+        if (rc) return rc;
+        if (mi) SIVO_HIP(hipMemcpy(mi, dm.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+        if (reduction) SIVO_HIP(hipMemcpy(reduction, dr.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+        if (accept) SIVO_HIP(hipMemcpy(accept, da.p, (size_t)n, hipMemcpyDeviceToHost));
+        return SIVO_OK;
+    });
+}

@@ -102,3 +102,25 @@ def test_ba_edge_cases(oracle):
     bad = edges[:1].copy(); bad["point"] = 10 ** 6
     with pytest.raises(SivoError):
         optimizer.linearize(poses, pts, bad, intr)
+
+
+def test_entropy_gate_matches_oracle(oracle):
+    from sivo_amd import selection
+    rng = np.random.default_rng(4)
+    n, H, W = 2000, 352, 1024
+    kps = np.zeros(n, oracle.KP_DTYPE)
+    kps["x"] = rng.uniform(19, W - 19, n); kps["y"] = rng.uniform(19, H - 19, n); kps["octave"] = rng.integers(0, 8, n)
+    depth = rng.uniform(-2, 60, n).astype(np.float32)
+    xyz = np.stack([rng.uniform(-20, 20, n), rng.uniform(-3, 3, n), rng.uniform(1, 60, n)], 1)
+    ent = rng.uniform(0, 3.9, (H, W))
+    A = rng.standard_normal((6, 6)); Sx = A @ A.T * 1e-3 + np.eye(6) * 1e-4
+    ls2 = (np.float32(1.2) ** (2 * np.arange(8))).astype(np.float32)
+    o = oracle.entropy_gate(kps, depth, xyz, ent, Sx, 718.856, 718.856, 0.537, ls2, 4.0)
+    g = selection.entropy_gate(kps, depth, xyz, ent, Sx, 718.856, 718.856, 0.537, ls2, 4.0)
+    np.testing.assert_allclose(g[0], o[0], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(g[1], o[1], rtol=1e-12, atol=1e-11)
+    far = np.abs(o[1] - 4.0) > 1e-9
+    assert np.array_equal(g[2][far], o[2][far]) and 0 < o[2].sum() < n
+    assert (g[2][~(depth > 0)] == 0).all()
+    e = selection.entropy_gate(kps[:0], depth[:0], xyz[:0], ent, Sx, 718.856, 718.856, 0.537, ls2, 4.0)
+    assert len(e[0]) == 0
