@@ -1,0 +1,285 @@
+// conv_wino.hip — 3x3 convolution by Winograd F(2x2, 3x3) on the fp32 matrix cores.
+//
+// Lavin & Gray, "Fast Algorithms for Convolutional Neural Networks" (CVPR 2016):
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A   per 2x2 output tile, 4x4 input tile d, 3x3 filter g,
+// summed over input channels BEFORE the output transform, i.e. for each of the 16 transform
+// positions p an independent GEMM  M_p[tile][co] = sum_ci V_p[tile][ci] * U_p[ci][co]:
+// 16 multiplies per 4 outputs instead of 36 (2.25x fewer MFMA flops), every operation in fp32
+// (the transforms are +-, *0.5; measured |dlogit| stays ~1e-5, budget 1e-3).
+//
+// Mapping onto v_mfma_f32_16x16x4_f32 (A = 16 tiles x 4 channels, B = 4 channels x 16 couts):
+//   * an m-tile = 16 horizontally consecutive 2x2 tiles (32 x 2 output pixels);
+//   * lane l owns (tile i = l & 15, channel c0 + (l >> 4)): it reads that tile's 4x4 input patch
+//     from the LDS halo patch (16 ds_read_b32), applies B^T d B in registers (32 adds) and so
+//     holds exactly the A operand of all 16 positions — no cross-lane traffic;
+//   * B operand of position p: U slab row (p*4 + (l >> 4)), column n0 + (l & 15);
+//   * accumulators acc[p][nt]: lane holds, for its 4 tiles (rows 4*(l>>4)+r) and its cout, all 16
+//     positions, so the output transform A^T M A is lane-local too (24 adds per tile), followed
+//     by the fused epilogue (bias+BN affine, ReLU, Philox dropout) and two float4 stores per row.
+// Staging is the v2 scheme (conv_v2.hip): K-chunks of 4 channels, double-buffered LDS, the
+// pre-transformed weight slab (16 x 4 x BN, LDS image) by LDS-DMA, the patch by 16-byte loads.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "segnet_kernels.hpp"
+
+namespace sivo {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t wino_dropout_word(uint32_t e, uint32_t site, uint32_t sample, uint64_t seed) {
+    uint32_t c0 = e >> 7, c1 = site, c2 = sample, c3 = 0u, k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint32_t sel = (e >> 5) & 3u;
+    return sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
+}
+
+constexpr int wino_bnp(int bn) { return (bn % 32 == 0) ? bn + 16 : bn; }
+constexpr int wino_slab(int bn) { return (16 * 4 * wino_bnp(bn) + 255) / 256 * 256; }   // floats, whole KiB
+
+// Workgroup: WM m-tiles stacked vertically (2*WM output rows x 32 output columns) x BN = WN*NT*16 couts.
+template <int WM, int WN, int NT>
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a) {
+    constexpr int KC = 4, BN = WN * NT * 16, BNP = wino_bnp(BN);
+    constexpr int TH = 2 * WM, TW = 32;
+    constexpr int OFF = 4, PH = TH + 2, PWp = TW + 8;
+    constexpr int CS = (PH * PWp + 3) / 4 * 4 + 4;         // channel stride (dwords), multiple of 4; +4 de-phases the banks
+    constexpr int WSLAB = wino_slab(BN);
+    constexpr int PATCH = KC * CS;
+    constexpr int BUF = PATCH + WSLAB;
+    static_assert(WM * WN == 4, "4 waves");
+
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, lk = lane >> 4;
+
+    int bid = blockIdx.x;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+    const int n = bid;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int ntile = blockIdx.y, n0 = ntile * BN;
+    const int ntiles = a.CoutPad / BN;
+
+    const float *in_n = a.in + (int64_t)n * a.in_sample_stride;
+    const int64_t plane = (int64_t)a.H * a.W;
+
+    // 4x4 input patch of tile (row wm, column li): LDS rows 2*wm .. 2*wm+3, columns OFF-1+2*li .. +3
+    const int a_base = lk * CS + (2 * wm) * PWp + (OFF - 1) + 2 * li;
+    const int b_base = PATCH + lk * BNP + wn * NT * 16 + li;
+
+    f32x4 acc[16][NT];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[p][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- staging plan (as conv_v2): interior float4s + 2 halo scalars per patch row
+    constexpr int NV4 = KC * PH * (TW / 4), V4IT = (NV4 + 255) / 256;
+    constexpr int NSC = KC * PH * 2, SCIT = (NSC + 255) / 256;
+    int v_goff[V4IT], v_dst[V4IT];
+    bool v_ok[V4IT];
+#pragma unroll
+    for (int it = 0; it < V4IT; ++it) {
+        const int idx = tid + it * 256;
+        const int seg = idx % (TW / 4), r = idx / (TW / 4);
+        const int py = r % PH, c = r / PH;
+        const int gy = y0 + py - 1, gx = x0 + seg * 4;
+        v_ok[it] = idx < NV4 && gy >= 0 && gy < a.H && gx + 3 < a.W;
+        v_goff[it] = v_ok[it] ? (int)(c * plane + (int64_t)gy * a.W + gx) : 0;
+        v_dst[it] = idx < NV4 ? ((c * CS + py * PWp + OFF + seg * 4) | (c << 24)) : -1;
+    }
+    int s_goff[SCIT], s_dst[SCIT];
+#pragma unroll
+    for (int it = 0; it < SCIT; ++it) {
+        const int idx = tid + it * 256;
+        const int h = idx % 2, r = idx / 2;
+        const int py = r % PH, c = r / PH;
+        const int px = h == 0 ? OFF - 1 : OFF + TW;
+        const int gy = y0 + py - 1, gx = x0 + px - OFF;
+        const bool ok = idx < NSC && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        s_goff[it] = ok ? (int)(c * plane + (int64_t)gy * a.W + gx) : -1;
+        s_dst[it] = idx < NSC ? ((c * CS + py * PWp + px) | (c << 24)) : -1;
+    }
+    f32x4 pv4[V4IT];
+    float psc[SCIT];
+    const int nchunks = (a.Cin + KC - 1) / KC;
+
+    auto issue_patch = [&](int chunk) {
+        const float *psrc = in_n + (int64_t)chunk * KC * plane;
+        const int cleft = a.Cin - chunk * KC;
+#pragma unroll
+        for (int it = 0; it < V4IT; ++it) {
+            const bool ok = v_ok[it] && (v_dst[it] >> 24) < cleft;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(psrc + (ok ? v_goff[it] : 0));
+            pv4[it] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int it = 0; it < SCIT; ++it) {
+            const bool ok = s_goff[it] >= 0 && (s_dst[it] >> 24) < cleft;
+            const float v = psrc[ok ? s_goff[it] : 0];
+            psc[it] = ok ? v : 0.f;
+        }
+    };
+    auto commit_patch = [&](int buf) {
+        float *sp = lds + buf * BUF;
+#pragma unroll
+        for (int it = 0; it < V4IT; ++it)
+            if (v_dst[it] >= 0) *reinterpret_cast<f32x4 *>(sp + (v_dst[it] & 0xffffff)) = pv4[it];
+#pragma unroll
+        for (int it = 0; it < SCIT; ++it)
+            if (s_dst[it] >= 0) sp[s_dst[it] & 0xffffff] = psc[it];
+    };
+    constexpr int NDMA = (WSLAB / 256 + 3) / 4;
+    auto dma_weights = [&](int chunk, int buf) {
+        const float *wsrc = a.wt + ((int64_t)chunk * ntiles + ntile) * WSLAB;
+        float *dst = lds + buf * BUF + PATCH;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int kib = i * 4 + wave;
+            if (kib < WSLAB / 256)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + kib * 256 + lane * 4),
+                                                 (__attribute__((address_space(3))) void *)(dst + kib * 256), 16, 0, 0);
+        }
+    };
+
+    issue_patch(0);
+    dma_weights(0, 0);
+    commit_patch(0);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int cur = chunk & 1;
+        const bool more = chunk + 1 < nchunks;
+        issue_patch(more ? chunk + 1 : chunk);
+        if (more) dma_weights(chunk + 1, cur ^ 1);
+        const float *sp = lds + cur * BUF;
+        // ---- input transform V = B^T d B of this lane's (tile, channel)
+        float d[4][4], t[4][4], V[16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d[r][c] = sp[a_base + r * PWp + c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            t[0][c] = d[0][c] - d[2][c];
+            t[1][c] = d[1][c] + d[2][c];
+            t[2][c] = d[2][c] - d[1][c];
+            t[3][c] = d[1][c] - d[3][c];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            V[r * 4 + 0] = t[r][0] - t[r][2];
+            V[r * 4 + 1] = t[r][1] + t[r][2];
+            V[r * 4 + 2] = t[r][2] - t[r][1];
+            V[r * 4 + 3] = t[r][1] - t[r][3];
+        }
+        // ---- 16 positions x NT MFMAs
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float bf = sp[b_base + p * KC * BNP + nt * 16];
+                acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[p], bf, acc[p][nt], 0, 0, 0);
+            }
+            if (p == 10 && more) commit_patch(cur ^ 1);
+        }
+        __syncthreads();
+    }
+
+    // ---- output transform Y = A^T M A (lane-local) + epilogue
+    float *out_n = a.out + (int64_t)n * a.Cout * plane;
+    const int yb = y0 + 2 * wm;
+    const int xb = x0 + 8 * lk;                 // this lane's 4 tiles = 8 consecutive output columns
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = n0 + (wn * NT + nt) * 16 + li;
+        if (co >= a.Cout) continue;
+        const float sc = a.ep_scale[co], sh = a.ep_shift[co];
+        float y[2][8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s[2][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float m0 = acc[0 + c][nt][r], m1 = acc[4 + c][nt][r], m2 = acc[8 + c][nt][r], m3 = acc[12 + c][nt][r];
+                s[0][c] = m0 + m1 + m2;
+                s[1][c] = m1 - m2 - m3;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                y[i][2 * r + 0] = s[i][0] + s[i][1] + s[i][2];
+                y[i][2 * r + 1] = s[i][1] - s[i][2] - s[i][3];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int yy = yb + i;
+            if (yy >= a.H || xb >= a.W) continue;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = y[i][j] * sc + sh;
+                if (a.relu) v[j] = v[j] > 0.f ? v[j] : 0.f;
+            }
+            const uint32_t e = (uint32_t)((co * a.H + yy) * a.W + xb);
+            if (a.drop_site >= 0) {
+                const uint32_t w = wino_dropout_word(e, (uint32_t)a.drop_site, (uint32_t)(a.sample0 + n), a.seed) >> (e & 31);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = ((w >> j) & 1u) ? v[j] * 2.f : 0.f;
+            }
+            float *dst = out_n + (int64_t)co * plane + (int64_t)yy * a.W + xb;
+            *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4 *>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+}
+
+// Winograd is used for 3x3 layers whose geometry keeps every access aligned: W a multiple of 8
+// (float4 stores, one Philox word per 8 outputs), H even, Cout a multiple of 64.
+bool wino_supported(int ks, int cin, int cout, int H, int W) {
+    return ks == 3 && cin >= 4 && cout % 64 == 0 && (W % 8) == 0 && (H % 2) == 0;
+}
+int wino_cout_tile() { return 64; }
+
+// Caffe (Cout,Cin,3,3) -> U = G g G^T, laid out [ceil(Cin/4)][Cout/64][slab], slab row p*4 + ci%4, stride BNP.
+void wino_pack_weights(const float *W, int cin, int cout, std::vector<float> &out, int *cout_pad) {
+    const int bn = 64, bnp = wino_bnp(bn), slab = wino_slab(bn);
+    const int ntiles = cout / bn, nchunks = (cin + 3) / 4;
+    *cout_pad = cout;
+    out.assign((size_t)nchunks * ntiles * slab, 0.f);
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float *g = W + ((size_t)co * cin + ci) * 9;
+            double tmp[4][3], U[4][4];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 3; ++j) tmp[i][j] = G[i][0] * g[0 * 3 + j] + G[i][1] * g[1 * 3 + j] + G[i][2] * g[2 * 3 + j];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) U[i][j] = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
+            const size_t base = ((size_t)(ci / 4) * ntiles + co / bn) * slab;
+            for (int p = 0; p < 16; ++p) out[base + (size_t)(p * 4 + ci % 4) * bnp + co % bn] = (float)U[p / 4][p % 4];
+        }
+}
+
+void launch_conv_wino(const ConvArgs &a0, hipStream_t s) {
+    ConvArgs a = a0;
+    constexpr int WM = 2, WN = 2, NT = 2;
+    a.tiles_x = (a.W + 31) / 32;
+    a.tiles_y = (a.H + 2 * WM - 1) / (2 * WM);
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)(a.CoutPad / 64));
+    hipLaunchKernelGGL((conv_wino_kernel<WM, WN, NT>), grid, dim3(256), 0, s, a);
+}
+
+}  // namespace sivo

@@ -50,6 +50,7 @@ struct Op {
     float *d_w = nullptr, *d_scale = nullptr, *d_shift = nullptr;
     bool relu = false;
     bool v2 = false;           // conv_v2.hip kernel + weight layout
+    bool wino = false;         // conv_wino.hip kernel + pre-transformed weights
     int drop_site = -1;
     // lrn
     int local_size = 5;
@@ -123,12 +124,16 @@ int new_blob(sivo_segnet &S, const std::string &name, int C, int H, int W, bool 
 
 // Re-layout Caffe (Cout,Cin,k,k) weights to [ceil(Cin/KC)][k*k][KC][CoutPad] and fold
 // bias (+ BN scale/shift) into the epilogue's per-channel affine.
-void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias) {
+void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int H, int Wd) {
     const int ks = op.ks, cin = op.cin, cout = op.cout;
     std::vector<float> wt;
     static const bool force_v1 = std::getenv("SIVO_CONV_V1") != nullptr;
-    op.v2 = conv2_supported(ks) && !force_v1;
-    if (op.v2) {
+    static const bool no_wino = std::getenv("SIVO_NO_WINOGRAD") != nullptr;
+    op.wino = !no_wino && wino_supported(ks, cin, cout, H, Wd);
+    op.v2 = !op.wino && conv2_supported(ks) && !force_v1;
+    if (op.wino) {
+        wino_pack_weights(W, cin, cout, wt, &op.cout_pad);
+    } else if (op.v2) {
         conv2_pack_weights(W, ks, cin, cout, wt, &op.cout_pad);
     } else {
         const int KC = conv_k_chunk(ks, cin), BN = conv_cout_tile(ks, cout);
@@ -207,14 +212,16 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             op.kind = OP_CONV; op.in = bi; op.ks = L.kernel_size; op.cin = b.C; op.cout = L.num_output;
             op.out = new_blob(S, L.top[0], L.num_output, b.H, b.W, b.shared);
             const size_t nw = (size_t)op.cout * op.cin * op.ks * op.ks;
-            upload_conv(S, op, weights + woff, weights + woff + nw);
+            upload_conv(S, op, weights + woff, weights + woff + nw, b.H, b.W);
             woff += nw + op.cout;
             op.flops = 2.0 * op.ks * op.ks * op.cin * op.cout * (double)b.H * b.W;
             op.name = L.name;
             {
                 char kn[96];
                 const int bn = conv_cout_tile(op.ks, op.cout), kc = conv_k_chunk(op.ks, op.cin);
-                if (op.v2)
+                if (op.wino)
+                    snprintf(kn, sizeof kn, "conv_wino_kernel<2,2,2>");
+                else if (op.v2)
                     snprintf(kn, sizeof kn, "conv_mfma2_kernel<%d,%d,32,%d,%d,%d>", op.ks, bn == 128 ? 4 : 8, bn, bn == 128 ? 2 : 4,
                              bn == 128 ? 2 : 1);
                 else
@@ -373,7 +380,9 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
                 a.out = (float *)bo.d;
                 a.N = N; a.Cin = op.cin; a.H = bi.H; a.W = bi.W; a.Cout = op.cout; a.CoutPad = op.cout_pad;
                 a.relu = op.relu; a.drop_site = op.drop_site; a.sample0 = sample0; a.seed = seed;
-                if (op.v2) launch_conv2(a, op.ks, st); else launch_conv(a, op.ks, st);
+                if (op.wino) launch_conv_wino(a, st);
+                else if (op.v2) launch_conv2(a, op.ks, st);
+                else launch_conv(a, op.ks, st);
                 break;
             }
             case OP_POOL: {
@@ -632,11 +641,12 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
 extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, int iters, int variant, double *ms_out) {
     return guarded([&] {
         if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device");
-        const bool v2 = (variant & 16) && conv2_supported(ks);
+        const bool wino = (variant & 64) && wino_supported(ks, Cin, Cout, H, W);
+        const bool v2 = !wino && (variant & 16) && conv2_supported(ks);
         const int KC = v2 ? 4 : conv_k_chunk(ks, Cin), BN = conv_cout_tile(ks, Cout);
         const int cout_pad = cdiv(Cout, BN) * BN, nchunks = cdiv(Cin, KC);
         const size_t nin = (size_t)N * Cin * H * W, nout = (size_t)N * Cout * H * W;
-        const size_t nw = v2 ? (size_t)nchunks * (cout_pad / BN) * conv2_slab_floats(ks, Cout) : (size_t)nchunks * ks * ks * KC * cout_pad;
+        const size_t nw = wino ? (size_t)cdiv(Cin, 4) * (Cout / 64) * 5120 : v2 ? (size_t)nchunks * (cout_pad / BN) * conv2_slab_floats(ks, Cout) : (size_t)nchunks * ks * ks * KC * cout_pad;
         std::vector<float> hin(nin), hw(nw), hs(Cout, 1.f);
         uint32_t st = 12345;
         auto rnd = [&] { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
@@ -651,9 +661,11 @@ extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, i
         a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.CoutPad = cout_pad; a.relu = 1; a.drop_site = -1; a.variant = variant;
         hipEvent_t e0, e1;
         SIVO_HIP(hipEventCreate(&e0)); SIVO_HIP(hipEventCreate(&e1));
-        for (int i = 0; i < 2; ++i) { if (v2) launch_conv2(a, ks, nullptr); else launch_conv(a, ks, nullptr); }
+        auto go = [&] { if (wino) launch_conv_wino(a, nullptr); else if (v2) launch_conv2(a, ks, nullptr); else launch_conv(a, ks, nullptr); };
+        if (wino) a.CoutPad = Cout;
+        for (int i = 0; i < 2; ++i) go();
         SIVO_HIP(hipEventRecord(e0, nullptr));
-        for (int i = 0; i < iters; ++i) { if (v2) launch_conv2(a, ks, nullptr); else launch_conv(a, ks, nullptr); }
+        for (int i = 0; i < iters; ++i) go();
         SIVO_HIP(hipEventRecord(e1, nullptr));
         SIVO_HIP(hipEventSynchronize(e1));
         float ms = 0;

@@ -30,6 +30,10 @@ bool conv2_supported(int ks);
 int conv2_slab_floats(int ks, int cout);
 void conv2_pack_weights(const float *W, int ks, int cin, int cout, std::vector<float> &out, int *cout_pad);
 void launch_conv2(const ConvArgs &a, int ks, hipStream_t s);
+// Winograd F(2x2,3x3) kernel (conv_wino.hip)
+bool wino_supported(int ks, int cin, int cout, int H, int W);
+void wino_pack_weights(const float *W, int cin, int cout, std::vector<float> &out, int *cout_pad);
+void launch_conv_wino(const ConvArgs &a, hipStream_t s);
 
 struct PoolArgs {
     const float *in;
