@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a) {
     constexpr int WSLAB = wino_slab(BN);
     constexpr int PATCH = KC * CS;
     constexpr int BUF = PATCH + WSLAB;
-    static_assert(WM * WN == 4, "4 waves");
+    static_assert(WM * WN == 4 && NT == 2, "4 waves, paired n-tiles");
 
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a) {
 
     // 4x4 input patch of tile (row wm, column li): LDS rows 2*wm .. 2*wm+3, columns OFF-1+2*li .. +3
     const int a_base = lk * CS + (2 * wm) * PWp + (OFF - 1) + 2 * li;
-    const int b_base = PATCH + lk * BNP + wn * NT * 16 + li;
+    // B pair: the two 16-cout n-tiles of this wave's 32 couts are interleaved in the slab (one ds_read_b64 per position)
+    const int b_base = PATCH + lk * BNP + wn * 32 + 2 * li;
 
     f32x4 acc[16][NT];
 #pragma unroll
@@ -188,11 +189,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a) {
         // ---- 16 positions x NT MFMAs
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float bf = sp[b_base + p * KC * BNP + nt * 16];
-                acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[p], bf, acc[p][nt], 0, 0, 0);
-            }
+            const float2 bf = *reinterpret_cast<const float2 *>(sp + b_base + p * KC * BNP);
+            acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[p], bf.x, acc[p][0], 0, 0, 0);
+            acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[p], bf.y, acc[p][1], 0, 0, 0);
             if (p == 10 && more) commit_patch(cur ^ 1);
         }
         __syncthreads();
@@ -269,7 +268,9 @@ void wino_pack_weights(const float *W, int cin, int cout, std::vector<float> &ou
             for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 4; ++j) U[i][j] = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
             const size_t base = ((size_t)(ci / 4) * ntiles + co / bn) * slab;
-            for (int p = 0; p < 16; ++p) out[base + (size_t)(p * 4 + ci % 4) * bnp + co % bn] = (float)U[p / 4][p % 4];
+            // within each 32-cout group the two 16-cout n-tiles are interleaved (one ds_read_b64 feeds both MFMAs)
+            const int cl = co % bn, col = (cl / 32) * 32 + 2 * (cl % 16) + (cl % 32) / 16;
+            for (int p = 0; p < 16; ++p) out[base + (size_t)(p * 4 + ci % 4) * bnp + col] = (float)U[p / 4][p % 4];
         }
 }
 
