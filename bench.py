@@ -226,7 +226,7 @@ def main():
             k["ms"] += p["ms_total"]; k["launches"] += p["launches"]
             k["flops"] += p["flops_per_sample"] * p["samples"] * p["launches"]
             k["bytes"] += p["bytes_per_sample"] * p["samples"] * p["launches"]
-        conv = {k: v for k, v in by_kernel.items() if k.startswith("conv_mfma")}
+        conv = {k: v for k, v in by_kernel.items() if k.startswith("conv_")}
         dom_name, dom = max(conv.items(), key=lambda kv: kv[1]["ms"])
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         # Winograd F(2x2,3x3) executes 16 MFMA multiplies per 4 outputs instead of 36: the matrix cores do
