@@ -234,8 +234,15 @@ def main():
         exec_ratio = (1 / 2.25) if dom_name.startswith("conv_wino") else 1.0
         conv_ms = sum(v["ms"] for v in conv.values()); conv_fl = sum(v["flops"] for v in conv.values())
         all_ms = sum(v["ms"] for v in by_kernel.values())
+        traffic = None
+        try:   # HBM bytes per launch of the dominant kernel from the committed PMC pass (bench cannot collect PMC itself)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")))
+            traffic = tj.get(dom_name, {}).get("bytes")
+        except Exception:
+            pass
         roofline = {"bound": "mfma", "kernel": "sivo::" + dom_name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": "profiles/r01_g_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, bytes per launch)" if traffic else None,
                     "mfma_executed_tflops": round(achieved * exec_ratio, 2), "mfma_util": round(achieved * exec_ratio / FP32_MFMA_PEAK_TFLOPS, 4),
                     "note": "achieved = algorithmic direct-conv FLOPs / HIP-event time; the dominant kernel is Winograd F(2x2,3x3) in fp32, which issues 2.25x fewer MFMA flops (mfma_util = executed MFMA flops / peak)" if exec_ratio < 1 else "",
                     "launches_per_frame": dom["launches"] / args.steps,

@@ -69,13 +69,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : 3)) void conv_mfm
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 15, lk = lane >> 4;
 
-    int bid = blockIdx.x;
+    // XCD-aware tile order (see conv_wino.hip): workgroups of one XCD walk the Cout tiles of a pixel tile
+    const int ntiles = a.CoutPad / BN;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ntile = slot % ntiles;
+    int bid = (slot / ntiles) * 8 + xcd;
+    if (bid >= a.tiles_x * a.tiles_y * a.N) return;
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
     const int ty = bid % a.tiles_y; bid /= a.tiles_y;
     const int n = bid;
     const int x0 = tx * TW, y0 = ty * TH;
-    const int ntile = blockIdx.y, n0 = ntile * BN;
-    const int ntiles = a.CoutPad / BN;
+    const int n0 = ntile * BN;
 
     const float *in_n = a.in + (int64_t)n * a.in_sample_stride;
     const int64_t plane = (int64_t)a.H * a.W;
@@ -265,7 +269,8 @@ static void launch2_cfg(const ConvArgs &a0, hipStream_t s) {
     ConvArgs a = a0;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
-    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)(a.CoutPad / BN));
+    const int ptiles = a.tiles_x * a.tiles_y * a.N;
+    dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * (a.CoutPad / BN)));
     hipLaunchKernelGGL((conv_mfma2_kernel<KS, TH, TW, BN, WM, WN>), grid, dim3(WM * WN * 64), 0, s, a);
 }
 
