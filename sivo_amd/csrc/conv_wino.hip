@@ -47,7 +47,7 @@ constexpr int wino_slab(int bn) { return (16 * 4 * wino_bnp(bn) + 255) / 256 * 2
 
 // Workgroup: WM m-tiles stacked vertically (2*WM output rows x 32 output columns) x BN = WN*NT*16 couts.
 template <int WM, int WN, int NT>
-__global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 3) void conv_wino_kernel(ConvArgs a) {
     constexpr int KC = 4, BN = WN * NT * 16, BNP = wino_bnp(BN);
     constexpr int TH = 2 * WM, TW = 32;
     constexpr int OFF = 4, PH = TH + 2, PWp = TW + 8;
@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a) {
     // 4x4 input patch of tile (row wm, column li): LDS rows 2*wm .. 2*wm+3, columns OFF-1+2*li .. +3
     const int a_base = lk * CS + (2 * wm) * PWp + (OFF - 1) + 2 * li;
     // B pair: the two 16-cout n-tiles of this wave's 32 couts are interleaved in the slab (one ds_read_b64 per position)
-    const int b_base = PATCH + lk * BNP + wn * 32 + 2 * li;
+    // (odd slab rows are shifted by 16 dwords into the row padding: the two rows a 32-lane half reads then sit on
+    //  disjoint bank halves of the 64-bank ds_read_b64 — conflict-free with the 80-dword stride)
+    const int b_base = PATCH + lk * BNP + (lk & 1) * 16 + wn * 32 + 2 * li;
 
     f32x4 acc[16][NT];
 #pragma unroll
@@ -277,7 +279,7 @@ void wino_pack_weights(const float *W, int cin, int cout, std::vector<float> &ou
             const size_t base = ((size_t)(ci / 4) * ntiles + co / bn) * slab;
             // within each 32-cout group the two 16-cout n-tiles are interleaved (one ds_read_b64 feeds both MFMAs)
             const int cl = co % bn, col = (cl / 32) * 32 + 2 * (cl % 16) + (cl % 32) / 16;
-            for (int p = 0; p < 16; ++p) out[base + (size_t)(p * 4 + ci % 4) * bnp + col] = (float)U[p / 4][p % 4];
+            for (int p = 0; p < 16; ++p) out[base + (size_t)(p * 4 + ci % 4) * bnp + ((ci % 4) & 1) * 16 + col] = (float)U[p / 4][p % 4];
         }
 }
 
