@@ -42,17 +42,17 @@ __device__ __forceinline__ uint32_t wino_dropout_word(uint32_t e, uint32_t site,
     return sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
 }
 
-constexpr int wino_bnp(int bn) { return (bn % 32 == 0) ? bn + 16 : bn; }
-constexpr int wino_slab(int bn) { return (16 * 4 * wino_bnp(bn) + 255) / 256 * 256; }   // floats, whole KiB
+constexpr int wino_bnp(int bn) { return bn == 64 ? 80 : bn; }   // 64: 80-dword rows with odd rows shifted by 16; 32: dense rows (both conflict-free for ds_read_b64)
+constexpr int wino_slab(int bn, int kc) { return (16 * kc * wino_bnp(bn) + 255) / 256 * 256; }   // floats, whole KiB
 
 // Workgroup: WM m-tiles stacked vertically (2*WM output rows x 32 output columns) x BN = WN*NT*16 couts.
-template <int WM, int WN, int NT>
-__global__ __launch_bounds__(256, 3) void conv_wino_kernel(ConvArgs a) {
-    constexpr int KC = 4, BN = WN * NT * 16, BNP = wino_bnp(BN);
+template <int WM, int WN, int NT, int KC>
+__global__ __launch_bounds__(256, (KC == 4 ? 3 : 2)) void conv_wino_kernel(ConvArgs a) {
+    constexpr int BN = WN * NT * 16, BNP = wino_bnp(BN);
     constexpr int TH = 2 * WM, TW = 32;
     constexpr int OFF = 4, PH = TH + 2, PWp = TW + 8;
     constexpr int CS = (PH * PWp + 3) / 4 * 4 + 4;         // channel stride (dwords), multiple of 4; +4 de-phases the banks
-    constexpr int WSLAB = wino_slab(BN);
+    constexpr int WSLAB = wino_slab(BN, KC);
     constexpr int PATCH = KC * CS;
     constexpr int BUF = PATCH + WSLAB;
     static_assert(WM * WN == 4 && NT == 2, "4 waves, paired n-tiles");
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(ConvArgs a) {
     // B pair: the two 16-cout n-tiles of this wave's 32 couts are interleaved in the slab (one ds_read_b64 per position)
     // (odd slab rows are shifted by 16 dwords into the row padding: the two rows a 32-lane half reads then sit on
     //  disjoint bank halves of the 64-bank ds_read_b64 — conflict-free with the 80-dword stride)
-    const int b_base = PATCH + lk * BNP + (lk & 1) * 16 + wn * 32 + 2 * li;
+    const int b_base = PATCH + lk * BNP + (BN == 64 ? (lk & 1) * 16 : 0) + wn * 32 + 2 * li;
 
     f32x4 acc[16][NT];
 #pragma unroll
@@ -175,33 +175,36 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(ConvArgs a) {
         issue_patch(more ? chunk + 1 : chunk);
         if (more) dma_weights(chunk + 1, cur ^ 1);
         const float *sp = lds + cur * BUF;
-        // ---- input transform V = B^T d B of this lane's (tile, channel)
-        float d[4][4], t[4][4], V[16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int c4 = 0; c4 < KC / 4; ++c4) {
+            // ---- input transform V = B^T d B of this lane's (tile, channel c4*4 + lk)
+            float d[4][4], t[4][4], V[16];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) d[r][c] = sp[a_base + r * PWp + c];
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            t[0][c] = d[0][c] - d[2][c];
-            t[1][c] = d[1][c] + d[2][c];
-            t[2][c] = d[2][c] - d[1][c];
-            t[3][c] = d[1][c] - d[3][c];
-        }
+                for (int c = 0; c < 4; ++c) d[r][c] = sp[a_base + c4 * 4 * CS + r * PWp + c];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            V[r * 4 + 0] = t[r][0] - t[r][2];
-            V[r * 4 + 1] = t[r][1] + t[r][2];
-            V[r * 4 + 2] = t[r][2] - t[r][1];
-            V[r * 4 + 3] = t[r][1] - t[r][3];
-        }
-        // ---- 16 positions x NT MFMAs
+            for (int c = 0; c < 4; ++c) {
+                t[0][c] = d[0][c] - d[2][c];
+                t[1][c] = d[1][c] + d[2][c];
+                t[2][c] = d[2][c] - d[1][c];
+                t[3][c] = d[1][c] - d[3][c];
+            }
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const float2 bf = *reinterpret_cast<const float2 *>(sp + b_base + p * KC * BNP);
-            acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[p], bf.x, acc[p][0], 0, 0, 0);
-            acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[p], bf.y, acc[p][1], 0, 0, 0);
-            if (p == 10 && more) commit_patch(cur ^ 1);
+            for (int r = 0; r < 4; ++r) {
+                V[r * 4 + 0] = t[r][0] - t[r][2];
+                V[r * 4 + 1] = t[r][1] + t[r][2];
+                V[r * 4 + 2] = t[r][2] - t[r][1];
+                V[r * 4 + 3] = t[r][1] - t[r][3];
+            }
+            // ---- 16 positions x 2 MFMAs
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const float2 bf = *reinterpret_cast<const float2 *>(sp + b_base + (p * KC + c4 * 4) * BNP);
+                acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[p], bf.x, acc[p][0], 0, 0, 0);
+                acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[p], bf.y, acc[p][1], 0, 0, 0);
+                if (c4 == KC / 4 - 1 && p == 10 && more) commit_patch(cur ^ 1);
+            }
         }
         __syncthreads();
     }
@@ -255,16 +258,22 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(ConvArgs a) {
 }
 
 // Winograd is used for 3x3 layers whose geometry keeps every access aligned: W a multiple of 8
-// (float4 stores, one Philox word per 8 outputs), H even, Cout a multiple of 64.
+// (float4 stores, one Philox word per 8 outputs), H even, Cout a multiple of the Cout tile.
+// Two tilings: cfg 0 = 4 x 32 px x 64 couts, K-chunk 4 (3 workgroups/CU); cfg 1 = 8 x 32 px x 32 couts,
+// K-chunk 8 (2 workgroups/CU, half as many barriers per MFMA).
+static int wino_bn(int cfg) { return cfg == 1 ? 32 : 64; }
+static int wino_kc(int cfg) { return cfg == 1 ? 8 : 4; }
 bool wino_supported(int ks, int cin, int cout, int H, int W) {
     return ks == 3 && cin >= 4 && cout % 64 == 0 && (W % 8) == 0 && (H % 2) == 0;
 }
-int wino_cout_tile() { return 64; }
+int wino_slab_floats(int cfg) { return wino_slab(wino_bn(cfg), wino_kc(cfg)); }
+int wino_chunks(int cfg, int cin) { return (cin + wino_kc(cfg) - 1) / wino_kc(cfg); }
+int wino_cout_tile(int cfg) { return wino_bn(cfg); }
 
-// Caffe (Cout,Cin,3,3) -> U = G g G^T, laid out [ceil(Cin/4)][Cout/64][slab], slab row p*4 + ci%4, stride BNP.
-void wino_pack_weights(const float *W, int cin, int cout, std::vector<float> &out, int *cout_pad) {
-    const int bn = 64, bnp = wino_bnp(bn), slab = wino_slab(bn);
-    const int ntiles = cout / bn, nchunks = (cin + 3) / 4;
+// Caffe (Cout,Cin,3,3) -> U = G g G^T, laid out [ceil(Cin/KC)][Cout/BN][slab], slab row p*KC + ci%KC.
+void wino_pack_weights(const float *W, int cin, int cout, int cfg, std::vector<float> &out, int *cout_pad) {
+    const int bn = wino_bn(cfg), kc = wino_kc(cfg), bnp = wino_bnp(bn), slab = wino_slab(bn, kc);
+    const int ntiles = cout / bn, nchunks = (cin + kc - 1) / kc;
     *cout_pad = cout;
     out.assign((size_t)nchunks * ntiles * slab, 0.f);
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
@@ -276,21 +285,28 @@ void wino_pack_weights(const float *W, int cin, int cout, std::vector<float> &ou
                 for (int j = 0; j < 3; ++j) tmp[i][j] = G[i][0] * g[0 * 3 + j] + G[i][1] * g[1 * 3 + j] + G[i][2] * g[2 * 3 + j];
             for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 4; ++j) U[i][j] = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
-            const size_t base = ((size_t)(ci / 4) * ntiles + co / bn) * slab;
+            const size_t base = ((size_t)(ci / kc) * ntiles + co / bn) * slab;
             // within each 32-cout group the two 16-cout n-tiles are interleaved (one ds_read_b64 feeds both MFMAs)
             const int cl = co % bn, col = (cl / 32) * 32 + 2 * (cl % 16) + (cl % 32) / 16;
-            for (int p = 0; p < 16; ++p) out[base + (size_t)(p * 4 + ci % 4) * bnp + ((ci % 4) & 1) * 16 + col] = (float)U[p / 4][p % 4];
+            const int c = ci % kc, shift = bn == 64 ? (c & 1) * 16 : 0;
+            for (int p = 0; p < 16; ++p) out[base + (size_t)(p * kc + c) * bnp + shift + col] = (float)U[p / 4][p % 4];
         }
 }
 
-void launch_conv_wino(const ConvArgs &a0, hipStream_t s) {
+template <int WM, int WN, int NT, int KC>
+static void launch_wino_cfg(const ConvArgs &a0, hipStream_t s) {
     ConvArgs a = a0;
-    constexpr int WM = 2, WN = 2, NT = 2;
+    constexpr int BN = WN * NT * 16;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + 2 * WM - 1) / (2 * WM);
     const int ptiles = a.tiles_x * a.tiles_y * a.N;
-    dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * (a.CoutPad / 64)));
-    hipLaunchKernelGGL((conv_wino_kernel<WM, WN, NT>), grid, dim3(256), 0, s, a);
+    dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * (a.CoutPad / BN)));
+    hipLaunchKernelGGL((conv_wino_kernel<WM, WN, NT, KC>), grid, dim3(256), 0, s, a);
+}
+
+void launch_conv_wino(const ConvArgs &a, int cfg, hipStream_t s) {
+    if (cfg == 1) return launch_wino_cfg<4, 1, 2, 8>(a, s);
+    return launch_wino_cfg<2, 2, 2, 4>(a, s);
 }
 
 }  // namespace sivo

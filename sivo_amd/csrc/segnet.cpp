@@ -51,6 +51,7 @@ struct Op {
     bool relu = false;
     bool v2 = false;           // conv_v2.hip kernel + weight layout
     bool wino = false;         // conv_wino.hip kernel + pre-transformed weights
+    int wino_cfg = 0;
     int drop_site = -1;
     // lrn
     int local_size = 5;
@@ -132,7 +133,9 @@ void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int 
     op.wino = !no_wino && wino_supported(ks, cin, cout, H, Wd);
     op.v2 = !op.wino && conv2_supported(ks) && !force_v1;
     if (op.wino) {
-        wino_pack_weights(W, cin, cout, wt, &op.cout_pad);
+        static const int env_cfg = std::getenv("SIVO_WINO_CFG") ? std::atoi(std::getenv("SIVO_WINO_CFG")) : 0;
+        op.wino_cfg = env_cfg;
+        wino_pack_weights(W, cin, cout, op.wino_cfg, wt, &op.cout_pad);
     } else if (op.v2) {
         conv2_pack_weights(W, ks, cin, cout, wt, &op.cout_pad);
     } else {
@@ -220,7 +223,7 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
                 char kn[96];
                 const int bn = conv_cout_tile(op.ks, op.cout), kc = conv_k_chunk(op.ks, op.cin);
                 if (op.wino)
-                    snprintf(kn, sizeof kn, "conv_wino_kernel<2,2,2>");
+                    snprintf(kn, sizeof kn, op.wino_cfg == 1 ? "conv_wino_kernel<4,1,2,8>" : "conv_wino_kernel<2,2,2,4>");
                 else if (op.v2)
                     snprintf(kn, sizeof kn, "conv_mfma2_kernel<%d,%d,32,%d,%d,%d>", op.ks, bn == 128 ? 4 : 8, bn, bn == 128 ? 2 : 4,
                              bn == 128 ? 2 : 1);
@@ -380,7 +383,7 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
                 a.out = (float *)bo.d;
                 a.N = N; a.Cin = op.cin; a.H = bi.H; a.W = bi.W; a.Cout = op.cout; a.CoutPad = op.cout_pad;
                 a.relu = op.relu; a.drop_site = op.drop_site; a.sample0 = sample0; a.seed = seed;
-                if (op.wino) launch_conv_wino(a, st);
+                if (op.wino) launch_conv_wino(a, op.wino_cfg, st);
                 else if (op.v2) launch_conv2(a, op.ks, st);
                 else launch_conv(a, op.ks, st);
                 break;
@@ -642,11 +645,12 @@ extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, i
     return guarded([&] {
         if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device");
         const bool wino = (variant & 64) && wino_supported(ks, Cin, Cout, H, W);
+        const int wcfg = (variant & 128) ? 1 : 0;
         const bool v2 = !wino && (variant & 16) && conv2_supported(ks);
         const int KC = v2 ? 4 : conv_k_chunk(ks, Cin), BN = conv_cout_tile(ks, Cout);
         const int cout_pad = cdiv(Cout, BN) * BN, nchunks = cdiv(Cin, KC);
         const size_t nin = (size_t)N * Cin * H * W, nout = (size_t)N * Cout * H * W;
-        const size_t nw = wino ? (size_t)cdiv(Cin, 4) * (Cout / 64) * 5120 : v2 ? (size_t)nchunks * (cout_pad / BN) * conv2_slab_floats(ks, Cout) : (size_t)nchunks * ks * ks * KC * cout_pad;
+        const size_t nw = wino ? (size_t)wino_chunks(wcfg, Cin) * (Cout / wino_cout_tile(wcfg)) * wino_slab_floats(wcfg) : v2 ? (size_t)nchunks * (cout_pad / BN) * conv2_slab_floats(ks, Cout) : (size_t)nchunks * ks * ks * KC * cout_pad;
         std::vector<float> hin(nin), hw(nw), hs(Cout, 1.f);
         uint32_t st = 12345;
         auto rnd = [&] { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
@@ -661,7 +665,7 @@ extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, i
         a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.CoutPad = cout_pad; a.relu = 1; a.drop_site = -1; a.variant = variant;
         hipEvent_t e0, e1;
         SIVO_HIP(hipEventCreate(&e0)); SIVO_HIP(hipEventCreate(&e1));
-        auto go = [&] { if (wino) launch_conv_wino(a, nullptr); else if (v2) launch_conv2(a, ks, nullptr); else launch_conv(a, ks, nullptr); };
+        auto go = [&] { if (wino) launch_conv_wino(a, wcfg, nullptr); else if (v2) launch_conv2(a, ks, nullptr); else launch_conv(a, ks, nullptr); };
         if (wino) a.CoutPad = Cout;
         for (int i = 0; i < 2; ++i) go();
         SIVO_HIP(hipEventRecord(e0, nullptr));

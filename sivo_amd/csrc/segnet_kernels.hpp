@@ -32,8 +32,11 @@ void conv2_pack_weights(const float *W, int ks, int cin, int cout, std::vector<f
 void launch_conv2(const ConvArgs &a, int ks, hipStream_t s);
 // Winograd F(2x2,3x3) kernel (conv_wino.hip)
 bool wino_supported(int ks, int cin, int cout, int H, int W);
-void wino_pack_weights(const float *W, int cin, int cout, std::vector<float> &out, int *cout_pad);
-void launch_conv_wino(const ConvArgs &a, hipStream_t s);
+void wino_pack_weights(const float *W, int cin, int cout, int cfg, std::vector<float> &out, int *cout_pad);
+void launch_conv_wino(const ConvArgs &a, int cfg, hipStream_t s);
+int wino_slab_floats(int cfg);
+int wino_chunks(int cfg, int cin);
+int wino_cout_tile(int cfg);
 
 struct PoolArgs {
     const float *in;

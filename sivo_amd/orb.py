@@ -31,7 +31,10 @@ class ORBextractor:
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            lib().sivo_orb_destroy(h)
+            try:
+                lib().sivo_orb_destroy(h)
+            except Exception:      # interpreter shutdown: the module globals may already be gone
+                pass
             self._h = None
 
     # accessors of ORBextractor.h:62-84

@@ -59,7 +59,10 @@ class BayesianSegNet:
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            lib().sivo_segnet_destroy(h)
+            try:
+                lib().sivo_segnet_destroy(h)
+            except Exception:      # interpreter shutdown: the module globals may already be gone
+                pass
             self._h = None
 
     def get_input_geometry(self):
