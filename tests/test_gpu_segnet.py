@@ -173,3 +173,37 @@ def test_mc_reduce_random(oracle, T, K, H, W):
         np.testing.assert_allclose(ps2.cpu().numpy(), ps.cpu().numpy(), atol=1e-6, rtol=0)
     var = mc_variance(prob, cls)
     np.testing.assert_allclose(var.cpu().numpy(), oracle.mc_variance(prob_o, cls.cpu().numpy()), atol=1e-7, rtol=0)
+
+
+def _conv_stack_prototxt(T, H, W, width):
+    """data -> conv3x3(3->width) -> ReLU -> Dropout -> conv3x3(width->width)+BN+ReLU+Dropout -> conv3x3(width->width) ->
+    conv1x1(width->15) -> Softmax: exercises the direct kernel (Cin = 3), the Winograd kernel with every
+    epilogue option (BN, ReLU, dropout) and without, and the 1x1 kernel."""
+    from sivo_amd.netspec import _bn, _conv, _drop, _relu, _softmax
+    out = [f'name: "conv_stack"\ninput: "data"\ninput_dim: {T}\ninput_dim: 3\ninput_dim: {H}\ninput_dim: {W}\n']
+    out += [_conv("c0", "data", "c0", width, 3, 1), _relu("r0", "c0"), _drop("d0", "c0")]
+    out += [_conv("c1", "c0", "c1", width, 3, 1), _bn("c1_bn", "c1"), _relu("r1", "c1"), _drop("d1", "c1")]
+    out += [_conv("c2", "c1", "c2", width, 3, 1)]
+    out += [_conv("cls", "c2", "cls", 15, 1, 0), _softmax("cls")]
+    return "".join(out)
+
+
+@pytest.mark.parametrize("H,W,width", [(22, 64, 64), (44, 136, 128), (6, 8, 64), (32, 64, 192), (10, 20, 64)])
+def test_winograd_and_direct_conv_shapes(oracle, H, W, width):
+    """Ragged tile rows (H = 22 = 5.5 tiles of 4), widths that are multiples of 8 but not of 32, a Cout that is not a
+    multiple of 128, and a width (20) that falls back to the direct kernel: every blob against the oracle."""
+    T = 3
+    text = _conv_stack_prototxt(T, H, W, width)
+    net, w, sn = _make(text, T, seed=11)
+    img = _image(np.random.default_rng(H * W), H, W)
+    ob = oracle.run_net(net, w, oracle.preprocess(img, T, H, W), 31, sample0=2)
+    _, logits, _ = sn.forward(torch.from_numpy(img).cuda(), 31, sample0=2, want_logits=True)
+    torch.cuda.synchronize()
+    for name in ["c0", "c1", "c2", "cls"]:
+        g, o = sn.blob(name), ob[name]
+        np.testing.assert_allclose(g, o, atol=LOGIT_TOL, rtol=0, err_msg=name)
+        if name in ("c0", "c1"):
+            # dropout zero pattern is bit-exact; the only admissible differences are ReLU outputs within rounding of 0
+            mism = (g == 0) != (o == 0)
+            assert mism.mean() < 1e-4 and (np.abs(g[mism]) < 1e-4).all() and (np.abs(o[mism]) < 1e-4).all(), name
+    np.testing.assert_allclose(logits.cpu().numpy(), ob["cls"], atol=LOGIT_TOL, rtol=0)
