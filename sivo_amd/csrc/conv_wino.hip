@@ -46,16 +46,23 @@ constexpr int wino_bnp(int bn) { return bn == 64 ? 80 : bn; }   // 64: 80-dword 
 constexpr int wino_slab(int bn, int kc) { return (16 * kc * wino_bnp(bn) + 255) / 256 * 256; }   // floats, whole KiB
 
 // Workgroup: WM m-tiles stacked vertically (2*WM output rows x 32 output columns) x BN = WN*NT*16 couts.
-template <int WM, int WN, int NT, int KC>
-__global__ __launch_bounds__(256, (KC == 4 ? 3 : 2)) void conv_wino_kernel(ConvArgs a) {
+// ABL: ablation switches for tools/conv_probe.py only (0 in production): 1 no staging after the prologue,
+// 2 additionally no barrier, 4 additionally no input transform (V = raw patch), 8 additionally B from a register.
+template <int WM, int WN, int NT, int KC, int ABL = 0>
+__global__ __launch_bounds__(WM * WN * 64, ((KC == 4 || WM * WN == 12) ? 3 : 2)) void conv_wino_kernel(ConvArgs a) {
+    constexpr int NTHR = WM * WN * 64, NWAVE = WM * WN;
     constexpr int BN = WN * NT * 16, BNP = wino_bnp(BN);
     constexpr int TH = 2 * WM, TW = 32;
-    constexpr int OFF = 4, PH = TH + 2, PWp = TW + 8;
-    constexpr int CS = (PH * PWp + 3) / 4 * 4 + 4;         // channel stride (dwords), multiple of 4; +4 de-phases the banks
+    // Patch rows are stored DE-INTERLEAVED: with q = x - x0 + 1 in [0, 34), odd q go to O[q/2] at row offset 0..16 and
+    // even q to E[q/2] at row offset 19..35.  The 4x4 patch of tile t is then E[t], O[t], E[t+1], O[t+1] per row:
+    // the 16 lanes of an m-tile read CONSECUTIVE dwords (an interleaved row gives stride 2 = 2-way bank conflicts on
+    // every one of the 16 patch reads, 25 % of the LDS time of this LDS-bound kernel).  Channel stride = 16 (mod 32).
+    constexpr int PH = TH + 2, PWp = 36, EOFF = 19;
+    constexpr int CS = PH * PWp + ((16 - (PH * PWp) % 32) + 32) % 32;
     constexpr int WSLAB = wino_slab(BN, KC);
     constexpr int PATCH = KC * CS;
     constexpr int BUF = PATCH + WSLAB;
-    static_assert(WM * WN == 4 && NT == 2, "4 waves, paired n-tiles");
+    static_assert((NWAVE == 4 || NWAVE == 12) && NT == 2, "4 or 12 waves, paired n-tiles");
 
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
@@ -82,8 +89,8 @@ __global__ __launch_bounds__(256, (KC == 4 ? 3 : 2)) void conv_wino_kernel(ConvA
     const float *in_n = a.in + (int64_t)n * a.in_sample_stride;
     const int64_t plane = (int64_t)a.H * a.W;
 
-    // 4x4 input patch of tile (row wm, column li): LDS rows 2*wm .. 2*wm+3, columns OFF-1+2*li .. +3
-    const int a_base = lk * CS + (2 * wm) * PWp + (OFF - 1) + 2 * li;
+    // 4x4 input patch of tile (row wm, column li): LDS rows 2*wm .. 2*wm+3; columns q = 2*li .. 2*li+3
+    const int a_base = lk * CS + (2 * wm) * PWp + li;
     // B pair: the two 16-cout n-tiles of this wave's 32 couts are interleaved in the slab (one ds_read_b64 per position)
     // (odd slab rows are shifted by 16 dwords into the row padding: the two rows a 32-lane half reads then sit on
     //  disjoint bank halves of the 64-bank ds_read_b64 — conflict-free with the 80-dword stride)
@@ -96,28 +103,29 @@ __global__ __launch_bounds__(256, (KC == 4 ? 3 : 2)) void conv_wino_kernel(ConvA
         for (int nt = 0; nt < NT; ++nt) acc[p][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---- staging plan (as conv_v2): interior float4s + 2 halo scalars per patch row
-    constexpr int NV4 = KC * PH * (TW / 4), V4IT = (NV4 + 255) / 256;
-    constexpr int NSC = KC * PH * 2, SCIT = (NSC + 255) / 256;
+    constexpr int NV4 = KC * PH * (TW / 4), V4IT = (NV4 + NTHR - 1) / NTHR;
+    constexpr int NSC = KC * PH * 2, SCIT = (NSC + NTHR - 1) / NTHR;
     int v_goff[V4IT], v_dst[V4IT];
     bool v_ok[V4IT];
 #pragma unroll
     for (int it = 0; it < V4IT; ++it) {
-        const int idx = tid + it * 256;
+        const int idx = tid + it * NTHR;
         const int seg = idx % (TW / 4), r = idx / (TW / 4);
         const int py = r % PH, c = r / PH;
         const int gy = y0 + py - 1, gx = x0 + seg * 4;
         v_ok[it] = idx < NV4 && gy >= 0 && gy < a.H && gx + 3 < a.W;
         v_goff[it] = v_ok[it] ? (int)(c * plane + (int64_t)gy * a.W + gx) : 0;
-        v_dst[it] = idx < NV4 ? ((c * CS + py * PWp + OFF + seg * 4) | (c << 24)) : -1;
+        // pixels x0+4s..+3 are q = 4s+1..4s+4: (v0, v2) -> O[2s], O[2s+1]; (v1, v3) -> E[2s+1], E[2s+2]
+        v_dst[it] = idx < NV4 ? ((c * CS + py * PWp + 2 * seg) | (c << 24)) : -1;
     }
     int s_goff[SCIT], s_dst[SCIT];
 #pragma unroll
     for (int it = 0; it < SCIT; ++it) {
-        const int idx = tid + it * 256;
+        const int idx = tid + it * NTHR;
         const int h = idx % 2, r = idx / 2;
         const int py = r % PH, c = r / PH;
-        const int px = h == 0 ? OFF - 1 : OFF + TW;
-        const int gy = y0 + py - 1, gx = x0 + px - OFF;
+        const int px = h == 0 ? EOFF : 16;            // x = x0-1 is q = 0 -> E[0]; x = x0+32 is q = 33 -> O[16]
+        const int gy = y0 + py - 1, gx = h == 0 ? x0 - 1 : x0 + TW;
         const bool ok = idx < NSC && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         s_goff[it] = ok ? (int)(c * plane + (int64_t)gy * a.W + gx) : -1;
         s_dst[it] = idx < NSC ? ((c * CS + py * PWp + px) | (c << 24)) : -1;
@@ -146,18 +154,22 @@ __global__ __launch_bounds__(256, (KC == 4 ? 3 : 2)) void conv_wino_kernel(ConvA
         float *sp = lds + buf * BUF;
 #pragma unroll
         for (int it = 0; it < V4IT; ++it)
-            if (v_dst[it] >= 0) *reinterpret_cast<f32x4 *>(sp + (v_dst[it] & 0xffffff)) = pv4[it];
+            if (v_dst[it] >= 0) {
+                float *q = sp + (v_dst[it] & 0xffffff);
+                *reinterpret_cast<float2 *>(q) = make_float2(pv4[it][0], pv4[it][2]);                 // O[2s], O[2s+1]
+                *reinterpret_cast<float2 *>(q + EOFF + 1) = make_float2(pv4[it][1], pv4[it][3]);      // E[2s+1], E[2s+2]
+            }
 #pragma unroll
         for (int it = 0; it < SCIT; ++it)
             if (s_dst[it] >= 0) sp[s_dst[it] & 0xffffff] = psc[it];
     };
-    constexpr int NDMA = (WSLAB / 256 + 3) / 4;
+    constexpr int NDMA = (WSLAB / 256 + NWAVE - 1) / NWAVE;
     auto dma_weights = [&](int chunk, int buf) {
         const float *wsrc = a.wt + ((int64_t)chunk * ntiles + ntile) * WSLAB;
         float *dst = lds + buf * BUF + PATCH;
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
-            const int kib = i * 4 + wave;
+            const int kib = i * NWAVE + wave;
             if (kib < WSLAB / 256)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + kib * 256 + lane * 4),
                                                  (__attribute__((address_space(3))) void *)(dst + kib * 256), 16, 0, 0);
@@ -172,8 +184,8 @@ __global__ __launch_bounds__(256, (KC == 4 ? 3 : 2)) void conv_wino_kernel(ConvA
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int cur = chunk & 1;
         const bool more = chunk + 1 < nchunks;
-        issue_patch(more ? chunk + 1 : chunk);
-        if (more) dma_weights(chunk + 1, cur ^ 1);
+        if (!(ABL & 1)) issue_patch(more ? chunk + 1 : chunk);
+        if (more && !(ABL & 1)) dma_weights(chunk + 1, cur ^ 1);
         const float *sp = lds + cur * BUF;
 #pragma unroll
         for (int c4 = 0; c4 < KC / 4; ++c4) {
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(256, (KC == 4 ? 3 : 2)) void conv_wino_kernel(ConvA
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) d[r][c] = sp[a_base + c4 * 4 * CS + r * PWp + c];
+                for (int c = 0; c < 4; ++c) d[r][c] = sp[a_base + c4 * 4 * CS + r * PWp + ((c & 1) ? 0 : EOFF) + (c >> 1)];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 t[0][c] = d[0][c] - d[2][c];
@@ -190,6 +202,12 @@ __global__ __launch_bounds__(256, (KC == 4 ? 3 : 2)) void conv_wino_kernel(ConvA
                 t[2][c] = d[2][c] - d[1][c];
                 t[3][c] = d[1][c] - d[3][c];
             }
+            if (ABL & 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) V[r * 4 + c] = d[r][c];
+            } else
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 V[r * 4 + 0] = t[r][0] - t[r][2];
@@ -200,13 +218,13 @@ __global__ __launch_bounds__(256, (KC == 4 ? 3 : 2)) void conv_wino_kernel(ConvA
             // ---- 16 positions x 2 MFMAs
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
-                const float2 bf = *reinterpret_cast<const float2 *>(sp + b_base + (p * KC + c4 * 4) * BNP);
+                const float2 bf = (ABL & 8) ? make_float2(V[(p + 1) & 15], V[(p + 2) & 15]) : *reinterpret_cast<const float2 *>(sp + b_base + (p * KC + c4 * 4) * BNP);
                 acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[p], bf.x, acc[p][0], 0, 0, 0);
                 acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[p], bf.y, acc[p][1], 0, 0, 0);
-                if (c4 == KC / 4 - 1 && p == 10 && more) commit_patch(cur ^ 1);
+                if (c4 == KC / 4 - 1 && p == 10 && more && !(ABL & 1)) commit_patch(cur ^ 1);
             }
         }
-        __syncthreads();
+        if (!(ABL & 2)) __syncthreads();
     }
 
     // ---- output transform Y = A^T M A (lane-local) + epilogue
@@ -260,7 +278,8 @@ __global__ __launch_bounds__(256, (KC == 4 ? 3 : 2)) void conv_wino_kernel(ConvA
 // Winograd is used for 3x3 layers whose geometry keeps every access aligned: W a multiple of 8
 // (float4 stores, one Philox word per 8 outputs), H even, Cout a multiple of the Cout tile.
 // Two tilings: cfg 0 = 4 x 32 px x 64 couts, K-chunk 4 (3 workgroups/CU); cfg 1 = 8 x 32 px x 32 couts,
-// K-chunk 8 (2 workgroups/CU, half as many barriers per MFMA).
+// K-chunk 8 (2 workgroups/CU, half as many barriers per MFMA); cfg 2 = 12 x 32 px x 64 couts, K-chunk 4, 12 waves
+// (one workgroup per CU at 3 waves/SIMD: the weight slab is staged once for 3x as many MFMAs).
 static int wino_bn(int cfg) { return cfg == 1 ? 32 : 64; }
 static int wino_kc(int cfg) { return cfg == 1 ? 8 : 4; }
 bool wino_supported(int ks, int cin, int cout, int H, int W) {
@@ -293,7 +312,7 @@ void wino_pack_weights(const float *W, int cin, int cout, int cfg, std::vector<f
         }
 }
 
-template <int WM, int WN, int NT, int KC>
+template <int WM, int WN, int NT, int KC, int ABL = 0>
 static void launch_wino_cfg(const ConvArgs &a0, hipStream_t s) {
     ConvArgs a = a0;
     constexpr int BN = WN * NT * 16;
@@ -301,12 +320,20 @@ static void launch_wino_cfg(const ConvArgs &a0, hipStream_t s) {
     a.tiles_y = (a.H + 2 * WM - 1) / (2 * WM);
     const int ptiles = a.tiles_x * a.tiles_y * a.N;
     dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * (a.CoutPad / BN)));
-    hipLaunchKernelGGL((conv_wino_kernel<WM, WN, NT, KC>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_wino_kernel<WM, WN, NT, KC, ABL>), grid, dim3(WM * WN * 64), 0, s, a);
 }
 
 void launch_conv_wino(const ConvArgs &a, int cfg, hipStream_t s) {
     if (cfg == 1) return launch_wino_cfg<4, 1, 2, 8>(a, s);
-    return launch_wino_cfg<2, 2, 2, 4>(a, s);
+    if (cfg == 2) return launch_wino_cfg<6, 2, 2, 4>(a, s);   // 12 waves: 12 x 32 px x 64 couts, one workgroup per CU
+    switch (a.variant >> 8) {   // ablations, probe only
+        case 1: return launch_wino_cfg<2, 2, 2, 4, 1>(a, s);
+        case 3: return launch_wino_cfg<2, 2, 2, 4, 3>(a, s);
+        case 5: return launch_wino_cfg<2, 2, 2, 4, 5>(a, s);
+        case 9: return launch_wino_cfg<2, 2, 2, 4, 9>(a, s);
+        case 15: return launch_wino_cfg<2, 2, 2, 4, 15>(a, s);
+        default: return launch_wino_cfg<2, 2, 2, 4>(a, s);
+    }
 }
 
 }  // namespace sivo

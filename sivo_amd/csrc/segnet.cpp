@@ -223,7 +223,7 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
                 char kn[96];
                 const int bn = conv_cout_tile(op.ks, op.cout), kc = conv_k_chunk(op.ks, op.cin);
                 if (op.wino)
-                    snprintf(kn, sizeof kn, op.wino_cfg == 1 ? "conv_wino_kernel<4,1,2,8>" : "conv_wino_kernel<2,2,2,4>");
+                    snprintf(kn, sizeof kn, op.wino_cfg == 2 ? "conv_wino_kernel<6,2,2,4>" : op.wino_cfg == 1 ? "conv_wino_kernel<4,1,2,8>" : "conv_wino_kernel<2,2,2,4>");
                 else if (op.v2)
                     snprintf(kn, sizeof kn, "conv_mfma2_kernel<%d,%d,32,%d,%d,%d>", op.ks, bn == 128 ? 4 : 8, bn, bn == 128 ? 2 : 4,
                              bn == 128 ? 2 : 1);
@@ -645,7 +645,7 @@ extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, i
     return guarded([&] {
         if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device");
         const bool wino = (variant & 64) && wino_supported(ks, Cin, Cout, H, W);
-        const int wcfg = (variant & 128) ? 1 : 0;
+        const int wcfg = (variant & 128) ? ((variant & 32) ? 2 : 1) : 0;
         const bool v2 = !wino && (variant & 16) && conv2_supported(ks);
         const int KC = v2 ? 4 : conv_k_chunk(ks, Cin), BN = conv_cout_tile(ks, Cout);
         const int cout_pad = cdiv(Cout, BN) * BN, nchunks = cdiv(Cin, KC);

@@ -8,7 +8,7 @@ from sivo_amd._lib import lib, check
 
 SHAPES = {"conv4_2": (12, 512, 512, 44, 128), "conv5_2": (12, 512, 512, 22, 64), "conv3_2_D": (12, 256, 256, 88, 256),
           "conv2_2_D": (12, 128, 128, 176, 512), "conv1_2_D": (12, 64, 64, 352, 1024), "conv3_2": (1, 256, 256, 88, 256)}
-VARIANTS = {64: "wino A(4x32x64,kc4)", 192: "wino B(8x32x32,kc8)"}
+VARIANTS = {64: "wino cfg0", 64+128+32: "wino cfg2 (12 waves, kc8)"}
 
 def run(name, variant, iters=10):
     N, ci, co, H, W = SHAPES[name]
