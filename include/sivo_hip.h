@@ -57,8 +57,17 @@ typedef struct sivo_segnet *sivo_segnet_t;
  * SIVO_ERR_INVALID_ARGUMENT, as the reference constructor throws. */
 int sivo_segnet_create(const char *prototxt_text, size_t prototxt_len, int t_override,
                        const float *weights, size_t n_weights, int device, sivo_segnet_t *out);
-/* Same from files: model_file = prototxt, weights_file = .sivow container
- * (sivo_amd/weights.py).  Empty paths -> SIVO_ERR_INVALID_ARGUMENT
+/* Caffe's Net::CopyTrainedLayersFrom (called at bayesian_segnet.cpp:61): read a
+ * trained `.caffemodel` (binary protobuf NetParameter; both the `layer` and the
+ * legacy `layers` encodings), match its layers to the prototxt BY NAME and write
+ * the flat parameter array sivo_segnet_create takes.  Host-only (no GPU needed).
+ * *n_weights receives the count; `out` may be NULL to query it; capacity <
+ * count -> SIVO_ERR_CAPACITY.  A layer missing from the file or with blobs of the
+ * wrong size -> SIVO_ERR_INVALID_ARGUMENT (Caffe CHECK-fails there). */
+int sivo_caffemodel_weights(const char *prototxt_text, size_t prototxt_len, const void *model_bytes,
+                            size_t model_len, float *out, size_t capacity, size_t *n_weights);
+/* Same from files: model_file = prototxt, weights_file = the reference's
+ * `.caffemodel` or a .sivow container (sivo_amd/weights.py).  Empty paths -> SIVO_ERR_INVALID_ARGUMENT
  * (bayesian_segnet.cpp:80-89, pinned by tests/test_bayesian_segnet.cpp:138-150). */
 int sivo_segnet_create_from_files(const char *model_file, const char *weights_file, int t_override,
                                   int device, sivo_segnet_t *out);

@@ -23,6 +23,10 @@ class SivoError(RuntimeError):
         self.code = code
 
 
+class SivoInvalidArgument(SivoError, ValueError):
+    """SIVO_ERR_INVALID_ARGUMENT: where the reference throws std::invalid_argument."""
+
+
 class KeyPoint(C.Structure):  # == cv::KeyPoint / SivoKeyPoint (28 bytes)
     _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),
                 ("response", C.c_float), ("octave", C.c_int32), ("class_id", C.c_int32)]
@@ -46,6 +50,7 @@ SIGNATURES = {
     "sivo_version": [],
     "sivo_device_count": [],
     "sivo_segnet_create": [C.c_char_p, _sz, _i, _vp, _sz, _i, C.POINTER(_vp)],
+    "sivo_caffemodel_weights": [C.c_char_p, _sz, _vp, _sz, _vp, _sz, C.POINTER(_sz)],
     "sivo_segnet_create_from_files": [C.c_char_p, C.c_char_p, _i, _i, C.POINTER(_vp)],
     "sivo_segnet_destroy": [_vp],
     "sivo_segnet_shape": [_vp, _pi32, _pi32, _pi32, _pi32, _pi32],
@@ -101,6 +106,8 @@ def lib():
 
 
 def check(rc):
+    if rc == ERR_INVALID_ARGUMENT:      # the reference throws std::invalid_argument there
+        raise SivoInvalidArgument(rc, lib().sivo_last_error().decode(errors="replace"))
     if rc != OK:
         raise SivoError(rc, lib().sivo_last_error().decode(errors="replace"))
 

@@ -28,6 +28,8 @@
 #include "segnet_kernels.hpp"
 
 namespace sivo {
+bool looks_like_caffemodel(const std::string &bytes);
+std::vector<float> weights_from_caffemodel(const std::string &bytes, const ProtoNet &net);
 namespace {
 
 struct Blob {
@@ -465,6 +467,20 @@ extern "C" int sivo_segnet_create(const char *text, size_t len, int t_override, 
     });
 }
 
+extern "C" int sivo_caffemodel_weights(const char *prototxt_text, size_t prototxt_len, const void *model_bytes,
+                                       size_t model_len, float *out, size_t capacity, size_t *n_weights) {
+    return guarded([&] {
+        if (!prototxt_text || !prototxt_len || !model_bytes || !n_weights) throw std::invalid_argument("null argument");
+        const std::vector<float> w = weights_from_caffemodel(std::string((const char *)model_bytes, model_len),
+                                                             parse_prototxt(std::string(prototxt_text, prototxt_len)));
+        *n_weights = w.size();
+        if (!out) return SIVO_OK;
+        if (capacity < w.size()) return fail(SIVO_ERR_CAPACITY, "output capacity is smaller than the parameter count");
+        std::memcpy(out, w.data(), w.size() * sizeof(float));
+        return SIVO_OK;
+    });
+}
+
 extern "C" int sivo_segnet_create_from_files(const char *model_file, const char *weights_file, int t_override,
                                              int device, sivo_segnet_t *out) {
     return guarded([&] {
@@ -472,13 +488,20 @@ extern "C" int sivo_segnet_create_from_files(const char *model_file, const char 
         if (!weights_file || !*weights_file) throw std::invalid_argument("weights_file (.caffemodel file) is empty!");
         const std::string text = read_file(model_file);
         const std::string wb = read_file(weights_file);
-        if (wb.size() < 16 || std::memcmp(wb.data(), "SIVOW001", 8) != 0)
-            throw std::invalid_argument("weights_file is not a .sivow container (see sivo_amd/weights.py)");
-        uint64_t n = 0;
-        std::memcpy(&n, wb.data() + 8, 8);
-        if (wb.size() != 16 + 4 * n) throw std::invalid_argument("weights_file is truncated");
-        std::vector<float> w(n);
-        std::memcpy(w.data(), wb.data() + 16, 4 * n);
+        std::vector<float> w;
+        if (wb.size() >= 16 && std::memcmp(wb.data(), "SIVOW001", 8) == 0) {
+            uint64_t n = 0;
+            std::memcpy(&n, wb.data() + 8, 8);
+            if (wb.size() != 16 + 4 * n) throw std::invalid_argument("weights_file is truncated");
+            w.resize(n);
+            std::memcpy(w.data(), wb.data() + 16, 4 * n);
+        } else if (wb.size() < 200 && wb.compare(0, 7, "version") == 0) {
+            throw std::invalid_argument("weights_file is a Git-LFS pointer, not the trained model (run `git lfs pull`)");
+        } else if (looks_like_caffemodel(wb)) {
+            w = weights_from_caffemodel(wb, parse_prototxt(text));     // CopyTrainedLayersFrom: match layers by name
+        } else {
+            throw std::invalid_argument("weights_file is neither a .caffemodel (protobuf NetParameter) nor a .sivow container");
+        }
         return sivo_segnet_create(text.data(), text.size(), t_override, w.data(), w.size(), device, out);
     });
 }

@@ -80,3 +80,64 @@ def load(path):
         assert f.read(8) == MAGIC, "not a .sivow file"
         n = int(np.frombuffer(f.read(8), np.uint64)[0])
         return np.frombuffer(f.read(4 * n), "<f4").copy()
+
+
+def load_caffemodel(prototxt_text, path_or_bytes):
+    """Flat parameter array from a trained `.caffemodel` (what Net::CopyTrainedLayersFrom reads at
+    reference bayesian_segnet.cpp:61), layers matched to the prototxt by name.  Host-only."""
+    import ctypes as C
+    from ._lib import lib, check
+    blob = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
+    text = prototxt_text.encode() if isinstance(prototxt_text, str) else prototxt_text
+    n = C.c_size_t(0)
+    check(lib().sivo_caffemodel_weights(text, len(text), blob, len(blob), None, 0, C.byref(n)))
+    out = np.empty(n.value, np.float32)
+    check(lib().sivo_caffemodel_weights(text, len(text), blob, len(blob), out.ctypes.data_as(C.c_void_p), out.size, C.byref(n)))
+    return out
+
+
+# ---- minimal protobuf writer (tests and export only): NetParameter{name=1, layer=100{name=1,type=2,blobs=7}} ----
+def _varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _ld(field, payload):
+    return _varint((field << 3) | 2) + _varint(len(payload)) + payload
+
+
+def _blob_proto(arr, legacy_dims=False):
+    arr = np.ascontiguousarray(arr, "<f4")
+    if legacy_dims:
+        dims = ([1] * (4 - arr.ndim) + list(arr.shape)) if arr.ndim > 1 else [1, arr.size, 1, 1]
+        head = b"".join(_varint((f << 3) | 0) + _varint(d) for f, d in zip((1, 2, 3, 4), dims))
+        return head + _ld(5, arr.tobytes())
+    shape = _ld(1, b"".join(_varint(d) for d in arr.shape))
+    return _ld(7, shape) + _ld(5, arr.tobytes())
+
+
+def to_caffemodel(layers, weights, net_name="sivo", v1=False, legacy_dims=False, extra_layers=True):
+    """Encode `weights` ({layer name: [blob, blob]}) as a binary Caffe NetParameter.  v1=True writes the
+    legacy `layers` field (V1LayerParameter: name=4, blobs=6).  Parameter-free layers are written too
+    (as a real file has them) when extra_layers is set."""
+    body = _ld(1, net_name.encode())
+    for L in layers:
+        blobs = weights.get(L["name"])
+        if blobs is None and not extra_layers:
+            continue
+        if v1:
+            msg = _ld(4, L["name"].encode()) + b"".join(_ld(2, b.encode()) for b in L["bottom"])
+            msg += b"".join(_ld(6, _blob_proto(b, legacy_dims)) for b in (blobs or []))
+            body += _ld(2, msg)
+        else:
+            msg = _ld(1, L["name"].encode()) + _ld(2, L["type"].encode())
+            msg += b"".join(_ld(3, b.encode()) for b in L["bottom"]) + b"".join(_ld(4, t.encode()) for t in L["top"])
+            msg += _varint((10 << 3) | 0) + _varint(1)             # phase: TEST
+            msg += b"".join(_ld(7, _blob_proto(b, legacy_dims)) for b in (blobs or []))
+            body += _ld(100, msg)
+    return body

@@ -88,6 +88,43 @@ def test_weight_container_roundtrip(tmp_path):
     assert all(np.array_equal(a, b) for k in w for a, b in zip(w[k], w2[k]))      # seeded => reproducible
 
 
+def test_caffemodel_reader_matches_layers_by_name(tmp_path):
+    """Net::CopyTrainedLayersFrom semantics (reference bayesian_segnet.cpp:61): a binary NetParameter in the
+    `layer` (100) or legacy `layers` (2) encoding, blobs with BlobShape or legacy num/channels/height/width,
+    layers in any order, parameter-free layers present, is turned into the flat array bit-exactly."""
+    for text in (netspec.tiny_prototxt(2), netspec.basic_prototxt(6)):
+        layers = oproto.parse(text)["layers"]
+        w = wts.synth_weights(layers, 5)
+        flat = wts.pack(layers, w)
+        for v1 in (False, True):
+            for legacy in (False, True):
+                blob = wts.to_caffemodel(layers, w, v1=v1, legacy_dims=legacy)
+                assert np.array_equal(wts.load_caffemodel(text, blob), flat)
+        blob = wts.to_caffemodel(list(reversed(layers)), w)                 # file order is irrelevant, names decide
+        assert np.array_equal(wts.load_caffemodel(text, blob), flat)
+    # the Basic file size lands where the reference's LFS pointer says the trained model does (5,670,476 B):
+    # 4 B per parameter + protobuf framing
+    assert 4 * 1415823 < len(wts.to_caffemodel(layers, w)) < 5670476 + 4096
+    # errors Caffe CHECK-fails on: a parametrised layer missing from the file, or a blob of the wrong size
+    some = next(n for n, shp in wts.param_shapes(layers) if len(shp[0]) == 4)
+    w_missing = {k: v for k, v in w.items() if k != some}
+    with pytest.raises(ValueError, match=some):
+        wts.load_caffemodel(text, wts.to_caffemodel(layers, w_missing))
+    w_bad = dict(w); w_bad[some] = [w[some][0][:, :, :, :2], w[some][1]]
+    with pytest.raises(ValueError, match="prototxt implies"):
+        wts.load_caffemodel(text, wts.to_caffemodel(layers, w_bad))
+    with pytest.raises(ValueError):
+        wts.load_caffemodel(text, wts.to_caffemodel(layers, w)[:-7])        # truncated file
+    # an un-pulled Git-LFS pointer (what /root/reference ships, SURVEY.md F4) is named as such
+    ptr = tmp_path / "w.caffemodel"
+    ptr.write_text("version https://git-lfs.github.com/spec/v1\noid sha256:0\nsize 5670476\n")
+    proto = tmp_path / "m.prototxt"
+    proto.write_text(text)
+    h = C.c_void_p()
+    assert _lib.lib().sivo_segnet_create_from_files(str(proto).encode(), str(ptr).encode(), 0, 0, C.byref(h)) == _lib.ERR_INVALID_ARGUMENT
+    assert b"Git-LFS" in _lib.lib().sivo_last_error()
+
+
 def test_host_quadtree_matches_oracle(oracle, kitti_like_bgr):
     ex = oracle.OrbExtractor()
     ex(oracle.bgr2gray(kitti_like_bgr))
