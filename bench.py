@@ -134,10 +134,18 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     require_gpu()
+    # SIVO_BENCH_SHARE_GPU=1 + SIVO_BENCH_BACKEND=gloo: rehearse the N>1 path on a single-GPU box (every rank on
+    # cuda:0, reduction through gloo).  The driver's multi-GPU runs use neither: one rank per GPU over RCCL.
+    if os.environ.get("SIVO_BENCH_SHARE_GPU") == "1":
+        local = local % torch.cuda.device_count()
+    backend = os.environ.get("SIVO_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     T, H, W = args.T, args.height, args.width
     # contiguous shard of the T samples: the first T % world ranks take one extra

@@ -246,6 +246,56 @@ int sivo_ba_linearize(const double *poses, int n_poses, const double *points, in
                       double delta_stereo, double *err, double *jx, double *jp, double *chi2, double *rho,
                       double *w, uint8_t *depth_ok);
 
+/* ---------------------------------------------------------------------------
+ * The optimisation loops g2o runs for SIVO::Optimizer, on arrays.
+ * Levenberg-Marquardt as g2o::OptimizationAlgorithmLevenberg over BlockSolver_6_3:
+ * robustified normal equations, landmark block marginalised by a Schur complement,
+ * lambda_0 = 1e-5 max|diag H|, <= 10 trials per iteration, VertexSE3Expmap /
+ * VertexSBAPointXYZ updates (restated in oracle/ba_solve_oracle.c).  Host arrays
+ * in/out; every kernel runs on the GPU, the host only takes the accept/reject
+ * decision of each trial (3 doubles back per trial).
+ * ------------------------------------------------------------------------ */
+
+/* One g2o `optimizer.optimize(iterations)` call — what Optimizer::BundleAdjustment
+ * (Optimizer.cc:49-271) runs.  pose_fixed[i] != 0: keyframe i is held fixed
+ * (setFixed, :73, :601-610).  level[e] != 0: edge excluded (setLevel(1));
+ * robust[e] != 0: Huber kernel with delta_mono / delta_stereo; NULL = all
+ * active / all robust.  At most one edge per (keyframe, map point) pair.
+ * stop_flag is polled like g2o's forceStopFlag (:573-575).  poses and points are
+ * updated in place; err_out (3 per edge, may be NULL) receives the error vectors
+ * g2o would hold afterwards; hpp_last_out (36 per free pose, may be NULL) the
+ * pose blocks of the last buildSystem. */
+int sivo_ba_optimize(double *poses, const uint8_t *pose_fixed, int n_poses, double *points, int n_points,
+                     const SivoEdge *edges, int64_t n_edges, const double intr[5], double delta_mono,
+                     double delta_stereo, const uint8_t *level, const uint8_t *robust, int iterations,
+                     const volatile int *stop_flag, double *err_out, double *hpp_last_out,
+                     int *iterations_run, int *trials);
+
+/* Optimizer::LocalBundleAdjustment from the point the graph is built
+ * (Optimizer.cc:757-926): optimize(5) with Huber kernels; unless stopped, edges
+ * with chi2 > 5.991 (mono) / 7.815 (stereo) or non-positive depth are excluded
+ * and every kernel is dropped, optimize(10); outlier[e] = 1 for the observations
+ * the caller must erase (:824-858).  cov (36, row-major) = the marginal block
+ * of keyframe `cov_pose` as g2o's computeMarginals returns it (:900-907);
+ * *cov_ok = 0 when that keyframe is fixed / out of range / its block is singular. */
+int sivo_local_ba(double *poses, const uint8_t *pose_fixed, int n_poses, double *points, int n_points,
+                  const SivoEdge *edges, int64_t n_edges, const double intr[5], const volatile int *stop_flag,
+                  uint8_t *outlier, int cov_pose, double *cov, int *cov_ok, int *iterations, int *trials);
+
+/* Optimizer::PoseOptimization from the point the edges are built
+ * (Optimizer.cc:409-491): 4 rounds of optimize(10) from the initial pose, chi2
+ * test (7.815) on the STEREO edges after each round — the reference never
+ * re-classifies the mono edges (:432-467) — kernels of the stereo edges dropped
+ * after the third round, pose + 6x6 covariance out.  edges[e].pose is ignored;
+ * edges[e].point indexes `points` (map-point world positions, held fixed).
+ * outlier (n_edges) = Frame::mvbOutlier; *n_inliers = nInitialCorrespondences -
+ * nBad (0 and pose_out = pose0 when n_edges < 3, :409-411).  The whole schedule is
+ * one launch of one persistent workgroup. */
+int sivo_pose_optimize(const double pose0[12], const double *points, int n_points, const SivoEdge *edges,
+                       int64_t n_edges, const double intr[5], uint8_t *outlier, double pose_out[12],
+                       double cov[36], int *cov_ok, double *chi2, int *n_inliers, int *iterations,
+                       int *trials);
+
 /* ===========================================================================
  * Entropy feature-selection gate — stands behind SIVO's sivo_helpers
  * (reference src/sivo_helpers/sivo_helpers.cpp:64-88 computeStereoJacobianPose,

@@ -280,6 +280,55 @@ def ba_linearize(poses, points, edges, intr, delta_mono=np.sqrt(5.991), delta_st
     return {"err": err, "Jx": Jx, "Jp": Jp, "chi2": chi2, "rho": rho, "w": w, "depth_ok": ok}
 
 
+def pose_optimize(pose0, points, edges, intr):
+    """Optimizer::PoseOptimization (Optimizer.cc:273-491) on arrays; see ba_solve_oracle.c."""
+    pose0 = np.ascontiguousarray(pose0, np.float64).reshape(12); points = np.ascontiguousarray(points, np.float64)
+    edges = np.ascontiguousarray(edges, EDGE_DTYPE); intr = np.ascontiguousarray(intr, np.float64)
+    nE = edges.shape[0]
+    outlier = np.zeros(nE, np.uint8); pose = np.empty(12); cov = np.zeros((6, 6)); chi2 = np.zeros(nE)
+    cov_ok = C.c_int(0); iters = C.c_int(0); trials = C.c_int(0)
+    f = lib().orc_pose_optimize
+    f.restype = C.c_int
+    n_in = f(_p(pose0, c_f64p), _p(points, c_f64p), edges.ctypes.data_as(C.c_void_p), C.c_int64(nE), _p(intr, c_f64p),
+             _p(outlier, c_u8p), _p(pose, c_f64p), _p(cov, c_f64p), C.byref(cov_ok), _p(chi2, c_f64p), C.byref(iters),
+             C.byref(trials))
+    return {"pose": pose, "outlier": outlier, "cov": cov, "cov_ok": bool(cov_ok.value), "chi2": chi2, "inliers": n_in,
+            "iterations": iters.value, "trials": trials.value}
+
+
+def local_ba(poses, fixed, points, edges, intr, cov_pose=-1, stop=False):
+    """Optimizer::LocalBundleAdjustment (Optimizer.cc:757-926) on arrays; returns updated copies."""
+    poses = np.array(poses, np.float64).reshape(-1, 12).copy(); points = np.array(points, np.float64).reshape(-1, 3).copy()
+    fixed = np.ascontiguousarray(fixed, np.uint8); edges = np.ascontiguousarray(edges, EDGE_DTYPE)
+    intr = np.ascontiguousarray(intr, np.float64)
+    nE = edges.shape[0]
+    outlier = np.zeros(nE, np.uint8); cov = np.zeros((6, 6))
+    cov_ok = C.c_int(0); iters = C.c_int(0); trials = C.c_int(0); stop_flag = C.c_int(1 if stop else 0)
+    lib().orc_local_ba(_p(poses, c_f64p), _p(fixed, c_u8p), poses.shape[0], _p(points, c_f64p), points.shape[0],
+                       edges.ctypes.data_as(C.c_void_p), C.c_int64(nE), _p(intr, c_f64p), C.byref(stop_flag),
+                       _p(outlier, c_u8p), cov_pose, _p(cov, c_f64p), C.byref(cov_ok), C.byref(iters), C.byref(trials))
+    return {"poses": poses, "points": points, "outlier": outlier, "cov": cov, "cov_ok": bool(cov_ok.value),
+            "iterations": iters.value, "trials": trials.value}
+
+
+def ba_optimize(poses, fixed, points, edges, intr, iterations, level=None, robust=None,
+                delta_mono=float(np.sqrt(np.float32(5.991))), delta_stereo=float(np.sqrt(np.float32(7.815)))):
+    """One g2o optimize(iterations) call (Levenberg + Schur) on arrays; returns updated copies."""
+    poses = np.array(poses, np.float64).reshape(-1, 12).copy(); points = np.array(points, np.float64).reshape(-1, 3).copy()
+    fixed = np.ascontiguousarray(fixed, np.uint8); edges = np.ascontiguousarray(edges, EDGE_DTYPE)
+    intr = np.ascontiguousarray(intr, np.float64)
+    nE = edges.shape[0]
+    level = np.zeros(nE, np.uint8) if level is None else np.ascontiguousarray(level, np.uint8)
+    robust = np.ones(nE, np.uint8) if robust is None else np.ascontiguousarray(robust, np.uint8)
+    err = np.zeros((nE, 3)); hpp = np.zeros((int((fixed == 0).sum()), 6, 6)); trials = C.c_int(0)
+    f = lib().orc_ba_optimize
+    f.restype = C.c_int
+    n = f(_p(poses, c_f64p), _p(fixed, c_u8p), poses.shape[0], _p(points, c_f64p), points.shape[0],
+          edges.ctypes.data_as(C.c_void_p), C.c_int64(nE), _p(intr, c_f64p), C.c_double(delta_mono), C.c_double(delta_stereo),
+          _p(level, c_u8p), _p(robust, c_u8p), iterations, _p(err, c_f64p), _p(hpp, c_f64p), C.byref(trials))
+    return {"poses": poses, "points": points, "err": err, "hpp": hpp, "iterations": n, "trials": trials.value}
+
+
 # --------------------------------------------------------------------------- ORB
 KP_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32), ("angle", np.float32),
                      ("response", np.float32), ("octave", np.int32), ("class_id", np.int32)])

@@ -81,6 +81,9 @@ SIGNATURES = {
     "sivo_stereo_match": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp],
     "sivo_entropy_gate_dev": [_i, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(_d), _d, _d, _d, _vp, _i, _d, _vp, _vp, _vp, _vp],
     "sivo_entropy_gate": [_i, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(_d), _d, _d, _d, _vp, _i, _d, _vp, _vp, _vp],
+    "sivo_ba_optimize": [_vp, _vp, _i, _vp, _i, _vp, _i64, C.POINTER(_d), _d, _d, _vp, _vp, _i, _vp, _vp, _vp, C.POINTER(_i), C.POINTER(_i)],
+    "sivo_local_ba": [_vp, _vp, _i, _vp, _i, _vp, _i64, C.POINTER(_d), _vp, _vp, _i, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
+    "sivo_pose_optimize": [_vp, _vp, _i, _vp, _i64, C.POINTER(_d), _vp, _vp, _vp, C.POINTER(_i), _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
     "sivo_ba_linearize_dev": [_vp, _vp, _vp, _i64, C.POINTER(_d), _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sivo_ba_linearize": [_vp, _i, _vp, _i, _vp, _i64, C.POINTER(_d), _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }

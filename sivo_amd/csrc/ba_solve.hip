@@ -1,0 +1,960 @@
+// ba_solve.hip — the optimisation loops behind SIVO::Optimizer once the graph is built.
+//
+// Stands behind g2o as Optimizer::PoseOptimization (reference src/orbslam/Optimizer.cc:273-491),
+// Optimizer::LocalBundleAdjustment (:493-926) and Optimizer::BundleAdjustment (:49-271) drive it:
+// OptimizationAlgorithmLevenberg over BlockSolver_6_3 (landmarks marginalised by a Schur complement),
+// the chi2 re-classification schedules of the two callers, and computeMarginals for the 6x6 pose
+// covariance (:482-487, :900-907).  SURVEY.md 8f-3.  g2o is an un-vendored submodule; its published
+// algorithm is restated in oracle/ba_solve_oracle.c, which these kernels are checked against.
+//
+// Layout in HBM (fp64 throughout):
+//   poses 12/keyframe (Rcw row-major, tcw), points 3/map point, SivoEdge 48 B/edge;
+//   per edge:  err 3, Jp 18, Jx 9, W = w*Omega*Jp'Jx 18, Y = W*Hll^-1 18;
+//   per point: Hll 9, bl 3, Hll^-1 9, dx 3;   per free pose: Hpp 36, bp 6;
+//   reduced system S (6F x 6F, dense) + rhs; CSR edge lists by point and by free pose; a dense
+//   (free pose x point) -> edge table that turns the Schur products into gathers with a fixed
+//   summation order (no atomics: results are reproducible run to run).
+//
+// Pose-only problems (one vertex, <= a few thousand edges) run the WHOLE schedule — 4 rounds x 10
+// LM iterations x up to 10 trials, the chi2 re-classification and the covariance — in ONE launch of a
+// single persistent workgroup: the loop is latency-bound, so there is nothing to gain from more CUs
+// and everything to gain from not crossing the host 100+ times per frame.
+// The BA kernels are HBM-bound gathers/reductions; the LM accept/reject logic reads 3 doubles per trial.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include "common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace sivo {
+
+struct Intr { double fx, fy, cx, cy, bf; };
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+template <bool JAC>
+__device__ __forceinline__ void edge_eval(const double *P, const double *X, const SivoEdge &ed, const Intr &K, double *er,
+                                          double *jp, double *jx, bool &depth_ok) {
+    double R[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) R[i] = P[i];
+    const double X0 = X[0], X1 = X[1], X2 = X[2];
+    const double x = R[0] * X0 + R[1] * X1 + R[2] * X2 + R[9];
+    const double y = R[3] * X0 + R[4] * X1 + R[5] * X2 + R[10];
+    const double z = R[6] * X0 + R[7] * X1 + R[8] * X2 + R[11];
+    const double invz = 1.0 / z, z_2 = z * z;
+    const bool st = ed.stereo != 0;
+    er[0] = ed.obs[0] - (x * invz * K.fx + K.cx);
+    er[1] = ed.obs[1] - (y * invz * K.fy + K.cy);
+    er[2] = st ? ed.obs[2] - (x * invz * K.fx + K.cx - K.bf * invz) : 0.0;
+    depth_ok = z > 0.0;
+    if (JAC) {
+        if (jx) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double j0 = -K.fx * R[j] / z + K.fx * x * R[6 + j] / z_2;
+                jx[j] = j0;
+                jx[3 + j] = -K.fy * R[3 + j] / z + K.fy * y * R[6 + j] / z_2;
+                jx[6 + j] = st ? j0 - K.bf * R[6 + j] / z_2 : 0.0;
+            }
+        }
+        jp[0] = x * y / z_2 * K.fx;  jp[1] = -(1 + (x * x / z_2)) * K.fx;  jp[2] = y / z * K.fx;
+        jp[3] = -1. / z * K.fx;      jp[4] = 0;                            jp[5] = x / z_2 * K.fx;
+        jp[6] = (1 + y * y / z_2) * K.fy;  jp[7] = -x * y / z_2 * K.fy;    jp[8] = -x / z * K.fy;
+        jp[9] = 0;                   jp[10] = -1. / z * K.fy;              jp[11] = y / z_2 * K.fy;
+        if (st) {
+            jp[12] = jp[0] - K.bf * y / z_2;  jp[13] = jp[1] + K.bf * x / z_2;  jp[14] = jp[2];
+            jp[15] = jp[3];                   jp[16] = 0;                       jp[17] = jp[5] - K.bf / z_2;
+        } else {
+#pragma unroll
+            for (int j = 12; j < 18; ++j) jp[j] = 0.0;
+        }
+    }
+}
+
+__device__ __forceinline__ void huber(double c2, double delta, double &rho, double &w) {
+    const double dsqr = delta * delta;
+    if (c2 <= dsqr) { rho = c2; w = 1.0; }
+    else { const double s = sqrt(c2); rho = 2 * s * delta - dsqr; w = delta / s; }
+}
+
+// T <- exp([omega, upsilon]) * T   (g2o SE3Quat::exp, VertexSE3Expmap::oplusImpl)
+__host__ __device__ inline void se3_oplus(const double *Tin, const double *u, double *Tout) {
+    const double wx = u[0], wy = u[1], wz = u[2];
+    const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+    const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double O2[9], R[9], V[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+    if (theta < 0.00001) {
+        for (int i = 0; i < 9; ++i) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
+    } else {
+        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / (theta * theta * theta);
+        for (int i = 0; i < 9; ++i) {
+            const double I = (i % 4 == 0 ? 1.0 : 0.0);
+            R[i] = I + a * O[i] + b * O2[i];
+            V[i] = I + b * O[i] + c * O2[i];
+        }
+    }
+    double tn[3], Rn[9];
+    for (int i = 0; i < 3; ++i) tn[i] = V[3 * i] * u[3] + V[3 * i + 1] * u[4] + V[3 * i + 2] * u[5];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) Rn[3 * i + j] = R[3 * i] * Tin[j] + R[3 * i + 1] * Tin[3 + j] + R[3 * i + 2] * Tin[6 + j];
+        tn[i] += R[3 * i] * Tin[9] + R[3 * i + 1] * Tin[10] + R[3 * i + 2] * Tin[11];
+    }
+    for (int i = 0; i < 9; ++i) Tout[i] = Rn[i];
+    for (int i = 0; i < 3; ++i) Tout[9 + i] = tn[i];
+}
+
+// in-place lower Cholesky of a 6x6 (row-major); false when not positive definite
+__host__ __device__ inline bool chol6(double *A) {
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j * 6 + j];
+        for (int k = 0; k < j; ++k) d -= A[j * 6 + k] * A[j * 6 + k];
+        if (!(d > 0.0)) return false;
+        d = sqrt(d);
+        A[j * 6 + j] = d;
+        for (int i = j + 1; i < 6; ++i) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; ++k) s -= A[i * 6 + k] * A[j * 6 + k];
+            A[i * 6 + j] = s / d;
+        }
+    }
+    return true;
+}
+__host__ __device__ inline void chol6_solve(const double *L, double *x) {
+    for (int i = 0; i < 6; ++i) { double s = x[i]; for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * x[k]; x[i] = s / L[i * 6 + i]; }
+    for (int i = 5; i >= 0; --i) { double s = x[i]; for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k]; x[i] = s / L[i * 6 + i]; }
+}
+__host__ __device__ inline bool inv6_spd(const double *H, double *out) {
+    double L[36];
+    for (int i = 0; i < 36; ++i) L[i] = H[i];
+    if (!chol6(L)) return false;
+    for (int c = 0; c < 6; ++c) {
+        double e[6] = {0, 0, 0, 0, 0, 0};
+        e[c] = 1;
+        chol6_solve(L, e);
+        for (int r = 0; r < 6; ++r) out[6 * r + c] = e[r];
+    }
+    return true;
+}
+
+// Sum K per-thread values over the workgroup in a fixed order: wave butterfly, then waves in index order.
+template <int K, int NT>
+__device__ __forceinline__ void block_sum(double (&v)[K], double *s_red /* [NT/64][K] */, double *s_out /* [K] */) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double x = v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        v[k] = x;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) s_red[wave * K + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        double s = 0;
+        for (int w = 0; w < NT / 64; ++w) s += s_red[w * K + threadIdx.x];
+        s_out[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// PoseOptimization: one persistent workgroup
+// ------------------------------------------------------------------------------------------------
+constexpr int PO_THREADS = 512;
+
+struct PoseOptArgs {
+    const double *pose0;     // 12
+    const double *points;    // 3 per map point (fixed)
+    const SivoEdge *edges;
+    int n;
+    Intr K;
+    double delta_mono, delta_stereo;
+    uint8_t *outlier;        // n   (Frame::mvbOutlier)
+    double *err;             // 3n  workspace: the error vectors g2o would hold
+    double *pose_out;        // 12
+    double *cov;             // 36
+    double *chi2;            // n or null
+    int *info;               // [0] cov_ok [1] nBad [2] iterations [3] trials
+};
+
+__global__ __launch_bounds__(PO_THREADS) void pose_optimize_kernel(PoseOptArgs a) {
+    __shared__ double sP[12], sBk[12], sH[36], sHlast[36], sb[6];
+    __shared__ double s_red[(PO_THREADS / 64) * 28], s_sum[28];
+    __shared__ double s_lambda, s_ni, s_current, s_scale;
+    __shared__ int s_ok, s_cont, s_term, s_qmax, s_iters, s_trials;
+    const int tid = threadIdx.x;
+    const Intr K = a.K;
+    if (tid == 0) { s_iters = 0; s_trials = 0; }
+    for (int e = tid; e < a.n; e += PO_THREADS) a.outlier[e] = 0;
+    for (int i = tid; i < 36; i += PO_THREADS) sHlast[i] = 0.0;
+    __syncthreads();
+    int nbad_total = 0;
+    for (int round = 0; round < 4; ++round) {
+        if (tid < 12) sP[tid] = a.pose0[tid];      // vSE3->setEstimate(pFrame->mTcw) at every round (:419)
+        __syncthreads();
+        for (int it = 0; it < 10; ++it) {
+            // computeActiveErrors + buildSystem
+            double acc[28];
+#pragma unroll
+            for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+            for (int e = tid; e < a.n; e += PO_THREADS) {
+                const SivoEdge ed = a.edges[e];
+                const bool st = ed.stereo != 0;
+                if (st && a.outlier[e]) continue;                 // level 1
+                double er[3], jp[18];
+                bool dok;
+                edge_eval<true>(sP, a.points + 3 * (int64_t)ed.point, ed, K, er, jp, nullptr, dok);
+                a.err[3 * e] = er[0]; a.err[3 * e + 1] = er[1]; a.err[3 * e + 2] = er[2];
+                const double c2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * ed.inv_sigma2;
+                double r = c2, w = 1.0;
+                if (!st || round < 3) huber(c2, st ? a.delta_stereo : a.delta_mono, r, w);   // kernel dropped after it==2 (:462)
+                const double wo = w * ed.inv_sigma2;
+                int k = 0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = i; j < 6; ++j) acc[k++] += wo * (jp[i] * jp[j] + jp[6 + i] * jp[6 + j] + jp[12 + i] * jp[12 + j]);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) acc[21 + i] -= wo * (jp[i] * er[0] + jp[6 + i] * er[1] + jp[12 + i] * er[2]);
+                acc[27] += r;
+            }
+            block_sum<28, PO_THREADS>(acc, s_red, s_sum);
+            if (tid == 0) {
+                int k = 0;
+                for (int i = 0; i < 6; ++i)
+                    for (int j = i; j < 6; ++j) { sH[6 * i + j] = s_sum[k]; sH[6 * j + i] = s_sum[k]; ++k; }
+                for (int i = 0; i < 6; ++i) sb[i] = s_sum[21 + i];
+                for (int i = 0; i < 36; ++i) sHlast[i] = sH[i];
+                s_current = s_sum[27];
+                if (it == 0) {
+                    double md = 0;
+                    for (int i = 0; i < 6; ++i) md = fmax(md, fabs(sH[7 * i]));
+                    s_lambda = 1e-5 * md; s_ni = 2;
+                }
+                s_qmax = 0;
+            }
+            __syncthreads();
+            do {
+                if (tid == 0) {
+                    double A[36], x[6];
+                    for (int i = 0; i < 12; ++i) sBk[i] = sP[i];
+                    for (int i = 0; i < 36; ++i) A[i] = sH[i];
+                    for (int i = 0; i < 6; ++i) { A[7 * i] += s_lambda; x[i] = sb[i]; }
+                    const bool ok = chol6(A);
+                    double scale = 0;
+                    if (ok) {
+                        chol6_solve(A, x);
+                        double Tn[12];
+                        se3_oplus(sBk, x, Tn);
+                        for (int i = 0; i < 12; ++i) sP[i] = Tn[i];
+                        for (int i = 0; i < 6; ++i) scale += x[i] * (s_lambda * x[i] + sb[i]);
+                    }
+                    s_ok = ok; s_scale = scale;
+                }
+                __syncthreads();
+                double chi[1] = {0.0};
+                for (int e = tid; e < a.n; e += PO_THREADS) {
+                    const SivoEdge ed = a.edges[e];
+                    const bool st = ed.stereo != 0;
+                    if (st && a.outlier[e]) continue;
+                    double er[3];
+                    bool dok;
+                    edge_eval<false>(sP, a.points + 3 * (int64_t)ed.point, ed, K, er, nullptr, nullptr, dok);
+                    a.err[3 * e] = er[0]; a.err[3 * e + 1] = er[1]; a.err[3 * e + 2] = er[2];
+                    const double c2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * ed.inv_sigma2;
+                    double r = c2, w;
+                    if (!st || round < 3) huber(c2, st ? a.delta_stereo : a.delta_mono, r, w);
+                    chi[0] += r;
+                }
+                block_sum<1, PO_THREADS>(chi, s_red, s_sum);
+                if (tid == 0) {
+                    const double temp = s_ok ? s_sum[0] : DBL_MAX;
+                    const double rho = (s_current - temp) / (s_scale + 1e-3);
+                    if (rho > 0 && isfinite(temp)) {
+                        double alpha = 1. - pow(2 * rho - 1, 3);
+                        alpha = fmin(alpha, 2. / 3.);
+                        s_lambda *= fmax(1. / 3., alpha);
+                        s_ni = 2; s_current = temp;
+                    } else {
+                        s_lambda *= s_ni; s_ni *= 2;
+                        for (int i = 0; i < 12; ++i) sP[i] = sBk[i];
+                    }
+                    ++s_qmax; ++s_trials;
+                    s_cont = (rho < 0 && s_qmax < 10);
+                    s_term = (s_qmax == 10 || rho == 0);
+                }
+                __syncthreads();
+            } while (s_cont);
+            if (tid == 0) ++s_iters;
+            if (s_term) break;
+        }
+        __syncthreads();
+        // chi2 test on the stereo edges (:432-467); mono edges are not re-classified by the reference
+        double bad[1] = {0.0};
+        for (int e = tid; e < a.n; e += PO_THREADS) {
+            const SivoEdge ed = a.edges[e];
+            if (!ed.stereo) continue;
+            double er[3];
+            if (a.outlier[e]) {
+                bool dok;
+                edge_eval<false>(sP, a.points + 3 * (int64_t)ed.point, ed, K, er, nullptr, nullptr, dok);
+                a.err[3 * e] = er[0]; a.err[3 * e + 1] = er[1]; a.err[3 * e + 2] = er[2];
+            } else {
+                er[0] = a.err[3 * e]; er[1] = a.err[3 * e + 1]; er[2] = a.err[3 * e + 2];
+            }
+            const float c2 = (float)((er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * ed.inv_sigma2);
+            const bool out = c2 > 7.815f;
+            a.outlier[e] = out;
+            bad[0] += out ? 1.0 : 0.0;
+        }
+        block_sum<1, PO_THREADS>(bad, s_red, s_sum);
+        nbad_total = (int)s_sum[0];
+        __syncthreads();
+        if (a.n < 10) break;                                   // optimizer.edges().size() < 10 (:469)
+    }
+    if (tid < 12) a.pose_out[tid] = sP[tid];
+    if (a.chi2)
+        for (int e = tid; e < a.n; e += PO_THREADS)
+            a.chi2[e] = (a.err[3 * e] * a.err[3 * e] + a.err[3 * e + 1] * a.err[3 * e + 1] + a.err[3 * e + 2] * a.err[3 * e + 2]) * a.edges[e].inv_sigma2;
+    if (tid == 0) {
+        double C[36];
+        const bool ok = inv6_spd(sHlast, C);
+        for (int i = 0; i < 36; ++i) a.cov[i] = ok ? C[i] : 0.0;
+        a.info[0] = ok; a.info[1] = nbad_total; a.info[2] = s_iters; a.info[3] = s_trials;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bundle adjustment: kernels of one LM iteration
+// ------------------------------------------------------------------------------------------------
+constexpr int BA_T = 256;
+
+struct BaDev {
+    // problem
+    const SivoEdge *edges; int64_t nE;
+    const int32_t *slot;        // pose -> free slot or -1
+    const uint8_t *level, *robust;
+    int nP, nF, nX;
+    Intr K; double delta_mono, delta_stereo;
+    // CSR
+    const int64_t *pt_off; const int32_t *pt_edges;     // by point
+    const int64_t *ps_off; const int32_t *ps_edges;     // by free pose
+    const int32_t *table;                               // [nF][nX] edge id or -1
+    // per edge
+    double *err, *Jp, *Jx, *wo, *rchi, *W, *Y;
+    // per point / pose
+    double *Hll, *bl, *Hinv, *xl, *sc_pt;
+    double *Hpp, *bp;
+    // reduced system
+    double *S, *xs;
+    double *scal;               // [0] chi  [1] scale  [2] maxdiag  [3] ok(0/1)
+};
+
+// errors (+ Jacobians, W) of the active edges at (poses, points)
+template <bool JAC>
+__global__ __launch_bounds__(BA_T) void ba_edge_kernel(BaDev d, const double *poses, const double *points) {
+    const int64_t e = (int64_t)blockIdx.x * BA_T + threadIdx.x;
+    if (e >= d.nE) return;
+    if (d.level[e]) { d.rchi[e] = 0.0; return; }
+    const SivoEdge ed = d.edges[e];
+    double er[3], jp[18], jx[9];
+    bool dok;
+    edge_eval<JAC>(poses + 12 * (int64_t)ed.pose, points + 3 * (int64_t)ed.point, ed, d.K, er, jp, jx, dok);
+    d.err[3 * e] = er[0]; d.err[3 * e + 1] = er[1]; d.err[3 * e + 2] = er[2];
+    const double c2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * ed.inv_sigma2;
+    double r = c2, w = 1.0;
+    if (d.robust[e]) huber(c2, ed.stereo ? d.delta_stereo : d.delta_mono, r, w);
+    d.rchi[e] = r;
+    if (JAC) {
+        const double wo = w * ed.inv_sigma2;
+        d.wo[e] = wo;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) d.Jp[18 * e + i] = jp[i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) d.Jx[9 * e + i] = jx[i];
+        if (d.slot[ed.pose] >= 0) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                    d.W[18 * e + 3 * a + b] = wo * (jp[a] * jx[b] + jp[6 + a] * jx[3 + b] + jp[12 + a] * jx[6 + b]);
+        }
+    }
+}
+
+// out[0] = sum(in[0..n)) in a fixed order; one workgroup
+__global__ __launch_bounds__(1024) void ba_sum_kernel(const double *in, int64_t n, double *out) {
+    __shared__ double s_red[16], s_out[1];
+    double v[1] = {0.0};
+    for (int64_t i = threadIdx.x; i < n; i += 1024) v[0] += in[i];
+    block_sum<1, 1024>(v, s_red, s_out);
+    if (threadIdx.x == 0) out[0] = s_out[0];
+}
+
+// Hll, bl of every point from its active edges (CSR order)
+__global__ __launch_bounds__(BA_T) void ba_point_kernel(BaDev d) {
+    const int q = blockIdx.x * BA_T + threadIdx.x;
+    if (q >= d.nX) return;
+    double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    for (int64_t i = d.pt_off[q]; i < d.pt_off[q + 1]; ++i) {
+        const int e = d.pt_edges[i];
+        if (d.level[e]) continue;
+        const double wo = d.wo[e];
+        const double *jx = d.Jx + 9 * (int64_t)e, *er = d.err + 3 * (int64_t)e;
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = a; c < 3; ++c) H[k++] += wo * (jx[a] * jx[c] + jx[3 + a] * jx[3 + c] + jx[6 + a] * jx[6 + c]);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) b[a] -= wo * (jx[a] * er[0] + jx[3 + a] * er[1] + jx[6 + a] * er[2]);
+    }
+    double *Hq = d.Hll + 9 * (int64_t)q;
+    Hq[0] = H[0]; Hq[1] = H[1]; Hq[2] = H[2]; Hq[3] = H[1]; Hq[4] = H[3]; Hq[5] = H[4]; Hq[6] = H[2]; Hq[7] = H[4]; Hq[8] = H[5];
+    d.bl[3 * q] = b[0]; d.bl[3 * q + 1] = b[1]; d.bl[3 * q + 2] = b[2];
+}
+
+// Hpp, bp of one free pose per workgroup
+__global__ __launch_bounds__(BA_T) void ba_pose_kernel(BaDev d) {
+    __shared__ double s_red[(BA_T / 64) * 27], s_out[27];
+    const int s = blockIdx.x;
+    double acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+    for (int64_t i = d.ps_off[s] + threadIdx.x; i < d.ps_off[s + 1]; i += BA_T) {
+        const int e = d.ps_edges[i];
+        if (d.level[e]) continue;
+        const double wo = d.wo[e];
+        const double *jp = d.Jp + 18 * (int64_t)e, *er = d.err + 3 * (int64_t)e;
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = a; c < 6; ++c) acc[k++] += wo * (jp[a] * jp[c] + jp[6 + a] * jp[6 + c] + jp[12 + a] * jp[12 + c]);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[21 + a] -= wo * (jp[a] * er[0] + jp[6 + a] * er[1] + jp[12 + a] * er[2]);
+    }
+    block_sum<27, BA_T>(acc, s_red, s_out);
+    if (threadIdx.x == 0) {
+        int k = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int c = a; c < 6; ++c) { d.Hpp[36 * s + 6 * a + c] = s_out[k]; d.Hpp[36 * s + 6 * c + a] = s_out[k]; ++k; }
+        for (int a = 0; a < 6; ++a) d.bp[6 * s + a] = s_out[21 + a];
+    }
+}
+
+// scal[2] = max |diag| over Hpp and Hll (computeLambdaInit)
+__global__ __launch_bounds__(1024) void ba_maxdiag_kernel(BaDev d, int with_points) {
+    __shared__ double s_m[1024];
+    double m = 0;
+    for (int i = threadIdx.x; i < 6 * d.nF; i += 1024) m = fmax(m, fabs(d.Hpp[36 * (i / 6) + 7 * (i % 6)]));
+    if (with_points)
+        for (int i = threadIdx.x; i < 3 * d.nX; i += 1024) m = fmax(m, fabs(d.Hll[9 * (int64_t)(i / 3) + 4 * (i % 3)]));
+    s_m[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (threadIdx.x < s) s_m[threadIdx.x] = fmax(s_m[threadIdx.x], s_m[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) d.scal[2] = s_m[0];
+}
+
+// (Hll + lambda I)^-1 per point, and Y_e = W_e Hll^-1 for the point's edges that touch a free pose
+__global__ __launch_bounds__(BA_T) void ba_point_inverse_kernel(BaDev d, double lambda) {
+    const int q = blockIdx.x * BA_T + threadIdx.x;
+    if (q >= d.nX) return;
+    double A[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) A[i] = d.Hll[9 * (int64_t)q + i];
+    A[0] += lambda; A[4] += lambda; A[8] += lambda;
+    const double c0 = A[4] * A[8] - A[5] * A[7], c1 = A[5] * A[6] - A[3] * A[8], c2 = A[3] * A[7] - A[4] * A[6];
+    const double det = A[0] * c0 + A[1] * c1 + A[2] * c2, id = 1.0 / det;
+    double Ai[9];
+    Ai[0] = c0 * id; Ai[1] = (A[2] * A[7] - A[1] * A[8]) * id; Ai[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+    Ai[3] = c1 * id; Ai[4] = (A[0] * A[8] - A[2] * A[6]) * id; Ai[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+    Ai[6] = c2 * id; Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id; Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d.Hinv[9 * (int64_t)q + i] = Ai[i];
+    for (int64_t i = d.pt_off[q]; i < d.pt_off[q + 1]; ++i) {
+        const int e = d.pt_edges[i];
+        if (d.level[e] || d.slot[d.edges[e].pose] < 0) continue;
+        const double *W = d.W + 18 * (int64_t)e;
+        double *Y = d.Y + 18 * (int64_t)e;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) Y[3 * a + b] = W[3 * a] * Ai[b] + W[3 * a + 1] * Ai[3 + b] + W[3 * a + 2] * Ai[6 + b];
+    }
+}
+
+// S block (i, j), i <= j:  [i == j] (Hpp_i + lambda I)  -  sum_q Y_{e(i,q)} W_{e(j,q)}' ; rhs_i = bp_i - sum_q Y_{e(i,q)} bl_q
+__global__ __launch_bounds__(BA_T) void ba_schur_kernel(BaDev d, double lambda) {
+    __shared__ double s_red[(BA_T / 64) * 42], s_out[42];
+    // block index -> (i, j) of the upper triangle
+    int i = 0, rem = blockIdx.x;
+    while (rem >= d.nF - i) { rem -= d.nF - i; ++i; }
+    const int j = i + rem;
+    const int32_t *ti = d.table + (int64_t)i * d.nX, *tj = d.table + (int64_t)j * d.nX;
+    double acc[42];
+#pragma unroll
+    for (int k = 0; k < 42; ++k) acc[k] = 0.0;
+    for (int q = threadIdx.x; q < d.nX; q += BA_T) {
+        const int e1 = ti[q];
+        if (e1 < 0 || d.level[e1]) continue;
+        const double *Y = d.Y + 18 * (int64_t)e1;
+        if (i == j) {
+            const double *bl = d.bl + 3 * (int64_t)q;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[36 + a] += Y[3 * a] * bl[0] + Y[3 * a + 1] * bl[1] + Y[3 * a + 2] * bl[2];
+        }
+        const int e2 = tj[q];
+        if (e2 < 0 || d.level[e2]) continue;
+        const double *W = d.W + 18 * (int64_t)e2;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) acc[6 * a + b] += Y[3 * a] * W[3 * b] + Y[3 * a + 1] * W[3 * b + 1] + Y[3 * a + 2] * W[3 * b + 2];
+    }
+    block_sum<42, BA_T>(acc, s_red, s_out);
+    const int n6 = 6 * d.nF;
+    if (threadIdx.x < 36) {
+        const int a = threadIdx.x / 6, b = threadIdx.x % 6;
+        double v = -s_out[6 * a + b];
+        if (i == j) { v += d.Hpp[36 * i + 6 * a + b]; if (a == b) v += lambda; }
+        d.S[(int64_t)(6 * i + a) * n6 + 6 * j + b] = v;
+        if (i != j) d.S[(int64_t)(6 * j + b) * n6 + 6 * i + a] = v;
+    }
+    if (i == j && threadIdx.x < 6) d.xs[6 * i + threadIdx.x] = d.bp[6 * i + threadIdx.x] - s_out[36 + threadIdx.x];
+}
+
+// dense Cholesky solve S x = xs in place (single workgroup; S is L2-resident); scal[3] = 1 on success
+__global__ __launch_bounds__(1024) void ba_dense_solve_kernel(BaDev d) {
+    __shared__ int s_ok;
+    __shared__ double s_piv;
+    const int n = 6 * d.nF, tid = threadIdx.x;
+    double *S = d.S, *x = d.xs;
+    if (tid == 0) s_ok = 1;
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        if (tid == 0) {
+            const double dj = S[(int64_t)j * n + j];
+            if (!(dj > 0.0)) s_ok = 0;
+            s_piv = sqrt(dj);
+        }
+        __syncthreads();
+        if (!s_ok) break;
+        const double piv = s_piv;
+        for (int i = j + tid; i < n; i += 1024) S[(int64_t)i * n + j] = (i == j) ? piv : S[(int64_t)i * n + j] / piv;
+        __syncthreads();
+        // trailing update of the lower triangle: rows i > j, columns j < k <= i
+        const int m = n - j - 1;
+        for (int idx = tid; idx < m * m; idx += 1024) {
+            const int i = j + 1 + idx / m, k = j + 1 + idx % m;
+            if (k <= i) S[(int64_t)i * n + k] -= S[(int64_t)i * n + j] * S[(int64_t)k * n + j];
+        }
+        __syncthreads();
+    }
+    if (s_ok) {
+        for (int j = 0; j < n; ++j) {          // L y = b
+            if (tid == 0) x[j] /= S[(int64_t)j * n + j];
+            __syncthreads();
+            const double xj = x[j];
+            for (int i = j + 1 + tid; i < n; i += 1024) x[i] -= S[(int64_t)i * n + j] * xj;
+            __syncthreads();
+        }
+        for (int j = n - 1; j >= 0; --j) {     // L' x = y
+            if (tid == 0) x[j] /= S[(int64_t)j * n + j];
+            __syncthreads();
+            const double xj = x[j];
+            for (int i = tid; i < j; i += 1024) x[i] -= S[(int64_t)j * n + i] * xj;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) d.scal[3] = s_ok ? 1.0 : 0.0;
+}
+
+// dx_l = Hll^-1 (bl - sum_e W_e' dx_p), points_trial = points + dx_l, per-point share of computeScale
+__global__ __launch_bounds__(BA_T) void ba_point_update_kernel(BaDev d, double lambda, const double *points, double *points_trial) {
+    const int q = blockIdx.x * BA_T + threadIdx.x;
+    if (q >= d.nX) return;
+    const bool ok = d.scal[3] != 0.0;
+    const double *bl = d.bl + 3 * (int64_t)q;
+    double v[3] = {bl[0], bl[1], bl[2]}, x[3] = {0, 0, 0};
+    if (ok) {
+        for (int64_t i = d.pt_off[q]; i < d.pt_off[q + 1]; ++i) {
+            const int e = d.pt_edges[i];
+            if (d.level[e]) continue;
+            const int s = d.slot[d.edges[e].pose];
+            if (s < 0) continue;
+            const double *W = d.W + 18 * (int64_t)e, *xp = d.xs + 6 * s;
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int a = 0; a < 6; ++a) v[b] -= W[3 * a + b] * xp[a];
+        }
+        const double *Ai = d.Hinv + 9 * (int64_t)q;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) x[a] = Ai[3 * a] * v[0] + Ai[3 * a + 1] * v[1] + Ai[3 * a + 2] * v[2];
+    }
+    double sc = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        points_trial[3 * (int64_t)q + a] = points[3 * (int64_t)q + a] + x[a];
+        sc += x[a] * (lambda * x[a] + bl[a]);
+    }
+    d.sc_pt[q] = sc;
+}
+
+// poses_trial = exp(dx) * poses for the free poses (copy for the fixed ones); scal[1] = pose share of computeScale
+__global__ __launch_bounds__(BA_T) void ba_pose_update_kernel(BaDev d, double lambda, const double *poses, double *poses_trial) {
+    __shared__ double s_red[BA_T / 64], s_out[1];
+    const bool ok = d.scal[3] != 0.0;
+    double sc[1] = {0.0};
+    for (int p = threadIdx.x; p < d.nP; p += BA_T) {
+        const int s = d.slot[p];
+        double T[12];
+        if (s >= 0 && ok) {
+            double u[6];
+            for (int a = 0; a < 6; ++a) { u[a] = d.xs[6 * s + a]; sc[0] += u[a] * (lambda * u[a] + d.bp[6 * s + a]); }
+            se3_oplus(poses + 12 * (int64_t)p, u, T);
+        } else {
+            for (int a = 0; a < 12; ++a) T[a] = poses[12 * (int64_t)p + a];
+        }
+        for (int a = 0; a < 12; ++a) poses_trial[12 * (int64_t)p + a] = T[a];
+    }
+    block_sum<1, BA_T>(sc, s_red, s_out);
+    if (threadIdx.x == 0) d.scal[1] = s_out[0];
+}
+
+// pose-only variant of the reduced system (no landmarks in the state): S = blockdiag(Hpp + lambda I), xs = bp
+__global__ void ba_pose_only_system_kernel(BaDev d, double lambda) {
+    const int n6 = 6 * d.nF;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n6 * n6; idx += gridDim.x * blockDim.x) {
+        const int r = idx / n6, c = idx % n6;
+        double v = 0;
+        if (r / 6 == c / 6) { v = d.Hpp[36 * (r / 6) + 6 * (r % 6) + c % 6]; if (r == c) v += lambda; }
+        d.S[idx] = v;
+        if (c == 0) d.xs[r] = d.bp[r];
+    }
+}
+
+// final chi2 / depth test of LocalBundleAdjustment (:774-821, :826-858)
+__global__ __launch_bounds__(BA_T) void ba_classify_kernel(BaDev d, const double *poses, const double *points, uint8_t *out) {
+    const int64_t e = (int64_t)blockIdx.x * BA_T + threadIdx.x;
+    if (e >= d.nE) return;
+    const SivoEdge ed = d.edges[e];
+    const double *er = d.err + 3 * e;
+    const double c2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * ed.inv_sigma2;
+    const double *R = poses + 12 * (int64_t)ed.pose, *X = points + 3 * (int64_t)ed.point;
+    const double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + R[11];
+    out[e] = (c2 > (ed.stereo ? 7.815 : 5.991)) || !(z > 0.0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct Buf {
+    void *p = nullptr;
+    ~Buf() { if (p) (void)hipFree(p); }
+    void alloc(size_t bytes) { SIVO_HIP(hipMalloc(&p, bytes ? bytes : 8)); }
+    void upload(const void *src, size_t bytes) { alloc(bytes); if (bytes) SIVO_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice)); }
+    void zero(size_t bytes) { alloc(bytes); SIVO_HIP(hipMemset(p, 0, bytes ? bytes : 8)); }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+class BaSolver {
+ public:
+    BaSolver(const double *poses, const uint8_t *fixed, int nP, const double *points, int nX, bool points_fixed,
+             const SivoEdge *edges, int64_t nE, const double intr[5], double dm, double ds)
+        : nP_(nP), nX_(nX), nE_(nE), points_fixed_(points_fixed) {
+        if (nP < 0 || nX < 0 || nE < 0) throw std::invalid_argument("negative size");
+        if (nE > INT32_MAX) throw std::invalid_argument("too many edges");
+        std::vector<int32_t> slot((size_t)std::max(nP, 1), -1);
+        nF_ = 0;
+        for (int i = 0; i < nP; ++i) slot[i] = fixed && fixed[i] ? -1 : nF_++;
+        for (int64_t e = 0; e < nE; ++e)
+            if (edges[e].pose < 0 || edges[e].pose >= nP || edges[e].point < 0 || edges[e].point >= nX)
+                throw std::invalid_argument("edge refers to a pose/point outside the arrays");
+        if ((int64_t)nF_ * nX > ((int64_t)1 << 28)) throw std::invalid_argument("problem too large for the dense (free pose x point) edge table");
+        // CSR by point and by free pose; (free pose, point) -> edge table
+        std::vector<int64_t> pt_off((size_t)nX + 1, 0), ps_off((size_t)nF_ + 1, 0);
+        for (int64_t e = 0; e < nE; ++e) {
+            pt_off[edges[e].point + 1]++;
+            if (slot[edges[e].pose] >= 0) ps_off[slot[edges[e].pose] + 1]++;
+        }
+        for (int q = 0; q < nX; ++q) pt_off[q + 1] += pt_off[q];
+        for (int s = 0; s < nF_; ++s) ps_off[s + 1] += ps_off[s];
+        std::vector<int32_t> pt_edges((size_t)std::max<int64_t>(nE, 1)), ps_edges((size_t)std::max<int64_t>(ps_off[nF_], 1));
+        std::vector<int32_t> table(points_fixed ? 1 : (size_t)std::max<int64_t>((int64_t)nF_ * nX, 1), -1);
+        {
+            std::vector<int64_t> f1(pt_off.begin(), pt_off.end() - 1), f2(ps_off.begin(), ps_off.end() - 1);
+            for (int64_t e = 0; e < nE; ++e) {
+                pt_edges[f1[edges[e].point]++] = (int32_t)e;
+                const int s = slot[edges[e].pose];
+                if (s >= 0) {
+                    ps_edges[f2[s]++] = (int32_t)e;
+                    if (!points_fixed) {
+                        int32_t &t = table[(size_t)s * nX + edges[e].point];
+                        if (t >= 0) throw std::invalid_argument("two edges join the same (keyframe, map point) pair");
+                        t = (int32_t)e;
+                    }
+                }
+            }
+        }
+        slot_.upload(slot.data(), slot.size() * 4);
+        pt_off_.upload(pt_off.data(), pt_off.size() * 8); pt_edges_.upload(pt_edges.data(), pt_edges.size() * 4);
+        ps_off_.upload(ps_off.data(), ps_off.size() * 8); ps_edges_.upload(ps_edges.data(), ps_edges.size() * 4);
+        table_.upload(table.data(), table.size() * 4);
+        edges_.upload(edges, (size_t)nE * sizeof(SivoEdge));
+        level_.zero((size_t)nE); robust_.alloc((size_t)nE);
+        SIVO_HIP(hipMemset(robust_.p, 1, (size_t)std::max<int64_t>(nE, 1)));
+        for (int k = 0; k < 2; ++k) { poses_[k].upload(poses, (size_t)nP * 96); points_[k].upload(points, (size_t)nX * 24); }
+        err_.zero((size_t)nE * 24); Jp_.alloc((size_t)nE * 144); Jx_.alloc((size_t)nE * 72); wo_.alloc((size_t)nE * 8);
+        rchi_.zero((size_t)nE * 8); W_.alloc((size_t)nE * 144); Y_.alloc((size_t)nE * 144);
+        Hll_.alloc((size_t)nX * 72); bl_.alloc((size_t)nX * 24); Hinv_.alloc((size_t)nX * 72); xl_.alloc((size_t)nX * 24);
+        sc_pt_.zero((size_t)nX * 8);
+        Hpp_.zero((size_t)nF_ * 288); bp_.zero((size_t)nF_ * 48);
+        S_.alloc((size_t)36 * nF_ * nF_ * 8); xs_.zero((size_t)nF_ * 48);
+        scal_.zero(8 * 8);
+        hpp_last_.assign((size_t)std::max(nF_, 1) * 36, 0.0);
+        d_.edges = edges_.as<SivoEdge>(); d_.nE = nE; d_.slot = slot_.as<int32_t>();
+        d_.level = level_.as<uint8_t>(); d_.robust = robust_.as<uint8_t>();
+        d_.nP = nP; d_.nF = nF_; d_.nX = nX;
+        d_.K = Intr{intr[0], intr[1], intr[2], intr[3], intr[4]}; d_.delta_mono = dm; d_.delta_stereo = ds;
+        d_.pt_off = pt_off_.as<int64_t>(); d_.pt_edges = pt_edges_.as<int32_t>();
+        d_.ps_off = ps_off_.as<int64_t>(); d_.ps_edges = ps_edges_.as<int32_t>(); d_.table = table_.as<int32_t>();
+        d_.err = err_.as<double>(); d_.Jp = Jp_.as<double>(); d_.Jx = Jx_.as<double>(); d_.wo = wo_.as<double>();
+        d_.rchi = rchi_.as<double>(); d_.W = W_.as<double>(); d_.Y = Y_.as<double>();
+        d_.Hll = Hll_.as<double>(); d_.bl = bl_.as<double>(); d_.Hinv = Hinv_.as<double>(); d_.xl = xl_.as<double>();
+        d_.sc_pt = sc_pt_.as<double>(); d_.Hpp = Hpp_.as<double>(); d_.bp = bp_.as<double>();
+        d_.S = S_.as<double>(); d_.xs = xs_.as<double>(); d_.scal = scal_.as<double>();
+        slot_host_ = slot;
+    }
+
+    void set_flags(const uint8_t *level, const uint8_t *robust) {
+        if (level && nE_) SIVO_HIP(hipMemcpy(level_.p, level, (size_t)nE_, hipMemcpyHostToDevice));
+        if (robust && nE_) SIVO_HIP(hipMemcpy(robust_.p, robust, (size_t)nE_, hipMemcpyHostToDevice));
+    }
+    void get_level(uint8_t *level) const { if (nE_) SIVO_HIP(hipMemcpy(level, level_.p, (size_t)nE_, hipMemcpyDeviceToHost)); }
+
+    // g2o::SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg
+    int optimize(int iterations, const volatile int *stop, int *trials) {
+        const unsigned gE = (unsigned)cdiv64(std::max<int64_t>(nE_, 1), BA_T), gX = (unsigned)cdiv(std::max(nX_, 1), BA_T);
+        const bool landmarks = !points_fixed_ && nX_ > 0;
+        double lambda = 0, ni = 2;
+        int it = 0;
+        for (; it < iterations; ++it) {
+            if (stop && *stop) break;
+            const double *P = poses_[cur_].as<double>(), *X = points_[cur_].as<double>();
+            if (nE_) hipLaunchKernelGGL(ba_edge_kernel<true>, dim3(gE), dim3(BA_T), 0, 0, d_, P, X);
+            hipLaunchKernelGGL(ba_sum_kernel, dim3(1), dim3(1024), 0, 0, d_.rchi, nE_, d_.scal);
+            if (landmarks) hipLaunchKernelGGL(ba_point_kernel, dim3(gX), dim3(BA_T), 0, 0, d_);
+            if (nF_) hipLaunchKernelGGL(ba_pose_kernel, dim3(nF_), dim3(BA_T), 0, 0, d_);
+            hipLaunchKernelGGL(ba_maxdiag_kernel, dim3(1), dim3(1024), 0, 0, d_, landmarks ? 1 : 0);
+            SIVO_HIP(hipGetLastError());
+            double sc[4];
+            SIVO_HIP(hipMemcpy(sc, d_.scal, sizeof sc, hipMemcpyDeviceToHost));
+            if (nF_) SIVO_HIP(hipMemcpy(hpp_last_.data(), d_.Hpp, (size_t)nF_ * 288, hipMemcpyDeviceToHost));
+            double current = sc[0];
+            if (it == 0) { lambda = 1e-5 * sc[2]; ni = 2; }
+            double rho = 0;
+            int qmax = 0;
+            do {
+                double *Pt = poses_[cur_ ^ 1].as<double>(), *Xt = points_[cur_ ^ 1].as<double>();
+                if (nF_) {
+                    if (landmarks) {
+                        hipLaunchKernelGGL(ba_point_inverse_kernel, dim3(gX), dim3(BA_T), 0, 0, d_, lambda);
+                        hipLaunchKernelGGL(ba_schur_kernel, dim3((unsigned)(nF_ * (nF_ + 1) / 2)), dim3(BA_T), 0, 0, d_, lambda);
+                    } else {
+                        hipLaunchKernelGGL(ba_pose_only_system_kernel, dim3(64), dim3(256), 0, 0, d_, lambda);
+                    }
+                    hipLaunchKernelGGL(ba_dense_solve_kernel, dim3(1), dim3(1024), 0, 0, d_);
+                } else {
+                    if (landmarks) hipLaunchKernelGGL(ba_point_inverse_kernel, dim3(gX), dim3(BA_T), 0, 0, d_, lambda);
+                    const double one = 1.0;
+                    SIVO_HIP(hipMemcpy(d_.scal + 3, &one, 8, hipMemcpyHostToDevice));
+                }
+                hipLaunchKernelGGL(ba_pose_update_kernel, dim3(1), dim3(BA_T), 0, 0, d_, lambda, P, Pt);
+                if (landmarks) hipLaunchKernelGGL(ba_point_update_kernel, dim3(gX), dim3(BA_T), 0, 0, d_, lambda, X, Xt);
+                else if (nX_) SIVO_HIP(hipMemcpyAsync(Xt, X, (size_t)nX_ * 24, hipMemcpyDeviceToDevice, 0));
+                if (nE_) hipLaunchKernelGGL(ba_edge_kernel<false>, dim3(gE), dim3(BA_T), 0, 0, d_, (const double *)Pt, (const double *)Xt);
+                hipLaunchKernelGGL(ba_sum_kernel, dim3(1), dim3(1024), 0, 0, d_.rchi, nE_, d_.scal);
+                if (landmarks) hipLaunchKernelGGL(ba_sum_kernel, dim3(1), dim3(1024), 0, 0, d_.sc_pt, (int64_t)nX_, d_.scal + 4);
+                SIVO_HIP(hipGetLastError());
+                double r[5];
+                SIVO_HIP(hipMemcpy(r, d_.scal, sizeof r, hipMemcpyDeviceToHost));
+                const bool ok = r[3] != 0.0;
+                double temp = ok ? r[0] : DBL_MAX;
+                const double scale = ok ? r[1] + (landmarks ? r[4] : 0.0) : 0.0;
+                rho = (current - temp) / (scale + 1e-3);
+                if (rho > 0 && std::isfinite(temp)) {
+                    double alpha = 1. - std::pow(2 * rho - 1, 3);
+                    alpha = std::min(alpha, 2. / 3.);
+                    lambda *= std::max(1. / 3., alpha);
+                    ni = 2; current = temp;
+                    cur_ ^= 1;
+                    P = poses_[cur_].as<double>(); X = points_[cur_].as<double>();
+                } else {
+                    lambda *= ni; ni *= 2;
+                }
+                ++qmax;
+                if (trials) ++*trials;
+            } while (rho < 0 && qmax < 10 && !(stop && *stop));
+            if (qmax == 10 || rho == 0) { ++it; break; }
+        }
+        return it;
+    }
+
+    // chi2 / depth classification at the current estimates using the error vectors g2o would hold
+    void classify(uint8_t *outlier_host, bool to_level, bool drop_kernels) {
+        if (!nE_) return;
+        Buf out;
+        out.alloc((size_t)nE_);
+        hipLaunchKernelGGL(ba_classify_kernel, dim3((unsigned)cdiv64(nE_, BA_T)), dim3(BA_T), 0, 0, d_,
+                           (const double *)poses_[cur_].p, (const double *)points_[cur_].p, out.as<uint8_t>());
+        SIVO_HIP(hipGetLastError());
+        if (to_level) SIVO_HIP(hipMemcpy(level_.p, out.p, (size_t)nE_, hipMemcpyDeviceToDevice));
+        if (drop_kernels) SIVO_HIP(hipMemset(robust_.p, 0, (size_t)nE_));
+        if (outlier_host) SIVO_HIP(hipMemcpy(outlier_host, out.p, (size_t)nE_, hipMemcpyDeviceToHost));
+    }
+
+    void download(double *poses, double *points, double *err) const {
+        if (poses && nP_) SIVO_HIP(hipMemcpy(poses, poses_[cur_].p, (size_t)nP_ * 96, hipMemcpyDeviceToHost));
+        if (points && nX_ && !points_fixed_) SIVO_HIP(hipMemcpy(points, points_[cur_].p, (size_t)nX_ * 24, hipMemcpyDeviceToHost));
+        if (err && nE_) SIVO_HIP(hipMemcpy(err, err_.p, (size_t)nE_ * 24, hipMemcpyDeviceToHost));
+    }
+    const std::vector<double> &hpp_last() const { return hpp_last_; }
+    int free_slot(int pose) const { return pose >= 0 && pose < nP_ ? slot_host_[pose] : -1; }
+    int n_free() const { return nF_; }
+
+ private:
+    int nP_, nX_, nF_ = 0;
+    int64_t nE_;
+    bool points_fixed_;
+    int cur_ = 0;
+    Buf slot_, pt_off_, pt_edges_, ps_off_, ps_edges_, table_, edges_, level_, robust_, poses_[2], points_[2];
+    Buf err_, Jp_, Jx_, wo_, rchi_, W_, Y_, Hll_, bl_, Hinv_, xl_, sc_pt_, Hpp_, bp_, S_, xs_, scal_;
+    std::vector<double> hpp_last_;
+    std::vector<int32_t> slot_host_;
+    BaDev d_{};
+};
+
+}  // namespace sivo
+
+using namespace sivo;
+
+static void need_gpu() {
+    if (sivo_device_count() < 1) throw std::runtime_error("no HIP device: libsivo_hip has no CPU fallback");
+}
+
+extern "C" int sivo_ba_optimize(double *poses, const uint8_t *pose_fixed, int n_poses, double *points, int n_points,
+                                const SivoEdge *edges, int64_t n_edges, const double intr[5], double delta_mono,
+                                double delta_stereo, const uint8_t *level, const uint8_t *robust, int iterations,
+                                const volatile int *stop_flag, double *err_out, double *hpp_last_out,
+                                int *iterations_run, int *trials) {
+    return guarded([&] {
+        if (!poses || !intr || (n_edges && !edges) || (n_points && !points)) throw std::invalid_argument("null argument");
+        if (iterations < 0) throw std::invalid_argument("negative iteration count");
+        need_gpu();
+        BaSolver s(poses, pose_fixed, n_poses, points, n_points, false, edges, n_edges, intr, delta_mono, delta_stereo);
+        s.set_flags(level, robust);
+        int tr = 0;
+        const int n = s.optimize(iterations, stop_flag, &tr);
+        s.download(poses, points, err_out);
+        if (hpp_last_out && s.n_free()) std::memcpy(hpp_last_out, s.hpp_last().data(), (size_t)s.n_free() * 288);
+        if (iterations_run) *iterations_run = n;
+        if (trials) *trials = tr;
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_local_ba(double *poses, const uint8_t *pose_fixed, int n_poses, double *points, int n_points,
+                             const SivoEdge *edges, int64_t n_edges, const double intr[5], const volatile int *stop_flag,
+                             uint8_t *outlier, int cov_pose, double *cov, int *cov_ok, int *iterations, int *trials) {
+    return guarded([&] {
+        if (!poses || !intr || (n_edges && !edges) || (n_points && !points)) throw std::invalid_argument("null argument");
+        need_gpu();
+        if (iterations) *iterations = 0;
+        if (trials) *trials = 0;
+        if (cov_ok) *cov_ok = 0;
+        if (outlier && n_edges) std::memset(outlier, 0, (size_t)n_edges);
+        if (stop_flag && *stop_flag) return SIVO_OK;                         // :757-761
+        BaSolver s(poses, pose_fixed, n_poses, points, n_points, false, edges, n_edges, intr,
+                   (double)std::sqrt(5.991f), (double)std::sqrt(7.815f));      // const float thHuber = sqrt(5.991f) (:646-647)
+        int tr = 0;
+        int n = s.optimize(5, stop_flag, &tr);                                // :763-764
+        if (!(stop_flag && *stop_flag)) {                                     // bDoMore (:766-772)
+            s.classify(nullptr, true, true);                                  // :774-817
+            n += s.optimize(10, stop_flag, &tr);                              // :820-821
+        }
+        s.classify(outlier, false, false);                                    // :824-858
+        s.download(poses, points, nullptr);
+        if (cov && s.free_slot(cov_pose) >= 0) {
+            const bool ok = inv6_spd(s.hpp_last().data() + 36 * s.free_slot(cov_pose), cov);
+            if (cov_ok) *cov_ok = ok;
+        }
+        if (iterations) *iterations = n;
+        if (trials) *trials = tr;
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_pose_optimize(const double pose0[12], const double *points, int n_points, const SivoEdge *edges,
+                                  int64_t n_edges, const double intr[5], uint8_t *outlier, double pose_out[12],
+                                  double cov[36], int *cov_ok, double *chi2, int *n_inliers, int *iterations,
+                                  int *trials) {
+    return guarded([&] {
+        if (!pose0 || !pose_out || !intr || (n_edges && (!edges || !points || !outlier))) throw std::invalid_argument("null argument");
+        if (n_edges < 0 || n_edges > (1 << 24)) throw std::invalid_argument("edge count out of range");
+        for (int64_t e = 0; e < n_edges; ++e)
+            if (edges[e].point < 0 || edges[e].point >= n_points) throw std::invalid_argument("edge refers to a point outside the array");
+        std::memcpy(pose_out, pose0, 96);
+        if (cov_ok) *cov_ok = 0;
+        if (n_inliers) *n_inliers = 0;
+        if (iterations) *iterations = 0;
+        if (trials) *trials = 0;
+        if (n_edges < 3) {                                                    // nInitialCorrespondences < 3 (:409-411)
+            if (n_edges) std::memset(outlier, 0, (size_t)n_edges);
+            return SIVO_OK;
+        }
+        need_gpu();
+        Buf dP, dX, dE, dOut, dErr, dPose, dCov, dChi, dInfo;
+        dP.upload(pose0, 96); dX.upload(points, (size_t)n_points * 24); dE.upload(edges, (size_t)n_edges * sizeof(SivoEdge));
+        dOut.zero((size_t)n_edges); dErr.zero((size_t)n_edges * 24); dPose.alloc(96); dCov.alloc(288);
+        dChi.alloc((size_t)n_edges * 8); dInfo.zero(16);
+        PoseOptArgs a;
+        a.pose0 = dP.as<double>(); a.points = dX.as<double>(); a.edges = dE.as<SivoEdge>(); a.n = (int)n_edges;
+        a.K = Intr{intr[0], intr[1], intr[2], intr[3], intr[4]};
+        a.delta_mono = (double)std::sqrt(5.991f); a.delta_stereo = (double)std::sqrt(7.815f);   // :307-308
+        a.outlier = dOut.as<uint8_t>(); a.err = dErr.as<double>(); a.pose_out = dPose.as<double>(); a.cov = dCov.as<double>();
+        a.chi2 = chi2 ? dChi.as<double>() : nullptr; a.info = dInfo.as<int>();
+        hipLaunchKernelGGL(pose_optimize_kernel, dim3(1), dim3(PO_THREADS), 0, 0, a);
+        SIVO_HIP(hipGetLastError());
+        int info[4];
+        SIVO_HIP(hipMemcpy(info, dInfo.p, sizeof info, hipMemcpyDeviceToHost));
+        SIVO_HIP(hipMemcpy(pose_out, dPose.p, 96, hipMemcpyDeviceToHost));
+        SIVO_HIP(hipMemcpy(outlier, dOut.p, (size_t)n_edges, hipMemcpyDeviceToHost));
+        if (cov) SIVO_HIP(hipMemcpy(cov, dCov.p, 288, hipMemcpyDeviceToHost));
+        if (chi2) SIVO_HIP(hipMemcpy(chi2, dChi.p, (size_t)n_edges * 8, hipMemcpyDeviceToHost));
+        if (cov_ok) *cov_ok = info[0];
+        if (n_inliers) *n_inliers = (int)n_edges - info[1];
+        if (iterations) *iterations = info[2];
+        if (trials) *trials = info[3];
+        return SIVO_OK;
+    });
+}

@@ -46,3 +46,46 @@ def synthetic_stereo(seed, rows=352, cols=1024, disparity=8):
     rng = np.random.default_rng(seed + 1)
     right = left[:, disparity:disparity + cols].astype(np.float64) + rng.normal(0, 1.0, (rows, cols))
     return left[:, :cols].copy(), np.clip(np.rint(right), 0, 255).astype(np.uint8)
+
+
+EDGE_DTYPE = np.dtype([("pose", np.int32), ("point", np.int32), ("stereo", np.int32), ("pad_", np.int32),
+                       ("obs", np.float64, 3), ("inv_sigma2", np.float64)])     # == SivoEdge (48 B)
+
+
+def make_ba_scene(seed=99, n_kf=20, n_pts=3000, stereo_frac=0.8):
+    """forward trajectory, frustum box of points, KITTI-00 intrinsics."""
+    rng = np.random.default_rng(seed)
+    fx = fy = 718.856; cx, cy, bf = 498.692, 173.215, 386.1448
+    poses = np.zeros((n_kf, 12))
+    for k in range(n_kf):
+        yaw = np.deg2rad(rng.uniform(-2, 2))
+        Rwc = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+        twc = np.array([rng.normal(0, 0.05), rng.normal(0, 0.02), 1.0 * k])
+        Rcw = Rwc.T; tcw = -Rcw @ twc
+        poses[k, :9] = Rcw.ravel(); poses[k, 9:] = tcw
+    pts = np.stack([rng.uniform(-20, 20, n_pts), rng.uniform(-5, 5, n_pts), rng.uniform(2, 62, n_pts)], 1)
+    edges = []
+    for k in range(n_kf):
+        R = poses[k, :9].reshape(3, 3); t = poses[k, 9:]
+        pc = pts @ R.T + t
+        z = pc[:, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u = fx * pc[:, 0] / z + cx; v = fy * pc[:, 1] / z + cy
+        vis = (z > 0.5) & (z < 80) & (u >= 0) & (u < 1024) & (v >= 0) & (v < 352)
+        for i in np.nonzero(vis)[0]:
+            lvl = rng.integers(0, 8); sig = 1.2 ** lvl
+            st = rng.random() < stereo_frac
+            obs = [u[i] + rng.normal(0, sig), v[i] + rng.normal(0, sig), u[i] - bf / z[i] + rng.normal(0, sig)]
+            if rng.random() < 0.02: obs[0] += 30          # outliers exercise the Huber branch
+            edges.append((k, i, int(st), 0, obs, 1.0 / (sig * sig)))
+    return poses, pts, np.array(edges, dtype=EDGE_DTYPE), (fx, fy, cx, cy, bf)
+
+
+def perturb_pose(P, rng, rot=0.01, trans=0.1):
+    """Left-multiply a pose (12: Rcw row-major, tcw) by a small random rigid motion."""
+    w = rng.normal(0, rot, 3); th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+    Q = np.array(P, np.float64)
+    Q[:9] = (R @ P[:9].reshape(3, 3)).ravel(); Q[9:] = R @ P[9:] + rng.normal(0, trans, 3)
+    return Q
