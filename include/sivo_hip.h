@@ -261,14 +261,15 @@ int sivo_ba_linearize(const double *poses, int n_poses, const double *points, in
  * (setFixed, :73, :601-610).  level[e] != 0: edge excluded (setLevel(1));
  * robust[e] != 0: Huber kernel with delta_mono / delta_stereo; NULL = all
  * active / all robust.  At most one edge per (keyframe, map point) pair.
- * stop_flag is polled like g2o's forceStopFlag (:573-575).  poses and points are
+ * stop_flag (one byte, i.e. the reference's `bool *pbStopFlag`; may be NULL) is
+ * polled between trials like g2o's forceStopFlag (:573-575).  poses and points are
  * updated in place; err_out (3 per edge, may be NULL) receives the error vectors
  * g2o would hold afterwards; hpp_last_out (36 per free pose, may be NULL) the
  * pose blocks of the last buildSystem. */
 int sivo_ba_optimize(double *poses, const uint8_t *pose_fixed, int n_poses, double *points, int n_points,
                      const SivoEdge *edges, int64_t n_edges, const double intr[5], double delta_mono,
                      double delta_stereo, const uint8_t *level, const uint8_t *robust, int iterations,
-                     const volatile int *stop_flag, double *err_out, double *hpp_last_out,
+                     const volatile uint8_t *stop_flag, double *err_out, double *hpp_last_out,
                      int *iterations_run, int *trials);
 
 /* Optimizer::LocalBundleAdjustment from the point the graph is built
@@ -279,7 +280,7 @@ int sivo_ba_optimize(double *poses, const uint8_t *pose_fixed, int n_poses, doub
  * of keyframe `cov_pose` as g2o's computeMarginals returns it (:900-907);
  * *cov_ok = 0 when that keyframe is fixed / out of range / its block is singular. */
 int sivo_local_ba(double *poses, const uint8_t *pose_fixed, int n_poses, double *points, int n_points,
-                  const SivoEdge *edges, int64_t n_edges, const double intr[5], const volatile int *stop_flag,
+                  const SivoEdge *edges, int64_t n_edges, const double intr[5], const volatile uint8_t *stop_flag,
                   uint8_t *outlier, int cov_pose, double *cov, int *cov_ok, int *iterations, int *trials);
 
 /* Optimizer::PoseOptimization from the point the edges are built

@@ -1,11 +1,11 @@
 // SIVO::Optimizer — the per-edge arithmetic of the reference class (reference include/orbslam/Optimizer.h:43-79).
 //
 // The reference's static members build g2o graphs from KeyFrame / MapPoint objects and hand the solve to
-// g2o + CHOLMOD; that control plane and the sparse solve stay on the host and outside this library
-// (SURVEY.md 8f-3 ranks the device-side Hessian assembly as a later step).  What runs once per LM
-// iteration over ALL edges — computeError + linearizeOplus + chi2 + Huber — is provided here on arrays,
-// plus the chi2 inlier classification the reference applies between optimisation rounds
-// (Optimizer.cc:423-471, 774-821).
+// g2o + CHOLMOD.  The graph walk (which keyframes / map points take part, writing the results back under the
+// map mutex) is SLAM control plane and stays with the caller; everything from "the graph is built" to "the
+// estimates are recovered" is provided here on arrays and runs on the GPU: per-edge computeError +
+// linearizeOplus + chi2 + Huber, the Levenberg-Marquardt / Schur-complement loops with the reference's
+// iteration and re-classification schedules, and the marginal pose covariance (Optimizer.cc:409-491, 757-926).
 #ifndef OPTIMIZER_H
 #define OPTIMIZER_H
 
@@ -37,6 +37,29 @@ class Optimizer {
     // Outlier test of LocalBundleAdjustment (Optimizer.cc:774-821): an edge is an outlier iff
     // chi2 > 5.991 (mono) / 7.815 (stereo) or the point is behind the camera.
     static int ClassifyOutliers(const std::vector<SivoEdge> &edges, const EdgeBatchResult &lin, std::vector<uint8_t> &outlier);
+
+    // int Optimizer::PoseOptimization(Frame *pFrame) (Optimizer.cc:273-491) from the built edges on: `pose` (12:
+    // Rcw row-major, tcw = pFrame->mTcw) is optimised in place against the fixed map points; outlier = mvbOutlier;
+    // covariance = the 6x6 block SetCovariance receives (left untouched and covarianceValid = false when
+    // computeMarginals would fail).  Returns nInitialCorrespondences - nBad.
+    static int PoseOptimization(double pose[12], const std::vector<double> &mapPoints, const std::vector<SivoEdge> &edges,
+                                const double intr[5], std::vector<uint8_t> &outlier, double covariance[36],
+                                bool *covarianceValid = nullptr);
+
+    // void Optimizer::LocalBundleAdjustment(KeyFrame*, bool *pbStopFlag, Map*, bool) (Optimizer.cc:493-926) from the
+    // built graph on: poses (fixedPose[i] != 0 for lFixedCameras and keyframe 0) and points are optimised in place;
+    // erase[e] = 1 for the observations the caller removes (:824-878); covariance = marginal block of keyframe
+    // covariancePose (:900-907).
+    static void LocalBundleAdjustment(std::vector<double> &poses, const std::vector<uint8_t> &fixedPose,
+                                      std::vector<double> &points, const std::vector<SivoEdge> &edges, const double intr[5],
+                                      const bool *pbStopFlag, std::vector<uint8_t> &erase, int covariancePose = -1,
+                                      double *covariance = nullptr, bool *covarianceValid = nullptr);
+
+    // void Optimizer::BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust) (Optimizer.cc:49-271)
+    // from the built graph on: one optimize(nIterations) with (bRobust) or without Huber kernels.
+    static void BundleAdjustment(std::vector<double> &poses, const std::vector<uint8_t> &fixedPose, std::vector<double> &points,
+                                 const std::vector<SivoEdge> &edges, const double intr[5], int nIterations = 5,
+                                 const bool *pbStopFlag = nullptr, bool bRobust = true);
 };
 
 }  // namespace SIVO

@@ -753,7 +753,7 @@ class BaSolver {
     void get_level(uint8_t *level) const { if (nE_) SIVO_HIP(hipMemcpy(level, level_.p, (size_t)nE_, hipMemcpyDeviceToHost)); }
 
     // g2o::SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg
-    int optimize(int iterations, const volatile int *stop, int *trials) {
+    int optimize(int iterations, const volatile uint8_t *stop, int *trials) {
         const unsigned gE = (unsigned)cdiv64(std::max<int64_t>(nE_, 1), BA_T), gX = (unsigned)cdiv(std::max(nX_, 1), BA_T);
         const bool landmarks = !points_fixed_ && nX_ > 0;
         double lambda = 0, ni = 2;
@@ -865,7 +865,7 @@ static void need_gpu() {
 extern "C" int sivo_ba_optimize(double *poses, const uint8_t *pose_fixed, int n_poses, double *points, int n_points,
                                 const SivoEdge *edges, int64_t n_edges, const double intr[5], double delta_mono,
                                 double delta_stereo, const uint8_t *level, const uint8_t *robust, int iterations,
-                                const volatile int *stop_flag, double *err_out, double *hpp_last_out,
+                                const volatile uint8_t *stop_flag, double *err_out, double *hpp_last_out,
                                 int *iterations_run, int *trials) {
     return guarded([&] {
         if (!poses || !intr || (n_edges && !edges) || (n_points && !points)) throw std::invalid_argument("null argument");
@@ -884,7 +884,7 @@ extern "C" int sivo_ba_optimize(double *poses, const uint8_t *pose_fixed, int n_
 }
 
 extern "C" int sivo_local_ba(double *poses, const uint8_t *pose_fixed, int n_poses, double *points, int n_points,
-                             const SivoEdge *edges, int64_t n_edges, const double intr[5], const volatile int *stop_flag,
+                             const SivoEdge *edges, int64_t n_edges, const double intr[5], const volatile uint8_t *stop_flag,
                              uint8_t *outlier, int cov_pose, double *cov, int *cov_ok, int *iterations, int *trials) {
     return guarded([&] {
         if (!poses || !intr || (n_edges && !edges) || (n_points && !points)) throw std::invalid_argument("null argument");

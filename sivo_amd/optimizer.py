@@ -67,7 +67,7 @@ def ba_optimize(poses, fixed, points, edges, intr, iterations, level=None, robus
 
 
 def local_ba(poses, fixed, points, edges, intr, cov_pose=-1, stop=None):
-    """Optimizer::LocalBundleAdjustment (reference Optimizer.cc:757-926) on arrays; `stop` is a ctypes c_int or None."""
+    """Optimizer::LocalBundleAdjustment (reference Optimizer.cc:757-926) on arrays; `stop` is a ctypes c_uint8 (the reference's bool *pbStopFlag) or None."""
     poses = np.array(poses, np.float64).reshape(-1, 12).copy(); points = np.array(points, np.float64).reshape(-1, 3).copy()
     fixed = np.ascontiguousarray(fixed, np.uint8); edges = np.ascontiguousarray(edges, EDGE_DTYPE)
     nE = edges.shape[0]

@@ -5,6 +5,7 @@
 //   test_api gpu <prototxt> <weights.sivow> <frame.bin> <outdir>
 //        frame.bin = int32 rows, int32 cols, then rows*cols*3 BGR bytes; writes the outputs for
 //        tests/test_gpu_cpp_api.py to compare with the Python binding (same library, bit-identical).
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -135,7 +136,7 @@ static int run_gpu(int argc, char **argv) {
     std::vector<SivoEdge> edges;
     const double intr[5] = {718.856, 718.856, 498.692, 173.215, 386.1448};
     for (int i = 0; i < 100; ++i) {
-        const double X = -5 + 0.1 * i, Y = 0.5, Z = 10 + i;
+        const double X = -5 + 0.1 * i, Y = 0.5 + 0.3 * ((i * 7) % 11 - 5), Z = 10 + i;   // not collinear
         points.insert(points.end(), {X, Y, Z});
         SivoEdge e{};
         e.pose = 0; e.point = i; e.stereo = i & 1; e.inv_sigma2 = 1.0;
@@ -148,6 +149,45 @@ static int run_gpu(int argc, char **argv) {
     std::vector<uint8_t> outlier;
     CHECK(SIVO::Optimizer::ClassifyOutliers(edges, lin, outlier) == 1 && outlier[50] == 1);
     CHECK(lin.chi2[0] < 1e-20 && lin.weight[50] < 1.0 && lin.Jpose[3] == -1.0 / 10 * intr[0]);
+
+    // PoseOptimization: start 5 cm / 0.3 deg off, all-stereo edges -> back at the identity, the planted outlier flagged
+    for (auto &e : edges) e.stereo = 1;
+    double pose[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0.05, -0.02, 0.03}, cov[36];
+    {
+        const double a = 0.005;
+        pose[0] = std::cos(a); pose[2] = std::sin(a); pose[6] = -std::sin(a); pose[8] = std::cos(a);
+    }
+    bool covValid = false;
+    const int inliers = SIVO::Optimizer::PoseOptimization(pose, points, edges, intr, outlier, cov, &covValid);
+    CHECK(inliers == 99 && outlier[50] == 1 && covValid && cov[0] > 0 && cov[35] > 0);
+    CHECK(std::fabs(pose[9]) < 2e-3 && std::fabs(pose[10]) < 2e-3 && std::fabs(pose[11]) < 2e-3 && std::fabs(pose[2]) < 1e-4);
+
+    // LocalBundleAdjustment: two keyframes (first fixed), perturbed points, noise-free observations
+    std::vector<double> kfs = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, -0.5, 0, -1.0};
+    std::vector<SivoEdge> ba;
+    for (int k = 0; k < 2; ++k)
+        for (int i = 0; i < 100; ++i) {
+            const double X = points[3 * i] + kfs[12 * k + 9], Y = points[3 * i + 1] + kfs[12 * k + 10], Z = points[3 * i + 2] + kfs[12 * k + 11];
+            SivoEdge e{};
+            e.pose = k; e.point = i; e.stereo = 1; e.inv_sigma2 = 1.0;
+            e.obs[0] = intr[0] * X / Z + intr[2]; e.obs[1] = intr[1] * Y / Z + intr[3]; e.obs[2] = e.obs[0] - intr[4] / Z;
+            ba.push_back(e);
+        }
+    std::vector<double> kfs0 = kfs, pts0 = points;
+    kfs[12 + 9] += 0.03; kfs[12 + 11] -= 0.02;
+    for (int i = 0; i < 100; ++i) pts0[3 * i + 2] += (i % 2 ? 0.05 : -0.05);
+    std::vector<uint8_t> erase;
+    bool stop = false;
+    SIVO::Optimizer::LocalBundleAdjustment(kfs, {1, 0}, pts0, ba, intr, &stop, erase, 1, cov, &covValid);
+    int nErase = 0;
+    for (uint8_t b : erase) nErase += b;
+    CHECK(nErase == 0 && covValid && std::fabs(kfs[12 + 9] - kfs0[12 + 9]) < 5e-3 && std::fabs(kfs[12 + 11] - kfs0[12 + 11]) < 5e-3);
+    CHECK(kfs[9] == 0.0 && kfs[0] == 1.0);                                          // fixed keyframe untouched
+    stop = true;
+    std::vector<double> kfs1 = kfs;
+    SIVO::Optimizer::LocalBundleAdjustment(kfs1, {1, 0}, pts0, ba, intr, &stop, erase);
+    CHECK(kfs1 == kfs);                                                              // pbStopFlag honoured
+    SIVO::Optimizer::BundleAdjustment(kfs1, {1, 0}, pts0, ba, intr, 3, nullptr, false);
     std::printf(failures ? "gpu checks FAILED\n" : "gpu checks ok\n");
     return failures;
 }

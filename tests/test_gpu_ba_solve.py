@@ -78,7 +78,7 @@ def test_local_ba_config5_matches_oracle(oracle):
     g2 = optimizer.local_ba(P0, fixed, X0, edges, intr, cov_pose=19)
     assert np.array_equal(g2["poses"], g["poses"]) and np.array_equal(g2["points"], g["points"])
     # pbStopFlag raised before the call: untouched (Optimizer.cc:757-761)
-    stop = C.c_int(1)
+    stop = C.c_uint8(1)
     s = optimizer.local_ba(P0, fixed, X0, edges, intr, stop=stop)
     assert np.array_equal(s["poses"], P0) and s["iterations"] == 0 and not s["outlier"].any()
 
