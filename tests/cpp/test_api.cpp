@@ -20,6 +20,7 @@
 #include "orbslam/ORBextractor.h"
 #include "orbslam/ORBmatcher.h"
 #include "orbslam/Optimizer.h"
+#include "kitti_io.hpp"
 
 static int failures = 0;
 #define CHECK(cond)                                                              \
@@ -195,6 +196,19 @@ static int run_gpu(int argc, char **argv) {
 int main(int argc, char **argv) {
     if (argc >= 2 && std::string(argv[1]) == "cpu") return run_cpu();
     if (argc >= 2 && std::string(argv[1]) == "gpu") return run_gpu(argc, argv);
+    if (argc >= 5 && std::string(argv[1]) == "kitti") {          // kitti <sequence dir> <Tcw.bin> <out.txt>
+        std::vector<std::string> l, r;
+        std::vector<double> t;
+        SIVO::loadImages(argv[2], l, r, t);
+        std::printf("%zu %s %s %g\n", t.size(), l.back().c_str(), r.back().c_str(), t.back());
+        std::vector<float> T;
+        if (FILE *f = std::fopen(argv[3], "rb")) {
+            float v;
+            while (std::fread(&v, 4, 1, f) == 1) T.push_back(v);
+            std::fclose(f);
+        }
+        return SIVO::saveTrajectoryKITTI(argv[4], T) ? 0 : 1;
+    }
     std::printf("usage: test_api cpu | gpu ...\n");
     return 2;
 }

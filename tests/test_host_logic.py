@@ -183,3 +183,41 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "liboracle" not in src, f
+
+
+def test_kitti_sequence_listing_and_trajectory_format(tmp_path):
+    """times.txt parsing + file naming (reference sivo.cc:145-177) and the CameraTrajectory.txt line format
+    (System.cc:322-329): 12 numbers, fixed, 9 decimals, [Rwc | twc] row-major; the header-only C++ twin writes
+    the same bytes (exercised by tests/cpp/test_api cpu)."""
+    from sivo_amd import kitti
+    seq = tmp_path / "00"
+    seq.mkdir()
+    (seq / "times.txt").write_text("0.000000e+00\n1.037875e-01\n\n2.076350e-01\n")
+    left, right, times = kitti.load_images(str(seq))
+    assert times == [0.0, 0.1037875, 0.207635]
+    assert left[2] == f"{seq}/image_2/000002.png" and right[0] == f"{seq}/image_3/000000.png" and len(left) == 3
+    a = 0.1
+    T = np.array([[np.cos(a), 0, -np.sin(a), 0, 1, 0, np.sin(a), 0, np.cos(a), 0.5, -0.25, 2.0],
+                  [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0]], np.float32)
+    out = tmp_path / "CameraTrajectory.txt"
+    kitti.save_trajectory_kitti(str(out), T)
+    lines = out.read_text().splitlines()
+    # identity pose: twc = -Rwc * 0 is a NEGATIVE zero, which `f << fixed` prints with its sign (as the reference does)
+    assert lines[1] == " ".join(["1.000000000", "0.000000000", "0.000000000", "-0.000000000",
+                                 "0.000000000", "1.000000000", "0.000000000", "-0.000000000",
+                                 "0.000000000", "0.000000000", "1.000000000", "-0.000000000"])
+    v = np.array(lines[0].split(), np.float64).reshape(3, 4)
+    Rcw = T[0, :9].reshape(3, 3).astype(np.float64)
+    np.testing.assert_allclose(v[:, :3], Rcw.T, atol=1e-7)
+    np.testing.assert_allclose(v[:, 3], -Rcw.T @ T[0, 9:].astype(np.float64), atol=1e-6)
+    assert all(len(x.split(".")[1]) == 9 for x in lines[0].split())
+    # the C++ twin produces the same file
+    import subprocess
+    from test_cpp_api import BIN, _build
+    if not os.path.exists(BIN):
+        _build()
+    T.tofile(tmp_path / "T.bin")
+    r = subprocess.run([BIN, "kitti", str(seq), str(tmp_path / "T.bin"), str(tmp_path / "cpp.txt")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "cpp.txt").read_text() == out.read_text()
+    assert r.stdout.split() == ["3", f"{seq}/image_2/000002.png", f"{seq}/image_3/000002.png", "0.207635"]
