@@ -231,28 +231,33 @@ def main():
         by_kernel = {}
         for p in prof:
             k = by_kernel.setdefault(p["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
-            k["ms"] += p["ms_total"]; k["launches"] += p["launches"]
+            k["ms"] += p["ms_total"]; k["launches"] += p["kernel_launches"]
             k["flops"] += p["flops_per_sample"] * p["samples"] * p["launches"]
             k["bytes"] += p["bytes_per_sample"] * p["samples"] * p["launches"]
-        conv = {k: v for k, v in by_kernel.items() if k.startswith("conv_")}
-        dom_name, dom = max(conv.items(), key=lambda kv: kv[1]["ms"])
+        conv = {k: v for k, v in by_kernel.items() if k.startswith("conv_") or k.startswith("wino4_")}
+        mfma = {k: v for k, v in conv.items() if v["flops"] > 0}            # the transform kernels carry no MFMA work
+        dom_name, dom = max(mfma.items(), key=lambda kv: kv[1]["ms"])
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        # Winograd F(2x2,3x3) executes 16 MFMA multiplies per 4 outputs instead of 36: the matrix cores do
-        # algorithmic/2.25 flops.  `achieved` stays the ALGORITHMIC (direct-convolution) count of SURVEY 8d.
-        exec_ratio = (1 / 2.25) if dom_name.startswith("conv_wino") else 1.0
+        # Winograd executes fewer MFMA multiplies than the direct convolution it computes: F(2x2,3x3) 16 per 4 outputs
+        # instead of 36 (algorithmic/2.25), F(4x4,3x3) 36 per 16 outputs instead of 144 (algorithmic/4).  `achieved`
+        # stays the ALGORITHMIC (direct-convolution) count of SURVEY 8d; mfma_util prices the executed flops.
+        exec_ratio = 0.25 if dom_name.startswith("wino4") else (1 / 2.25) if dom_name.startswith("conv_wino") else 1.0
         conv_ms = sum(v["ms"] for v in conv.values()); conv_fl = sum(v["flops"] for v in conv.values())
         all_ms = sum(v["ms"] for v in by_kernel.values())
         traffic = None
         try:   # HBM bytes per launch of the dominant kernel from the committed PMC pass (bench cannot collect PMC itself)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")))
             traffic = tj.get(dom_name, {}).get("bytes")
+            traffic_file = "profiles/r01_g_pmc_traffic.json"
         except Exception:
             pass
         roofline = {"bound": "mfma", "kernel": "sivo::" + dom_name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_source": "profiles/r01_g_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, bytes per launch)" if traffic else None,
                     "mfma_executed_tflops": round(achieved * exec_ratio, 2), "mfma_util": round(achieved * exec_ratio / FP32_MFMA_PEAK_TFLOPS, 4),
-                    "note": "achieved = algorithmic direct-conv FLOPs / HIP-event time; the dominant kernel is Winograd F(2x2,3x3) in fp32, which issues 2.25x fewer MFMA flops (mfma_util = executed MFMA flops / peak)" if exec_ratio < 1 else "",
+                    "note": ("achieved = algorithmic direct-conv FLOPs of the layers this kernel serves / its HIP-event time; the kernel is the batched GEMM of Winograd F(4x4,3x3) in fp32, "
+                             "which issues 4x fewer MFMA flops (mfma_util = executed MFMA flops / peak); its input/output transform kernels are listed in kernels_ms_per_frame and counted in all_conv") if exec_ratio == 0.25
+                    else "achieved = algorithmic direct-conv FLOPs / HIP-event time; the dominant kernel is Winograd F(2x2,3x3) in fp32, which issues 2.25x fewer MFMA flops (mfma_util = executed MFMA flops / peak)" if exec_ratio < 1 else "",
                     "launches_per_frame": dom["launches"] / args.steps,
                     "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
                     "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),

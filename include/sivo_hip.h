@@ -136,6 +136,9 @@ typedef struct {
     double flops_per_sample; /* algorithmic FLOPs of one sample (convolutions; 0 otherwise) */
     double bytes_per_sample; /* algorithmic HBM bytes of one sample */
     double ms_total;         /* sum of the event-timed durations of all harvested launches */
+    int32_t kernel_launches; /* kernel launches behind `launches` forward passes (an F(4x4,3x3) layer runs its three
+                              * kernels once per sample group and reports them as three rows) */
+    int32_t pad_;
 } SivoOpProfile;
 int sivo_segnet_profile(sivo_segnet_t h, int enable);
 int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int capacity, int *n_out);

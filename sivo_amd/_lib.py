@@ -34,7 +34,8 @@ class KeyPoint(C.Structure):  # == cv::KeyPoint / SivoKeyPoint (28 bytes)
 
 class OpProfile(C.Structure):  # == SivoOpProfile
     _fields_ = [("layer", C.c_char * 64), ("kernel", C.c_char * 96), ("samples", C.c_int32), ("launches", C.c_int32),
-                ("flops_per_sample", C.c_double), ("bytes_per_sample", C.c_double), ("ms_total", C.c_double)]
+                ("flops_per_sample", C.c_double), ("bytes_per_sample", C.c_double), ("ms_total", C.c_double),
+                ("kernel_launches", C.c_int32), ("pad_", C.c_int32)]
 
 
 class Edge(C.Structure):      # == SivoEdge (48 bytes)

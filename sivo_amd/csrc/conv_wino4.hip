@@ -1,0 +1,339 @@
+// conv_wino4.hip — 3x3 convolution by Winograd F(4x4, 3x3) as three kernels around a batched fp32 MFMA GEMM.
+//
+// Lavin & Gray (CVPR 2016), interpolation points {0, +-1, +-2, inf}:
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A   per 4x4 output tile, 6x6 input tile d;
+// for each of the 36 transform positions xi an independent GEMM over the input channels
+//   M_xi[tile][cout] = sum_c V_xi[tile][c] * U_xi[c][cout]
+// i.e. 36 multiplies per 16 outputs instead of 144: 4x fewer MFMA flops than the direct convolution
+// (F(2x2,3x3) in conv_wino.hip saves 2.25x).  Everything stays fp32; the larger transform constants cost
+// accuracy (measured through the whole Standard net: |dlogit| ~2e-4 against the 1e-3 budget, F(2x2) ~3e-5), so
+// this path is used only where it pays: the wide (>= 128 channel) layers, where a transform-position GEMM has
+// enough arithmetic intensity (C*K / (2 (C + K)) flop/byte >= 32) to sit on the matrix cores.
+//
+// A fused F(4x4) kernel would need 36 positions x 4 accumulator registers per 16x16 MFMA block = 144 VGPRs
+// with no register blocking left, i.e. two LDS operand reads per MFMA — LDS-bound.  Splitting the work lets
+// the GEMM use 64x64 register tiles (0.5 LDS reads per MFMA) while the two transforms are plain streaming
+// kernels; the price is the V and M round trip (2.25x the activation size each), which is why the work is
+// issued in groups of samples small enough for V and M to stay in the 256 MB memory-side cache.
+//
+//   wino4_input_kernel   x (n,C,H,W)            -> V [36][C][Pp]      thread = (channel, tile), 6 float4 loads +
+//                                                                     neighbour columns by wave shuffle
+//   wino4_gemm_kernel    V, U [36][C][Kp]       -> M [36][Kp][Pp]     128 tiles x 128 couts per workgroup, 4 waves
+//                                                                     x (64 x 64), K-chunks of 16 channels by
+//                                                                     LDS-DMA into a double buffer, XOR-swizzled
+//   wino4_output_kernel  M                      -> y (n,K,H,W)        thread = (cout, tile): A^T M A, bias+BN,
+//                                                                     ReLU, Philox dropout, 4 float4 stores
+// P = tiles of the sample group (n * ceil(H/4) * W/4), Pp / Kp padded to multiples of 128.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdlib>
+#include <vector>
+
+#include "segnet_kernels.hpp"
+
+namespace sivo {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t wino4_dropout_word(uint32_t e, uint32_t site, uint32_t sample, uint64_t seed) {
+    uint32_t c0 = e >> 7, c1 = site, c2 = sample, c3 = 0u, k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint32_t sel = (e >> 5) & 3u;
+    return sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
+}
+
+struct Wino4Args {
+    const float *in; int64_t in_sample_stride;   // (n or 1, C, H, W)
+    float *V, *M;                                // workspace
+    const float *U;                              // [36][C][Kp]
+    const float *ep_scale, *ep_shift;
+    float *out;                                  // (n, K, H, W)
+    int n, C, K, Kp, H, W, th, tw, P, Pp;
+    int relu, drop_site, sample0;
+    uint64_t seed;
+};
+
+// 1-D input transform B^T d (points 0, +-1, +-2, inf)
+__device__ __forceinline__ void wino4_bt(const float d0, const float d1, const float d2, const float d3, const float d4,
+                                         const float d5, float *t) {
+    const float a = d4 - 4.f * d2, b = d3 - 4.f * d1, c = d4 - d2, e = 2.f * (d3 - d1);
+    t[0] = 4.f * d0 - 5.f * d2 + d4;
+    t[1] = a + b;
+    t[2] = a - b;
+    t[3] = c + e;
+    t[4] = c - e;
+    t[5] = 4.f * d1 - 5.f * d3 + d5;
+}
+
+constexpr int W4_TIN = 256;
+
+// grid: (ceil(P / 256), C).  Lanes run over consecutive tiles (x fastest), so V stores are fully coalesced.
+__global__ __launch_bounds__(W4_TIN) void wino4_input_kernel(Wino4Args a) {
+    const int p = blockIdx.x * W4_TIN + threadIdx.x, c = blockIdx.y;
+    if (p >= a.P) return;       // whole waves leave together except in the last block; shuffles below only pair live lanes
+    const int tx = p % a.tw, ty = (p / a.tw) % a.th, n = p / (a.tw * a.th);
+    const float *src = a.in + (int64_t)n * a.in_sample_stride + (int64_t)c * a.H * a.W;
+    const int x0 = 4 * tx, y0 = 4 * ty - 1;
+    const int lane = threadIdx.x & 63;
+    // the left / right neighbour tile is the previous / next lane when it exists in this wave and in this tile row
+    const bool left_lane = lane > 0 && tx > 0, right_lane = lane < 63 && tx < a.tw - 1 && p + 1 < a.P;
+    float d[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const int y = y0 + r;
+        const bool row_ok = y >= 0 && y < a.H;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row_ok) v = *reinterpret_cast<const f32x4 *>(src + (int64_t)y * a.W + x0);     // W % 4 == 0: aligned, in bounds
+        // every lane takes part in the shuffles (rows outside the image contribute zeros)
+        const float from_left = __shfl_up(v.w, 1, 64), from_right = __shfl_down(v.x, 1, 64);
+        float l = 0.f, rr = 0.f;
+        if (row_ok) {
+            if (left_lane) l = from_left; else if (x0 > 0) l = src[(int64_t)y * a.W + x0 - 1];
+            if (right_lane) rr = from_right; else if (x0 + 4 < a.W) rr = src[(int64_t)y * a.W + x0 + 4];
+        }
+        d[r][0] = l; d[r][1] = v.x; d[r][2] = v.y; d[r][3] = v.z; d[r][4] = v.w; d[r][5] = rr;
+    }
+    // columns, then rows
+    float t[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float col[6];
+        wino4_bt(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], col);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t[i][j] = col[i];
+    }
+    float *dst = a.V + (int64_t)c * a.Pp + p;
+    const int64_t xi_stride = (int64_t)a.C * a.Pp;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float row[6];
+        wino4_bt(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], row);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) dst[(int64_t)(i * 6 + j) * xi_stride] = row[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// batched GEMM  M_xi[k][p] = sum_c U_xi[c][k] * V_xi[c][p]
+// ---------------------------------------------------------------------------------------------------
+constexpr int G_BM = 128, G_BN = 128, G_KC = 16;          // tiles x couts x channels per stage
+constexpr int G_STAGE = G_KC * (G_BM + G_BN);             // floats per LDS stage (16 KB)
+
+// Stage rows are 128 floats (a multiple of the 32 banks): the four k-rows a wave reads together would collide, so
+// row c stores its 16-float groups XOR-swizzled by (c & 1): even rows as they are, odd rows with neighbouring
+// groups exchanged.  LDS-DMA fixes the destination (wave base + lane * 16 B), so the swizzle is applied to the SOURCE.
+__global__ __launch_bounds__(256, 2) void wino4_gemm_kernel(Wino4Args a, int ptiles, int ktiles) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int wm = wave & 1, wn = wave >> 1;
+    // XCD-aware order: (position, p-tile) pairs round-robin over the 8 XCDs, the k-tiles of a pair back to back on one
+    // XCD so the V tile is fetched into that L2 once; U_xi (C*Kp*4 B <= 1 MB) stays resident in every L2.
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    const int kt = j % ktiles, pair = (j / ktiles) * 8 + xcd;
+    if (pair >= 36 * ptiles) return;
+    const int xi = pair / ptiles, pt = pair % ptiles;
+    const float *Vg = a.V + ((int64_t)xi * a.C) * a.Pp + (int64_t)pt * G_BM;
+    const float *Ug = a.U + ((int64_t)xi * a.C) * a.Kp + (int64_t)kt * G_BN;
+
+    // DMA: a stage = 16 V rows (512 B each) then 16 U rows; one instruction = 1 KB = two rows; 16 instructions per
+    // stage, 4 per wave.  Lane -> (row within the pair, 16-byte chunk); logical chunk = physical ^ (4 * (row & 1)).
+    const int d_row = lane >> 5, d_chunk = lane & 31;
+    auto dma = [&](int chunk, int buf) {
+        float *dstb = lds + buf * G_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int inst = wave * 4 + i;               // 0..15: 0..7 -> V rows 2*inst, 2*inst+1; 8..15 -> U rows
+            const bool isU = inst >= 8;
+            const int row = ((inst & 7) << 1) + d_row;
+            const int lchunk = d_chunk ^ ((row & 1) << 2);
+            const float *src = (isU ? Ug + (int64_t)(chunk * G_KC + row) * a.Kp : Vg + (int64_t)(chunk * G_KC + row) * a.Pp) + lchunk * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dstb + inst * 256), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = a.C / G_KC;
+    dma(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
+    __syncthreads();
+    const int sw = (lk & 1) << 4;            // swizzle of this lane's k-row (c = 4*step + lk)
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int cur = chunk & 1;
+        if (chunk + 1 < nchunks) dma(chunk + 1, cur ^ 1);
+        const float *Vs = lds + cur * G_STAGE, *Us = Vs + G_KC * G_BM;
+#pragma unroll
+        for (int s = 0; s < G_KC / 4; ++s) {
+            const int rowoff = (4 * s + lk) * 128;
+            float af[4], bf[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) af[mt] = Vs[rowoff + ((wm * 64 + mt * 16 + li) ^ sw)];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bf[nt] = Us[rowoff + ((wn * 64 + nt * 16 + li) ^ sw)];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+    }
+    // acc[mt][nt][r] = M[tile p0 + wm*64 + mt*16 + 4*lk + r][cout k0 + wn*64 + nt*16 + li]
+    float *Mg = a.M + ((int64_t)xi * a.Kp + (int64_t)kt * G_BN) * a.Pp + (int64_t)pt * G_BM;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            *reinterpret_cast<f32x4 *>(Mg + (int64_t)(wn * 64 + nt * 16 + li) * a.Pp + wm * 64 + mt * 16 + 4 * lk) = acc[mt][nt];
+}
+
+// 1-D output transform A^T m
+__device__ __forceinline__ void wino4_at(const float m0, const float m1, const float m2, const float m3, const float m4,
+                                         const float m5, float *s) {
+    const float p12 = m1 + m2, q12 = m1 - m2, p34 = m3 + m4, q34 = m3 - m4;
+    s[0] = m0 + p12 + p34;
+    s[1] = q12 + 2.f * q34;
+    s[2] = p12 + 4.f * p34;
+    s[3] = q12 + 8.f * q34 + m5;
+}
+
+// grid: (ceil(P / 256), K)
+__global__ __launch_bounds__(W4_TIN) void wino4_output_kernel(Wino4Args a) {
+    const int p = blockIdx.x * W4_TIN + threadIdx.x, co = blockIdx.y;
+    if (p >= a.P) return;
+    const int tx = p % a.tw, ty = (p / a.tw) % a.th, n = p / (a.tw * a.th);
+    const float *src = a.M + (int64_t)co * a.Pp + p;
+    const int64_t xi_stride = (int64_t)a.Kp * a.Pp;
+    float t[4][6];      // A^T M (columns)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float m[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m[i] = src[(int64_t)(i * 6 + j) * xi_stride];
+        float s[4];
+        wino4_at(m[0], m[1], m[2], m[3], m[4], m[5], s);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i][j] = s[i];
+    }
+    const float sc = a.ep_scale[co], sh = a.ep_shift[co];
+    float *dst = a.out + ((int64_t)n * a.K + co) * a.H * a.W;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = 4 * ty + i;
+        if (y >= a.H) break;
+        float v[4];
+        wino4_at(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = v[r] * sc + sh;
+            if (a.relu) v[r] = v[r] > 0.f ? v[r] : 0.f;
+        }
+        const int x = 4 * tx;
+        if (a.drop_site >= 0) {
+            const uint32_t e = (uint32_t)((co * a.H + y) * a.W + x);
+            const uint32_t w = wino4_dropout_word(e, (uint32_t)a.drop_site, (uint32_t)(a.sample0 + n), a.seed) >> (e & 31);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = ((w >> r) & 1u) ? v[r] * 2.f : 0.f;
+        }
+        *reinterpret_cast<f32x4 *>(dst + (int64_t)y * a.W + x) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+bool wino4_supported(int ks, int cin, int cout, int H, int W) {
+    // below 128 channels a transform-position GEMM is HBM-bound on V and M (C*K / (2 (C + K)) < 32 flop/byte; couts are
+    // padded to 128 as well) and the fused F(2x2) kernel wins — measured on the Standard shapes: 256->128 0.69 vs 0.92 ms,
+    // 128->128 1.52 vs 1.74 ms, but 128->64 1.37 vs 0.95 ms and 64->64 3.2 vs 1.9 ms.  SIVO_WINO4_MINC moves the threshold.
+    static const int minc = std::getenv("SIVO_WINO4_MINC") ? std::atoi(std::getenv("SIVO_WINO4_MINC")) : 128;
+    return ks == 3 && cin % G_KC == 0 && cin >= minc && cout >= minc && W % 4 == 0 && H >= 4 && W >= 4;
+}
+
+int wino4_cout_pad(int cout) { return (cout + G_BN - 1) / G_BN * G_BN; }
+
+// Caffe (Cout,Cin,3,3) -> U [36][Cin][Kp] = G g G^T, evaluated in double and rounded once
+void wino4_pack_weights(const float *W, int cin, int cout, std::vector<float> &out, int *cout_pad) {
+    static const double G[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+    const int Kp = wino4_cout_pad(cout);
+    *cout_pad = Kp;
+    out.assign((size_t)36 * cin * Kp, 0.f);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float *g = W + ((size_t)co * cin + ci) * 9;
+            double t[6][3];
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[j] + G[i][1] * g[3 + j] + G[i][2] * g[6 + j];
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j)
+                    out[((size_t)(i * 6 + j) * cin + ci) * Kp + co] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+        }
+}
+
+// samples per group so that V + M of a group stay within `budget` bytes (memory-side cache), at least 1
+int wino4_group(int N, int cin, int cout, int H, int W, size_t budget) {
+    const int64_t tiles = (int64_t)((H + 3) / 4) * (W / 4);
+    const int64_t per_sample = 36 * tiles * 4 * ((int64_t)cin + wino4_cout_pad(cout));
+    int g = (int)(budget / (size_t)per_sample);
+    if (g < 1) g = 1;
+    if (g > N) g = N;
+    return g;
+}
+
+size_t wino4_workspace_floats(int group, int cin, int cout, int H, int W) {
+    const int64_t P = (int64_t)group * ((H + 3) / 4) * (W / 4), Pp = (P + G_BM - 1) / G_BM * G_BM;
+    return (size_t)(36 * Pp * ((int64_t)cin + wino4_cout_pad(cout)));
+}
+
+// ev (optional, profiling): 4 events per group, recorded before the input transform, after it, after the GEMM and
+// after the output transform.
+void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream_t s, hipEvent_t *ev) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_STAGE * 4);
+        attr_set = true;
+    }
+    Wino4Args a{};
+    a.C = c.Cin; a.K = c.Cout; a.Kp = c.CoutPad; a.H = c.H; a.W = c.W;
+    a.th = (c.H + 3) / 4; a.tw = c.W / 4;
+    a.U = c.wt; a.ep_scale = c.ep_scale; a.ep_shift = c.ep_shift;
+    a.relu = c.relu; a.drop_site = c.drop_site; a.seed = c.seed; a.in_sample_stride = c.in_sample_stride;
+    for (int n0 = 0; n0 < c.N; n0 += group) {
+        a.n = c.N - n0 < group ? c.N - n0 : group;
+        a.P = a.n * a.th * a.tw;
+        a.Pp = (a.P + G_BM - 1) / G_BM * G_BM;
+        a.in = c.in + (int64_t)n0 * c.in_sample_stride;
+        a.out = c.out + (int64_t)n0 * c.Cout * c.H * c.W;
+        a.sample0 = c.sample0 + n0;
+        a.V = workspace;
+        a.M = workspace + (size_t)36 * a.C * a.Pp;
+        const int ptiles = a.Pp / G_BM, ktiles = a.Kp / G_BN;
+        const unsigned pblocks = (unsigned)((a.P + W4_TIN - 1) / W4_TIN);
+        hipEvent_t *e = ev ? ev + 4 * (n0 / group) : nullptr;
+        if (e) (void)hipEventRecord(e[0], s);
+        hipLaunchKernelGGL(wino4_input_kernel, dim3(pblocks, (unsigned)a.C), dim3(W4_TIN), 0, s, a);
+        if (e) (void)hipEventRecord(e[1], s);
+        const int pairs8 = (36 * ptiles + 7) / 8;
+        hipLaunchKernelGGL(wino4_gemm_kernel, dim3((unsigned)(pairs8 * ktiles * 8)), dim3(256), 2 * G_STAGE * 4, s, a, ptiles, ktiles);
+        if (e) (void)hipEventRecord(e[2], s);
+        hipLaunchKernelGGL(wino4_output_kernel, dim3(pblocks, (unsigned)a.K), dim3(W4_TIN), 0, s, a);
+        if (e) (void)hipEventRecord(e[3], s);
+    }
+}
+
+}  // namespace sivo

@@ -54,6 +54,11 @@ struct Op {
     bool v2 = false;           // conv_v2.hip kernel + weight layout
     bool wino = false;         // conv_wino.hip kernel + pre-transformed weights
     int wino_cfg = 0;
+    bool wino4 = false;        // conv_wino4.hip: F(4x4,3x3) as input transform + batched GEMM + output transform
+    int wino4_group = 1;       // samples per V/M workspace pass
+    std::vector<hipEvent_t> w4_ev;                 // profiling: 4 events per group of the last launch
+    double w4_ms[3] = {0.0, 0.0, 0.0};             // input transform, GEMM, output transform
+    int w4_groups_last = 0, w4_launches = 0;
     int drop_site = -1;
     // lrn
     int local_size = 5;
@@ -85,6 +90,8 @@ struct sivo_segnet {
     double flops_shared = 0.0, flops_sample = 0.0;
     bool profile = false, pending = false;
     std::vector<void *> owned;
+    float *d_wino4_ws = nullptr;    // V + M workspace shared by every F(4x4,3x3) layer
+    size_t wino4_ws_floats = 0;
     ~sivo_segnet() {
         for (sivo::Op &op : ops) {
             if (op.ev0) (void)hipEventDestroy(op.ev0);
@@ -132,9 +139,17 @@ void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int 
     std::vector<float> wt;
     static const bool force_v1 = std::getenv("SIVO_CONV_V1") != nullptr;
     static const bool no_wino = std::getenv("SIVO_NO_WINOGRAD") != nullptr;
-    op.wino = !no_wino && wino_supported(ks, cin, cout, H, Wd);
-    op.v2 = !op.wino && conv2_supported(ks) && !force_v1;
-    if (op.wino) {
+    // F(4x4,3x3) for the wide layers (4x fewer MFMA flops; costs ~2e-4 of the 1e-3 logit budget) — SIVO_NO_WINO4 disables
+    static const bool no_wino4 = std::getenv("SIVO_NO_WINO4") != nullptr;
+    static const size_t wino4_budget = (size_t)(std::getenv("SIVO_WINO4_MB") ? std::atoi(std::getenv("SIVO_WINO4_MB")) : 2048) << 20;
+    op.wino4 = !no_wino && !no_wino4 && wino4_supported(ks, cin, cout, H, Wd);
+    op.wino = !op.wino4 && !no_wino && wino_supported(ks, cin, cout, H, Wd);
+    op.v2 = !op.wino4 && !op.wino && conv2_supported(ks) && !force_v1;
+    if (op.wino4) {
+        wino4_pack_weights(W, cin, cout, wt, &op.cout_pad);
+        op.wino4_group = wino4_group(S.T, cin, cout, H, Wd, wino4_budget);
+        S.wino4_ws_floats = std::max(S.wino4_ws_floats, wino4_workspace_floats(op.wino4_group, cin, cout, H, Wd));
+    } else if (op.wino) {
         static const int env_cfg = std::getenv("SIVO_WINO_CFG") ? std::atoi(std::getenv("SIVO_WINO_CFG")) : 0;
         op.wino_cfg = env_cfg;
         wino_pack_weights(W, cin, cout, op.wino_cfg, wt, &op.cout_pad);
@@ -224,7 +239,9 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             {
                 char kn[96];
                 const int bn = conv_cout_tile(op.ks, op.cout), kc = conv_k_chunk(op.ks, op.cin);
-                if (op.wino)
+                if (op.wino4)
+                    snprintf(kn, sizeof kn, "conv_wino4 (input + gemm + output kernels)");
+                else if (op.wino)
                     snprintf(kn, sizeof kn, op.wino_cfg == 2 ? "conv_wino_kernel<6,2,2,4>" : op.wino_cfg == 1 ? "conv_wino_kernel<4,1,2,8>" : "conv_wino_kernel<2,2,2,4>");
                 else if (op.v2)
                     snprintf(kn, sizeof kn, "conv_mfma2_kernel<%d,%d,32,%d,%d,%d>", op.ks, bn == 128 ? 4 : 8, bn, bn == 128 ? 2 : 4,
@@ -338,6 +355,10 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
         b.d = b.is_mask ? (void *)dev_alloc<uint8_t>(n) : (void *)dev_alloc<float>(n);
         S.owned.push_back(b.d);
     }
+    if (S.wino4_ws_floats) {
+        S.d_wino4_ws = dev_alloc<float>(S.wino4_ws_floats);
+        S.owned.push_back(S.d_wino4_ws);
+    }
     const int64_t hw = (int64_t)S.H * S.W;
     S.d_image = dev_alloc<uint8_t>(hw * 3);
     S.d_prob_sum = dev_alloc<float>(S.classes * hw);
@@ -359,6 +380,12 @@ void harvest(sivo_segnet &S) {
         SIVO_HIP(hipEventElapsedTime(&ms, op.ev0, op.ev1));
         op.ms_total += ms;
         op.launches += 1;
+        for (int g = 0; g < op.w4_groups_last; ++g)
+            for (int k = 0; k < 3; ++k) {
+                SIVO_HIP(hipEventElapsedTime(&ms, op.w4_ev[4 * g + k], op.w4_ev[4 * g + k + 1]));
+                op.w4_ms[k] += ms;
+            }
+        op.w4_launches += op.w4_groups_last;
     }
     S.pending = false;
 }
@@ -385,7 +412,22 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
                 a.out = (float *)bo.d;
                 a.N = N; a.Cin = op.cin; a.H = bi.H; a.W = bi.W; a.Cout = op.cout; a.CoutPad = op.cout_pad;
                 a.relu = op.relu; a.drop_site = op.drop_site; a.sample0 = sample0; a.seed = seed;
-                if (op.wino) launch_conv_wino(a, op.wino_cfg, st);
+                if (op.wino4) {
+                    hipEvent_t *sub = nullptr;
+                    if (S.profile) {
+                        op.w4_groups_last = cdiv(N, op.wino4_group);
+                        while ((int)op.w4_ev.size() < 4 * op.w4_groups_last) {
+                            hipEvent_t e;
+                            SIVO_HIP(hipEventCreate(&e));
+                            op.w4_ev.push_back(e);
+                        }
+                        sub = op.w4_ev.data();
+                    } else {
+                        op.w4_groups_last = 0;
+                    }
+                    launch_conv_wino4(a, S.d_wino4_ws, op.wino4_group, st, sub);
+                }
+                else if (op.wino) launch_conv_wino(a, op.wino_cfg, st);
                 else if (op.v2) launch_conv2(a, op.ks, st);
                 else launch_conv(a, op.ks, st);
                 break;
@@ -643,12 +685,38 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
         if (!h || !n_out) throw std::invalid_argument("null argument");
         DeviceGuard dg(h->device);
         harvest(*h);
-        *n_out = (int)h->ops.size();
+        int rows = 0;
+        for (const Op &op : h->ops) rows += op.wino4 ? 3 : 1;      // an F(4x4,3x3) layer reports its three kernels separately
+        *n_out = rows;
         if (!out) return SIVO_OK;
-        if (capacity < *n_out) return fail(SIVO_ERR_CAPACITY, "%d ops, capacity %d", *n_out, capacity);
+        if (capacity < *n_out) return fail(SIVO_ERR_CAPACITY, "%d rows, capacity %d", *n_out, capacity);
+        int r = 0;
         for (size_t i = 0; i < h->ops.size(); ++i) {
             const Op &op = h->ops[i];
-            SivoOpProfile &p = out[i];
+            if (op.wino4) {
+                static const char *kn[3] = {"wino4_input_kernel", "wino4_gemm_kernel", "wino4_output_kernel"};
+                const Blob &bi = h->blobs[op.in];
+                const double tiles = (double)((bi.H + 3) / 4) * (bi.W / 4), kp = wino4_cout_pad(op.cout);
+                const double bytes[3] = {4.0 * (op.cin * (double)bi.H * bi.W + 36.0 * op.cin * tiles),
+                                         4.0 * 36.0 * tiles * (op.cin + kp),
+                                         4.0 * (36.0 * kp * tiles + op.cout * (double)bi.H * bi.W)};
+                const int groups = op.launches ? op.w4_launches / op.launches : 1;
+                for (int k = 0; k < 3; ++k) {
+                    SivoOpProfile &p = out[r++];
+                    std::memset(&p, 0, sizeof p);
+                    std::snprintf(p.layer, sizeof p.layer, "%s", op.name.c_str());
+                    std::snprintf(p.kernel, sizeof p.kernel, "%s", kn[k]);
+                    p.samples = op.last_n;                           // per forward pass; `launches` below counts passes
+                    p.flops_per_sample = k == 1 ? op.flops : 0.0;    // algorithmic (direct-convolution) flops, on the GEMM row
+                    p.bytes_per_sample = bytes[k];
+                    p.ms_total = op.w4_ms[k];
+                    p.launches = op.launches;
+                    p.kernel_launches = op.w4_launches;
+                    (void)groups;
+                }
+                continue;
+            }
+            SivoOpProfile &p = out[r++];
             std::memset(&p, 0, sizeof p);
             std::snprintf(p.layer, sizeof p.layer, "%s", op.name.c_str());
             std::snprintf(p.kernel, sizeof p.kernel, "%s", op.kernel.c_str());
@@ -657,6 +725,7 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
             p.bytes_per_sample = op.bytes;
             p.ms_total = op.ms_total;
             p.launches = op.launches;
+            p.kernel_launches = op.launches;
         }
         return SIVO_OK;
     });
@@ -667,13 +736,15 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
 extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, int iters, int variant, double *ms_out) {
     return guarded([&] {
         if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device");
-        const bool wino = (variant & 64) && wino_supported(ks, Cin, Cout, H, W);
+        const bool wino4 = (variant & 512) && wino4_supported(ks, Cin, Cout, H, W);
+        const bool wino = !wino4 && (variant & 64) && wino_supported(ks, Cin, Cout, H, W);
         const int wcfg = (variant & 128) ? ((variant & 32) ? 2 : 1) : 0;
         const bool v2 = !wino && (variant & 16) && conv2_supported(ks);
         const int KC = v2 ? 4 : conv_k_chunk(ks, Cin), BN = conv_cout_tile(ks, Cout);
         const int cout_pad = cdiv(Cout, BN) * BN, nchunks = cdiv(Cin, KC);
         const size_t nin = (size_t)N * Cin * H * W, nout = (size_t)N * Cout * H * W;
-        const size_t nw = wino ? (size_t)wino_chunks(wcfg, Cin) * (Cout / wino_cout_tile(wcfg)) * wino_slab_floats(wcfg) : v2 ? (size_t)nchunks * (cout_pad / BN) * conv2_slab_floats(ks, Cout) : (size_t)nchunks * ks * ks * KC * cout_pad;
+        const int w4group = wino4 ? wino4_group(N, Cin, Cout, H, W, (size_t)(std::getenv("SIVO_WINO4_MB") ? std::atoi(std::getenv("SIVO_WINO4_MB")) : 2048) << 20) : 0;
+        const size_t nw = wino4 ? (size_t)36 * Cin * wino4_cout_pad(Cout) : wino ? (size_t)wino_chunks(wcfg, Cin) * (Cout / wino_cout_tile(wcfg)) * wino_slab_floats(wcfg) : v2 ? (size_t)nchunks * (cout_pad / BN) * conv2_slab_floats(ks, Cout) : (size_t)nchunks * ks * ks * KC * cout_pad;
         std::vector<float> hin(nin), hw(nw), hs(Cout, 1.f);
         uint32_t st = 12345;
         auto rnd = [&] { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
@@ -688,7 +759,9 @@ extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, i
         a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.CoutPad = cout_pad; a.relu = 1; a.drop_site = -1; a.variant = variant;
         hipEvent_t e0, e1;
         SIVO_HIP(hipEventCreate(&e0)); SIVO_HIP(hipEventCreate(&e1));
-        auto go = [&] { if (wino) launch_conv_wino(a, wcfg, nullptr); else if (v2) launch_conv2(a, ks, nullptr); else launch_conv(a, ks, nullptr); };
+        float *dws = wino4 ? dev_alloc<float>(wino4_workspace_floats(w4group, Cin, Cout, H, W)) : nullptr;
+        if (wino4) a.CoutPad = wino4_cout_pad(Cout);
+        auto go = [&] { if (wino4) launch_conv_wino4(a, dws, w4group, nullptr); else if (wino) launch_conv_wino(a, wcfg, nullptr); else if (v2) launch_conv2(a, ks, nullptr); else launch_conv(a, ks, nullptr); };
         if (wino) a.CoutPad = Cout;
         for (int i = 0; i < 2; ++i) go();
         SIVO_HIP(hipEventRecord(e0, nullptr));
@@ -698,7 +771,7 @@ extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, i
         float ms = 0;
         SIVO_HIP(hipEventElapsedTime(&ms, e0, e1));
         *ms_out = ms / iters;
-        (void)hipFree(din); (void)hipFree(dout); (void)hipFree(dw); (void)hipFree(ds);
+        (void)hipFree(din); (void)hipFree(dout); (void)hipFree(dw); (void)hipFree(ds); (void)hipFree(dws);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         return SIVO_OK;
     });

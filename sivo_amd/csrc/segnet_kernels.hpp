@@ -38,6 +38,14 @@ int wino_slab_floats(int cfg);
 int wino_chunks(int cfg, int cin);
 int wino_cout_tile(int cfg);
 
+// Winograd F(4x4,3x3): input transform + batched GEMM + output transform (conv_wino4.hip)
+bool wino4_supported(int ks, int cin, int cout, int H, int W);
+int wino4_cout_pad(int cout);
+void wino4_pack_weights(const float *W, int cin, int cout, std::vector<float> &out, int *cout_pad);
+int wino4_group(int N, int cin, int cout, int H, int W, size_t budget_bytes);
+size_t wino4_workspace_floats(int group, int cin, int cout, int H, int W);
+void launch_conv_wino4(const ConvArgs &a, float *workspace, int group, hipStream_t s, hipEvent_t *stage_events = nullptr);
+
 struct PoolArgs {
     const float *in;
     int64_t in_sample_stride;

@@ -117,13 +117,15 @@ class BayesianSegNet:
         check(lib().sivo_segnet_profile(self._h, 2 if (enable and reset) else int(bool(enable))))
 
     def profile_read(self):
-        """List of dicts: layer, kernel, samples, launches, flops_per_sample, bytes_per_sample, ms_total."""
+        """List of dicts: layer, kernel, samples, launches (forward passes), kernel_launches, flops_per_sample,
+        bytes_per_sample, ms_total."""
         n = C.c_int32(0)
         check(lib().sivo_segnet_profile_read(self._h, None, 0, C.byref(n)))
         arr = (_lib.OpProfile * n.value)()
         check(lib().sivo_segnet_profile_read(self._h, arr, n.value, C.byref(n)))
         return [dict(layer=a.layer.decode(), kernel=a.kernel.decode(), samples=a.samples, launches=a.launches,
-                     flops_per_sample=a.flops_per_sample, bytes_per_sample=a.bytes_per_sample, ms_total=a.ms_total)
+                     flops_per_sample=a.flops_per_sample, bytes_per_sample=a.bytes_per_sample, ms_total=a.ms_total,
+                     kernel_launches=a.kernel_launches)
                 for a in arr]
 
     def blob(self, name):

@@ -188,10 +188,12 @@ def _conv_stack_prototxt(T, H, W, width):
     return "".join(out)
 
 
-@pytest.mark.parametrize("H,W,width", [(22, 64, 64), (44, 136, 128), (6, 8, 64), (32, 64, 192), (10, 20, 64)])
+@pytest.mark.parametrize("H,W,width", [(22, 64, 64), (44, 136, 128), (6, 8, 64), (32, 64, 192), (10, 20, 64),
+                                       (22, 64, 256), (9, 12, 256), (4, 4, 256)])
 def test_winograd_and_direct_conv_shapes(oracle, H, W, width):
     """Ragged tile rows (H = 22 = 5.5 tiles of 4), widths that are multiples of 8 but not of 32, a Cout that is not a
-    multiple of 128, and a width (20) that falls back to the direct kernel: every blob against the oracle."""
+    multiple of 128, and a width (20) that falls back to the direct kernel: every blob against the oracle.
+    width 256 takes the F(4x4,3x3) path (conv_wino4.hip): ragged and odd tile rows, W a multiple of 4 only, one tile."""
     T = 3
     text = _conv_stack_prototxt(T, H, W, width)
     net, w, sn = _make(text, T, seed=11)
