@@ -169,19 +169,28 @@ def main():
     stats = {"kps": 0, "matches": 0}
 
     def orb_extract(res):
-        # Frame.cc:126-129: two extractor threads; here they also overlap the network on the GPU
+        # Frame.cc:126-129: two extractor threads; here they also overlap the network on the GPU.  A third thread
+        # joins them and matches EVERY left keypoint (candidates, Hamming, SAD refinement) while the network still
+        # runs; only the median cull of ComputeStereoMatches needs the class map (sivo_stereo_match_begin / _cull).
         th = [threading.Thread(target=lambda k=k, e=e, im=im: res.__setitem__(k, e(im)))
               for k, e, im in (("l", ex_l, d_left), ("r", ex_r, d_right))]
         [t.start() for t in th]
-        return th
+
+        def match():
+            [t.join() for t in th]
+            (kl, dl), (kr, dr) = res["l"], res["r"]
+            res["m"] = orb.stereo_match_begin(ex_l, ex_r, kl, dl, kr, dr, 386.1448, 386.1448 / 718.856)
+        tm = threading.Thread(target=match)
+        tm.start()
+        return [tm]
 
     def orb_finish(res, cls_host):
-        (kl, dl), (kr, dr) = res["l"], res["r"]
+        kl = res["l"][0]
+        uR, depth, _, sad = res["m"]
         # SelectSemanticKeys (Frame.cc:177-203): class <= TERRAIN(8) at the truncated keypoint position
         keep = cls_host[kl["y"].astype(np.int32), kl["x"].astype(np.int32)] <= 8
-        kl, dl = kl[keep], dl[keep]
-        uR, depth, _ = orb.stereo_match(ex_l, ex_r, kl, dl, kr, dr, 386.1448, 386.1448 / 718.856)
-        stats["kps"], stats["matches"] = len(kl), int((uR >= 0).sum())
+        orb.stereo_match_cull(keep, sad, uR, depth)
+        stats["kps"], stats["matches"] = int(keep.sum()), int((uR >= 0).sum())
 
     def frame(seed):
         res = {}

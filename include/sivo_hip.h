@@ -220,6 +220,16 @@ int sivo_hamming_bruteforce_dev(const uint8_t *d_a, int n_a, const uint8_t *d_b,
 int sivo_stereo_match(sivo_orb_t left, sivo_orb_t right, const SivoKeyPoint *kp_left, const uint8_t *desc_left,
                       int n_left, const SivoKeyPoint *kp_right, const uint8_t *desc_right, int n_right,
                       float bf, float b, float *u_right, float *depth, int32_t *best_right);
+/* The same in two steps, so that everything except the median cull (Frame.cc:616-628) can run while the network
+ * is still computing the class map that SelectSemanticKeys (Frame.cc:177-203) needs: `begin` matches EVERY left
+ * keypoint (each is independent of the other left keypoints) and returns the pre-cull u_right / depth plus the
+ * SAD distance of each match (sad_dist, -1 where unmatched); `cull` then applies the median test over the
+ * keypoints with keep[i] != 0 (NULL = all) and clears the others.  begin + cull(keep) == sivo_stereo_match on
+ * the kept subset. */
+int sivo_stereo_match_begin(sivo_orb_t left, sivo_orb_t right, const SivoKeyPoint *kp_left, const uint8_t *desc_left,
+                            int n_left, const SivoKeyPoint *kp_right, const uint8_t *desc_right, int n_right,
+                            float bf, float b, float *u_right, float *depth, int32_t *best_right, int32_t *sad_dist);
+int sivo_stereo_match_cull(int n, const uint8_t *keep, const int32_t *sad_dist, float *u_right, float *depth);
 
 /* ===========================================================================
  * Bundle-adjustment edges — stands behind the g2o edges SIVO::Optimizer

@@ -80,6 +80,8 @@ SIGNATURES = {
     "sivo_hamming_argmin2": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "sivo_hamming_bruteforce_dev": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "sivo_stereo_match": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp],
+    "sivo_stereo_match_begin": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp],
+    "sivo_stereo_match_cull": [_i, _vp, _vp, _vp, _vp],
     "sivo_entropy_gate_dev": [_i, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(_d), _d, _d, _d, _vp, _i, _d, _vp, _vp, _vp, _vp],
     "sivo_entropy_gate": [_i, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(_d), _d, _d, _d, _vp, _i, _d, _vp, _vp, _vp],
     "sivo_ba_optimize": [_vp, _vp, _i, _vp, _i, _vp, _i64, C.POINTER(_d), _d, _d, _vp, _vp, _i, _vp, _vp, _vp, C.POINTER(_i), C.POINTER(_i)],

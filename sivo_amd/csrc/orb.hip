@@ -398,6 +398,19 @@ struct sivo_orb {
     hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
     std::vector<std::vector<SivoKeyPoint>> last_candidates;
     bool have_pyramid = false;
+    // grow-only device arena of sivo_stereo_match_begin (no hipMalloc / hipFree — and so no device-wide
+    // synchronisation — on the per-frame path once it has reached its working size)
+    void *d_match = nullptr;
+    size_t match_cap = 0;
+    void *match_arena(size_t bytes) {
+        if (bytes > match_cap) {
+            if (d_match) (void)hipFree(d_match);
+            d_match = nullptr;
+            match_cap = bytes + bytes / 2;
+            SIVO_HIP(hipMalloc(&d_match, match_cap));
+        }
+        return d_match;
+    }
 
     void free_geometry() {
         for (void *p : {(void *)d_pyr, (void *)d_blur, (void *)d_src, (void *)d_cells, (void *)d_slots, (void *)d_dense,
@@ -416,6 +429,7 @@ struct sivo_orb {
     }
     ~sivo_orb() {
         free_geometry();
+        if (d_match) (void)hipFree(d_match);
         if (d_kps) (void)hipFree(d_kps);
         if (d_angles) (void)hipFree(d_angles);
         if (d_desc) (void)hipFree(d_desc);
@@ -703,8 +717,13 @@ extern "C" int sivo_orb_create(int nfeatures, float scale_factor, int nlevels, i
         DeviceGuard dg(device);
         SIVO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), h_pattern, sizeof h_pattern));
         SIVO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), o->umax, sizeof(int) * 16));
-        SIVO_HIP(hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking));
-        SIVO_HIP(hipStreamCreateWithFlags(&o->stream2, hipStreamNonBlocking));
+        // Highest stream priority: the extractor is ~0.5 ms of small latency-bound kernels with two host round trips
+        // (candidate read-back, quadtree) that runs BESIDE the network (Frame.cc:126-129 threads); at default priority
+        // each of its launches queues behind a chip-filling convolution and the frame waits for ORB, not the network.
+        int prio_lo = 0, prio_hi = 0;
+        SIVO_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        SIVO_HIP(hipStreamCreateWithPriority(&o->stream, hipStreamNonBlocking, prio_hi));
+        SIVO_HIP(hipStreamCreateWithPriority(&o->stream2, hipStreamNonBlocking, prio_hi));
         SIVO_HIP(hipEventCreateWithFlags(&o->ev_pyr, hipEventDisableTiming));
         SIVO_HIP(hipEventCreateWithFlags(&o->ev_blur, hipEventDisableTiming));
         *out = o.release();
@@ -798,16 +817,17 @@ extern "C" int sivo_orb_candidates(sivo_orb_t h, int level, SivoKeyPoint *out, i
 // Frame::ComputeStereoMatches (Frame.cc:444-629).  Host: row table, candidate lists and the
 // float decision logic exactly as the reference orders it; device: Hamming argmin over the
 // candidate lists and the 11 SAD windows per match on the two resident pyramids.
-extern "C" int sivo_stereo_match(sivo_orb_t left, sivo_orb_t right, const SivoKeyPoint *kpL, const uint8_t *descL,
-                                 int nL, const SivoKeyPoint *kpR, const uint8_t *descR, int nR, float bf, float b,
-                                 float *u_right, float *depth, int32_t *best_right) {
+extern "C" int sivo_stereo_match_begin(sivo_orb_t left, sivo_orb_t right, const SivoKeyPoint *kpL, const uint8_t *descL,
+                                       int nL, const SivoKeyPoint *kpR, const uint8_t *descR, int nR, float bf, float b,
+                                       float *u_right, float *depth, int32_t *best_right, int32_t *sad_dist) {
     return guarded([&] {
         if (!left || !right || nL < 0 || nR < 0 || (nL && (!kpL || !descL || !u_right || !depth)) || (nR && (!kpR || !descR)))
             throw std::invalid_argument("bad argument");
         if (!left->have_pyramid || !right->have_pyramid) throw std::invalid_argument("both extractors must hold a pyramid");
         if (left->nlevels != right->nlevels || left->rows != right->rows || left->cols != right->cols)
             throw std::invalid_argument("left/right extractors differ in geometry");
-        for (int i = 0; i < nL; ++i) { u_right[i] = -1.f; depth[i] = -1.f; if (best_right) best_right[i] = -1; }
+        if (nL && !sad_dist) throw std::invalid_argument("bad argument");
+        for (int i = 0; i < nL; ++i) { u_right[i] = -1.f; depth[i] = -1.f; sad_dist[i] = -1; if (best_right) best_right[i] = -1; }
         if (nL == 0 || nR == 0) return SIVO_OK;
         DeviceGuard dg(left->device);
         const int TH_HIGH = 100, TH_LOW = 50, thOrbDist = (TH_HIGH + TH_LOW) / 2;
@@ -834,9 +854,26 @@ extern "C" int sivo_stereo_match(sivo_orb_t left, sivo_orb_t right, const SivoKe
             }
         }
         off[nL] = (int)idx.size();
+        // Device work on the left extractor's own (non-blocking, high-priority) stream and arena: nothing here touches
+        // the null stream, so the call can run beside a network forward that is queued on another stream.
+        hipStream_t st = left->stream;
+        auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+        const size_t o_dl = 0, o_dr = o_dl + al((size_t)nL * 32), o_off = o_dr + al((size_t)nR * 32),
+                     o_idx = o_off + al((size_t)(nL + 1) * 4), o_bi = o_idx + al(idx.size() * 4 + 4), o_bd = o_bi + al((size_t)nL * 4),
+                     o_sd = o_bd + al((size_t)nL * 4), o_jobs = o_sd + al((size_t)nL * 4),
+                     o_dists = o_jobs + al((size_t)nL * sizeof(SadJob)), total = o_dists + al((size_t)nL * 11 * 4);
+        uint8_t *base = (uint8_t *)left->match_arena(total);
+        SIVO_HIP(hipMemcpyAsync(base + o_dl, descL, (size_t)nL * 32, hipMemcpyHostToDevice, st));
+        SIVO_HIP(hipMemcpyAsync(base + o_dr, descR, (size_t)nR * 32, hipMemcpyHostToDevice, st));
+        SIVO_HIP(hipMemcpyAsync(base + o_off, off.data(), (size_t)(nL + 1) * 4, hipMemcpyHostToDevice, st));
+        if (!idx.empty()) SIVO_HIP(hipMemcpyAsync(base + o_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, st));
         std::vector<int> bi(nL), bd(nL), sd(nL);
-        int rc = sivo_hamming_argmin2(descL, nL, descR, nR, off.data(), idx.data(), bi.data(), bd.data(), sd.data());
+        int rc = sivo_hamming_argmin2_dev(base + o_dl, nL, base + o_dr, (const int32_t *)(base + o_off), (const int32_t *)(base + o_idx),
+                                          (int32_t *)(base + o_bi), (int32_t *)(base + o_bd), (int32_t *)(base + o_sd), st);
         if (rc) return rc;
+        SIVO_HIP(hipMemcpyAsync(bi.data(), base + o_bi, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
+        SIVO_HIP(hipMemcpyAsync(bd.data(), base + o_bd, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
+        SIVO_HIP(hipStreamSynchronize(st));
         // SAD jobs (:538-565)
         std::vector<SadJob> jobs;
         std::vector<int> jobL;
@@ -855,18 +892,18 @@ extern "C" int sivo_stereo_match(sivo_orb_t left, sivo_orb_t right, const SivoKe
         }
         std::vector<int> dists(jobs.size() * 11);
         if (!jobs.empty()) {
-            SadJob *dj = dev_alloc<SadJob>(jobs.size());
-            int *dd = dev_alloc<int>(dists.size());
-            SIVO_HIP(hipMemcpy(dj, jobs.data(), jobs.size() * sizeof(SadJob), hipMemcpyHostToDevice));
-            SIVO_HIP(hipStreamSynchronize(left->stream2));
+            SadJob *dj = (SadJob *)(base + o_jobs);
+            int *dd = (int *)(base + o_dists);
+            SIVO_HIP(hipMemcpyAsync(dj, jobs.data(), jobs.size() * sizeof(SadJob), hipMemcpyHostToDevice, st));
+            SIVO_HIP(hipStreamSynchronize(left->stream2));       // the pyramids of both extractors are complete
+            SIVO_HIP(hipStreamSynchronize(right->stream));
             SIVO_HIP(hipStreamSynchronize(right->stream2));
-            hipLaunchKernelGGL(stereo_sad_kernel, dim3(cdiv((int)jobs.size(), 4)), dim3(256), 0, nullptr, left->d_pyr, left->table,
+            hipLaunchKernelGGL(stereo_sad_kernel, dim3(cdiv((int)jobs.size(), 4)), dim3(256), 0, st, left->d_pyr, left->table,
                                right->d_pyr, right->table, dj, (int)jobs.size(), dd);
-            SIVO_HIP(hipMemcpy(dists.data(), dd, dists.size() * sizeof(int), hipMemcpyDeviceToHost));
-            (void)hipFree(dj); (void)hipFree(dd);
+            SIVO_HIP(hipMemcpyAsync(dists.data(), dd, dists.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+            SIVO_HIP(hipStreamSynchronize(st));
         }
         // decision logic (:567-628)
-        std::vector<std::pair<int, int>> vDistIdx;
         for (size_t j = 0; j < jobs.size(); ++j) {
             const int iL = jobL[j], lvl = jobs[j].level;
             int bestDist = INT32_MAX, bestinc = 0;
@@ -887,8 +924,22 @@ extern "C" int sivo_stereo_match(sivo_orb_t left, sivo_orb_t right, const SivoKe
                 if (disparity <= 0) { disparity = 0.01f; bestuR = (float)(uL - 0.01); }
                 depth[iL] = bf / disparity;
                 u_right[iL] = bestuR;
-                vDistIdx.emplace_back(bestDist, iL);
+                sad_dist[iL] = bestDist;
             }
+        }
+        return SIVO_OK;
+    });
+}
+
+// Median cull of Frame::ComputeStereoMatches (Frame.cc:616-628) over the keypoints with keep[i] != 0 (all when keep
+// is NULL): matches whose SAD distance is >= 1.5 * 1.4 * median are dropped; keypoints that are not kept get -1.
+extern "C" int sivo_stereo_match_cull(int n, const uint8_t *keep, const int32_t *sad_dist, float *u_right, float *depth) {
+    return guarded([&] {
+        if (n < 0 || (n && (!sad_dist || !u_right || !depth))) throw std::invalid_argument("bad argument");
+        std::vector<std::pair<int, int>> vDistIdx;
+        for (int i = 0; i < n; ++i) {
+            if (keep && !keep[i]) { u_right[i] = -1.f; depth[i] = -1.f; continue; }
+            if (sad_dist[i] >= 0 && u_right[i] >= 0) vDistIdx.emplace_back(sad_dist[i], i);
         }
         if (!vDistIdx.empty()) {
             std::sort(vDistIdx.begin(), vDistIdx.end());
@@ -902,4 +953,13 @@ extern "C" int sivo_stereo_match(sivo_orb_t left, sivo_orb_t right, const SivoKe
         }
         return SIVO_OK;
     });
+}
+
+extern "C" int sivo_stereo_match(sivo_orb_t left, sivo_orb_t right, const SivoKeyPoint *kpL, const uint8_t *descL,
+                                 int nL, const SivoKeyPoint *kpR, const uint8_t *descR, int nR, float bf, float b,
+                                 float *u_right, float *depth, int32_t *best_right) {
+    std::vector<int32_t> sad((size_t)(nL > 0 ? nL : 1));
+    const int rc = sivo_stereo_match_begin(left, right, kpL, descL, nL, kpR, descR, nR, bf, b, u_right, depth, best_right, sad.data());
+    if (rc) return rc;
+    return sivo_stereo_match_cull(nL, nullptr, sad.data(), u_right, depth);
 }

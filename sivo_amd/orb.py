@@ -100,3 +100,21 @@ def stereo_match(left, right, kpL, descL, kpR, descR, bf, b):
     check(lib().sivo_stereo_match(left._h, right._h, _p(kpL), _p(descL), nL, _p(kpR), _p(descR), len(kpR),
                                   C.c_float(bf), C.c_float(b), _p(uR), _p(depth), _p(best)))
     return uR, depth, best
+
+
+def stereo_match_begin(left, right, kpL, descL, kpR, descR, bf, b):
+    """Everything of ComputeStereoMatches except the median cull, for ALL left keypoints (see sivo_hip.h)."""
+    kpL = np.ascontiguousarray(kpL, KP_DTYPE); kpR = np.ascontiguousarray(kpR, KP_DTYPE)
+    descL = np.ascontiguousarray(descL, np.uint8); descR = np.ascontiguousarray(descR, np.uint8)
+    nL = len(kpL)
+    uR = np.empty(nL, np.float32); depth = np.empty(nL, np.float32); best = np.empty(nL, np.int32); sad = np.empty(nL, np.int32)
+    check(lib().sivo_stereo_match_begin(left._h, right._h, _p(kpL), _p(descL), nL, _p(kpR), _p(descR), len(kpR),
+                                        C.c_float(bf), C.c_float(b), _p(uR), _p(depth), _p(best), _p(sad)))
+    return uR, depth, best, sad
+
+
+def stereo_match_cull(keep, sad, uR, depth):
+    """Median cull over the kept keypoints (keep: bool/uint8 mask or None); uR / depth are updated in place."""
+    k = None if keep is None else np.ascontiguousarray(keep, np.uint8)
+    check(lib().sivo_stereo_match_cull(len(uR), _p(k) if k is not None else None, _p(sad), _p(uR), _p(depth)))
+    return uR, depth

@@ -81,3 +81,17 @@ def test_stereo_matches(oracle):
     assert np.array_equal(uR.view(np.uint32), uR_o.view(np.uint32))
     assert np.array_equal(depth.view(np.uint32), depth_o.view(np.uint32))
     assert kept > 200 and abs(np.median((kl["x"] - uR)[uR >= 0]) - 8) < 0.5
+    # two-step form: matching every left keypoint first and culling over a kept subset afterwards gives, bit for bit,
+    # what the one-call form (and the oracle) give on that subset alone — the property bench.py relies on to run the
+    # matching beside the network and only the median cull after SelectSemanticKeys
+    keep = np.random.default_rng(1).random(len(kgl)) < 0.4
+    uR_a, depth_a, best_a, sad = orb.stereo_match_begin(eg_l, eg_r, kgl, dgl, kgr, dgr, bf, b)
+    assert np.array_equal(best_a, best)
+    orb.stereo_match_cull(keep, sad, uR_a, depth_a)
+    uR_s, depth_s, best_s = orb.stereo_match(eg_l, eg_r, kgl[keep], dgl[keep], kgr, dgr, bf, b)
+    uR_so, depth_so, _, _ = oracle.stereo_matches(kl[keep], dl[keep], kr, dr, eo_l.scale, eo_l.inv_scale, pyrL, pyrR, bf, b)
+    assert np.array_equal(uR_a[keep].view(np.uint32), uR_s.view(np.uint32)) and np.array_equal(uR_s.view(np.uint32), uR_so.view(np.uint32))
+    assert np.array_equal(depth_a[keep].view(np.uint32), depth_s.view(np.uint32)) and (uR_a[~keep] == -1).all()
+    uR_n, depth_n, _, sad_n = orb.stereo_match_begin(eg_l, eg_r, kgl, dgl, kgr, dgr, bf, b)
+    orb.stereo_match_cull(None, sad_n, uR_n, depth_n)
+    assert np.array_equal(uR_n.view(np.uint32), uR.view(np.uint32))
