@@ -215,12 +215,20 @@ def main():
     for i in range(args.warmup):
         frame(1000 + i)
     barrier()
-    sn.profile(True, reset=True)
+    # timed region: only the MFMA kernels are bracketed by HIP events (the roofline of the dominant kernel is measured
+    # live here); the full per-kernel breakdown comes from a few extra, untimed frames afterwards
+    sn.profile(True, mfma_only=True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         frame(2000 + i)
     barrier()
     elapsed = time.perf_counter() - t0
+    prof_timed = sn.profile_read()
+    n_detail = min(args.steps, 10)
+    sn.profile(True, reset=True)
+    for i in range(n_detail):
+        frame(3000 + i)
+    barrier()
     prof = sn.profile_read()
     sn.profile(False)
     if world > 1:
@@ -234,17 +242,25 @@ def main():
         if args.per_layer:
             for p in prof:
                 ms = p["ms_total"] / max(p["launches"], 1)
+                if not p["launches"]:
+                    continue
                 fl = p["flops_per_sample"] * p["samples"]
                 print(f'{p["layer"]:14s} {p["kernel"]:42s} N={p["samples"]:2d} {ms:8.4f} ms  {fl / ms / 1e9 if ms else 0:7.1f} TFLOP/s  '
                       f'{p["bytes_per_sample"] * p["samples"] / ms / 1e6 if ms else 0:8.1f} GB/s(alg)', file=sys.stderr)
-        by_kernel = {}
-        for p in prof:
-            k = by_kernel.setdefault(p["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
-            k["ms"] += p["ms_total"]; k["launches"] += p["kernel_launches"]
-            k["flops"] += p["flops_per_sample"] * p["samples"] * p["launches"]
-            k["bytes"] += p["bytes_per_sample"] * p["samples"] * p["launches"]
+        def aggregate(rows):
+            agg = {}
+            for p in rows:
+                if not p["launches"]:
+                    continue
+                k = agg.setdefault(p["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+                k["ms"] += p["ms_total"]; k["launches"] += p["kernel_launches"]
+                k["flops"] += p["flops_per_sample"] * p["samples"] * p["launches"]
+                k["bytes"] += p["bytes_per_sample"] * p["samples"] * p["launches"]
+            return agg
+        by_kernel = aggregate(prof)                  # every kernel, from the untimed detail frames
+        timed = aggregate(prof_timed)                # MFMA kernels, from the timed region
         conv = {k: v for k, v in by_kernel.items() if k.startswith("conv_") or k.startswith("wino4_")}
-        mfma = {k: v for k, v in conv.items() if v["flops"] > 0}            # the transform kernels carry no MFMA work
+        mfma = {k: v for k, v in timed.items() if v["flops"] > 0 and v["ms"] > 0}
         dom_name, dom = max(mfma.items(), key=lambda kv: kv[1]["ms"])
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         # Winograd executes fewer MFMA multiplies than the direct convolution it computes: F(2x2,3x3) 16 per 4 outputs
@@ -270,10 +286,11 @@ def main():
                     "launches_per_frame": dom["launches"] / args.steps,
                     "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
                     "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
-                    "all_conv": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "ms_per_frame": round(conv_ms / args.steps, 3),
+                    "all_conv": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "ms_per_frame": round(conv_ms / n_detail, 3),
                                  "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
-                    "kernels_ms_per_frame": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(by_kernel.items())},
-                    "segnet_kernel_ms_per_frame": round(all_ms / args.steps, 3)}
+                    "kernels_ms_per_frame": {k: round(v["ms"] / n_detail, 3) for k, v in sorted(by_kernel.items())},
+                    "segnet_kernel_ms_per_frame": round(all_ms / n_detail, 3),
+                    "breakdown_source": f"dominant kernel: HIP events inside the {args.steps} timed frames; kernels_ms_per_frame / all_conv: {n_detail} further untimed frames with every kernel bracketed"}
         out = {"metric": "frames/sec, SIVO per-frame path (ORB+SegNet T=%d+entropy) %dx%d" % (T, H, W),
                "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong",

@@ -171,6 +171,9 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_kernel(Wino4Args a, int pti
     __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
     __syncthreads();
     const int sw = (lk & 1) << 4;            // swizzle of this lane's k-row (c = 4*step + lk)
+    // MFMA block mt takes the tiles {4*i + mt}, block nt the couts {4*j + nt} of the wave's 64 x 64 sub-tile: the four A
+    // (B) fragments of a lane are then 4 consecutive floats of a stage row — ONE ds_read_b128 each instead of 4 b32.
+    const int a_off = (wm * 64 + 4 * li) ^ sw, b_off = (wn * 64 + 4 * li) ^ sw;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int cur = chunk & 1;
         if (chunk + 1 < nchunks) dma(chunk + 1, cur ^ 1);
@@ -178,11 +181,8 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_kernel(Wino4Args a, int pti
 #pragma unroll
         for (int s = 0; s < G_KC / 4; ++s) {
             const int rowoff = (4 * s + lk) * 128;
-            float af[4], bf[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) af[mt] = Vs[rowoff + ((wm * 64 + mt * 16 + li) ^ sw)];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bf[nt] = Us[rowoff + ((wn * 64 + nt * 16 + li) ^ sw)];
+            const f32x4 af = *reinterpret_cast<const f32x4 *>(Vs + rowoff + a_off);
+            const f32x4 bf = *reinterpret_cast<const f32x4 *>(Us + rowoff + b_off);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -192,13 +192,16 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_kernel(Wino4Args a, int pti
         __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
     }
-    // acc[mt][nt][r] = M[tile p0 + wm*64 + mt*16 + 4*lk + r][cout k0 + wn*64 + nt*16 + li]
+    // acc[mt][nt][r] = M[tile p0 + wm*64 + 4*(4*lk + r) + mt][cout k0 + wn*64 + 4*li + nt]: per cout a lane owns the 16
+    // consecutive tiles 16*lk .. 16*lk+15, four float4 stores; the four lk lanes of a cout write 256 contiguous bytes.
     float *Mg = a.M + ((int64_t)xi * a.Kp + (int64_t)kt * G_BN) * a.Pp + (int64_t)pt * G_BM;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < 4; ++nt) {
+        float *row = Mg + (int64_t)(wn * 64 + 4 * li + nt) * a.Pp + wm * 64 + 16 * lk;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-            *reinterpret_cast<f32x4 *>(Mg + (int64_t)(wn * 64 + nt * 16 + li) * a.Pp + wm * 64 + mt * 16 + 4 * lk) = acc[mt][nt];
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<f32x4 *>(row + 4 * r) = f32x4{acc[0][nt][r], acc[1][nt][r], acc[2][nt][r], acc[3][nt][r]};
+    }
 }
 
 // 1-D output transform A^T m
@@ -301,8 +304,8 @@ size_t wino4_workspace_floats(int group, int cin, int cout, int H, int W) {
 }
 
 // ev (optional, profiling): 4 events per group, recorded before the input transform, after it, after the GEMM and
-// after the output transform.
-void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream_t s, hipEvent_t *ev) {
+// after the output transform (gemm_only_events: only the two around the GEMM).
+void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream_t s, hipEvent_t *ev, bool gemm_only_events) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_STAGE * 4);
@@ -325,14 +328,14 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         const int ptiles = a.Pp / G_BM, ktiles = a.Kp / G_BN;
         const unsigned pblocks = (unsigned)((a.P + W4_TIN - 1) / W4_TIN);
         hipEvent_t *e = ev ? ev + 4 * (n0 / group) : nullptr;
-        if (e) (void)hipEventRecord(e[0], s);
+        if (e && !gemm_only_events) (void)hipEventRecord(e[0], s);
         hipLaunchKernelGGL(wino4_input_kernel, dim3(pblocks, (unsigned)a.C), dim3(W4_TIN), 0, s, a);
         if (e) (void)hipEventRecord(e[1], s);
         const int pairs8 = (36 * ptiles + 7) / 8;
         hipLaunchKernelGGL(wino4_gemm_kernel, dim3((unsigned)(pairs8 * ktiles * 8)), dim3(256), 2 * G_STAGE * 4, s, a, ptiles, ktiles);
         if (e) (void)hipEventRecord(e[2], s);
         hipLaunchKernelGGL(wino4_output_kernel, dim3(pblocks, (unsigned)a.K), dim3(W4_TIN), 0, s, a);
-        if (e) (void)hipEventRecord(e[3], s);
+        if (e && !gemm_only_events) (void)hipEventRecord(e[3], s);
     }
 }
 

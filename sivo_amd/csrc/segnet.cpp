@@ -59,6 +59,7 @@ struct Op {
     std::vector<hipEvent_t> w4_ev;                 // profiling: 4 events per group of the last launch
     double w4_ms[3] = {0.0, 0.0, 0.0};             // input transform, GEMM, output transform
     int w4_groups_last = 0, w4_launches = 0;
+    bool timed_last = false, w4_gemm_only_last = false;
     int drop_site = -1;
     // lrn
     int local_size = 5;
@@ -89,6 +90,7 @@ struct sivo_segnet {
     hipStream_t stream = nullptr;   // for the host-level entry point
     double flops_shared = 0.0, flops_sample = 0.0;
     bool profile = false, pending = false;
+    bool profile_mfma_only = false;   // bracket only the MFMA kernels (convolutions / the F(4x4) GEMM): fewer events in a timed run
     std::vector<void *> owned;
     float *d_wino4_ws = nullptr;    // V + M workspace shared by every F(4x4,3x3) layer
     size_t wino4_ws_floats = 0;
@@ -374,14 +376,18 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
 void harvest(sivo_segnet &S) {
     if (!S.pending) return;
     for (Op &op : S.ops) {
-        if (!op.ev1) continue;
-        SIVO_HIP(hipEventSynchronize(op.ev1));
+        if (!op.timed_last) continue;
+        op.timed_last = false;
         float ms = 0.f;
-        SIVO_HIP(hipEventElapsedTime(&ms, op.ev0, op.ev1));
-        op.ms_total += ms;
+        if (!op.w4_gemm_only_last) {
+            SIVO_HIP(hipEventSynchronize(op.ev1));
+            SIVO_HIP(hipEventElapsedTime(&ms, op.ev0, op.ev1));
+            op.ms_total += ms;
+        }
         op.launches += 1;
         for (int g = 0; g < op.w4_groups_last; ++g)
-            for (int k = 0; k < 3; ++k) {
+            for (int k = op.w4_gemm_only_last ? 1 : 0; k < (op.w4_gemm_only_last ? 2 : 3); ++k) {
+                SIVO_HIP(hipEventSynchronize(op.w4_ev[4 * g + k + 1]));
                 SIVO_HIP(hipEventElapsedTime(&ms, op.w4_ev[4 * g + k], op.w4_ev[4 * g + k + 1]));
                 op.w4_ms[k] += ms;
             }
@@ -399,10 +405,12 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
         const Blob &bi = S.blobs[op.in];
         const Blob &bo = S.blobs[op.out];
         const int N = bo.shared ? 1 : n;
-        if (S.profile) {
+        const bool timed = S.profile && (!S.profile_mfma_only || op.kind == OP_CONV);
+        const bool bracket = timed && !(S.profile_mfma_only && op.wino4);      // an F(4x4) layer then only times its GEMM
+        if (timed) { op.timed_last = true; op.w4_gemm_only_last = S.profile_mfma_only && op.wino4; op.last_n = N; }
+        if (bracket) {
             if (!op.ev0) { SIVO_HIP(hipEventCreate(&op.ev0)); SIVO_HIP(hipEventCreate(&op.ev1)); }
             SIVO_HIP(hipEventRecord(op.ev0, st));
-            op.last_n = N;
         }
         switch (op.kind) {
             case OP_CONV: {
@@ -425,7 +433,7 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
                     } else {
                         op.w4_groups_last = 0;
                     }
-                    launch_conv_wino4(a, S.d_wino4_ws, op.wino4_group, st, sub);
+                    launch_conv_wino4(a, S.d_wino4_ws, op.wino4_group, st, sub, S.profile_mfma_only);
                 }
                 else if (op.wino) launch_conv_wino(a, op.wino_cfg, st);
                 else if (op.v2) launch_conv2(a, op.ks, st);
@@ -461,7 +469,7 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
                            op.beta, st);
                 break;
         }
-        if (S.profile) SIVO_HIP(hipEventRecord(op.ev1, st));
+        if (bracket) SIVO_HIP(hipEventRecord(op.ev1, st));
     }
     if (S.profile) S.pending = true;
     const Blob &lg = S.blobs[S.logits_blob];
@@ -674,8 +682,12 @@ extern "C" int sivo_segnet_profile(sivo_segnet_t h, int enable) {
         DeviceGuard dg(h->device);
         if (h->profile) harvest(*h);
         h->profile = enable != 0;
-        if (enable == 2)   // reset the accumulators
-            for (Op &op : h->ops) { op.ms_total = 0.0; op.launches = 0; }
+        h->profile_mfma_only = enable == 3;
+        if (enable >= 2)   // reset the accumulators
+            for (Op &op : h->ops) {
+                op.ms_total = 0.0; op.launches = 0; op.w4_launches = 0;
+                op.w4_ms[0] = op.w4_ms[1] = op.w4_ms[2] = 0.0;
+            }
         return SIVO_OK;
     });
 }

@@ -44,7 +44,8 @@ int wino4_cout_pad(int cout);
 void wino4_pack_weights(const float *W, int cin, int cout, std::vector<float> &out, int *cout_pad);
 int wino4_group(int N, int cin, int cout, int H, int W, size_t budget_bytes);
 size_t wino4_workspace_floats(int group, int cin, int cout, int H, int W);
-void launch_conv_wino4(const ConvArgs &a, float *workspace, int group, hipStream_t s, hipEvent_t *stage_events = nullptr);
+void launch_conv_wino4(const ConvArgs &a, float *workspace, int group, hipStream_t s, hipEvent_t *stage_events = nullptr,
+                       bool gemm_only_events = false);
 
 struct PoolArgs {
     const float *in;

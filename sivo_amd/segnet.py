@@ -112,9 +112,10 @@ class BayesianSegNet:
                                         conf.ctypes.data_as(C.c_void_p), ent.ctypes.data_as(C.c_void_p)))
         return classes, conf, ent
 
-    def profile(self, enable=True, reset=False):
-        """Bracket every kernel of the forward with HIP events on its launch stream."""
-        check(lib().sivo_segnet_profile(self._h, 2 if (enable and reset) else int(bool(enable))))
+    def profile(self, enable=True, reset=False, mfma_only=False):
+        """Bracket every kernel of the forward with HIP events on its launch stream (mfma_only: just the convolution
+        kernels / the F(4x4,3x3) GEMM — a handful of events per forward, for use inside a timed run; implies reset)."""
+        check(lib().sivo_segnet_profile(self._h, 3 if (enable and mfma_only) else 2 if (enable and reset) else int(bool(enable))))
 
     def profile_read(self):
         """List of dicts: layer, kernel, samples, launches (forward passes), kernel_launches, flops_per_sample,
