@@ -50,7 +50,8 @@ __device__ __forceinline__ uint32_t wino4_dropout_word(uint32_t e, uint32_t site
 }
 
 struct Wino4Args {
-    const float *in; int64_t in_sample_stride;   // (n or 1, C, H, W)
+    const float *in; int64_t in_sample_stride;   // (n or 1, C, H, W); pooled (n or 1, C, H/2, W/2) when mask != null
+    const uint8_t *mask; int64_t mask_sample_stride;
     float *V, *M;                                // workspace
     const float *U;                              // [36][C][Kp]
     const float *ep_scale, *ep_shift;
@@ -75,30 +76,74 @@ __device__ __forceinline__ void wino4_bt(const float d0, const float d1, const f
 constexpr int W4_TIN = 256;
 
 // grid: (ceil(P / 256), C).  Lanes run over consecutive tiles (x fastest), so V stores are fully coalesced.
+// UNPOOL: the input is read through a max-unpool (Upsample scale 2): 4 x 4 pooled values + window codes per tile
+// instead of 6 x 6 unpooled values, and the unpooled tensor never exists in HBM.
+template <bool UNPOOL>
 __global__ __launch_bounds__(W4_TIN) void wino4_input_kernel(Wino4Args a) {
     const int p = blockIdx.x * W4_TIN + threadIdx.x, c = blockIdx.y;
     if (p >= a.P) return;       // whole waves leave together except in the last block; shuffles below only pair live lanes
     const int tx = p % a.tw, ty = (p / a.tw) % a.th, n = p / (a.tw * a.th);
-    const float *src = a.in + (int64_t)n * a.in_sample_stride + (int64_t)c * a.H * a.W;
-    const int x0 = 4 * tx, y0 = 4 * ty - 1;
     const int lane = threadIdx.x & 63;
     // the left / right neighbour tile is the previous / next lane when it exists in this wave and in this tile row
     const bool left_lane = lane > 0 && tx > 0, right_lane = lane < 63 && tx < a.tw - 1 && p + 1 < a.P;
     float d[6][6];
+    if (UNPOOL) {
+        const int Hp = a.H >> 1, Wp = a.W >> 1;
+        const float *src = a.in + (int64_t)n * a.in_sample_stride + (int64_t)c * Hp * Wp;
+        const uint8_t *msk = a.mask + (int64_t)n * a.mask_sample_stride + (int64_t)c * Hp * Wp;
+        const int px0 = 2 * tx;
+        float pv[4][4];
+        int pc[4][4];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        const int y = y0 + r;
-        const bool row_ok = y >= 0 && y < a.H;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row_ok) v = *reinterpret_cast<const f32x4 *>(src + (int64_t)y * a.W + x0);     // W % 4 == 0: aligned, in bounds
-        // every lane takes part in the shuffles (rows outside the image contribute zeros)
-        const float from_left = __shfl_up(v.w, 1, 64), from_right = __shfl_down(v.x, 1, 64);
-        float l = 0.f, rr = 0.f;
-        if (row_ok) {
-            if (left_lane) l = from_left; else if (x0 > 0) l = src[(int64_t)y * a.W + x0 - 1];
-            if (right_lane) rr = from_right; else if (x0 + 4 < a.W) rr = src[(int64_t)y * a.W + x0 + 4];
+        for (int r = 0; r < 4; ++r) {
+            const int py = 2 * ty - 1 + r;
+            const bool row_ok = py >= 0 && py < Hp;
+            float v0 = 0.f, v1 = 0.f;
+            int m0 = -1, m1 = -1;
+            if (row_ok) {
+                const float2 v = *reinterpret_cast<const float2 *>(src + (int64_t)py * Wp + px0);     // Wp even: aligned
+                const uchar2 m = *reinterpret_cast<const uchar2 *>(msk + (int64_t)py * Wp + px0);
+                v0 = v.x; v1 = v.y; m0 = m.x; m1 = m.y;
+            }
+            const float vl = __shfl_up(v1, 1, 64), vr = __shfl_down(v0, 1, 64);
+            const int ml = __shfl_up(m1, 1, 64), mr = __shfl_down(m0, 1, 64);
+            float l = 0.f, rr = 0.f;
+            int lm = -1, rm = -1;
+            if (row_ok) {
+                if (left_lane) { l = vl; lm = ml; }
+                else if (px0 > 0) { l = src[(int64_t)py * Wp + px0 - 1]; lm = msk[(int64_t)py * Wp + px0 - 1]; }
+                if (right_lane) { rr = vr; rm = mr; }
+                else if (px0 + 2 < Wp) { rr = src[(int64_t)py * Wp + px0 + 2]; rm = msk[(int64_t)py * Wp + px0 + 2]; }
+            }
+            pv[r][0] = l; pv[r][1] = v0; pv[r][2] = v1; pv[r][3] = rr;
+            pc[r][0] = lm; pc[r][1] = m0; pc[r][2] = m1; pc[r][3] = rm;
         }
-        d[r][0] = l; d[r][1] = v.x; d[r][2] = v.y; d[r][3] = v.z; d[r][4] = v.w; d[r][5] = rr;
+        // unpooled pixel (4ty - 1 + i, 4tx - 1 + j): pooled index ((i + 1) >> 1, (j + 1) >> 1), window position ((i + 1) & 1, (j + 1) & 1)
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int pi = (i + 1) >> 1, pj = (j + 1) >> 1, code = (((i + 1) & 1) << 1) | ((j + 1) & 1);
+                d[i][j] = pc[pi][pj] == code ? pv[pi][pj] : 0.f;
+            }
+    } else {
+        const float *src = a.in + (int64_t)n * a.in_sample_stride + (int64_t)c * a.H * a.W;
+        const int x0 = 4 * tx, y0 = 4 * ty - 1;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int y = y0 + r;
+            const bool row_ok = y >= 0 && y < a.H;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row_ok) v = *reinterpret_cast<const f32x4 *>(src + (int64_t)y * a.W + x0);     // W % 4 == 0: aligned, in bounds
+            // every lane takes part in the shuffles (rows outside the image contribute zeros)
+            const float from_left = __shfl_up(v.w, 1, 64), from_right = __shfl_down(v.x, 1, 64);
+            float l = 0.f, rr = 0.f;
+            if (row_ok) {
+                if (left_lane) l = from_left; else if (x0 > 0) l = src[(int64_t)y * a.W + x0 - 1];
+                if (right_lane) rr = from_right; else if (x0 + 4 < a.W) rr = src[(int64_t)y * a.W + x0 + 4];
+            }
+            d[r][0] = l; d[r][1] = v.x; d[r][2] = v.y; d[r][3] = v.z; d[r][4] = v.w; d[r][5] = rr;
+        }
     }
     // columns, then rows
     float t[6][6];
@@ -321,6 +366,8 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         a.P = a.n * a.th * a.tw;
         a.Pp = (a.P + G_BM - 1) / G_BM * G_BM;
         a.in = c.in + (int64_t)n0 * c.in_sample_stride;
+        a.mask = c.unpool_mask ? c.unpool_mask + (int64_t)n0 * c.unpool_mask_stride : nullptr;
+        a.mask_sample_stride = c.unpool_mask_stride;
         a.out = c.out + (int64_t)n0 * c.Cout * c.H * c.W;
         a.sample0 = c.sample0 + n0;
         a.V = workspace;
@@ -329,7 +376,8 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         const unsigned pblocks = (unsigned)((a.P + W4_TIN - 1) / W4_TIN);
         hipEvent_t *e = ev ? ev + 4 * (n0 / group) : nullptr;
         if (e && !gemm_only_events) (void)hipEventRecord(e[0], s);
-        hipLaunchKernelGGL(wino4_input_kernel, dim3(pblocks, (unsigned)a.C), dim3(W4_TIN), 0, s, a);
+        if (a.mask) hipLaunchKernelGGL(wino4_input_kernel<true>, dim3(pblocks, (unsigned)a.C), dim3(W4_TIN), 0, s, a);
+        else hipLaunchKernelGGL(wino4_input_kernel<false>, dim3(pblocks, (unsigned)a.C), dim3(W4_TIN), 0, s, a);
         if (e) (void)hipEventRecord(e[1], s);
         const int pairs8 = (36 * ptiles + 7) / 8;
         hipLaunchKernelGGL(wino4_gemm_kernel, dim3((unsigned)(pairs8 * ktiles * 8)), dim3(256), 2 * G_STAGE * 4, s, a, ptiles, ktiles);

@@ -39,6 +39,7 @@ struct Blob {
     bool is_mask = false;  // pooling argmax codes (u8)
     int src_W = 0;         // masks: width of the pooled input plane (for index reconstruction)
     void *d = nullptr;
+    bool fused_away = false;   // an Upsample output read straight through its pooled input by the next convolution
     int64_t chw() const { return (int64_t)C * H * W; }
 };
 
@@ -60,6 +61,8 @@ struct Op {
     double w4_ms[3] = {0.0, 0.0, 0.0};             // input transform, GEMM, output transform
     int w4_groups_last = 0, w4_launches = 0;
     bool timed_last = false, w4_gemm_only_last = false;
+    bool skip = false;             // Upsample fused into the following F(4x4,3x3) convolution
+    int unpool_in = -1, unpool_mask = -1;   // that convolution: pooled blob and mask blob it reads through
     int drop_site = -1;
     // lrn
     int local_size = 5;
@@ -351,8 +354,27 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
         if (op.out2 >= 0) S.blobs[op.out2].shared = S.blobs[op.in].shared;   // the argmax only depends on the input
         (sh ? S.flops_shared : S.flops_sample) += op.flops;
     }
+    // Upsample -> F(4x4,3x3) convolution: the input transform reads the pooled tensor and the window codes directly
+    // (4x fewer input bytes, no unpool kernel, the unpooled tensor is never written).  SIVO_NO_FUSE_UNPOOL disables.
+    if (!std::getenv("SIVO_NO_FUSE_UNPOOL"))
+        for (Op &u : S.ops) {
+            if (u.kind != OP_UNPOOL) continue;
+            Op *consumer = nullptr;
+            int uses = u.out == S.logits_blob ? 2 : 0;
+            for (Op &c : S.ops)
+                if (c.in == u.out || c.in2 == u.out) { ++uses; consumer = &c; }
+            if (uses != 1 || consumer->kind != OP_CONV || !consumer->wino4 || consumer->in != u.out) continue;
+            const Blob &pooled = S.blobs[u.in], &mask = S.blobs[u.in2], &up = S.blobs[u.out];
+            if (pooled.shared && !up.shared) continue;            // (not produced by the reference nets)
+            if (up.H != 2 * pooled.H || up.W != 2 * pooled.W || (pooled.W & 1)) continue;
+            (void)mask;
+            consumer->unpool_in = u.in; consumer->unpool_mask = u.in2;
+            u.skip = true;
+            S.blobs[u.out].fused_away = true;
+        }
     // allocate
     for (Blob &b : S.blobs) {
+        if (b.fused_away) continue;
         const size_t n = (size_t)(b.shared ? 1 : S.T) * b.chw();
         b.d = b.is_mask ? (void *)dev_alloc<uint8_t>(n) : (void *)dev_alloc<float>(n);
         S.owned.push_back(b.d);
@@ -402,6 +424,7 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
     if (S.profile) harvest(S);
     launch_preprocess(d_bgr, (float *)S.blobs[S.input_blob].d, hw, st);
     for (Op &op : S.ops) {
+        if (op.skip) continue;
         const Blob &bi = S.blobs[op.in];
         const Blob &bo = S.blobs[op.out];
         const int N = bo.shared ? 1 : n;
@@ -420,6 +443,11 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
                 a.out = (float *)bo.d;
                 a.N = N; a.Cin = op.cin; a.H = bi.H; a.W = bi.W; a.Cout = op.cout; a.CoutPad = op.cout_pad;
                 a.relu = op.relu; a.drop_site = op.drop_site; a.sample0 = sample0; a.seed = seed;
+                if (op.unpool_in >= 0) {
+                    const Blob &bp = S.blobs[op.unpool_in], &bm = S.blobs[op.unpool_mask];
+                    a.in = (const float *)bp.d; a.in_sample_stride = bp.shared ? 0 : bp.chw();
+                    a.unpool_mask = (const uint8_t *)bm.d; a.unpool_mask_stride = bm.shared ? 0 : bm.chw();
+                }
                 if (op.wino4) {
                     hipEvent_t *sub = nullptr;
                     if (S.profile) {
@@ -657,6 +685,8 @@ extern "C" int sivo_segnet_blob(sivo_segnet_t h, const char *name, float *host_o
         auto it = h->blob_id.find(name);
         if (it == h->blob_id.end()) throw std::invalid_argument(std::string("no blob named '") + name + "'");
         const Blob &b = h->blobs[it->second];
+        if (b.fused_away)
+            throw std::invalid_argument(std::string("blob '") + name + "' is not materialised: its Upsample layer is fused into the next convolution (SIVO_NO_FUSE_UNPOOL=1 keeps it)");
         const int N = b.shared ? 1 : h->T;
         if (shape) { shape[0] = N; shape[1] = b.C; shape[2] = b.H; shape[3] = b.W; }
         const size_t n = (size_t)N * b.chw();

@@ -20,6 +20,11 @@ struct ConvArgs {
     int drop_site;             // < 0: no dropout in the epilogue
     int sample0;
     uint64_t seed;
+    // F(4x4,3x3) path only: when set, `in` is the POOLED tensor (N or 1, Cin, H/2, W/2) and the kernel reads the
+    // max-unpooled input through it (value at the recorded 2x2 window position, zero elsewhere): the Upsample
+    // layer in front of the convolution is never materialised
+    const uint8_t *unpool_mask = nullptr;
+    int64_t unpool_mask_stride = 0;   // 0 when the mask is shared by all samples
     int variant;               // diagnostics only (sivo_debug_conv): bit0 no epilogue stores, bit1 no LDS commit, bit2 no global loads
 };
 int conv_cout_tile(int ks, int cout);  // BN the launcher will pick (CoutPad must be a multiple)

@@ -103,6 +103,30 @@ def test_reference_nets_reduced_geometry(oracle, kind):
     _check_outputs(oracle, res, cls.cpu().numpy(), conf.cpu().numpy(), ent.cpu().numpy(), prob_sum.cpu().numpy(), T)
 
 
+def test_fused_upsample_is_bit_identical_to_the_materialised_one():
+    """Upsample -> F(4x4,3x3) convolution reads the pooled tensor + window codes inside the input transform; the same
+    net built with SIVO_NO_FUSE_UNPOOL=1 runs the unpool kernel first.  Same arithmetic -> identical logits, and the
+    fused-away blob is reported as such."""
+    import os
+    from sivo_amd._lib import SivoError
+    T, H, W = 3, 64, 96
+    text = netspec.standard_prototxt(T, H, W)
+    net, w, sn = _make(text, T)
+    img = torch.from_numpy(_image(np.random.default_rng(8), H, W)).cuda()
+    _, lg_fused, _ = sn.forward(img, 123, want_logits=True)
+    with pytest.raises(ValueError, match="not materialised"):
+        sn.blob("pool4_D")
+    os.environ["SIVO_NO_FUSE_UNPOOL"] = "1"
+    try:
+        _, _, sn2 = _make(text, T)
+    finally:
+        del os.environ["SIVO_NO_FUSE_UNPOOL"]
+    _, lg_plain, _ = sn2.forward(img, 123, want_logits=True)
+    torch.cuda.synchronize()
+    assert sn2.blob("pool4_D").shape == (T, 512, H // 8, W // 8)
+    assert torch.equal(lg_fused, lg_plain)
+
+
 def test_sample_sharding_matches_single_pass(oracle):
     """Samples {0,1} + {2,3} computed separately sum to the 4-sample pass (multi-GPU partitioning)."""
     T, H, W = 4, 32, 64
