@@ -270,15 +270,19 @@ def main():
         conv_ms = sum(v["ms"] for v in conv.values()); conv_fl = sum(v["flops"] for v in conv.values())
         all_ms = sum(v["ms"] for v in by_kernel.values())
         traffic = None
-        try:   # HBM bytes per launch of the dominant kernel from the committed PMC pass (bench cannot collect PMC itself)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")))
-            traffic = tj.get(dom_name, {}).get("bytes")
-            traffic_file = "profiles/r01_g_pmc_traffic.json"
-        except Exception:
-            pass
+        traffic_file = None
+        for cand in ("r01_i_pmc_traffic_wino4.json", "r01_g_pmc_traffic.json"):
+            # HBM bytes per launch of the dominant kernel from the committed PMC passes (bench cannot collect PMC itself)
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                if dom_name in tj and tj[dom_name].get("bytes"):
+                    traffic, traffic_file = tj[dom_name]["bytes"], "profiles/" + cand
+                    break
+            except Exception:
+                pass
         roofline = {"bound": "mfma", "kernel": "sivo::" + dom_name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": "profiles/r01_g_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, bytes per launch)" if traffic else None,
+                    "traffic_source": f"{traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, mean bytes per launch)" if traffic else None,
                     "mfma_executed_tflops": round(achieved * exec_ratio, 2), "mfma_util": round(achieved * exec_ratio / FP32_MFMA_PEAK_TFLOPS, 4),
                     "note": ("achieved = algorithmic direct-conv FLOPs of the layers this kernel serves / its HIP-event time; the kernel is the batched GEMM of Winograd F(4x4,3x3) in fp32, "
                              "which issues 4x fewer MFMA flops (mfma_util = executed MFMA flops / peak); its input/output transform kernels are listed in kernels_ms_per_frame and counted in all_conv") if exec_ratio == 0.25
