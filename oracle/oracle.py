@@ -154,12 +154,20 @@ def preprocess(bgr, T, H, W):
     return None if rc else blob
 
 
-def run_net(net, weights, blob, seed, sample0=0, keep=None, acc64=False, dropout_on=True):
+def run_net(net, weights, blob, seed, sample0=0, keep=None, acc64=False, dropout_on=True, force_masks=None, flips=None):
     """Execute a parsed prototxt (oracle.prototxt.parse) layer by layer, as
     caffe::Net::Forward does (bayesian_segnet.cpp:310).  `weights[name]` is the
     list of parameter blobs of layer `name` (conv: [W, b]; BN: [scale, shift]).
     Dropout sites are numbered in layer order.  Returns the blob dict (only
-    names in `keep` plus the last top when keep is given)."""
+    names in `keep` plus the last top when keep is given).
+
+    force_masks: {mask blob name: argmax indices (N or 1, C, Ho, Wo)} — the pooling SWITCHES of another
+    implementation.  Max pooling is discontinuous: where two window elements agree to the last few ulps, two
+    correct fp32 implementations may pick different ones and every logit in the receptive field of that
+    switch then differs by O(1).  With the switches forced, the rest of the arithmetic is compared at the
+    stated tolerance, and `flips[name] = (count, max gap)` records, per pooling layer, how many forced
+    switches differ from this oracle's own choice and the largest (oracle max - forced element) among them:
+    a genuine near-tie has a gap of a few ulps."""
     blobs = {net["input"]: blob}
     site = 0
     last = net["input"]
@@ -175,6 +183,17 @@ def run_net(net, weights, blob, seed, sample0=0, keep=None, acc64=False, dropout
             out = relu(bot[0])
         elif t == "Pooling":
             out, mask = maxpool(bot[0], L["kernel_size"], L["stride"])
+            if force_masks is not None and L["top"][1] in force_masks:
+                x = bot[0]
+                fm = np.asarray(force_masks[L["top"][1]]).astype(np.int64)
+                fm = np.broadcast_to(fm, mask.shape)
+                forced = np.take_along_axis(x.reshape(x.shape[0], x.shape[1], -1), fm.reshape(fm.shape[0], fm.shape[1], -1),
+                                            axis=2).reshape(out.shape)
+                diff = fm != mask.astype(np.int64)
+                if flips is not None:
+                    flips[L["top"][1]] = (int(diff.sum()), float((out - forced)[diff].max()) if diff.any() else 0.0,
+                                          float(np.abs(out[diff]).max()) if diff.any() else 0.0)
+                out, mask = forced.astype(out.dtype), fm.astype(mask.dtype)
             blobs[L["top"][1]] = mask
         elif t == "Upsample":
             s = L["scale"]
@@ -203,12 +222,12 @@ def run_net(net, weights, blob, seed, sample0=0, keep=None, acc64=False, dropout
     return blobs
 
 
-def segment(net, weights, bgr, seed, sample0=0, logits_name=None):
+def segment(net, weights, bgr, seed, sample0=0, logits_name=None, force_masks=None, flips=None):
     """BayesianSegNet::segmentImage (bayesian_segnet.cpp:299-318) on the oracle."""
     T, _, H, W = net["shape"]
     blob = preprocess(bgr, T, H, W)
     keep = [logits_name] if logits_name else []
-    blobs = run_net(net, weights, blob, seed, sample0, keep=keep)
+    blobs = run_net(net, weights, blob, seed, sample0, keep=keep, force_masks=force_masks, flips=flips)
     prob = blobs["__last__"]
     mean = mc_mean(prob)
     classes, conf, ent = mc_finalize(mean)

@@ -27,13 +27,14 @@ def _image(rng, H, W):
     return rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
 
 
-def _check_outputs(oracle, res, cls, conf, ent, prob_sum, T):
+def _check_outputs(oracle, res, cls, conf, ent, prob_sum, T, prob_tol=1e-5, ent_tol=2e-4):
+    """prob_tol follows from the logit error: |dp| <= p (1 - p) * 2 |dlogit| <= |dlogit| / 2."""
     mean = res["mean"]
-    np.testing.assert_allclose(prob_sum / T, mean, atol=1e-5, rtol=0)
-    np.testing.assert_allclose(conf, res["confidence"], atol=1e-5, rtol=0)
-    np.testing.assert_allclose(ent, res["entropy"], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(prob_sum / T, mean, atol=prob_tol, rtol=0)
+    np.testing.assert_allclose(conf, res["confidence"], atol=prob_tol, rtol=0)
+    np.testing.assert_allclose(ent, res["entropy"], atol=ent_tol, rtol=0)
     srt = np.sort(mean, axis=0)
-    decided = (srt[-1] - srt[-2]) > 1e-5
+    decided = (srt[-1] - srt[-2]) > 2 * prob_tol
     assert (cls[decided] == res["classes"][decided]).all()
     assert decided.mean() > 0.99
 
@@ -101,6 +102,41 @@ def test_reference_nets_reduced_geometry(oracle, kind):
     assert np.abs(res["logits"]).max() > 0.1            # the comparison is not vacuous
     np.testing.assert_allclose(lg, res["logits"], atol=LOGIT_TOL, rtol=0)
     _check_outputs(oracle, res, cls.cpu().numpy(), conf.cpu().numpy(), ent.cpu().numpy(), prob_sum.cpu().numpy(), T)
+
+
+@pytest.mark.parametrize("kind", ["basic", "standard"])
+def test_full_size_frame_logits_within_tolerance(oracle, kind, kitti_like_bgr):
+    """BASELINE configs[1] / configs[2] geometry (352 x 1024, full channel widths), two MC samples: every logit within
+    the north-star tolerance (1e-3, fp32) of the CPU oracle, and the finalized maps consistent.  The oracle needs
+    ~10 s on the GPU box's host cores for this."""
+    T, H, W = 2, 352, 1024
+    text = netspec.basic_prototxt(T, H, W) if kind == "basic" else netspec.standard_prototxt(T, H, W)
+    net, w, sn = _make(text, T)
+    img = np.ascontiguousarray(kitti_like_bgr[:H, :W])
+    assert img.shape == (H, W, 3)
+    seed = 2024
+    logits_name = "dense_softmax_inner_prod" if kind == "basic" else "conv1_1_D"
+    prob_sum, logits, _ = sn.forward(torch.from_numpy(img).cuda(), seed, want_logits=True)
+    cls, conf, ent = sn.finalize(prob_sum)
+    torch.cuda.synchronize()
+    # Max pooling is discontinuous: at ~12 M pooling windows a few dozen hold two elements equal to the last ulps and two
+    # correct fp32 evaluations pick different ones, after which every logit in that switch's receptive field differs by
+    # O(1) (measured free-running: 165 of 11.9 M switches differ, 1.2 % of the logits move by > 1e-3).  So the oracle is
+    # run with the device's switches; each differing switch must be a genuine near-tie, and THEN every logit has to agree.
+    masks = {L["top"][1]: sn.blob(L["top"][1]) for L in net["layers"] if L["type"] == "Pooling"}
+    flips = {}
+    res = oracle.segment(net, w, img, seed, logits_name=logits_name, force_masks=masks, flips=flips)
+    total = 0
+    for name, (count, gap, mag) in flips.items():
+        total += count
+        assert count <= 1e-4 * masks[name].size and gap <= 2e-5 * max(mag, 1.0), (name, count, gap, mag)
+    err = np.abs(logits.cpu().numpy() - res["logits"])
+    print(f"{kind}: {total} pooling switches differ (near-ties); max |dlogit| = {err.max():.3e}, mean = {err.mean():.3e}, "
+          f"max |logit| = {np.abs(res['logits']).max():.2f}")
+    assert np.abs(res["logits"]).max() > 0.5
+    assert err.max() < LOGIT_TOL
+    _check_outputs(oracle, res, cls.cpu().numpy(), conf.cpu().numpy(), ent.cpu().numpy(), prob_sum.cpu().numpy(), T,
+                   prob_tol=LOGIT_TOL / 2, ent_tol=5e-3)
 
 
 def test_fused_upsample_is_bit_identical_to_the_materialised_one():
