@@ -301,6 +301,86 @@ __global__ __launch_bounds__(W4_TIN) void wino4_output_kernel(Wino4Args a) {
     }
 }
 
+// Output transform of layer A fused with the input transform of layer B = the next convolution (same geometry,
+// C_B = K_A): the activation between two F(4x4) convolutions never goes to HBM.  One workgroup per (sample, channel)
+// plane: every thread turns its tiles' 36 M values into the 4x4 outputs (+ A's epilogue) and puts them into an LDS
+// image of the plane with a zero border; after one barrier it reads its 6x6 window back and writes B's 36 V values.
+// Reads 2.25 y + writes 2.25 y instead of (2.25 y + y) + (y + 2.25 y).   grid: (n, K_A), dynamic LDS = plane.
+__global__ __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *Vnext) {
+    extern __shared__ float plane[];            // (4*th + 2) rows x (W + 4) floats; image pixel (y, x) at [y + 1][x + 1]
+    const int n = blockIdx.x, co = blockIdx.y;
+    const int RS = a.W + 4, rows = 4 * a.th + 2, ntile = a.th * a.tw;
+    for (int i = threadIdx.x; i < rows * RS; i += blockDim.x) plane[i] = 0.f;
+    __syncthreads();
+    const float sc = a.ep_scale[co], sh = a.ep_shift[co];
+    const int64_t xs_m = (int64_t)a.Kp * a.Pp, xs_v = (int64_t)a.K * a.Pp;
+    for (int t = threadIdx.x; t < ntile; t += blockDim.x) {
+        const int tx = t % a.tw, ty = t / a.tw;
+        const float *src = a.M + (int64_t)co * a.Pp + (int64_t)n * ntile + t;
+        float tt[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float m[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) m[i] = src[(int64_t)(i * 6 + j) * xs_m];
+            float s4[4];
+            wino4_at(m[0], m[1], m[2], m[3], m[4], m[5], s4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tt[i][j] = s4[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int y = 4 * ty + i;
+            if (y >= a.H) break;                 // rows below the image stay zero
+            float v[4];
+            wino4_at(tt[i][0], tt[i][1], tt[i][2], tt[i][3], tt[i][4], tt[i][5], v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = v[r] * sc + sh;
+                if (a.relu) v[r] = v[r] > 0.f ? v[r] : 0.f;
+            }
+            const int x = 4 * tx;
+            if (a.drop_site >= 0) {
+                const uint32_t e = (uint32_t)((co * a.H + y) * a.W + x);
+                const uint32_t w = wino4_dropout_word(e, (uint32_t)a.drop_site, (uint32_t)(a.sample0 + n), a.seed) >> (e & 31);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = ((w >> r) & 1u) ? v[r] * 2.f : 0.f;
+            }
+            float *dst = plane + (y + 1) * RS + x + 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[r] = v[r];
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < ntile; t += blockDim.x) {
+        const int tx = t % a.tw, ty = t / a.tw;
+        const float *win = plane + (4 * ty) * RS + 4 * tx;       // 16-byte aligned: RS % 4 == 0
+        float d[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(win + i * RS);
+            const float2 r2 = *reinterpret_cast<const float2 *>(win + i * RS + 4);
+            d[i][0] = q.x; d[i][1] = q.y; d[i][2] = q.z; d[i][3] = q.w; d[i][4] = r2.x; d[i][5] = r2.y;
+        }
+        float tb[6][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float col[6];
+            wino4_bt(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], col);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) tb[i][j] = col[i];
+        }
+        float *dst = Vnext + (int64_t)co * a.Pp + (int64_t)n * ntile + t;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float row[6];
+            wino4_bt(tb[i][0], tb[i][1], tb[i][2], tb[i][3], tb[i][4], tb[i][5], row);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) dst[(int64_t)(i * 6 + j) * xs_v] = row[j];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
@@ -348,12 +428,21 @@ size_t wino4_workspace_floats(int group, int cin, int cout, int H, int W) {
     return (size_t)(36 * Pp * ((int64_t)cin + wino4_cout_pad(cout)));
 }
 
+size_t wino4_bridge_lds_bytes(int H, int W) { return (size_t)(4 * ((H + 3) / 4) + 2) * (W + 4) * sizeof(float); }
+
+// One F(4x4,3x3) layer.  `group` samples per pass over the workspace.  plan (optional) chains layers without going
+// through HBM with the activation: V / M / Vnext are caller-chosen disjoint buffers, skip_input says V already holds
+// this layer's transformed input (written by the previous layer's bridge), bridge replaces the output transform by
+// wino4_bridge_kernel writing the NEXT layer's V into Vnext (the plain output `c.out` is then not produced).  A plan
+// requires all samples in one group.
 // ev (optional, profiling): 4 events per group, recorded before the input transform, after it, after the GEMM and
-// after the output transform (gemm_only_events: only the two around the GEMM).
-void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream_t s, hipEvent_t *ev, bool gemm_only_events) {
+// after the output transform / bridge (gemm_only_events: only the two around the GEMM).
+void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream_t s, hipEvent_t *ev, bool gemm_only_events,
+                       const Wino4Plan *plan) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_STAGE * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_bridge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     Wino4Args a{};
@@ -361,6 +450,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
     a.th = (c.H + 3) / 4; a.tw = c.W / 4;
     a.U = c.wt; a.ep_scale = c.ep_scale; a.ep_shift = c.ep_shift;
     a.relu = c.relu; a.drop_site = c.drop_site; a.seed = c.seed; a.in_sample_stride = c.in_sample_stride;
+    if (plan) group = c.N;
     for (int n0 = 0; n0 < c.N; n0 += group) {
         a.n = c.N - n0 < group ? c.N - n0 : group;
         a.P = a.n * a.th * a.tw;
@@ -370,19 +460,27 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         a.mask_sample_stride = c.unpool_mask_stride;
         a.out = c.out + (int64_t)n0 * c.Cout * c.H * c.W;
         a.sample0 = c.sample0 + n0;
-        a.V = workspace;
-        a.M = workspace + (size_t)36 * a.C * a.Pp;
+        a.V = plan ? plan->V : workspace;
+        a.M = plan ? plan->M : workspace + (size_t)36 * a.C * a.Pp;
         const int ptiles = a.Pp / G_BM, ktiles = a.Kp / G_BN;
         const unsigned pblocks = (unsigned)((a.P + W4_TIN - 1) / W4_TIN);
         hipEvent_t *e = ev ? ev + 4 * (n0 / group) : nullptr;
         if (e && !gemm_only_events) (void)hipEventRecord(e[0], s);
-        if (a.mask) hipLaunchKernelGGL(wino4_input_kernel<true>, dim3(pblocks, (unsigned)a.C), dim3(W4_TIN), 0, s, a);
-        else hipLaunchKernelGGL(wino4_input_kernel<false>, dim3(pblocks, (unsigned)a.C), dim3(W4_TIN), 0, s, a);
+        if (!(plan && plan->skip_input)) {
+            if (a.mask) hipLaunchKernelGGL(wino4_input_kernel<true>, dim3(pblocks, (unsigned)a.C), dim3(W4_TIN), 0, s, a);
+            else hipLaunchKernelGGL(wino4_input_kernel<false>, dim3(pblocks, (unsigned)a.C), dim3(W4_TIN), 0, s, a);
+        }
         if (e) (void)hipEventRecord(e[1], s);
         const int pairs8 = (36 * ptiles + 7) / 8;
         hipLaunchKernelGGL(wino4_gemm_kernel, dim3((unsigned)(pairs8 * ktiles * 8)), dim3(256), 2 * G_STAGE * 4, s, a, ptiles, ktiles);
         if (e) (void)hipEventRecord(e[2], s);
-        hipLaunchKernelGGL(wino4_output_kernel, dim3(pblocks, (unsigned)a.K), dim3(W4_TIN), 0, s, a);
+        if (plan && plan->bridge) {
+            const int ntile = a.th * a.tw;
+            const int nthr = ntile >= 1024 ? 1024 : (ntile + 63) / 64 * 64;
+            hipLaunchKernelGGL(wino4_bridge_kernel, dim3((unsigned)a.n, (unsigned)a.K), dim3(nthr), wino4_bridge_lds_bytes(a.H, a.W), s, a, plan->Vnext);
+        } else {
+            hipLaunchKernelGGL(wino4_output_kernel, dim3(pblocks, (unsigned)a.K), dim3(W4_TIN), 0, s, a);
+        }
         if (e && !gemm_only_events) (void)hipEventRecord(e[3], s);
     }
 }

@@ -62,6 +62,8 @@ struct Op {
     int w4_groups_last = 0, w4_launches = 0;
     bool timed_last = false, w4_gemm_only_last = false;
     bool skip = false;             // Upsample fused into the following F(4x4,3x3) convolution
+    bool w4_bridge = false;        // output transform fused with the next F(4x4) layer's input transform (no HBM round trip)
+    bool w4_bridged_in = false;    // this layer's transformed input is written by its predecessor's bridge
     int unpool_in = -1, unpool_mask = -1;   // that convolution: pooled blob and mask blob it reads through
     int drop_site = -1;
     // lrn
@@ -97,6 +99,7 @@ struct sivo_segnet {
     std::vector<void *> owned;
     float *d_wino4_ws = nullptr;    // V + M workspace shared by every F(4x4,3x3) layer
     size_t wino4_ws_floats = 0;
+    size_t wino4_slot_floats = 0;   // three rotating slots (V, M, next V) for layers that run all samples in one pass
     ~sivo_segnet() {
         for (sivo::Op &op : ops) {
             if (op.ev0) (void)hipEventDestroy(op.ev0);
@@ -372,6 +375,29 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             u.skip = true;
             S.blobs[u.out].fused_away = true;
         }
+    // F(4x4) conv -> F(4x4) conv at the same resolution: the activation in between stays on chip (wino4_bridge_kernel).
+    // SIVO_NO_FUSE_BRIDGE disables (the intermediate blob is then materialised and can be inspected).
+    for (size_t i = 0; i < S.ops.size(); ++i) {
+        Op &A = S.ops[i];
+        if (A.kind != OP_CONV || !A.wino4) continue;
+        const Blob &bo = S.blobs[A.out];
+        const int N = bo.shared ? 1 : S.T;
+        if (A.wino4_group < N) continue;                           // several passes over the workspace: plain path
+        const int64_t P = (int64_t)N * ((bo.H + 3) / 4) * (bo.W / 4), Pp = (P + 127) / 128 * 128;
+        S.wino4_slot_floats = std::max(S.wino4_slot_floats, (size_t)(36 * Pp * std::max<int64_t>(A.cin, A.cout_pad)));
+        if (std::getenv("SIVO_NO_FUSE_BRIDGE") || A.out == S.logits_blob) continue;
+        Op *B = nullptr;
+        int uses = 0;
+        for (Op &c : S.ops)
+            if (c.in == A.out || c.in2 == A.out) { ++uses; B = &c; }
+        if (uses != 1 || B->kind != OP_CONV || !B->wino4 || B->in != A.out || B->unpool_in >= 0) continue;
+        const Blob &bn = S.blobs[B->out];
+        if (bn.shared != bo.shared || bn.H != bo.H || bn.W != bo.W || B->wino4_group < N) continue;
+        if (wino4_bridge_lds_bytes(bo.H, bo.W) > 150 * 1024) continue;
+        A.w4_bridge = true; B->w4_bridged_in = true;
+        S.blobs[A.out].fused_away = true;
+    }
+    if (S.wino4_slot_floats) S.wino4_ws_floats = std::max(S.wino4_ws_floats, 3 * S.wino4_slot_floats);
     // allocate
     for (Blob &b : S.blobs) {
         if (b.fused_away) continue;
@@ -423,6 +449,7 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
     const int64_t hw = (int64_t)S.H * S.W;
     if (S.profile) harvest(S);
     launch_preprocess(d_bgr, (float *)S.blobs[S.input_blob].d, hw, st);
+    int w4_vslot = 0;
     for (Op &op : S.ops) {
         if (op.skip) continue;
         const Blob &bi = S.blobs[op.in];
@@ -461,7 +488,18 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
                     } else {
                         op.w4_groups_last = 0;
                     }
-                    launch_conv_wino4(a, S.d_wino4_ws, op.wino4_group, st, sub, S.profile_mfma_only);
+                    Wino4Plan plan{};
+                    const bool planned = op.wino4_group >= N && S.wino4_slot_floats;
+                    if (planned) {
+                        // three rotating slots: V of this layer, its M, V of the next layer (when bridged)
+                        if (!op.w4_bridged_in) w4_vslot = 0;
+                        plan.V = S.d_wino4_ws + (size_t)w4_vslot * S.wino4_slot_floats;
+                        plan.M = S.d_wino4_ws + (size_t)((w4_vslot + 1) % 3) * S.wino4_slot_floats;
+                        plan.Vnext = S.d_wino4_ws + (size_t)((w4_vslot + 2) % 3) * S.wino4_slot_floats;
+                        plan.skip_input = op.w4_bridged_in; plan.bridge = op.w4_bridge;
+                        if (op.w4_bridge) w4_vslot = (w4_vslot + 2) % 3;
+                    }
+                    launch_conv_wino4(a, S.d_wino4_ws, op.wino4_group, st, sub, S.profile_mfma_only, planned ? &plan : nullptr);
                 }
                 else if (op.wino) launch_conv_wino(a, op.wino_cfg, st);
                 else if (op.v2) launch_conv2(a, op.ks, st);
@@ -686,7 +724,7 @@ extern "C" int sivo_segnet_blob(sivo_segnet_t h, const char *name, float *host_o
         if (it == h->blob_id.end()) throw std::invalid_argument(std::string("no blob named '") + name + "'");
         const Blob &b = h->blobs[it->second];
         if (b.fused_away)
-            throw std::invalid_argument(std::string("blob '") + name + "' is not materialised: its Upsample layer is fused into the next convolution (SIVO_NO_FUSE_UNPOOL=1 keeps it)");
+            throw std::invalid_argument(std::string("blob '") + name + "' is not materialised: it only exists on chip, fused into the next convolution (SIVO_NO_FUSE_UNPOOL=1 / SIVO_NO_FUSE_BRIDGE=1 keep Upsample outputs / conv-to-conv activations in HBM)");
         const int N = b.shared ? 1 : h->T;
         if (shape) { shape[0] = N; shape[1] = b.C; shape[2] = b.H; shape[3] = b.W; }
         const size_t n = (size_t)N * b.chw();
@@ -728,7 +766,7 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
         DeviceGuard dg(h->device);
         harvest(*h);
         int rows = 0;
-        for (const Op &op : h->ops) rows += op.wino4 ? 3 : 1;      // an F(4x4,3x3) layer reports its three kernels separately
+        for (const Op &op : h->ops) rows += op.wino4 ? (op.w4_bridged_in ? 2 : 3) : 1;   // an F(4x4,3x3) layer reports its kernels separately
         *n_out = rows;
         if (!out) return SIVO_OK;
         if (capacity < *n_out) return fail(SIVO_ERR_CAPACITY, "%d rows, capacity %d", *n_out, capacity);
@@ -736,14 +774,14 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
         for (size_t i = 0; i < h->ops.size(); ++i) {
             const Op &op = h->ops[i];
             if (op.wino4) {
-                static const char *kn[3] = {"wino4_input_kernel", "wino4_gemm_kernel", "wino4_output_kernel"};
+                const char *kn[3] = {"wino4_input_kernel", "wino4_gemm_kernel", op.w4_bridge ? "wino4_bridge_kernel" : "wino4_output_kernel"};
                 const Blob &bi = h->blobs[op.in];
                 const double tiles = (double)((bi.H + 3) / 4) * (bi.W / 4), kp = wino4_cout_pad(op.cout);
                 const double bytes[3] = {4.0 * (op.cin * (double)bi.H * bi.W + 36.0 * op.cin * tiles),
                                          4.0 * 36.0 * tiles * (op.cin + kp),
                                          4.0 * (36.0 * kp * tiles + op.cout * (double)bi.H * bi.W)};
                 const int groups = op.launches ? op.w4_launches / op.launches : 1;
-                for (int k = 0; k < 3; ++k) {
+                for (int k = op.w4_bridged_in ? 1 : 0; k < 3; ++k) {
                     SivoOpProfile &p = out[r++];
                     std::memset(&p, 0, sizeof p);
                     std::snprintf(p.layer, sizeof p.layer, "%s", op.name.c_str());

@@ -49,8 +49,14 @@ int wino4_cout_pad(int cout);
 void wino4_pack_weights(const float *W, int cin, int cout, std::vector<float> &out, int *cout_pad);
 int wino4_group(int N, int cin, int cout, int H, int W, size_t budget_bytes);
 size_t wino4_workspace_floats(int group, int cin, int cout, int H, int W);
+struct Wino4Plan {
+    float *V, *M, *Vnext;    // disjoint buffers: this layer's transformed input, its GEMM output, the next layer's input
+    bool skip_input;         // V was written by the previous layer's bridge
+    bool bridge;             // fuse the output transform with the next layer's input transform (writes Vnext, not `out`)
+};
+size_t wino4_bridge_lds_bytes(int H, int W);
 void launch_conv_wino4(const ConvArgs &a, float *workspace, int group, hipStream_t s, hipEvent_t *stage_events = nullptr,
-                       bool gemm_only_events = false);
+                       bool gemm_only_events = false, const Wino4Plan *plan = nullptr);
 
 struct PoolArgs {
     const float *in;

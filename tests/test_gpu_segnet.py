@@ -4,6 +4,8 @@ Tolerances: logits max-abs 1e-3 (BASELINE.json north_star: "segmentation logits 
 1e-3 fp32"); probabilities / confidence / entropy 1e-5 (fp32 softmax, expf 1-ulp
 differences between libm and the device); classes exact except where the top-2 mean
 probabilities are closer than 1e-5."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -139,11 +141,33 @@ def test_full_size_frame_logits_within_tolerance(oracle, kind, kitti_like_bgr):
                    prob_tol=LOGIT_TOL / 2, ent_tol=5e-3)
 
 
+@pytest.mark.parametrize("H,W,width", [(22, 64, 256), (9, 12, 128), (44, 128, 128)])
+def test_bridged_convolutions_are_bit_identical(H, W, width):
+    """conv -> conv at >= 128 channels: output transform + epilogue (BN, ReLU, dropout) + next input transform in one
+    kernel through an LDS image of the channel plane, vs the three-kernel path that writes the activation to HBM.
+    Same arithmetic in the same order -> identical logits; ragged tile rows (22, 9) included."""
+    T = 3
+    text = _conv_stack_prototxt(T, H, W, width)
+    net, w, sn = _make(text, T, seed=5)
+    img = torch.from_numpy(_image(np.random.default_rng(H + W), H, W)).cuda()
+    _, lg_fused, _ = sn.forward(img, 77, sample0=1, want_logits=True)
+    with pytest.raises(ValueError, match="not materialised"):
+        sn.blob("c1")
+    os.environ["SIVO_NO_FUSE_BRIDGE"] = "1"
+    try:
+        _, _, sn2 = _make(text, T, seed=5)
+    finally:
+        del os.environ["SIVO_NO_FUSE_BRIDGE"]
+    _, lg_plain, _ = sn2.forward(img, 77, sample0=1, want_logits=True)
+    torch.cuda.synchronize()
+    assert sn2.blob("c1").shape == (T, width, H, W)
+    assert torch.equal(lg_fused, lg_plain)
+
+
 def test_fused_upsample_is_bit_identical_to_the_materialised_one():
     """Upsample -> F(4x4,3x3) convolution reads the pooled tensor + window codes inside the input transform; the same
     net built with SIVO_NO_FUSE_UNPOOL=1 runs the unpool kernel first.  Same arithmetic -> identical logits, and the
     fused-away blob is reported as such."""
-    import os
     from sivo_amd._lib import SivoError
     T, H, W = 3, 64, 96
     text = netspec.standard_prototxt(T, H, W)
@@ -256,7 +280,11 @@ def test_winograd_and_direct_conv_shapes(oracle, H, W, width):
     width 256 takes the F(4x4,3x3) path (conv_wino4.hip): ragged and odd tile rows, W a multiple of 4 only, one tile."""
     T = 3
     text = _conv_stack_prototxt(T, H, W, width)
-    net, w, sn = _make(text, T, seed=11)
+    os.environ["SIVO_NO_FUSE_BRIDGE"] = "1"          # every intermediate blob is inspected below
+    try:
+        net, w, sn = _make(text, T, seed=11)
+    finally:
+        del os.environ["SIVO_NO_FUSE_BRIDGE"]
     img = _image(np.random.default_rng(H * W), H, W)
     ob = oracle.run_net(net, w, oracle.preprocess(img, T, H, W), 31, sample0=2)
     _, logits, _ = sn.forward(torch.from_numpy(img).cuda(), 31, sample0=2, want_logits=True)
