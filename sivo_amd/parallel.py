@@ -7,11 +7,14 @@ so the result does not depend on the number of ranks."""
 
 
 def shard_samples(T, world, rank):
-    """Contiguous shard of the T samples: returns (sample0, n_local); the first T % world ranks take
-    one extra sample.  n_local may be 0 when world > T."""
+    """Contiguous shard of the T samples: returns (sample0, n_local).  When T is not a multiple of the
+    world size the LAST T % world ranks take one extra sample: rank 0 also runs the ORB extractors, the
+    stereo matching and the host side of the frame, so it gets the lighter share (T = 12 on 8 GPUs:
+    1,1,1,1,2,2,2,2).  n_local may be 0 when world > T."""
     base, extra = divmod(T, world)
-    n_local = base + (1 if rank < extra else 0)
-    sample0 = rank * base + min(rank, extra)
+    first_heavy = world - extra
+    n_local = base + (1 if rank >= first_heavy else 0)
+    sample0 = rank * base + max(0, rank - first_heavy)
     return sample0, n_local
 
 
