@@ -48,7 +48,9 @@ constexpr int wino_slab(int bn, int kc) { return (16 * kc * wino_bnp(bn) + 255) 
 // Workgroup: WM m-tiles stacked vertically (2*WM output rows x 32 output columns) x BN = WN*NT*16 couts.
 // ABL: ablation switches for tools/conv_probe.py only (0 in production): 1 no staging after the prologue,
 // 2 additionally no barrier, 4 additionally no input transform (V = raw patch), 8 additionally B from a register.
-template <int WM, int WN, int NT, int KC, int ABL = 0>
+// UNPOOL: `a.in` is the pooled tensor of an Upsample (scale 2) layer and `a.unpool_mask` its window codes; the patch
+// loader reads 2 pooled values + 2 codes where it would read 4 unpooled pixels (the unpooled tensor never exists).
+template <int WM, int WN, int NT, int KC, int ABL = 0, bool UNPOOL = false>
 __global__ __launch_bounds__(WM * WN * 64, ((KC == 4 || WM * WN == 12) ? 3 : 2)) void conv_wino_kernel(ConvArgs a) {
     constexpr int NTHR = WM * WN * 64, NWAVE = WM * WN;
     constexpr int BN = WN * NT * 16, BNP = wino_bnp(BN);
@@ -88,6 +90,10 @@ __global__ __launch_bounds__(WM * WN * 64, ((KC == 4 || WM * WN == 12) ? 3 : 2))
 
     const float *in_n = a.in + (int64_t)n * a.in_sample_stride;
     const int64_t plane = (int64_t)a.H * a.W;
+    // UNPOOL: geometry of the pooled source (H/2 x W/2) and the codes of this sample
+    const int Wh = a.W >> 1;
+    const int64_t plane_in = UNPOOL ? (int64_t)(a.H >> 1) * Wh : plane;
+    const uint8_t *mk_n = UNPOOL ? a.unpool_mask + (int64_t)n * a.unpool_mask_stride : nullptr;
 
     // 4x4 input patch of tile (row wm, column li): LDS rows 2*wm .. 2*wm+3; columns q = 2*li .. 2*li+3
     const int a_base = lk * CS + (2 * wm) * PWp + li;
@@ -114,7 +120,8 @@ __global__ __launch_bounds__(WM * WN * 64, ((KC == 4 || WM * WN == 12) ? 3 : 2))
         const int py = r % PH, c = r / PH;
         const int gy = y0 + py - 1, gx = x0 + seg * 4;
         v_ok[it] = idx < NV4 && gy >= 0 && gy < a.H && gx + 3 < a.W;
-        v_goff[it] = v_ok[it] ? (int)(c * plane + (int64_t)gy * a.W + gx) : 0;
+        if (UNPOOL) v_goff[it] = v_ok[it] ? (int)(c * plane_in + (int64_t)(gy >> 1) * Wh + (gx >> 1)) | ((gy & 1) << 30) : 0;   // bit 30: window row
+        else v_goff[it] = v_ok[it] ? (int)(c * plane + (int64_t)gy * a.W + gx) : 0;
         // pixels x0+4s..+3 are q = 4s+1..4s+4: (v0, v2) -> O[2s], O[2s+1]; (v1, v3) -> E[2s+1], E[2s+2]
         v_dst[it] = idx < NV4 ? ((c * CS + py * PWp + 2 * seg) | (c << 24)) : -1;
     }
@@ -127,7 +134,8 @@ __global__ __launch_bounds__(WM * WN * 64, ((KC == 4 || WM * WN == 12) ? 3 : 2))
         const int px = h == 0 ? EOFF : 16;            // x = x0-1 is q = 0 -> E[0]; x = x0+32 is q = 33 -> O[16]
         const int gy = y0 + py - 1, gx = h == 0 ? x0 - 1 : x0 + TW;
         const bool ok = idx < NSC && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        s_goff[it] = ok ? (int)(c * plane + (int64_t)gy * a.W + gx) : -1;
+        if (UNPOOL) s_goff[it] = ok ? (int)(c * plane_in + (int64_t)(gy >> 1) * Wh + (gx >> 1)) | ((gy & 1) << 30) | ((gx & 1) << 29) : -1;
+        else s_goff[it] = ok ? (int)(c * plane + (int64_t)gy * a.W + gx) : -1;
         s_dst[it] = idx < NSC ? ((c * CS + py * PWp + px) | (c << 24)) : -1;
     }
     f32x4 pv4[V4IT];
@@ -135,8 +143,29 @@ __global__ __launch_bounds__(WM * WN * 64, ((KC == 4 || WM * WN == 12) ? 3 : 2))
     const int nchunks = (a.Cin + KC - 1) / KC;
 
     auto issue_patch = [&](int chunk) {
-        const float *psrc = in_n + (int64_t)chunk * KC * plane;
+        const float *psrc = in_n + (int64_t)chunk * KC * plane_in;
         const int cleft = a.Cin - chunk * KC;
+        if (UNPOOL) {
+            const uint8_t *msrc = mk_n + (int64_t)chunk * KC * plane_in;
+#pragma unroll
+            for (int it = 0; it < V4IT; ++it) {
+                const bool ok = v_ok[it] && (v_dst[it] >> 24) < cleft;
+                const int off = ok ? (v_goff[it] & 0x1fffffff) : 0, code0 = (v_goff[it] >> 30) << 1;   // window row * 2
+                const float2 v = *reinterpret_cast<const float2 *>(psrc + off);                          // gx % 4 == 0: 8-byte aligned
+                const uchar2 m = *reinterpret_cast<const uchar2 *>(msrc + off);
+                pv4[it] = ok ? (f32x4){m.x == code0 ? v.x : 0.f, m.x == code0 + 1 ? v.x : 0.f, m.y == code0 ? v.y : 0.f, m.y == code0 + 1 ? v.y : 0.f}
+                             : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int it = 0; it < SCIT; ++it) {
+                const bool ok = s_goff[it] >= 0 && (s_dst[it] >> 24) < cleft;
+                const int off = ok ? (s_goff[it] & 0x1fffffff) : 0, code = ((s_goff[it] >> 30) & 1) * 2 + ((s_goff[it] >> 29) & 1);
+                const float v = psrc[off];
+                const int m = msrc[off];
+                psc[it] = (ok && m == code) ? v : 0.f;
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < V4IT; ++it) {
             const bool ok = v_ok[it] && (v_dst[it] >> 24) < cleft;
@@ -312,7 +341,7 @@ void wino_pack_weights(const float *W, int cin, int cout, int cfg, std::vector<f
         }
 }
 
-template <int WM, int WN, int NT, int KC, int ABL = 0>
+template <int WM, int WN, int NT, int KC, int ABL = 0, bool UNPOOL = false>
 static void launch_wino_cfg(const ConvArgs &a0, hipStream_t s) {
     ConvArgs a = a0;
     constexpr int BN = WN * NT * 16;
@@ -320,10 +349,11 @@ static void launch_wino_cfg(const ConvArgs &a0, hipStream_t s) {
     a.tiles_y = (a.H + 2 * WM - 1) / (2 * WM);
     const int ptiles = a.tiles_x * a.tiles_y * a.N;
     dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * (a.CoutPad / BN)));
-    hipLaunchKernelGGL((conv_wino_kernel<WM, WN, NT, KC, ABL>), grid, dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((conv_wino_kernel<WM, WN, NT, KC, ABL, UNPOOL>), grid, dim3(WM * WN * 64), 0, s, a);
 }
 
 void launch_conv_wino(const ConvArgs &a, int cfg, hipStream_t s) {
+    if (a.unpool_mask) return launch_wino_cfg<2, 2, 2, 4, 0, true>(a, s);     // Upsample fused into the patch loader (cfg 0 only)
     if (cfg == 1) return launch_wino_cfg<4, 1, 2, 8>(a, s);
     if (cfg == 2) return launch_wino_cfg<6, 2, 2, 4>(a, s);   // 12 waves: 12 x 32 px x 64 couts, one workgroup per CU
     switch (a.variant >> 8) {   // ablations, probe only

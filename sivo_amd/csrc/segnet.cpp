@@ -357,8 +357,9 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
         if (op.out2 >= 0) S.blobs[op.out2].shared = S.blobs[op.in].shared;   // the argmax only depends on the input
         (sh ? S.flops_shared : S.flops_sample) += op.flops;
     }
-    // Upsample -> F(4x4,3x3) convolution: the input transform reads the pooled tensor and the window codes directly
-    // (4x fewer input bytes, no unpool kernel, the unpooled tensor is never written).  SIVO_NO_FUSE_UNPOOL disables.
+    // Upsample -> Winograd convolution: the F(4x4) input transform / the F(2x2) patch loader reads the pooled tensor and
+    // the window codes directly (4x fewer input bytes, no unpool kernel, the unpooled tensor is never written).
+    // SIVO_NO_FUSE_UNPOOL disables.
     if (!std::getenv("SIVO_NO_FUSE_UNPOOL"))
         for (Op &u : S.ops) {
             if (u.kind != OP_UNPOOL) continue;
@@ -366,7 +367,8 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             int uses = u.out == S.logits_blob ? 2 : 0;
             for (Op &c : S.ops)
                 if (c.in == u.out || c.in2 == u.out) { ++uses; consumer = &c; }
-            if (uses != 1 || consumer->kind != OP_CONV || !consumer->wino4 || consumer->in != u.out) continue;
+            if (uses != 1 || consumer->kind != OP_CONV || consumer->in != u.out) continue;
+            if (!consumer->wino4 && !(consumer->wino && consumer->wino_cfg == 0)) continue;   // both Winograd paths read through the pooling
             const Blob &pooled = S.blobs[u.in], &mask = S.blobs[u.in2], &up = S.blobs[u.out];
             if (pooled.shared && !up.shared) continue;            // (not produced by the reference nets)
             if (up.H != 2 * pooled.H || up.W != 2 * pooled.W || (pooled.W & 1)) continue;
