@@ -1,0 +1,332 @@
+// conv_wino4f.hip — FUSED Winograd F(4x4, 3x3) for the narrow layers (64 output channels per workgroup).
+//
+// The three-kernel F(4x4) path (conv_wino4.hip) moves 2.25x the activation through HBM twice; with 64..128 channels
+// its position-GEMMs are bandwidth-bound and the fused F(2x2) kernel (conv_wino.hip) was the faster choice — at 2.25x
+// instead of 4x fewer MFMA flops, and with a full per-lane tile transform in front of every 32 MFMAs.  This kernel
+// keeps everything on chip AND gets the 4x, by giving every wave ONE ROW of the 6x6 transform:
+//
+//   workgroup = 12 waves = 2 m-tiles (16 horizontally adjacent 4x4-output tiles each: 4 rows x 64 px) x 6 transform
+//   rows; 64 couts.  Wave (mt, i), lane (tile li, channel c0 + lk):
+//     * reads the 3-4 raw patch rows that row i of B^T touches (b128 + b64 per row), forms t = (B^T d)[i][0..5] and
+//       V[i][0..5] = t B in registers (~35 VALU ops) — exactly the A operands of positions (i, 0..5);
+//     * B operand of position (i, j): ONE ds_read_b128 gives the four 16-cout blocks (slab is stored [position]
+//       [channel][cout%16][cout/16]);  acc[6][4] = 96 accumulator VGPRs, 24 MFMAs per 4-channel step;
+//     * after the channel loop A^T M A is split the same way: the column half (over j) is lane-local, the row half
+//       (over i) is a 6-way reduction across the waves of an m-tile through LDS, done per 16-cout block in the space
+//       the staging buffers no longer need; the final stage writes 256-byte row segments.
+//   Per 24 MFMAs a wave issues ~7 patch reads + 6 slab reads: far less staging per MFMA than the F(2x2) kernel.
+//   K-chunks of 4 channels, double-buffered LDS (2 x (patch 10.8 KB + slab 36 KB) = 93.5 KB, one workgroup per CU at
+//   3 waves/SIMD); the pre-transformed weight slab is the LDS image and is copied by LDS-DMA; the patch goes through
+//   registers one chunk ahead (the Upsample in front of the layer can be folded into that load: UNPOOL).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "segnet_kernels.hpp"
+
+namespace sivo {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t w4f_dropout_word(uint32_t e, uint32_t site, uint32_t sample, uint64_t seed) {
+    uint32_t c0 = e >> 7, c1 = site, c2 = sample, c3 = 0u, k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint32_t sel = (e >> 5) & 3u;
+    return sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
+}
+
+constexpr int F_MT = 2;                       // m-tiles per workgroup (stacked vertically)
+constexpr int F_NW = F_MT * 6, F_NTHR = F_NW * 64;
+constexpr int F_TH = 4 * F_MT, F_TW = 64;     // output pixels per workgroup
+constexpr int F_PR = F_TH + 2;                // patch rows
+constexpr int F_PC = 68;                      // patch row stride (66 used): image column x0 - 1 + q at patch column q
+constexpr int F_CS = 688;                     // channel stride: F_PR * F_PC = 680, padded to 16 (mod 32)
+constexpr int F_PATCH = 4 * F_CS;             // floats per patch buffer
+constexpr int F_SLAB = 36 * 4 * 64;           // floats per weight slab (36 KiB)
+constexpr int F_BUF = F_PATCH + F_SLAB;
+constexpr int F_RS = 17;                      // epilogue exchange: [mt][i][tile*4 + j'][cout16 + pad]
+
+__device__ __forceinline__ void w4f_bt(const float d0, const float d1, const float d2, const float d3, const float d4,
+                                       const float d5, float *t) {
+    const float a = d4 - 4.f * d2, b = d3 - 4.f * d1, c = d4 - d2, e = 2.f * (d3 - d1);
+    t[0] = 4.f * d0 - 5.f * d2 + d4;
+    t[1] = a + b;
+    t[2] = a - b;
+    t[3] = c + e;
+    t[4] = c - e;
+    t[5] = 4.f * d1 - 5.f * d3 + d5;
+}
+__device__ __forceinline__ void w4f_at(const float m0, const float m1, const float m2, const float m3, const float m4,
+                                       const float m5, float *s) {
+    const float p12 = m1 + m2, q12 = m1 - m2, p34 = m3 + m4, q34 = m3 - m4;
+    s[0] = m0 + p12 + p34;
+    s[1] = q12 + 2.f * q34;
+    s[2] = p12 + 4.f * p34;
+    s[3] = q12 + 8.f * q34 + m5;
+}
+
+template <bool UNPOOL>
+__global__ __launch_bounds__(F_NTHR, 1) void conv_wino4f_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // 2 * F_BUF floats
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int mt = wave / 6, wi = wave % 6;
+
+    // XCD-aware order as in conv_wino.hip: workgroup L -> XCD L % 8, the Cout tiles of one pixel tile back to back
+    const int ntiles = a.CoutPad / 64;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ntile = slot % ntiles;
+    int bid = (slot / ntiles) * 8 + xcd;
+    if (bid >= a.tiles_x * a.tiles_y * a.N) return;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+    const int n = bid;
+    const int x0 = tx * F_TW, y0 = ty * F_TH;
+    const int n0 = ntile * 64;
+
+    const float *in_n = a.in + (int64_t)n * a.in_sample_stride;
+    const int64_t plane = (int64_t)a.H * a.W;
+    const int Wh = a.W >> 1;
+    const int64_t plane_in = UNPOOL ? (int64_t)(a.H >> 1) * Wh : plane;
+    const uint8_t *mk_n = UNPOOL ? a.unpool_mask + (int64_t)n * a.unpool_mask_stride : nullptr;
+
+    // ---- staging plan: one interior float4 per thread (4 ch x 10 rows x 16 segments = 640) + 80 halo scalars
+    constexpr int NV4 = 4 * F_PR * (F_TW / 4), NSC = 4 * F_PR * 2;
+    static_assert(NV4 <= F_NTHR && NSC <= F_NTHR, "one staging item per thread");
+    int v_goff = 0, v_dst = -1, v_c = 0;
+    bool v_ok = false;
+    if (tid < NV4) {
+        const int seg = tid % (F_TW / 4), r = tid / (F_TW / 4);
+        const int py = r % F_PR, c = r / F_PR;
+        const int gy = y0 + py - 1, gx = x0 + seg * 4;
+        v_ok = gy >= 0 && gy < a.H && gx + 3 < a.W;
+        if (UNPOOL) v_goff = v_ok ? ((int)(c * plane_in + (int64_t)(gy >> 1) * Wh + (gx >> 1)) | ((gy & 1) << 30)) : 0;
+        else v_goff = v_ok ? (int)(c * plane + (int64_t)gy * a.W + gx) : 0;
+        v_dst = c * F_CS + py * F_PC + seg * 4 + 1;       // image column x0 + 4 seg sits at patch column 4 seg + 1
+        v_c = c;
+    }
+    int s_goff = -1, s_dst = -1, s_c = 0;
+    if (tid < NSC) {
+        const int h = tid % 2, r = tid / 2;
+        const int py = r % F_PR, c = r / F_PR;
+        const int gy = y0 + py - 1, gx = h == 0 ? x0 - 1 : x0 + F_TW;
+        const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        if (UNPOOL) s_goff = ok ? ((int)(c * plane_in + (int64_t)(gy >> 1) * Wh + (gx >> 1)) | ((gy & 1) << 30) | ((gx & 1) << 29)) : -1;
+        else s_goff = ok ? (int)(c * plane + (int64_t)gy * a.W + gx) : -1;
+        s_dst = c * F_CS + py * F_PC + (h == 0 ? 0 : F_TW + 1);
+        s_c = c;
+    }
+    f32x4 pv4 = {0.f, 0.f, 0.f, 0.f};
+    float psc = 0.f;
+    const int nchunks = (a.Cin + 3) / 4;
+
+    auto issue_patch = [&](int chunk) {
+        const float *psrc = in_n + (int64_t)chunk * 4 * plane_in;
+        const int cleft = a.Cin - chunk * 4;
+        if (UNPOOL) {
+            const uint8_t *msrc = mk_n + (int64_t)chunk * 4 * plane_in;
+            {
+                const bool ok = v_ok && v_c < cleft;
+                const int off = ok ? (v_goff & 0x1fffffff) : 0, code0 = (v_goff >> 30) << 1;
+                const float2 v = *reinterpret_cast<const float2 *>(psrc + off);
+                const uchar2 m = *reinterpret_cast<const uchar2 *>(msrc + off);
+                pv4 = ok ? (f32x4){m.x == code0 ? v.x : 0.f, m.x == code0 + 1 ? v.x : 0.f, m.y == code0 ? v.y : 0.f, m.y == code0 + 1 ? v.y : 0.f}
+                         : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            {
+                const bool ok = s_goff >= 0 && s_c < cleft;
+                const int off = ok ? (s_goff & 0x1fffffff) : 0, code = ((s_goff >> 30) & 1) * 2 + ((s_goff >> 29) & 1);
+                const float v = psrc[off];
+                const int m = msrc[off];
+                psc = (ok && m == code) ? v : 0.f;
+            }
+            return;
+        }
+        {
+            const bool ok = v_ok && v_c < cleft;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(psrc + (ok ? v_goff : 0));
+            pv4 = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        {
+            const bool ok = s_goff >= 0 && s_c < cleft;
+            const float v = psrc[ok ? s_goff : 0];
+            psc = ok ? v : 0.f;
+        }
+    };
+    auto commit_patch = [&](int buf) {
+        float *sp = lds + buf * F_BUF;
+        if (v_dst >= 0) {
+            float *q = sp + v_dst;
+            q[0] = pv4[0]; q[1] = pv4[1]; q[2] = pv4[2]; q[3] = pv4[3];
+        }
+        if (s_dst >= 0) sp[s_dst] = psc;
+    };
+    auto dma_weights = [&](int chunk, int buf) {
+        const float *wsrc = a.wt + ((int64_t)chunk * ntiles + ntile) * F_SLAB;
+        float *dst = lds + buf * F_BUF + F_PATCH;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int kib = i * F_NW + wave;          // 36 KiB: three 1 KiB copies per wave
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + kib * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void *)(dst + kib * 256), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[6][4];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[j][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue_patch(0);
+    dma_weights(0, 0);
+    commit_patch(0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+
+    // this lane's 6 x 6 window: patch rows 4 mt .. 4 mt + 5, columns 4 li .. 4 li + 5 of channel lk
+    const int a_base = lk * F_CS + (4 * mt) * F_PC + 4 * li;
+    const int b_base = F_PATCH + (wi * 6 * 4 + lk) * 64 + li * 4;        // position (wi, j): + j * 256
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int cur = chunk & 1;
+        const bool more = chunk + 1 < nchunks;
+        if (more) { issue_patch(chunk + 1); dma_weights(chunk + 1, cur ^ 1); }
+        const float *sp = lds + cur * F_BUF;
+        // ---- row wi of B^T d, then the row transform: V[j] = (B^T d B)[wi][j]
+        float t[6];
+        auto row = [&](int r, float *d) {
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(sp + a_base + r * F_PC);
+            const float2 e = *reinterpret_cast<const float2 *>(sp + a_base + r * F_PC + 4);
+            d[0] = q[0]; d[1] = q[1]; d[2] = q[2]; d[3] = q[3]; d[4] = e.x; d[5] = e.y;
+        };
+        if (wi == 0) {
+            float d0[6], d2[6], d4[6];
+            row(0, d0); row(2, d2); row(4, d4);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) t[j] = 4.f * d0[j] - 5.f * d2[j] + d4[j];
+        } else if (wi == 5) {
+            float d1[6], d3[6], d5[6];
+            row(1, d1); row(3, d3); row(5, d5);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) t[j] = 4.f * d1[j] - 5.f * d3[j] + d5[j];
+        } else {
+            float d1[6], d2[6], d3[6], d4[6];
+            row(1, d1); row(2, d2); row(3, d3); row(4, d4);
+            if (wi <= 2) {
+                const float sgn = wi == 1 ? 1.f : -1.f;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) t[j] = (d4[j] - 4.f * d2[j]) + sgn * (d3[j] - 4.f * d1[j]);
+            } else {
+                const float sgn = wi == 3 ? 2.f : -2.f;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) t[j] = (d4[j] - d2[j]) + sgn * (d3[j] - d1[j]);
+            }
+        }
+        float V[6];
+        w4f_bt(t[0], t[1], t[2], t[3], t[4], t[5], V);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const f32x4 bq = *reinterpret_cast<const f32x4 *>(sp + b_base + j * 256);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[j], bq[nb], acc[j][nb], 0, 0, 0);
+            if (j == 3 && more) commit_patch(cur ^ 1);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+    }
+
+    // ---- output transform.  acc[j][nb][r] = M_(wi,j)[tile 4 lk + r][cout nb*16 + li]
+    float *Rb = lds;                                  // [mt][i][q = tile*4 + j'][F_RS]
+    float *out_n = a.out + (int64_t)n * a.Cout * plane;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        // column half (over j), lane-local
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s[4];
+            w4f_at(acc[0][nb][r], acc[1][nb][r], acc[2][nb][r], acc[3][nb][r], acc[4][nb][r], acc[5][nb][r], s);
+            float *dst = Rb + ((mt * 6 + wi) * 64 + (4 * lk + r) * 4) * F_RS + li;
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) dst[jp * F_RS] = s[jp];
+        }
+        __syncthreads();
+        // row half (over i): one output column x = x0 + q of 4 rows per item, 64 consecutive q per wave
+        for (int it = wave; it < F_MT * 16; it += F_NW) {
+            const int m2 = it >> 4, c16 = it & 15, q = lane;
+            const int co = n0 + nb * 16 + c16, x = x0 + q;
+            const float *src = Rb + (m2 * 6 * 64 + q) * F_RS + c16;
+            float y4[4];
+            w4f_at(src[0], src[64 * F_RS], src[2 * 64 * F_RS], src[3 * 64 * F_RS], src[4 * 64 * F_RS], src[5 * 64 * F_RS], y4);
+            if (co < a.Cout && x < a.W) {
+                const float sc = a.ep_scale[co], sh = a.ep_shift[co];
+#pragma unroll
+                for (int ip = 0; ip < 4; ++ip) {
+                    const int y = y0 + 4 * m2 + ip;
+                    if (y >= a.H) break;
+                    float v = y4[ip] * sc + sh;
+                    if (a.relu) v = v > 0.f ? v : 0.f;
+                    if (a.drop_site >= 0) {
+                        const uint32_t e = (uint32_t)((co * a.H + y) * a.W + x);
+                        const uint32_t w = w4f_dropout_word(e, (uint32_t)a.drop_site, (uint32_t)(a.sample0 + n), a.seed);
+                        v = ((w >> (e & 31)) & 1u) ? v * 2.f : 0.f;
+                    }
+                    out_n[(int64_t)co * plane + (int64_t)y * a.W + x] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+bool wino4f_supported(int ks, int cin, int cout, int H, int W) {
+    return ks == 3 && cin >= 4 && cout % 64 == 0 && (W % 8) == 0 && (H % 2) == 0;
+}
+int wino4f_slab_floats() { return F_SLAB; }
+
+// Caffe (Cout,Cin,3,3) -> [ceil(Cin/4)][Cout/64][36][4 ch][16 = cout%16][4 = (cout%64)/16], U = G g G^T in double
+void wino4f_pack_weights(const float *W, int cin, int cout, std::vector<float> &out, int *cout_pad) {
+    static const double G[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+    const int ntiles = cout / 64, nchunks = (cin + 3) / 4;
+    *cout_pad = cout;
+    out.assign((size_t)nchunks * ntiles * F_SLAB, 0.f);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float *g = W + ((size_t)co * cin + ci) * 9;
+            double t[6][3];
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[j] + G[i][1] * g[3 + j] + G[i][2] * g[6 + j];
+            const size_t base = ((size_t)(ci / 4) * ntiles + co / 64) * F_SLAB;
+            const int cl = co % 64;
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j)
+                    out[base + (size_t)(((i * 6 + j) * 4 + ci % 4) * 16 + cl % 16) * 4 + cl / 16] =
+                        (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+        }
+}
+
+void launch_conv_wino4f(const ConvArgs &a0, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino4f_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F_BUF * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino4f_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F_BUF * 4);
+        attr_set = true;
+    }
+    ConvArgs a = a0;
+    a.tiles_x = (a.W + F_TW - 1) / F_TW;
+    a.tiles_y = (a.H + F_TH - 1) / F_TH;
+    const int ptiles = a.tiles_x * a.tiles_y * a.N;
+    dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * (a.CoutPad / 64)));
+    if (a.unpool_mask) hipLaunchKernelGGL(conv_wino4f_kernel<true>, grid, dim3(F_NTHR), 2 * F_BUF * 4, s, a);
+    else hipLaunchKernelGGL(conv_wino4f_kernel<false>, grid, dim3(F_NTHR), 2 * F_BUF * 4, s, a);
+}
+
+}  // namespace sivo

@@ -55,6 +55,7 @@ struct Op {
     bool v2 = false;           // conv_v2.hip kernel + weight layout
     bool wino = false;         // conv_wino.hip kernel + pre-transformed weights
     int wino_cfg = 0;
+    bool wino4f = false;       // conv_wino4f.hip: fused F(4x4,3x3), 64 couts per workgroup (narrow layers)
     bool wino4 = false;        // conv_wino4.hip: F(4x4,3x3) as input transform + batched GEMM + output transform
     int wino4_group = 1;       // samples per V/M workspace pass
     std::vector<hipEvent_t> w4_ev;                 // profiling: 4 events per group of the last launch
@@ -142,7 +143,7 @@ int new_blob(sivo_segnet &S, const std::string &name, int C, int H, int W, bool 
 
 // Re-layout Caffe (Cout,Cin,k,k) weights to [ceil(Cin/KC)][k*k][KC][CoutPad] and fold
 // bias (+ BN scale/shift) into the epilogue's per-channel affine.
-void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int H, int Wd) {
+void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int H, int Wd, bool keep_ties) {
     const int ks = op.ks, cin = op.cin, cout = op.cout;
     std::vector<float> wt;
     static const bool force_v1 = std::getenv("SIVO_CONV_V1") != nullptr;
@@ -150,10 +151,24 @@ void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int 
     // F(4x4,3x3) for the wide layers (4x fewer MFMA flops; costs ~2e-4 of the 1e-3 logit budget) — SIVO_NO_WINO4 disables
     static const bool no_wino4 = std::getenv("SIVO_NO_WINO4") != nullptr;
     static const size_t wino4_budget = (size_t)(std::getenv("SIVO_WINO4_MB") ? std::atoi(std::getenv("SIVO_WINO4_MB")) : 2048) << 20;
-    op.wino4 = !no_wino && !no_wino4 && wino4_supported(ks, cin, cout, H, Wd);
-    op.wino = !op.wino4 && !no_wino && wino_supported(ks, cin, cout, H, Wd);
-    op.v2 = !op.wino4 && !op.wino && conv2_supported(ks) && !force_v1;
-    if (op.wino4) {
+    // keep_ties: the layer belongs to the sample-invariant encoder prefix (conv1_1 .. conv3_3), whose outputs decide the
+    // switches of pool1..pool3.  Over a flat image region (sky, saturated pixels) the four elements of a pooling window
+    // are EXACTLY equal in the reference, which then takes the first; the direct and the F(2x2) kernels reproduce that (a
+    // constant patch gives bit-identical outputs at every position of a tile), F(4x4) does not (4d - 5d + d is not
+    // exactly 0 in fp32), its noise survives the following layers, and the switch picked instead moves the value by a
+    // pixel after unpooling.  Measured on the KITTI test frame with F(4x4) in the prefix: 5672 instead of 27 differing
+    // switches at pool1, 0.46 % instead of 0.04 % of the final class map differing from the oracle.  The prefix runs once
+    // per frame, so keeping it on F(2x2) costs 0.13 ms.
+    const bool f4_ok = !no_wino && !keep_ties;
+    op.wino4 = f4_ok && !no_wino4 && wino4_supported(ks, cin, cout, H, Wd);
+    // narrow layers (below the F(4x4) GEMM threshold): the fused F(4x4) kernel — SIVO_NO_WINO4F falls back to fused F(2x2)
+    static const bool no_wino4f = std::getenv("SIVO_NO_WINO4F") != nullptr;
+    op.wino4f = !op.wino4 && f4_ok && !no_wino4f && wino4f_supported(ks, cin, cout, H, Wd);
+    op.wino = !op.wino4 && !op.wino4f && !no_wino && wino_supported(ks, cin, cout, H, Wd);
+    op.v2 = !op.wino4 && !op.wino4f && !op.wino && conv2_supported(ks) && !force_v1;
+    if (op.wino4f) {
+        wino4f_pack_weights(W, cin, cout, wt, &op.cout_pad);
+    } else if (op.wino4) {
         wino4_pack_weights(W, cin, cout, wt, &op.cout_pad);
         op.wino4_group = wino4_group(S.T, cin, cout, H, Wd, wino4_budget);
         S.wino4_ws_floats = std::max(S.wino4_ws_floats, wino4_workspace_floats(op.wino4_group, cin, cout, H, Wd));
@@ -240,14 +255,16 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             op.kind = OP_CONV; op.in = bi; op.ks = L.kernel_size; op.cin = b.C; op.cout = L.num_output;
             op.out = new_blob(S, L.top[0], L.num_output, b.H, b.W, b.shared);
             const size_t nw = (size_t)op.cout * op.cin * op.ks * op.ks;
-            upload_conv(S, op, weights + woff, weights + woff + nw, b.H, b.W);
+            upload_conv(S, op, weights + woff, weights + woff + nw, b.H, b.W, /*keep_ties=*/b.shared);
             woff += nw + op.cout;
             op.flops = 2.0 * op.ks * op.ks * op.cin * op.cout * (double)b.H * b.W;
             op.name = L.name;
             {
                 char kn[96];
                 const int bn = conv_cout_tile(op.ks, op.cout), kc = conv_k_chunk(op.ks, op.cin);
-                if (op.wino4)
+                if (op.wino4f)
+                    snprintf(kn, sizeof kn, "conv_wino4f_kernel");
+                else if (op.wino4)
                     snprintf(kn, sizeof kn, "conv_wino4 (input + gemm + output kernels)");
                 else if (op.wino)
                     snprintf(kn, sizeof kn, op.wino_cfg == 2 ? "conv_wino_kernel<6,2,2,4>" : op.wino_cfg == 1 ? "conv_wino_kernel<4,1,2,8>" : "conv_wino_kernel<2,2,2,4>");
@@ -368,7 +385,7 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             for (Op &c : S.ops)
                 if (c.in == u.out || c.in2 == u.out) { ++uses; consumer = &c; }
             if (uses != 1 || consumer->kind != OP_CONV || consumer->in != u.out) continue;
-            if (!consumer->wino4 && !(consumer->wino && consumer->wino_cfg == 0)) continue;   // both Winograd paths read through the pooling
+            if (!consumer->wino4 && !consumer->wino4f && !(consumer->wino && consumer->wino_cfg == 0)) continue;   // every Winograd path reads through the pooling
             const Blob &pooled = S.blobs[u.in], &mask = S.blobs[u.in2], &up = S.blobs[u.out];
             if (pooled.shared && !up.shared) continue;            // (not produced by the reference nets)
             if (up.H != 2 * pooled.H || up.W != 2 * pooled.W || (pooled.W & 1)) continue;
@@ -477,7 +494,9 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
                     a.in = (const float *)bp.d; a.in_sample_stride = bp.shared ? 0 : bp.chw();
                     a.unpool_mask = (const uint8_t *)bm.d; a.unpool_mask_stride = bm.shared ? 0 : bm.chw();
                 }
-                if (op.wino4) {
+                if (op.wino4f) {
+                    launch_conv_wino4f(a, st);
+                } else if (op.wino4) {
                     hipEvent_t *sub = nullptr;
                     if (S.profile) {
                         op.w4_groups_last = cdiv(N, op.wino4_group);
@@ -818,15 +837,16 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
 extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, int iters, int variant, double *ms_out) {
     return guarded([&] {
         if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device");
-        const bool wino4 = (variant & 512) && wino4_supported(ks, Cin, Cout, H, W);
-        const bool wino = !wino4 && (variant & 64) && wino_supported(ks, Cin, Cout, H, W);
+        const bool wino4f = (variant & 1024) && wino4f_supported(ks, Cin, Cout, H, W);
+        const bool wino4 = !wino4f && (variant & 512) && wino4_supported(ks, Cin, Cout, H, W);
+        const bool wino = !wino4 && !wino4f && (variant & 64) && wino_supported(ks, Cin, Cout, H, W);
         const int wcfg = (variant & 128) ? ((variant & 32) ? 2 : 1) : 0;
         const bool v2 = !wino && (variant & 16) && conv2_supported(ks);
         const int KC = v2 ? 4 : conv_k_chunk(ks, Cin), BN = conv_cout_tile(ks, Cout);
         const int cout_pad = cdiv(Cout, BN) * BN, nchunks = cdiv(Cin, KC);
         const size_t nin = (size_t)N * Cin * H * W, nout = (size_t)N * Cout * H * W;
         const int w4group = wino4 ? wino4_group(N, Cin, Cout, H, W, (size_t)(std::getenv("SIVO_WINO4_MB") ? std::atoi(std::getenv("SIVO_WINO4_MB")) : 2048) << 20) : 0;
-        const size_t nw = wino4 ? (size_t)36 * Cin * wino4_cout_pad(Cout) : wino ? (size_t)wino_chunks(wcfg, Cin) * (Cout / wino_cout_tile(wcfg)) * wino_slab_floats(wcfg) : v2 ? (size_t)nchunks * (cout_pad / BN) * conv2_slab_floats(ks, Cout) : (size_t)nchunks * ks * ks * KC * cout_pad;
+        const size_t nw = wino4f ? (size_t)((Cin + 3) / 4) * (Cout / 64) * wino4f_slab_floats() : wino4 ? (size_t)36 * Cin * wino4_cout_pad(Cout) : wino ? (size_t)wino_chunks(wcfg, Cin) * (Cout / wino_cout_tile(wcfg)) * wino_slab_floats(wcfg) : v2 ? (size_t)nchunks * (cout_pad / BN) * conv2_slab_floats(ks, Cout) : (size_t)nchunks * ks * ks * KC * cout_pad;
         std::vector<float> hin(nin), hw(nw), hs(Cout, 1.f);
         uint32_t st = 12345;
         auto rnd = [&] { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
@@ -843,7 +863,8 @@ extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, i
         SIVO_HIP(hipEventCreate(&e0)); SIVO_HIP(hipEventCreate(&e1));
         float *dws = wino4 ? dev_alloc<float>(wino4_workspace_floats(w4group, Cin, Cout, H, W)) : nullptr;
         if (wino4) a.CoutPad = wino4_cout_pad(Cout);
-        auto go = [&] { if (wino4) launch_conv_wino4(a, dws, w4group, nullptr); else if (wino) launch_conv_wino(a, wcfg, nullptr); else if (v2) launch_conv2(a, ks, nullptr); else launch_conv(a, ks, nullptr); };
+        if (wino4f) a.CoutPad = Cout;
+        auto go = [&] { if (wino4f) launch_conv_wino4f(a, nullptr); else if (wino4) launch_conv_wino4(a, dws, w4group, nullptr); else if (wino) launch_conv_wino(a, wcfg, nullptr); else if (v2) launch_conv2(a, ks, nullptr); else launch_conv(a, ks, nullptr); };
         if (wino) a.CoutPad = Cout;
         for (int i = 0; i < 2; ++i) go();
         SIVO_HIP(hipEventRecord(e0, nullptr));

@@ -49,6 +49,12 @@ int wino4_cout_pad(int cout);
 void wino4_pack_weights(const float *W, int cin, int cout, std::vector<float> &out, int *cout_pad);
 int wino4_group(int N, int cin, int cout, int H, int W, size_t budget_bytes);
 size_t wino4_workspace_floats(int group, int cin, int cout, int H, int W);
+// fused Winograd F(4x4,3x3), 64 couts per workgroup (conv_wino4f.hip)
+bool wino4f_supported(int ks, int cin, int cout, int H, int W);
+int wino4f_slab_floats();
+void wino4f_pack_weights(const float *W, int cin, int cout, std::vector<float> &out, int *cout_pad);
+void launch_conv_wino4f(const ConvArgs &a, hipStream_t s);
+
 struct Wino4Plan {
     float *V, *M, *Vnext;    // disjoint buffers: this layer's transformed input, its GEMM output, the next layer's input
     bool skip_input;         // V was written by the previous layer's bridge

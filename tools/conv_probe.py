@@ -10,7 +10,7 @@ SHAPES = {"conv4_2": (12, 512, 512, 44, 128), "conv5_2": (12, 512, 512, 22, 64),
           "conv2_2_D": (12, 128, 128, 176, 512), "conv1_2_D": (12, 64, 64, 352, 1024), "conv3_2": (1, 256, 256, 88, 256),
           "conv4_1": (12, 256, 512, 44, 128), "conv4_1_D": (12, 512, 256, 44, 128),
           "conv3_1_D": (12, 256, 128, 88, 256), "conv2_1_D": (12, 128, 64, 176, 512), "conv3_1": (1, 128, 256, 88, 256)}
-VARIANTS = {64: "wino F(2x2)", 512: "wino4 F(4x4)"}
+VARIANTS = {64: "wino F(2x2)", 512: "wino4 F(4x4)", 1024: "fused F(4x4)"}
 
 def run(name, variant, iters=10):
     N, ci, co, H, W = SHAPES[name]
