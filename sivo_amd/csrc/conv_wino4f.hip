@@ -7,8 +7,8 @@
 //
 //   workgroup = 12 waves = 2 m-tiles (16 horizontally adjacent 4x4-output tiles each: 4 rows x 64 px) x 6 transform
 //   rows; 64 couts.  Wave (mt, i), lane (tile li, channel c0 + lk):
-//     * reads the 3-4 raw patch rows that row i of B^T touches (b128 + b64 per row), forms t = (B^T d)[i][0..5] and
-//       V[i][0..5] = t B in registers (~35 VALU ops) — exactly the A operands of positions (i, 0..5);
+//     * reads the 3-4 raw patch rows that row i of B^T touches (b128 + b64 per row, one row live at a time), forms
+//       t = (B^T d)[i][0..5] and V[i][0..5] = t B in registers (~40 VALU ops) — the A operands of positions (i, 0..5);
 //     * B operand of position (i, j): ONE ds_read_b128 gives the four 16-cout blocks (slab is stored [position]
 //       [channel][cout%16][cout/16]);  acc[6][4] = 96 accumulator VGPRs, 24 MFMAs per 4-channel step;
 //     * after the channel loop A^T M A is split the same way: the column half (over j) is lane-local, the row half
@@ -195,39 +195,30 @@ __global__ __launch_bounds__(F_NTHR, 1) void conv_wino4f_kernel(ConvArgs a) {
     const int a_base = lk * F_CS + (4 * mt) * F_PC + 4 * li;
     const int b_base = F_PATCH + (wi * 6 * 4 + lk) * 64 + li * 4;        // position (wi, j): + j * 256
 
+    // row wi of B^T (wave-uniform)
+    float bt_row[6];
+    {
+        const float BT[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                                {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+#pragma unroll
+        for (int r = 0; r < 6; ++r) bt_row[r] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(BT[wi][r])));
+    }
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int cur = chunk & 1;
         const bool more = chunk + 1 < nchunks;
         if (more) { issue_patch(chunk + 1); dma_weights(chunk + 1, cur ^ 1); }
         const float *sp = lds + cur * F_BUF;
         // ---- row wi of B^T d, then the row transform: V[j] = (B^T d B)[wi][j]
-        float t[6];
-        auto row = [&](int r, float *d) {
-            const f32x4 q = *reinterpret_cast<const f32x4 *>(sp + a_base + r * F_PC);
-            const float2 e = *reinterpret_cast<const float2 *>(sp + a_base + r * F_PC + 4);
-            d[0] = q[0]; d[1] = q[1]; d[2] = q[2]; d[3] = q[3]; d[4] = e.x; d[5] = e.y;
-        };
-        if (wi == 0) {
-            float d0[6], d2[6], d4[6];
-            row(0, d0); row(2, d2); row(4, d4);
+        // (one raw row live at a time: t += B^T[wi][r] * d_r with a wave-uniform coefficient, zero rows skipped)
+        float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 6; ++j) t[j] = 4.f * d0[j] - 5.f * d2[j] + d4[j];
-        } else if (wi == 5) {
-            float d1[6], d3[6], d5[6];
-            row(1, d1); row(3, d3); row(5, d5);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) t[j] = 4.f * d1[j] - 5.f * d3[j] + d5[j];
-        } else {
-            float d1[6], d2[6], d3[6], d4[6];
-            row(1, d1); row(2, d2); row(3, d3); row(4, d4);
-            if (wi <= 2) {
-                const float sgn = wi == 1 ? 1.f : -1.f;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) t[j] = (d4[j] - 4.f * d2[j]) + sgn * (d3[j] - 4.f * d1[j]);
-            } else {
-                const float sgn = wi == 3 ? 2.f : -2.f;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) t[j] = (d4[j] - d2[j]) + sgn * (d3[j] - d1[j]);
+        for (int r = 0; r < 6; ++r) {
+            const float c = bt_row[r];
+            if (c != 0.f) {
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(sp + a_base + r * F_PC);
+                const float2 e = *reinterpret_cast<const float2 *>(sp + a_base + r * F_PC + 4);
+                t[0] = __builtin_fmaf(c, q[0], t[0]); t[1] = __builtin_fmaf(c, q[1], t[1]); t[2] = __builtin_fmaf(c, q[2], t[2]);
+                t[3] = __builtin_fmaf(c, q[3], t[3]); t[4] = __builtin_fmaf(c, e.x, t[4]); t[5] = __builtin_fmaf(c, e.y, t[5]);
             }
         }
         float V[6];
