@@ -255,7 +255,10 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             op.kind = OP_CONV; op.in = bi; op.ks = L.kernel_size; op.cin = b.C; op.cout = L.num_output;
             op.out = new_blob(S, L.top[0], L.num_output, b.H, b.W, b.shared);
             const size_t nw = (size_t)op.cout * op.cin * op.ks * op.ks;
-            upload_conv(S, op, weights + woff, weights + woff + nw, b.H, b.W, /*keep_ties=*/b.shared);
+            bool keep_ties = b.shared;
+            if (const char *extra = std::getenv("SIVO_KEEP_TIES_LAYERS"))        // comma-separated layer names (experiments)
+                keep_ties = keep_ties || ("," + std::string(extra) + ",").find("," + L.name + ",") != std::string::npos;
+            upload_conv(S, op, weights + woff, weights + woff + nw, b.H, b.W, keep_ties);
             woff += nw + op.cout;
             op.flops = 2.0 * op.ks * op.ks * op.cin * op.cout * (double)b.H * b.W;
             op.name = L.name;
