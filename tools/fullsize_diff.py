@@ -8,16 +8,17 @@ from oracle import oracle, prototxt as oproto
 from sivo_amd import netspec, weights as wts
 from sivo_amd.segnet import BayesianSegNet
 kind = sys.argv[1] if len(sys.argv) > 1 else "standard"
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 2024
 T, H, W = 2, 352, 1024
 text = netspec.basic_prototxt(T, H, W) if kind == "basic" else netspec.standard_prototxt(T, H, W)
 net = oproto.parse(text); w = wts.synth_weights(net["layers"], 42)
 sn = BayesianSegNet(prototxt=text, weights=wts.pack(net["layers"], w), T=T)
 img = np.load(os.path.join(ROOT, "tests/golden/frame_bgr_352x1024.npy"))[:H, :W].copy()
-ob = oracle.run_net(net, w, oracle.preprocess(img, T, H, W), 2024)
-_, logits, _ = sn.forward(torch.from_numpy(img).cuda(), 2024, want_logits=True)
+ob = oracle.run_net(net, w, oracle.preprocess(img, T, H, W), SEED)
+_, logits, _ = sn.forward(torch.from_numpy(img).cuda(), SEED, want_logits=True)
 torch.cuda.synchronize()
 name = "dense_softmax_inner_prod" if kind == "basic" else "conv1_1_D"
-prob_sum, _, _ = sn.forward(torch.from_numpy(img).cuda(), 2024)
+prob_sum, _, _ = sn.forward(torch.from_numpy(img).cuda(), SEED)
 cls, conf, ent = sn.finalize(prob_sum)
 mean = oracle.mc_mean(ob["__last__"]); cls_o, conf_o, ent_o = oracle.mc_finalize(mean)
 cls = cls.cpu().numpy(); ent = ent.cpu().numpy()
