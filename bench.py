@@ -275,8 +275,11 @@ def main():
             # HBM bytes per launch of the dominant kernel from the committed PMC passes (bench cannot collect PMC itself)
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                hits = [v for k, v in tj.items() if k.split("<")[0] == dom_name.split("<")[0] and isinstance(v, dict) and v.get("bytes")]
                 if dom_name in tj and tj[dom_name].get("bytes"):
-                    traffic, traffic_file = tj[dom_name]["bytes"], "profiles/" + cand
+                    hits = [tj[dom_name]]
+                if hits:      # template instances of one kernel: the one with the most dispatches
+                    traffic, traffic_file = max(hits, key=lambda v: v.get("dispatches", 0))["bytes"], "profiles/" + cand
                     break
             except Exception:
                 pass

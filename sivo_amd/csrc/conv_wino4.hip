@@ -168,14 +168,21 @@ __global__ __launch_bounds__(W4_TIN) void wino4_input_kernel(Wino4Args a) {
 // ---------------------------------------------------------------------------------------------------
 // batched GEMM  M_xi[k][p] = sum_c U_xi[c][k] * V_xi[c][p]
 // ---------------------------------------------------------------------------------------------------
-constexpr int G_BM = 128, G_BN = 128, G_KC = 16;          // tiles x couts x channels per stage
-constexpr int G_STAGE = G_KC * (G_BM + G_BN);             // floats per LDS stage (16 KB)
+constexpr int G_BM = 128, G_BN = 128, G_KC = 16;          // largest tile: tiles x couts x channels per stage (Pp, Kp are padded to these)
+constexpr int G_STAGE = G_KC * (G_BM + G_BN);             // floats per LDS stage of the largest tile (16 KB)
 
-// Stage rows are 128 floats (a multiple of the 32 banks): the four k-rows a wave reads together would collide, so
+// Workgroup tile BM tiles x BN couts (128x128, 64x128 or 64x64: the smaller ones keep the CUs busy when a launch has
+// few tiles — the 22x64 layers, or one or two samples per GPU), 4 waves as 2 x 2, wave tile (BM/2) x (BN/2).
+// Stage rows are BM / BN floats (multiples of the 32 banks): the four k-rows a wave reads together would collide, so
 // row c stores its 16-float groups XOR-swizzled by (c & 1): even rows as they are, odd rows with neighbouring
 // groups exchanged.  LDS-DMA fixes the destination (wave base + lane * 16 B), so the swizzle is applied to the SOURCE.
+template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void wino4_gemm_kernel(Wino4Args a, int ptiles, int ktiles) {
     extern __shared__ float lds[];
+    constexpr int TM = BM / 2, TN = BN / 2, MTF = TM / 16, NTF = TN / 16;     // fragments per lane: 4 or 2
+    constexpr int STAGE = G_KC * (BM + BN);
+    constexpr int NV = BM / 16, NU = BN / 16;           // 1 KiB DMA instructions per stage for the V / U part
+    static_assert((NV + NU) % 4 == 0, "whole DMA instructions per wave");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int wm = wave & 1, wn = wave >> 1;
@@ -185,67 +192,72 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_kernel(Wino4Args a, int pti
     const int kt = j % ktiles, pair = (j / ktiles) * 8 + xcd;
     if (pair >= 36 * ptiles) return;
     const int xi = pair / ptiles, pt = pair % ptiles;
-    const float *Vg = a.V + ((int64_t)xi * a.C) * a.Pp + (int64_t)pt * G_BM;
-    const float *Ug = a.U + ((int64_t)xi * a.C) * a.Kp + (int64_t)kt * G_BN;
+    const float *Vg = a.V + ((int64_t)xi * a.C) * a.Pp + (int64_t)pt * BM;
+    const float *Ug = a.U + ((int64_t)xi * a.C) * a.Kp + (int64_t)kt * BN;
 
-    // DMA: a stage = 16 V rows (512 B each) then 16 U rows; one instruction = 1 KB = two rows; 16 instructions per
-    // stage, 4 per wave.  Lane -> (row within the pair, 16-byte chunk); logical chunk = physical ^ (4 * (row & 1)).
-    const int d_row = lane >> 5, d_chunk = lane & 31;
+    // DMA: a stage = 16 V rows then 16 U rows; one instruction = 1 KiB = 256 / L rows of L floats.
+    // Lane -> (row within the instruction, 16-byte chunk); logical chunk = physical ^ (4 * (row & 1)).
     auto dma = [&](int chunk, int buf) {
-        float *dstb = lds + buf * G_STAGE;
+        float *dstb = lds + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int inst = wave * 4 + i;               // 0..15: 0..7 -> V rows 2*inst, 2*inst+1; 8..15 -> U rows
-            const bool isU = inst >= 8;
-            const int row = ((inst & 7) << 1) + d_row;
-            const int lchunk = d_chunk ^ ((row & 1) << 2);
+        for (int i = 0; i < (NV + NU) / 4; ++i) {
+            const int inst = wave * ((NV + NU) / 4) + i;
+            const bool isU = inst >= NV;
+            const int L4 = (isU ? BN : BM) / 4;                  // 16-byte chunks per row
+            const int il = isU ? inst - NV : inst;
+            const int row = il * (64 / L4) + lane / L4, ch = lane % L4;
+            const int lchunk = ch ^ ((row & 1) << 2);
             const float *src = (isU ? Ug + (int64_t)(chunk * G_KC + row) * a.Kp : Vg + (int64_t)(chunk * G_KC + row) * a.Pp) + lchunk * 4;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(dstb + inst * 256), 16, 0, 0);
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[MTF][NTF];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MTF; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NTF; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = a.C / G_KC;
     dma(0, 0);
     __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
     __syncthreads();
     const int sw = (lk & 1) << 4;            // swizzle of this lane's k-row (c = 4*step + lk)
-    // MFMA block mt takes the tiles {4*i + mt}, block nt the couts {4*j + nt} of the wave's 64 x 64 sub-tile: the four A
-    // (B) fragments of a lane are then 4 consecutive floats of a stage row — ONE ds_read_b128 each instead of 4 b32.
-    const int a_off = (wm * 64 + 4 * li) ^ sw, b_off = (wn * 64 + 4 * li) ^ sw;
+    // MFMA block mt takes the tiles {MTF*i + mt}, block nt the couts {NTF*j + nt} of the wave's sub-tile: the A (B)
+    // fragments of a lane are then MTF (NTF) consecutive floats of a stage row — ONE ds_read_b128 / b64 each.
+    const int a_off = (wm * TM + MTF * li) ^ sw, b_off = (wn * TN + NTF * li) ^ sw;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int cur = chunk & 1;
         if (chunk + 1 < nchunks) dma(chunk + 1, cur ^ 1);
-        const float *Vs = lds + cur * G_STAGE, *Us = Vs + G_KC * G_BM;
+        const float *Vs = lds + cur * STAGE, *Us = Vs + G_KC * BM;
 #pragma unroll
         for (int s = 0; s < G_KC / 4; ++s) {
-            const int rowoff = (4 * s + lk) * 128;
-            const f32x4 af = *reinterpret_cast<const f32x4 *>(Vs + rowoff + a_off);
-            const f32x4 bf = *reinterpret_cast<const f32x4 *>(Us + rowoff + b_off);
+            float af[MTF], bf[NTF];
+            if (MTF == 4) { const f32x4 q = *reinterpret_cast<const f32x4 *>(Vs + (4 * s + lk) * BM + a_off); af[0] = q[0]; af[1] = q[1]; af[MTF - 2] = q[2]; af[MTF - 1] = q[3]; }
+            else { const float2 q = *reinterpret_cast<const float2 *>(Vs + (4 * s + lk) * BM + a_off); af[0] = q.x; af[1] = q.y; }
+            if (NTF == 4) { const f32x4 q = *reinterpret_cast<const f32x4 *>(Us + (4 * s + lk) * BN + b_off); bf[0] = q[0]; bf[1] = q[1]; bf[NTF - 2] = q[2]; bf[NTF - 1] = q[3]; }
+            else { const float2 q = *reinterpret_cast<const float2 *>(Us + (4 * s + lk) * BN + b_off); bf[0] = q.x; bf[1] = q.y; }
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MTF; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                for (int nt = 0; nt < NTF; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
         }
         __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
     }
-    // acc[mt][nt][r] = M[tile p0 + wm*64 + 4*(4*lk + r) + mt][cout k0 + wn*64 + 4*li + nt]: per cout a lane owns the 16
-    // consecutive tiles 16*lk .. 16*lk+15, four float4 stores; the four lk lanes of a cout write 256 contiguous bytes.
-    float *Mg = a.M + ((int64_t)xi * a.Kp + (int64_t)kt * G_BN) * a.Pp + (int64_t)pt * G_BM;
+    // acc[mt][nt][r] = M[tile p0 + wm*TM + MTF*(4*lk + r) + mt][cout k0 + wn*TN + NTF*li + nt]: per cout a lane owns the
+    // 4*MTF consecutive tiles from 4*MTF*lk, MTF floats per store; the four lk lanes of a cout write 64*MTF contiguous bytes.
+    float *Mg = a.M + ((int64_t)xi * a.Kp + (int64_t)kt * BN) * a.Pp + (int64_t)pt * BM;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        float *row = Mg + (int64_t)(wn * 64 + 4 * li + nt) * a.Pp + wm * 64 + 16 * lk;
+    for (int nt = 0; nt < NTF; ++nt) {
+        float *row = Mg + (int64_t)(wn * TN + NTF * li + nt) * a.Pp + wm * TM + 4 * MTF * lk;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<f32x4 *>(row + 4 * r) = f32x4{acc[0][nt][r], acc[1][nt][r], acc[2][nt][r], acc[3][nt][r]};
+        for (int r = 0; r < 4; ++r) {
+            if (MTF == 4) *reinterpret_cast<f32x4 *>(row + 4 * r) = f32x4{acc[0][nt][r], acc[1][nt][r], acc[MTF - 2][nt][r], acc[MTF - 1][nt][r]};
+            else *reinterpret_cast<float2 *>(row + 2 * r) = make_float2(acc[0][nt][r], acc[1][nt][r]);
+        }
     }
 }
 
@@ -441,7 +453,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
                        const Wino4Plan *plan) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_STAGE * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_kernel<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_STAGE * 4);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_bridge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
@@ -462,7 +474,6 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         a.sample0 = c.sample0 + n0;
         a.V = plan ? plan->V : workspace;
         a.M = plan ? plan->M : workspace + (size_t)36 * a.C * a.Pp;
-        const int ptiles = a.Pp / G_BM, ktiles = a.Kp / G_BN;
         const unsigned pblocks = (unsigned)((a.P + W4_TIN - 1) / W4_TIN);
         hipEvent_t *e = ev ? ev + 4 * (n0 / group) : nullptr;
         if (e && !gemm_only_events) (void)hipEventRecord(e[0], s);
@@ -471,8 +482,19 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
             else hipLaunchKernelGGL(wino4_input_kernel<false>, dim3(pblocks, (unsigned)a.C), dim3(W4_TIN), 0, s, a);
         }
         if (e) (void)hipEventRecord(e[1], s);
-        const int pairs8 = (36 * ptiles + 7) / 8;
-        hipLaunchKernelGGL(wino4_gemm_kernel, dim3((unsigned)(pairs8 * ktiles * 8)), dim3(256), 2 * G_STAGE * 4, s, a, ptiles, ktiles);
+        // tile choice: the largest one that still gives every CU ~4 workgroups (256 CUs; SIVO_WINO4_TILE forces 0/1/2)
+        static const int force_tile = std::getenv("SIVO_WINO4_TILE") ? std::atoi(std::getenv("SIVO_WINO4_TILE")) : -1;
+        auto nblocks = [&](int bm, int bn) { return (int64_t)36 * ((a.P + bm - 1) / bm) * (a.Kp / bn); };
+        static const int min_blocks = std::getenv("SIVO_WINO4_MINBLOCKS") ? std::atoi(std::getenv("SIVO_WINO4_MINBLOCKS")) : 1024;
+        int tile = nblocks(128, 128) >= min_blocks ? 0 : nblocks(64, 128) >= min_blocks ? 1 : 2;
+        if (force_tile >= 0) tile = force_tile;
+        const int bm = tile == 0 ? 128 : 64, bn = tile == 2 ? 64 : 128;
+        const int pt_n = (a.P + bm - 1) / bm, kt_n = a.Kp / bn, pairs8 = (36 * pt_n + 7) / 8;
+        const dim3 ggrid((unsigned)(pairs8 * kt_n * 8));
+        const size_t glds = (size_t)2 * G_KC * (bm + bn) * 4;
+        if (tile == 0) hipLaunchKernelGGL((wino4_gemm_kernel<128, 128>), ggrid, dim3(256), glds, s, a, pt_n, kt_n);
+        else if (tile == 1) hipLaunchKernelGGL((wino4_gemm_kernel<64, 128>), ggrid, dim3(256), glds, s, a, pt_n, kt_n);
+        else hipLaunchKernelGGL((wino4_gemm_kernel<64, 64>), ggrid, dim3(256), glds, s, a, pt_n, kt_n);
         if (e) (void)hipEventRecord(e[2], s);
         if (plan && plan->bridge) {
             const int ntile = a.th * a.tw;
