@@ -126,7 +126,6 @@ def main():
     from sivo_amd import netspec, orb, parallel, weights as wts
     from sivo_amd._lib import require_gpu
     from sivo_amd.segnet import BayesianSegNet
-    from oracle import prototxt as oproto    # used only to size the synthetic weights + cpu_baseline leg
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -152,7 +151,7 @@ def main():
     sample0, n_local = parallel.shard_samples(T, world, rank)
     t_alloc = max(2, parallel.max_shard(T, world))
     text = (netspec.standard_prototxt if args.net == "standard" else netspec.basic_prototxt)(t_alloc, H, W)
-    layers = oproto.parse(text)["layers"]
+    layers = netspec.parse_layers(text)        # (the oracle is imported by the cpu_baseline leg only)
     w = wts.synth_weights(layers, 42)
     sn = BayesianSegNet(prototxt=text, weights=wts.pack(layers, w), T=t_alloc, device=local)
 

@@ -119,3 +119,29 @@ def tiny_prototxt(T, H=32, W=64, classes=15):
     out.append(_conv("cls", "d1", "cls", classes, 1, 0))
     out.append(_softmax("cls"))
     return "".join(out)
+
+
+def parse_layers(text):
+    """Layer list of a (generated or reference) prototxt: dicts with name / type / bottom / top / num_output /
+    kernel_size — what weights.param_shapes needs to size the parameter array.  The C++ reader in csrc/prototxt.cpp is
+    the one the library itself uses; this is its small Python twin for callers that prepare weights."""
+    import re
+    text = re.sub(r"#[^\n]*", "", text)
+    layers = []
+    i = 0
+    while True:
+        m = re.compile(r"\blayer\s*\{").search(text, i)
+        if not m:
+            break
+        depth, j = 1, m.end()
+        while depth and j < len(text):
+            depth += {"{": 1, "}": -1}.get(text[j], 0)
+            j += 1
+        body = text[m.end():j - 1]
+        get = lambda k: re.findall(rf'\b{k}\s*:\s*"?([^"\s]+)"?', body)
+        L = {"name": (get("name") or [""])[0], "type": (get("type") or [""])[0], "bottom": get("bottom"), "top": get("top")}
+        if get("num_output"): L["num_output"] = int(get("num_output")[0])
+        if get("kernel_size"): L["kernel_size"] = int(get("kernel_size")[0])
+        layers.append(L)
+        i = j
+    return layers

@@ -32,6 +32,24 @@ def test_netspec_reproduces_reference_graph(kind):
         assert _graph(oproto.parse(open(ref_path).read())) == gold["layers"]
 
 
+def test_netspec_layer_parser_agrees_with_the_oracle_parser():
+    """sivo_amd.netspec.parse_layers (what bench.py sizes the synthetic weights with, so that the product path never
+    imports oracle/) yields the same parameter shapes as the oracle's prototxt parser, on generated and reference text."""
+    texts = [netspec.standard_prototxt(12), netspec.basic_prototxt(6), netspec.tiny_prototxt(2)]
+    for kind in ("standard/kitti/bayesian_segnet_kitti", "basic/kitti/bayesian_segnet_basic_kitti"):
+        ref = f"/root/reference/config/bayesian_segnet/{kind}.prototxt"
+        if os.path.exists(ref):
+            texts.append(open(ref).read())
+    for text in texts:
+        assert wts.param_shapes(netspec.parse_layers(text)) == wts.param_shapes(oproto.parse(text)["layers"])
+
+
+def test_bench_imports_the_oracle_only_in_its_cpu_baseline_leg():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def main"):]
+    assert "oracle" not in re.sub(r"#.*", "", body).replace("cpu_baseline", "")
+
+
 def test_parameter_counts_match_reference_weight_files():
     """1,415,823 fp32 parameters for Basic (the 5,670,476-byte LFS object minus protobuf framing), SURVEY.md A.2."""
     n = C.c_size_t()
