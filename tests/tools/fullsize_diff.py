@@ -2,7 +2,7 @@
 """Where do full-size logits differ from the oracle?  Attributes the outliers to max-pool argmax flips."""
 import sys, os
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import oracle, prototxt as oproto
 from sivo_amd import netspec, weights as wts
