@@ -150,7 +150,7 @@ void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int 
     static const bool no_wino = std::getenv("SIVO_NO_WINOGRAD") != nullptr;
     // F(4x4,3x3) for the wide layers (4x fewer MFMA flops; costs ~2e-4 of the 1e-3 logit budget) — SIVO_NO_WINO4 disables
     static const bool no_wino4 = std::getenv("SIVO_NO_WINO4") != nullptr;
-    static const size_t wino4_budget = (size_t)(std::getenv("SIVO_WINO4_MB") ? std::atoi(std::getenv("SIVO_WINO4_MB")) : 2048) << 20;
+    static const size_t wino4_budget = (size_t)(std::getenv("SIVO_WINO4_MB") ? std::atoi(std::getenv("SIVO_WINO4_MB")) : 16384) << 20;
     // keep_ties: the layer belongs to the sample-invariant encoder prefix (conv1_1 .. conv3_3), whose outputs decide the
     // switches of pool1..pool3.  Over a flat image region (sky, saturated pixels) the four elements of a pooling window
     // are EXACTLY equal in the reference, which then takes the first; the direct and the F(2x2) kernels reproduce that (a
@@ -848,7 +848,7 @@ extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, i
         const int KC = v2 ? 4 : conv_k_chunk(ks, Cin), BN = conv_cout_tile(ks, Cout);
         const int cout_pad = cdiv(Cout, BN) * BN, nchunks = cdiv(Cin, KC);
         const size_t nin = (size_t)N * Cin * H * W, nout = (size_t)N * Cout * H * W;
-        const int w4group = wino4 ? wino4_group(N, Cin, Cout, H, W, (size_t)(std::getenv("SIVO_WINO4_MB") ? std::atoi(std::getenv("SIVO_WINO4_MB")) : 2048) << 20) : 0;
+        const int w4group = wino4 ? wino4_group(N, Cin, Cout, H, W, (size_t)(std::getenv("SIVO_WINO4_MB") ? std::atoi(std::getenv("SIVO_WINO4_MB")) : 16384) << 20) : 0;
         const size_t nw = wino4f ? (size_t)((Cin + 3) / 4) * (Cout / 64) * wino4f_slab_floats() : wino4 ? (size_t)36 * Cin * wino4_cout_pad(Cout) : wino ? (size_t)wino_chunks(wcfg, Cin) * (Cout / wino_cout_tile(wcfg)) * wino_slab_floats(wcfg) : v2 ? (size_t)nchunks * (cout_pad / BN) * conv2_slab_floats(ks, Cout) : (size_t)nchunks * ks * ks * KC * cout_pad;
         std::vector<float> hin(nin), hw(nw), hs(Cout, 1.f);
         uint32_t st = 12345;
