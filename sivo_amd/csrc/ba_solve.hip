@@ -474,7 +474,7 @@ __global__ __launch_bounds__(1024) void ba_maxdiag_kernel(BaDev d, int with_poin
     if (threadIdx.x == 0) d.scal[2] = s_m[0];
 }
 
-// (Hll + lambda I)^-1 per point, and Y_e = W_e Hll^-1 for the point's edges that touch a free pose
+// (Hll + lambda I)^-1 per point
 __global__ __launch_bounds__(BA_T) void ba_point_inverse_kernel(BaDev d, double lambda) {
     const int q = blockIdx.x * BA_T + threadIdx.x;
     if (q >= d.nX) return;
@@ -490,16 +490,23 @@ __global__ __launch_bounds__(BA_T) void ba_point_inverse_kernel(BaDev d, double 
     Ai[6] = c2 * id; Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id; Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
 #pragma unroll
     for (int i = 0; i < 9; ++i) d.Hinv[9 * (int64_t)q + i] = Ai[i];
-    for (int64_t i = d.pt_off[q]; i < d.pt_off[q + 1]; ++i) {
-        const int e = d.pt_edges[i];
-        if (d.level[e] || d.slot[d.edges[e].pose] < 0) continue;
-        const double *W = d.W + 18 * (int64_t)e;
-        double *Y = d.Y + 18 * (int64_t)e;
+}
+
+// Y_e = W_e Hll^-1 for every active edge that touches a free keyframe (one thread per edge)
+__global__ __launch_bounds__(BA_T) void ba_edge_y_kernel(BaDev d) {
+    const int64_t e = (int64_t)blockIdx.x * BA_T + threadIdx.x;
+    if (e >= d.nE || d.level[e]) return;
+    const SivoEdge ed = d.edges[e];
+    if (d.slot[ed.pose] < 0) return;
+    const double *W = d.W + 18 * e, *Ai = d.Hinv + 9 * (int64_t)ed.point;
+    double A9[9];
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
+    for (int i = 0; i < 9; ++i) A9[i] = Ai[i];
+    double *Y = d.Y + 18 * e;
 #pragma unroll
-            for (int b = 0; b < 3; ++b) Y[3 * a + b] = W[3 * a] * Ai[b] + W[3 * a + 1] * Ai[3 + b] + W[3 * a + 2] * Ai[6 + b];
-    }
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) Y[3 * a + b] = W[3 * a] * A9[b] + W[3 * a + 1] * A9[3 + b] + W[3 * a + 2] * A9[6 + b];
 }
 
 // S block (i, j), i <= j:  [i == j] (Hpp_i + lambda I)  -  sum_q Y_{e(i,q)} W_{e(j,q)}' ; rhs_i = bp_i - sum_q Y_{e(i,q)} bl_q
@@ -542,46 +549,105 @@ __global__ __launch_bounds__(BA_T) void ba_schur_kernel(BaDev d, double lambda) 
     if (i == j && threadIdx.x < 6) d.xs[6 * i + threadIdx.x] = d.bp[6 * i + threadIdx.x] - s_out[36 + threadIdx.x];
 }
 
-// dense Cholesky solve S x = xs in place (single workgroup; S is L2-resident); scal[3] = 1 on success
-__global__ __launch_bounds__(1024) void ba_dense_solve_kernel(BaDev d) {
+// dense Cholesky solve S x = xs (single workgroup); scal[3] = 1 on success.  The system is a grid of 6x6 keyframe blocks,
+// and the factorisation is blocked accordingly (factor the diagonal block, solve the panel, update the trailing
+// matrix: 3 barriers per keyframe instead of 3 per column), as are the two triangular solves.  LDS_COPY: the reduced
+// system of a local BA (<= 21 free keyframes: n <= 126, n*n*8 <= 127 KB) is factorised in LDS — the loop is a chain of
+// dependent steps, i.e. pure latency, and LDS answers ~20x faster than L2.
+constexpr int BA_SOLVE_T = 256;
+template <bool LDS_COPY>
+__global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_kernel(BaDev d) {
     __shared__ int s_ok;
-    __shared__ double s_piv;
-    const int n = 6 * d.nF, tid = threadIdx.x;
-    double *S = d.S, *x = d.xs;
+    __shared__ double s_x[6];
+    extern __shared__ double s_mat[];
+    const int nb = d.nF, n = 6 * nb, tid = threadIdx.x;
+    double *S = LDS_COPY ? s_mat : d.S, *x = d.xs;
+    if (LDS_COPY) {
+        for (int i = tid; i < n * n; i += BA_SOLVE_T) s_mat[i] = d.S[i];
+    }
     if (tid == 0) s_ok = 1;
     __syncthreads();
-    for (int j = 0; j < n; ++j) {
-        if (tid == 0) {
-            const double dj = S[(int64_t)j * n + j];
-            if (!(dj > 0.0)) s_ok = 0;
-            s_piv = sqrt(dj);
+    for (int jb = 0; jb < nb; ++jb) {
+        const int j0 = 6 * jb;
+        if (tid == 0) {                       // 6x6 Cholesky of the diagonal block, in place (lower)
+            for (int j = 0; j < 6 && s_ok; ++j) {
+                double dj = S[(int64_t)(j0 + j) * n + j0 + j];
+                for (int k = 0; k < j; ++k) dj -= S[(int64_t)(j0 + j) * n + j0 + k] * S[(int64_t)(j0 + j) * n + j0 + k];
+                if (!(dj > 0.0)) { s_ok = 0; break; }
+                dj = sqrt(dj);
+                S[(int64_t)(j0 + j) * n + j0 + j] = dj;
+                for (int i = j + 1; i < 6; ++i) {
+                    double v = S[(int64_t)(j0 + i) * n + j0 + j];
+                    for (int k = 0; k < j; ++k) v -= S[(int64_t)(j0 + i) * n + j0 + k] * S[(int64_t)(j0 + j) * n + j0 + k];
+                    S[(int64_t)(j0 + i) * n + j0 + j] = v / dj;
+                }
+            }
         }
         __syncthreads();
         if (!s_ok) break;
-        const double piv = s_piv;
-        for (int i = j + tid; i < n; i += 1024) S[(int64_t)i * n + j] = (i == j) ? piv : S[(int64_t)i * n + j] / piv;
+        // panel: rows below the block, L_ij = S_ij L_jj^-T (one row per thread, 6 unknowns)
+        for (int i = j0 + 6 + tid; i < n; i += BA_SOLVE_T) {
+            double r[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double v = S[(int64_t)i * n + j0 + c];
+                for (int k = 0; k < c; ++k) v -= r[k] * S[(int64_t)(j0 + c) * n + j0 + k];
+                r[c] = v / S[(int64_t)(j0 + c) * n + j0 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) S[(int64_t)i * n + j0 + c] = r[c];
+        }
         __syncthreads();
-        // trailing update of the lower triangle: rows i > j, columns j < k <= i
-        const int m = n - j - 1;
-        for (int idx = tid; idx < m * m; idx += 1024) {
-            const int i = j + 1 + idx / m, k = j + 1 + idx % m;
-            if (k <= i) S[(int64_t)i * n + k] -= S[(int64_t)i * n + j] * S[(int64_t)k * n + j];
+        // trailing update of the lower triangle: rows i >= j0 + 6, columns j0 + 6 <= k <= i
+        const int m = n - j0 - 6;
+        for (int idx = tid; idx < m * m; idx += BA_SOLVE_T) {
+            const int i = j0 + 6 + idx / m, k = j0 + 6 + idx % m;
+            if (k <= i) {
+                double v = 0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v += S[(int64_t)i * n + j0 + c] * S[(int64_t)k * n + j0 + c];
+                S[(int64_t)i * n + k] -= v;
+            }
         }
         __syncthreads();
     }
     if (s_ok) {
-        for (int j = 0; j < n; ++j) {          // L y = b
-            if (tid == 0) x[j] /= S[(int64_t)j * n + j];
+        for (int jb = 0; jb < nb; ++jb) {          // L y = b, one keyframe block per step
+            const int j0 = 6 * jb;
+            if (tid == 0) {
+                for (int c = 0; c < 6; ++c) {
+                    double v = x[j0 + c];
+                    for (int k = 0; k < c; ++k) v -= S[(int64_t)(j0 + c) * n + j0 + k] * s_x[k];
+                    s_x[c] = v / S[(int64_t)(j0 + c) * n + j0 + c];
+                    x[j0 + c] = s_x[c];
+                }
+            }
             __syncthreads();
-            const double xj = x[j];
-            for (int i = j + 1 + tid; i < n; i += 1024) x[i] -= S[(int64_t)i * n + j] * xj;
+            for (int i = j0 + 6 + tid; i < n; i += BA_SOLVE_T) {
+                double v = x[i];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v -= S[(int64_t)i * n + j0 + c] * s_x[c];
+                x[i] = v;
+            }
             __syncthreads();
         }
-        for (int j = n - 1; j >= 0; --j) {     // L' x = y
-            if (tid == 0) x[j] /= S[(int64_t)j * n + j];
+        for (int jb = nb - 1; jb >= 0; --jb) {     // L' x = y
+            const int j0 = 6 * jb;
+            if (tid == 0) {
+                for (int c = 5; c >= 0; --c) {
+                    double v = x[j0 + c];
+                    for (int k = c + 1; k < 6; ++k) v -= S[(int64_t)(j0 + k) * n + j0 + c] * s_x[k];
+                    s_x[c] = v / S[(int64_t)(j0 + c) * n + j0 + c];
+                    x[j0 + c] = s_x[c];
+                }
+            }
             __syncthreads();
-            const double xj = x[j];
-            for (int i = tid; i < j; i += 1024) x[i] -= S[(int64_t)j * n + i] * xj;
+            for (int i = tid; i < j0; i += BA_SOLVE_T) {
+                double v = x[i];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v -= S[(int64_t)(j0 + c) * n + i] * s_x[c];
+                x[i] = v;
+            }
             __syncthreads();
         }
     }
@@ -668,10 +734,33 @@ __global__ __launch_bounds__(BA_T) void ba_classify_kernel(BaDev d, const double
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// Per-thread, grow-only device arena: a solver call makes ~30 allocations; hipMalloc / hipFree each cost tens of
+// microseconds and hipFree synchronises the device, which is most of a 10 ms LocalBundleAdjustment.  Chunks are kept
+// between calls (PoseOptimization runs every frame on the tracking thread, LocalBundleAdjustment on the mapping
+// thread: one arena each) and released when the thread exits.
+struct BaArena {
+    struct Chunk { char *p; size_t cap, used; int device; };
+    std::vector<Chunk> chunks;
+    ~BaArena() { for (Chunk &c : chunks) (void)hipFree(c.p); }
+    void reset() { for (Chunk &c : chunks) c.used = 0; }
+    void *take(size_t bytes) {
+        bytes = (bytes + 255) / 256 * 256;
+        int dev = 0;
+        SIVO_HIP(hipGetDevice(&dev));
+        for (Chunk &c : chunks)
+            if (c.device == dev && c.cap - c.used >= bytes) { void *r = c.p + c.used; c.used += bytes; return r; }
+        Chunk c{nullptr, std::max(bytes, (size_t)64 << 20), 0, dev};
+        SIVO_HIP(hipMalloc((void **)&c.p, c.cap));
+        c.used = bytes;
+        chunks.push_back(c);
+        return c.p;
+    }
+};
+static thread_local BaArena t_arena;
+
 struct Buf {
     void *p = nullptr;
-    ~Buf() { if (p) (void)hipFree(p); }
-    void alloc(size_t bytes) { SIVO_HIP(hipMalloc(&p, bytes ? bytes : 8)); }
+    void alloc(size_t bytes) { p = t_arena.take(bytes ? bytes : 8); }
     void upload(const void *src, size_t bytes) { alloc(bytes); if (bytes) SIVO_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice)); }
     void zero(size_t bytes) { alloc(bytes); SIVO_HIP(hipMemset(p, 0, bytes ? bytes : 8)); }
     template <class T> T *as() const { return (T *)p; }
@@ -779,11 +868,18 @@ class BaSolver {
                 if (nF_) {
                     if (landmarks) {
                         hipLaunchKernelGGL(ba_point_inverse_kernel, dim3(gX), dim3(BA_T), 0, 0, d_, lambda);
+                        if (nE_) hipLaunchKernelGGL(ba_edge_y_kernel, dim3(gE), dim3(BA_T), 0, 0, d_);
                         hipLaunchKernelGGL(ba_schur_kernel, dim3((unsigned)(nF_ * (nF_ + 1) / 2)), dim3(BA_T), 0, 0, d_, lambda);
                     } else {
                         hipLaunchKernelGGL(ba_pose_only_system_kernel, dim3(64), dim3(256), 0, 0, d_, lambda);
                     }
-                    hipLaunchKernelGGL(ba_dense_solve_kernel, dim3(1), dim3(1024), 0, 0, d_);
+                    if (6 * nF_ <= 126) {
+                        static bool attr = false;
+                        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ba_dense_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 126 * 126 * 8); attr = true; }
+                        hipLaunchKernelGGL(ba_dense_solve_kernel<true>, dim3(1), dim3(BA_SOLVE_T), (size_t)36 * nF_ * nF_ * 8, 0, d_);
+                    } else {
+                        hipLaunchKernelGGL(ba_dense_solve_kernel<false>, dim3(1), dim3(BA_SOLVE_T), 0, 0, d_);
+                    }
                 } else {
                     if (landmarks) hipLaunchKernelGGL(ba_point_inverse_kernel, dim3(gX), dim3(BA_T), 0, 0, d_, lambda);
                     const double one = 1.0;
@@ -871,6 +967,7 @@ extern "C" int sivo_ba_optimize(double *poses, const uint8_t *pose_fixed, int n_
         if (!poses || !intr || (n_edges && !edges) || (n_points && !points)) throw std::invalid_argument("null argument");
         if (iterations < 0) throw std::invalid_argument("negative iteration count");
         need_gpu();
+        t_arena.reset();
         BaSolver s(poses, pose_fixed, n_poses, points, n_points, false, edges, n_edges, intr, delta_mono, delta_stereo);
         s.set_flags(level, robust);
         int tr = 0;
@@ -894,6 +991,7 @@ extern "C" int sivo_local_ba(double *poses, const uint8_t *pose_fixed, int n_pos
         if (cov_ok) *cov_ok = 0;
         if (outlier && n_edges) std::memset(outlier, 0, (size_t)n_edges);
         if (stop_flag && *stop_flag) return SIVO_OK;                         // :757-761
+        t_arena.reset();
         BaSolver s(poses, pose_fixed, n_poses, points, n_points, false, edges, n_edges, intr,
                    (double)std::sqrt(5.991f), (double)std::sqrt(7.815f));      // const float thHuber = sqrt(5.991f) (:646-647)
         int tr = 0;
@@ -933,6 +1031,7 @@ extern "C" int sivo_pose_optimize(const double pose0[12], const double *points, 
             return SIVO_OK;
         }
         need_gpu();
+        t_arena.reset();
         Buf dP, dX, dE, dOut, dErr, dPose, dCov, dChi, dInfo;
         dP.upload(pose0, 96); dX.upload(points, (size_t)n_points * 24); dE.upload(edges, (size_t)n_edges * sizeof(SivoEdge));
         dOut.zero((size_t)n_edges); dErr.zero((size_t)n_edges * 24); dPose.alloc(96); dCov.alloc(288);

@@ -61,6 +61,18 @@ def test_ba_optimize_levels_kernels_and_degenerate_graphs(oracle):
         optimizer.ba_optimize(P0, fixed, X0, dup, intr, 1)
 
 
+def test_ba_optimize_more_than_21_free_keyframes(oracle):
+    """28 free keyframes: the reduced system (168 x 168) no longer fits the LDS-resident Cholesky and takes the
+    global-memory path of the same blocked solver."""
+    poses, pts, edges, intr = make_ba_scene(seed=12, n_kf=30, n_pts=400)
+    P0, fixed, X0 = _start(poses, pts, 2, 5)
+    g = optimizer.ba_optimize(P0, fixed, X0, edges, intr, 3)
+    o = oracle.ba_optimize(P0, fixed, X0, edges, intr, 3)
+    assert (g["iterations"], g["trials"]) == (o["iterations"], o["trials"])
+    np.testing.assert_allclose(g["poses"], o["poses"], atol=1e-9, rtol=0)
+    np.testing.assert_allclose(g["points"], o["points"], atol=1e-8, rtol=0)
+
+
 def test_local_ba_config5_matches_oracle(oracle):
     """20 keyframes x 3000 map points (~36 k edges), the first two keyframes fixed."""
     poses, pts, edges, intr = make_ba_scene()
