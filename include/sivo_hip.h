@@ -141,7 +141,8 @@ typedef struct {
     int32_t pad_;
 } SivoOpProfile;
 /* enable: 0 off; 1 on; 2 on + reset the accumulators; 3 like 2 but only the MFMA kernels are bracketed (convolution
- * kernels and the F(4x4,3x3) GEMM): a handful of events per forward, for timing inside a throughput run. */
+ * kernels and the F(4x4,3x3) GEMM): a handful of events per forward, for timing inside a throughput run; 4 like 3
+ * without the reset (to profile a subset of the frames of a run). */
 int sivo_segnet_profile(sivo_segnet_t h, int enable);
 int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int capacity, int *n_out);
 

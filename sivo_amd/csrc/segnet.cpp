@@ -774,8 +774,8 @@ extern "C" int sivo_segnet_profile(sivo_segnet_t h, int enable) {
         DeviceGuard dg(h->device);
         if (h->profile) harvest(*h);
         h->profile = enable != 0;
-        h->profile_mfma_only = enable == 3;
-        if (enable >= 2)   // reset the accumulators
+        h->profile_mfma_only = enable == 3 || enable == 4;
+        if (enable == 2 || enable == 3)   // reset the accumulators
             for (Op &op : h->ops) {
                 op.ms_total = 0.0; op.launches = 0; op.w4_launches = 0;
                 op.w4_ms[0] = op.w4_ms[1] = op.w4_ms[2] = 0.0;

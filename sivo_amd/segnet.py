@@ -114,8 +114,9 @@ class BayesianSegNet:
 
     def profile(self, enable=True, reset=False, mfma_only=False):
         """Bracket every kernel of the forward with HIP events on its launch stream (mfma_only: just the convolution
-        kernels / the F(4x4,3x3) GEMM — a handful of events per forward, for use inside a timed run; implies reset)."""
-        check(lib().sivo_segnet_profile(self._h, 3 if (enable and mfma_only) else 2 if (enable and reset) else int(bool(enable))))
+        kernels / the F(4x4,3x3) GEMM — a handful of events per forward, for use inside a timed run)."""
+        mode = (3 if reset else 4) if (enable and mfma_only) else 2 if (enable and reset) else int(bool(enable))
+        check(lib().sivo_segnet_profile(self._h, mode))
 
     def profile_read(self):
         """List of dicts: layer, kernel, samples, launches (forward passes), kernel_launches, flops_per_sample,
