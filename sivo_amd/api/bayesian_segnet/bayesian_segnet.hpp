@@ -45,7 +45,7 @@ struct BayesianSegNetParams {
     /// throws std::runtime_error when it is false.
     bool use_gpu = true;
     std::string model_file;    ///< .prototxt
-    std::string weights_file;  ///< .sivow parameter container (sivo_amd/weights.py); a .caffemodel reader is future work
+    std::string weights_file;  ///< the trained .caffemodel (read directly) or a .sivow parameter container (sivo_amd/weights.py)
     /// Additions (defaults keep the reference behaviour): MC sample count when the prototxt leaves it
     /// blank, dropout seed (Caffe's RNG is unseeded in the reference), HIP device.
     int monte_carlo_samples = 0;

@@ -20,6 +20,7 @@
 #include "orbslam/ORBextractor.h"
 #include "orbslam/ORBmatcher.h"
 #include "orbslam/Optimizer.h"
+#include "orbslam/Frame.h"
 #include "kitti_io.hpp"
 
 static int failures = 0;
@@ -114,6 +115,59 @@ static int run_gpu(int argc, char **argv) {
     std::vector<cv::KeyPoint> none; cv::Mat nd, empty;
     left(empty, nomask, none, nd);                         // empty image: returns silently
     CHECK(none.empty());
+
+    // Frame (Frame.cc:85-181): grey left, right = left shifted by 8 px (disparity 8), the network on the colour frame.
+    // Results go to files; the Python test rebuilds the same frame through the Python binding and compares bit for bit.
+    {
+        cv::Mat grayR(rows, cols, CV_8UC1);
+        for (int r = 0; r < rows; ++r)
+            for (int c = 0; c < cols; ++c) grayR.at<unsigned char>(r, c) = gray.at<unsigned char>(r, c + 8 < cols ? c + 8 : cols - 1);
+        // the network of this test is smaller than the frame: segmentImage centre-crops, so the Frame is built on the crop
+        const int y0 = (rows - g.height) / 2, x0 = (cols - g.width) / 2;
+        cv::Mat cl(g.height, g.width, CV_8UC1), cr(g.height, g.width, CV_8UC1), cc(g.height, g.width, CV_8UC3);
+        for (int r = 0; r < g.height; ++r) {
+            std::memcpy(cl.ptr(r), gray.ptr(r + y0) + x0, (size_t)g.width);
+            std::memcpy(cr.ptr(r), grayR.ptr(r + y0) + x0, (size_t)g.width);
+            std::memcpy(cc.ptr(r), bgr.ptr(r + y0) + 3 * x0, (size_t)g.width * 3);
+        }
+        SIVO::ORBextractor fl(500, 1.2f, 1, 20, 7), fr(500, 1.2f, 1, 20, 7);     // one level: the 64-row crop holds no second one
+        {   // errors inside the worker threads come back as exceptions of the constructor
+            SIVO::ORBextractor bl(500, 1.2f, 4, 20, 7), br(500, 1.2f, 4, 20, 7);
+            SIVO::BayesianSegNetParams p3(proto, weights);
+            SIVO::BayesianSegNet seg3(p3);
+            bool threw2 = false;
+            try { SIVO::Frame bad(cl, cc, cr, 0.0, &bl, &br, &seg3, 718.856f, 718.856f, 64.f, 32.f, 386.1448f, 40.f); } catch (const std::runtime_error &) { threw2 = true; }
+            CHECK(threw2);
+        }
+        SIVO::BayesianSegNetParams p2(proto, weights);
+        p2.seed = 7;
+        SIVO::BayesianSegNet seg2(p2);
+        SIVO::Frame F(cl, cc, cr, 0.0, &fl, &fr, &seg2, 718.856f, 718.856f, 0.5f * g.width, 0.5f * g.height, 386.1448f, 40.f);
+        CHECK(F.numSemanticKeys == (int)F.mvKeysSemantic.size() && F.mvRight.size() == F.mvKeysSemantic.size());
+        CHECK(F.mDescriptorsSemantic.rows == F.numSemanticKeys && F.mvDepth.size() == F.mvRight.size());
+        size_t in_grid = 0;
+        for (int i = 0; i < FRAME_GRID_COLS; ++i) for (int j = 0; j < FRAME_GRID_ROWS; ++j) in_grid += F.mGrid[i][j].size();
+        CHECK((int)in_grid == F.numSemanticKeys);
+        if (F.numSemanticKeys > 0) {
+            const cv::KeyPoint &k0 = F.mvKeysSemantic[0];
+            const std::vector<size_t> near = F.GetFeaturesInArea(k0.pt.x, k0.pt.y, 5.f);
+            bool found = false;
+            for (size_t i : near) found |= (i == 0);
+            CHECK(found);
+            // one-call ComputeStereoMatches on the semantic keys == what the constructor produced
+            std::vector<float> r0 = F.mvRight, d0 = F.mvDepth;
+            F.ComputeStereoMatches();
+            CHECK(r0.size() == F.mvRight.size() && std::memcmp(r0.data(), F.mvRight.data(), r0.size() * 4) == 0);
+            CHECK(std::memcmp(d0.data(), F.mvDepth.data(), d0.size() * 4) == 0);
+            float xyz[3];
+            for (size_t i = 0; i < F.mvDepth.size(); ++i)
+                if (F.mvDepth[i] > 0) { CHECK(F.UnprojectStereoCamera(i, xyz) && xyz[2] == F.mvDepth[i]); break; }
+        }
+        write_file(out + "/frame_keys.bin", F.mvKeysSemantic.data(), F.mvKeysSemantic.size() * sizeof(cv::KeyPoint));
+        write_file(out + "/frame_right.bin", F.mvRight.data(), F.mvRight.size() * 4);
+        write_file(out + "/frame_depth.bin", F.mvDepth.data(), F.mvDepth.size() * 4);
+        write_file(out + "/frame_classes.bin", F.mClasses.data(), (size_t)g.height * g.width);
+    }
 
     // matcher: every descriptor against itself + neighbours -> best = itself at distance 0
     SIVO::ORBmatcher matcher(0.9f, true);

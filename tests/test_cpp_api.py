@@ -54,3 +54,19 @@ def test_cpp_api_matches_python_binding(tmp_path, kitti_like_bgr):
     kps, desc = orb.ORBextractor()(np.ascontiguousarray(frame[..., 0]))
     assert np.fromfile(tmp_path / "kps.bin", orb.KP_DTYPE).tobytes() == kps.tobytes()
     assert np.array_equal(np.fromfile(tmp_path / "desc.bin", np.uint8).reshape(-1, 32), desc)
+    # SIVO::Frame: the same stereo frame rebuilt through the Python binding (centre crop, right = left shifted by 8 px,
+    # extractors (500, 1.2, 1, 20, 7), class <= TERRAIN filter, stereo matching on the kept keys)
+    g = frame[..., 0]
+    gR = np.concatenate([g[:, 8:], np.repeat(g[:, -1:], 8, axis=1)], axis=1)
+    y0, x0 = (frame.shape[0] - H) // 2, (frame.shape[1] - W) // 2
+    cl, cr = np.ascontiguousarray(g[y0:y0 + H, x0:x0 + W]), np.ascontiguousarray(gR[y0:y0 + H, x0:x0 + W])
+    cls2, _, _ = sn.segment_image(np.ascontiguousarray(frame[y0:y0 + H, x0:x0 + W]), seed=7)
+    assert np.array_equal(np.fromfile(tmp_path / "frame_classes.bin", np.uint8).reshape(H, W), cls2)
+    ex_l, ex_r = orb.ORBextractor(500, 1.2, 1, 20, 7), orb.ORBextractor(500, 1.2, 1, 20, 7)
+    kl, dl = ex_l(cl); kr, dr = ex_r(cr)
+    keep = cls2[kl["y"].astype(np.int32), kl["x"].astype(np.int32)] <= 8
+    uR, depth, _ = orb.stereo_match(ex_l, ex_r, kl[keep], dl[keep], kr, dr, 386.1448, 386.1448 / 718.856)
+    assert np.fromfile(tmp_path / "frame_keys.bin", orb.KP_DTYPE).tobytes() == kl[keep].tobytes()
+    assert np.array_equal(np.fromfile(tmp_path / "frame_right.bin", np.float32).view(np.uint32), uR.view(np.uint32))
+    assert np.array_equal(np.fromfile(tmp_path / "frame_depth.bin", np.float32).view(np.uint32), depth.view(np.uint32))
+    assert keep.sum() > 20
