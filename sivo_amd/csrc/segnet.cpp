@@ -98,7 +98,13 @@ struct sivo_segnet {
     bool profile = false, pending = false;
     bool profile_mfma_only = false;   // bracket only the MFMA kernels (convolutions / the F(4x4) GEMM): fewer events in a timed run
     std::vector<void *> owned;
-    float *d_wino4_ws = nullptr;    // V + M workspace shared by every F(4x4,3x3) layer
+    // two-lane execution of the per-sample part: the MC samples are split in two halves that run on two streams, so the
+    // tail of one lane's kernel (CUs running out of workgroups) and its launch bubbles are filled by the other lane
+    static constexpr int MAX_LANES = 4;
+    int ws_lanes = 1;               // workspace regions allocated
+    hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};      // [0] unused: lane 0 is the caller's stream
+    hipEvent_t lane_fork = nullptr, lane_join[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    float *d_wino4_ws = nullptr;    // V + M workspace shared by every F(4x4,3x3) layer (one region per lane)
     size_t wino4_ws_floats = 0;
     size_t wino4_slot_floats = 0;   // three rotating slots (V, M, next V) for layers that run all samples in one pass
     ~sivo_segnet() {
@@ -108,6 +114,11 @@ struct sivo_segnet {
         }
         for (void *p : owned) (void)hipFree(p);
         if (stream) (void)hipStreamDestroy(stream);
+        for (int l = 0; l < MAX_LANES; ++l) {
+            if (lane_stream[l]) (void)hipStreamDestroy(lane_stream[l]);
+            if (lane_join[l]) (void)hipEventDestroy(lane_join[l]);
+        }
+        if (lane_fork) (void)hipEventDestroy(lane_fork);
     }
 };
 
@@ -428,7 +439,9 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
         S.owned.push_back(b.d);
     }
     if (S.wino4_ws_floats) {
-        S.d_wino4_ws = dev_alloc<float>(S.wino4_ws_floats);
+        const int env_lanes = std::getenv("SIVO_LANES") ? std::atoi(std::getenv("SIVO_LANES")) : 3;
+        S.ws_lanes = std::max(1, std::min(env_lanes, (int)sivo_segnet::MAX_LANES));
+        S.d_wino4_ws = dev_alloc<float>((size_t)S.ws_lanes * S.wino4_ws_floats);      // one region per lane
         S.owned.push_back(S.d_wino4_ws);
     }
     const int64_t hw = (int64_t)S.H * S.W;
@@ -466,13 +479,16 @@ void harvest(sivo_segnet &S) {
     S.pending = false;
 }
 
-void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t seed, float *d_prob_sum,
-             float *d_logits, float *d_prob, hipStream_t st) {
-    const int64_t hw = (int64_t)S.H * S.W;
-    if (S.profile) harvest(S);
-    launch_preprocess(d_bgr, (float *)S.blobs[S.input_blob].d, hw, st);
+// Runs the ops [first, last) for the samples [n0, n0 + n) of the per-sample blobs on stream st, using workspace
+// region `lane` (0 / 1).  Shared (sample-invariant) blobs are addressed as they are.
+void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sample0, uint64_t seed, hipStream_t st, int lane) {
+    auto fptr = [&](const Blob &b) { return (float *)b.d + (b.shared ? 0 : (int64_t)n0 * b.chw()); };
+    auto mptr = [&](const Blob &b) { return (uint8_t *)b.d + (b.shared ? 0 : (int64_t)n0 * b.chw()); };
+    float *ws = S.d_wino4_ws ? S.d_wino4_ws + (size_t)lane * S.wino4_ws_floats : nullptr;
+    sample0 += n0;
     int w4_vslot = 0;
-    for (Op &op : S.ops) {
+    for (size_t oi = first; oi < last; ++oi) {
+        Op &op = S.ops[oi];
         if (op.skip) continue;
         const Blob &bi = S.blobs[op.in];
         const Blob &bo = S.blobs[op.out];
@@ -487,15 +503,15 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
         switch (op.kind) {
             case OP_CONV: {
                 ConvArgs a{};
-                a.in = (const float *)bi.d; a.in_sample_stride = bi.shared ? 0 : bi.chw();
+                a.in = fptr(bi); a.in_sample_stride = bi.shared ? 0 : bi.chw();
                 a.wt = op.d_w; a.ep_scale = op.d_scale; a.ep_shift = op.d_shift;
-                a.out = (float *)bo.d;
+                a.out = fptr(bo);
                 a.N = N; a.Cin = op.cin; a.H = bi.H; a.W = bi.W; a.Cout = op.cout; a.CoutPad = op.cout_pad;
                 a.relu = op.relu; a.drop_site = op.drop_site; a.sample0 = sample0; a.seed = seed;
                 if (op.unpool_in >= 0) {
                     const Blob &bp = S.blobs[op.unpool_in], &bm = S.blobs[op.unpool_mask];
-                    a.in = (const float *)bp.d; a.in_sample_stride = bp.shared ? 0 : bp.chw();
-                    a.unpool_mask = (const uint8_t *)bm.d; a.unpool_mask_stride = bm.shared ? 0 : bm.chw();
+                    a.in = fptr(bp); a.in_sample_stride = bp.shared ? 0 : bp.chw();
+                    a.unpool_mask = mptr(bm); a.unpool_mask_stride = bm.shared ? 0 : bm.chw();
                 }
                 if (op.wino4f) {
                     launch_conv_wino4f(a, st);
@@ -517,13 +533,13 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
                     if (planned) {
                         // three rotating slots: V of this layer, its M, V of the next layer (when bridged)
                         if (!op.w4_bridged_in) w4_vslot = 0;
-                        plan.V = S.d_wino4_ws + (size_t)w4_vslot * S.wino4_slot_floats;
-                        plan.M = S.d_wino4_ws + (size_t)((w4_vslot + 1) % 3) * S.wino4_slot_floats;
-                        plan.Vnext = S.d_wino4_ws + (size_t)((w4_vslot + 2) % 3) * S.wino4_slot_floats;
+                        plan.V = ws + (size_t)w4_vslot * S.wino4_slot_floats;
+                        plan.M = ws + (size_t)((w4_vslot + 1) % 3) * S.wino4_slot_floats;
+                        plan.Vnext = ws + (size_t)((w4_vslot + 2) % 3) * S.wino4_slot_floats;
                         plan.skip_input = op.w4_bridged_in; plan.bridge = op.w4_bridge;
                         if (op.w4_bridge) w4_vslot = (w4_vslot + 2) % 3;
                     }
-                    launch_conv_wino4(a, S.d_wino4_ws, op.wino4_group, st, sub, S.profile_mfma_only, planned ? &plan : nullptr);
+                    launch_conv_wino4(a, ws, op.wino4_group, st, sub, S.profile_mfma_only, planned ? &plan : nullptr);
                 }
                 else if (op.wino) launch_conv_wino(a, op.wino_cfg, st);
                 else if (op.v2) launch_conv2(a, op.ks, st);
@@ -532,8 +548,8 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
             }
             case OP_POOL: {
                 PoolArgs a{};
-                a.in = (const float *)bi.d; a.in_sample_stride = bi.shared ? 0 : bi.chw();
-                a.out = (float *)bo.d; a.mask = (uint8_t *)S.blobs[op.out2].d;
+                a.in = fptr(bi); a.in_sample_stride = bi.shared ? 0 : bi.chw();
+                a.out = fptr(bo); a.mask = mptr(S.blobs[op.out2]);
                 a.mask_N = S.blobs[op.out2].shared ? 1 : n;
                 a.N = N; a.C = bi.C; a.H = bi.H; a.W = bi.W; a.Ho = bo.H; a.Wo = bo.W;
                 a.drop_site = op.drop_site; a.sample0 = sample0; a.seed = seed;
@@ -543,23 +559,62 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
             case OP_UNPOOL: {
                 UnpoolArgs a{};
                 const Blob &bm = S.blobs[op.in2];
-                a.in = (const float *)bi.d; a.mask = (const uint8_t *)bm.d;
+                a.in = fptr(bi); a.mask = mptr(bm);
                 a.mask_sample_stride = bm.shared ? 0 : bm.chw();
-                a.out = (float *)bo.d; a.N = N; a.C = bi.C; a.H = bi.H; a.W = bi.W;
+                a.out = fptr(bo); a.N = N; a.C = bi.C; a.H = bi.H; a.W = bi.W;
                 if (bi.shared && !bo.shared) throw std::runtime_error("unpool of a shared blob with a per-sample mask is not supported");
                 launch_unpool2(a, st);
                 break;
             }
             case OP_DROPOUT:
-                launch_dropout((const float *)bi.d, bi.shared ? 0 : bi.chw(), (float *)bo.d, n, bi.chw(), op.drop_site,
+                launch_dropout(fptr(bi), bi.shared ? 0 : bi.chw(), fptr(bo), n, bi.chw(), op.drop_site,
                                sample0, seed, st);
                 break;
             case OP_LRN:
-                launch_lrn((const float *)bi.d, (float *)bo.d, N, bi.C, (int64_t)bi.H * bi.W, op.local_size, op.alpha,
+                launch_lrn(fptr(bi), fptr(bo), N, bi.C, (int64_t)bi.H * bi.W, op.local_size, op.alpha,
                            op.beta, st);
                 break;
         }
         if (bracket) SIVO_HIP(hipEventRecord(op.ev1, st));
+    }
+}
+
+void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t seed, float *d_prob_sum,
+             float *d_logits, float *d_prob, hipStream_t st) {
+    const int64_t hw = (int64_t)S.H * S.W;
+    if (S.profile) harvest(S);
+    launch_preprocess(d_bgr, (float *)S.blobs[S.input_blob].d, hw, st);
+    // the sample-invariant ops form a prefix of the plan
+    size_t fork = 0;
+    while (fork < S.ops.size() && (S.ops[fork].skip || S.blobs[S.ops[fork].out].shared)) ++fork;
+    // SIVO_LANES = 1..4 (default 3: measured 68.5 / 70.0 / 70.7 / 66.6 frames/s for 1 / 2 / 3 / 4 lanes at T = 12): how many
+    // sample groups run side by side; profiling keeps one launch per op, and lanes of fewer than 2 samples gain nothing
+    int lanes = S.d_wino4_ws ? S.ws_lanes : 3;
+    if (S.profile) lanes = 1;
+    while (lanes > 1 && n < 2 * lanes) --lanes;
+    run_ops(S, 0, fork, 0, n, sample0, seed, st, 0);
+    if (lanes == 1) {
+        run_ops(S, fork, S.ops.size(), 0, n, sample0, seed, st, 0);
+    } else {
+        if (!S.lane_fork) SIVO_HIP(hipEventCreateWithFlags(&S.lane_fork, hipEventDisableTiming));
+        SIVO_HIP(hipEventRecord(S.lane_fork, st));
+        int n0 = 0;
+        for (int l = 0; l < lanes; ++l) {
+            const int nl = n / lanes + (l < n % lanes ? 1 : 0);
+            hipStream_t ls = st;
+            if (l > 0) {
+                if (!S.lane_stream[l]) {
+                    SIVO_HIP(hipStreamCreateWithFlags(&S.lane_stream[l], hipStreamNonBlocking));
+                    SIVO_HIP(hipEventCreateWithFlags(&S.lane_join[l], hipEventDisableTiming));
+                }
+                ls = S.lane_stream[l];
+                SIVO_HIP(hipStreamWaitEvent(ls, S.lane_fork, 0));
+            }
+            run_ops(S, fork, S.ops.size(), n0, nl, sample0, seed, ls, l);
+            if (l > 0) SIVO_HIP(hipEventRecord(S.lane_join[l], ls));
+            n0 += nl;
+        }
+        for (int l = 1; l < lanes; ++l) SIVO_HIP(hipStreamWaitEvent(st, S.lane_join[l], 0));
     }
     if (S.profile) S.pending = true;
     const Blob &lg = S.blobs[S.logits_blob];
