@@ -305,7 +305,7 @@ def main():
                                  "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
                     "kernels_ms_per_frame": {k: round(v["ms"] / n_detail, 3) for k, v in sorted(by_kernel.items())},
                     "segnet_kernel_ms_per_frame": round(all_ms / n_detail, 3),
-                    "breakdown_source": f"dominant kernel: HIP events in every {PROFILE_EVERY}th of the {args.steps} timed frames; kernels_ms_per_frame / all_conv: {n_detail} further untimed frames with every kernel bracketed"}
+                    "breakdown_source": f"dominant kernel: HIP events in every {PROFILE_EVERY}th of the {args.steps} timed frames (those frames issue the forward in one lane, one launch per layer; the others split the samples over three lanes); kernels_ms_per_frame / all_conv: {n_detail} further untimed single-lane frames with every kernel bracketed"}
         out = {"metric": "frames/sec, SIVO per-frame path (ORB+SegNet T=%d+entropy) %dx%d" % (T, H, W),
                "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong",
