@@ -215,10 +215,10 @@ def main():
         frame(1000 + i)
     barrier()
     # timed region: only the MFMA kernels are bracketed by HIP events (the roofline of the dominant kernel is measured
-    # live here, on a quarter of the frames); the full per-kernel breakdown comes from a few extra, untimed frames afterwards
-    # Every 4th timed frame carries HIP events around its MFMA kernels (that is what `roofline` is measured on): with
+    # live here, on every 8th frame); the full per-kernel breakdown comes from a few extra, untimed frames afterwards
+    # Every 8th timed frame carries HIP events around its MFMA kernels (that is what `roofline` is measured on): with
     # one or two MC samples per GPU the ~60 event records of a frame cost 6 % of it (SIVO_BENCH_NO_EVENTS=1: none at all).
-    PROFILE_EVERY = 4
+    PROFILE_EVERY = 8
     events = os.environ.get("SIVO_BENCH_NO_EVENTS") != "1"
     t0 = time.perf_counter()
     for i in range(args.steps):
