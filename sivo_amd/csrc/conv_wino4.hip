@@ -59,6 +59,10 @@ struct Wino4Args {
     int n, C, K, Kp, H, W, th, tw, P, Pp;
     int relu, drop_site, sample0;
     uint64_t seed;
+    // output transform fused with the MAX 2x2 pooling that consumes this layer (the 4x4 tile holds four whole windows):
+    float *pool_out;            // (n, K, Ho, Wo) or null
+    uint8_t *pool_mask;         // window codes, same shape
+    int pool_drop_site, Ho, Wo;
 };
 
 // 1-D input transform B^T d (points 0, +-1, +-2, inf)
@@ -272,6 +276,9 @@ __device__ __forceinline__ void wino4_at(const float m0, const float m1, const f
 }
 
 // grid: (ceil(P / 256), K)
+// POOL: instead of the 4x4 outputs the kernel writes the 2x2 pooled values (first strict maximum in scan order, as
+// maxpool2_kernel / Caffe), their window codes and the pooling layer's dropout — the convolution output is not stored.
+template <bool POOL>
 __global__ __launch_bounds__(W4_TIN) void wino4_output_kernel(Wino4Args a) {
     const int p = blockIdx.x * W4_TIN + threadIdx.x, co = blockIdx.y;
     if (p >= a.P) return;
@@ -291,10 +298,10 @@ __global__ __launch_bounds__(W4_TIN) void wino4_output_kernel(Wino4Args a) {
     }
     const float sc = a.ep_scale[co], sh = a.ep_shift[co];
     float *dst = a.out + ((int64_t)n * a.K + co) * a.H * a.W;
+    float y4[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int y = 4 * ty + i;
-        if (y >= a.H) break;
         float v[4];
         wino4_at(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], v);
 #pragma unroll
@@ -303,13 +310,54 @@ __global__ __launch_bounds__(W4_TIN) void wino4_output_kernel(Wino4Args a) {
             if (a.relu) v[r] = v[r] > 0.f ? v[r] : 0.f;
         }
         const int x = 4 * tx;
-        if (a.drop_site >= 0) {
+        if (a.drop_site >= 0 && y < a.H) {
             const uint32_t e = (uint32_t)((co * a.H + y) * a.W + x);
             const uint32_t w = wino4_dropout_word(e, (uint32_t)a.drop_site, (uint32_t)(a.sample0 + n), a.seed) >> (e & 31);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = ((w >> r) & 1u) ? v[r] * 2.f : 0.f;
         }
-        *reinterpret_cast<f32x4 *>(dst + (int64_t)y * a.W + x) = f32x4{v[0], v[1], v[2], v[3]};
+        if (POOL) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y4[i][r] = v[r];
+        } else if (y < a.H) {
+            *reinterpret_cast<f32x4 *>(dst + (int64_t)y * a.W + x) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+    }
+    if (POOL) {
+        const int64_t chw = (int64_t)a.K * a.Ho * a.Wo;
+#pragma unroll
+        for (int wy = 0; wy < 2; ++wy) {
+            const int py = 2 * ty + wy;
+            if (py >= a.Ho) break;
+            float pv[2];
+            int pc[2];
+#pragma unroll
+            for (int wx = 0; wx < 2; ++wx) {
+                float best = -3.402823466e+38f;
+                int code = 0;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int yy = 4 * ty + 2 * wy + dy;
+                        const float v = y4[2 * wy + dy][2 * wx + dx];
+                        if (yy < a.H && v > best) { best = v; code = dy * 2 + dx; }
+                    }
+                pv[wx] = best; pc[wx] = code;
+            }
+            const int px = 2 * tx;
+            const int64_t e = ((int64_t)co * a.Ho + py) * a.Wo + px;       // element index inside the sample
+            if (a.pool_drop_site >= 0) {
+#pragma unroll
+                for (int wx = 0; wx < 2; ++wx) {
+                    const uint32_t ee = (uint32_t)(e + wx);
+                    const uint32_t w = wino4_dropout_word(ee, (uint32_t)a.pool_drop_site, (uint32_t)(a.sample0 + n), a.seed);
+                    pv[wx] = ((w >> (ee & 31)) & 1u) ? pv[wx] * 2.f : 0.f;
+                }
+            }
+            *reinterpret_cast<float2 *>(a.pool_out + (int64_t)n * chw + e) = make_float2(pv[0], pv[1]);
+            *reinterpret_cast<uchar2 *>(a.pool_mask + (int64_t)n * chw + e) = make_uchar2((unsigned char)pc[0], (unsigned char)pc[1]);
+        }
     }
 }
 
@@ -462,6 +510,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
     a.th = (c.H + 3) / 4; a.tw = c.W / 4;
     a.U = c.wt; a.ep_scale = c.ep_scale; a.ep_shift = c.ep_shift;
     a.relu = c.relu; a.drop_site = c.drop_site; a.seed = c.seed; a.in_sample_stride = c.in_sample_stride;
+    a.pool_out = c.pool_out; a.pool_mask = c.pool_mask; a.pool_drop_site = c.pool_drop_site; a.Ho = (c.H + 1) / 2; a.Wo = (c.W + 1) / 2;
     if (plan) group = c.N;
     for (int n0 = 0; n0 < c.N; n0 += group) {
         a.n = c.N - n0 < group ? c.N - n0 : group;
@@ -470,7 +519,11 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         a.in = c.in + (int64_t)n0 * c.in_sample_stride;
         a.mask = c.unpool_mask ? c.unpool_mask + (int64_t)n0 * c.unpool_mask_stride : nullptr;
         a.mask_sample_stride = c.unpool_mask_stride;
-        a.out = c.out + (int64_t)n0 * c.Cout * c.H * c.W;
+        a.out = c.out ? c.out + (int64_t)n0 * c.Cout * c.H * c.W : nullptr;
+        if (c.pool_out) {
+            a.pool_out = c.pool_out + (int64_t)n0 * c.Cout * a.Ho * a.Wo;
+            a.pool_mask = c.pool_mask + (int64_t)n0 * c.Cout * a.Ho * a.Wo;
+        }
         a.sample0 = c.sample0 + n0;
         a.V = plan ? plan->V : workspace;
         a.M = plan ? plan->M : workspace + (size_t)36 * a.C * a.Pp;
@@ -501,7 +554,8 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
             const int nthr = ntile >= 1024 ? 1024 : (ntile + 63) / 64 * 64;
             hipLaunchKernelGGL(wino4_bridge_kernel, dim3((unsigned)a.n, (unsigned)a.K), dim3(nthr), wino4_bridge_lds_bytes(a.H, a.W), s, a, plan->Vnext);
         } else {
-            hipLaunchKernelGGL(wino4_output_kernel, dim3(pblocks, (unsigned)a.K), dim3(W4_TIN), 0, s, a);
+            if (a.pool_out) hipLaunchKernelGGL(wino4_output_kernel<true>, dim3(pblocks, (unsigned)a.K), dim3(W4_TIN), 0, s, a);
+            else hipLaunchKernelGGL(wino4_output_kernel<false>, dim3(pblocks, (unsigned)a.K), dim3(W4_TIN), 0, s, a);
         }
         if (e && !gemm_only_events) (void)hipEventRecord(e[3], s);
     }

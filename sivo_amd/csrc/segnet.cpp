@@ -65,6 +65,7 @@ struct Op {
     bool skip = false;             // Upsample fused into the following F(4x4,3x3) convolution
     bool w4_bridge = false;        // output transform fused with the next F(4x4) layer's input transform (no HBM round trip)
     bool w4_bridged_in = false;    // this layer's transformed input is written by its predecessor's bridge
+    int pool_op = -1;              // F(4x4) conv: index of the MAX 2x2 pooling fused into its output transform
     int unpool_in = -1, unpool_mask = -1;   // that convolution: pooled blob and mask blob it reads through
     int drop_site = -1;
     // lrn
@@ -431,6 +432,22 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
         S.blobs[A.out].fused_away = true;
     }
     if (S.wino4_slot_floats) S.wino4_ws_floats = std::max(S.wino4_ws_floats, 3 * S.wino4_slot_floats);
+    // F(4x4) conv -> MAX 2x2 pooling (per-sample part: conv4_3 -> pool4, conv5_3 -> pool5): the output transform holds
+    // whole pooling windows, so it writes the pooled tensor + window codes (+ the pooling layer's dropout) directly.
+    // SIVO_NO_FUSE_POOL disables.
+    if (!std::getenv("SIVO_NO_FUSE_POOL"))
+        for (size_t i = 0; i < S.ops.size(); ++i) {
+            Op &A = S.ops[i];
+            if (A.kind != OP_CONV || !A.wino4 || A.w4_bridge || A.out == S.logits_blob || S.blobs[A.out].shared) continue;
+            int uses = 0, pi = -1;
+            for (size_t k = 0; k < S.ops.size(); ++k)
+                if (S.ops[k].in == A.out || S.ops[k].in2 == A.out) { ++uses; pi = (int)k; }
+            if (uses != 1 || S.ops[pi].kind != OP_POOL || S.ops[pi].in != A.out || S.blobs[S.ops[pi].out2].shared) continue;
+            if (S.blobs[A.out].W % 4) continue;
+            A.pool_op = pi;
+            S.ops[pi].skip = true;
+            S.blobs[A.out].fused_away = true;
+        }
     // allocate
     for (Blob &b : S.blobs) {
         if (b.fused_away) continue;
@@ -508,6 +525,11 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                 a.out = fptr(bo);
                 a.N = N; a.Cin = op.cin; a.H = bi.H; a.W = bi.W; a.Cout = op.cout; a.CoutPad = op.cout_pad;
                 a.relu = op.relu; a.drop_site = op.drop_site; a.sample0 = sample0; a.seed = seed;
+                if (op.pool_op >= 0) {
+                    const Op &P = S.ops[op.pool_op];
+                    a.pool_out = fptr(S.blobs[P.out]); a.pool_mask = mptr(S.blobs[P.out2]); a.pool_drop_site = P.drop_site;
+                    a.out = nullptr;
+                }
                 if (op.unpool_in >= 0) {
                     const Blob &bp = S.blobs[op.unpool_in], &bm = S.blobs[op.unpool_mask];
                     a.in = fptr(bp); a.in_sample_stride = bp.shared ? 0 : bp.chw();
@@ -803,7 +825,7 @@ extern "C" int sivo_segnet_blob(sivo_segnet_t h, const char *name, float *host_o
         if (it == h->blob_id.end()) throw std::invalid_argument(std::string("no blob named '") + name + "'");
         const Blob &b = h->blobs[it->second];
         if (b.fused_away)
-            throw std::invalid_argument(std::string("blob '") + name + "' is not materialised: it only exists on chip, fused into the next convolution (SIVO_NO_FUSE_UNPOOL=1 / SIVO_NO_FUSE_BRIDGE=1 keep Upsample outputs / conv-to-conv activations in HBM)");
+            throw std::invalid_argument(std::string("blob '") + name + "' is not materialised: it only exists on chip, fused into the next convolution (SIVO_NO_FUSE_UNPOOL=1 / SIVO_NO_FUSE_BRIDGE=1 / SIVO_NO_FUSE_POOL=1 keep Upsample outputs / conv-to-conv activations / pooled convolutions in HBM)");
         const int N = b.shared ? 1 : h->T;
         if (shape) { shape[0] = N; shape[1] = b.C; shape[2] = b.H; shape[3] = b.W; }
         const size_t n = (size_t)N * b.chw();

@@ -25,6 +25,11 @@ struct ConvArgs {
     // layer in front of the convolution is never materialised
     const uint8_t *unpool_mask = nullptr;
     int64_t unpool_mask_stride = 0;   // 0 when the mask is shared by all samples
+    // F(4x4,3x3) three-kernel path only: when set, the output transform applies the MAX 2x2 pooling that follows (window
+    // codes + the pooling layer's dropout) and writes these instead of `out`
+    float *pool_out = nullptr;
+    uint8_t *pool_mask = nullptr;
+    int pool_drop_site = -1;
     int variant;               // diagnostics only (sivo_debug_conv): bit0 no epilogue stores, bit1 no LDS commit, bit2 no global loads
 };
 int conv_cout_tile(int ks, int cout);  // BN the launcher will pick (CoutPad must be a multiple)

@@ -164,6 +164,29 @@ def test_bridged_convolutions_are_bit_identical(H, W, width):
     assert torch.equal(lg_fused, lg_plain)
 
 
+def test_pooling_fused_into_the_output_transform_is_bit_identical():
+    """conv4_3 -> pool4 and conv5_3 -> pool5: the F(4x4) output transform writes pooled values, window codes and the
+    pooling dropout itself; SIVO_NO_FUSE_POOL=1 runs the separate pooling kernel.  Identical logits and identical masks."""
+    T, H, W = 3, 64, 128
+    text = netspec.standard_prototxt(T, H, W)
+    net, w, sn = _make(text, T)
+    img = torch.from_numpy(_image(np.random.default_rng(9), H, W)).cuda()
+    _, lg_fused, _ = sn.forward(img, 321, sample0=2, want_logits=True)
+    with pytest.raises(ValueError, match="not materialised"):
+        sn.blob("conv4_3")
+    os.environ["SIVO_NO_FUSE_POOL"] = "1"
+    try:
+        _, _, sn2 = _make(text, T)
+    finally:
+        del os.environ["SIVO_NO_FUSE_POOL"]
+    _, lg_plain, _ = sn2.forward(img, 321, sample0=2, want_logits=True)
+    torch.cuda.synchronize()
+    assert sn2.blob("conv4_3").shape == (T, 512, H // 8, W // 8)
+    for name in ("pool4", "pool4_mask", "pool5", "pool5_mask"):
+        assert np.array_equal(sn.blob(name), sn2.blob(name)), name
+    assert torch.equal(lg_fused, lg_plain)
+
+
 def test_fused_upsample_is_bit_identical_to_the_materialised_one():
     """Upsample -> F(4x4,3x3) convolution reads the pooled tensor + window codes inside the input transform; the same
     net built with SIVO_NO_FUSE_UNPOOL=1 runs the unpool kernel first.  Same arithmetic -> identical logits, and the
