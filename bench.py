@@ -279,7 +279,7 @@ def main():
         all_ms = sum(v["ms"] for v in by_kernel.values())
         traffic = None
         traffic_file = None
-        for cand in ("r01_n_pmc_traffic.json", "r01_i_pmc_traffic_wino4.json", "r01_g_pmc_traffic.json"):
+        for cand in ("r01_o_pmc_traffic.json", "r01_i_pmc_traffic_wino4.json", "r01_g_pmc_traffic.json"):
             # HBM bytes per launch of the dominant kernel from the committed PMC passes (bench cannot collect PMC itself)
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
