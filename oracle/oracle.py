@@ -154,7 +154,8 @@ def preprocess(bgr, T, H, W):
     return None if rc else blob
 
 
-def run_net(net, weights, blob, seed, sample0=0, keep=None, acc64=False, dropout_on=True, force_masks=None, flips=None):
+def run_net(net, weights, blob, seed, sample0=0, keep=None, acc64=False, dropout_on=True, force_masks=None, flips=None,
+            expand_to=None):
     """Execute a parsed prototxt (oracle.prototxt.parse) layer by layer, as
     caffe::Net::Forward does (bayesian_segnet.cpp:310).  `weights[name]` is the
     list of parameter blobs of layer `name` (conv: [W, b]; BN: [scale, shift]).
@@ -167,7 +168,13 @@ def run_net(net, weights, blob, seed, sample0=0, keep=None, acc64=False, dropout
     switch then differs by O(1).  With the switches forced, the rest of the arithmetic is compared at the
     stated tolerance, and `flips[name] = (count, max gap)` records, per pooling layer, how many forced
     switches differ from this oracle's own choice and the largest (oracle max - forced element) among them:
-    a genuine near-tie has a gap of a few ulps."""
+    a genuine near-tie has a gap of a few ulps.
+
+    expand_to: T — test-time shortcut.  The reference fills the T batch slots with T copies of one image
+    (bayesian_segnet.cpp:174-177), so every layer upstream of the first test-time Dropout computes T identical
+    results.  With expand_to the caller passes ONE slot (blob of shape (1,3,H,W)); the layers run on it and the
+    bottom of the first active Dropout is repeated T times there (blobs upstream keep N = 1, pooling masks are
+    broadcast where the decoder consumes them).  Same values as the T-slot run, T-1 redundant prefixes less."""
     blobs = {net["input"]: blob}
     site = 0
     last = net["input"]
@@ -197,9 +204,16 @@ def run_net(net, weights, blob, seed, sample0=0, keep=None, acc64=False, dropout
             blobs[L["top"][1]] = mask
         elif t == "Upsample":
             s = L["scale"]
-            out = unpool(bot[0], bot[1], bot[0].shape[2] * s, bot[0].shape[3] * s)
+            m = bot[1]
+            if m.shape[0] != bot[0].shape[0]:
+                m = np.ascontiguousarray(np.broadcast_to(m, bot[0].shape))
+            out = unpool(bot[0], m, bot[0].shape[2] * s, bot[0].shape[3] * s)
         elif t == "Dropout":
-            out = dropout(bot[0], site, sample0, seed, L["dropout_ratio"]) if (dropout_on and L["sample_weights_test"]) else bot[0]
+            active = dropout_on and L["sample_weights_test"]
+            x = bot[0]
+            if active and expand_to is not None and x.shape[0] == 1 and expand_to > 1:
+                x = np.ascontiguousarray(np.broadcast_to(x, (expand_to,) + x.shape[1:]))
+            out = dropout(x, site, sample0, seed, L["dropout_ratio"]) if active else x
             site += 1
         elif t == "LRN":
             out = lrn(bot[0], L["local_size"], L["alpha"], L["beta"])
@@ -222,17 +236,20 @@ def run_net(net, weights, blob, seed, sample0=0, keep=None, acc64=False, dropout
     return blobs
 
 
-def segment(net, weights, bgr, seed, sample0=0, logits_name=None, force_masks=None, flips=None):
-    """BayesianSegNet::segmentImage (bayesian_segnet.cpp:299-318) on the oracle."""
+def segment(net, weights, bgr, seed, sample0=0, logits_name=None, force_masks=None, flips=None, keep=(),
+            shared_prefix=False):
+    """BayesianSegNet::segmentImage (bayesian_segnet.cpp:299-318) on the oracle.  shared_prefix: run the
+    sample-invariant prefix once (run_net's expand_to); `keep`: further blob names to return in "blobs"."""
     T, _, H, W = net["shape"]
-    blob = preprocess(bgr, T, H, W)
-    keep = [logits_name] if logits_name else []
-    blobs = run_net(net, weights, blob, seed, sample0, keep=keep, force_masks=force_masks, flips=flips)
+    blob = preprocess(bgr, 1 if shared_prefix else T, H, W)
+    keep = list(keep) + ([logits_name] if logits_name else [])
+    blobs = run_net(net, weights, blob, seed, sample0, keep=keep, force_masks=force_masks, flips=flips,
+                    expand_to=T if shared_prefix else None)
     prob = blobs["__last__"]
     mean = mc_mean(prob)
     classes, conf, ent = mc_finalize(mean)
     return {"prob": prob, "mean": mean, "classes": classes, "confidence": conf, "entropy": ent,
-            "logits": blobs.get(logits_name) if logits_name else None}
+            "logits": blobs.get(logits_name) if logits_name else None, "blobs": blobs}
 
 
 # --------------------------------------------------------------------------- matching

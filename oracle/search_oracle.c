@@ -1,0 +1,686 @@
+/*
+ * oracle/search_oracle.c — TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * CPU restatement, on plain arrays, of the guided-matching routines of
+ * navganti/SIVO's ORBmatcher and of the feature grid they query:
+ *   Frame::AssignFeaturesToGrid / PosInGrid       src/orbslam/Frame.cc:205-221, 392-404
+ *   Frame::GetFeaturesInArea                       src/orbslam/Frame.cc:326-390
+ *   ORBmatcher::SearchByProjection(F, MapPoints)   src/orbslam/ORBmatcher.cc:44-127
+ *   ORBmatcher::SearchByBoW(KF, F)                 src/orbslam/ORBmatcher.cc:161-284
+ *   ORBmatcher::SearchByProjection(KF, Scw, ...)   src/orbslam/ORBmatcher.cc:286-399
+ *   ORBmatcher::SearchForInitialization            src/orbslam/ORBmatcher.cc:401-506
+ *   ORBmatcher::SearchByBoW(KF, KF)                src/orbslam/ORBmatcher.cc:508-629
+ *   ORBmatcher::SearchForTriangulation             src/orbslam/ORBmatcher.cc:631-785
+ *   ORBmatcher::Fuse x2                            src/orbslam/ORBmatcher.cc:787-1053
+ *   ORBmatcher::SearchBySim3                       src/orbslam/ORBmatcher.cc:1055-1276
+ *   ORBmatcher::SearchByProjection(Cur, Last)      src/orbslam/ORBmatcher.cc:1278-1418
+ *   ORBmatcher::SearchByProjection(Cur, KF, ...)   src/orbslam/ORBmatcher.cc:1420-1543
+ *   ORBmatcher::ComputeThreeMaxima                 src/orbslam/ORBmatcher.cc:1545-1577
+ *
+ * What is restated is everything from the PROJECTED point on: the window query,
+ * the gates, the sequential best / second-best scans (which see the matches made
+ * by earlier iterations of the same call), the acceptance rules and the rotation
+ * histogram.  What stays with the caller is what needs the SLAM object graph,
+ * which is outside this repo's scope: MapPoint::isBad /
+ * Observations / PredictScale / GetDescriptor, the DBoW2 feature vectors (passed
+ * in as the node-wise index lists the routines iterate) and the pose algebra in
+ * cv::Mat (passed in as the projected u, v, 1/z, distances).  Each function is
+ * a loop-for-loop restatement; variable names follow the reference.
+ *
+ * PARITY UNPINNED: the reference holds no test for ORBmatcher.
+ */
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define TH_HIGH 100
+#define TH_LOW 50
+#define HISTO_LENGTH 30
+#define FRAME_GRID_ROWS 48
+#define FRAME_GRID_COLS 64
+
+int orc_descriptor_distance(const uint8_t *a, const uint8_t *b);   /* match_oracle.c */
+
+typedef struct {  /* == cv::KeyPoint */
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} OrcKp;
+
+typedef struct {
+    int32_t *v;
+    int32_t n, cap;
+} OrcVec;
+
+static void vec_push(OrcVec *a, int32_t x) {
+    if (a->n == a->cap) {
+        a->cap = a->cap ? 2 * a->cap : 8;
+        a->v = (int32_t *)realloc(a->v, sizeof(int32_t) * (size_t)a->cap);
+    }
+    a->v[a->n++] = x;
+}
+
+/* The part of Frame / KeyFrame the matcher reads. */
+typedef struct {
+    int32_t N;                 /* numSemanticKeys */
+    const OrcKp *keys;         /* mvKeysSemantic */
+    const float *mvRight;      /* may be NULL (monocular): treated as all -1 */
+    const uint8_t *desc;       /* mDescriptorsSemantic, N x 32 */
+    float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
+    int32_t nlevels;
+    const float *mvScaleFactors, *mvLevelSigma2, *mvInvLevelSigma2;
+    OrcVec grid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+} OrcFrame;
+
+/* Frame.cc:392-404 */
+static int pos_in_grid(const OrcFrame *F, const OrcKp *kp, int *posX, int *posY) {
+    *posX = (int)roundf((kp->x - F->mnMinX) * F->mfGridElementWidthInv);
+    *posY = (int)roundf((kp->y - F->mnMinY) * F->mfGridElementHeightInv);
+    if (*posX < 0 || *posX >= FRAME_GRID_COLS || *posY < 0 || *posY >= FRAME_GRID_ROWS) return 0;
+    return 1;
+}
+
+/* Frame constructor tail (Frame.cc:143-175) + AssignFeaturesToGrid (:205-221).  The arrays stay owned by the caller. */
+OrcFrame *orc_frame_create(const OrcKp *keys, int32_t N, const float *mvRight, const uint8_t *desc, float minX,
+                           float maxX, float minY, float maxY, const float *scale, const float *sigma2,
+                           const float *inv_sigma2, int32_t nlevels) {
+    OrcFrame *F = (OrcFrame *)calloc(1, sizeof(OrcFrame));
+    F->N = N; F->keys = keys; F->mvRight = mvRight; F->desc = desc;
+    F->mnMinX = minX; F->mnMaxX = maxX; F->mnMinY = minY; F->mnMaxY = maxY;
+    F->mfGridElementWidthInv = (float)FRAME_GRID_COLS / (maxX - minX);
+    F->mfGridElementHeightInv = (float)FRAME_GRID_ROWS / (maxY - minY);
+    F->nlevels = nlevels; F->mvScaleFactors = scale; F->mvLevelSigma2 = sigma2; F->mvInvLevelSigma2 = inv_sigma2;
+    for (int i = 0; i < N; i++) {
+        int gx, gy;
+        if (pos_in_grid(F, &keys[i], &gx, &gy)) vec_push(&F->grid[gx][gy], i);
+    }
+    return F;
+}
+
+void orc_frame_destroy(OrcFrame *F) {
+    if (!F) return;
+    for (int i = 0; i < FRAME_GRID_COLS; i++)
+        for (int j = 0; j < FRAME_GRID_ROWS; j++) free(F->grid[i][j].v);
+    free(F);
+}
+
+/* Frame.cc:326-390 */
+static void get_features_in_area(const OrcFrame *F, float x, float y, float r, int minLevel, int maxLevel, OrcVec *vIndices) {
+    vIndices->n = 0;
+    int nMinCellX = (int)floorf((x - F->mnMinX - r) * F->mfGridElementWidthInv);
+    if (nMinCellX < 0) nMinCellX = 0;
+    if (nMinCellX >= FRAME_GRID_COLS) return;
+    int nMaxCellX = (int)ceilf((x - F->mnMinX + r) * F->mfGridElementWidthInv);
+    if (nMaxCellX > FRAME_GRID_COLS - 1) nMaxCellX = FRAME_GRID_COLS - 1;
+    if (nMaxCellX < 0) return;
+    int nMinCellY = (int)floorf((y - F->mnMinY - r) * F->mfGridElementHeightInv);
+    if (nMinCellY < 0) nMinCellY = 0;
+    if (nMinCellY >= FRAME_GRID_ROWS) return;
+    int nMaxCellY = (int)ceilf((y - F->mnMinY + r) * F->mfGridElementHeightInv);
+    if (nMaxCellY > FRAME_GRID_ROWS - 1) nMaxCellY = FRAME_GRID_ROWS - 1;
+    if (nMaxCellY < 0) return;
+    const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const OrcVec *vCell = &F->grid[ix][iy];
+            for (int j = 0; j < vCell->n; j++) {
+                const OrcKp *kp = &F->keys[vCell->v[j]];
+                if (bCheckLevels) {
+                    if (kp->octave < minLevel) continue;
+                    if (maxLevel >= 0)
+                        if (kp->octave > maxLevel) continue;
+                }
+                const float distx = kp->x - x, disty = kp->y - y;
+                if (fabsf(distx) < r && fabsf(disty) < r) vec_push(vIndices, vCell->v[j]);
+            }
+        }
+}
+
+int orc_frame_features_in_area(const OrcFrame *F, float x, float y, float r, int minLevel, int maxLevel, int32_t *out, int cap) {
+    OrcVec v = {0};
+    get_features_in_area(F, x, y, r, minLevel, maxLevel, &v);
+    for (int i = 0; i < v.n && i < cap; i++) out[i] = v.v[i];
+    const int n = v.n;
+    free(v.v);
+    return n;
+}
+
+/* ORBmatcher.cc:1545-1577 */
+static void compute_three_maxima(const OrcVec *histo, int L, int *ind1, int *ind2, int *ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i].n;
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; *ind3 = *ind2; *ind2 = i; }
+        else if (s > max3) { max3 = s; *ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { *ind3 = -1; }
+}
+
+static int rot_bin(float a1, float a2) {
+    const float factor = 1.0f / HISTO_LENGTH;
+    float rot = a1 - a2;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+static void free_hist(OrcVec *h) { for (int i = 0; i < HISTO_LENGTH; i++) free(h[i].v); }
+
+/* ---------------------------------------------------------------------------------------------------------
+ * SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th)        ORBmatcher.cc:44-127
+ * Per map point iMP (arrays of nMP): track_in_view = mbTrackInView && !isBad(); proj_x/y/xr, level, view_cos =
+ * the mTrack* fields Frame::isInFrustum left (Frame.cc:246-324); mp_desc = GetDescriptor(); mp_obs = Observations().
+ * Frame state: occ_obs[idx] = -1 where F.mvpMapPoints[idx] is NULL, else that point's Observations();
+ * match[idx] (out) = iMP whose map point the call stored into F.mvpMapPoints[idx], -1 where the call stored nothing.
+ * ------------------------------------------------------------------------------------------------------- */
+int orc_search_by_projection_mappoints(const OrcFrame *F, int nMP, const uint8_t *track_in_view, const float *proj_x,
+                                       const float *proj_y, const float *proj_xr, const int32_t *level,
+                                       const float *view_cos, const uint8_t *mp_desc, const int32_t *mp_obs, float th,
+                                       float mfNNratio, int32_t *occ_obs, int32_t *match) {
+    int nmatches = 0;
+    const int bFactor = th != 1.0;
+    OrcVec vIndices = {0};
+    for (int i = 0; i < F->N; i++) match[i] = -1;
+    for (int iMP = 0; iMP < nMP; iMP++) {
+        if (!track_in_view[iMP]) continue;
+        const int nPredictedLevel = level[iMP];
+        float r = view_cos[iMP] > 0.998 ? 2.5f : 4.0f;            /* RadiusByViewingCos :129-134 */
+        if (bFactor) r *= th;
+        get_features_in_area(F, proj_x[iMP], proj_y[iMP], r * F->mvScaleFactors[nPredictedLevel], nPredictedLevel - 1,
+                             nPredictedLevel, &vIndices);
+        if (vIndices.n == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = 0; c < vIndices.n; c++) {
+            const int idx = vIndices.v[c];
+            if (occ_obs[idx] >= 0)
+                if (occ_obs[idx] > 0) continue;
+            if (F->mvRight && F->mvRight[idx] > 0) {
+                const float er = fabsf(proj_xr[iMP] - F->mvRight[idx]);
+                if (er > r * F->mvScaleFactors[nPredictedLevel]) continue;
+            }
+            const int dist = orc_descriptor_distance(mp_desc + 32 * (size_t)iMP, F->desc + 32 * (size_t)idx);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = F->keys[idx].octave; bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = F->keys[idx].octave; bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+            occ_obs[bestIdx] = mp_obs[iMP]; match[bestIdx] = iMP;
+            nmatches++;
+        }
+    }
+    free(vIndices.v);
+    return nmatches;
+}
+
+/* ---------------------------------------------------------------------------------------------------------
+ * SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)     ORBmatcher.cc:1278-1418
+ * Per last-frame key i (arrays of nLast): valid = has a map point && !mvbOutlier (:1304-1307); u, v, invzc = the
+ * projection with the current pose (:1309-1322, computed by the caller in cv::Mat float algebra); last_octave /
+ * last_angle = LastFrame.mvKeysSemantic[i]; mp_desc, mp_obs as above.  bForward / bBackward (:1299-1300) from the
+ * caller.  match[idx] (out): >= 0 the last-frame key whose point ends up in CurrentFrame.mvpMapPoints[idx], -2
+ * where the rotation check stored NULL, -1 untouched.
+ * ------------------------------------------------------------------------------------------------------- */
+int orc_search_by_projection_frame(const OrcFrame *Cur, int nLast, const uint8_t *valid, const float *pu, const float *pv,
+                                   const float *pinvz, const int32_t *last_octave, const float *last_angle,
+                                   const uint8_t *mp_desc, const int32_t *mp_obs, float th, int bForward, int bBackward,
+                                   float mbf, int mbCheckOrientation, int32_t *occ_obs, int32_t *match) {
+    int nmatches = 0;
+    OrcVec rotHist[HISTO_LENGTH];
+    memset(rotHist, 0, sizeof rotHist);
+    OrcVec vIndices2 = {0};
+    for (int i = 0; i < Cur->N; i++) match[i] = -1;
+    for (int i = 0; i < nLast; i++) {
+        if (!valid[i]) continue;
+        const float invzc = pinvz[i];
+        if (invzc < 0) continue;
+        const float u = pu[i], v = pv[i];
+        if (u < Cur->mnMinX || u > Cur->mnMaxX) continue;
+        if (v < Cur->mnMinY || v > Cur->mnMaxY) continue;
+        const int nLastOctave = last_octave[i];
+        const float radius = th * Cur->mvScaleFactors[nLastOctave];
+        if (bForward) get_features_in_area(Cur, u, v, radius, nLastOctave, -1, &vIndices2);
+        else if (bBackward) get_features_in_area(Cur, u, v, radius, 0, nLastOctave, &vIndices2);
+        else get_features_in_area(Cur, u, v, radius, nLastOctave - 1, nLastOctave + 1, &vIndices2);
+        if (vIndices2.n == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < vIndices2.n; c++) {
+            const int i2 = vIndices2.v[c];
+            if (occ_obs[i2] >= 0)
+                if (occ_obs[i2] > 0) continue;
+            if (Cur->mvRight && Cur->mvRight[i2] > 0) {
+                const float ur = u - mbf * invzc;
+                const float er = fabsf(ur - Cur->mvRight[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = orc_descriptor_distance(mp_desc + 32 * (size_t)i, Cur->desc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            occ_obs[bestIdx2] = mp_obs[i]; match[bestIdx2] = i;
+            nmatches++;
+            if (mbCheckOrientation) vec_push(&rotHist[rot_bin(last_angle[i], Cur->keys[bestIdx2].angle)], bestIdx2);
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < rotHist[i].n; j++) {
+                    occ_obs[rotHist[i].v[j]] = -1; match[rotHist[i].v[j]] = -2;
+                    nmatches--;
+                }
+    }
+    free_hist(rotHist);
+    free(vIndices2.v);
+    return nmatches;
+}
+
+/* ---------------------------------------------------------------------------------------------------------
+ * SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist)   ORBmatcher.cc:1420-1543
+ * Per keyframe key i: valid = pMP && !isBad && !sAlreadyFound.count(pMP) && dist3D inside [min, max] distance
+ * (:1441-1468, caller); u, v as projected; pred_level = PredictScale (:1470); kf_angle = pKF->mvKeysSemantic[i].angle.
+ * occupied[idx] != 0 where CurrentFrame.mvpMapPoints[idx] is non-NULL (in/out).
+ * ------------------------------------------------------------------------------------------------------- */
+int orc_search_by_projection_reloc(const OrcFrame *Cur, int nKF, const uint8_t *valid, const float *pu, const float *pv,
+                                   const int32_t *pred_level, const float *kf_angle, const uint8_t *mp_desc, float th,
+                                   int ORBdist, int mbCheckOrientation, uint8_t *occupied, int32_t *match) {
+    int nmatches = 0;
+    OrcVec rotHist[HISTO_LENGTH];
+    memset(rotHist, 0, sizeof rotHist);
+    OrcVec vIndices2 = {0};
+    for (int i = 0; i < Cur->N; i++) match[i] = -1;
+    for (int i = 0; i < nKF; i++) {
+        if (!valid[i]) continue;
+        const float u = pu[i], v = pv[i];
+        if (u < Cur->mnMinX || u > Cur->mnMaxX) continue;
+        if (v < Cur->mnMinY || v > Cur->mnMaxY) continue;
+        const int nPredictedLevel = pred_level[i];
+        const float radius = th * Cur->mvScaleFactors[nPredictedLevel];
+        get_features_in_area(Cur, u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1, &vIndices2);
+        if (vIndices2.n == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < vIndices2.n; c++) {
+            const int i2 = vIndices2.v[c];
+            if (occupied[i2]) continue;
+            const int dist = orc_descriptor_distance(mp_desc + 32 * (size_t)i, Cur->desc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= ORBdist) {
+            occupied[bestIdx2] = 1; match[bestIdx2] = i;
+            nmatches++;
+            if (mbCheckOrientation) vec_push(&rotHist[rot_bin(kf_angle[i], Cur->keys[bestIdx2].angle)], bestIdx2);
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < rotHist[i].n; j++) {
+                    occupied[rotHist[i].v[j]] = 0; match[rotHist[i].v[j]] = -2;
+                    nmatches--;
+                }
+    }
+    free_hist(rotHist);
+    free(vIndices2.v);
+    return nmatches;
+}
+
+/* ---------------------------------------------------------------------------------------------------------
+ * SearchByProjection(KeyFrame *pKF, Scw, vpPoints, vpMatched, th)                 ORBmatcher.cc:286-399
+ * valid = !isBad && !spAlreadyFound && z >= 0 && IsInImage && distance range && viewing angle (:313-353, caller).
+ * matched[idx] != 0 where vpMatched[idx] is non-NULL (in/out).
+ * ------------------------------------------------------------------------------------------------------- */
+int orc_search_by_projection_kf(const OrcFrame *KF, int nMP, const uint8_t *valid, const float *pu, const float *pv,
+                                const int32_t *pred_level, const uint8_t *mp_desc, int th, uint8_t *matched, int32_t *match) {
+    int nmatches = 0;
+    OrcVec vIndices = {0};
+    for (int i = 0; i < KF->N; i++) match[i] = -1;
+    for (int iMP = 0; iMP < nMP; iMP++) {
+        if (!valid[iMP]) continue;
+        const int nPredictedLevel = pred_level[iMP];
+        const float radius = th * KF->mvScaleFactors[nPredictedLevel];
+        get_features_in_area(KF, pu[iMP], pv[iMP], radius, -1, -1, &vIndices);
+        if (vIndices.n == 0) continue;
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < vIndices.n; c++) {
+            const int idx = vIndices.v[c];
+            if (matched[idx]) continue;
+            const int kpLevel = KF->keys[idx].octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const int dist = orc_descriptor_distance(mp_desc + 32 * (size_t)iMP, KF->desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) {
+            matched[bestIdx] = 1; match[bestIdx] = iMP;
+            nmatches++;
+        }
+    }
+    free(vIndices.v);
+    return nmatches;
+}
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Fuse(KeyFrame *pKF, vpMapPoints, th)   ORBmatcher.cc:787-929   (scw_variant = 0: stereo / mono chi2 gate)
+ * Fuse(KeyFrame *pKF, Scw, vpPoints, th, vpReplacePoint)   :931-1053   (scw_variant = 1: no gate)
+ * valid = the per-point tests up to the viewing angle (:806-848 / :968-1006, caller).  pur = u - bf * invz.
+ * best_idx[iMP] (out) = the keypoint the point is fused with, -1 when bestDist > TH_LOW or no candidate; what
+ * happens to the two map points there (Replace / AddObservation, :909-923) is the caller's.  Returns nFused.
+ * ------------------------------------------------------------------------------------------------------- */
+int orc_fuse(const OrcFrame *KF, int nMP, const uint8_t *valid, const float *pu, const float *pv, const float *pur,
+             const int32_t *pred_level, const uint8_t *mp_desc, float th, int scw_variant, int32_t *best_idx,
+             int32_t *best_dist) {
+    int nFused = 0;
+    OrcVec vIndices = {0};
+    for (int i = 0; i < nMP; i++) {
+        best_idx[i] = -1; best_dist[i] = scw_variant ? INT_MAX : 256;
+        if (!valid[i]) continue;
+        const float u = pu[i], v = pv[i], ur = pur ? pur[i] : 0.f;
+        const int nPredictedLevel = pred_level[i];
+        const float radius = th * KF->mvScaleFactors[nPredictedLevel];
+        get_features_in_area(KF, u, v, radius, -1, -1, &vIndices);
+        if (vIndices.n == 0) continue;
+        int bestDist = scw_variant ? INT_MAX : 256, bestIdx = -1;
+        for (int c = 0; c < vIndices.n; c++) {
+            const int idx = vIndices.v[c];
+            const OrcKp *kp = &KF->keys[idx];
+            const int kpLevel = kp->octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (!scw_variant) {
+                if (KF->mvRight && KF->mvRight[idx] >= 0) {
+                    const float kpx = kp->x, kpy = kp->y, kpr = KF->mvRight[idx];
+                    const float ex = u - kpx, ey = v - kpy, er = ur - kpr;
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * KF->mvInvLevelSigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float kpx = kp->x, kpy = kp->y;
+                    const float ex = u - kpx, ey = v - kpy;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * KF->mvInvLevelSigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            const int dist = orc_descriptor_distance(mp_desc + 32 * (size_t)i, KF->desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        best_dist[i] = bestDist;
+        if (bestDist <= TH_LOW) { best_idx[i] = bestIdx; nFused++; }
+    }
+    free(vIndices.v);
+    return nFused;
+}
+
+/* ---------------------------------------------------------------------------------------------------------
+ * SearchBySim3                                                                    ORBmatcher.cc:1055-1276
+ * One direction (:1102-1176 resp. :1178-1252): points of one keyframe projected into the OTHER keyframe `KF`.
+ * valid = pMP && !vbAlreadyMatched && !isBad && z >= 0 && IsInImage && distance range (caller).
+ * vnMatch[i] (out) = best key of KF or -1.  The agreement step (:1254-1273) is orc_sim3_agree.
+ * ------------------------------------------------------------------------------------------------------- */
+void orc_search_by_sim3_dir(const OrcFrame *KF, int n, const uint8_t *valid, const float *pu, const float *pv,
+                            const int32_t *pred_level, const uint8_t *mp_desc, float th, int32_t *vnMatch) {
+    OrcVec vIndices = {0};
+    for (int i = 0; i < n; i++) {
+        vnMatch[i] = -1;
+        if (!valid[i]) continue;
+        const int nPredictedLevel = pred_level[i];
+        const float radius = th * KF->mvScaleFactors[nPredictedLevel];
+        get_features_in_area(KF, pu[i], pv[i], radius, -1, -1, &vIndices);
+        if (vIndices.n == 0) continue;
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (int c = 0; c < vIndices.n; c++) {
+            const int idx = vIndices.v[c];
+            const OrcKp *kp = &KF->keys[idx];
+            if (kp->octave < nPredictedLevel - 1 || kp->octave > nPredictedLevel) continue;
+            const int dist = orc_descriptor_distance(mp_desc + 32 * (size_t)i, KF->desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_HIGH) vnMatch[i] = bestIdx;
+    }
+    free(vIndices.v);
+}
+
+int orc_sim3_agree(int N1, const int32_t *vnMatch1, const int32_t *vnMatch2, int32_t *matches12) {
+    int nFound = 0;
+    for (int i1 = 0; i1 < N1; i1++) {
+        matches12[i1] = -1;
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0) {
+            const int idx1 = vnMatch2[idx2];
+            if (idx1 == i1) { matches12[i1] = idx2; nFound++; }
+        }
+    }
+    return nFound;
+}
+
+/* ---------------------------------------------------------------------------------------------------------
+ * The BoW-guided routines walk the two DBoW2 feature vectors in lock step and, for every vocabulary node both
+ * hold, loop over the node's key indices of one side against the node's indices of the other.  DBoW2 is outside
+ * this repo, so the common nodes are passed as two CSR lists: node k holds keys idx1[off1[k] .. off1[k+1]) of the
+ * first operand and idx2[off2[k] .. off2[k+1]) of the second.
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* SearchByBoW(KeyFrame *pKF, Frame &F, vpMapPointMatches)   ORBmatcher.cc:161-284
+ * kf_valid[realIdxKF] = pMP && !pMP->isBad().  match_f[realIdxF] (out) = the keyframe key whose point is stored in
+ * vpMapPointMatches[realIdxF], -1 for NULL. */
+int orc_search_by_bow_kf_frame(int n_nodes, const int32_t *off1, const int32_t *idx1, const int32_t *off2,
+                               const int32_t *idx2, const uint8_t *kf_valid, const OrcKp *keysKF, const uint8_t *descKF,
+                               const OrcKp *keysF, const uint8_t *descF, int nF, float mfNNratio, int mbCheckOrientation,
+                               int32_t *match_f) {
+    int nmatches = 0;
+    OrcVec rotHist[HISTO_LENGTH];
+    memset(rotHist, 0, sizeof rotHist);
+    for (int i = 0; i < nF; i++) match_f[i] = -1;
+    for (int k = 0; k < n_nodes; k++)
+        for (int iKF = off1[k]; iKF < off1[k + 1]; iKF++) {
+            const int realIdxKF = idx1[iKF];
+            if (!kf_valid[realIdxKF]) continue;
+            const uint8_t *dKF = descKF + 32 * (size_t)realIdxKF;
+            int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+            for (int iF = off2[k]; iF < off2[k + 1]; iF++) {
+                const int realIdxF = idx2[iF];
+                if (match_f[realIdxF] >= 0) continue;
+                const int dist = orc_descriptor_distance(dKF, descF + 32 * (size_t)realIdxF);
+                if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                else if (dist < bestDist2) { bestDist2 = dist; }
+            }
+            if (bestDist1 <= TH_LOW) {
+                if ((float)bestDist1 < mfNNratio * (float)bestDist2) {
+                    match_f[bestIdxF] = realIdxKF;
+                    if (mbCheckOrientation) vec_push(&rotHist[rot_bin(keysKF[realIdxKF].angle, keysF[bestIdxF].angle)], bestIdxF);
+                    nmatches++;
+                }
+            }
+        }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotHist[i].n; j++) { match_f[rotHist[i].v[j]] = -1; nmatches--; }
+        }
+    }
+    free_hist(rotHist);
+    return nmatches;
+}
+
+/* SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12)   ORBmatcher.cc:508-629
+ * valid1 / valid2 = map point present and not bad.  matches12[idx1] (out) = idx2 or -1. */
+int orc_search_by_bow_kf_kf(int n_nodes, const int32_t *off1, const int32_t *idx1, const int32_t *off2, const int32_t *idx2,
+                            const uint8_t *valid1, const OrcKp *keys1, const uint8_t *desc1, int n1, const uint8_t *valid2,
+                            const OrcKp *keys2, const uint8_t *desc2, int n2, float mfNNratio, int mbCheckOrientation,
+                            int32_t *matches12) {
+    int nmatches = 0;
+    OrcVec rotHist[HISTO_LENGTH];
+    memset(rotHist, 0, sizeof rotHist);
+    uint8_t *vbMatched2 = (uint8_t *)calloc((size_t)(n2 > 0 ? n2 : 1), 1);
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    for (int k = 0; k < n_nodes; k++)
+        for (int i1 = off1[k]; i1 < off1[k + 1]; i1++) {
+            const int idx1_ = idx1[i1];
+            if (!valid1[idx1_]) continue;
+            const uint8_t *d1 = desc1 + 32 * (size_t)idx1_;
+            int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+            for (int i2 = off2[k]; i2 < off2[k + 1]; i2++) {
+                const int idx2_ = idx2[i2];
+                if (vbMatched2[idx2_] || !valid2[idx2_]) continue;
+                const int dist = orc_descriptor_distance(d1, desc2 + 32 * (size_t)idx2_);
+                if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2_; }
+                else if (dist < bestDist2) { bestDist2 = dist; }
+            }
+            if (bestDist1 < TH_LOW) {
+                if ((float)bestDist1 < mfNNratio * (float)bestDist2) {
+                    matches12[idx1_] = bestIdx2;
+                    vbMatched2[bestIdx2] = 1;
+                    if (mbCheckOrientation) vec_push(&rotHist[rot_bin(keys1[idx1_].angle, keys2[bestIdx2].angle)], idx1_);
+                    nmatches++;
+                }
+            }
+        }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotHist[i].n; j++) { matches12[rotHist[i].v[j]] = -1; nmatches--; }
+        }
+    }
+    free_hist(rotHist);
+    free(vbMatched2);
+    return nmatches;
+}
+
+/* CheckDistEpipolarLine   ORBmatcher.cc:137-159   (F12 row-major 3x3 float) */
+static int check_dist_epipolar_line(const OrcKp *kp1, const OrcKp *kp2, const float *F12, const float *sigma2_2) {
+    const float a = kp1->x * F12[0] + kp1->y * F12[3] + F12[6];
+    const float b = kp1->x * F12[1] + kp1->y * F12[4] + F12[7];
+    const float c = kp1->x * F12[2] + kp1->y * F12[5] + F12[8];
+    const float num = a * kp2->x + b * kp2->y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2_2[kp2->octave];
+}
+
+/* SearchForTriangulation   ORBmatcher.cc:631-785
+ * has_mp1 / has_mp2 = GetMapPoint(idx) != NULL; ex, ey = the epipole in image 2 (:639-647, caller).
+ * vbMatched2 is declared and tested by the reference but never set (:654, :695) — restated as is.
+ * matches12[idx1] (out) = idx2 or -1; returns nmatches. */
+int orc_search_for_triangulation(int n_nodes, const int32_t *off1, const int32_t *idx1, const int32_t *off2,
+                                 const int32_t *idx2, const OrcKp *keys1, const float *mvRight1, const uint8_t *has_mp1,
+                                 const uint8_t *desc1, int n1, const OrcKp *keys2, const float *mvRight2,
+                                 const uint8_t *has_mp2, const uint8_t *desc2, int n2, const float *F12, float ex, float ey,
+                                 const float *scale2, const float *sigma2_2, int bOnlyStereo, int mbCheckOrientation,
+                                 int32_t *matches12) {
+    int nmatches = 0;
+    OrcVec rotHist[HISTO_LENGTH];
+    memset(rotHist, 0, sizeof rotHist);
+    uint8_t *vbMatched2 = (uint8_t *)calloc((size_t)(n2 > 0 ? n2 : 1), 1);
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    for (int k = 0; k < n_nodes; k++)
+        for (int i1 = off1[k]; i1 < off1[k + 1]; i1++) {
+            const int idx1_ = idx1[i1];
+            if (has_mp1[idx1_]) continue;
+            const int bStereo1 = mvRight1 && mvRight1[idx1_] >= 0;
+            if (bOnlyStereo)
+                if (!bStereo1) continue;
+            const OrcKp *kp1 = &keys1[idx1_];
+            const uint8_t *d1 = desc1 + 32 * (size_t)idx1_;
+            int bestDist = TH_LOW, bestIdx2 = -1;
+            for (int i2 = off2[k]; i2 < off2[k + 1]; i2++) {
+                const int idx2_ = idx2[i2];
+                if (vbMatched2[idx2_] || has_mp2[idx2_]) continue;
+                const int bStereo2 = mvRight2 && mvRight2[idx2_] >= 0;
+                if (bOnlyStereo)
+                    if (!bStereo2) continue;
+                const int dist = orc_descriptor_distance(d1, desc2 + 32 * (size_t)idx2_);
+                if (dist > TH_LOW || dist > bestDist) continue;
+                const OrcKp *kp2 = &keys2[idx2_];
+                if (!bStereo1 && !bStereo2) {
+                    const float distex = ex - kp2->x, distey = ey - kp2->y;
+                    if (distex * distex + distey * distey < 100 * scale2[kp2->octave]) continue;
+                }
+                if (check_dist_epipolar_line(kp1, kp2, F12, sigma2_2)) { bestIdx2 = idx2_; bestDist = dist; }
+            }
+            if (bestIdx2 >= 0) {
+                matches12[idx1_] = bestIdx2;
+                nmatches++;
+                if (mbCheckOrientation) vec_push(&rotHist[rot_bin(kp1->angle, keys2[bestIdx2].angle)], idx1_);
+            }
+        }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotHist[i].n; j++) { matches12[rotHist[i].v[j]] = -1; nmatches--; }
+        }
+    }
+    free_hist(rotHist);
+    free(vbMatched2);
+    return nmatches;
+}
+
+/* SearchForInitialization   ORBmatcher.cc:401-506   (monocular initialisation; F2 carries the grid)
+ * prev (x, y per key of F1, in/out) = vbPrevMatched.  vnMatches12[i1] (out). */
+int orc_search_for_initialization(const OrcKp *keys1, const uint8_t *desc1, int n1, const OrcFrame *F2, float *prev_xy,
+                                  int windowSize, float mfNNratio, int mbCheckOrientation, int32_t *vnMatches12) {
+    int nmatches = 0;
+    OrcVec rotHist[HISTO_LENGTH];
+    memset(rotHist, 0, sizeof rotHist);
+    OrcVec vIndices2 = {0};
+    int *vMatchedDistance = (int *)malloc(sizeof(int) * (size_t)(F2->N > 0 ? F2->N : 1));
+    int *vnMatches21 = (int *)malloc(sizeof(int) * (size_t)(F2->N > 0 ? F2->N : 1));
+    for (int i = 0; i < F2->N; i++) { vMatchedDistance[i] = INT_MAX; vnMatches21[i] = -1; }
+    for (int i = 0; i < n1; i++) vnMatches12[i] = -1;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = keys1[i1].octave;
+        if (level1 > 0) continue;
+        get_features_in_area(F2, prev_xy[2 * i1], prev_xy[2 * i1 + 1], (float)windowSize, level1, level1, &vIndices2);
+        if (vIndices2.n == 0) continue;
+        const uint8_t *d1 = desc1 + 32 * (size_t)i1;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int c = 0; c < vIndices2.n; c++) {
+            const int i2 = vIndices2.v[c];
+            const int dist = orc_descriptor_distance(d1, F2->desc + 32 * (size_t)i2);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) { bestDist2 = dist; }
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * mfNNratio) {
+                if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                vnMatches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (mbCheckOrientation) vec_push(&rotHist[rot_bin(keys1[i1].angle, F2->keys[bestIdx2].angle)], i1);
+            }
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotHist[i].n; j++) {
+                const int idx1_ = rotHist[i].v[j];
+                if (vnMatches12[idx1_] >= 0) { vnMatches12[idx1_] = -1; nmatches--; }
+            }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)
+        if (vnMatches12[i1] >= 0) {
+            prev_xy[2 * i1] = F2->keys[vnMatches12[i1]].x;
+            prev_xy[2 * i1 + 1] = F2->keys[vnMatches12[i1]].y;
+        }
+    free_hist(rotHist);
+    free(vIndices2.v); free(vMatchedDistance); free(vnMatches21);
+    return nmatches;
+}

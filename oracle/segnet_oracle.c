@@ -93,53 +93,69 @@ void orc_dropout(float *x, int N, int64_t chw, uint32_t site, uint32_t sample0,
 void orc_conv2d(const float *in, int N, int Cin, int H, int W, const float *w,
                 const float *bias, int Cout, int k, int pad, float *out, int acc64) {
     const int64_t plane = (int64_t)H * W;
+    if (!acc64) {
+        /* fp32 accumulation in the order (ci, ky, kx) per output element.  The plane is walked in blocks of
+         * RB output rows so that the accumulator rows stay in L1 while the input channels stream by: a cache
+         * blocking only — every output element still receives its terms in exactly the order above. */
+        int RB = 6144 / (W > 0 ? W : 1);
+        if (RB < 1) RB = 1;
+        if (RB > H) RB = H;
+        const int nrb = (H + RB - 1) / RB;
+#pragma omp parallel for collapse(3) schedule(dynamic)
+        for (int n = 0; n < N; ++n)
+            for (int co = 0; co < Cout; ++co)
+                for (int rb = 0; rb < nrb; ++rb) {
+                    const int r0 = rb * RB, r1 = r0 + RB < H ? r0 + RB : H;
+                    float *o = out + ((int64_t)n * Cout + co) * plane;
+                    for (int64_t i = (int64_t)r0 * W; i < (int64_t)r1 * W; ++i) o[i] = 0.0f;
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        const float *ip = in + ((int64_t)n * Cin + ci) * plane;
+                        for (int ky = 0; ky < k; ++ky)
+                            for (int kx = 0; kx < k; ++kx) {
+                                const float wv = w[(((int64_t)co * Cin + ci) * k + ky) * k + kx];
+                                const int dy = ky - pad, dx = kx - pad;
+                                int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? H - dy : H;
+                                const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? W - dx : W;
+                                if (y0 < r0) y0 = r0;
+                                if (y1 > r1) y1 = r1;
+                                for (int y = y0; y < y1; ++y) {
+                                    const float *ir = ip + (int64_t)(y + dy) * W + dx;
+                                    float *orow = o + (int64_t)y * W;
+                                    for (int x = x0; x < x1; ++x) orow[x] += wv * ir[x];
+                                }
+                            }
+                    }
+                    if (bias) {
+                        const float b = bias[co];
+                        for (int64_t i = (int64_t)r0 * W; i < (int64_t)r1 * W; ++i) o[i] += b;
+                    }
+                }
+        return;
+    }
 #pragma omp parallel for collapse(2) schedule(dynamic)
     for (int n = 0; n < N; ++n) {
         for (int co = 0; co < Cout; ++co) {
             float *o = out + ((int64_t)n * Cout + co) * plane;
-            if (acc64) {
-                double *acc = (double *)malloc(sizeof(double) * plane);
-                for (int64_t i = 0; i < plane; ++i) acc[i] = 0.0;
-                for (int ci = 0; ci < Cin; ++ci) {
-                    const float *ip = in + ((int64_t)n * Cin + ci) * plane;
-                    for (int ky = 0; ky < k; ++ky)
-                        for (int kx = 0; kx < k; ++kx) {
-                            const double wv = w[(((int64_t)co * Cin + ci) * k + ky) * k + kx];
-                            const int dy = ky - pad, dx = kx - pad;
-                            const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? H - dy : H;
-                            const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? W - dx : W;
-                            for (int y = y0; y < y1; ++y) {
-                                const float *ir = ip + (int64_t)(y + dy) * W + dx;
-                                double *ar = acc + (int64_t)y * W;
-                                for (int x = x0; x < x1; ++x) ar[x] += wv * (double)ir[x];
-                            }
+            double *acc = (double *)malloc(sizeof(double) * plane);
+            for (int64_t i = 0; i < plane; ++i) acc[i] = 0.0;
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float *ip = in + ((int64_t)n * Cin + ci) * plane;
+                for (int ky = 0; ky < k; ++ky)
+                    for (int kx = 0; kx < k; ++kx) {
+                        const double wv = w[(((int64_t)co * Cin + ci) * k + ky) * k + kx];
+                        const int dy = ky - pad, dx = kx - pad;
+                        const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? H - dy : H;
+                        const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? W - dx : W;
+                        for (int y = y0; y < y1; ++y) {
+                            const float *ir = ip + (int64_t)(y + dy) * W + dx;
+                            double *ar = acc + (int64_t)y * W;
+                            for (int x = x0; x < x1; ++x) ar[x] += wv * (double)ir[x];
                         }
-                }
-                const double b = bias ? bias[co] : 0.0;
-                for (int64_t i = 0; i < plane; ++i) o[i] = (float)(acc[i] + b);
-                free(acc);
-            } else {
-                for (int64_t i = 0; i < plane; ++i) o[i] = 0.0f;
-                for (int ci = 0; ci < Cin; ++ci) {
-                    const float *ip = in + ((int64_t)n * Cin + ci) * plane;
-                    for (int ky = 0; ky < k; ++ky)
-                        for (int kx = 0; kx < k; ++kx) {
-                            const float wv = w[(((int64_t)co * Cin + ci) * k + ky) * k + kx];
-                            const int dy = ky - pad, dx = kx - pad;
-                            const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? H - dy : H;
-                            const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? W - dx : W;
-                            for (int y = y0; y < y1; ++y) {
-                                const float *ir = ip + (int64_t)(y + dy) * W + dx;
-                                float *orow = o + (int64_t)y * W;
-                                for (int x = x0; x < x1; ++x) orow[x] += wv * ir[x];
-                            }
-                        }
-                }
-                if (bias) {
-                    const float b = bias[co];
-                    for (int64_t i = 0; i < plane; ++i) o[i] += b;
-                }
+                    }
             }
+            const double b = bias ? bias[co] : 0.0;
+            for (int64_t i = 0; i < plane; ++i) o[i] = (float)(acc[i] + b);
+            free(acc);
         }
     }
 }

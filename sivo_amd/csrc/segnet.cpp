@@ -614,6 +614,12 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
     int lanes = S.d_wino4_ws ? S.ws_lanes : 3;
     if (S.profile) lanes = 1;
     while (lanes > 1 && n < 2 * lanes) --lanes;
+    // The op at the fork (pool3 with its fused dropout in SegNet-Standard) produces per-sample values but also writes a
+    // SHARED blob, the pooling switches every sample's decoder reads.  It runs once for all samples on the caller's
+    // stream, ahead of the lane fork, so that exactly one kernel writes the switches and every lane is ordered after it.
+    while (lanes > 1 && fork < S.ops.size() && !S.ops[fork].skip && S.ops[fork].out2 >= 0 && S.blobs[S.ops[fork].out2].shared &&
+           !S.blobs[S.ops[fork].out].shared)
+        ++fork;
     run_ops(S, 0, fork, 0, n, sample0, seed, st, 0);
     if (lanes == 1) {
         run_ops(S, fork, S.ops.size(), 0, n, sample0, seed, st, 0);

@@ -1,0 +1,251 @@
+"""Parity of the configurations bench.py TIMES, at BASELINE.json's full geometry (352 x 1024, full widths):
+SegNet-Standard T = 12 and SegNet-Basic T = 6, default build (the per-sample part of the forward in three lanes
+on three streams, bridge / pooling / upsample fusions on), through the C ABI, against the CPU oracle.
+
+Three statements per (net, image, dropout seed):
+  1. lanes: the three-lane forward is bit-identical to a one-lane forward of the same handle configuration;
+  2. teacher-forced: with the device's pooling switches imposed on the oracle, EVERY logit of EVERY sample agrees
+     within 1e-3 (north star), and every imposed switch that differs from the oracle's own choice is a near-tie;
+  3. free-running: the oracle decides its own switches.  Max pooling is discontinuous, so where the two sides
+     pick different elements of a near-tied window the unpooled value lands on a different pixel and the logits in
+     that switch's decoder receptive field move by O(1).  Asserted: every differing switch is a near-tie of the
+     oracle's own pre-pooling activations, every logit that differs by more than 1e-3 lies inside the receptive
+     field of such a switch (computed by propagating the switch positions through the decoder: Upsample = 2x2
+     block, k x k convolution = k x k dilation), and the class maps disagree on at most 0.3 % of the pixels.
+
+The oracle runs the sample-invariant prefix once (oracle.run_net expand_to) — same values, 11 redundant prefixes less.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+from scipy import ndimage
+
+from oracle import prototxt as oproto
+from sivo_amd import netspec, weights as wts
+from sivo_amd.segnet import BayesianSegNet
+
+pytestmark = pytest.mark.gpu
+H, W = 352, 1024
+LOGIT_TOL = 1e-3
+# A pooling switch may differ between two fp32 evaluations only where the two window elements are closer than the
+# evaluations' own error: 1e-4 relative to the activation magnitude (pre-pooling activations of the deep layers reach
+# +-13 and carry the same ~2e-4 absolute error as the logits; measured gaps: <= 3.4e-5 relative).
+NEAR_TIE = 1e-4
+LOGITS = {"standard": "conv1_1_D", "basic": "dense_softmax_inner_prod"}
+_cache = {}
+
+
+def _text(kind, T):
+    return (netspec.standard_prototxt if kind == "standard" else netspec.basic_prototxt)(T, H, W)
+
+
+def _handle(kind, T, lanes=None, mutate=None, tag=""):
+    """One device handle per configuration for the whole module (Standard T = 12 holds ~22 GB)."""
+    key = (kind, T, lanes, tag)
+    if key not in _cache:
+        text = _text(kind, T)
+        net = oproto.parse(text)
+        w = wts.synth_weights(net["layers"], 42)
+        if mutate:
+            mutate(net, w)
+        if lanes is not None:
+            os.environ["SIVO_LANES"] = str(lanes)
+        try:
+            sn = BayesianSegNet(prototxt=text, weights=wts.pack(net["layers"], w), T=T)
+        finally:
+            os.environ.pop("SIVO_LANES", None)
+        _cache[key] = (net, w, sn)
+    return _cache[key]
+
+
+def _images(kitti_like_bgr):
+    from bench import make_inputs
+    return {"kitti": np.ascontiguousarray(kitti_like_bgr[:H, :W]), "synthetic": make_inputs(H, W)[0]}
+
+
+def _pool_layers(net):
+    return [L for L in net["layers"] if L["type"] == "Pooling"]
+
+
+def _device_run(sn, net, img, seed):
+    prob_sum, logits, _ = sn.forward(torch.from_numpy(img).cuda(), seed, want_logits=True)
+    cls, conf, ent = sn.finalize(prob_sum)
+    torch.cuda.synchronize()
+    masks = {L["top"][1]: sn.blob(L["top"][1]) for L in _pool_layers(net)}
+    return logits.cpu().numpy(), masks, cls.cpu().numpy(), conf.cpu().numpy(), ent.cpu().numpy()
+
+
+@pytest.mark.parametrize("kind,T", [("standard", 12), ("basic", 6)])
+def test_three_lanes_equal_one_lane_at_full_size(kind, T, kitti_like_bgr):
+    net, _, sn3 = _handle(kind, T)
+    _, _, sn1 = _handle(kind, T, lanes=1)
+    img = torch.from_numpy(_images(kitti_like_bgr)["kitti"]).cuda()
+    for seed in (2024, 5):
+        ps3, lg3, _ = sn3.forward(img, seed, want_logits=True)
+        ps1, lg1, _ = sn1.forward(img, seed, want_logits=True)
+        torch.cuda.synchronize()
+        assert torch.equal(lg3, lg1) and torch.equal(ps3, ps1)
+        for L in _pool_layers(net):
+            assert np.array_equal(sn3.blob(L["top"][1]), sn1.blob(L["top"][1])), L["name"]
+    _cache.pop((kind, T, 1, ""))            # free the one-lane handle
+
+
+def _decoder_influence(net, mask_name, dirty_pooled, logits_name):
+    """dirty_pooled: bool (N, Ho, Wo) — pooling windows (any channel) whose switch differs.  Returns bool (N, H, W):
+    the logits pixels that can see the displaced unpooled value."""
+    layers = net["layers"]
+    start = next(i for i, L in enumerate(layers) if L["type"] == "Upsample" and L["bottom"][1] == mask_name)
+    cur = layers[start]["top"][0]
+    d = np.kron(dirty_pooled, np.ones((1, 2, 2), bool))
+    for L in layers[start + 1:]:
+        if not L["bottom"] or L["bottom"][0] != cur:
+            continue
+        if L["type"] == "Convolution":
+            k = L["kernel_size"]
+            if k > 1:
+                d = ndimage.maximum_filter(d, size=(1, k, k), mode="constant", cval=False)
+        elif L["type"] == "Upsample":
+            d = np.kron(d, np.ones((1, 2, 2), bool))
+        elif L["type"] == "Softmax":
+            break
+        cur = L["top"][0]
+        if cur == logits_name and L["type"] == "Convolution":
+            break
+    return d[:, :H, :W]
+
+
+CASES = [("standard", 12, "kitti", 2024), ("standard", 12, "kitti", 7), ("standard", 12, "kitti", 99),
+         ("standard", 12, "synthetic", 2024), ("standard", 12, "synthetic", 7), ("standard", 12, "synthetic", 99),
+         ("basic", 6, "kitti", 2024), ("basic", 6, "kitti", 7), ("basic", 6, "synthetic", 99)]
+
+
+@pytest.mark.parametrize("kind,T,image,seed", CASES)
+def test_timed_configuration_against_the_oracle(oracle, kind, T, image, seed, kitti_like_bgr):
+    net, w, sn = _handle(kind, T)
+    img = _images(kitti_like_bgr)[image]
+    lname = LOGITS[kind]
+    lg, masks, cls, conf, ent = _device_run(sn, net, img, seed)
+    pools = _pool_layers(net)
+
+    # ---- teacher-forced: the device's switches imposed on the oracle; every logit within tolerance
+    flips = {}
+    res = oracle.segment(net, w, img, seed, logits_name=lname, force_masks=masks, flips=flips, shared_prefix=True)
+    n_forced = 0
+    for name, (count, gap, mag) in flips.items():
+        n_forced += count
+        assert count <= 1e-4 * masks[name].size, (name, count)
+        assert gap <= NEAR_TIE * max(mag, 1.0), (name, count, gap, mag)
+    err = np.abs(lg - res["logits"])
+    assert np.abs(res["logits"]).max() > 0.5
+    print(f"[{kind} T={T} {image} seed={seed}] forced: {n_forced} near-tie switches, max|dlogit| {err.max():.3e} "
+          f"(mean {err.mean():.2e}, max|logit| {np.abs(res['logits']).max():.1f})")
+    assert err.max() < LOGIT_TOL
+    np.testing.assert_allclose(conf, res["confidence"], atol=LOGIT_TOL / 2, rtol=0)
+    np.testing.assert_allclose(ent, res["entropy"], atol=5e-3, rtol=0)
+    del res, err
+
+    # ---- free-running: the oracle's own switches
+    pre = [L["bottom"][0] for L in pools]
+    free = oracle.segment(net, w, img, seed, logits_name=lname, shared_prefix=True,
+                          keep=pre + [L["top"][1] for L in pools])
+    dirty = np.zeros((T, H, W), bool)
+    n_free = 0
+    for L in pools:
+        mname = L["top"][1]
+        dm, om = masks[mname].astype(np.int64), free["blobs"][mname].astype(np.int64)
+        x = free["blobs"][L["bottom"][0]]
+        assert dm.shape == om.shape, (mname, dm.shape, om.shape)
+        diff = dm != om
+        if not diff.any():
+            continue
+        n_free += int(diff.sum())
+        assert diff.sum() <= 2e-4 * diff.size, (mname, int(diff.sum()))
+        flat = x.reshape(x.shape[0], x.shape[1], -1)
+        v_o = np.take_along_axis(flat, om.reshape(om.shape[0], om.shape[1], -1), 2).reshape(om.shape)[diff]
+        v_d = np.take_along_axis(flat, dm.reshape(dm.shape[0], dm.shape[1], -1), 2).reshape(dm.shape)[diff]
+        gap = float((v_o - v_d).max())
+        assert gap >= 0 and gap <= NEAR_TIE * max(1.0, float(np.abs(v_o).max())), (mname, gap)
+        d = _decoder_influence(net, mname, diff.any(axis=1), lname)
+        dirty |= d if d.shape[0] == T else np.broadcast_to(d, dirty.shape)
+    err = np.abs(lg - free["logits"]).max(axis=1)                 # (T, H, W)
+    moved = err > LOGIT_TOL
+    outside = moved & ~dirty
+    mism = float((cls != free["classes"]).mean())
+    print(f"[{kind} T={T} {image} seed={seed}] free: {n_free} switches differ, {moved.mean():.3%} of the pixels "
+          f"move by > 1e-3, receptive fields cover {dirty.mean():.2%}, class map differs at {mism:.3%}, "
+          f"max|dlogit| outside the receptive fields {err[~dirty].max():.2e}")
+    assert not outside.any(), f"{int(outside.sum())} pixels differ by > 1e-3 outside every flipped switch's receptive field"
+    assert dirty.mean() < 0.6
+    assert mism <= 3e-3
+    clean = ~dirty.any(axis=0)
+    np.testing.assert_allclose(ent[clean], free["entropy"][clean], atol=5e-3, rtol=0)
+    np.testing.assert_allclose(conf[clean], free["confidence"][clean], atol=LOGIT_TOL / 2, rtol=0)
+
+
+def _scale_weights(factor):
+    """Convolution weights x factor, the BN that follows / factor: the same function with weights (and Winograd-domain
+    products) of another magnitude.  factor is not a power of two, so the roundings differ."""
+    def f(net, w):
+        layers = net["layers"]
+        for i, L in enumerate(layers):
+            if L["type"] == "Convolution" and i + 1 < len(layers) and layers[i + 1]["type"] == "BN":
+                w[L["name"]][0] *= np.float32(factor)
+                w[L["name"]][1] *= np.float32(factor)
+                w[layers[i + 1]["name"]][0] /= np.float32(factor)
+    return f
+
+
+def _bn_spread(net, w):
+    """BN scale log-uniform in [0.1, 10] per channel (trained SegNet BN scales span far more than the default
+    [0.5, 1.5]): channels of very different magnitude meet in every contraction.  E[s^2] = 10.9, so the convolutions
+    are scaled by 10.9^-0.5 to keep activations O(1)."""
+    rng = np.random.default_rng(3)
+    for L in net["layers"]:
+        if L["type"] == "BN":
+            w[L["name"]][0] = np.exp(rng.uniform(np.log(0.1), np.log(10.0), w[L["name"]][0].shape)).astype(np.float32)
+    for L in [L for L in net["layers"] if L["type"] == "Convolution"][1:]:
+        w[L["name"]][0] *= np.float32(0.303)
+
+
+def _bn_offset(net, w):
+    """BN shift +3: every activation carries a large common-mode component, which is what the F(4x4) input transform
+    (4 d0 - 5 d2 + d4) has to cancel — its worst case.  The weights are centred per filter (zero mean over the taps of
+    each input channel), so the offset itself contributes nothing and the logits stay O(1..10)."""
+    for L in net["layers"]:
+        if L["type"] == "BN":
+            w[L["name"]][1] = (w[L["name"]][1] + 3.0).astype(np.float32)
+    for L in [L for L in net["layers"] if L["type"] == "Convolution"][1:]:
+        Wt = w[L["name"]][0]
+        w[L["name"]][0] = (Wt - Wt.mean(axis=(2, 3), keepdims=True)).astype(np.float32) if Wt.shape[2] > 1 else Wt
+
+
+SWEEP = [("w_x0.3", _scale_weights(0.3), "kitti"), ("w_x3", _scale_weights(3.0), "kitti"), ("bn_0.1_10", _bn_spread, "kitti"),
+         ("bn_offset", _bn_offset, "kitti"), ("white", None, "white"), ("black", None, "black")]
+
+
+@pytest.mark.parametrize("tag,mutate,image", SWEEP, ids=[s[0] for s in SWEEP])
+def test_f4x4_margin_robustness_sweep(oracle, tag, mutate, image, kitti_like_bgr):
+    """How much of the 1e-3 logit budget Winograd F(4x4,3x3) uses depends on the dynamic range of weights and
+    activations: weight scale x0.25 / x4, BN scales over two decades, saturated all-255 and all-0 frames (every pooling
+    window an exact tie).  SegNet-Standard, full geometry, T = 2, switches teacher-forced; the error is asserted relative
+    to the logit magnitude of each variant (1e-3 at |logit| <= 30, the range of the reference configuration)."""
+    T = 2
+    net, w, sn = _handle("standard", T, mutate=mutate, tag=tag if mutate else "")
+    img = {"white": np.full((H, W, 3), 255, np.uint8), "black": np.zeros((H, W, 3), np.uint8)}.get(image)
+    if img is None:
+        img = _images(kitti_like_bgr)[image]
+    lg, masks, *_ = _device_run(sn, net, img, 11)
+    flips = {}
+    res = oracle.segment(net, w, img, 11, logits_name="conv1_1_D", force_masks=masks, flips=flips, shared_prefix=True)
+    for name, (count, gap, mag) in flips.items():
+        assert gap <= NEAR_TIE * max(mag, 1.0), (name, count, gap, mag)
+    mag = float(np.abs(res["logits"]).max())
+    err = float(np.abs(lg - res["logits"]).max())
+    print(f"[sweep {tag}/{image}] max|logit| {mag:.2f}, max|dlogit| {err:.3e}, switches forced "
+          f"{sum(c for c, _, _ in flips.values())}")
+    assert np.isfinite(lg).all()
+    assert err < LOGIT_TOL * max(1.0, mag / 30.0)
+    if mutate:
+        _cache.pop(("standard", T, None, tag))
