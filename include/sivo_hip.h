@@ -202,17 +202,146 @@ int sivo_hamming_matrix(const uint8_t *a, int n_a, const uint8_t *b, int n_b, in
 /* Candidate-list argmin with best / second best (the inner loop of every
  * Search* routine, e.g. ORBmatcher.cc:78-104): for query i the candidates are
  * rows cand_idx[cand_off[i] .. cand_off[i+1]) of b, visited in order; ties keep
- * the earlier candidate; empty list -> idx -1, dist 256. */
+ * the earlier candidate; empty list -> idx -1, dist 256.  second_idx (may be
+ * NULL) = the row that holds the second-best distance as the reference's scan
+ * leaves it (its octave is what the ratio rule of ORBmatcher.cc:117-119 compares), -1 if none. */
 int sivo_hamming_argmin2_dev(const uint8_t *d_a, int n_a, const uint8_t *d_b, const int32_t *d_cand_off,
                              const int32_t *d_cand_idx, int32_t *d_best_idx, int32_t *d_best_dist,
-                             int32_t *d_second_dist, void *stream);
+                             int32_t *d_second_dist, int32_t *d_second_idx, void *stream);
 int sivo_hamming_argmin2(const uint8_t *a, int n_a, const uint8_t *b, int n_b, const int32_t *cand_off,
                          const int32_t *cand_idx, int32_t *best_idx, int32_t *best_dist,
-                         int32_t *second_dist);
+                         int32_t *second_dist, int32_t *second_idx);
 /* Brute-force argmin over ALL rows of b for every row of a (best, second). */
 int sivo_hamming_bruteforce_dev(const uint8_t *d_a, int n_a, const uint8_t *d_b, int n_b,
                                 int32_t *d_best_idx, int32_t *d_best_dist, int32_t *d_second_dist,
                                 void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Guided matching — the Search* / Fuse members of SIVO::ORBmatcher
+ * (reference include/orbslam/ORBmatcher.h:44-120) from the PROJECTED point on:
+ * window query on the frame grid (Frame::GetFeaturesInArea, Frame.cc:326-390),
+ * the per-candidate gates, best / second-best Hamming scan, acceptance rule,
+ * the dependence of every iteration on the matches made by the earlier
+ * iterations of the same call, and the 30-bin rotation histogram
+ * (ComputeThreeMaxima, ORBmatcher.cc:1545-1577) — all on the GPU.  What needs
+ * the SLAM object graph stays with the caller and arrives as arrays
+ * (MapPoint::isBad / Observations / PredictScale / GetDescriptor, the cv::Mat
+ * pose algebra, the DBoW2 node lists).
+ *
+ * The reference loops are sequential: iteration i skips the keypoints that
+ * iterations < i matched.  The device reproduces exactly that result by
+ * speculation + repair: every query matches in parallel against the state the
+ * call started with; if two accepted queries chose one keypoint, rounds repeat
+ * in which query i sees the picks of the queries < i of the previous round,
+ * until nothing changes (query i is final after round i at the latest; one
+ * round when there is no collision).
+ * ------------------------------------------------------------------------ */
+typedef struct sivo_mframe *sivo_mframe_t;
+/* The part of Frame / KeyFrame the matcher reads: mvKeysSemantic, mvRight (NULL =
+ * monocular, all -1), mDescriptorsSemantic (n x 32), image bounds mnMinX .. mnMaxY,
+ * mvScaleFactors / mvLevelSigma2 / mvInvLevelSigma2.  Builds mGrid
+ * (AssignFeaturesToGrid, Frame.cc:205-221; 64 x 48 cells) and uploads everything. */
+int sivo_mframe_create(const SivoKeyPoint *keys, int n, const float *u_right, const uint8_t *descriptors,
+                       float min_x, float max_x, float min_y, float max_y, const float *scale_factors,
+                       const float *level_sigma2, const float *inv_level_sigma2, int nlevels, int device,
+                       sivo_mframe_t *out);
+int sivo_mframe_destroy(sivo_mframe_t h);
+/* Frame::GetFeaturesInArea (Frame.cc:326-390) from that grid, host side, in the reference's order. */
+int sivo_mframe_features_in_area(sivo_mframe_t h, float x, float y, float r, int min_level, int max_level,
+                                 int32_t *out, int capacity, int *n_out);
+
+#define SIVO_Q_VALID 1   /* the iteration is not skipped by the per-point tests in front of the window query */
+#define SIVO_Q_BLOCKS 2  /* an accepted match of this query makes the keypoint unavailable to later queries */
+#define SIVO_Q_STEREO 4  /* SearchForTriangulation: bStereo1 */
+typedef struct {
+    float u, v;            /* window centre (projected point; kp1.pt for SearchForTriangulation) */
+    float radius;          /* GetFeaturesInArea r */
+    int32_t lvl_lo, lvl_hi;/* admissible octaves lvl_lo <= octave <= lvl_hi */
+    float ur;              /* projection into the right image (gate 1 and 2) */
+    float gate;            /* gate 1: max |ur - mvRight[k]| */
+    float angle;           /* keypoint angle of the query (rotation histogram) */
+    int32_t flags;         /* SIVO_Q_* */
+} SivoSearchQuery;
+
+typedef struct {
+    int32_t th_dist;           /* accept iff best <= th_dist (accept_lt: best < th_dist) */
+    int32_t accept_lt;
+    int32_t ratio_mode;        /* 0 none; 1 reject iff octave(best) == octave(second) && best > nn_ratio * second
+                                  (ORBmatcher.cc:117-119); 2 accept only iff (float) best < nn_ratio * (float) second (:230, :582) */
+    float nn_ratio;
+    int32_t gate_mode;         /* 0 none; 1 skip k iff mvRight[k] > 0 && |ur - mvRight[k]| > gate (:93-97, :1353-1358);
+                                  2 Fuse chi2: stereo 7.8 / mono 5.99 on the reprojection error (:880-902);
+                                  3 SearchForTriangulation: dist <= th_dist, epipole distance, CheckDistEpipolarLine (:703-719) */
+    int32_t check_orientation; /* mbCheckOrientation */
+    int32_t dynamic;           /* later queries see earlier matches (sequential semantics) */
+    int32_t tie_last;          /* 0: the first candidate wins ties (dist < best); 1: the last (:703 `dist > bestDist` continue) */
+    float F12[9];              /* gate 3: fundamental matrix, row-major */
+    float ex, ey;              /* gate 3: epipole in the train image */
+} SivoSearchRule;
+
+/* The engine.  Candidates of query q: the window query on the train frame's grid when cand_idx is NULL, else the
+ * rows cand_idx[cand_begin[q] .. cand_end[q]) (BoW node lists; several queries may share a range).
+ * blocked (n bytes, may be NULL): keypoints unavailable from the start.
+ * Outputs (any may be NULL): match_query[q] = the keypoint query q is matched with after the rotation check, -1 none;
+ * match_train[k] = the query whose match the call leaves in slot k (-1 untouched, -2 cleared by the rotation
+ * check); best_dist / second_dist per query (256 = none); *n_matches as the reference routine counts it. */
+int sivo_search(sivo_mframe_t train, const SivoSearchQuery *queries, const uint8_t *query_desc, int n_queries,
+                const int32_t *cand_begin, const int32_t *cand_end, const int32_t *cand_idx, int n_cand,
+                const SivoSearchRule *rule, const uint8_t *blocked, int32_t *match_query, int32_t *match_train,
+                int32_t *best_dist, int32_t *second_dist, int *n_matches, int *rounds);
+
+/* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &, th)  (ORBmatcher.cc:44-127).
+ * Per map point: track_in_view = mbTrackInView && !isBad(); proj_x / proj_y / proj_xr / level / view_cos = the
+ * mTrack* fields; mp_desc = GetDescriptor(); mp_obs = Observations().  occ_obs[k] (in/out) = -1 where
+ * F.mvpMapPoints[k] is NULL, else that point's Observations(); match[k] (out) = the map point stored into
+ * F.mvpMapPoints[k], -1 where the call stored nothing. */
+int sivo_search_by_projection_mappoints(sivo_mframe_t F, int n_mp, const uint8_t *track_in_view, const float *proj_x,
+                                        const float *proj_y, const float *proj_xr, const int32_t *level,
+                                        const float *view_cos, const uint8_t *mp_desc, const int32_t *mp_obs, float th,
+                                        float nn_ratio, int32_t *occ_obs, int32_t *match, int *n_matches);
+/* ORBmatcher::SearchByProjection(Frame &Current, const Frame &Last, th, bMono)  (ORBmatcher.cc:1278-1418).
+ * Per last-frame key: valid = map point present && !mvbOutlier; u, v, inv_z = its projection with the current pose
+ * (:1309-1322); last_octave / last_angle; mp_desc; mp_obs.  forward / backward = bForward / bBackward (:1299-1300).
+ * match[k]: >= 0 last-frame key, -2 cleared by the rotation check, -1 untouched. */
+int sivo_search_by_projection_frame(sivo_mframe_t current, int n_last, const uint8_t *valid, const float *u, const float *v,
+                                    const float *inv_z, const int32_t *last_octave, const float *last_angle,
+                                    const uint8_t *mp_desc, const int32_t *mp_obs, float th, int forward, int backward,
+                                    float bf, int check_orientation, int32_t *occ_obs, int32_t *match, int *n_matches);
+/* ORBmatcher::SearchByProjection(Frame &Current, KeyFrame*, sAlreadyFound, th, ORBdist)  (ORBmatcher.cc:1420-1543).
+ * valid = pMP && !isBad && !sAlreadyFound && distance inside the scale-invariance range; occupied[k] (in/out). */
+int sivo_search_by_projection_reloc(sivo_mframe_t current, int n_kf, const uint8_t *valid, const float *u, const float *v,
+                                    const int32_t *pred_level, const float *kf_angle, const uint8_t *mp_desc, float th,
+                                    int orb_dist, int check_orientation, uint8_t *occupied, int32_t *match, int *n_matches);
+/* ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th)  (ORBmatcher.cc:286-399). */
+int sivo_search_by_projection_kf(sivo_mframe_t kf, int n_mp, const uint8_t *valid, const float *u, const float *v,
+                                 const int32_t *pred_level, const uint8_t *mp_desc, int th, uint8_t *matched,
+                                 int32_t *match, int *n_matches);
+/* ORBmatcher::Fuse (ORBmatcher.cc:787-929; scw_variant != 0: :931-1053): best_idx[i] = the keypoint map point i is
+ * fused with (-1: none / bestDist > TH_LOW); the Replace / AddObservation surgery (:909-923) is the caller's. */
+int sivo_fuse(sivo_mframe_t kf, int n_mp, const uint8_t *valid, const float *u, const float *v, const float *ur,
+              const int32_t *pred_level, const uint8_t *mp_desc, float th, int scw_variant, int32_t *best_idx,
+              int32_t *best_dist, int *n_fused);
+/* ORBmatcher::SearchBySim3, one direction (ORBmatcher.cc:1102-1176 / :1178-1252): match_out[i] = best key or -1. */
+int sivo_search_by_sim3_dir(sivo_mframe_t kf, int n, const uint8_t *valid, const float *u, const float *v,
+                            const int32_t *pred_level, const uint8_t *mp_desc, float th, int32_t *match_out);
+/* The BoW-guided routines.  DBoW2 is outside this library: the vocabulary nodes both operands hold arrive as two CSR
+ * lists (node k: keys idx1[off1[k] .. off1[k+1]) of the first operand, idx2[off2[k] .. off2[k+1]) of the second).
+ * SearchByBoW(KeyFrame*, Frame&, ...) (ORBmatcher.cc:161-284): match_f[k] = keyframe key or -1. */
+int sivo_search_by_bow_kf_frame(int n_nodes, const int32_t *off1, const int32_t *idx1, const int32_t *off2,
+                                const int32_t *idx2, const uint8_t *kf_valid, const SivoKeyPoint *keys_kf,
+                                const uint8_t *desc_kf, int n_kf, sivo_mframe_t frame, float nn_ratio,
+                                int check_orientation, int32_t *match_f, int *n_matches);
+/* SearchByBoW(KeyFrame*, KeyFrame*, ...) (ORBmatcher.cc:508-629): matches12[idx1] = idx2 or -1. */
+int sivo_search_by_bow_kf_kf(int n_nodes, const int32_t *off1, const int32_t *idx1, const int32_t *off2,
+                             const int32_t *idx2, const uint8_t *valid1, const SivoKeyPoint *keys1, const uint8_t *desc1,
+                             int n1, const uint8_t *valid2, sivo_mframe_t kf2, float nn_ratio, int check_orientation,
+                             int32_t *matches12, int *n_matches);
+/* SearchForTriangulation (ORBmatcher.cc:631-785): F12 row-major, (ex, ey) the epipole in image 2. */
+int sivo_search_for_triangulation(int n_nodes, const int32_t *off1, const int32_t *idx1, const int32_t *off2,
+                                  const int32_t *idx2, const SivoKeyPoint *keys1, const float *u_right1,
+                                  const uint8_t *has_mp1, const uint8_t *desc1, int n1, sivo_mframe_t kf2,
+                                  const uint8_t *has_mp2, const float F12[9], float ex, float ey, int only_stereo,
+                                  int check_orientation, int32_t *matches12, int *n_matches);
 
 /* Frame::ComputeStereoMatches (reference src/orbslam/Frame.cc:444-629):
  * row-band candidates, octave +-1, disparity window, best Hamming < 100,

@@ -38,6 +38,17 @@ class OpProfile(C.Structure):  # == SivoOpProfile
                 ("kernel_launches", C.c_int32), ("pad_", C.c_int32)]
 
 
+class SearchQuery(C.Structure):   # == SivoSearchQuery (36 bytes)
+    _fields_ = [("u", C.c_float), ("v", C.c_float), ("radius", C.c_float), ("lvl_lo", C.c_int32), ("lvl_hi", C.c_int32),
+                ("ur", C.c_float), ("gate", C.c_float), ("angle", C.c_float), ("flags", C.c_int32)]
+
+
+class SearchRule(C.Structure):    # == SivoSearchRule
+    _fields_ = [("th_dist", C.c_int32), ("accept_lt", C.c_int32), ("ratio_mode", C.c_int32), ("nn_ratio", C.c_float),
+                ("gate_mode", C.c_int32), ("check_orientation", C.c_int32), ("dynamic", C.c_int32), ("tie_last", C.c_int32),
+                ("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float)]
+
+
 class Edge(C.Structure):      # == SivoEdge (48 bytes)
     _fields_ = [("pose", C.c_int32), ("point", C.c_int32), ("stereo", C.c_int32), ("pad_", C.c_int32),
                 ("obs", C.c_double * 3), ("inv_sigma2", C.c_double)]
@@ -76,9 +87,22 @@ SIGNATURES = {
     "sivo_orb_distribute": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _pi32],
     "sivo_hamming_matrix_dev": [_vp, _i, _vp, _i, _vp, _vp],
     "sivo_hamming_matrix": [_vp, _i, _vp, _i, _vp],
-    "sivo_hamming_argmin2_dev": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "sivo_hamming_argmin2": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "sivo_hamming_argmin2_dev": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sivo_hamming_argmin2": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sivo_hamming_bruteforce_dev": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
+    "sivo_mframe_create": [_vp, _i, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _i, _i, C.POINTER(_vp)],
+    "sivo_mframe_destroy": [_vp],
+    "sivo_mframe_features_in_area": [_vp, _f, _f, _f, _i, _i, _vp, _i, _pi32],
+    "sivo_search": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _pi32, _pi32],
+    "sivo_search_by_projection_mappoints": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _pi32],
+    "sivo_search_by_projection_frame": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _f, _i, _vp, _vp, _pi32],
+    "sivo_search_by_projection_reloc": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _pi32],
+    "sivo_search_by_projection_kf": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _pi32],
+    "sivo_fuse": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _pi32],
+    "sivo_search_by_sim3_dir": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp],
+    "sivo_search_by_bow_kf_frame": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _vp, _pi32],
+    "sivo_search_by_bow_kf_kf": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _i, _vp, _pi32],
+    "sivo_search_for_triangulation": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _pi32],
     "sivo_stereo_match": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp],
     "sivo_stereo_match_begin": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp],
     "sivo_stereo_match_cull": [_i, _vp, _vp, _vp, _vp],

@@ -39,7 +39,7 @@ void ORBmatcher::BestTwo(const cv::Mat &queries, const cv::Mat &train, const std
     if (n == 0) return;
     static_assert(sizeof(int) == sizeof(int32_t), "int is 32 bits");
     const int rc = sivo_hamming_argmin2(queries.data, n, train.data, train.rows, candOff.data(), candIdx.data(),
-                                        bestIdx.data(), bestDist.data(), secondDist.data());
+                                        bestIdx.data(), bestDist.data(), secondDist.data(), nullptr);
     if (rc != SIVO_OK) throw std::runtime_error(std::string("ORBmatcher: ") + sivo_last_error());
 }
 

@@ -42,58 +42,46 @@ __global__ __launch_bounds__(256) void hamming_matrix_kernel(const uint4 *__rest
     }
 }
 
-// (dist, position) lexicographic merge of two partial (best, second) states.
-struct Best2 { int best, pos, second; };
-__device__ __forceinline__ Best2 merge(const Best2 x, const Best2 y) {
-    Best2 r;
-    const bool xwins = x.best < y.best || (x.best == y.best && x.pos <= y.pos);
-    r.best = xwins ? x.best : y.best;
-    r.pos = xwins ? x.pos : y.pos;
-    const int loser = xwins ? y.best : x.best;
-    const int s = x.second < y.second ? x.second : y.second;
-    r.second = s < loser ? s : loser;
-    return r;
+// Top-2 of a (key, row) multiset with key = dist << 22 | list position: the reference's sequential scan
+// (`dist < best` moves best to second, `else if dist < second`; ORBmatcher.cc:99-110) ends with best = first minimum
+// and second = first minimum of the rest, which is exactly the two smallest keys.
+struct Top2 { uint32_t k1, k2; int j1, j2; };
+__device__ __forceinline__ void top2_push(Top2 &t, uint32_t k, int j) {
+    if (k < t.k1) { t.k2 = t.k1; t.j2 = t.j1; t.k1 = k; t.j1 = j; }
+    else if (k < t.k2) { t.k2 = k; t.j2 = j; }
 }
 
-// One wave per query: lanes stride over the candidate list; sequential semantics of the
-// reference loop (first minimum wins, second = second smallest of the multiset) are kept by
-// the (dist, list position) order.  cand_idx == nullptr: candidates are rows [0, nB).
+// One wave per query: lanes stride over the candidate list; the butterfly merges the lanes' top-2 sets.
+// cand_idx == nullptr: candidates are rows [0, nB).  Lists hold fewer than 2^22 candidates.
 __global__ __launch_bounds__(256) void hamming_argmin2_kernel(const uint4 *__restrict__ A, int nA,
                                                              const uint4 *__restrict__ B, int nB,
                                                              const int32_t *__restrict__ cand_off,
                                                              const int32_t *__restrict__ cand_idx,
                                                              int32_t *best_idx, int32_t *best_dist,
-                                                             int32_t *second_dist) {
+                                                             int32_t *second_dist, int32_t *second_idx) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nA) return;
     const uint4 a0 = A[(int64_t)q * 2], a1 = A[(int64_t)q * 2 + 1];
     const int c0 = cand_off ? cand_off[q] : 0, c1 = cand_off ? cand_off[q + 1] : nB;
-    Best2 st{256, 0x7fffffff, 256};
-    int my_j = -1;
+    Top2 t{0xffffffffu, 0xffffffffu, -1, -1};
     for (int c = c0 + lane; c < c1; c += 64) {
         const int j = cand_idx ? cand_idx[c] : c;
         const int d = ham256(a0, a1, B[(int64_t)j * 2], B[(int64_t)j * 2 + 1]);
-        if (d < st.best) { st.second = st.best; st.best = d; st.pos = c; my_j = j; }
-        else if (d < st.second) st.second = d;
+        if (d < 256) top2_push(t, ((uint32_t)d << 22) | (uint32_t)(c - c0), j);     // `dist < 256` is the reference's initial test
     }
-    // butterfly over the 64 lanes; carry the row index of the winner along with its position
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-        Best2 o;
-        o.best = __shfl_xor(st.best, off);
-        o.pos = __shfl_xor(st.pos, off);
-        o.second = __shfl_xor(st.second, off);
-        const int oj = __shfl_xor(my_j, off);
-        const Best2 m = merge(st, o);
-        if (m.pos != st.pos) my_j = oj;
-        st = m;
+        const uint32_t ok1 = __shfl_xor(t.k1, off), ok2 = __shfl_xor(t.k2, off);
+        const int oj1 = __shfl_xor(t.j1, off), oj2 = __shfl_xor(t.j2, off);
+        top2_push(t, ok1, oj1);
+        top2_push(t, ok2, oj2);
     }
     if (lane == 0) {
-        best_idx[q] = st.best < 256 || c1 > c0 ? my_j : -1;
-        if (c1 <= c0) best_idx[q] = -1;
-        best_dist[q] = st.best;
-        second_dist[q] = st.second;
+        best_idx[q] = t.j1;
+        best_dist[q] = t.j1 >= 0 ? (int)(t.k1 >> 22) : 256;
+        second_dist[q] = t.j2 >= 0 ? (int)(t.k2 >> 22) : 256;
+        if (second_idx) second_idx[q] = t.j2;
     }
 }
 
@@ -117,14 +105,14 @@ extern "C" int sivo_hamming_matrix_dev(const uint8_t *d_a, int n_a, const uint8_
 
 extern "C" int sivo_hamming_argmin2_dev(const uint8_t *d_a, int n_a, const uint8_t *d_b, const int32_t *d_cand_off,
                                         const int32_t *d_cand_idx, int32_t *d_best_idx, int32_t *d_best_dist,
-                                        int32_t *d_second_dist, void *stream) {
+                                        int32_t *d_second_dist, int32_t *d_second_idx, void *stream) {
     return guarded([&] {
         if (n_a == 0) return SIVO_OK;
         if (!d_a || !d_b || !d_cand_off || !d_cand_idx || !d_best_idx || !d_best_dist || !d_second_dist || n_a < 0)
             throw std::invalid_argument("null argument");
         hipLaunchKernelGGL(hamming_argmin2_kernel, dim3((unsigned)cdiv(n_a, 4)), dim3(256), 0, (hipStream_t)stream,
                            (const uint4 *)d_a, n_a, (const uint4 *)d_b, 0, d_cand_off, d_cand_idx, d_best_idx,
-                           d_best_dist, d_second_dist);
+                           d_best_dist, d_second_dist, d_second_idx);
         SIVO_HIP(hipGetLastError());
         return SIVO_OK;
     });
@@ -139,7 +127,7 @@ extern "C" int sivo_hamming_bruteforce_dev(const uint8_t *d_a, int n_a, const ui
             throw std::invalid_argument("null argument");
         hipLaunchKernelGGL(hamming_argmin2_kernel, dim3((unsigned)cdiv(n_a, 4)), dim3(256), 0, (hipStream_t)stream,
                            (const uint4 *)d_a, n_a, (const uint4 *)d_b, n_b, nullptr, nullptr, d_best_idx, d_best_dist,
-                           d_second_dist);
+                           d_second_dist, nullptr);
         SIVO_HIP(hipGetLastError());
         return SIVO_OK;
     });
@@ -173,7 +161,7 @@ extern "C" int sivo_hamming_matrix(const uint8_t *a, int n_a, const uint8_t *b, 
 
 extern "C" int sivo_hamming_argmin2(const uint8_t *a, int n_a, const uint8_t *b, int n_b, const int32_t *cand_off,
                                     const int32_t *cand_idx, int32_t *best_idx, int32_t *best_dist,
-                                    int32_t *second_dist) {
+                                    int32_t *second_dist, int32_t *second_idx) {
     return guarded([&] {
         if (n_a < 0 || n_b < 0) throw std::invalid_argument("negative size");
         if (n_a == 0) return SIVO_OK;
@@ -181,16 +169,17 @@ extern "C" int sivo_hamming_argmin2(const uint8_t *a, int n_a, const uint8_t *b,
         if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device: libsivo_hip has no CPU fallback");
         const int ncand = cand_off[n_a];
         DevBuf<uint8_t> da((size_t)n_a * 32), db((size_t)n_b * 32);
-        DevBuf<int32_t> doff((size_t)n_a + 1), didx((size_t)ncand), dbi(n_a), dbd(n_a), dsd(n_a);
+        DevBuf<int32_t> doff((size_t)n_a + 1), didx((size_t)ncand), dbi(n_a), dbd(n_a), dsd(n_a), dsi(n_a);
         SIVO_HIP(hipMemcpy(da.p, a, (size_t)n_a * 32, hipMemcpyHostToDevice));
         if (n_b) SIVO_HIP(hipMemcpy(db.p, b, (size_t)n_b * 32, hipMemcpyHostToDevice));
         SIVO_HIP(hipMemcpy(doff.p, cand_off, ((size_t)n_a + 1) * 4, hipMemcpyHostToDevice));
         if (ncand) SIVO_HIP(hipMemcpy(didx.p, cand_idx, (size_t)ncand * 4, hipMemcpyHostToDevice));
-        int rc = sivo_hamming_argmin2_dev(da.p, n_a, db.p, doff.p, didx.p, dbi.p, dbd.p, dsd.p, nullptr);
+        int rc = sivo_hamming_argmin2_dev(da.p, n_a, db.p, doff.p, didx.p, dbi.p, dbd.p, dsd.p, dsi.p, nullptr);
         if (rc) return rc;
         SIVO_HIP(hipMemcpy(best_idx, dbi.p, (size_t)n_a * 4, hipMemcpyDeviceToHost));
         SIVO_HIP(hipMemcpy(best_dist, dbd.p, (size_t)n_a * 4, hipMemcpyDeviceToHost));
         SIVO_HIP(hipMemcpy(second_dist, dsd.p, (size_t)n_a * 4, hipMemcpyDeviceToHost));
+        if (second_idx) SIVO_HIP(hipMemcpy(second_idx, dsi.p, (size_t)n_a * 4, hipMemcpyDeviceToHost));
         return SIVO_OK;
     });
 }

@@ -869,7 +869,7 @@ extern "C" int sivo_stereo_match_begin(sivo_orb_t left, sivo_orb_t right, const 
         if (!idx.empty()) SIVO_HIP(hipMemcpyAsync(base + o_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, st));
         std::vector<int> bi(nL), bd(nL), sd(nL);
         int rc = sivo_hamming_argmin2_dev(base + o_dl, nL, base + o_dr, (const int32_t *)(base + o_off), (const int32_t *)(base + o_idx),
-                                          (int32_t *)(base + o_bi), (int32_t *)(base + o_bd), (int32_t *)(base + o_sd), st);
+                                          (int32_t *)(base + o_bi), (int32_t *)(base + o_bd), (int32_t *)(base + o_sd), nullptr, st);
         if (rc) return rc;
         SIVO_HIP(hipMemcpyAsync(bi.data(), base + o_bi, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
         SIVO_HIP(hipMemcpyAsync(bd.data(), base + o_bd, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
