@@ -1,4 +1,5 @@
-// SIVO::ORBmatcher core over libsivo_hip (reference src/orbslam/ORBmatcher.cc:37-39, 78-121, 1545-1596).
+// SIVO::ORBmatcher, non-template members (reference src/orbslam/ORBmatcher.cc:37-39, 78-121, 1545-1596); the Search* / Fuse
+// members are templates in ORBmatcher.h.
 #include "ORBmatcher.h"
 
 #include <cmath>
@@ -32,31 +33,41 @@ int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b) {
 
 void ORBmatcher::BestTwo(const cv::Mat &queries, const cv::Mat &train, const std::vector<int32_t> &candOff,
                          const std::vector<int32_t> &candIdx, std::vector<int> &bestIdx, std::vector<int> &bestDist,
-                         std::vector<int> &secondDist) const {
+                         std::vector<int> &secondDist, std::vector<int> *secondIdx) const {
     const int n = queries.rows;
     if ((int)candOff.size() != n + 1) throw std::invalid_argument("candOff must hold rows + 1 offsets");
     bestIdx.assign(n, -1); bestDist.assign(n, 256); secondDist.assign(n, 256);
+    if (secondIdx) secondIdx->assign(n, -1);
     if (n == 0) return;
     static_assert(sizeof(int) == sizeof(int32_t), "int is 32 bits");
     const int rc = sivo_hamming_argmin2(queries.data, n, train.data, train.rows, candOff.data(), candIdx.data(),
-                                        bestIdx.data(), bestDist.data(), secondDist.data(), nullptr);
+                                        bestIdx.data(), bestDist.data(), secondDist.data(), secondIdx ? secondIdx->data() : nullptr);
     if (rc != SIVO_OK) throw std::runtime_error(std::string("ORBmatcher: ") + sivo_last_error());
 }
 
 int ORBmatcher::MatchCandidates(const cv::Mat &queries, const std::vector<float> &queryAngles, const cv::Mat &train,
                                 const std::vector<float> &trainAngles, const std::vector<int32_t> &candOff,
-                                const std::vector<int32_t> &candIdx, int thDist, bool useRatio,
-                                std::vector<int> &matches) const {
-    std::vector<int> bi, bd, sd;
-    BestTwo(queries, train, candOff, candIdx, bi, bd, sd);
+                                const std::vector<int32_t> &candIdx, int thDist, RatioRule rule,
+                                const std::vector<int> &trainOctaves, std::vector<int> &matches) const {
+    std::vector<int> bi, bd, sd, si;
+    BestTwo(queries, train, candOff, candIdx, bi, bd, sd, &si);
     const int n = queries.rows;
+    if (rule == RATIO_SAME_LEVEL && (int)trainOctaves.size() != train.rows)
+        throw std::invalid_argument("RATIO_SAME_LEVEL needs one octave per train row");
     matches.assign(n, -1);
     int nmatches = 0;
     std::vector<int> rotHist[30];
     const float factor = 1.0f / HISTO_LENGTH;
     for (int i = 0; i < n; ++i) {
         if (bi[i] < 0 || bd[i] > thDist) continue;
-        if (useRatio && sd[i] < 256 && bd[i] > mfNNratio * sd[i]) continue;
+        if (rule == RATIO_SAME_LEVEL) {
+            // ORBmatcher.cc:117-119: only when best and second lie on the same pyramid level (no second: levels differ)
+            const int bestLevel = trainOctaves[bi[i]], bestLevel2 = si[i] >= 0 ? trainOctaves[si[i]] : -1;
+            if (bestLevel == bestLevel2 && bd[i] > mfNNratio * sd[i]) continue;
+        } else if (rule == RATIO_ALWAYS) {
+            // ORBmatcher.cc:230, :582: static_cast<float>(best) < mfNNratio * static_cast<float>(second)
+            if (!(static_cast<float>(bd[i]) < mfNNratio * static_cast<float>(sd[i]))) continue;
+        }
         matches[i] = bi[i];
         ++nmatches;
         if (mbCheckOrientation) {

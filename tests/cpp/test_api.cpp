@@ -6,6 +6,9 @@
 //        frame.bin = int32 rows, int32 cols, then rows*cols*3 BGR bytes; writes the outputs for
 //        tests/test_gpu_cpp_api.py to compare with the Python binding (same library, bit-identical).
 #include <cmath>
+#include <map>
+#include <mutex>
+#include <set>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,6 +23,7 @@
 #include "orbslam/ORBextractor.h"
 #include "orbslam/ORBmatcher.h"
 #include "orbslam/Optimizer.h"
+#include "orbslam/OptimizerAdapter.h"
 #include "orbslam/Frame.h"
 #include "kitti_io.hpp"
 
@@ -64,6 +68,265 @@ static int run_cpu() {
     CHECK(i1 == 9 && i2 == -1 && i3 == -1);                 // max2 < 0.1 * max1
     std::printf(failures ? "cpu checks FAILED\n" : "cpu checks ok\n");
     return failures;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Minimal stand-ins for the SLAM data model (reference include/orbslam/{MapPoint,Frame,KeyFrame}.h): exactly the members the
+// ORBmatcher / Optimizer templates read, under the reference's names.  The reference's own classes satisfy the same
+// expressions, which is what makes the templates drop-in.
+struct TKeyFrame;
+struct TMapPoint {
+    cv::Mat pos = cv::Mat::zeros(3, 1, CV_32F), normal = cv::Mat::zeros(3, 1, CV_32F), desc = cv::Mat::zeros(1, 32, CV_8UC1);
+    int obs = 1, level = 0;
+    bool bad = false;
+    std::map<const void *, size_t> inKF;
+    TMapPoint *replacedBy = nullptr;
+    // Frame::isInFrustum leaves these (Frame.cc:246-324)
+    bool mbTrackInView = false;
+    float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0, mTrackViewCos = 1;
+    int mnTrackScaleLevel = 0;
+    bool isBad() const { return bad; }
+    int Observations() const { return obs; }
+    cv::Mat GetDescriptor() const { return desc; }
+    cv::Mat GetWorldPos() const { return pos; }
+    cv::Mat GetNormal() const { return normal; }
+    float GetMinDistanceInvariance() const { return 0.01f; }
+    float GetMaxDistanceInvariance() const { return 1e6f; }
+    template <class T> int PredictScale(const float &, T *) const { return level; }
+    template <class KF> bool IsInKeyFrame(KF *kf) const { return inKF.count(kf) != 0; }
+    template <class KF> int GetIndexInKeyFrame(KF *kf) const { auto it = inKF.find(kf); return it == inKF.end() ? -1 : (int)it->second; }
+    template <class KF> void AddObservation(KF *kf, size_t idx) { inKF[kf] = idx; ++obs; }
+    void Replace(TMapPoint *other) { replacedBy = other; bad = true; }
+    // what Optimizer::LocalBundleAdjustment reads / writes (Optimizer.cc:514-562, 863-925)
+    unsigned long mnBALocalForKF = ~0ul;
+    std::map<TKeyFrame *, size_t> observations;
+    std::map<TKeyFrame *, size_t> GetObservations() const { return observations; }
+    void EraseObservation(TKeyFrame *kf) { observations.erase(kf); }
+    void SetWorldPos(const cv::Mat &X) { pos = X.clone(); }
+    int normalUpdates = 0;
+    void UpdateNormalAndDepth() { ++normalUpdates; }
+};
+
+struct TFrame {
+    std::vector<cv::KeyPoint> mvKeysSemantic;
+    std::vector<float> mvRight;
+    cv::Mat mDescriptorsSemantic;
+    std::vector<TMapPoint *> mvpMapPoints;
+    std::vector<bool> mvbOutlier;
+    cv::Mat mTcw = cv::Mat::zeros(4, 4, CV_32F);
+    std::vector<float> mvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
+    float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0, fx = 718.856f, fy = 718.856f, cx = 0, cy = 0, mbf = 386.1448f, mb = 0.5372f;
+    int numSemanticKeys = 0;
+    std::map<unsigned, std::vector<unsigned> > mFeatVec;      // DBoW2::FeatureVector
+    // Frame::SetPose / SetCovariance (reference Frame.cc:237-260)
+    void SetPose(const cv::Mat &T) { mTcw = T.clone(); }
+    cv::Mat GetPose() const { return mTcw; }
+    double mSigmacw[36] = {0};
+    bool covarianceSet = false;
+    void SetCovariance(const double *c) { std::memcpy(mSigmacw, c, sizeof mSigmacw); covarianceSet = true; }
+    void setPose(float tx, float ty, float tz) {
+        for (int i = 0; i < 4; ++i) mTcw.at<float>(i, i) = 1.f;
+        mTcw.at<float>(0, 3) = tx; mTcw.at<float>(1, 3) = ty; mTcw.at<float>(2, 3) = tz;
+    }
+    std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r, int minLevel = -1, int maxLevel = -1) const {
+        SIVO::matcher_detail::DeviceFrame d(*this);
+        std::vector<int32_t> out(mvKeysSemantic.size() + 1);
+        int n = 0;
+        sivo_mframe_features_in_area(d.get(), x, y, r, minLevel, maxLevel, out.data(), (int)out.size(), &n);
+        return std::vector<size_t>(out.begin(), out.begin() + n);
+    }
+};
+
+struct TKeyFrame : TFrame {
+    unsigned long mnId = 0, mnBALocalForKF = ~0ul, mnBAFixedForKF = ~0ul;
+    std::vector<TKeyFrame *> covisible;
+    std::vector<TKeyFrame *> GetVectorCovisibleKeyFrames() const { return covisible; }
+    bool isBad() const { return false; }
+    void EraseMapPointMatch(TMapPoint *p) { for (auto &q : mvpMapPoints) if (q == p) q = nullptr; }
+    std::vector<TMapPoint *> GetMapPointMatches() const { return mvpMapPoints; }
+    TMapPoint *GetMapPoint(size_t i) const { return mvpMapPoints[i]; }
+    std::set<TMapPoint *> GetMapPoints() const {
+        std::set<TMapPoint *> s;
+        for (TMapPoint *p : mvpMapPoints) if (p && !p->isBad()) s.insert(p);
+        return s;
+    }
+    void AddMapPoint(TMapPoint *p, size_t i) { mvpMapPoints[i] = p; }
+    cv::Mat GetRotation() const { cv::Mat R(3, 3, CV_32F); for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R.at<float>(r, c) = mTcw.at<float>(r, c); return R; }
+    cv::Mat GetTranslation() const { cv::Mat t(3, 1, CV_32F); for (int r = 0; r < 3; ++r) t.at<float>(r, 0) = mTcw.at<float>(r, 3); return t; }
+    cv::Mat GetCameraCenter() const { cv::Mat c(3, 1, CV_32F); for (int r = 0; r < 3; ++r) c.at<float>(r, 0) = -mTcw.at<float>(r, 3); return c; }   // R = I here
+    bool IsInImage(const float &x, const float &y) const { return x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY; }
+};
+
+// A frame / keyframe from extracted keys: every key gets depth 20 m (uR = u - bf / 20) and a map point at its back-projection.
+template <class F>
+static void fill_frame(F &f, const std::vector<cv::KeyPoint> &keys, const cv::Mat &desc, const SIVO::ORBextractor &ex, int rows, int cols,
+                       std::vector<TMapPoint> &points) {
+    f.mvKeysSemantic = keys; f.mDescriptorsSemantic = desc.clone(); f.numSemanticKeys = (int)keys.size();
+    f.mvScaleFactors = const_cast<SIVO::ORBextractor &>(ex).GetScaleFactors();
+    f.mvLevelSigma2 = const_cast<SIVO::ORBextractor &>(ex).GetScaleSigmaSquares();
+    f.mvInvLevelSigma2 = const_cast<SIVO::ORBextractor &>(ex).GetInverseScaleSigmaSquares();
+    f.mnMaxX = (float)cols; f.mnMaxY = (float)rows; f.cx = 0.5f * cols; f.cy = 0.5f * rows;
+    f.setPose(0, 0, 0);
+    f.mvRight.resize(keys.size()); f.mvpMapPoints.assign(keys.size(), nullptr); f.mvbOutlier.assign(keys.size(), false);
+    points.resize(keys.size());
+    for (size_t i = 0; i < keys.size(); ++i) {
+        const float z = 20.f;
+        f.mvRight[i] = keys[i].pt.x - f.mbf / z;
+        TMapPoint &p = points[i];
+        p.pos.at<float>(0, 0) = (keys[i].pt.x - f.cx) * z / f.fx; p.pos.at<float>(1, 0) = (keys[i].pt.y - f.cy) * z / f.fy; p.pos.at<float>(2, 0) = z;
+        p.normal.at<float>(2, 0) = 1.f;
+        std::memcpy(p.desc.data, desc.ptr((int)i), 32);
+        p.level = keys[i].octave;
+        f.mvpMapPoints[i] = &p;
+        f.mFeatVec[(unsigned)(i % 17)].push_back((unsigned)i);
+    }
+}
+
+// Every Search* / Fuse template on one pair of identical frames: a map point must find the key it was created from.
+static void run_matcher_templates(const std::vector<cv::KeyPoint> &keys, const cv::Mat &desc, const SIVO::ORBextractor &ex, int rows, int cols) {
+    SIVO::ORBmatcher matcher(0.9f, true);
+    std::vector<TMapPoint> pts1, pts2;
+    TFrame last, cur;
+    fill_frame(last, keys, desc, ex, rows, cols, pts1);
+    fill_frame(cur, keys, desc, ex, rows, cols, pts2);
+    const int n = (int)keys.size();
+    // frame -> frame (ORBmatcher.cc:1278-1418): same pose, empty current frame
+    cur.mvpMapPoints.assign(keys.size(), nullptr);
+    int nm = matcher.SearchByProjection(cur, last, 7.f, false);
+    int self = 0;
+    for (int i = 0; i < n; ++i) self += cur.mvpMapPoints[i] == &pts1[i];
+    CHECK(nm > n * 8 / 10 && self >= nm * 9 / 10);
+    // local map points -> frame (:44-127)
+    std::vector<TMapPoint *> local;
+    for (int i = 0; i < n; ++i) {
+        TMapPoint &p = pts1[i];
+        p.mbTrackInView = true; p.mTrackProjX = keys[i].pt.x; p.mTrackProjY = keys[i].pt.y; p.mTrackProjXR = last.mvRight[i];
+        p.mnTrackScaleLevel = keys[i].octave; p.mTrackViewCos = 0.9999f;
+        local.push_back(&p);
+    }
+    cur.mvpMapPoints.assign(keys.size(), nullptr);
+    nm = matcher.SearchByProjection(cur, local, 1.f);
+    self = 0;
+    for (int i = 0; i < n; ++i) self += cur.mvpMapPoints[i] == &pts1[i];
+    CHECK(nm > n / 2 && self >= nm * 9 / 10);
+    // keyframe stand-ins
+    std::vector<TMapPoint> ptsA, ptsB;
+    TKeyFrame kfA, kfB;
+    fill_frame(kfA, keys, desc, ex, rows, cols, ptsA);
+    fill_frame(kfB, keys, desc, ex, rows, cols, ptsB);
+    for (int i = 0; i < n; ++i) { ptsA[i].inKF[&kfA] = (size_t)i; ptsB[i].inKF[&kfB] = (size_t)i; }
+    // relocalisation (:1420-1543)
+    cur.mvpMapPoints.assign(keys.size(), nullptr);
+    std::set<TMapPoint *> found;
+    nm = matcher.SearchByProjection(cur, &kfA, found, 10.f, 100);
+    CHECK(nm > n * 8 / 10);
+    // BoW keyframe -> frame (:161-284) and keyframe -> keyframe (:508-629)
+    std::vector<TMapPoint *> bow;
+    nm = matcher.SearchByBoW(&kfA, cur, bow);
+    CHECK((int)bow.size() == n && nm > n / 2);
+    std::vector<TMapPoint *> m12;
+    nm = matcher.SearchByBoW(&kfA, &kfB, m12);
+    self = 0;
+    for (int i = 0; i < n; ++i) self += m12[i] == &ptsB[i];
+    CHECK(nm > n / 2 && self >= nm * 9 / 10);
+    // Sim3 with the identity (:1055-1276) and the Sim3 projection search (:286-399)
+    std::vector<TMapPoint *> sim(keys.size(), nullptr);
+    cv::Mat R12 = cv::Mat::zeros(3, 3, CV_32F), t12 = cv::Mat::zeros(3, 1, CV_32F);
+    for (int i = 0; i < 3; ++i) R12.at<float>(i, i) = 1.f;
+    const float s12 = 1.f;
+    nm = matcher.SearchBySim3(&kfA, &kfB, sim, s12, R12, t12, 7.5f);
+    CHECK(nm > n * 8 / 10);
+    std::vector<TMapPoint *> candidates, matched(keys.size(), nullptr);
+    for (TMapPoint &p : ptsB) candidates.push_back(&p);
+    nm = matcher.SearchByProjection(&kfA, kfA.mTcw, candidates, matched, 10);
+    CHECK(nm > n * 8 / 10);
+    // Fuse (:787-929): B's points into A -> every one meets A's own point and one of the two is replaced
+    nm = matcher.Fuse(&kfA, candidates, 3.f);
+    int replaced = 0;
+    for (int i = 0; i < n; ++i) replaced += (ptsA[i].replacedBy != nullptr) + (ptsB[i].replacedBy != nullptr);
+    CHECK(nm > n * 8 / 10 && replaced >= nm * 9 / 10 && replaced <= nm);
+    for (int i = 0; i < n; ++i) { ptsA[i].bad = ptsB[i].bad = false; }
+    std::vector<TMapPoint *> repl(candidates.size(), nullptr);
+    nm = matcher.Fuse(&kfA, kfA.mTcw, candidates, 4.f, repl);
+    CHECK(nm > n * 8 / 10);
+    // triangulation (:631-785): drop the map points, camera 2 moved 1 m to the right (F12 = [t]x up to K; here K-normalised lines are rows)
+    kfA.mvpMapPoints.assign(keys.size(), nullptr); kfB.mvpMapPoints.assign(keys.size(), nullptr);
+    cv::Mat F12 = cv::Mat::zeros(3, 3, CV_32F);
+    F12.at<float>(1, 2) = -1.f; F12.at<float>(2, 1) = 1.f;          // x2' F x1 = y1 - y2: same row
+    kfB.setPose(-1.f, 0, 0);
+    std::vector<std::pair<size_t, size_t> > pairs;
+    nm = matcher.SearchForTriangulation(&kfA, &kfB, F12, pairs, false);
+    CHECK(nm == (int)pairs.size() && nm > n / 2);
+    // monocular initialisation (:401-506)
+    std::vector<cv::Point2f> prev;
+    for (const cv::KeyPoint &k : keys) prev.push_back(k.pt);
+    std::vector<int> init;
+    nm = matcher.SearchForInitialization(last, cur, prev, init, 20);
+    int lvl0 = 0;
+    for (const cv::KeyPoint &k : keys) lvl0 += k.octave == 0;
+    CHECK(nm > lvl0 / 2 && nm <= lvl0);
+}
+
+struct TMap { std::mutex mMutexMapUpdate; };
+
+// Optimizer::PoseOptimization(Frame*) and LocalBundleAdjustment(KeyFrame*, bool*, Map*) through the adapter templates.
+static void run_optimizer_templates(const std::vector<cv::KeyPoint> &keys, const cv::Mat &desc, const SIVO::ORBextractor &ex, int rows, int cols) {
+    // pose-only: map points sit exactly on the keys' back-projections; start 5 cm off; 3 keys carry a gross error
+    std::vector<TMapPoint> pts;
+    TFrame F;
+    fill_frame(F, keys, desc, ex, rows, cols, pts);
+    const int n = (int)keys.size();
+    for (int i = 0; i < n; i += 3) F.mvRight[i] = -1.f;                 // a third of the observations monocular
+    for (int i = 1; i < 10; i += 3) F.mvKeysSemantic[i].pt.x += 25.f;   // stereo outliers
+    F.setPose(0.05f, -0.02f, 0.03f);
+    const int inliers = SIVO::PoseOptimization(&F);
+    CHECK(inliers == n - 3 && F.mvbOutlier[1] && F.mvbOutlier[4] && F.mvbOutlier[7] && !F.mvbOutlier[2]);
+    CHECK(std::fabs(F.mTcw.at<float>(0, 3)) < 2e-3f && std::fabs(F.mTcw.at<float>(1, 3)) < 2e-3f && std::fabs(F.mTcw.at<float>(2, 3)) < 5e-3f);
+    CHECK(F.covarianceSet && F.mSigmacw[0] > 0 && F.mSigmacw[35] > 0);
+    TFrame few;
+    std::vector<TMapPoint> p2;
+    fill_frame(few, std::vector<cv::KeyPoint>(keys.begin(), keys.begin() + 2), desc, ex, rows, cols, p2);
+    CHECK(SIVO::PoseOptimization(&few) == 0);                             // fewer than 3 correspondences (:409-411)
+
+    // local BA: three keyframes 0.5 m apart seeing the same points; keyframe 0 is the map's first one (held fixed)
+    std::vector<TMapPoint> mp;
+    TKeyFrame kf[3];
+    std::vector<TMapPoint> tmp[3];
+    for (int k = 0; k < 3; ++k) {
+        fill_frame(kf[k], keys, desc, ex, rows, cols, tmp[k]);
+        kf[k].mnId = (unsigned long)k;
+        kf[k].setPose(-0.5f * k, 0, 0);
+    }
+    mp = tmp[0];                                                          // the shared points (world = camera-0 coordinates)
+    for (int i = 0; i < n; ++i) {
+        mp[i].observations.clear();
+        for (int k = 0; k < 3; ++k) {
+            // exact observation of point i in keyframe k: x shifts by fx * tx / z, the right coordinate by the same amount
+            const float z = 20.f, dx = kf[k].fx * (-0.5f * k) / z;
+            kf[k].mvKeysSemantic[i].pt.x = keys[i].pt.x + dx;
+            kf[k].mvRight[i] = keys[i].pt.x + dx - kf[k].mbf / z;
+            kf[k].mvpMapPoints[i] = &mp[i];
+            mp[i].observations[&kf[k]] = (size_t)i;
+        }
+    }
+    kf[2].covisible = {&kf[1], &kf[0]};
+    const float truth = kf[2].mTcw.at<float>(0, 3);
+    kf[2].mTcw.at<float>(0, 3) += 0.04f;                                  // perturb the current keyframe
+    for (int i = 0; i < n; i += 2) mp[i].pos.at<float>(2, 0) += 0.1f;    // and half of the points
+    kf[1].mvKeysSemantic[3].pt.y += 40.f;                                 // one gross observation -> erased
+    TMap map;
+    bool stop = false;
+    SIVO::LocalBundleAdjustment(&kf[2], &stop, &map);
+    CHECK(std::fabs(kf[2].mTcw.at<float>(0, 3) - truth) < 5e-3f);
+    CHECK(kf[0].mTcw.at<float>(0, 3) == 0.f);                             // keyframe 0 fixed
+    CHECK(kf[1].mvpMapPoints[3] == nullptr && mp[3].observations.count(&kf[1]) == 0 && mp[3].observations.size() == 2);
+    CHECK(mp[0].normalUpdates == 1 && std::fabs(mp[0].pos.at<float>(2, 0) - 20.f) < 0.05f);
+    CHECK(kf[2].covarianceSet && kf[2].mSigmacw[0] > 0);
+    stop = true;
+    const float before = kf[2].mTcw.at<float>(0, 3);
+    kf[2].mTcw.at<float>(0, 3) += 0.04f;
+    SIVO::LocalBundleAdjustment(&kf[2], &stop, &map);                     // pbStopFlag set: returns before optimising (:757-761)
+    CHECK(kf[2].mTcw.at<float>(0, 3) == before + 0.04f);
 }
 
 static int run_gpu(int argc, char **argv) {
@@ -115,6 +378,9 @@ static int run_gpu(int argc, char **argv) {
     std::vector<cv::KeyPoint> none; cv::Mat nd, empty;
     left(empty, nomask, none, nd);                         // empty image: returns silently
     CHECK(none.empty());
+
+    run_matcher_templates(kl, dl, left, rows, cols);
+    run_optimizer_templates(kl, dl, left, rows, cols);
 
     // Frame (Frame.cc:85-181): grey left, right = left shifted by 8 px (disparity 8), the network on the colour frame.
     // Results go to files; the Python test rebuilds the same frame through the Python binding and compares bit for bit.
@@ -181,7 +447,9 @@ static int run_gpu(int argc, char **argv) {
     }
     off[n] = (int32_t)idx.size();
     std::vector<int> matches;
-    const int nm = matcher.MatchCandidates(dl, ang, dr, ang, off, idx, SIVO::ORBmatcher::TH_LOW, true, matches);
+    std::vector<int> octs(n);
+    for (int i = 0; i < n; ++i) octs[i] = kl[i].octave;
+    const int nm = matcher.MatchCandidates(dl, ang, dr, ang, off, idx, SIVO::ORBmatcher::TH_LOW, SIVO::ORBmatcher::RATIO_SAME_LEVEL, octs, matches);
     int self = 0;
     for (int i = 0; i < n; ++i) self += matches[i] == i;
     CHECK(nm > n * 8 / 10 && self == nm);
