@@ -83,8 +83,10 @@ int sivo_segnet_num_params(const char *prototxt_text, size_t prototxt_len, size_
  *   d_bgr       device, H*W*3 u8, BGR interleaved, already cropped to H x W
  *               (preprocessImage, :164-178: no scaling, no mean)
  *   d_prob_sum  device, classes*H*W fp32: sum over the n_samples of the
- *               per-pixel softmax (the tensor the all-reduce carries); the mean
- *               of extractMeanConfidence (:278-297) is this / T_total
+ *               per-pixel softmax (the tensor the all-reduce carries), accumulated
+ *               in f64 and rounded once to fp32; the mean of extractMeanConfidence
+ *               (:278-297) is this / T_total up to that rounding (6e-8 relative; the
+ *               single-device entry points sivo_segnet_segment[_dev] keep f64 throughout)
  *   d_logits    device or NULL, n_samples*classes*H*W fp32 pre-softmax scores
  *   d_prob      device or NULL, n_samples*classes*H*W fp32 softmax ("prob" blob)
  * Dropout masks: Philox4x32-10 keyed on (seed; site, global sample, element). */
@@ -115,6 +117,12 @@ int sivo_mc_variance_dev(const float *d_prob, int T, int classes, int64_t hw, co
  * classes: H*W u8, confidence / entropy: H*W f64 (row-major, like MatXu/MatXd). */
 int sivo_segnet_segment(sivo_segnet_t h, const uint8_t *bgr_hwc, int rows, int cols, uint64_t seed,
                         uint8_t *classes, double *confidence, double *entropy);
+
+/* segmentImage with the frame already in HBM and the maps left there (no synchronisation): all T samples, then the
+ * mean over the T float probabilities in f64 exactly as extractMeanConfidence (bayesian_segnet.cpp:278-297) — the
+ * probability sum never goes through fp32 memory — and classes / confidence / entropy.  d_bgr: H*W*3 u8. */
+int sivo_segnet_segment_dev(sivo_segnet_t h, const uint8_t *d_bgr, uint64_t seed, uint8_t *d_classes,
+                            double *d_confidence, double *d_entropy, void *stream);
 
 /* Copy a named blob of the last forward to the host (fp32; pooling masks are
  * returned as the flat input-plane index Caffe stores, as fp32).  shape =

@@ -28,6 +28,8 @@
 #include <stdint.h>
 
 #include <cstdlib>
+#include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "segnet_kernels.hpp"
@@ -265,6 +267,166 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_kernel(Wino4Args a, int pti
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same batched GEMM on the bf16 matrix cores, fp32 in / fp32 out: "bf16x6".
+//
+// fp32 MFMA runs at 1/16 of the bf16 rate, and this GEMM is the one kernel of the path that sits on the MFMA
+// roofline.  An fp32 value is the exact sum of three bf16 values up to 2^-24 relative (x = x1 + x2 + x3,
+// x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2); bf16 keeps fp32's exponent, so no range problem), and
+// a product of two bf16 values is exact in fp32.  So
+//     v u  =  v1 u1 + (v1 u2 + v2 u1) + (v1 u3 + v2 u2 + v3 u1)  +  O(2^-23 |v u|)
+// is six v_mfma_f32_16x16x32_bf16 with fp32 accumulation per 32 channels (6 x ~17 cycles) instead of eight
+// v_mfma_f32_16x16x4_f32 (8 x 32 cycles): 2.5x fewer matrix-core cycles at the accuracy of the fp32 chain (emulated on
+// Winograd-domain data: rms error 5.0e-6 vs 8.0e-6 for the sequential fp32 FMA chain it replaces; three products
+// only — "bf16x3" — would be 15x worse and is not used).  The logits tests state the tolerance.
+//
+// V stays what the transform kernels write (fp32 [36][C][Pp]): every thread loads its 2 x 8 channel values of the
+// next K-chunk with coalesced dword loads one chunk ahead, splits them in registers (v_cvt_pk_bf16_f32) and stores
+// three 16-byte pieces per (tile, channel octet) into LDS.  U is split once on the host and stored as the LDS image of
+// its stage (LDS-DMA).  Operand pieces are laid out so that every ds_read_b128 / ds_write_b128 is conflict-free.
+// Workgroup 128 tiles x 128 couts, 4 waves x (64 x 64), K-chunk 32: V single-buffered (24 KB, it goes through
+// registers anyway), U double-buffered (2 x 24 KB) -> 72 KB, two workgroups per CU whose phases interleave.
+// ---------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int X6_KC = 32;                       // channels per stage (= K of one MFMA)
+constexpr int X6_PLANE = 128 * X6_KC * 2;       // bytes of one bf16 plane of a 128-row operand stage (8 KB)
+constexpr int X6_LDS = 3 * X6_PLANE * 3;        // V + 2 x U
+
+// 16-byte piece (row r of the 128-row operand tile, channel octet kg) -> slot of the plane.  Rows are grouped by
+// MFMA block (r & 3) so that a block's 16 rows x 4 octets are 64 consecutive pieces; inside, the octet is XOR-ed /
+// rotated so that the four 16-lane groups of a ds_read_b128 and the eight 8-lane groups of a ds_write_b128 each cover
+// distinct bank quads.
+__host__ __device__ __forceinline__ int x6_slot(int r, int kg) {
+    const int mt = r & 3, q = r >> 2;
+    return 4 * (mt * 32 + q) + (((kg ^ ((q & 8) ? 3 : 0)) + mt) & 3);
+}
+
+// ABL (diagnostics, tools/x6_probe.py): 1 no V loads after the first chunk, 2 no split / LDS stores after it, 4 no U DMA
+// after it, 8 no MFMAs, 16 no epilogue stores.  0 = the production kernel.
+template <int ABL>
+__global__ __launch_bounds__(256, 2) void wino4_gemm_x6_kernel(Wino4Args a, const uint4 *__restrict__ Ux, int ptiles, int ktiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds6[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    const int kt = j % ktiles, pair = (j / ktiles) * 8 + xcd;
+    if (pair >= 36 * ptiles) return;
+    const int xi = pair / ptiles, pt = pair % ptiles;
+    const int nchunks = a.C / X6_KC;
+    const float *Vg = a.V + ((int64_t)xi * a.C) * a.Pp + (int64_t)pt * 128;
+    // U image: [xi][kt][chunk][plane][512 pieces]
+    const uint4 *Ug = Ux + ((int64_t)(xi * ktiles + kt) * nchunks) * (3 * 512);
+
+    unsigned char *Vl = lds6;                                   // 3 planes
+    auto Ul = [&](int buf) { return lds6 + 3 * X6_PLANE * (1 + buf); };
+
+    // V of a stage = 32 channel rows x 128 tiles fp32 (16 KB): four 16-byte loads per thread, a wave-load covering two whole
+    // 512-byte channel rows (lanes 0-31 / 32-63).  Thread (wave w, half h = lane >> 5, tile quad tq = lane & 31) holds
+    // x[i][t] = V[32 chunk + 8 w + 2 i + h][4 tq + t]: for each of its four tiles the 4 channels {8 w + 2 i + h} — half of
+    // the (tile, octet w) piece.  The order of the 8 channels inside a piece is free as long as U uses the same one
+    // (x6_channel_of): element e of octet kg <-> channel 8 kg + 2 (e & 3) + (e >> 2).
+    const int vh = lane >> 5, vtq = lane & 31;
+    f32x4 vreg[4];
+    auto load_v = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            vreg[i] = *reinterpret_cast<const f32x4 *>(Vg + (int64_t)(chunk * X6_KC + wave * 8 + 2 * i + vh) * a.Pp + 4 * vtq);
+    };
+    auto dma_u = [&](int chunk, int buf) {
+        const uint4 *src = Ug + (int64_t)chunk * (3 * 512);
+        unsigned char *dst = Ul(buf);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int kib = wave * 6 + i;                        // 24 KiB: six 1 KiB copies per wave
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + kib * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)(dst + kib * 1024), 16, 0, 0);
+        }
+    };
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    auto split_store_v = [&]() {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bf16x4 p1, p2, p3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x = vreg[i][t];
+                const __bf16 x1 = (__bf16)x;
+                const float r1 = x - (float)x1;
+                const __bf16 x2 = (__bf16)r1;
+                const float r2 = r1 - (float)x2;
+                p1[i] = x1; p2[i] = x2; p3[i] = (__bf16)r2;
+            }
+            unsigned char *dst = Vl + x6_slot(4 * vtq + t, wave) * 16 + 8 * vh;
+            *reinterpret_cast<bf16x4 *>(dst) = p1;
+            *reinterpret_cast<bf16x4 *>(dst + X6_PLANE) = p2;
+            *reinterpret_cast<bf16x4 *>(dst + 2 * X6_PLANE) = p3;
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // MFMA block mt of this wave takes the tiles 64 wm + 4 i + mt (i = A row), block nt the couts 64 wn + 4 j + nt:
+    // the accumulators of a lane are then runs of 4 consecutive tiles per cout (f32x4 stores, as in the fp32 kernel)
+    int a_off[4], b_off[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        a_off[t] = x6_slot(64 * wm + 4 * li + t, lk) * 16;
+        b_off[t] = x6_slot(64 * wn + 4 * li + t, lk) * 16;
+    }
+
+    // Pipeline: at the start of chunk c's MFMA phase U(c + 1) goes by LDS-DMA into the other U buffer and V(c + 1) into
+    // registers; both have the whole phase to arrive and are waited for (vmcnt(0)) at the top of the next chunk.
+    dma_u(0, 0);
+    load_v(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int cur = chunk & 1;
+        __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): this chunk's V values in registers, its U stage in LDS
+        __syncthreads();                             // every wave is done reading the previous chunk's V stage
+        if (!(ABL & 2) || chunk == 0) split_store_v();
+        __syncthreads();                             // V stage + U stage visible
+        if (chunk + 1 < nchunks) {
+            if (!(ABL & 4)) dma_u(chunk + 1, cur ^ 1);
+            if (!(ABL & 1)) load_v(chunk + 1);
+        }
+        const unsigned char *Us = Ul(cur);
+        bf16x8 bfrag[4][3];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bfrag[nt][pl] = *reinterpret_cast<const bf16x8 *>(Us + pl * X6_PLANE + b_off[nt]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            bf16x8 af[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const bf16x8 *>(Vl + pl * X6_PLANE + a_off[mt]);
+            // smallest terms first: (3,1) (2,2) (1,3) (2,1) (1,2) (1,1)
+#pragma unroll
+            for (int term = 0; term < 6; ++term) {
+                constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    if (ABL & 8) acc[mt][nt][0] += (float)af[PA[term]][0] + (float)bfrag[nt][PB[term]][1];
+                    else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA[term]], bfrag[nt][PB[term]], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float *Mg = a.M + ((int64_t)xi * a.Kp + (int64_t)kt * 128) * a.Pp + (int64_t)pt * 128;
+    if ((ABL & 16) && acc[0][0][0] != 12345.678f) return;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        float *row = Mg + (int64_t)(wn * 64 + 4 * li + nt) * a.Pp + wm * 64 + 16 * lk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<f32x4 *>(row + 4 * r) = f32x4{acc[0][nt][r], acc[1][nt][r], acc[2][nt][r], acc[3][nt][r]};
+    }
+}
+
 // 1-D output transform A^T m
 __device__ __forceinline__ void wino4_at(const float m0, const float m1, const float m2, const float m3, const float m4,
                                          const float m5, float *s) {
@@ -473,6 +635,45 @@ void wino4_pack_weights(const float *W, int cin, int cout, std::vector<float> &o
         }
 }
 
+// bf16x6: U [36][Cin][Kp] fp32 -> three bf16 planes per (position, 128-cout tile, 32-channel chunk), in the order the
+// kernel's LDS stage has them: [xi][kt][chunk][plane][x6_slot(cout row, channel octet)][8 channels]
+bool wino4_x6_supported(int cin, int cout_pad) { return cin % X6_KC == 0 && cout_pad % 128 == 0; }
+
+static inline uint16_t bf16_rne(float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_float(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float x;
+    std::memcpy(&x, &u, 4);
+    return x;
+}
+
+void wino4_x6_pack_weights(const std::vector<float> &U, int cin, int Kp, std::vector<uint16_t> &out) {
+    const int ktiles = Kp / 128, nchunks = cin / X6_KC;
+    out.assign((size_t)36 * ktiles * nchunks * 3 * 512 * 8, 0);
+    for (int xi = 0; xi < 36; ++xi)
+        for (int kt = 0; kt < ktiles; ++kt)
+            for (int ch = 0; ch < nchunks; ++ch) {
+                uint16_t *stage = out.data() + ((size_t)((xi * ktiles + kt) * nchunks + ch)) * (3 * 512 * 8);
+                for (int r = 0; r < 128; ++r)
+                    for (int kg = 0; kg < 4; ++kg)
+                        for (int e = 0; e < 8; ++e) {
+                            // element e of octet kg <-> channel 8 kg + 2 (e & 3) + (e >> 2): the order the kernel's V loads produce
+                            const float x = U[((size_t)xi * cin + ch * X6_KC + kg * 8 + 2 * (e & 3) + (e >> 2)) * Kp + kt * 128 + r];
+                            const uint16_t x1 = bf16_rne(x);
+                            const float r1 = x - bf16_to_float(x1);
+                            const uint16_t x2 = bf16_rne(r1);
+                            const float r2 = r1 - bf16_to_float(x2);
+                            const size_t o = (size_t)x6_slot(r, kg) * 8 + e;
+                            stage[o] = x1; stage[512 * 8 + o] = x2; stage[2 * 512 * 8 + o] = bf16_rne(r2);
+                        }
+            }
+}
+
 // samples per group so that V + M of a group stay within `budget` bytes (memory-side cache), at least 1
 int wino4_group(int N, int cin, int cout, int H, int W, size_t budget) {
     const int64_t tiles = (int64_t)((H + 3) / 4) * (W / 4);
@@ -501,6 +702,10 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
                        const Wino4Plan *plan) {
     static bool attr_set = false;
     if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_x6_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS);
+        for (const void *f : {(const void *)wino4_gemm_x6_kernel<1>, (const void *)wino4_gemm_x6_kernel<2>, (const void *)wino4_gemm_x6_kernel<4>,
+                              (const void *)wino4_gemm_x6_kernel<8>, (const void *)wino4_gemm_x6_kernel<16>, (const void *)wino4_gemm_x6_kernel<7>})
+            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_kernel<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_STAGE * 4);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_bridge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
@@ -541,11 +746,29 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         static const int min_blocks = std::getenv("SIVO_WINO4_MINBLOCKS") ? std::atoi(std::getenv("SIVO_WINO4_MINBLOCKS")) : 1024;
         int tile = nblocks(128, 128) >= min_blocks ? 0 : nblocks(64, 128) >= min_blocks ? 1 : 2;
         if (force_tile >= 0) tile = force_tile;
+        // bf16x6 (128 x 128 tiles only): whenever the layer has the split weights and the launch is not tiny
+        static const int x6_min_blocks = std::getenv("SIVO_X6_MINBLOCKS") ? std::atoi(std::getenv("SIVO_X6_MINBLOCKS")) : 128;
+        if (c.wt_x6 && nblocks(128, 128) >= x6_min_blocks) {
+            const int pt6 = (a.P + 127) / 128, kt6 = a.Kp / 128, pairs6 = (36 * pt6 + 7) / 8;
+            const dim3 g6((unsigned)(pairs6 * kt6 * 8));
+            const uint4 *u6 = reinterpret_cast<const uint4 *>(c.wt_x6);
+            switch ((c.variant >> 12) & 31) {          // ablations for tools/x6_probe.py; 0 in production
+                case 1: hipLaunchKernelGGL(wino4_gemm_x6_kernel<1>, g6, dim3(256), X6_LDS, s, a, u6, pt6, kt6); break;
+                case 2: hipLaunchKernelGGL(wino4_gemm_x6_kernel<2>, g6, dim3(256), X6_LDS, s, a, u6, pt6, kt6); break;
+                case 4: hipLaunchKernelGGL(wino4_gemm_x6_kernel<4>, g6, dim3(256), X6_LDS, s, a, u6, pt6, kt6); break;
+                case 7: hipLaunchKernelGGL(wino4_gemm_x6_kernel<7>, g6, dim3(256), X6_LDS, s, a, u6, pt6, kt6); break;
+                case 8: hipLaunchKernelGGL(wino4_gemm_x6_kernel<8>, g6, dim3(256), X6_LDS, s, a, u6, pt6, kt6); break;
+                case 16: hipLaunchKernelGGL(wino4_gemm_x6_kernel<16>, g6, dim3(256), X6_LDS, s, a, u6, pt6, kt6); break;
+                default: hipLaunchKernelGGL(wino4_gemm_x6_kernel<0>, g6, dim3(256), X6_LDS, s, a, u6, pt6, kt6);
+            }
+            tile = -1;
+        }
         const int bm = tile == 0 ? 128 : 64, bn = tile == 2 ? 64 : 128;
         const int pt_n = (a.P + bm - 1) / bm, kt_n = a.Kp / bn, pairs8 = (36 * pt_n + 7) / 8;
         const dim3 ggrid((unsigned)(pairs8 * kt_n * 8));
         const size_t glds = (size_t)2 * G_KC * (bm + bn) * 4;
-        if (tile == 0) hipLaunchKernelGGL((wino4_gemm_kernel<128, 128>), ggrid, dim3(256), glds, s, a, pt_n, kt_n);
+        if (tile < 0) {}
+        else if (tile == 0) hipLaunchKernelGGL((wino4_gemm_kernel<128, 128>), ggrid, dim3(256), glds, s, a, pt_n, kt_n);
         else if (tile == 1) hipLaunchKernelGGL((wino4_gemm_kernel<64, 128>), ggrid, dim3(256), glds, s, a, pt_n, kt_n);
         else hipLaunchKernelGGL((wino4_gemm_kernel<64, 64>), ggrid, dim3(256), glds, s, a, pt_n, kt_n);
         if (e) (void)hipEventRecord(e[2], s);

@@ -21,6 +21,7 @@
 #include <memory>
 #include <sstream>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "common.hpp"
@@ -51,6 +52,7 @@ struct Op {
     // conv
     int ks = 0, cin = 0, cout = 0, cout_pad = 0;
     float *d_w = nullptr, *d_scale = nullptr, *d_shift = nullptr;
+    void *d_wx6 = nullptr;     // wino4: the transformed weights as three bf16 planes (bf16x6 GEMM); null = fp32 MFMA GEMM
     bool relu = false;
     bool v2 = false;           // conv_v2.hip kernel + weight layout
     bool wino = false;         // conv_wino.hip kernel + pre-transformed weights
@@ -182,6 +184,15 @@ void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int 
         wino4f_pack_weights(W, cin, cout, wt, &op.cout_pad);
     } else if (op.wino4) {
         wino4_pack_weights(W, cin, cout, wt, &op.cout_pad);
+        // SIVO_GEMM=f32 keeps the batched GEMM on the fp32 matrix-core instructions; default: bf16x6 (conv_wino4.hip)
+        static const bool gemm_f32 = std::getenv("SIVO_GEMM") && std::string(std::getenv("SIVO_GEMM")) == "f32";
+        if (!gemm_f32 && wino4_x6_supported(cin, op.cout_pad)) {
+            std::vector<uint16_t> planes;
+            wino4_x6_pack_weights(wt, cin, op.cout_pad, planes);
+            op.d_wx6 = dev_alloc<uint16_t>(planes.size());
+            S.owned.push_back(op.d_wx6);
+            SIVO_HIP(hipMemcpy(op.d_wx6, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
         op.wino4_group = wino4_group(S.T, cin, cout, H, Wd, wino4_budget);
         S.wino4_ws_floats = std::max(S.wino4_ws_floats, wino4_workspace_floats(op.wino4_group, cin, cout, H, Wd));
     } else if (op.wino) {
@@ -525,6 +536,7 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                 a.out = fptr(bo);
                 a.N = N; a.Cin = op.cin; a.H = bi.H; a.W = bi.W; a.Cout = op.cout; a.CoutPad = op.cout_pad;
                 a.relu = op.relu; a.drop_site = op.drop_site; a.sample0 = sample0; a.seed = seed;
+                a.wt_x6 = op.d_wx6;
                 if (op.pool_op >= 0) {
                     const Op &P = S.ops[op.pool_op];
                     a.pool_out = fptr(S.blobs[P.out]); a.pool_mask = mptr(S.blobs[P.out2]); a.pool_drop_site = P.drop_site;
@@ -601,6 +613,7 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
     }
 }
 
+// d_prob_sum may be null when the caller finalizes from the logits itself (segment / segment_dev: the exact f64 mean).
 void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t seed, float *d_prob_sum,
              float *d_logits, float *d_prob, hipStream_t st) {
     const int64_t hw = (int64_t)S.H * S.W;
@@ -647,7 +660,7 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
     if (S.profile) S.pending = true;
     const Blob &lg = S.blobs[S.logits_blob];
     if (lg.shared) throw std::runtime_error("the network has no test-time dropout: nothing to sample");
-    launch_mc_reduce((const float *)lg.d, n, S.classes, hw, d_prob_sum, d_prob, 0, st);
+    if (d_prob_sum || d_prob) launch_mc_reduce((const float *)lg.d, n, S.classes, hw, d_prob_sum ? d_prob_sum : S.d_prob_sum, d_prob, 0, st);
     if (d_logits)
         SIVO_HIP(hipMemcpyAsync(d_logits, lg.d, (size_t)n * lg.chw() * sizeof(float), hipMemcpyDeviceToDevice, st));
     SIVO_HIP(hipGetLastError());
@@ -812,13 +825,27 @@ extern "C" int sivo_segnet_segment(sivo_segnet_t h, const uint8_t *bgr, int rows
         hipStream_t st = h->stream;
         SIVO_HIP(hipMemcpy2DAsync(h->d_image, (size_t)h->W * 3, bgr + ((size_t)y_tl * cols + x_tl) * 3, (size_t)cols * 3,
                                   (size_t)h->W * 3, (size_t)h->H, hipMemcpyHostToDevice, st));
-        forward(*h, h->d_image, h->T, 0, seed, h->d_prob_sum, nullptr, nullptr, st);
+        forward(*h, h->d_image, h->T, 0, seed, nullptr, nullptr, nullptr, st);
         const int64_t hw = (int64_t)h->H * h->W;
-        launch_mc_finalize(h->d_prob_sum, h->classes, hw, h->T, h->d_classes, h->d_conf, h->d_ent, st);
+        launch_mc_reduce_finalize((const float *)h->blobs[h->logits_blob].d, h->T, h->classes, hw, h->d_classes, h->d_conf, h->d_ent, st);
         if (classes) SIVO_HIP(hipMemcpyAsync(classes, h->d_classes, hw, hipMemcpyDeviceToHost, st));
         if (confidence) SIVO_HIP(hipMemcpyAsync(confidence, h->d_conf, hw * sizeof(double), hipMemcpyDeviceToHost, st));
         if (entropy) SIVO_HIP(hipMemcpyAsync(entropy, h->d_ent, hw * sizeof(double), hipMemcpyDeviceToHost, st));
         SIVO_HIP(hipStreamSynchronize(st));
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_segnet_segment_dev(sivo_segnet_t h, const uint8_t *d_bgr, uint64_t seed, uint8_t *d_classes,
+                                       double *d_confidence, double *d_entropy, void *stream) {
+    return guarded([&] {
+        if (!h || !d_bgr || !d_classes || !d_confidence || !d_entropy) throw std::invalid_argument("null argument");
+        DeviceGuard dg(h->device);
+        hipStream_t st = (hipStream_t)stream;
+        forward(*h, d_bgr, h->T, 0, seed, nullptr, nullptr, nullptr, st);
+        launch_mc_reduce_finalize((const float *)h->blobs[h->logits_blob].d, h->T, h->classes, (int64_t)h->H * h->W, d_classes,
+                                  d_confidence, d_entropy, st);
+        SIVO_HIP(hipGetLastError());
         return SIVO_OK;
     });
 }
@@ -881,7 +908,7 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
         for (size_t i = 0; i < h->ops.size(); ++i) {
             const Op &op = h->ops[i];
             if (op.wino4) {
-                const char *kn[3] = {"wino4_input_kernel", "wino4_gemm_kernel", op.w4_bridge ? "wino4_bridge_kernel" : "wino4_output_kernel"};
+                const char *kn[3] = {"wino4_input_kernel", op.d_wx6 ? "wino4_gemm_x6_kernel" : "wino4_gemm_kernel", op.w4_bridge ? "wino4_bridge_kernel" : "wino4_output_kernel"};
                 const Blob &bi = h->blobs[op.in];
                 const double tiles = (double)((bi.H + 3) / 4) * (bi.W / 4), kp = wino4_cout_pad(op.cout);
                 const double bytes[3] = {4.0 * (op.cin * (double)bi.H * bi.W + 36.0 * op.cin * tiles),
@@ -949,6 +976,14 @@ extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, i
         SIVO_HIP(hipEventCreate(&e0)); SIVO_HIP(hipEventCreate(&e1));
         float *dws = wino4 ? dev_alloc<float>(wino4_workspace_floats(w4group, Cin, Cout, H, W)) : nullptr;
         if (wino4) a.CoutPad = wino4_cout_pad(Cout);
+        void *dx6 = nullptr;
+        if (wino4 && (variant & 2048) && wino4_x6_supported(Cin, a.CoutPad)) {      // bf16x6 GEMM on the same (random) U
+            std::vector<uint16_t> planes;
+            wino4_x6_pack_weights(hw, Cin, a.CoutPad, planes);
+            dx6 = dev_alloc<uint16_t>(planes.size());
+            SIVO_HIP(hipMemcpy(dx6, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+            a.wt_x6 = dx6;
+        }
         if (wino4f) a.CoutPad = Cout;
         auto go = [&] { if (wino4f) launch_conv_wino4f(a, nullptr); else if (wino4) launch_conv_wino4(a, dws, w4group, nullptr); else if (wino) launch_conv_wino(a, wcfg, nullptr); else if (v2) launch_conv2(a, ks, nullptr); else launch_conv(a, ks, nullptr); };
         if (wino) a.CoutPad = Cout;
@@ -960,7 +995,7 @@ extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, i
         float ms = 0;
         SIVO_HIP(hipEventElapsedTime(&ms, e0, e1));
         *ms_out = ms / iters;
-        (void)hipFree(din); (void)hipFree(dout); (void)hipFree(dw); (void)hipFree(ds); (void)hipFree(dws);
+        (void)hipFree(din); (void)hipFree(dout); (void)hipFree(dw); (void)hipFree(ds); (void)hipFree(dws); (void)hipFree(dx6);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         return SIVO_OK;
     });

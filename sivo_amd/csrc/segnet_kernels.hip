@@ -480,6 +480,58 @@ int launch_mc_reduce(const float *logits, int n, int C, int64_t hw, float *prob_
     return 0;
 }
 
+// Single-device form of the whole Monte-Carlo post-processing (extractMeanConfidence + computeClasses +
+// computeMaxConfidence + computeClassificationEntropy, bayesian_segnet.cpp:180-203, 262-297) in ONE pass over the logits:
+// per pixel, softmax of each of the T samples (fp32, as the Softmax layer), the T float probabilities summed and divided
+// by T in f64 exactly as the reference's f32 -> f64 cast + mean does, then argmax / max / entropy.  No probability sum
+// goes through memory, so nothing is rounded to fp32 on the way.  One pixel per thread (360 k threads at 352 x 1024).
+template <int CMAX>
+__global__ __launch_bounds__(256) void mc_reduce_finalize_kernel(const float *__restrict__ logits, int T, int C, int64_t hw,
+                                                                 uint8_t *classes, double *confidence, double *entropy) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hw) return;
+    double sum[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) sum[c] = 0.0;
+    for (int s = 0; s < T; ++s) {
+        const float *lp = logits + (int64_t)s * C * hw + p;
+        float x[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) x[c] = lp[(int64_t)c * hw];
+        float m = x[0];
+#pragma unroll
+        for (int c = 1; c < CMAX; ++c)
+            if (c < C) m = x[c] > m ? x[c] : m;
+        float den = 0.f;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) { x[c] = expf(x[c] - m); den = __fadd_rn(den, x[c]); }
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) sum[c] += (double)__fdiv_rn(x[c], den);
+    }
+    const double dT = (double)T;
+    int best = 0;
+    double bv = sum[0] / dT;
+    double ent = bv == 0 ? 0 : -1.0 * bv * log2(bv);
+#pragma unroll
+    for (int c = 1; c < CMAX; ++c)
+        if (c < C) {
+            const double v = sum[c] / dT;
+            if (v > bv) { bv = v; best = c; }
+            ent += v == 0 ? 0 : -1.0 * v * log2(v);
+        }
+    classes[p] = (uint8_t)best;
+    confidence[p] = bv;
+    entropy[p] = ent;
+}
+void launch_mc_reduce_finalize(const float *logits, int T, int C, int64_t hw, uint8_t *classes, double *confidence,
+                               double *entropy, hipStream_t s) {
+    hipLaunchKernelGGL((mc_reduce_finalize_kernel<16>), dim3((unsigned)((hw + 255) / 256)), dim3(256), 0, s, logits, T, C, hw, classes,
+                       confidence, entropy);
+}
+
 // mean = sum / T (f64); argmax with first-wins ties; max; entropy in bits with the
 // exact-zero guard of computeEntropy (bayesian_segnet.cpp:38-44).
 __global__ void mc_finalize_kernel(const float *prob_sum, int C, int64_t hw, int T, uint8_t *classes,

@@ -30,6 +30,7 @@ struct ConvArgs {
     float *pool_out = nullptr;
     uint8_t *pool_mask = nullptr;
     int pool_drop_site = -1;
+    const void *wt_x6 = nullptr;   // F(4x4,3x3) three-kernel path: the weights split into three bf16 planes (bf16x6 GEMM), or null
     int variant;               // diagnostics only (sivo_debug_conv): bit0 no epilogue stores, bit1 no LDS commit, bit2 no global loads
 };
 int conv_cout_tile(int ks, int cout);  // BN the launcher will pick (CoutPad must be a multiple)
@@ -53,6 +54,9 @@ bool wino4_supported(int ks, int cin, int cout, int H, int W);
 int wino4_cout_pad(int cout);
 void wino4_pack_weights(const float *W, int cin, int cout, std::vector<float> &out, int *cout_pad);
 int wino4_group(int N, int cin, int cout, int H, int W, size_t budget_bytes);
+// bf16x6 GEMM (fp32 operands split into three bf16 planes, six products, fp32 accumulate)
+bool wino4_x6_supported(int cin, int cout_pad);
+void wino4_x6_pack_weights(const std::vector<float> &U, int cin, int cout_pad, std::vector<uint16_t> &out);
 size_t wino4_workspace_floats(int group, int cin, int cout, int H, int W);
 // fused Winograd F(4x4,3x3), 64 couts per workgroup (conv_wino4f.hip)
 bool wino4f_supported(int ks, int cin, int cout, int H, int W);
@@ -97,6 +101,8 @@ void launch_lrn(const float *in, float *out, int N, int C, int64_t hw, int local
                 hipStream_t s);
 int launch_mc_reduce(const float *logits, int n, int C, int64_t hw, float *prob_sum, float *prob, int accumulate,
                      hipStream_t s);
+void launch_mc_reduce_finalize(const float *logits, int T, int C, int64_t hw, uint8_t *classes, double *confidence,
+                               double *entropy, hipStream_t s);
 void launch_mc_finalize(const float *prob_sum, int C, int64_t hw, int T, uint8_t *classes, double *confidence,
                         double *entropy, hipStream_t s);
 void launch_mc_variance(const float *prob, int T, int C, int64_t hw, const uint8_t *classes, double *variance,

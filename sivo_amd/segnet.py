@@ -100,6 +100,12 @@ class BayesianSegNet:
                                          out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), _stream()))
         return out
 
+    def segment_into(self, d_bgr, seed, out):
+        """segmentImage on device-resident data: out = (classes u8, confidence f64, entropy f64) cuda tensors (H, W)."""
+        check(lib().sivo_segnet_segment_dev(self._h, d_bgr.data_ptr(), C.c_uint64(seed), out[0].data_ptr(), out[1].data_ptr(),
+                                            out[2].data_ptr(), _stream()))
+        return out
+
     # -- host path == segmentImage --------------------------------------------------------
     def segment_image(self, image_bgr, seed=0):
         """segmentImage(const cv::Mat&, MatXu&, MatXd&, MatXd&) (bayesian_segnet.cpp:299-318)."""

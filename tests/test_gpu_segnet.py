@@ -131,7 +131,7 @@ def test_full_size_frame_logits_within_tolerance(oracle, kind, kitti_like_bgr):
     total = 0
     for name, (count, gap, mag) in flips.items():
         total += count
-        assert count <= 1e-4 * masks[name].size and gap <= 2e-5 * max(mag, 1.0), (name, count, gap, mag)
+        assert count <= 1e-4 * masks[name].size and gap <= 1e-4 * max(mag, 1.0), (name, count, gap, mag)
     err = np.abs(logits.cpu().numpy() - res["logits"])
     print(f"{kind}: {total} pooling switches differ (near-ties); max |dlogit| = {err.max():.3e}, mean = {err.mean():.3e}, "
           f"max |logit| = {np.abs(res['logits']).max():.2f}")
