@@ -13,10 +13,13 @@ sharded over the ranks (global sample index keys the dropout masks, so the resul
 depend on N), each rank recomputes the sample-invariant prefix, one all-reduce(SUM) of the
 15x352x1024 fp32 probability sums per frame.  T is fixed -> "scaling": "strong".
 
-Prints ONE JSON line (rank 0).  `roofline`: the dominant kernel (the convolution
-instantiation with the largest share of GPU time), algorithmic FLOPs per launch / mean
-launch duration measured with HIP events on the launch stream during the timed region,
-against the dense fp32 MFMA peak (157.3 TFLOP/s).  `cpu_baseline`: this repo's CPU oracle
+Prints ONE JSON line (rank 0).  `roofline`: the dominant kernel (the MFMA kernel with the
+largest share of GPU time): executed matrix-core FLOP/s from HIP events on its launch stream
+during the timed region against the dense peak of the instruction type it issues (frac <= 1),
+with the algorithmic (direct-convolution) rate beside it and the whole-frame matrix-core
+utilisation.  At N = 1 the line also carries `configs` (BASELINE configs[1], [3] on one GPU and
+[4], each with its own roofline and the tests that cover it) and `host_boundary_fps` (the
+reference's segmentImage boundary, PCIe included).  `cpu_baseline`: this repo's CPU oracle
 (a restatement of the reference path — not Caffe/cuDNN/OpenCV, which are unavailable)
 timed on the host cores for a bounded sample and extrapolated to the same frame.
 """
@@ -107,6 +110,141 @@ def cpu_baseline(kind, T, H, W, text, w, bgr, left, right, budget_note):
                        f"MC reduction {t_mc:.2f}s + ORB stereo pair and matching {t_orb:.2f}s on {kind} {H}x{W}")}
 
 
+# Matrix-core work of a kernel family relative to the ALGORITHMIC (direct-convolution) FLOPs it is credited with, and the
+# dense peak of the instruction type it issues (/opt/skills/guides/MI355X_MICROARCH.md):
+#   Winograd F(4x4,3x3) multiplies 36 instead of 144 per 4x4 outputs (1/4), F(2x2,3x3) 16 instead of 36 (1/2.25);
+#   the bf16x6 GEMM issues six bf16 MFMA products per fp32 product (6/4 of the algorithmic count, on the bf16 pipe).
+BF16_MFMA_PEAK_TFLOPS = 2500.0
+KERNEL_CLASS = [("wino4_gemm_x6", 6.0 / 4.0, BF16_MFMA_PEAK_TFLOPS, "bf16 MFMA (fp32 operands split into 3 bf16 planes, 6 products, fp32 accumulate)"),
+                ("wino4_gemm", 1.0 / 4.0, FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA"),
+                ("conv_wino4f", 1.0 / 4.0, FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA"),
+                ("conv_wino", 1.0 / 2.25, FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA"),
+                ("conv_mfma", 1.0, FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA")]
+
+
+def kernel_class(name):
+    for prefix, ratio, peak, what in KERNEL_CLASS:
+        if name.startswith(prefix):
+            return ratio, peak, what
+    return None
+
+
+def aggregate(rows):
+    agg = {}
+    for p in rows:
+        if not p["launches"]:
+            continue
+        k = agg.setdefault(p["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+        k["ms"] += p["ms_total"]; k["launches"] += p["kernel_launches"]
+        k["flops"] += p["flops_per_sample"] * p["samples"] * p["launches"]
+        k["bytes"] += p["bytes_per_sample"] * p["samples"] * p["launches"]
+    return agg
+
+
+def traffic_from_profiles(dom_name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (bench cannot collect PMC itself)."""
+    for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
+            hits = [v for k, v in tj.items() if k.split("<")[0] == dom_name.split("<")[0] and isinstance(v, dict) and v.get("bytes")]
+            if dom_name in tj and tj[dom_name].get("bytes"):
+                hits = [tj[dom_name]]
+            if hits:
+                return max(hits, key=lambda v: v.get("dispatches", 0))["bytes"], "profiles/" + cand
+        except Exception:
+            pass
+    return None, None
+
+
+def mfma_roofline(prof_timed, prof_detail, n_timed_frames, n_detail, ms_per_frame, note):
+    """roofline object of a SegNet run.  frac = EXECUTED matrix-core FLOP/s of the dominant kernel / the dense peak of the
+    instruction type it issues (<= 1).  The algorithmic (direct-convolution) rate is reported beside it."""
+    by_kernel = aggregate(prof_detail)
+    timed = aggregate(prof_timed) if prof_timed else {}
+    mfma = {k: v for k, v in timed.items() if v["flops"] > 0 and v["ms"] > 0 and kernel_class(k)}
+    frames = n_timed_frames
+    if not mfma:
+        mfma = {k: v for k, v in by_kernel.items() if v["flops"] > 0 and v["ms"] > 0 and kernel_class(k)}
+        frames = n_detail
+    dom_name, dom = max(mfma.items(), key=lambda kv: kv[1]["ms"])
+    ratio, peak, what = kernel_class(dom_name)
+    alg = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    executed = alg * ratio
+    # whole frame: time the matrix cores would need at peak for the executed work of every MFMA kernel / frame time
+    t_peak_ms = 0.0
+    for k, v in by_kernel.items():
+        c = kernel_class(k)
+        if c and v["flops"] > 0:
+            t_peak_ms += v["flops"] / n_detail * c[0] / (c[1] * 1e12) * 1e3
+    traffic, tsrc = traffic_from_profiles(dom_name)
+    return {"bound": "mfma", "kernel": "sivo::" + dom_name, "instruction": what,
+            "achieved": round(executed, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(executed / peak, 4),
+            "algorithmic_tflops": round(alg, 2), "algorithmic_ratio": round(1.0 / ratio, 4),
+            "traffic": traffic, "traffic_source": f"{tsrc} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, mean bytes per launch)" if traffic else None,
+            "launches_per_frame": dom["launches"] / max(frames, 1), "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
+            "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
+            "whole_frame_mfma_util": round(t_peak_ms / ms_per_frame, 4),
+            "kernels_ms_per_frame": {k: round(v["ms"] / n_detail, 3) for k, v in sorted(by_kernel.items())},
+            "segnet_kernel_ms_per_frame": round(sum(v["ms"] for v in by_kernel.values()) / n_detail, 3),
+            "note": note}
+
+
+def time_segnet(sn, frame, steps, warmup, barrier, profile_every=8, events=True):
+    """Warm up, time `steps` calls of frame(seed) between barriers, return (elapsed s, MFMA-kernel rows of the timed region,
+    all-kernel rows of min(steps, 10) further untimed single-lane frames)."""
+    for i in range(warmup):
+        frame(1000 + i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if events and i % profile_every == 0:
+            sn.profile(True, mfma_only=True, reset=(i == 0))
+        elif events and i % profile_every == 1:
+            sn.profile(False)
+        frame(2000 + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof_timed = sn.profile_read() if events else []
+    n_detail = min(steps, 10)
+    sn.profile(True, reset=True)
+    for i in range(n_detail):
+        frame(3000 + i)
+    barrier()
+    prof = sn.profile_read()
+    sn.profile(False)
+    return elapsed, prof_timed, prof, n_detail
+
+
+def ba_scene(seed=99, n_kf=20, n_pts=3000):
+    """20 keyframes along a forward trajectory, 3000 points in a frustum box, KITTI-00 intrinsics,
+    an edge for every (keyframe, point) that projects into the image (80 % stereo)."""
+    from sivo_amd.optimizer import EDGE_DTYPE
+    rng = np.random.default_rng(seed)
+    fx = fy = 718.856; cx, cy, bf = 498.692, 173.215, 386.1448
+    poses = np.zeros((n_kf, 12))
+    for k in range(n_kf):
+        yaw = np.deg2rad(rng.uniform(-2, 2))
+        Rwc = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+        twc = np.array([rng.normal(0, 0.05), rng.normal(0, 0.02), 1.0 * k])
+        poses[k, :9] = Rwc.T.ravel(); poses[k, 9:] = -Rwc.T @ twc
+    pts = np.stack([rng.uniform(-20, 20, n_pts), rng.uniform(-5, 5, n_pts), rng.uniform(2, 62, n_pts)], 1)
+    parts = []
+    for k in range(n_kf):
+        pc = pts @ poses[k, :9].reshape(3, 3).T + poses[k, 9:]
+        z = pc[:, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u = fx * pc[:, 0] / z + cx; v = fy * pc[:, 1] / z + cy
+        idx = np.nonzero((z > 0.5) & (z < 80) & (u >= 0) & (u < 1024) & (v >= 0) & (v < 352))[0]
+        e = np.zeros(len(idx), EDGE_DTYPE)
+        sig = 1.2 ** rng.integers(0, 8, len(idx))
+        e["pose"], e["point"], e["stereo"] = k, idx, rng.random(len(idx)) < 0.8
+        e["obs"][:, 0] = u[idx] + rng.normal(0, sig); e["obs"][:, 1] = v[idx] + rng.normal(0, sig)
+        e["obs"][:, 2] = u[idx] - bf / z[idx] + rng.normal(0, sig)
+        e["inv_sigma2"] = 1.0 / (sig * sig)
+        parts.append(e)
+    return poses, pts, np.concatenate(parts), (fx, fy, cx, cy, bf)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +256,8 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--no-orb", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--configs", default="all", help="N = 1 only: which further BASELINE configs to measure after the main one and "
+                    "report under \"configs\": all | none | comma list of basic,t48,ba,host (rocprofv3 runs use one at a time)")
     ap.add_argument("--per-layer", action="store_true", help="print the per-layer event timings to stderr")
     args = ap.parse_args()
 
@@ -147,21 +287,26 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     T, H, W = args.T, args.height, args.width
-    # contiguous shard of the T samples: the first T % world ranks take one extra
     sample0, n_local = parallel.shard_samples(T, world, rank)
     t_alloc = max(2, parallel.max_shard(T, world))
-    text = (netspec.standard_prototxt if args.net == "standard" else netspec.basic_prototxt)(t_alloc, H, W)
-    layers = netspec.parse_layers(text)        # (the oracle is imported by the cpu_baseline leg only)
-    w = wts.synth_weights(layers, 42)
-    sn = BayesianSegNet(prototxt=text, weights=wts.pack(layers, w), T=t_alloc, device=local)
 
+    def build_net(kind, t):
+        text = (netspec.standard_prototxt if kind == "standard" else netspec.basic_prototxt)(t, H, W)
+        layers = netspec.parse_layers(text)        # (the oracle is imported by the cpu_baseline leg only)
+        w = wts.synth_weights(layers, 42)
+        return text, w, BayesianSegNet(prototxt=text, weights=wts.pack(layers, w), T=t, device=local)
+
+    text, w, sn = build_net(args.net, t_alloc)
     bgr, left, right = make_inputs(H, W)
     d_bgr = torch.from_numpy(bgr).cuda()
     d_left = torch.from_numpy(left).cuda()
     d_right = torch.from_numpy(right).cuda()
     prob_sum = torch.zeros((sn.classes, H, W), dtype=torch.float32, device="cuda")
-    maps = (torch.empty((H, W), dtype=torch.uint8, device="cuda"), torch.empty((H, W), dtype=torch.float64, device="cuda"),
-            torch.empty((H, W), dtype=torch.float64, device="cuda"))
+
+    def new_maps():
+        return (torch.empty((H, W), dtype=torch.uint8, device="cuda"), torch.empty((H, W), dtype=torch.float64, device="cuda"),
+                torch.empty((H, W), dtype=torch.float64, device="cuda"))
+    maps = new_maps()
     do_orb = (rank == 0) and not args.no_orb
     if do_orb:
         ex_l, ex_r = orb.ORBextractor(device=local), orb.ORBextractor(device=local)
@@ -194,12 +339,16 @@ def main():
     def frame(seed):
         res = {}
         th = orb_extract(res) if do_orb else []          # ORB of this frame runs beside the network
-        if n_local:
-            sn.forward_into(d_bgr, seed, prob_sum, n_samples=n_local, sample0=sample0)
+        if world == 1:
+            # one device holds all T samples: segmentImage on device-resident data (f64 mean, no probability sum in memory)
+            sn.segment_into(d_bgr, seed, maps)
         else:
-            prob_sum.zero_()                               # more ranks than samples: contribute nothing
-        parallel.all_reduce_prob_sum(prob_sum)
-        sn.finalize(prob_sum, t_total=T, out=maps)
+            if n_local:
+                sn.forward_into(d_bgr, seed, prob_sum, n_samples=n_local, sample0=sample0)
+            else:
+                prob_sum.zero_()                           # more ranks than samples: contribute nothing
+            parallel.all_reduce_prob_sum(prob_sum)
+            sn.finalize(prob_sum, t_total=T, out=maps)
         if do_orb:
             cls_host = maps[0].cpu().numpy()              # 360 KB D2H; waits for this frame's class map
             [t.join() for t in th]
@@ -211,32 +360,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        frame(1000 + i)
-    barrier()
-    # timed region: only the MFMA kernels are bracketed by HIP events (the roofline of the dominant kernel is measured
-    # live here, on every 8th frame); the full per-kernel breakdown comes from a few extra, untimed frames afterwards
-    # Every 8th timed frame carries HIP events around its MFMA kernels (that is what `roofline` is measured on): with
-    # one or two MC samples per GPU the ~60 event records of a frame cost 6 % of it (SIVO_BENCH_NO_EVENTS=1: none at all).
+    # Every 8th timed frame carries HIP events around its MFMA kernels (that is what `roofline` is measured on; those frames
+    # issue the forward in one lane so that a launch has the GPU to itself); SIVO_BENCH_NO_EVENTS=1: none at all.
     PROFILE_EVERY = 8
     events = os.environ.get("SIVO_BENCH_NO_EVENTS") != "1"
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if events and i % PROFILE_EVERY == 0:
-            sn.profile(True, mfma_only=True, reset=(i == 0))
-        elif events and i % PROFILE_EVERY == 1:
-            sn.profile(False)
-        frame(2000 + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof_timed = sn.profile_read()
-    n_detail = min(args.steps, 10)
-    sn.profile(True, reset=True)
-    for i in range(n_detail):
-        frame(3000 + i)
-    barrier()
-    prof = sn.profile_read()
-    sn.profile(False)
+    elapsed, prof_timed, prof, n_detail = time_segnet(sn, frame, args.steps, args.warmup, barrier, PROFILE_EVERY, events)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -244,7 +372,7 @@ def main():
 
     if rank == 0:
         fps = args.steps / elapsed
-        # per-kernel aggregation of the event-timed launches
+        ms_frame = 1e3 * elapsed / args.steps
         if args.per_layer:
             for p in prof:
                 ms = p["ms_total"] / max(p["launches"], 1)
@@ -253,69 +381,88 @@ def main():
                 fl = p["flops_per_sample"] * p["samples"]
                 print(f'{p["layer"]:14s} {p["kernel"]:42s} N={p["samples"]:2d} {ms:8.4f} ms  {fl / ms / 1e9 if ms else 0:7.1f} TFLOP/s  '
                       f'{p["bytes_per_sample"] * p["samples"] / ms / 1e6 if ms else 0:8.1f} GB/s(alg)', file=sys.stderr)
-        def aggregate(rows):
-            agg = {}
-            for p in rows:
-                if not p["launches"]:
-                    continue
-                k = agg.setdefault(p["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
-                k["ms"] += p["ms_total"]; k["launches"] += p["kernel_launches"]
-                k["flops"] += p["flops_per_sample"] * p["samples"] * p["launches"]
-                k["bytes"] += p["bytes_per_sample"] * p["samples"] * p["launches"]
-            return agg
-        by_kernel = aggregate(prof)                  # every kernel, from the untimed detail frames
-        timed = aggregate(prof_timed)                # MFMA kernels, from the timed region
-        conv = {k: v for k, v in by_kernel.items() if k.startswith("conv_") or k.startswith("wino4_")}
-        mfma = {k: v for k, v in timed.items() if v["flops"] > 0 and v["ms"] > 0}
-        if not mfma:       # SIVO_BENCH_NO_EVENTS=1: no events in the timed frames, take the untimed detail frames
-            mfma = {k: v for k, v in by_kernel.items() if v["flops"] > 0 and v["ms"] > 0}
-        dom_name, dom = max(mfma.items(), key=lambda kv: kv[1]["ms"])
-        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        # Winograd executes fewer MFMA multiplies than the direct convolution it computes: F(2x2,3x3) 16 per 4 outputs
-        # instead of 36 (algorithmic/2.25), F(4x4,3x3) 36 per 16 outputs instead of 144 (algorithmic/4).  `achieved`
-        # stays the ALGORITHMIC (direct-convolution) count of SURVEY 8d; mfma_util prices the executed flops.
-        exec_ratio = 0.25 if dom_name.startswith("wino4") else (1 / 2.25) if dom_name.startswith("conv_wino") else 1.0
-        conv_ms = sum(v["ms"] for v in conv.values()); conv_fl = sum(v["flops"] for v in conv.values())
-        all_ms = sum(v["ms"] for v in by_kernel.values())
-        traffic = None
-        traffic_file = None
-        for cand in ("r01_o_pmc_traffic.json", "r01_i_pmc_traffic_wino4.json", "r01_g_pmc_traffic.json"):
-            # HBM bytes per launch of the dominant kernel from the committed PMC passes (bench cannot collect PMC itself)
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
-                hits = [v for k, v in tj.items() if k.split("<")[0] == dom_name.split("<")[0] and isinstance(v, dict) and v.get("bytes")]
-                if dom_name in tj and tj[dom_name].get("bytes"):
-                    hits = [tj[dom_name]]
-                if hits:      # template instances of one kernel: the one with the most dispatches
-                    traffic, traffic_file = max(hits, key=lambda v: v.get("dispatches", 0))["bytes"], "profiles/" + cand
-                    break
-            except Exception:
-                pass
-        roofline = {"bound": "mfma", "kernel": "sivo::" + dom_name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": f"{traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, mean bytes per launch)" if traffic else None,
-                    "mfma_executed_tflops": round(achieved * exec_ratio, 2), "mfma_util": round(achieved * exec_ratio / FP32_MFMA_PEAK_TFLOPS, 4),
-                    "note": ("achieved = algorithmic direct-conv FLOPs of the layers this kernel serves / its HIP-event time; the kernel is the batched GEMM of Winograd F(4x4,3x3) in fp32, "
-                             "which issues 4x fewer MFMA flops (mfma_util = executed MFMA flops / peak); its input/output transform kernels are listed in kernels_ms_per_frame and counted in all_conv") if exec_ratio == 0.25
-                    else "achieved = algorithmic direct-conv FLOPs / HIP-event time; the dominant kernel is Winograd F(2x2,3x3) in fp32, which issues 2.25x fewer MFMA flops (mfma_util = executed MFMA flops / peak)" if exec_ratio < 1 else "",
-                    "launches_per_frame": dom["launches"] / (len(range(0, args.steps, PROFILE_EVERY)) if (events and timed) else n_detail),
-                    "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
-                    "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
-                    "all_conv": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "ms_per_frame": round(conv_ms / n_detail, 3),
-                                 "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
-                    "kernels_ms_per_frame": {k: round(v["ms"] / n_detail, 3) for k, v in sorted(by_kernel.items())},
-                    "segnet_kernel_ms_per_frame": round(all_ms / n_detail, 3),
-                    "breakdown_source": f"dominant kernel: HIP events in every {PROFILE_EVERY}th of the {args.steps} timed frames (those frames issue the forward in one lane, one launch per layer; the others split the samples over three lanes); kernels_ms_per_frame / all_conv: {n_detail} further untimed single-lane frames with every kernel bracketed"}
+        n_timed = len(range(0, args.steps, PROFILE_EVERY))
+        note = (f"dominant kernel: HIP events on its launch stream in every {PROFILE_EVERY}th of the {args.steps} timed frames (those frames run the forward in one "
+                f"lane, one launch per layer; the others split the samples over three lanes); kernels_ms_per_frame: {n_detail} further untimed single-lane "
+                "frames with every kernel bracketed.  achieved = EXECUTED matrix-core FLOP/s (the Winograd-domain GEMM of F(4x4,3x3) multiplies 1/4 of the direct "
+                "convolution's products; each fp32 product is six bf16 MFMA products); algorithmic_tflops = direct-convolution FLOPs (SURVEY 8d) / the same time")
+        roofline = mfma_roofline(prof_timed, prof, n_timed, n_detail, ms_frame, note)
         out = {"metric": "frames/sec, SIVO per-frame path (ORB+SegNet T=%d+entropy) %dx%d" % (T, H, W),
                "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong",
+               "ms_per_step": round(ms_frame, 3), "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "arithmetic": ("activations, weights, transforms, accumulators and outputs fp32; the batched GEMM of the Winograd F(4x4,3x3) layers multiplies fp32 operands "
+                              "as 3 + 3 bf16 planes / 6 bf16 MFMA products with fp32 accumulation (error at the level of the fp32 FMA chain it replaces: "
+                              "tests/test_gpu_segnet_fullsize.py; SIVO_GEMM=f32 selects the fp32 MFMA kernel); MC mean / confidence / entropy in f64"),
                "config": {"workload": f"full per-frame path: ORB 2000x8 stereo + SegNet-{args.net} T={T} MC-dropout + entropy maps + semantic key filter + stereo match, {H}x{W}, synthetic stereo pair, seeded random weights",
                           "T": T, "samples_per_rank": [parallel.shard_samples(T, world, r)[1] for r in range(world)],
                           "orb": bool(do_orb), "semantic_keys": stats["kps"], "stereo_matches": stats["matches"],
                           "algorithmic_gflop_per_frame": round((sn.flops_shared + T * sn.flops_per_sample) / 1e9, 2),
-                          "reference_equivalent_gflop_per_frame": round(T * (sn.flops_shared + sn.flops_per_sample) / 1e9, 2)},
+                          "reference_equivalent_gflop_per_frame": round(T * (sn.flops_shared + sn.flops_per_sample) / 1e9, 2),
+                          "parity": "tests/test_gpu_segnet_fullsize.py (this configuration, three lanes, oracle-checked), tests/test_gpu_orb.py, tests/test_gpu_match_ba.py"},
                "roofline": roofline}
+
+    # ------------------------------------------------------------------------------------------ further configs (N = 1)
+    want = set() if (world > 1 or args.configs == "none") else set(("basic,t48,ba,host" if args.configs == "all" else args.configs).split(","))
+    extra = []
+    if rank == 0 and want:
+        if "host" in want:
+            # the reference boundary (segmentImage: host image in, host maps out): H2D 1.08 MB + D2H 6.1 MB inside the loop
+            for i in range(2):
+                sn.segment_image(bgr, seed=i)
+            t0 = time.perf_counter()
+            nh = max(5, args.steps // 2)
+            for i in range(nh):
+                sn.segment_image(bgr, seed=100 + i)
+            out["host_boundary_fps"] = round(nh / (time.perf_counter() - t0), 3)
+            out["host_boundary_note"] = ("sivo_segnet_segment through the C ABI: pageable host BGR frame in, classes / confidence / entropy maps out "
+                                         "(PCIe both ways, no ORB); never the reported value")
+        del sn
+        torch.cuda.empty_cache()
+
+        def segnet_config(name, kind, t, steps, parity):
+            _, _, net = build_net(kind, t)
+            m = new_maps()
+            el, pt_, pd_, nd = time_segnet(net, lambda seed: net.segment_into(d_bgr, seed, m), steps, 2, barrier, 4, events)
+            ms = 1e3 * el / steps
+            r = mfma_roofline(pt_, pd_, len(range(0, steps, 4)), nd, ms, "as the main roofline; SegNet only (no ORB)")
+            alg = (net.flops_shared + t * net.flops_per_sample) / 1e9
+            del net
+            torch.cuda.empty_cache()
+            return {"name": name, "metric": "frames/sec", "value": round(steps / el, 3), "ms_per_step": round(ms, 3), "steps": steps,
+                    "algorithmic_gflop_per_frame": round(alg, 2), "roofline": r, "parity": parity}
+        if "basic" in want:
+            extra.append(segnet_config("BASELINE configs[1]: Bayesian SegNet Basic, T=6, 352x1024, 1 MI355X (SegNet + MC maps)", "basic", 6, 20,
+                                       "tests/test_gpu_segnet_fullsize.py [basic-6-*] (every logit within 1e-3 of the oracle, three lanes)"))
+        if "t48" in want:
+            extra.append(segnet_config("BASELINE configs[3] on ONE GPU: SegNet Standard T=48 (the 8-GPU form shards 6 samples per rank)", "standard", 48, 6,
+                                       "same kernels as the T=12 configuration; sharding: tests/test_gpu_segnet.py::test_sample_sharding_matches_single_pass, tests/test_distributed_cpu.py"))
+        if "ba" in want:
+            from sivo_amd import optimizer
+            poses, pts, edges, intr = ba_scene()
+            rng = np.random.default_rng(3)
+            fixed = np.zeros(len(poses), np.uint8); fixed[:2] = 1
+            P0 = poses.copy(); P0[2:, 9:] += rng.normal(0, 0.02, (len(poses) - 2, 3))
+            X0 = pts + rng.normal(0, 0.05, pts.shape)
+            optimizer.local_ba(P0, fixed, X0, edges, intr, cov_pose=19)
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter(); g = optimizer.local_ba(P0, fixed, X0, edges, intr, cov_pose=19); ts.append(time.perf_counter() - t0)
+            t_call = min(ts)
+            nE, it = len(edges), max(g["iterations"], 1)
+            alg_bytes = nE * (48 + 96 + 24 + (3 + 18 + 9 + 1 + 18 + 18) * 8) * it      # ~0.9 KB per edge per LM iteration
+            extra.append({"name": "BASELINE configs[4]: local BA, 20 keyframes x 3000 map points (whole Optimizer::LocalBundleAdjustment solve on the GPU: "
+                                  "per-edge residuals / Jacobians, Schur complement, LM, marginal covariance)",
+                          "metric": "ms per LocalBundleAdjustment call", "value": round(t_call * 1e3, 3), "edges": int(nE), "lm_iterations": g["iterations"],
+                          "ms_per_lm_iteration": round(t_call * 1e3 / it, 3),
+                          "roofline": {"bound": "hbm", "achieved": round(alg_bytes / t_call / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(alg_bytes / t_call / 1e9 / HBM_PEAK_GBS, 5),
+                                       "note": "algorithmic bytes (edge + pose + point in, err / Jp / Jx / W / Y per edge per LM iteration) / whole-call wall time incl. host CSR build, "
+                                               "H2D / D2H and one host decision per trial: this size (36 k edges, 32 MB per iteration) is launch- and latency-bound, not bandwidth-bound"},
+                          "parity": "tests/test_gpu_ba_solve.py (poses 1e-9, covariance 1e-7 vs the oracle), tests/test_gpu_match_ba.py (per-edge outputs bit-exact)"})
+    if rank == 0:
+        if extra:
+            out["configs"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.net, T, H, W, text, w, bgr, left, right, "")
         print(json.dumps(out))

@@ -29,6 +29,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <type_traits>
 #include <vector>
 
@@ -427,6 +428,196 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_x6_kernel(Wino4Args a, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// bf16x6 GEMM, producer / consumer form (the production kernel).
+//
+// Measured on the kernel above (rocprofv3 PMC, conv4_2 at T = 12): matrix cores busy 43 % of the time; with all staging
+// removed 69 %, i.e. the MFMA phase itself loses a quarter to the two barriers per chunk and to two waves per SIMD taking
+// turns, and none of the staging (V loads + split, U DMA, epilogue stores) hides behind the other workgroup's MFMA phase.
+// So the roles are separated inside one 512-thread workgroup per CU:
+//   waves 0-3  CONSUMERS  one per SIMD: per stage 24 ds_read_b128 + 96 back-to-back independent MFMAs, nothing else;
+//                         at the end of a work item the 64 accumulators go to M and are cleared;
+//   waves 4-7  PRODUCERS  one per SIMD, beside a consumer: wait for the V values of the NEXT stage (loaded one stage
+//                         earlier), split them into the three bf16 planes of the other V buffer, start the LDS-DMA of the
+//                         next stage's U image, issue the V loads of the stage after that.
+// LDS: bf16 V planes x 2, U planes x 3, raw fp32 V x 2 = 152 KB; ONE barrier per stage hands a stage over in both directions.
+// The workgroup is persistent: it walks a list of (position, tile block, cout block) items, so the producers run ahead
+// across item boundaries and a consumer's epilogue stores overlap the next item's first stages.  Items are dealt so
+// that the cout blocks of one (position, tile block) pair run at the same time on CUs of ONE XCD (V tile fetched into
+// that L2 once), and an XCD stays on one position for many items (U_xi resident in its L2).
+// ---------------------------------------------------------------------------------------------------
+// Workgroup barrier without the release / acquire fences of __syncthreads(): those wait for vmcnt(0), i.e. for the LDS-DMA a
+// producer has just issued for the NEXT stage and for a consumer's epilogue stores — exactly what has to stay in flight.
+// What the hand-over needs: this wave's LDS writes and reads done (lgkmcnt(0)); a producer additionally waits for the
+// DMA of the stage it hands over with an explicit vmcnt before calling this.
+__device__ __forceinline__ void x6p_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int X6P_VRAW = 128 * X6_KC * 4;        // one fp32 V stage as the LDS-DMA leaves it (16 KB)
+constexpr int X6P_LDS = (2 + 3) * 3 * X6_PLANE + 2 * X6P_VRAW;       // V planes x 2, U planes x 3, raw V x 2 = 152 KB
+
+// ABL (diagnostics): 1 no V DMA after stage 0, 2 no U DMA after stage 0, 4 no split after stage 0, 8 no MFMAs, 16 operand
+// fragments read from LDS in stage 0 only, 32 no M stores.
+template <int ABL>
+__global__ __launch_bounds__(512, 1) void wino4_gemm_x6p_kernel(Wino4Args a, const uint4 *__restrict__ Ux, int ptiles, int ktiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds6[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nchunks = a.C / X6_KC;
+    // item list of this XCD: pairs xcd, xcd + 8, ... (pair = position * ptiles + tile block), each with its ktiles cout
+    // blocks back to back; the workgroups of the XCD (blockIdx.x >> 3 = 0 .. per_xcd - 1) take the items round-robin
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int npairs = 36 * ptiles, pairs_x = (npairs - xcd + 7) / 8;          // pairs of this XCD
+    const int nitems = pairs_x * ktiles;
+    if (wg >= nitems) return;
+    const int my_items = (nitems - wg + per_xcd - 1) / per_xcd;
+    const int nstages = my_items * nchunks;
+    auto item_of = [&](int k, int &xi, int &pt, int &kt) {       // k-th item of this workgroup
+        const int it = wg + k * per_xcd;
+        kt = it % ktiles;
+        const int pair = (it / ktiles) * 8 + xcd;
+        xi = pair / ptiles; pt = pair % ptiles;
+    };
+    auto Vl = [&](int buf) { return lds6 + 3 * X6_PLANE * buf; };
+    auto Ul = [&](int buf) { return lds6 + 3 * X6_PLANE * (2 + buf); };
+    auto Vraw = [&](int buf) { return lds6 + 3 * X6_PLANE * 5 + X6P_VRAW * buf; };
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        // Everything a producer brings in comes by LDS-DMA, issued a whole stage ahead and waited for with vmcnt only:
+        // the U image of the next stage (24 KB, 6 x 1 KiB per wave) and the raw fp32 V rows of the next stage — wave w
+        // copies exactly the 8 channel rows it splits itself (4 x 1 KiB), so no producer depends on another one.
+        const int w = wave - 4, vh = lane >> 5, vtq = lane & 31;
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        int k_item = 0, chunk = 0;                  // the stage the NEXT DMA batch belongs to
+        int xi, pt, kt;
+        item_of(0, xi, pt, kt);
+        auto issue_stage = [&](int s) {             // DMA of stage s = (xi, pt, kt, chunk); then step to the next stage
+            const uint4 *usrc = Ux + ((int64_t)(xi * ktiles + kt) * nchunks + chunk) * (3 * 512);
+            unsigned char *udst = Ul(s % 3);
+#pragma unroll
+            for (int i = 0; i < ((ABL & 2) && s > 2 ? 0 : 6); ++i) {
+                const int kib = w * 6 + i;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(usrc + kib * 64 + lane),
+                                                 (__attribute__((address_space(3))) void *)(udst + kib * 1024), 16, 0, 0);
+            }
+            const float *Vg = a.V + ((int64_t)xi * a.C) * a.Pp + (int64_t)pt * 128;
+            unsigned char *vdst = Vraw(s & 1) + w * 4096;
+            if (!((ABL & 1) && s > 1))
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(Vg + (int64_t)(chunk * X6_KC + w * 8 + 2 * i + vh) * a.Pp + 4 * vtq),
+                    (__attribute__((address_space(3))) void *)(vdst + i * 1024), 16, 0, 0);
+            if (++chunk == nchunks) {
+                chunk = 0;
+                if (++k_item < my_items) item_of(k_item, xi, pt, kt);
+            }
+        };
+        auto split_stage = [&](int s) {             // raw V rows of this wave -> three bf16 planes of V buffer s & 1
+            const unsigned char *src = Vraw(s & 1) + w * 4096 + lane * 16;
+            f32x4 vr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vr[i] = *reinterpret_cast<const f32x4 *>(src + i * 1024);
+            unsigned char *Vb = Vl(s & 1);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bf16x4 p1, p2, p3;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float x = vr[i][t];
+                    const __bf16 x1 = (__bf16)x;
+                    const float r1 = x - (float)x1;
+                    const __bf16 x2 = (__bf16)r1;
+                    const float r2 = r1 - (float)x2;
+                    p1[i] = x1; p2[i] = x2; p3[i] = (__bf16)r2;
+                }
+                unsigned char *dst = Vb + x6_slot(4 * vtq + t, w) * 16 + 8 * vh;
+                *reinterpret_cast<bf16x4 *>(dst) = p1;
+                *reinterpret_cast<bf16x4 *>(dst + X6_PLANE) = p2;
+                *reinterpret_cast<bf16x4 *>(dst + 2 * X6_PLANE) = p3;
+            }
+        };
+        issue_stage(0);
+        for (int s = 0; s <= nstages; ++s) {
+            if (s < nstages) {
+                if (s + 1 < nstages) {
+                    issue_stage(s + 1);                          // lands during the consumers' stage s - 1 .. s
+                    if (ABL & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // all but that batch: stage s has landed
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (!((ABL & 4) && s > 1)) split_stage(s);
+            }
+            x6p_barrier();                          // stage s handed to the consumers, stage s - 1's buffers free again
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int li = lane & 15, lk = lane >> 4;
+    const int wm = wave & 1, wn = wave >> 1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int a_off[4], b_off[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        a_off[t] = x6_slot(64 * wm + 4 * li + t, lk) * 16;
+        b_off[t] = x6_slot(64 * wn + 4 * li + t, lk) * 16;
+    }
+    int k_item = 0, chunk = 0;
+    x6p_barrier();                                // stage 0 ready
+    bf16x8 bfrag[4][3], afr[4][3];
+    for (int s = 0; s < nstages; ++s) {
+        const unsigned char *Vs = Vl(s & 1), *Us = Ul(s % 3);
+        if (!(ABL & 16) || s == 0) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bfrag[nt][pl] = *reinterpret_cast<const bf16x8 *>(Us + pl * X6_PLANE + b_off[nt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            if (!(ABL & 16) || s == 0) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) afr[(ABL & 16) ? mt : 0][pl] = *reinterpret_cast<const bf16x8 *>(Vs + pl * X6_PLANE + a_off[mt]);
+            }
+            const bf16x8 *af = afr[(ABL & 16) ? mt : 0];
+            // smallest terms first: (3,1) (2,2) (1,3) (2,1) (1,2) (1,1)
+#pragma unroll
+            for (int term = 0; term < 6; ++term) {
+                constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    if (ABL & 8) acc[mt][nt][0] += (float)af[PA[term]][0] + (float)bfrag[nt][PB[term]][1];
+                    else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA[term]], bfrag[nt][PB[term]], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        if (++chunk == nchunks) {
+            chunk = 0;
+            int xi, pt, kt;
+            item_of(k_item++, xi, pt, kt);
+            float *Mg = a.M + ((int64_t)xi * a.Kp + (int64_t)kt * 128) * a.Pp + (int64_t)pt * 128;
+            if (!(ABL & 32) || acc[0][0][0] == 12345.678f)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float *row = Mg + (int64_t)(wn * 64 + 4 * li + nt) * a.Pp + wm * 64 + 16 * lk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<f32x4 *>(row + 4 * r) = f32x4{acc[0][nt][r], acc[1][nt][r], acc[2][nt][r], acc[3][nt][r]};
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        x6p_barrier();                            // done with stage s; stage s + 1 ready
+    }
+}
+
 // 1-D output transform A^T m
 __device__ __forceinline__ void wino4_at(const float m0, const float m1, const float m2, const float m3, const float m4,
                                          const float m5, float *s) {
@@ -702,6 +893,11 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
                        const Wino4Plan *plan) {
     static bool attr_set = false;
     if (!attr_set) {
+        for (const void *f : {(const void *)wino4_gemm_x6p_kernel<0>, (const void *)wino4_gemm_x6p_kernel<1>, (const void *)wino4_gemm_x6p_kernel<2>,
+                              (const void *)wino4_gemm_x6p_kernel<3>, (const void *)wino4_gemm_x6p_kernel<4>, (const void *)wino4_gemm_x6p_kernel<7>,
+                              (const void *)wino4_gemm_x6p_kernel<8>, (const void *)wino4_gemm_x6p_kernel<16>, (const void *)wino4_gemm_x6p_kernel<23>,
+                              (const void *)wino4_gemm_x6p_kernel<32>})
+            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_x6_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS);
         for (const void *f : {(const void *)wino4_gemm_x6_kernel<1>, (const void *)wino4_gemm_x6_kernel<2>, (const void *)wino4_gemm_x6_kernel<4>,
                               (const void *)wino4_gemm_x6_kernel<8>, (const void *)wino4_gemm_x6_kernel<16>, (const void *)wino4_gemm_x6_kernel<7>})
@@ -752,7 +948,27 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
             const int pt6 = (a.P + 127) / 128, kt6 = a.Kp / 128, pairs6 = (36 * pt6 + 7) / 8;
             const dim3 g6((unsigned)(pairs6 * kt6 * 8));
             const uint4 *u6 = reinterpret_cast<const uint4 *>(c.wt_x6);
-            switch ((c.variant >> 12) & 31) {          // ablations for tools/x6_probe.py; 0 in production
+            // SIVO_X6=flat: the two-workgroups-per-CU kernel without role separation (kept for comparison and ablations)
+            static const bool x6_flat = std::getenv("SIVO_X6") && std::string(std::getenv("SIVO_X6")) == "flat";
+            static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
+            const int abl = (c.variant >> 12) & 31;
+            (void)abl;
+            if (!x6_flat) {
+                const dim3 gp((unsigned)((n_cu / 8) * 8 > 0 ? (n_cu / 8) * 8 : 8));        // one persistent workgroup per CU, a multiple of the 8 XCDs
+                switch ((c.variant >> 12) & 63) {
+                    case 1: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<1>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
+                    case 2: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<2>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
+                    case 3: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<3>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
+                    case 4: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<4>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
+                    case 7: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<7>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
+                    case 8: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<8>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
+                    case 16: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<16>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
+                    case 23: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<23>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
+                    case 32: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<32>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
+                    default: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<0>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6);
+                }
+            } else
+            switch (abl) {          // ablations for tools/x6_probe.py; 0 in production
                 case 1: hipLaunchKernelGGL(wino4_gemm_x6_kernel<1>, g6, dim3(256), X6_LDS, s, a, u6, pt6, kt6); break;
                 case 2: hipLaunchKernelGGL(wino4_gemm_x6_kernel<2>, g6, dim3(256), X6_LDS, s, a, u6, pt6, kt6); break;
                 case 4: hipLaunchKernelGGL(wino4_gemm_x6_kernel<4>, g6, dim3(256), X6_LDS, s, a, u6, pt6, kt6); break;

@@ -24,7 +24,7 @@ def run(shape, variant, iters=10):
 if len(sys.argv) > 1 and sys.argv[1] == "ablate":
     for name in sys.argv[2:] or ["conv4_2 512->512 44x128", "conv3_2_D 256->256 88x256"]:
         base = 512 | 2048
-        print(name, "f32 %.3f" % run(SHAPES[name], 512), " ".join(f"abl{a}={run(SHAPES[name], base | (a << 12)):.3f}" for a in (0, 1, 2, 4, 7, 8, 16)), flush=True)
+        print(name, "f32 %.3f" % run(SHAPES[name], 512), " ".join(f"abl{a}={run(SHAPES[name], base | (a << 12)):.3f}" for a in ((0, 1, 2, 3, 4, 7, 8, 16, 23, 32) if os.environ.get("SIVO_X6") != "flat" else (0, 1, 2, 4, 7, 8, 16))), flush=True)
     sys.exit(0)
 for name, shape in SHAPES.items():
     N, ci, co, H, W = shape
