@@ -71,6 +71,16 @@ int sivo_caffemodel_weights(const char *prototxt_text, size_t prototxt_len, cons
  * (bayesian_segnet.cpp:80-89, pinned by tests/test_bayesian_segnet.cpp:138-150). */
 int sivo_segnet_create_from_files(const char *model_file, const char *weights_file, int t_override,
                                   int device, sivo_segnet_t *out);
+/* The same network with the T Monte-Carlo samples of a frame spread over several GPUs INSIDE the handle (the reference
+ * constructs one BayesianSegNet, src/orbslam/System.cc:94-95, so a multi-GPU drop-in has to live behind that object).
+ * One process; every device holds the full weights and takes a contiguous share of the samples (dropout keyed by the
+ * global sample index); per frame: local softmax sums -> RCCL reduce-scatter over pixel ranges (fp32) -> every device
+ * finalizes its 1/ndev of the pixels in f64 -> RCCL all-gather of the class / confidence / entropy chunks -> device
+ * device_ids[0] hands the maps to the caller.  H*W must be a multiple of ndev, T >= ndev, devices distinct.
+ * Only sivo_segnet_segment, _shape, _num_devices and _destroy take such a handle.  librccl.so is opened on first use. */
+int sivo_segnet_create_multi(const char *prototxt_text, size_t prototxt_len, int t_override, const float *weights,
+                             size_t n_weights, const int *device_ids, int ndev, sivo_segnet_t *out);
+int sivo_segnet_num_devices(sivo_segnet_t h, int *ndev);
 int sivo_segnet_destroy(sivo_segnet_t h);
 /* getInputGeometry (bayesian_segnet.hpp) and the blob shapes: T, C(=3), H, W, classes. */
 int sivo_segnet_shape(sivo_segnet_t h, int32_t *T, int32_t *C, int32_t *H, int32_t *W, int32_t *classes);

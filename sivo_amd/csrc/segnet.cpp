@@ -27,6 +27,7 @@
 #include "common.hpp"
 #include "prototxt.hpp"
 #include "segnet_kernels.hpp"
+#include "segnet_multi.hpp"
 
 namespace sivo {
 bool looks_like_caffemodel(const std::string &bytes);
@@ -85,6 +86,7 @@ struct Op {
 }  // namespace sivo
 
 struct sivo_segnet {
+    sivo::SegnetMulti *multi = nullptr;   // set by sivo_segnet_create_multi: this handle only fronts the per-device ones
     int device = 0;
     int T = 0, C = 3, H = 0, W = 0, classes = 0;
     std::vector<sivo::Blob> blobs;
@@ -97,6 +99,7 @@ struct sivo_segnet {
     uint8_t *d_classes = nullptr;
     double *d_conf = nullptr, *d_ent = nullptr;
     hipStream_t stream = nullptr;   // for the host-level entry point
+    int64_t sum_chunk = 0;          // layout of the probability sum the next forward writes (0 = [class][pixel])
     double flops_shared = 0.0, flops_sample = 0.0;
     bool profile = false, pending = false;
     bool profile_mfma_only = false;   // bracket only the MFMA kernels (convolutions / the F(4x4) GEMM): fewer events in a timed run
@@ -111,6 +114,7 @@ struct sivo_segnet {
     size_t wino4_ws_floats = 0;
     size_t wino4_slot_floats = 0;   // three rotating slots (V, M, next V) for layers that run all samples in one pass
     ~sivo_segnet() {
+        if (multi) sivo::segnet_multi_destroy(multi);
         for (sivo::Op &op : ops) {
             if (op.ev0) (void)hipEventDestroy(op.ev0);
             if (op.ev1) (void)hipEventDestroy(op.ev1);
@@ -660,7 +664,7 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
     if (S.profile) S.pending = true;
     const Blob &lg = S.blobs[S.logits_blob];
     if (lg.shared) throw std::runtime_error("the network has no test-time dropout: nothing to sample");
-    if (d_prob_sum || d_prob) launch_mc_reduce((const float *)lg.d, n, S.classes, hw, d_prob_sum ? d_prob_sum : S.d_prob_sum, d_prob, 0, st);
+    if (d_prob_sum || d_prob) launch_mc_reduce((const float *)lg.d, n, S.classes, hw, d_prob_sum ? d_prob_sum : S.d_prob_sum, d_prob, 0, st, S.sum_chunk);
     if (d_logits)
         SIVO_HIP(hipMemcpyAsync(d_logits, lg.d, (size_t)n * lg.chw() * sizeof(float), hipMemcpyDeviceToDevice, st));
     SIVO_HIP(hipGetLastError());
@@ -677,7 +681,50 @@ std::string read_file(const char *path) {
 }  // namespace
 }  // namespace sivo
 
+void sivo::segnet_forward_chunked(sivo_segnet_t h, const uint8_t *d_bgr, int n, int sample0, uint64_t seed, float *d_sum_chunked,
+                                  int64_t chunk, hipStream_t st) {
+    DeviceGuard dg(h->device);
+    h->sum_chunk = chunk;
+    try {
+        forward(*h, d_bgr, n, sample0, seed, d_sum_chunked, nullptr, nullptr, st);
+    } catch (...) {
+        h->sum_chunk = 0;
+        throw;
+    }
+    h->sum_chunk = 0;
+}
+
 using namespace sivo;
+
+extern "C" int sivo_segnet_create_multi(const char *text, size_t len, int t_override, const float *weights, size_t n_weights,
+                                        const int *device_ids, int ndev, sivo_segnet_t *out) {
+    return guarded([&] {
+        if (!out) throw std::invalid_argument("out is NULL");
+        *out = nullptr;
+        if (!text || !len) throw std::invalid_argument("model_file (.prototxt file) is empty!");
+        if (!weights || !n_weights) throw std::invalid_argument("weights_file (.caffemodel file) is empty!");
+        if (!device_ids || ndev < 1) throw std::invalid_argument("device_ids is empty");
+        for (int d = 0; d < ndev; ++d)
+            if (device_ids[d] < 0 || device_ids[d] >= sivo_device_count())
+                return fail(SIVO_ERR_RUNTIME, "HIP device %d is not available (%d visible): libsivo_hip has no CPU fallback", device_ids[d],
+                            sivo_device_count());
+        std::unique_ptr<sivo_segnet> S(new sivo_segnet);
+        S->multi = segnet_multi_create(text, len, t_override, weights, n_weights, device_ids, ndev);
+        int32_t T, H, W, K;
+        segnet_multi_shape(S->multi, &T, &H, &W, &K, nullptr);
+        S->device = device_ids[0]; S->T = T; S->H = H; S->W = W; S->classes = K;
+        *out = S.release();
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_segnet_num_devices(sivo_segnet_t h, int *ndev) {
+    if (!h || !ndev) return fail(SIVO_ERR_INVALID_ARGUMENT, "null argument");
+    int32_t n = 1;
+    if (h->multi) segnet_multi_shape(h->multi, nullptr, nullptr, nullptr, nullptr, &n);
+    *ndev = n;
+    return SIVO_OK;
+}
 
 extern "C" int sivo_segnet_num_params(const char *text, size_t len, size_t *n_params) {
     return guarded([&] {
@@ -774,6 +821,7 @@ extern "C" int sivo_segnet_forward_dev(sivo_segnet_t h, const uint8_t *d_bgr, in
                                        void *stream) {
     return guarded([&] {
         if (!h || !d_bgr || !d_prob_sum) throw std::invalid_argument("null argument");
+        if (h->multi) throw std::invalid_argument("a multi-device handle shards the samples itself: use sivo_segnet_segment");
         if (n_samples < 1 || n_samples > h->T) throw std::invalid_argument("n_samples must be in [1, T]");
         DeviceGuard dg(h->device);
         forward(*h, d_bgr, n_samples, sample0, seed, d_prob_sum, d_logits, d_prob, (hipStream_t)stream);
@@ -819,6 +867,10 @@ extern "C" int sivo_segnet_segment(sivo_segnet_t h, const uint8_t *bgr, int rows
         // resizeImage (bayesian_segnet.cpp:142-162): exact size -> as is; larger -> centre crop; smaller -> empty
         if (rows < h->H || cols < h->W)
             return fail(SIVO_ERR_IMAGE_TOO_SMALL, "image %dx%d is smaller than the network geometry %dx%d", cols, rows, h->W, h->H);
+        if (h->multi) {
+            segnet_multi_segment(h->multi, bgr, rows, cols, seed, classes, confidence, entropy);
+            return SIVO_OK;
+        }
         DeviceGuard dg(h->device);
         const int x_tl = (rows == h->H && cols == h->W) ? 0 : cols / 2 - h->W / 2;
         const int y_tl = (rows == h->H && cols == h->W) ? 0 : rows / 2 - h->H / 2;
@@ -840,6 +892,7 @@ extern "C" int sivo_segnet_segment_dev(sivo_segnet_t h, const uint8_t *d_bgr, ui
                                        double *d_confidence, double *d_entropy, void *stream) {
     return guarded([&] {
         if (!h || !d_bgr || !d_classes || !d_confidence || !d_entropy) throw std::invalid_argument("null argument");
+        if (h->multi) throw std::invalid_argument("a multi-device handle takes host buffers: use sivo_segnet_segment");
         DeviceGuard dg(h->device);
         hipStream_t st = (hipStream_t)stream;
         forward(*h, d_bgr, h->T, 0, seed, nullptr, nullptr, nullptr, st);
@@ -854,6 +907,7 @@ extern "C" int sivo_segnet_blob(sivo_segnet_t h, const char *name, float *host_o
                                 int32_t shape[4]) {
     return guarded([&] {
         if (!h || !name) throw std::invalid_argument("null argument");
+        if (h->multi) throw std::invalid_argument("blobs live in the per-device handles of a multi-device handle");
         auto it = h->blob_id.find(name);
         if (it == h->blob_id.end()) throw std::invalid_argument(std::string("no blob named '") + name + "'");
         const Blob &b = h->blobs[it->second];

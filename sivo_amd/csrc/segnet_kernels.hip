@@ -404,7 +404,7 @@ void launch_lrn(const float *in, float *out, int N, int C, int64_t hw, int local
 // coalesced VEC*4-byte access along the pixel axis.
 template <int VEC, int CMAX>
 __global__ void mc_reduce_kernel(const float *logits, int n, int C, int64_t hw, float *prob_sum, float *prob,
-                                 int accumulate) {
+                                 int accumulate, int64_t chunk) {
     const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (p >= hw) return;
     double sum[CMAX][VEC];
@@ -453,7 +453,9 @@ __global__ void mc_reduce_kernel(const float *logits, int n, int C, int64_t hw, 
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
         if (c < C) {
-            float *dst = prob_sum + (int64_t)c * hw + p;
+            // chunk == hw: [class][pixel]; otherwise pixel-chunk-major [pixel / chunk][class][pixel % chunk] (the layout a
+            // reduce-scatter over pixel ranges needs; chunk is even when VEC == 2, so a pixel pair never straddles chunks)
+            float *dst = prob_sum + ((p / chunk) * C + c) * chunk + (p % chunk);
             if (VEC == 2) {
                 float2 o = make_float2((float)sum[c][0], (float)sum[c][1 % VEC]);
                 if (accumulate) { const float2 old = *reinterpret_cast<float2 *>(dst); o.x += old.x; o.y += old.y; }
@@ -467,15 +469,16 @@ __global__ void mc_reduce_kernel(const float *logits, int n, int C, int64_t hw, 
 }
 
 int launch_mc_reduce(const float *logits, int n, int C, int64_t hw, float *prob_sum, float *prob, int accumulate,
-                     hipStream_t s) {
+                     hipStream_t s, int64_t chunk) {
     if (C > 16) return 1;
-    if ((hw & 1) == 0) {
+    if (chunk <= 0 || chunk > hw) chunk = hw;
+    if ((hw & 1) == 0 && (chunk & 1) == 0) {
         const int64_t threads = hw / 2;
         hipLaunchKernelGGL((mc_reduce_kernel<2, 16>), dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, s, logits,
-                           n, C, hw, prob_sum, prob, accumulate);
+                           n, C, hw, prob_sum, prob, accumulate, chunk);
     } else {
         hipLaunchKernelGGL((mc_reduce_kernel<1, 16>), dim3((unsigned)((hw + 127) / 128)), dim3(128), 0, s, logits, n, C,
-                           hw, prob_sum, prob, accumulate);
+                           hw, prob_sum, prob, accumulate, chunk);
     }
     return 0;
 }

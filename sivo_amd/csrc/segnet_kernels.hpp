@@ -99,8 +99,9 @@ void launch_dropout(const float *in, int64_t in_sample_stride, float *out, int N
                     int sample0, uint64_t seed, hipStream_t s);
 void launch_lrn(const float *in, float *out, int N, int C, int64_t hw, int local_size, float alpha, float beta,
                 hipStream_t s);
+// chunk (0 = hw): pixel-chunk-major output [hw / chunk][C][chunk] for the multi-device reduce-scatter (segnet_multi.cpp)
 int launch_mc_reduce(const float *logits, int n, int C, int64_t hw, float *prob_sum, float *prob, int accumulate,
-                     hipStream_t s);
+                     hipStream_t s, int64_t chunk = 0);
 void launch_mc_reduce_finalize(const float *logits, int T, int C, int64_t hw, uint8_t *classes, double *confidence,
                                double *entropy, hipStream_t s);
 void launch_mc_finalize(const float *prob_sum, int C, int64_t hw, int T, uint8_t *classes, double *confidence,

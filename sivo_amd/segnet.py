@@ -29,8 +29,11 @@ def _stream():
 class BayesianSegNet:
     """Constructor from a params object (files) like the reference, or from prototxt text + flat weights."""
 
-    def __init__(self, params=None, prototxt=None, weights=None, T=0, device=0):
+    def __init__(self, params=None, prototxt=None, weights=None, T=0, device=0, devices=None):
+        """devices: list of HIP device ids -> the T samples of a frame are spread over them inside the handle
+        (sivo_segnet_create_multi: RCCL reduce-scatter / all-gather); only segment_image works on such a handle."""
         h = C.c_void_p()
+        self.devices = list(devices) if devices is not None else None
         if params is not None:
             if not params.model_file:
                 raise ValueError("model_file (.prototxt file) is empty!")       # bayesian_segnet.cpp:80-89
@@ -40,6 +43,12 @@ class BayesianSegNet:
                 raise _lib.SivoError(_lib.ERR_UNSUPPORTED, "use_gpu=false: this library has no CPU path")
             rc = lib().sivo_segnet_create_from_files(params.model_file.encode(), params.weights_file.encode(), T,
                                                      device, C.byref(h))
+        elif self.devices is not None:
+            text = prototxt.encode() if isinstance(prototxt, str) else (prototxt or b"")
+            w = np.ascontiguousarray(weights if weights is not None else np.zeros(0), np.float32)
+            ids = (C.c_int32 * len(self.devices))(*self.devices)
+            rc = lib().sivo_segnet_create_multi(text, len(text), T, w.ctypes.data_as(C.c_void_p), w.size, ids, len(self.devices), C.byref(h))
+            device = self.devices[0] if self.devices else 0
         else:
             text = prototxt.encode() if isinstance(prototxt, str) else (prototxt or b"")
             w = np.ascontiguousarray(weights if weights is not None else np.zeros(0), np.float32)

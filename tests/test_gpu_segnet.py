@@ -320,3 +320,26 @@ def test_winograd_and_direct_conv_shapes(oracle, H, W, width):
             mism = (g == 0) != (o == 0)
             assert mism.mean() < 1e-4 and (np.abs(g[mism]) < 1e-4).all() and (np.abs(o[mism]) < 1e-4).all(), name
     np.testing.assert_allclose(logits.cpu().numpy(), ob["cls"], atol=LOGIT_TOL, rtol=0)
+
+
+def test_multi_device_handle_on_one_device(oracle, kitti_like_bgr):
+    """sivo_segnet_create_multi with device_ids = [0]: the whole multi-device path (chunk-major sums, RCCL communicator,
+    reduce-scatter, per-chunk finalize, all-gather, hand-over) runs, on one rank.  Same maps as the single-device handle up
+    to the fp32 rounding of the probability sums (the single-device entry point keeps them in f64)."""
+    T, H, W = 4, 32, 64
+    text = netspec.tiny_prototxt(T, H, W)
+    net, w, sn = _make(text, T)
+    multi = BayesianSegNet(prototxt=text, weights=wts.pack(net["layers"], w), T=T, devices=[0])
+    assert (multi.T, multi.H, multi.W, multi.classes) == (sn.T, sn.H, sn.W, sn.classes)
+    big = np.ascontiguousarray(kitti_like_bgr[:80, :150])
+    cls_m, conf_m, ent_m = multi.segment_image(big, seed=5)
+    cls_s, conf_s, ent_s = sn.segment_image(big, seed=5)
+    np.testing.assert_allclose(conf_m, conf_s, atol=2e-7, rtol=0)
+    np.testing.assert_allclose(ent_m, ent_s, atol=5e-6, rtol=0)
+    assert (cls_m == cls_s).mean() > 0.999
+    res = oracle.segment(net, w, big, 5)
+    np.testing.assert_allclose(conf_m, res["confidence"], atol=1e-5, rtol=0)
+    with pytest.raises(ValueError):
+        multi.forward(torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda"), 1)
+    with pytest.raises(ValueError):
+        BayesianSegNet(prototxt=text, weights=wts.pack(net["layers"], w), T=T, devices=[0, 0])
