@@ -461,7 +461,7 @@ int sivo_pose_optimize(const double pose0[12], const double *points, int n_point
                        int *trials);
 
 /* ===========================================================================
- * Entropy feature-selection gate — stands behind SIVO's sivo_helpers
+ * Entropy feature-selection gate (the Tracking form; sivo_check_semantics below is the LocalMapping form) — stands behind SIVO's sivo_helpers
  * (reference src/sivo_helpers/sivo_helpers.cpp:64-88 computeStereoJacobianPose,
  * :160-180 computeStereoCovariance, :201-219 computeStereoMutualInformation) as
  * Tracking::CreateNewKeyFrame applies them per semantic keypoint
@@ -481,6 +481,20 @@ int sivo_entropy_gate(int n, const SivoKeyPoint *kps, const float *depth, const 
                       const double *entropy, int rows, int cols, const double state_cov[36], double fx,
                       double fy, double bl, const float *level_sigma2, int nlevels, double th, double *mi,
                       double *reduction, uint8_t *accept);
+
+/* LocalMapping::CheckSemantics(pKF, idx, wP, compute_information = true) (reference src/orbslam/LocalMapping.cc:474-538)
+ * over n keypoints: detected_class[i] = the class at the truncated keypoint position if depth > 0, the class is static
+ * (<= TERRAIN = 8), confidence >= th_confidence and NOT (MI - entropy < th_entropy) — equality passes, unlike the
+ * Tracking gate above — else VOID (255).  mi / reduction may be NULL. */
+int sivo_check_semantics_dev(int n, const SivoKeyPoint *d_kps, const float *d_depth, const double *d_xyz,
+                             const double *d_entropy, const double *d_confidence, const uint8_t *d_classes, int rows, int cols,
+                             const double state_cov[36], double fx, double fy, double bl, const float *level_sigma2,
+                             int nlevels, double th_entropy, double th_confidence, double *d_mi, double *d_reduction,
+                             uint8_t *d_detected_class, void *stream);
+int sivo_check_semantics(int n, const SivoKeyPoint *kps, const float *depth, const double *xyz, const double *entropy,
+                         const double *confidence, const uint8_t *classes, int rows, int cols, const double state_cov[36],
+                         double fx, double fy, double bl, const float *level_sigma2, int nlevels, double th_entropy,
+                         double th_confidence, double *mi, double *reduction, uint8_t *detected_class);
 
 #ifdef __cplusplus
 }

@@ -473,3 +473,18 @@ def entropy_gate(kps, depth, xyz, entropy, Sx, fx, fy, bl, level_sigma2, th):
                            entropy.shape[0], entropy.shape[1], _p(Sx, c_f64p), C.c_double(fx), C.c_double(fy), C.c_double(bl),
                            _p(ls2, c_f32p), C.c_double(th), _p(mi, c_f64p), _p(red, c_f64p), _p(acc, c_u8p))
     return mi, red, acc
+
+
+def check_semantics(kps, depth, xyz, entropy, confidence, classes, Sx, fx, fy, bl, level_sigma2, th, th_conf):
+    """LocalMapping.cc:474-538 (compute_information = true) over all keypoints: (mutual_information, entropy_reduction, detected_class)."""
+    kps = np.ascontiguousarray(kps, KP_DTYPE); depth = np.ascontiguousarray(depth, np.float32)
+    xyz = np.ascontiguousarray(xyz, np.float64); entropy = np.ascontiguousarray(entropy, np.float64)
+    confidence = np.ascontiguousarray(confidence, np.float64); classes = np.ascontiguousarray(classes, np.uint8)
+    Sx = np.ascontiguousarray(Sx, np.float64); ls2 = np.ascontiguousarray(level_sigma2, np.float32)
+    n = len(kps)
+    mi = np.empty(n); red = np.empty(n); det = np.empty(n, np.uint8)
+    lib().orc_check_semantics(n, kps.ctypes.data_as(C.c_void_p), _p(depth, c_f32p), _p(xyz, c_f64p), _p(entropy, c_f64p),
+                              _p(confidence, c_f64p), _p(classes, c_u8p), entropy.shape[0], entropy.shape[1], _p(Sx, c_f64p), C.c_double(fx),
+                              C.c_double(fy), C.c_double(bl), _p(ls2, c_f32p), C.c_double(th), C.c_double(th_conf), _p(mi, c_f64p),
+                              _p(red, c_f64p), _p(det, c_u8p))
+    return mi, red, det

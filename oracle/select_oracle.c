@@ -110,3 +110,26 @@ void orc_entropy_gate(int n, const OrcKeyPoint *kps, const float *depth, const d
         accept[i] = (m - e) > th;
     }
 }
+
+/* LocalMapping::CheckSemantics(pKF, idx, wP, compute_information = true) (reference src/orbslam/LocalMapping.cc:474-538) over n
+ * keypoints: detected_class[i] = the class at the truncated position, or VOID (255) unless depth > 0, class <= TERRAIN (8),
+ * confidence >= th_conf, and the entropy reduction is not below th (`if (entropy_reduction < mThEntropyReduction)` rejects). */
+void orc_check_semantics(int n, const OrcKeyPoint *kps, const float *depth, const double *xyz, const double *entropy,
+                         const double *confidence, const uint8_t *classes, int rows, int cols, const double *Sx, double fx, double fy,
+                         double bl, const float *level_sigma2, double th, double th_conf, double *mi, double *reduction,
+                         uint8_t *detected_class) {
+    for (int i = 0; i < n; ++i) {
+        mi[i] = 0.0; reduction[i] = 0.0; detected_class[i] = 255;
+        const int col = (int)kps[i].x, row = (int)kps[i].y;
+        if (row < 0 || row >= rows || col < 0 || col >= cols) continue;
+        const uint8_t cls = classes[(int64_t)row * cols + col];
+        const int depth_criteria = depth[i] > 0, class_criteria = cls <= 8;
+        const int confidence_criteria = confidence[(int64_t)row * cols + col] >= th_conf;
+        if (!(depth_criteria && class_criteria && confidence_criteria)) continue;
+        const double sigma2 = level_sigma2[kps[i].octave];
+        const double m = orc_stereo_mutual_information(Sx, fx, fy, bl, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], sigma2);
+        mi[i] = m;
+        reduction[i] = m - entropy[(int64_t)row * cols + col];
+        detected_class[i] = reduction[i] < th ? 255 : cls;
+    }
+}

@@ -111,6 +111,8 @@ SIGNATURES = {
     "sivo_stereo_match_cull": [_i, _vp, _vp, _vp, _vp],
     "sivo_entropy_gate_dev": [_i, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(_d), _d, _d, _d, _vp, _i, _d, _vp, _vp, _vp, _vp],
     "sivo_entropy_gate": [_i, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(_d), _d, _d, _d, _vp, _i, _d, _vp, _vp, _vp],
+    "sivo_check_semantics_dev": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(_d), _d, _d, _d, _vp, _i, _d, _d, _vp, _vp, _vp, _vp],
+    "sivo_check_semantics": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(_d), _d, _d, _d, _vp, _i, _d, _d, _vp, _vp, _vp],
     "sivo_ba_optimize": [_vp, _vp, _i, _vp, _i, _vp, _i64, C.POINTER(_d), _d, _d, _vp, _vp, _i, _vp, _vp, _vp, C.POINTER(_i), C.POINTER(_i)],
     "sivo_local_ba": [_vp, _vp, _i, _vp, _i, _vp, _i64, C.POINTER(_d), _vp, _vp, _i, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
     "sivo_pose_optimize": [_vp, _vp, _i, _vp, _i64, C.POINTER(_d), _vp, _vp, _vp, C.POINTER(_i), _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],

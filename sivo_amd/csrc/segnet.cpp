@@ -962,7 +962,7 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
         for (size_t i = 0; i < h->ops.size(); ++i) {
             const Op &op = h->ops[i];
             if (op.wino4) {
-                const char *kn[3] = {"wino4_input_kernel", op.d_wx6 ? "wino4_gemm_x6_kernel" : "wino4_gemm_kernel", op.w4_bridge ? "wino4_bridge_kernel" : "wino4_output_kernel"};
+                const char *kn[3] = {"wino4_input_kernel", op.d_wx6 ? ((std::getenv("SIVO_X6") && std::string(std::getenv("SIVO_X6")) == "flat") ? "wino4_gemm_x6_kernel" : "wino4_gemm_x6p_kernel") : "wino4_gemm_kernel", op.w4_bridge ? "wino4_bridge_kernel" : "wino4_output_kernel"};
                 const Blob &bi = h->blobs[op.in];
                 const double tiles = (double)((bi.H + 3) / 4) * (bi.W / 4), kp = wino4_cout_pad(op.cout);
                 const double bytes[3] = {4.0 * (op.cin * (double)bi.H * bi.W + 36.0 * op.cin * tiles),

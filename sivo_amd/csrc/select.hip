@@ -2,9 +2,13 @@
 // keypoints of a frame.  Stands behind
 //   SIVO::computeStereoJacobianPose / computeStereoCovariance / computeStereoMutualInformation
 //   (reference src/sivo_helpers/sivo_helpers.cpp:64-88, 160-180, 201-219)
-// as they are applied in Tracking::CreateNewKeyFrame (reference src/orbslam/Tracking.cc:934-1023) and
-// LocalMapping::CheckSemantics: entropy lookup at the truncated keypoint position in the entropy map the
-// SegNet path left in HBM, depth > 0, accept iff MI - entropy > ThEntropyReduction.
+// as they are applied in
+//   Tracking::CreateNewKeyFrame (reference src/orbslam/Tracking.cc:934-1023): entropy lookup at the truncated keypoint
+//     position in the entropy map the SegNet path left in HBM, depth > 0, accept iff MI - entropy > ThEntropyReduction
+//     (sivo_entropy_gate);
+//   LocalMapping::CheckSemantics (reference src/orbslam/LocalMapping.cc:474-538, compute_information = true): also a
+//     static class (<= TERRAIN) and confidence >= ThConfidence, and the point is rejected only when
+//     MI - entropy < ThEntropyReduction, i.e. it passes at equality (sivo_check_semantics).
 // One thread per keypoint, fp64, determinants as Eigen takes them (3x3 cofactors, 6x6 / 9x9 partial-
 // pivot LU); a few thousand independent 9x9 factorizations: latency bound, microseconds.
 #include <hip/hip_runtime.h>
@@ -46,6 +50,10 @@ struct GateArgs {
     float level_sigma2[16];
     double *mi, *reduction;
     uint8_t *accept;
+    // CheckSemantics form (classes != nullptr): accept[] receives the detected class, or VOID (255)
+    const double *confidence;
+    const uint8_t *classes;
+    double th_conf;
 };
 
 __global__ void entropy_gate_kernel(GateArgs g) {
@@ -55,7 +63,16 @@ __global__ void entropy_gate_kernel(GateArgs g) {
     uint8_t acc = 0;
     const SivoKeyPoint kp = g.kps[i];
     const int col = (int)kp.x, row = (int)kp.y;
-    if (g.depth[i] > 0 && row >= 0 && row < g.rows && col >= 0 && col < g.cols) {
+    bool ok = g.depth[i] > 0 && row >= 0 && row < g.rows && col >= 0 && col < g.cols;
+    int cls = 255;
+    if (g.classes) {
+        acc = 255;                                                   // Classes::VOID
+        if (ok) {
+            cls = g.classes[(int64_t)row * g.cols + col];
+            ok = cls <= 8 && g.confidence[(int64_t)row * g.cols + col] >= g.th_conf;     // <= Classes::TERRAIN, >= mThConfidence
+        }
+    }
+    if (ok) {
         const double X = g.xyz[3 * i], Y = g.xyz[3 * i + 1], Z = g.xyz[3 * i + 2];
         const double fx = g.fx, fy = g.fy, bl = g.bl;
         double J[18];
@@ -100,7 +117,8 @@ __global__ void entropy_gate_kernel(GateArgs g) {
         const double cov_det = det_lu(S9, 9);
         m = 0.5 * log2(state_det * meas_det / cov_det);
         red = m - g.entropy[(int64_t)row * g.cols + col];
-        acc = red > g.th;
+        if (g.classes) acc = red < g.th ? 255 : (uint8_t)cls;         // LocalMapping.cc:529-532: rejected only below the threshold
+        else acc = red > g.th;
     }
     if (g.mi) g.mi[i] = m;
     if (g.reduction) g.reduction[i] = red;
@@ -127,6 +145,59 @@ extern "C" int sivo_entropy_gate_dev(int n, const SivoKeyPoint *d_kps, const flo
         g.mi = d_mi; g.reduction = d_reduction; g.accept = d_accept;
         hipLaunchKernelGGL(entropy_gate_kernel, dim3(cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, g);
         SIVO_HIP(hipGetLastError());
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_check_semantics_dev(int n, const SivoKeyPoint *d_kps, const float *d_depth, const double *d_xyz,
+                                        const double *d_entropy, const double *d_confidence, const uint8_t *d_classes, int rows,
+                                        int cols, const double state_cov[36], double fx, double fy, double bl,
+                                        const float *level_sigma2, int nlevels, double th_entropy, double th_confidence,
+                                        double *d_mi, double *d_reduction, uint8_t *d_detected_class, void *stream) {
+    return guarded([&] {
+        if (n < 0 || nlevels < 1 || nlevels > 16) throw std::invalid_argument("bad sizes (nlevels <= 16)");
+        if (n == 0) return SIVO_OK;
+        if (!d_kps || !d_depth || !d_xyz || !d_entropy || !d_confidence || !d_classes || !state_cov || !level_sigma2 || !d_detected_class)
+            throw std::invalid_argument("null argument");
+        GateArgs g{};
+        g.kps = d_kps; g.depth = d_depth; g.xyz = d_xyz; g.entropy = d_entropy; g.rows = rows; g.cols = cols; g.n = n;
+        for (int i = 0; i < 36; ++i) g.Sx[i] = state_cov[i];
+        g.fx = fx; g.fy = fy; g.bl = bl; g.th = th_entropy;
+        for (int i = 0; i < nlevels; ++i) g.level_sigma2[i] = level_sigma2[i];
+        g.mi = d_mi; g.reduction = d_reduction; g.accept = d_detected_class;
+        g.confidence = d_confidence; g.classes = d_classes; g.th_conf = th_confidence;
+        hipLaunchKernelGGL(entropy_gate_kernel, dim3(cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, g);
+        SIVO_HIP(hipGetLastError());
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_check_semantics(int n, const SivoKeyPoint *kps, const float *depth, const double *xyz, const double *entropy,
+                                    const double *confidence, const uint8_t *classes, int rows, int cols, const double state_cov[36],
+                                    double fx, double fy, double bl, const float *level_sigma2, int nlevels, double th_entropy,
+                                    double th_confidence, double *mi, double *reduction, uint8_t *detected_class) {
+    return guarded([&] {
+        if (n < 0) throw std::invalid_argument("negative size");
+        if (n == 0) return SIVO_OK;
+        if (!kps || !depth || !xyz || !entropy || !confidence || !classes || !detected_class) throw std::invalid_argument("null argument");
+        if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device: libsivo_hip has no CPU fallback");
+        struct Buf { void *p = nullptr; ~Buf() { (void)hipFree(p); } };
+        auto up = [](Buf &b, const void *src, size_t bytes) {
+            SIVO_HIP(hipMalloc(&b.p, bytes ? bytes : 1));
+            if (src) SIVO_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+        };
+        Buf dk, dd, dx, de, dc, dl, dm, dr, da;
+        const size_t px = (size_t)rows * cols;
+        up(dk, kps, (size_t)n * sizeof(SivoKeyPoint)); up(dd, depth, (size_t)n * 4); up(dx, xyz, (size_t)n * 24);
+        up(de, entropy, px * 8); up(dc, confidence, px * 8); up(dl, classes, px);
+        up(dm, nullptr, (size_t)n * 8); up(dr, nullptr, (size_t)n * 8); up(da, nullptr, (size_t)n);
+        const int rc = sivo_check_semantics_dev(n, (const SivoKeyPoint *)dk.p, (const float *)dd.p, (const double *)dx.p, (const double *)de.p,
+                                                (const double *)dc.p, (const uint8_t *)dl.p, rows, cols, state_cov, fx, fy, bl, level_sigma2,
+                                                nlevels, th_entropy, th_confidence, (double *)dm.p, (double *)dr.p, (uint8_t *)da.p, nullptr);
+        if (rc) return rc;
+        if (mi) SIVO_HIP(hipMemcpy(mi, dm.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+        if (reduction) SIVO_HIP(hipMemcpy(reduction, dr.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+        SIVO_HIP(hipMemcpy(detected_class, da.p, (size_t)n, hipMemcpyDeviceToHost));
         return SIVO_OK;
     });
 }

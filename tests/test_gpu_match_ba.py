@@ -98,3 +98,24 @@ def test_entropy_gate_matches_oracle(oracle):
     assert (g[2][~(depth > 0)] == 0).all()
     e = selection.entropy_gate(kps[:0], depth[:0], xyz[:0], ent, Sx, 718.856, 718.856, 0.537, ls2, 4.0)
     assert len(e[0]) == 0
+
+
+def test_check_semantics_matches_oracle(oracle):
+    from sivo_amd import selection
+    rng = np.random.default_rng(6)
+    n, H, W = 1500, 352, 1024
+    kps = np.zeros(n, oracle.KP_DTYPE)
+    kps["x"] = rng.uniform(19, W - 19, n); kps["y"] = rng.uniform(19, H - 19, n); kps["octave"] = rng.integers(0, 8, n)
+    depth = rng.uniform(-2, 60, n).astype(np.float32)
+    xyz = np.stack([rng.uniform(-20, 20, n), rng.uniform(-3, 3, n), rng.uniform(1, 60, n)], 1)
+    ent = rng.uniform(0, 3.9, (H, W)); conf = rng.uniform(0.3, 1.0, (H, W)); cls = rng.integers(0, 15, (H, W)).astype(np.uint8)
+    A = rng.standard_normal((6, 6)); Sx = A @ A.T * 1e-3 + np.eye(6) * 1e-4
+    ls2 = (np.float32(1.2) ** (2 * np.arange(8))).astype(np.float32)
+    red0 = oracle.check_semantics(kps, depth, xyz, ent, conf, cls, Sx, 718.856, 718.856, 0.537, ls2, -1e9, 0.7)
+    th = float(np.median(red0[1][red0[2] != 255])) + 1e-3
+    o = oracle.check_semantics(kps, depth, xyz, ent, conf, cls, Sx, 718.856, 718.856, 0.537, ls2, th, 0.7)
+    g = selection.check_semantics(kps, depth, xyz, ent, conf, cls, Sx, 718.856, 718.856, 0.537, ls2, th, 0.7)
+    np.testing.assert_allclose(g[0], o[0], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(g[1], o[1], rtol=1e-12, atol=1e-11)
+    far = np.abs(o[1] - th) > 1e-9
+    assert np.array_equal(g[2][far], o[2][far]) and 0 < (o[2] != 255).sum() < n
