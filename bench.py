@@ -360,6 +360,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The frame loop is host code in Python: a generational collection of CPython's GC in the middle of a frame stalls the
+    # thread hand-over to the ORB extractor threads by ~3 ms (measured: tools/frame_timeline.py — whether a full collection
+    # lands in every frame depends on the exact count of live objects).  Everything set up so far is long-lived: move it
+    # out of the collector's reach, as a real-time host loop would.
+    import gc
+    gc.collect()
+    gc.freeze()
+
     # Every 8th timed frame carries HIP events around its MFMA kernels (that is what `roofline` is measured on; those frames
     # issue the forward in one lane so that a launch has the GPU to itself); SIVO_BENCH_NO_EVENTS=1: none at all.
     PROFILE_EVERY = 8

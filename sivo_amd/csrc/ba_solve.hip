@@ -28,6 +28,7 @@
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -766,6 +767,20 @@ struct Buf {
     template <class T> T *as() const { return (T *)p; }
 };
 
+// The LDS-resident Cholesky needs up to 127 KB of dynamic LDS: the opt-in is per device and per process, so it is made once
+// per device under a lock and its result is kept; a device that refuses it uses the global-memory kernel.
+static bool dense_solve_lds_ok() {
+    static std::mutex mu;
+    static int state[64] = {0};                 // per device: 0 unknown, 1 granted, -1 refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (state[dev] == 0)
+        state[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(ba_dense_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         126 * 126 * 8) == hipSuccess ? 1 : -1;
+    return state[dev] == 1;
+}
+
 class BaSolver {
  public:
     BaSolver(const double *poses, const uint8_t *fixed, int nP, const double *points, int nX, bool points_fixed,
@@ -873,9 +888,7 @@ class BaSolver {
                     } else {
                         hipLaunchKernelGGL(ba_pose_only_system_kernel, dim3(64), dim3(256), 0, 0, d_, lambda);
                     }
-                    if (6 * nF_ <= 126) {
-                        static bool attr = false;
-                        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ba_dense_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 126 * 126 * 8); attr = true; }
+                    if (6 * nF_ <= 126 && dense_solve_lds_ok()) {
                         hipLaunchKernelGGL(ba_dense_solve_kernel<true>, dim3(1), dim3(BA_SOLVE_T), (size_t)36 * nF_ * nF_ * 8, 0, d_);
                     } else {
                         hipLaunchKernelGGL(ba_dense_solve_kernel<false>, dim3(1), dim3(BA_SOLVE_T), 0, 0, d_);

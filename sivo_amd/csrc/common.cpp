@@ -1,5 +1,6 @@
 #include "common.hpp"
 
+#include <mutex>
 #include <stdexcept>
 
 namespace sivo {
@@ -17,6 +18,16 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     last_error_ref() = buf;
     return code;
+}
+
+bool first_use_on_device(int *flags) {
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    std::lock_guard<std::mutex> lock(mu);
+    if (flags[dev]) return false;
+    flags[dev] = 1;
+    return true;
 }
 
 }  // namespace sivo

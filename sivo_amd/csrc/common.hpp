@@ -59,6 +59,10 @@ T *dev_alloc(size_t n) {
     return p;
 }
 
+// true the first time it is called on the current device (thread-safe): kernel attributes such as the dynamic-LDS opt-in are
+// per device, and a process may drive several (sivo_segnet_create_multi)
+bool first_use_on_device(int *flags /* 64 ints, zero-initialised, one array per call site */);
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

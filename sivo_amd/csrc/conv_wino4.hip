@@ -33,6 +33,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "common.hpp"
 #include "segnet_kernels.hpp"
 
 namespace sivo {
@@ -891,8 +892,8 @@ size_t wino4_bridge_lds_bytes(int H, int W) { return (size_t)(4 * ((H + 3) / 4) 
 // after the output transform / bridge (gemm_only_events: only the two around the GEMM).
 void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream_t s, hipEvent_t *ev, bool gemm_only_events,
                        const Wino4Plan *plan) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int attr_set[64] = {0};
+    if (first_use_on_device(attr_set)) {
         for (const void *f : {(const void *)wino4_gemm_x6p_kernel<0>, (const void *)wino4_gemm_x6p_kernel<1>, (const void *)wino4_gemm_x6p_kernel<2>,
                               (const void *)wino4_gemm_x6p_kernel<3>, (const void *)wino4_gemm_x6p_kernel<4>, (const void *)wino4_gemm_x6p_kernel<7>,
                               (const void *)wino4_gemm_x6p_kernel<8>, (const void *)wino4_gemm_x6p_kernel<16>, (const void *)wino4_gemm_x6p_kernel<23>,
@@ -904,7 +905,6 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_kernel<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_STAGE * 4);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_bridge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     Wino4Args a{};
     a.C = c.Cin; a.K = c.Cout; a.Kp = c.CoutPad; a.H = c.H; a.W = c.W;

@@ -23,6 +23,7 @@
 
 #include <vector>
 
+#include "common.hpp"
 #include "segnet_kernels.hpp"
 
 namespace sivo {
@@ -305,11 +306,10 @@ void wino4f_pack_weights(const float *W, int cin, int cout, std::vector<float> &
 }
 
 void launch_conv_wino4f(const ConvArgs &a0, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int attr_set[64] = {0};
+    if (first_use_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino4f_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F_BUF * 4);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino4f_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F_BUF * 4);
-        attr_set = true;
     }
     ConvArgs a = a0;
     a.tiles_x = (a.W + F_TW - 1) / F_TW;
