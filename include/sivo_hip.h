@@ -80,6 +80,9 @@ int sivo_segnet_create_from_files(const char *model_file, const char *weights_fi
  * Only sivo_segnet_segment, _shape, _num_devices and _destroy take such a handle.  librccl.so is opened on first use. */
 int sivo_segnet_create_multi(const char *prototxt_text, size_t prototxt_len, int t_override, const float *weights,
                              size_t n_weights, const int *device_ids, int ndev, sivo_segnet_t *out);
+/* The same from the two files of BayesianSegNetParams (bayesian_segnet.hpp:23-40), like sivo_segnet_create_from_files. */
+int sivo_segnet_create_multi_from_files(const char *model_file, const char *weights_file, int t_override,
+                                        const int *device_ids, int ndev, sivo_segnet_t *out);
 int sivo_segnet_num_devices(sivo_segnet_t h, int *ndev);
 int sivo_segnet_destroy(sivo_segnet_t h);
 /* getInputGeometry (bayesian_segnet.hpp) and the blob shapes: T, C(=3), H, W, classes. */

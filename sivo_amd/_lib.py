@@ -65,6 +65,7 @@ SIGNATURES = {
     "sivo_caffemodel_weights": [C.c_char_p, _sz, _vp, _sz, _vp, _sz, C.POINTER(_sz)],
     "sivo_segnet_create_from_files": [C.c_char_p, C.c_char_p, _i, _i, C.POINTER(_vp)],
     "sivo_segnet_create_multi": [C.c_char_p, _sz, _i, _vp, _sz, _pi32, _i, C.POINTER(_vp)],
+    "sivo_segnet_create_multi_from_files": [C.c_char_p, C.c_char_p, _i, _pi32, _i, C.POINTER(_vp)],
     "sivo_segnet_num_devices": [_vp, _pi32],
     "sivo_segnet_destroy": [_vp],
     "sivo_segnet_shape": [_vp, _pi32, _pi32, _pi32, _pi32, _pi32],

@@ -17,6 +17,7 @@
 
 #include <cstdint>
 #include <string>
+#include <vector>
 
 struct sivo_segnet;
 
@@ -51,6 +52,10 @@ struct BayesianSegNetParams {
     int monte_carlo_samples = 0;
     uint64_t seed = 0;
     int device = 0;
+    /// More than one entry: the T samples of every segmentImage call are spread over these HIP devices inside this one
+    /// object (sivo_segnet_create_multi: per-device stream + RCCL communicator, reduce-scatter / all-gather over xGMI).
+    /// Empty: the single `device` above.
+    std::vector<int> devices;
 };
 
 class BayesianSegNet {

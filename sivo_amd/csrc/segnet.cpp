@@ -764,28 +764,45 @@ extern "C" int sivo_caffemodel_weights(const char *prototxt_text, size_t prototx
     });
 }
 
+// The weights of BayesianSegNetParams::weights_file as the flat fp32 array sivo_segnet_create takes: a .caffemodel is
+// read like Net::CopyTrainedLayersFrom does (bayesian_segnet.cpp:61, layers matched by name), a .sivow container as is.
+static std::vector<float> weights_from_file(const char *model_file, const char *weights_file, std::string &text) {
+    if (!model_file || !*model_file) throw std::invalid_argument("model_file (.prototxt file) is empty!");
+    if (!weights_file || !*weights_file) throw std::invalid_argument("weights_file (.caffemodel file) is empty!");
+    text = read_file(model_file);
+    const std::string wb = read_file(weights_file);
+    std::vector<float> w;
+    if (wb.size() >= 16 && std::memcmp(wb.data(), "SIVOW001", 8) == 0) {
+        uint64_t n = 0;
+        std::memcpy(&n, wb.data() + 8, 8);
+        if (wb.size() != 16 + 4 * n) throw std::invalid_argument("weights_file is truncated");
+        w.resize(n);
+        std::memcpy(w.data(), wb.data() + 16, 4 * n);
+    } else if (wb.size() < 200 && wb.compare(0, 7, "version") == 0) {
+        throw std::invalid_argument("weights_file is a Git-LFS pointer, not the trained model (run `git lfs pull`)");
+    } else if (looks_like_caffemodel(wb)) {
+        w = weights_from_caffemodel(wb, parse_prototxt(text));
+    } else {
+        throw std::invalid_argument("weights_file is neither a .caffemodel (protobuf NetParameter) nor a .sivow container");
+    }
+    return w;
+}
+
 extern "C" int sivo_segnet_create_from_files(const char *model_file, const char *weights_file, int t_override,
                                              int device, sivo_segnet_t *out) {
     return guarded([&] {
-        if (!model_file || !*model_file) throw std::invalid_argument("model_file (.prototxt file) is empty!");
-        if (!weights_file || !*weights_file) throw std::invalid_argument("weights_file (.caffemodel file) is empty!");
-        const std::string text = read_file(model_file);
-        const std::string wb = read_file(weights_file);
-        std::vector<float> w;
-        if (wb.size() >= 16 && std::memcmp(wb.data(), "SIVOW001", 8) == 0) {
-            uint64_t n = 0;
-            std::memcpy(&n, wb.data() + 8, 8);
-            if (wb.size() != 16 + 4 * n) throw std::invalid_argument("weights_file is truncated");
-            w.resize(n);
-            std::memcpy(w.data(), wb.data() + 16, 4 * n);
-        } else if (wb.size() < 200 && wb.compare(0, 7, "version") == 0) {
-            throw std::invalid_argument("weights_file is a Git-LFS pointer, not the trained model (run `git lfs pull`)");
-        } else if (looks_like_caffemodel(wb)) {
-            w = weights_from_caffemodel(wb, parse_prototxt(text));     // CopyTrainedLayersFrom: match layers by name
-        } else {
-            throw std::invalid_argument("weights_file is neither a .caffemodel (protobuf NetParameter) nor a .sivow container");
-        }
+        std::string text;
+        const std::vector<float> w = weights_from_file(model_file, weights_file, text);
         return sivo_segnet_create(text.data(), text.size(), t_override, w.data(), w.size(), device, out);
+    });
+}
+
+extern "C" int sivo_segnet_create_multi_from_files(const char *model_file, const char *weights_file, int t_override,
+                                                   const int *device_ids, int ndev, sivo_segnet_t *out) {
+    return guarded([&] {
+        std::string text;
+        const std::vector<float> w = weights_from_file(model_file, weights_file, text);
+        return sivo_segnet_create_multi(text.data(), text.size(), t_override, w.data(), w.size(), device_ids, ndev, out);
     });
 }
 

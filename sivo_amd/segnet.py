@@ -41,8 +41,14 @@ class BayesianSegNet:
                 raise ValueError("weights_file (.caffemodel file) is empty!")
             if not params.use_gpu:
                 raise _lib.SivoError(_lib.ERR_UNSUPPORTED, "use_gpu=false: this library has no CPU path")
-            rc = lib().sivo_segnet_create_from_files(params.model_file.encode(), params.weights_file.encode(), T,
-                                                     device, C.byref(h))
+            if self.devices is not None:
+                ids = (C.c_int32 * len(self.devices))(*self.devices)
+                rc = lib().sivo_segnet_create_multi_from_files(params.model_file.encode(), params.weights_file.encode(), T,
+                                                               ids, len(self.devices), C.byref(h))
+                device = self.devices[0] if self.devices else 0
+            else:
+                rc = lib().sivo_segnet_create_from_files(params.model_file.encode(), params.weights_file.encode(), T,
+                                                         device, C.byref(h))
         elif self.devices is not None:
             text = prototxt.encode() if isinstance(prototxt, str) else (prototxt or b"")
             w = np.ascontiguousarray(weights if weights is not None else np.zeros(0), np.float32)

@@ -51,6 +51,11 @@ def test_cpp_api_matches_python_binding(tmp_path, kitti_like_bgr):
     assert np.array_equal(np.fromfile(tmp_path / "classes.bin", np.uint8).reshape(H, W), cls)
     assert np.array_equal(np.fromfile(tmp_path / "confidence.bin", np.float64).reshape(H, W), conf)
     assert np.array_equal(np.fromfile(tmp_path / "entropy.bin", np.float64).reshape(H, W), ent)
+    # BayesianSegNetParams::devices: the file constructor of the multi-device handle (one rank here)
+    snm = BayesianSegNet(BayesianSegNetParams(str(tmp_path / "m.prototxt"), str(tmp_path / "w.sivow")), devices=[0])
+    cls_m, conf_m, _ = snm.segment_image(frame, seed=7)
+    np.testing.assert_allclose(conf_m, conf, atol=2e-7, rtol=0)
+    assert (cls_m == cls).mean() > 0.999
     kps, desc = orb.ORBextractor()(np.ascontiguousarray(frame[..., 0]))
     assert np.fromfile(tmp_path / "kps.bin", orb.KP_DTYPE).tobytes() == kps.tobytes()
     assert np.array_equal(np.fromfile(tmp_path / "desc.bin", np.uint8).reshape(-1, 32), desc)
