@@ -9,9 +9,10 @@
  *     best/second update at :86-104)
  *   - Frame::ComputeStereoMatches             src/orbslam/Frame.cc:444-629
  *
- * PARITY UNPINNED: the reference has no tests for ORBmatcher / Frame; the only
- * known answers are the SWAR popcount identity (== builtin popcount) and the
- * thresholds TH_LOW=50 / TH_HIGH=100 (ORBmatcher.cc:37-39).
+ * PARITY: orc_descriptor_distance and the best / second-best scan are PINNED against the reference's own
+ * ORBmatcher.cc compiled into oracle/_ref (tests/cpp/pin_matcher.cpp, tests/test_pin_matcher.py).  ComputeStereoMatches
+ * stays UNPINNED (Frame.cc needs OpenCV): the known answers there are the SWAR popcount identity and the thresholds
+ * TH_LOW=50 / TH_HIGH=100 (ORBmatcher.cc:37-39).
  */
 #include <limits.h>
 #include <math.h>

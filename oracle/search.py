@@ -1,7 +1,7 @@
 """ctypes front-end of oracle/search_oracle.c — TEST INFRASTRUCTURE ONLY.
 
 Sequential restatements of the ORBmatcher Search* / Fuse routines (reference src/orbslam/ORBmatcher.cc) and of the
-frame grid (reference src/orbslam/Frame.cc:205-221, 326-390) on plain arrays.  PARITY UNPINNED (no reference tests).
+frame grid (reference src/orbslam/Frame.cc:205-221, 326-390) on plain arrays.  Parity pinned against the reference's own ORBmatcher.cc compiled into oracle/_ref (tests/cpp/pin_matcher.cpp).
 """
 import ctypes as C
 

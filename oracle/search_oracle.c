@@ -27,7 +27,12 @@
  * cv::Mat (passed in as the projected u, v, 1/z, distances).  Each function is
  * a loop-for-loop restatement; variable names follow the reference.
  *
- * PARITY UNPINNED: the reference holds no test for ORBmatcher.
+ * PARITY PINNED AGAINST THE REFERENCE'S OWN CODE: the reference holds no test for ORBmatcher, but its ORBmatcher.cc
+ * compiles untouched against stand-in SLAM types (oracle/Makefile `ref` -> oracle/_ref/, shims under oracle/ref_shims/);
+ * tests/cpp/pin_matcher.cpp runs that code and this restatement (behind the SIVO::ORBmatcher templates) on 144 scenes x
+ * routines and requires identical results (tests/test_pin_matcher.py; fixture tests/golden/matcher_reference.txt).
+ * What stays restated on BOTH sides of that comparison: the grid query (Frame.cc:326-390 / KeyFrame.cc:589-636, below)
+ * and cv::Mat's float arithmetic (sivo_amd/api/compat/cv_min.hpp) — Frame.cc and OpenCV cannot be compiled here.
  */
 #include <limits.h>
 #include <math.h>

@@ -3,6 +3,7 @@
 // SIVO_HAVE_OPENCV and the headers include <opencv2/core/core.hpp> instead: the class
 // sources only use members that exist in both.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -50,6 +51,13 @@ struct Vec3b {
     uchar &operator[](int i) { return v[i]; }
     uchar operator[](int i) const { return v[i]; }
 };
+
+class Mat;
+// `A.t()`, `-A`, `s * A`, `A / s`: a matrix with a pending transpose / scale factor, as cv::MatExpr keeps them, because
+// OpenCV's arithmetic depends on it (see gemm below).  Converts to Mat where a Mat is expected.
+struct MatScaled;
+// `A * B (+ C)`: one cv::gemm call, evaluated when it is converted to Mat.
+struct MatProduct;
 
 class Mat {
  public:
@@ -103,11 +111,112 @@ class Mat {
         for (int r = 0; r < rows; ++r) std::memcpy(m.ptr(r), ptr(r), (size_t)cols * elemSize());
         return m;
     }
+    // element i of a row or column vector
+    template <class T> T &at(int i) { return rows == 1 ? ptr<T>(0)[i] : ptr<T>(i)[0]; }
+    template <class T> const T &at(int i) const { return rows == 1 ? ptr<T>(0)[i] : ptr<T>(i)[0]; }
+    // views (share the buffer)
+    Mat rowRange(int r0, int r1) const { Mat m = row(r0); m.rows = r1 - r0; return m; }
+    Mat colRange(int c0, int c1) const {
+        Mat m; m.rows = rows; m.cols = c1 - c0; m.type_ = type_; m.step = step; m.data = data + (size_t)c0 * elemSize(); m.buf_ = buf_;
+        return m;
+    }
+    Mat col(int c) const { return colRange(c, c + 1); }
+    void copyTo(Mat &dst) const { dst = clone(); }
+    // CV_32F algebra (defined below the class)
+    inline MatScaled t() const;
+    inline double dot(const Mat &o) const;
+    inline Mat(const MatScaled &e);
+    inline Mat(const MatProduct &e);
 
  private:
     int type_ = 0;
     std::shared_ptr<uchar> buf_;
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// CV_32F matrix algebra with the rounding of OpenCV 3.x (modules/core/src/matmul.cpp, convert.cpp, stat.cpp), which is
+// what decides last-bit results of expressions like `Rcw * x3Dw + tcw` or `-Rcw.t() * tcw`:
+//   * A * B + C with no transposed operand and an inner dimension of 2..4 takes gemm's small-matrix path: every dot
+//     product is accumulated left to right in float, then (float)(t * alpha + c * beta) with alpha / beta double;
+//   * any other product (a transposed operand) goes through GEMMSingleMul<float, double>: products and sum in double,
+//     (float)(alpha * sum + beta * c);
+//   * s * A, A / s, -A are convertTo with the factor narrowed to float: a * (float)alpha;
+//   * Mat::dot and cv::norm accumulate in double.
+struct MatScaled {
+    Mat m;
+    bool transposed;
+    double alpha;
+};
+struct MatProduct {
+    MatScaled a, b;
+    Mat c;          // empty: none
+    double beta;
+};
+
+inline MatScaled Mat::t() const { return MatScaled{*this, true, 1.0}; }
+inline double Mat::dot(const Mat &o) const {
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) s += (double)at<float>(r, c) * (double)o.at<float>(r, c);
+    return s;
+}
+inline Mat::Mat(const MatScaled &e) {
+    const int R = e.transposed ? e.m.cols : e.m.rows, C = e.transposed ? e.m.rows : e.m.cols;
+    create(R, C, CV_32F);
+    const float a = (float)e.alpha;
+    for (int r = 0; r < R; ++r)
+        for (int c = 0; c < C; ++c) {
+            const float v = e.transposed ? e.m.at<float>(c, r) : e.m.at<float>(r, c);
+            at<float>(r, c) = e.alpha == 1.0 ? v : v * a;
+        }
+}
+inline Mat::Mat(const MatProduct &e) {
+    const bool tA = e.a.transposed, tB = e.b.transposed;
+    const Mat &A = e.a.m, &B = e.b.m;
+    const int M = tA ? A.cols : A.rows, K = tA ? A.rows : A.cols, N = tB ? B.rows : B.cols;
+    const double alpha = e.a.alpha * e.b.alpha;
+    create(M, N, CV_32F);
+    const bool small = !tA && !tB && K >= 2 && K <= 4 && (K == N || K == M);
+    for (int i = 0; i < M; ++i)
+        for (int j = 0; j < N; ++j) {
+            const double c = e.c.empty() ? 0.0 : (double)e.c.at<float>(i, j) * e.beta;
+            if (small) {
+                float t = A.at<float>(i, 0) * B.at<float>(0, j);
+                for (int k = 1; k < K; ++k) t = t + A.at<float>(i, k) * B.at<float>(k, j);
+                at<float>(i, j) = (float)((double)t * alpha + c);
+            } else {
+                double s = 0.0;
+                for (int k = 0; k < K; ++k)
+                    s += (double)(tA ? A.at<float>(k, i) : A.at<float>(i, k)) * (double)(tB ? B.at<float>(j, k) : B.at<float>(k, j));
+                at<float>(i, j) = (float)(alpha * s + c);
+            }
+        }
+}
+
+inline MatScaled operator-(const Mat &a) { return MatScaled{a, false, -1.0}; }
+inline MatScaled operator-(const MatScaled &a) { return MatScaled{a.m, a.transposed, -a.alpha}; }
+inline MatScaled operator*(double s, const Mat &a) { return MatScaled{a, false, s}; }
+inline MatScaled operator*(const Mat &a, double s) { return MatScaled{a, false, s}; }
+inline MatScaled operator/(const Mat &a, double s) { return MatScaled{a, false, 1.0 / s}; }
+inline MatScaled operator*(double s, const MatScaled &a) { return MatScaled{a.m, a.transposed, a.alpha * s}; }
+inline MatProduct operator*(const Mat &a, const Mat &b) { return MatProduct{MatScaled{a, false, 1.0}, MatScaled{b, false, 1.0}, Mat(), 0.0}; }
+inline MatProduct operator*(const MatScaled &a, const Mat &b) { return MatProduct{a, MatScaled{b, false, 1.0}, Mat(), 0.0}; }
+inline MatProduct operator*(const Mat &a, const MatScaled &b) { return MatProduct{MatScaled{a, false, 1.0}, b, Mat(), 0.0}; }
+inline MatProduct operator+(const MatProduct &p, const Mat &c) { MatProduct q = p; q.c = c; q.beta = 1.0; return q; }
+inline MatProduct operator-(const MatProduct &p, const Mat &c) { MatProduct q = p; q.c = c; q.beta = -1.0; return q; }
+inline Mat operator+(const Mat &a, const Mat &b) {
+    Mat m(a.rows, a.cols, CV_32F);
+    for (int r = 0; r < a.rows; ++r)
+        for (int c = 0; c < a.cols; ++c) m.at<float>(r, c) = a.at<float>(r, c) + b.at<float>(r, c);
+    return m;
+}
+inline Mat operator-(const Mat &a, const Mat &b) {
+    Mat m(a.rows, a.cols, CV_32F);
+    for (int r = 0; r < a.rows; ++r)
+        for (int c = 0; c < a.cols; ++c) m.at<float>(r, c) = a.at<float>(r, c) - b.at<float>(r, c);
+    return m;
+}
+inline double norm(const Mat &a) { return std::sqrt(a.dot(a)); }
 
 // The reference passes cv::InputArray / cv::OutputArray; every call site hands a cv::Mat.
 typedef const Mat &InputArray;

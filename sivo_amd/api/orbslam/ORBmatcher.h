@@ -68,25 +68,48 @@ class DeviceFrame {
     int n_ = 0;
 };
 
-// p_c = R p_w + t for a 3 x 3 / 3 x 1 CV_32F pair taken from a 4 x 4 (or 3 x 4) pose matrix.  cv::Mat's `R * x + t` is one
-// gemm call, whose CV_32F kernel accumulates each dot product in double and rounds the sum (plus t) once.
-inline void transform(const cv::Mat &T, const cv::Mat &Xw, float Xc[3], float scale = 1.0f) {
-    const float X = Xw.at<float>(0, 0), Y = Xw.at<float>(1, 0), Z = Xw.at<float>(2, 0);
-    for (int r = 0; r < 3; ++r) {
-        const double s = (double)(T.at<float>(r, 0) / scale) * X + (double)(T.at<float>(r, 1) / scale) * Y +
-                         (double)(T.at<float>(r, 2) / scale) * Z;
-        Xc[r] = (float)(s + (double)(T.at<float>(r, 3) / scale));
+// The float arithmetic of the cv::Mat expressions the reference routines evaluate per point (OpenCV 3.x, matmul.cpp /
+// convert.cpp / stat.cpp; tests/cpp/pin_matcher.cpp compares against the reference's own ORBmatcher.cc):
+//   `R * x + t` (3 x 3 by 3 x 1, nothing transposed) is gemm's small-matrix path: each dot product summed left to right in
+//   float, then + t;   `-R.t() * t` goes through the general kernel: products and sum in double, rounded once;
+//   `M / s` is convertTo with the factor narrowed to float: m * (float)(1.0 / s);   Mat::dot and cv::norm sum in double.
+struct Pose {            // [R | t] of a 4 x 4 (or 3 x 4) CV_32F matrix, optionally with a similarity's scale divided out
+    float R[9], t[3];
+    explicit Pose(const cv::Mat &T, float scale = 1.0f) {
+        const float inv = (float)(1.0 / (double)scale);
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) R[3 * r + c] = scale == 1.0f ? T.at<float>(r, c) : T.at<float>(r, c) * inv;
+            t[r] = scale == 1.0f ? T.at<float>(r, 3) : T.at<float>(r, 3) * inv;
+        }
     }
-}
-
-// camera centre -R^T t of a pose matrix (with the scale of a similarity divided out)
-inline void centre(const cv::Mat &T, float O[3], float scale = 1.0f) {
-    for (int c = 0; c < 3; ++c) {
-        double s = 0.0;
-        for (int r = 0; r < 3; ++r) s += (double)(T.at<float>(r, c) / scale) * (double)(T.at<float>(r, 3) / scale);
-        O[c] = (float)(-s);
+    Pose(const cv::Mat &Rm, const cv::Mat &tm) {
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) R[3 * r + c] = Rm.at<float>(r, c);
+            t[r] = tm.at<float>(r, 0);
+        }
     }
-}
+    // Xc = R * X + t
+    void apply(const float X[3], float Xc[3]) const {
+        for (int r = 0; r < 3; ++r) {
+            float s = R[3 * r] * X[0];
+            s = s + R[3 * r + 1] * X[1];
+            s = s + R[3 * r + 2] * X[2];
+            Xc[r] = s + t[r];
+        }
+    }
+    void apply(const cv::Mat &Xw, float Xc[3]) const {
+        const float X[3] = {Xw.at<float>(0, 0), Xw.at<float>(1, 0), Xw.at<float>(2, 0)};
+        apply(X, Xc);
+    }
+    // O = -R.t() * t
+    void centre(float O[3]) const {
+        for (int c = 0; c < 3; ++c) {
+            double s = 0.0;
+            for (int r = 0; r < 3; ++r) s += (double)R[3 * r + c] * (double)t[r];
+            O[c] = (float)(-s);
+        }
+    }
+};
 
 inline float norm3(const float a[3]) { return (float)std::sqrt((double)a[0] * a[0] + (double)a[1] * a[1] + (double)a[2] * a[2]); }
 
@@ -247,13 +270,10 @@ template <class FrameT>
 int ORBmatcher::SearchByProjection(FrameT &CurrentFrame, const FrameT &LastFrame, const float th, const bool bMono) {
     using namespace matcher_detail;
     // relative motion along the optical axis decides the octave range searched (:1284-1300)
+    const Pose Tcw(CurrentFrame.mTcw), Tlw(LastFrame.mTcw);
     float twc[3], tlc[3];
-    centre(CurrentFrame.mTcw, twc);
-    {
-        cv::Mat c(3, 1, CV_32F);
-        for (int r = 0; r < 3; ++r) c.at<float>(r, 0) = twc[r];
-        transform(LastFrame.mTcw, c, tlc);
-    }
+    Tcw.centre(twc);
+    Tlw.apply(twc, tlc);
     const bool bForward = tlc[2] > CurrentFrame.mb && !bMono;
     const bool bBackward = -tlc[2] > CurrentFrame.mb && !bMono;
 
@@ -265,7 +285,7 @@ int ORBmatcher::SearchByProjection(FrameT &CurrentFrame, const FrameT &LastFrame
         auto *pMP = LastFrame.mvpMapPoints[i];
         if (!pMP || LastFrame.mvbOutlier[i]) continue;
         float x3Dc[3];
-        transform(CurrentFrame.mTcw, pMP->GetWorldPos(), x3Dc);
+        Tcw.apply(pMP->GetWorldPos(), x3Dc);
         const float invzc = 1.0 / x3Dc[2];
         valid[i] = 1;
         invz[i] = invzc;
@@ -295,8 +315,9 @@ template <class FrameT, class KeyFrameT, class MapPointT>
 int ORBmatcher::SearchByProjection(FrameT &CurrentFrame, KeyFrameT *pKF, const std::set<MapPointT *> &sAlreadyFound,
                                    const float th, const int ORBdist) {
     using namespace matcher_detail;
+    const Pose Tcw(CurrentFrame.mTcw);
     float Ow[3];
-    centre(CurrentFrame.mTcw, Ow);
+    Tcw.centre(Ow);
     const std::vector<MapPointT *> vpMPs = pKF->GetMapPointMatches();
     const size_t n = vpMPs.size();
     std::vector<uint8_t> valid(n, 0), desc(32 * n, 0);
@@ -307,7 +328,7 @@ int ORBmatcher::SearchByProjection(FrameT &CurrentFrame, KeyFrameT *pKF, const s
         if (!pMP || pMP->isBad() || sAlreadyFound.count(pMP)) continue;
         const cv::Mat x3Dw = pMP->GetWorldPos();
         float x3Dc[3];
-        transform(CurrentFrame.mTcw, x3Dw, x3Dc);
+        Tcw.apply(x3Dw, x3Dc);
         const float invzc = 1.0 / x3Dc[2];
         u[i] = CurrentFrame.fx * x3Dc[0] * invzc + CurrentFrame.cx;
         v[i] = CurrentFrame.fy * x3Dc[1] * invzc + CurrentFrame.cy;
@@ -339,11 +360,11 @@ namespace matcher_detail {
 // The per-point tests shared by SearchByProjection(KF, Scw), the two Fuse and SearchBySim3 (ORBmatcher.cc:313-353, 806-848,
 // 968-1006): positive depth, inside the image, distance inside the scale-invariance range, viewing angle below 60 deg.
 template <class KeyFrameT, class MapPointT>
-bool project_for_fusion(KeyFrameT *pKF, MapPointT *pMP, const cv::Mat &Tcw, float scale, const float Ow[3], bool checkNormal,
-                        float &u, float &v, float &invz, int &level) {
+bool project_for_fusion(KeyFrameT *pKF, MapPointT *pMP, const Pose &Tcw, const float Ow[3], bool checkNormal, float &u, float &v,
+                        float &invz, int &level) {
     const cv::Mat p3Dw = pMP->GetWorldPos();
     float p3Dc[3];
-    transform(Tcw, p3Dw, p3Dc, scale);
+    Tcw.apply(p3Dw, p3Dc);
     if (p3Dc[2] < 0.0f) return false;
     invz = 1.0 / p3Dc[2];
     u = pKF->fx * (p3Dc[0] * invz) + pKF->cx;
@@ -354,15 +375,15 @@ bool project_for_fusion(KeyFrameT *pKF, MapPointT *pMP, const cv::Mat &Tcw, floa
     if (dist3D < pMP->GetMinDistanceInvariance() || dist3D > pMP->GetMaxDistanceInvariance()) return false;
     if (checkNormal) {
         const cv::Mat Pn = pMP->GetNormal();
-        const float dot = PO[0] * Pn.at<float>(0, 0) + PO[1] * Pn.at<float>(1, 0) + PO[2] * Pn.at<float>(2, 0);
+        const double dot = (double)PO[0] * Pn.at<float>(0, 0) + (double)PO[1] * Pn.at<float>(1, 0) + (double)PO[2] * Pn.at<float>(2, 0);
         if (dot < 0.5 * dist3D) return false;
     }
     level = pMP->PredictScale(dist3D, pKF);
     return true;
 }
-inline float sim3_scale(const cv::Mat &Scw) {
-    const float a = Scw.at<float>(0, 0), b = Scw.at<float>(0, 1), c = Scw.at<float>(0, 2);
-    return std::sqrt(a * a + b * b + c * c);
+inline float sim3_scale(const cv::Mat &Scw) {      // sqrt(sRcw.row(0).dot(sRcw.row(0)))
+    const double a = Scw.at<float>(0, 0), b = Scw.at<float>(0, 1), c = Scw.at<float>(0, 2);
+    return (float)std::sqrt(a * a + b * b + c * c);
 }
 }  // namespace matcher_detail
 
@@ -370,9 +391,9 @@ template <class KeyFrameT, class MapPointT>
 int ORBmatcher::SearchByProjection(KeyFrameT *pKF, cv::Mat Scw, const std::vector<MapPointT *> &vpPoints,
                                    std::vector<MapPointT *> &vpMatched, int th) {
     using namespace matcher_detail;
-    const float scw = sim3_scale(Scw);
+    const Pose Tcw(Scw, sim3_scale(Scw));
     float Ow[3];
-    centre(Scw, Ow, scw);
+    Tcw.centre(Ow);
     std::set<MapPointT *> spAlreadyFound(vpMatched.begin(), vpMatched.end());
     spAlreadyFound.erase(static_cast<MapPointT *>(nullptr));
     const size_t n = vpPoints.size();
@@ -384,7 +405,7 @@ int ORBmatcher::SearchByProjection(KeyFrameT *pKF, cv::Mat Scw, const std::vecto
         if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
         float invz;
         int lvl;
-        if (!project_for_fusion(pKF, pMP, Scw, scw, Ow, true, u[i], v[i], invz, lvl)) continue;
+        if (!project_for_fusion(pKF, pMP, Tcw, Ow, true, u[i], v[i], invz, lvl)) continue;
         valid[i] = 1; level[i] = lvl;
         descriptor_row(pMP->GetDescriptor(), desc, i);
     }
@@ -404,14 +425,7 @@ int ORBmatcher::SearchByProjection(KeyFrameT *pKF, cv::Mat Scw, const std::vecto
 template <class KeyFrameT, class MapPointT>
 int ORBmatcher::Fuse(KeyFrameT *pKF, const std::vector<MapPointT *> &vpMapPoints, const float th) {
     using namespace matcher_detail;
-    cv::Mat Tcw(3, 4, CV_32F);
-    {
-        const cv::Mat R = pKF->GetRotation(), t = pKF->GetTranslation();
-        for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c) Tcw.at<float>(r, c) = R.at<float>(r, c);
-            Tcw.at<float>(r, 3) = t.at<float>(r, 0);
-        }
-    }
+    const Pose Tcw(pKF->GetRotation(), pKF->GetTranslation());
     const cv::Mat OwM = pKF->GetCameraCenter();
     const float Ow[3] = {OwM.at<float>(0, 0), OwM.at<float>(1, 0), OwM.at<float>(2, 0)};
     const size_t n = vpMapPoints.size();
@@ -423,7 +437,7 @@ int ORBmatcher::Fuse(KeyFrameT *pKF, const std::vector<MapPointT *> &vpMapPoints
         if (!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
         float invz;
         int lvl;
-        if (!project_for_fusion(pKF, pMP, Tcw, 1.0f, Ow, true, u[i], v[i], invz, lvl)) continue;
+        if (!project_for_fusion(pKF, pMP, Tcw, Ow, true, u[i], v[i], invz, lvl)) continue;
         ur[i] = u[i] - pKF->mbf * invz;
         valid[i] = 1; level[i] = lvl;
         descriptor_row(pMP->GetDescriptor(), desc, i);
@@ -433,10 +447,15 @@ int ORBmatcher::Fuse(KeyFrameT *pKF, const std::vector<MapPointT *> &vpMapPoints
     check(sivo_fuse(dKF.get(), (int)n, valid.data(), u.data(), v.data(), ur.data(), level.data(), desc.data(), th, 0, best.data(),
                     nullptr, &nFused),
           "Fuse");
-    // If there is already a MapPoint replace otherwise add new measurement (:909-923), in the reference's order
+    // If there is already a MapPoint replace otherwise add new measurement (:909-923), in the reference's order.  The
+    // reference tests isBad() / IsInKeyFrame() at the top of every iteration, i.e. AFTER the surgery of the earlier ones
+    // (a Replace can retire a point that comes later in the list); which key a point would fuse with does not depend on it.
+    nFused = 0;
     for (size_t i = 0; i < n; ++i) {
         if (best[i] < 0) continue;
         MapPointT *pMP = vpMapPoints[i];
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+        ++nFused;
         MapPointT *pMPinKF = pKF->GetMapPoint(best[i]);
         if (pMPinKF) {
             if (!pMPinKF->isBad()) {
@@ -455,9 +474,9 @@ template <class KeyFrameT, class MapPointT>
 int ORBmatcher::Fuse(KeyFrameT *pKF, cv::Mat Scw, const std::vector<MapPointT *> &vpPoints, float th,
                      std::vector<MapPointT *> &vpReplacePoint) {
     using namespace matcher_detail;
-    const float scw = sim3_scale(Scw);
+    const Pose Tcw(Scw, sim3_scale(Scw));
     float Ow[3];
-    centre(Scw, Ow, scw);
+    Tcw.centre(Ow);
     const std::set<MapPointT *> spAlreadyFound = pKF->GetMapPoints();
     const size_t n = vpPoints.size();
     std::vector<uint8_t> valid(n, 0), desc(32 * n, 0);
@@ -468,7 +487,7 @@ int ORBmatcher::Fuse(KeyFrameT *pKF, cv::Mat Scw, const std::vector<MapPointT *>
         if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
         float invz;
         int lvl;
-        if (!project_for_fusion(pKF, pMP, Scw, scw, Ow, true, u[i], v[i], invz, lvl)) continue;
+        if (!project_for_fusion(pKF, pMP, Tcw, Ow, true, u[i], v[i], invz, lvl)) continue;
         valid[i] = 1; level[i] = lvl;
         descriptor_row(pMP->GetDescriptor(), desc, i);
     }
@@ -497,19 +516,21 @@ int ORBmatcher::SearchBySim3(KeyFrameT *pKF1, KeyFrameT *pKF2, std::vector<MapPo
     using namespace matcher_detail;
     const std::vector<MapPointT *> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
     const int N1 = (int)vpMapPoints1.size(), N2 = (int)vpMapPoints2.size();
-    // [sR21 | t21] and [sR12 | t12] as 3 x 4 matrices (:1074-1077)
-    cv::Mat T12(3, 4, CV_32F), T21(3, 4, CV_32F);
-    for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) {
-            T12.at<float>(r, c) = s12 * R12.at<float>(r, c);
-            T21.at<float>(r, c) = (float)((1.0 / s12) * R12.at<float>(c, r));
+    // [sR12 | t12] and [sR21 | t21] (:1074-1077): sR12 = s12 * R12, sR21 = (1.0 / s12) * R12.t(), t21 = -sR21 * t12
+    Pose T12(R12, t12), T21(R12, t12);
+    {
+        const float inv = (float)(1.0 / (double)s12);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                T12.R[3 * r + c] = s12 * R12.at<float>(r, c);
+                T21.R[3 * r + c] = R12.at<float>(c, r) * inv;
+            }
+        for (int r = 0; r < 3; ++r) {
+            float acc = T21.R[3 * r] * t12.at<float>(0, 0);
+            acc = acc + T21.R[3 * r + 1] * t12.at<float>(1, 0);
+            acc = acc + T21.R[3 * r + 2] * t12.at<float>(2, 0);
+            T21.t[r] = -acc;
         }
-        T12.at<float>(r, 3) = t12.at<float>(r, 0);
-    }
-    for (int r = 0; r < 3; ++r) {
-        double s = 0.0;
-        for (int c = 0; c < 3; ++c) s += (double)T21.at<float>(r, c) * t12.at<float>(c, 0);
-        T21.at<float>(r, 3) = (float)(-s);
     }
     std::vector<uint8_t> already1((size_t)N1, 0), already2((size_t)N2, 0);
     for (int i = 0; i < N1; ++i) {
@@ -519,20 +540,11 @@ int ORBmatcher::SearchBySim3(KeyFrameT *pKF1, KeyFrameT *pKF2, std::vector<MapPo
         const int idx2 = pMP->GetIndexInKeyFrame(pKF2);
         if (idx2 >= 0 && idx2 < N2) already2[idx2] = 1;
     }
-    auto pose34 = [](KeyFrameT *pKF) {
-        cv::Mat T(3, 4, CV_32F);
-        const cv::Mat R = pKF->GetRotation(), t = pKF->GetTranslation();
-        for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c) T.at<float>(r, c) = R.at<float>(r, c);
-            T.at<float>(r, 3) = t.at<float>(r, 0);
-        }
-        return T;
-    };
     // one direction: the points of `from`, through its pose and the relative similarity, into `into`
     auto direction = [&](KeyFrameT *from, KeyFrameT *into, const std::vector<MapPointT *> &pts, const std::vector<uint8_t> &already,
-                         const cv::Mat &Trel, std::vector<int32_t> &vnMatch) {
+                         const Pose &Trel, std::vector<int32_t> &vnMatch) {
         const size_t n = pts.size();
-        const cv::Mat Tfw = pose34(from);
+        const Pose Tfw(from->GetRotation(), from->GetTranslation());
         std::vector<uint8_t> valid(n, 0), desc(32 * n, 0);
         std::vector<float> u(n, 0.f), v(n, 0.f);
         std::vector<int32_t> level(n, 0);
@@ -540,10 +552,8 @@ int ORBmatcher::SearchBySim3(KeyFrameT *pKF1, KeyFrameT *pKF2, std::vector<MapPo
             MapPointT *pMP = pts[i];
             if (!pMP || already[i] || pMP->isBad()) continue;
             float pa[3], pb[3];
-            transform(Tfw, pMP->GetWorldPos(), pa);
-            cv::Mat pam(3, 1, CV_32F);
-            for (int r = 0; r < 3; ++r) pam.at<float>(r, 0) = pa[r];
-            transform(Trel, pam, pb);
+            Tfw.apply(pMP->GetWorldPos(), pa);
+            Trel.apply(pa, pb);
             if (pb[2] < 0.0) continue;
             const float invz = 1.0 / pb[2];
             u[i] = into->fx * (pb[0] * invz) + into->cx;
@@ -621,16 +631,8 @@ int ORBmatcher::SearchForTriangulation(KeyFrameT *pKF1, KeyFrameT *pKF2, cv::Mat
                                        std::vector<std::pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo) {
     using namespace matcher_detail;
     // epipole in the second image (:639-647)
-    cv::Mat T2w(3, 4, CV_32F);
-    {
-        const cv::Mat R = pKF2->GetRotation(), t = pKF2->GetTranslation();
-        for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c) T2w.at<float>(r, c) = R.at<float>(r, c);
-            T2w.at<float>(r, 3) = t.at<float>(r, 0);
-        }
-    }
     float C2[3];
-    transform(T2w, pKF1->GetCameraCenter(), C2);
+    Pose(pKF2->GetRotation(), pKF2->GetTranslation()).apply(pKF1->GetCameraCenter(), C2);
     const float invz = 1.0f / C2[2];
     const float ex = pKF2->fx * C2[0] * invz + pKF2->cx, ey = pKF2->fy * C2[1] * invz + pKF2->cy;
     std::vector<int32_t> off1, idx1, off2, idx2;

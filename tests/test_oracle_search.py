@@ -1,5 +1,5 @@
 """CPU: the oracle's restatement of the ORBmatcher search routines and the frame grid (oracle/search_oracle.c).
-The reference has no tests for them (parity unpinned); what can be pinned is checked here: the grid query against a
+The reference has no tests for them; tests/test_pin_matcher.py pins them against the reference's own ORBmatcher.cc. Checked here: the grid query against a
 brute-force statement of Frame::GetFeaturesInArea's predicate, the sequential semantics on hand-made cases that have one
 possible answer, and the rotation-histogram rule."""
 import numpy as np
