@@ -25,7 +25,13 @@
  * it breaks size ties by heap address.  The stable rule used here: nodes
  * carry a creation sequence number and a later-created node compares greater.
  *
- * PARITY UNPINNED: the reference has no ORB tests and OpenCV is absent.
+ * PARITY: the reference has no ORB tests and OpenCV is absent, but ORBextractor.cc itself compiles untouched
+ * (oracle/Makefile `ref` -> oracle/_ref/libref_orb.so) once the OpenCV primitives above are supplied — by THIS file,
+ * through oracle/ref_shims/opencv2/imgproc/imgproc.hpp.  tests/test_pin_orb.py: on 32 image x configuration cases
+ * the extractor restated below equals the reference's own code in every cv::KeyPoint field, descriptor byte and
+ * pyramid pixel (with heap addresses growing in creation order, see DistributeOctTree above).  So the EXTRACTOR logic
+ * (constructor tables, pyramid, cell walk, octree, IC_Angle, pattern, steered BRIEF, scaling) is PINNED against the
+ * reference's code; the OpenCV PRIMITIVES stay restatements on both sides of that comparison and are UNPINNED.
  * Known answers checked in tests/test_oracle_orb.py: features-per-level
  * [434,362,302,251,209,175,145,122], pyramid sizes, umax table, scale chain.
  */

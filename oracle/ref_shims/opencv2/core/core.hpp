@@ -4,3 +4,4 @@
 #pragma once
 #include <cassert>   // the real header brings it in transitively; ORBmatcher.cc relies on that
 #include "../../../../sivo_amd/api/compat/cv_min.hpp"
+typedef unsigned char uchar;   // OpenCV declares it at global scope (cvdef.h)

@@ -1,2 +1,2 @@
 #pragma once
-#include "core/core.hpp"
+#include "imgproc/imgproc.hpp"

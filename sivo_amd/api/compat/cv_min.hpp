@@ -34,6 +34,12 @@ struct Point_ {
     T x = 0, y = 0;
     Point_() {}
     Point_(T x_, T y_) : x(x_), y(y_) {}
+    template <class S> Point_ &operator*=(S s) { x = (T)(x * s); y = (T)(y * s); return *this; }
+};
+struct Rect {
+    int x = 0, y = 0, width = 0, height = 0;
+    Rect() {}
+    Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {}
 };
 typedef Point_<float> Point2f;
 typedef Point_<int> Point2i;
@@ -43,6 +49,9 @@ struct KeyPoint {   // 28 bytes, the layout SivoKeyPoint mirrors
     Point2f pt;
     float size = 0, angle = -1, response = 0;
     int octave = 0, class_id = -1;
+    KeyPoint() {}
+    KeyPoint(float x, float y, float size_, float angle_ = -1, float response_ = 0, int octave_ = 0, int class_id_ = -1)
+        : pt(x, y), size(size_), angle(angle_), response(response_), octave(octave_), class_id(class_id_) {}
 };
 
 struct Vec3b {
@@ -73,10 +82,15 @@ class Mat {
         step = step_ ? step_ : (size_t)c * elemSize();
         data = static_cast<uchar *>(ptr);
     }
-    static Mat zeros(int r, int c, int type) {
-        Mat m(r, c, type);
-        if (m.data) std::memset(m.data, 0, m.step * (size_t)r);
-        return m;
+    // Mat::zeros is an initializer expression in OpenCV: ASSIGNED to a matrix that already has that size and type it
+    // fills the existing storage (a view stays a view — ORBextractor.cc:1012 relies on it), otherwise it allocates.
+    struct Zeros { int rows, cols, type; };
+    static Zeros zeros(int r, int c, int type) { return Zeros{r, c, type}; }
+    Mat(const Zeros &z) { *this = z; }
+    Mat &operator=(const Zeros &z) {
+        create(z.rows, z.cols, z.type);
+        for (int r = 0; r < rows; ++r) std::memset(ptr(r), 0, (size_t)cols * elemSize());
+        return *this;
     }
     void create(int r, int c, int type) {
         if (r == rows && c == cols && type == type_ && data) return;
@@ -121,6 +135,11 @@ class Mat {
         return m;
     }
     Mat col(int c) const { return colRange(c, c + 1); }
+    Mat operator()(const Rect &r) const { return rowRange(r.y, r.y + r.height).colRange(r.x, r.x + r.width); }
+    Mat(const Mat &m, const Rect &r) { *this = m(r); }
+    size_t step1() const { static const int sz[8] = {1, 1, 2, 2, 4, 4, 8, 0}; return step / (size_t)sz[depth()]; }
+    // cv::InputArray / cv::OutputArray are plain Mat references here
+    Mat getMat() const { return *this; }
     void copyTo(Mat &dst) const { dst = clone(); }
     // CV_32F algebra (defined below the class)
     inline MatScaled t() const;
