@@ -9,10 +9,10 @@
  *     best/second update at :86-104)
  *   - Frame::ComputeStereoMatches             src/orbslam/Frame.cc:444-629
  *
- * PARITY: orc_descriptor_distance and the best / second-best scan are PINNED against the reference's own
- * ORBmatcher.cc compiled into oracle/_ref (tests/cpp/pin_matcher.cpp, tests/test_pin_matcher.py).  ComputeStereoMatches
- * stays UNPINNED (Frame.cc needs OpenCV): the known answers there are the SWAR popcount identity and the thresholds
- * TH_LOW=50 / TH_HIGH=100 (ORBmatcher.cc:37-39).
+ * PARITY PINNED AGAINST THE REFERENCE'S OWN CODE: orc_descriptor_distance and the best / second-best scan against
+ * ORBmatcher.cc (tests/cpp/pin_matcher.cpp, tests/test_pin_matcher.py); orc_stereo_matches against Frame.cc's
+ * ComputeStereoMatches, both compiled untouched into oracle/_ref: mvRight / mvDepth bit for bit on 6 stereo scenes
+ * (tests/test_pin_frame.py; fixture tests/golden/frame_reference.json).
  */
 #include <limits.h>
 #include <math.h>

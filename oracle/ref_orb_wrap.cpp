@@ -9,50 +9,19 @@
 // greater.  To compare like with like, `mode 0` runs the reference on an arena that never reuses memory (addresses grow
 // with creation order: inside this library only — the version script keeps operator new local); `mode 1` leaves it on
 // the process's malloc, to show what that freedom amounts to.
-#include <sys/mman.h>
-
 #include <cstdint>
-#include <cstdlib>
 #include <cstring>
-#include <new>
 #include <vector>
 
 #include "include/orbslam/ORBextractor.h"   // the reference's header, found through -I/root/reference
-
-namespace {
-char *arena_base = nullptr;
-size_t arena_used = 0;
-const size_t ARENA_BYTES = 16ull << 30;       // virtual, MAP_NORESERVE
-bool arena_on = false;
-void *arena_alloc(size_t n) {
-    if (!arena_base) {
-        void *p = mmap(nullptr, ARENA_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-        if (p == MAP_FAILED) std::abort();
-        arena_base = static_cast<char *>(p);
-    }
-    n = (n + 15) & ~size_t(15);
-    if (arena_used + n > ARENA_BYTES) std::abort();
-    void *p = arena_base + arena_used;
-    arena_used += n;
-    return p;
-}
-bool in_arena(const void *p) { return arena_base && p >= arena_base && p < arena_base + ARENA_BYTES; }
-}  // namespace
-
-void *operator new(size_t n) { return arena_on ? arena_alloc(n) : std::malloc(n ? n : 1); }
-void *operator new[](size_t n) { return arena_on ? arena_alloc(n) : std::malloc(n ? n : 1); }
-void operator delete(void *p) noexcept { if (p && !in_arena(p)) std::free(p); }
-void operator delete[](void *p) noexcept { if (p && !in_arena(p)) std::free(p); }
-void operator delete(void *p, size_t) noexcept { if (p && !in_arena(p)) std::free(p); }
-void operator delete[](void *p, size_t) noexcept { if (p && !in_arena(p)) std::free(p); }
+#include "ref_arena.inc"
 
 // (*mpORBextractorLeft)(im, cv::Mat(), mvKeys, mDescriptors) on a fresh extractor: keys as cv::KeyPoint (28 bytes each),
 // descriptors n x 32, then mvImagePyramid (the views without the border, concatenated) and the four scale tables.
 extern "C" int ref_orb_extract(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int mode, const uint8_t *gray,
                                int rows, int cols, int step, void *keys_out, uint8_t *desc_out, int capacity, uint8_t *levels_out,
                                int levels_capacity, int32_t *level_rows, int32_t *level_cols, float *tables) {
-    arena_on = mode == 0;
-    arena_used = 0;
+    arena_begin(mode == 0);
     int n = 0;
     {
         SIVO::ORBextractor ex(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST);
@@ -78,7 +47,6 @@ extern "C" int ref_orb_extract(int nfeatures, float scaleFactor, int nlevels, in
                                  d = ex.GetInverseScaleSigmaSquares();
         for (int l = 0; l < nlevels; ++l) { tables[l] = a[(size_t)l]; tables[nlevels + l] = b[(size_t)l]; tables[2 * nlevels + l] = c[(size_t)l]; tables[3 * nlevels + l] = d[(size_t)l]; }
     }
-    if (arena_on && arena_used) madvise(arena_base, arena_used, MADV_DONTNEED);
-    arena_on = false;
+    arena_end();
     return n;
 }

@@ -84,6 +84,9 @@ inline void GaussianBlur(const Mat &src, Mat &dst, Size ksize, double sigmaX, do
     orc_gaussian7_u8(in.data, in.rows, in.cols, (int)in.step, dst.data, (int)dst.step);
 }
 
+// only reached for cameras with lens distortion (Frame::ComputeImageBounds); KITTI's rectified images have none
+inline void undistortPoints(const Mat &, Mat &, const Mat &, const Mat &, const Mat &, const Mat &) { std::abort(); }
+
 // cv::KeyPointsFilter::retainBest — only ORBextractor::ComputeKeyPointsOld (never called) uses it
 struct KeyPointsFilter {
     static void retainBest(std::vector<KeyPoint> &keypoints, int n_points) {

@@ -31,8 +31,9 @@
  * compiles untouched against stand-in SLAM types (oracle/Makefile `ref` -> oracle/_ref/, shims under oracle/ref_shims/);
  * tests/cpp/pin_matcher.cpp runs that code and this restatement (behind the SIVO::ORBmatcher templates) on 144 scenes x
  * routines and requires identical results (tests/test_pin_matcher.py; fixture tests/golden/matcher_reference.txt).
- * What stays restated on BOTH sides of that comparison: the grid query (Frame.cc:326-390 / KeyFrame.cc:589-636, below)
- * and cv::Mat's float arithmetic (sivo_amd/api/compat/cv_min.hpp) — Frame.cc and OpenCV cannot be compiled here.
+ * The grid (AssignFeaturesToGrid, PosInGrid, GetFeaturesInArea, below) is pinned separately against the reference's own
+ * Frame.cc (oracle/_ref/libref_frame.so, tests/test_pin_frame.py: 400 window queries per scene).  What stays restated
+ * on both sides: cv::Mat's float arithmetic (sivo_amd/api/compat/cv_min.hpp) — OpenCV cannot be compiled here.
  */
 #include <limits.h>
 #include <math.h>

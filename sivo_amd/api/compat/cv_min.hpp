@@ -140,6 +140,28 @@ class Mat {
     size_t step1() const { static const int sz[8] = {1, 1, 2, 2, 4, 4, 8, 0}; return step / (size_t)sz[depth()]; }
     // cv::InputArray / cv::OutputArray are plain Mat references here
     Mat getMat() const { return *this; }
+    // append rows (a view becomes an owning matrix, as in OpenCV)
+    void push_back(const Mat &m) {
+        if (empty()) { *this = m.clone(); return; }
+        Mat grown(rows + m.rows, cols, type_);
+        for (int r = 0; r < rows; ++r) std::memcpy(grown.ptr(r), ptr(r), (size_t)cols * elemSize());
+        for (int r = 0; r < m.rows; ++r) std::memcpy(grown.ptr(rows + r), m.ptr(r), (size_t)cols * elemSize());
+        *this = grown;
+    }
+    // convertTo without scaling: CV_8U / CV_32F -> CV_32F (dst may be *this)
+    void convertTo(Mat &dst, int type) const {
+        Mat out(rows, cols, type);
+        for (int r = 0; r < rows; ++r)
+            for (int c = 0; c < cols; ++c) out.at<float>(r, c) = depth() == CV_8U ? (float)at<uchar>(r, c) : at<float>(r, c);
+        dst = out;
+    }
+    static Mat ones(int r, int c, int type) {
+        Mat m(r, c, type);
+        for (int i = 0; i < r; ++i)
+            for (int j = 0; j < c; ++j) m.at<float>(i, j) = 1.0f;
+        return m;
+    }
+    Mat reshape(int) const { return *this; }      // only reached behind cv::undistortPoints, which is not provided
     void copyTo(Mat &dst) const { dst = clone(); }
     // CV_32F algebra (defined below the class)
     inline MatScaled t() const;
@@ -235,7 +257,38 @@ inline Mat operator-(const Mat &a, const Mat &b) {
         for (int c = 0; c < a.cols; ++c) m.at<float>(r, c) = a.at<float>(r, c) - b.at<float>(r, c);
     return m;
 }
+// A - s * B: addWeighted(A, 1, B, -s) with the weights narrowed to float
+inline Mat operator-(const Mat &a, const MatScaled &b) {
+    Mat m(a.rows, a.cols, CV_32F);
+    const float s = (float)b.alpha;
+    for (int r = 0; r < a.rows; ++r)
+        for (int c = 0; c < a.cols; ++c) m.at<float>(r, c) = a.at<float>(r, c) - s * (b.transposed ? b.m.at<float>(c, r) : b.m.at<float>(r, c));
+    return m;
+}
 inline double norm(const Mat &a) { return std::sqrt(a.dot(a)); }
+enum { NORM_L1 = 2, NORM_L2 = 4 };
+inline double norm(const Mat &a, const Mat &b, int type) {     // CV_32F, sums in double
+    double s = 0.0;
+    for (int r = 0; r < a.rows; ++r)
+        for (int c = 0; c < a.cols; ++c) {
+            const double d = (double)a.at<float>(r, c) - (double)b.at<float>(r, c);
+            s += type == NORM_L1 ? std::fabs(d) : d * d;
+        }
+    return type == NORM_L1 ? s : std::sqrt(s);
+}
+// cv::Mat_<float>(r, c) << a, b, c
+template <class T>
+class Mat_ : public Mat {
+ public:
+    Mat_(int r, int c) : Mat(r, c, sizeof(T) == 4 ? CV_32F : sizeof(T) == 8 ? CV_64F : CV_8U) {}
+    struct Filler {
+        Mat_ *m;
+        int i;
+        Filler &operator,(T v) { m->template ptr<T>(i / m->cols)[i % m->cols] = v; ++i; return *this; }
+        operator Mat() const { return *m; }
+    };
+    Filler operator<<(T v) { Filler f{this, 0}; f, v; return f; }
+};
 
 // The reference passes cv::InputArray / cv::OutputArray; every call site hands a cv::Mat.
 typedef const Mat &InputArray;
