@@ -500,7 +500,10 @@ void setup_geometry(sivo_orb &o, int rows, int cols) {
         L.off = (int64_t)poff; L.blur_off = (int64_t)boff;
         poff += ((size_t)L.step * (L.rows + 2 * EDGE_THRESHOLD) + 255) & ~(size_t)255;
         boff += ((size_t)L.cols * L.rows + 255) & ~(size_t)255;
-        if (L.cols < 2 * EDGE_THRESHOLD + 1 || L.rows < 2 * EDGE_THRESHOLD + 1)
+        // The reference needs maxBorder - minBorder = size - 2 * (EDGE_THRESHOLD - 3) >= 1 on every level: below that its
+        // DistributeOctTree sizes a vector with a negative count and aborts (ORBextractor.cc:553-560); from 33 px up a level
+        // that is too small for a 30 px cell simply yields no keys (tests/test_pin_orb.py, 120 x 160 at 8 levels).
+        if (L.cols < 2 * EDGE_THRESHOLD - 5 || L.rows < 2 * EDGE_THRESHOLD - 5)
             throw std::invalid_argument("image too small for the requested number of pyramid levels");
     }
     o.pyr_bytes = poff; o.blur_bytes = boff;
