@@ -10,7 +10,12 @@
  * MI - entropy > ThEntropyReduction.
  *
  * The reference takes determinants with Eigen (absent here): fixed 3x3 by cofactors, 6x6 and 9x9 by
- * partial-pivot LU — restated as such.  PARITY UNPINNED (no tests in the reference); anchors in
+ * partial-pivot LU with the diagonal multiplied in the order of Eigen's unrolled reduction — restated as such.
+ * PARITY: the FORMULAS are pinned against the reference's own sivo_helpers.cpp, compiled untouched into
+ * oracle/_ref/libref_helpers.so (Eigen replaced by the stand-in of oracle/ref_shims_eigen): orc_stereo_mutual_information
+ * equals the reference's Jacobian -> covariance -> mutual-information chain bit for bit on 512 cases
+ * (tests/test_pin_helpers.py; fixture tests/golden/helpers_reference.json).  Eigen's arithmetic itself and the call sites in
+ * Tracking.cc / LocalMapping.cc (which keypoints, which thresholds) stay restated.  Further anchors in
  * tests/test_oracle_select.py: numpy slogdet and the Schur identity det S9 = det Sx * det R.
  */
 #include <math.h>
@@ -18,9 +23,18 @@
 
 typedef struct { float x, y, size, angle, response; int32_t octave, class_id; } OrcKeyPoint;
 
-/* determinant by LU with partial pivoting (Eigen::PartialPivLU::determinant) */
+/* prod() of a fixed-size vector in the order of Eigen's unrolled reduction: halves, recursively */
+static double halving_product(const double *d, int start, int len) {
+    if (len == 1) return d[start];
+    const int half = len / 2;
+    return halving_product(d, start, half) * halving_product(d, start + half, len - half);
+}
+
+/* determinant by LU with partial pivoting (Eigen::PartialPivLU::determinant: first largest pivot, l = a / pivot,
+ * rank-1 update, sign * diagonal().prod()) */
 static double det_lu(double *a, int n) {
-    double det = 1.0;
+    double diag[16];
+    int sign = 1;
     for (int k = 0; k < n; ++k) {
         int piv = k;
         double best = fabs(a[k * n + k]);
@@ -29,15 +43,15 @@ static double det_lu(double *a, int n) {
         if (best == 0.0) return 0.0;
         if (piv != k) {
             for (int j = 0; j < n; ++j) { const double t = a[k * n + j]; a[k * n + j] = a[piv * n + j]; a[piv * n + j] = t; }
-            det = -det;
+            sign = -sign;
         }
-        det *= a[k * n + k];
+        diag[k] = a[k * n + k];
         for (int i = k + 1; i < n; ++i) {
             const double f = a[i * n + k] / a[k * n + k];
             for (int j = k + 1; j < n; ++j) a[i * n + j] -= f * a[k * n + j];
         }
     }
-    return det;
+    return (double)sign * halving_product(diag, 0, n);
 }
 
 static double det3(const double *m) {

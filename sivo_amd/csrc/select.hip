@@ -18,8 +18,16 @@
 
 namespace sivo {
 
+// diagonal().prod() in the order of Eigen's unrolled reduction (halves, recursively), written out for the two sizes used
+__device__ double diag_product(const double *d, int n) {
+    if (n == 6) return (d[0] * (d[1] * d[2])) * (d[3] * (d[4] * d[5]));
+    return ((d[0] * d[1]) * (d[2] * d[3])) * ((d[4] * d[5]) * (d[6] * (d[7] * d[8])));     // n == 9
+}
+
+// Eigen::PartialPivLU::determinant (what Matrix<double, 6, 6> / <9, 9>::determinant() evaluates: sivo_helpers.cpp:207-216)
 __device__ double det_lu(double *a, int n) {
-    double det = 1.0;
+    double diag[9];
+    double sign = 1.0;
     for (int k = 0; k < n; ++k) {
         int piv = k;
         double best = fabs(a[k * n + k]);
@@ -28,15 +36,15 @@ __device__ double det_lu(double *a, int n) {
         if (best == 0.0) return 0.0;
         if (piv != k) {
             for (int j = 0; j < n; ++j) { const double t = a[k * n + j]; a[k * n + j] = a[piv * n + j]; a[piv * n + j] = t; }
-            det = -det;
+            sign = -sign;
         }
-        det *= a[k * n + k];
+        diag[k] = a[k * n + k];
         for (int i = k + 1; i < n; ++i) {
             const double f = a[i * n + k] / a[k * n + k];
             for (int j = k + 1; j < n; ++j) a[i * n + j] -= f * a[k * n + j];
         }
     }
-    return det;
+    return sign * diag_product(diag, n);
 }
 
 struct GateArgs {
