@@ -9,11 +9,13 @@
  *   - the Monte-Carlo post-processing of
  *     src/bayesian_segnet/bayesian_segnet.cpp:38-44,180-203,262-297.
  *
- * PARITY UNPINNED: the reference ships no numeric fixture for this path
- * (tests/test_bayesian_segnet.cpp:152-168 pins output sizes only) and Caffe is
- * absent, so this file is checked against an independent second opinion
- * (PyTorch-CPU ops, tests/test_oracle_segnet.py) and known-answer constants
- * only.
+ * PARITY, two halves.  (1) The LAYERS (the forward pass) are UNPINNED: the reference ships no numeric fixture for this
+ * path (tests/test_bayesian_segnet.cpp:152-168 pins output sizes only) and Caffe is absent, so they are checked against an
+ * independent second opinion (PyTorch-CPU ops, tests/test_oracle_segnet.py) and known-answer constants only.
+ * (2) Everything AROUND the forward pass — orc_preprocess, orc_mc_mean, orc_mc_finalize, orc_mc_variance — is PINNED
+ * against the reference's own bayesian_segnet.cpp, compiled untouched into oracle/_ref/libref_segnet.so with a stand-in
+ * network whose Forward() copies in given probabilities: input blob, classes (ties included), confidence, entropy and
+ * variance bit for bit, up to the full 12 x 15 x 352 x 1024 size (tests/test_pin_segnet_post.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.

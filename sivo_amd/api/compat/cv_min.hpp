@@ -16,6 +16,7 @@
 #define CV_8UC1 CV_MAKETYPE(CV_8U, 1)
 #define CV_8UC3 CV_MAKETYPE(CV_8U, 3)
 #define CV_32FC1 CV_MAKETYPE(CV_32F, 1)
+#define CV_32FC3 CV_MAKETYPE(CV_32F, 3)
 #define CV_64FC1 CV_MAKETYPE(CV_64F, 1)
 
 namespace cv {
@@ -148,11 +149,14 @@ class Mat {
         for (int r = 0; r < m.rows; ++r) std::memcpy(grown.ptr(rows + r), m.ptr(r), (size_t)cols * elemSize());
         *this = grown;
     }
-    // convertTo without scaling: CV_8U / CV_32F -> CV_32F (dst may be *this)
+    // convertTo without scaling: CV_8U / CV_32F -> CV_32F, any channel count (dst may be *this)
     void convertTo(Mat &dst, int type) const {
         Mat out(rows, cols, type);
-        for (int r = 0; r < rows; ++r)
-            for (int c = 0; c < cols; ++c) out.at<float>(r, c) = depth() == CV_8U ? (float)at<uchar>(r, c) : at<float>(r, c);
+        const int n = cols * channels();
+        for (int r = 0; r < rows; ++r) {
+            float *o = out.ptr<float>(r);
+            for (int c = 0; c < n; ++c) o[c] = depth() == CV_8U ? (float)ptr<uchar>(r)[c] : ptr<float>(r)[c];
+        }
         dst = out;
     }
     static Mat ones(int r, int c, int type) {
