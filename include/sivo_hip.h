@@ -137,6 +137,22 @@ int sivo_segnet_segment(sivo_segnet_t h, const uint8_t *bgr_hwc, int rows, int c
 int sivo_segnet_segment_dev(sivo_segnet_t h, const uint8_t *d_bgr, uint64_t seed, uint8_t *d_classes,
                             double *d_confidence, double *d_entropy, void *stream);
 
+/* The same, and additionally the logits (T, classes, H, W fp32, the "conv1_1_D" blob of the reference's net) the maps
+ * were computed from.  When the net ends in a 3x3 classifier convolution, segment / segment_dev / forward_dev (without
+ * d_logits / d_prob) run that convolution, the Softmax layer and the reduction over the samples as ONE kernel
+ * (conv_cls_mc.hip) and the logits never reach memory; this entry point makes that kernel also store them, so a test can
+ * check (a) the logits against the reference net and (b) the maps against sivo_mc_segment_dev of exactly these logits.
+ * Test/diagnostic entry point (adds T x 21.6 MB of stores per frame). */
+int sivo_segnet_segment_logits_dev(sivo_segnet_t h, const uint8_t *d_bgr, uint64_t seed, uint8_t *d_classes,
+                                   double *d_confidence, double *d_entropy, float *d_logits, void *stream);
+
+/* The post-processing of segmentImage on given network outputs (bayesian_segnet.cpp:299-318 after Forward():
+ * extractMeanConfidence :278-297, computeClasses :180-190, computeMaxConfidence :192-203,
+ * computeClassificationEntropy :262-276): per pixel the Softmax of each of the T samples' logits (fp32), the mean of the T
+ * float probabilities in f64, its argmax (first maximum wins), maximum and entropy in bits.  d_logits: (T, classes, hw). */
+int sivo_mc_segment_dev(const float *d_logits, int T, int classes, int64_t hw, uint8_t *d_classes,
+                        double *d_confidence, double *d_entropy, void *stream);
+
 /* Copy a named blob of the last forward to the host (fp32; pooling masks are
  * returned as the flat input-plane index Caffe stores, as fp32).  shape =
  * {N, C, H, W}.  Test/diagnostic entry point. */

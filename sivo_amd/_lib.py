@@ -76,6 +76,8 @@ SIGNATURES = {
     "sivo_mc_variance_dev": [_vp, _i, _i, _i64, _vp, _vp, _vp],
     "sivo_segnet_segment": [_vp, _vp, _i, _i, _u64, _vp, _vp, _vp],
     "sivo_segnet_segment_dev": [_vp, _vp, _u64, _vp, _vp, _vp, _vp],
+    "sivo_segnet_segment_logits_dev": [_vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp],
+    "sivo_mc_segment_dev": [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp],
     "sivo_segnet_blob": [_vp, C.c_char_p, _vp, _sz, _pi32],
     "sivo_segnet_flops": [_vp, C.POINTER(_d), C.POINTER(_d)],
     "sivo_segnet_profile": [_vp, _i],

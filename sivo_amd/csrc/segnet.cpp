@@ -53,7 +53,10 @@ struct Op {
     // conv
     int ks = 0, cin = 0, cout = 0, cout_pad = 0;
     float *d_w = nullptr, *d_scale = nullptr, *d_shift = nullptr;
+    size_t w_off = 0;          // offset of the layer's Caffe weights in the flat parameter array
     void *d_wx6 = nullptr;     // wino4: the transformed weights as three bf16 planes (bf16x6 GEMM); null = fp32 MFMA GEMM
+    float *d_w_mc = nullptr;   // classifier: second copy of the weights in the layout of conv_cls_mc.hip (fused with the MC post-processing)
+    bool mc_fused_last = false;   // profiling: the last timed launch of this op was the fused kernel
     bool relu = false;
     bool v2 = false;           // conv_v2.hip kernel + weight layout
     bool wino = false;         // conv_wino.hip kernel + pre-transformed weights
@@ -93,6 +96,7 @@ struct sivo_segnet {
     std::vector<sivo::Op> ops;
     std::map<std::string, int> blob_id;
     int input_blob = -1, logits_blob = -1;
+    int cls_op = -1;               // the last op, when it is a classifier convolution conv_cls_mc.hip can fuse with the MC post-processing
     bool has_softmax = false;
     uint8_t *d_image = nullptr;     // H*W*3 staging for the host entry point
     float *d_prob_sum = nullptr;    // classes*H*W
@@ -285,6 +289,7 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             bool keep_ties = b.shared;
             if (const char *extra = std::getenv("SIVO_KEEP_TIES_LAYERS"))        // comma-separated layer names (experiments)
                 keep_ties = keep_ties || ("," + std::string(extra) + ",").find("," + L.name + ",") != std::string::npos;
+            op.w_off = woff;
             upload_conv(S, op, weights + woff, weights + woff + nw, b.H, b.W, keep_ties);
             woff += nw + op.cout;
             op.flops = 2.0 * op.ks * op.ks * op.cin * op.cout * (double)b.H * b.W;
@@ -463,6 +468,21 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             S.ops[pi].skip = true;
             S.blobs[A.out].fused_away = true;
         }
+    // classifier convolution -> Softmax -> mean over the samples -> argmax / max / entropy in one kernel (conv_cls_mc.hip):
+    // the logits stay on chip whenever the caller asks for the maps or the probability sums only.  SIVO_NO_FUSE_MC disables.
+    if (!std::getenv("SIVO_NO_FUSE_MC") && !S.ops.empty()) {
+        Op &L = S.ops.back();
+        const Blob &bi = S.blobs[L.in], &bo = S.blobs[L.out];
+        if (L.kind == OP_CONV && L.out == S.logits_blob && !bo.shared && !bi.shared && !bi.fused_away && L.pool_op < 0 &&
+            L.unpool_in < 0 && !L.w4_bridged_in && L.drop_site < 0 && cls_mc_supported(L.ks, L.cin, L.cout, bi.H, bi.W)) {
+            std::vector<float> wt;
+            cls_mc_pack_weights(weights + L.w_off, L.cin, L.cout, wt);
+            L.d_w_mc = dev_alloc<float>(wt.size());
+            S.owned.push_back(L.d_w_mc);
+            SIVO_HIP(hipMemcpy(L.d_w_mc, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+            S.cls_op = (int)S.ops.size() - 1;
+        }
+    }
     // allocate
     for (Blob &b : S.blobs) {
         if (b.fused_away) continue;
@@ -617,15 +637,30 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
     }
 }
 
-// d_prob_sum may be null when the caller finalizes from the logits itself (segment / segment_dev: the exact f64 mean).
+// Where the Monte-Carlo post-processing of a whole frame goes (segmentImage): maps on the device, optionally the logits
+// they were computed from.
+struct McTargets {
+    uint8_t *classes;
+    double *conf, *ent;
+    float *logits;     // optional (n, classes, H, W)
+};
+
+// d_prob_sum: fp32 sums of the softmax probabilities over the n samples (layout S.sum_chunk), or null.  mc: the f64 mean
+// and its maps (exact: no probability sum goes through memory).  When the plan ends in a classifier convolution that
+// conv_cls_mc.hip supports and neither the per-sample probabilities nor (outside mc) the logits are asked for, that
+// convolution, the Softmax and the reduction over the samples are ONE kernel and the logits blob is not written.
 void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t seed, float *d_prob_sum,
-             float *d_logits, float *d_prob, hipStream_t st) {
+             float *d_logits, float *d_prob, hipStream_t st, const McTargets *mc = nullptr) {
     const int64_t hw = (int64_t)S.H * S.W;
     if (S.profile) harvest(S);
+    const Blob &lg = S.blobs[S.logits_blob];
+    if (lg.shared) throw std::runtime_error("the network has no test-time dropout: nothing to sample");
     launch_preprocess(d_bgr, (float *)S.blobs[S.input_blob].d, hw, st);
+    const bool fuse = S.cls_op >= 0 && !d_prob && !d_logits && (mc || d_prob_sum);
+    const size_t last = fuse ? (size_t)S.cls_op : S.ops.size();
     // the sample-invariant ops form a prefix of the plan
     size_t fork = 0;
-    while (fork < S.ops.size() && (S.ops[fork].skip || S.blobs[S.ops[fork].out].shared)) ++fork;
+    while (fork < last && (S.ops[fork].skip || S.blobs[S.ops[fork].out].shared)) ++fork;
     // SIVO_LANES = 1..4 (default 3: measured 68.5 / 70.0 / 70.7 / 66.6 frames/s for 1 / 2 / 3 / 4 lanes at T = 12): how many
     // sample groups run side by side; profiling keeps one launch per op, and lanes of fewer than 2 samples gain nothing
     int lanes = S.d_wino4_ws ? S.ws_lanes : 3;
@@ -634,12 +669,12 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
     // The op at the fork (pool3 with its fused dropout in SegNet-Standard) produces per-sample values but also writes a
     // SHARED blob, the pooling switches every sample's decoder reads.  It runs once for all samples on the caller's
     // stream, ahead of the lane fork, so that exactly one kernel writes the switches and every lane is ordered after it.
-    while (lanes > 1 && fork < S.ops.size() && !S.ops[fork].skip && S.ops[fork].out2 >= 0 && S.blobs[S.ops[fork].out2].shared &&
+    while (lanes > 1 && fork < last && !S.ops[fork].skip && S.ops[fork].out2 >= 0 && S.blobs[S.ops[fork].out2].shared &&
            !S.blobs[S.ops[fork].out].shared)
         ++fork;
     run_ops(S, 0, fork, 0, n, sample0, seed, st, 0);
     if (lanes == 1) {
-        run_ops(S, fork, S.ops.size(), 0, n, sample0, seed, st, 0);
+        run_ops(S, fork, last, 0, n, sample0, seed, st, 0);
     } else {
         if (!S.lane_fork) SIVO_HIP(hipEventCreateWithFlags(&S.lane_fork, hipEventDisableTiming));
         SIVO_HIP(hipEventRecord(S.lane_fork, st));
@@ -655,18 +690,42 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
                 ls = S.lane_stream[l];
                 SIVO_HIP(hipStreamWaitEvent(ls, S.lane_fork, 0));
             }
-            run_ops(S, fork, S.ops.size(), n0, nl, sample0, seed, ls, l);
+            run_ops(S, fork, last, n0, nl, sample0, seed, ls, l);
             if (l > 0) SIVO_HIP(hipEventRecord(S.lane_join[l], ls));
             n0 += nl;
         }
         for (int l = 1; l < lanes; ++l) SIVO_HIP(hipStreamWaitEvent(st, S.lane_join[l], 0));
     }
+    if (fuse) {
+        // all samples are back on the caller's stream: classifier + Softmax + sum over the samples (+ maps) in one launch
+        Op &op = S.ops[S.cls_op];
+        const Blob &bi = S.blobs[op.in];
+        ClsMcArgs a{};
+        a.in = (const float *)bi.d; a.in_sample_stride = bi.chw();
+        a.wt = op.d_w_mc; a.ep_scale = op.d_scale; a.ep_shift = op.d_shift;
+        a.T = n; a.Cin = op.cin; a.H = bi.H; a.W = bi.W; a.C = op.cout; a.relu = op.relu;
+        a.logits = mc ? mc->logits : nullptr;
+        a.prob_sum = d_prob_sum; a.sum_chunk = S.sum_chunk;
+        if (mc) { a.classes = mc->classes; a.confidence = mc->conf; a.entropy = mc->ent; }
+        op.mc_fused_last = true;
+        if (S.profile) {
+            op.timed_last = true; op.w4_gemm_only_last = false; op.w4_groups_last = 0; op.last_n = n;
+            if (!op.ev0) { SIVO_HIP(hipEventCreate(&op.ev0)); SIVO_HIP(hipEventCreate(&op.ev1)); }
+            SIVO_HIP(hipEventRecord(op.ev0, st));
+        }
+        launch_conv_cls_mc(a, st);
+        if (S.profile) SIVO_HIP(hipEventRecord(op.ev1, st));
+    } else {
+        if (S.cls_op >= 0) S.ops[S.cls_op].mc_fused_last = false;
+        if (d_prob_sum || d_prob) launch_mc_reduce((const float *)lg.d, n, S.classes, hw, d_prob_sum ? d_prob_sum : S.d_prob_sum, d_prob, 0, st, S.sum_chunk);
+        if (mc) {
+            launch_mc_reduce_finalize((const float *)lg.d, n, S.classes, hw, mc->classes, mc->conf, mc->ent, st);
+            if (mc->logits) SIVO_HIP(hipMemcpyAsync(mc->logits, lg.d, (size_t)n * lg.chw() * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+        if (d_logits)
+            SIVO_HIP(hipMemcpyAsync(d_logits, lg.d, (size_t)n * lg.chw() * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
     if (S.profile) S.pending = true;
-    const Blob &lg = S.blobs[S.logits_blob];
-    if (lg.shared) throw std::runtime_error("the network has no test-time dropout: nothing to sample");
-    if (d_prob_sum || d_prob) launch_mc_reduce((const float *)lg.d, n, S.classes, hw, d_prob_sum ? d_prob_sum : S.d_prob_sum, d_prob, 0, st, S.sum_chunk);
-    if (d_logits)
-        SIVO_HIP(hipMemcpyAsync(d_logits, lg.d, (size_t)n * lg.chw() * sizeof(float), hipMemcpyDeviceToDevice, st));
     SIVO_HIP(hipGetLastError());
 }
 
@@ -894,9 +953,9 @@ extern "C" int sivo_segnet_segment(sivo_segnet_t h, const uint8_t *bgr, int rows
         hipStream_t st = h->stream;
         SIVO_HIP(hipMemcpy2DAsync(h->d_image, (size_t)h->W * 3, bgr + ((size_t)y_tl * cols + x_tl) * 3, (size_t)cols * 3,
                                   (size_t)h->W * 3, (size_t)h->H, hipMemcpyHostToDevice, st));
-        forward(*h, h->d_image, h->T, 0, seed, nullptr, nullptr, nullptr, st);
+        const McTargets mc{h->d_classes, h->d_conf, h->d_ent, nullptr};
+        forward(*h, h->d_image, h->T, 0, seed, nullptr, nullptr, nullptr, st, &mc);
         const int64_t hw = (int64_t)h->H * h->W;
-        launch_mc_reduce_finalize((const float *)h->blobs[h->logits_blob].d, h->T, h->classes, hw, h->d_classes, h->d_conf, h->d_ent, st);
         if (classes) SIVO_HIP(hipMemcpyAsync(classes, h->d_classes, hw, hipMemcpyDeviceToHost, st));
         if (confidence) SIVO_HIP(hipMemcpyAsync(confidence, h->d_conf, hw * sizeof(double), hipMemcpyDeviceToHost, st));
         if (entropy) SIVO_HIP(hipMemcpyAsync(entropy, h->d_ent, hw * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -912,9 +971,30 @@ extern "C" int sivo_segnet_segment_dev(sivo_segnet_t h, const uint8_t *d_bgr, ui
         if (h->multi) throw std::invalid_argument("a multi-device handle takes host buffers: use sivo_segnet_segment");
         DeviceGuard dg(h->device);
         hipStream_t st = (hipStream_t)stream;
-        forward(*h, d_bgr, h->T, 0, seed, nullptr, nullptr, nullptr, st);
-        launch_mc_reduce_finalize((const float *)h->blobs[h->logits_blob].d, h->T, h->classes, (int64_t)h->H * h->W, d_classes,
-                                  d_confidence, d_entropy, st);
+        const McTargets mc{d_classes, d_confidence, d_entropy, nullptr};
+        forward(*h, d_bgr, h->T, 0, seed, nullptr, nullptr, nullptr, st, &mc);
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_segnet_segment_logits_dev(sivo_segnet_t h, const uint8_t *d_bgr, uint64_t seed, uint8_t *d_classes,
+                                              double *d_confidence, double *d_entropy, float *d_logits, void *stream) {
+    return guarded([&] {
+        if (!h || !d_bgr || !d_classes || !d_confidence || !d_entropy || !d_logits) throw std::invalid_argument("null argument");
+        if (h->multi) throw std::invalid_argument("a multi-device handle takes host buffers: use sivo_segnet_segment");
+        DeviceGuard dg(h->device);
+        const McTargets mc{d_classes, d_confidence, d_entropy, d_logits};
+        forward(*h, d_bgr, h->T, 0, seed, nullptr, nullptr, nullptr, (hipStream_t)stream, &mc);
+        return SIVO_OK;
+    });
+}
+
+extern "C" int sivo_mc_segment_dev(const float *d_logits, int T, int classes, int64_t hw, uint8_t *d_classes,
+                                   double *d_confidence, double *d_entropy, void *stream) {
+    return guarded([&] {
+        if (!d_logits || !d_classes || !d_confidence || !d_entropy || T < 1 || classes < 1 || classes > 16 || hw < 1)
+            throw std::invalid_argument("bad argument (1 <= classes <= 16)");
+        launch_mc_reduce_finalize(d_logits, T, classes, hw, d_classes, d_confidence, d_entropy, (hipStream_t)stream);
         SIVO_HIP(hipGetLastError());
         return SIVO_OK;
     });
@@ -1004,7 +1084,7 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
             SivoOpProfile &p = out[r++];
             std::memset(&p, 0, sizeof p);
             std::snprintf(p.layer, sizeof p.layer, "%s", op.name.c_str());
-            std::snprintf(p.kernel, sizeof p.kernel, "%s", op.kernel.c_str());
+            std::snprintf(p.kernel, sizeof p.kernel, "%s", op.mc_fused_last ? "conv_wino_cls_mc_kernel" : op.kernel.c_str());
             p.samples = op.last_n;
             p.flops_per_sample = op.flops;
             p.bytes_per_sample = op.bytes;

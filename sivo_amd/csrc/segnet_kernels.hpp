@@ -64,6 +64,28 @@ int wino4f_slab_floats();
 void wino4f_pack_weights(const float *W, int cin, int cout, std::vector<float> &out, int *cout_pad);
 void launch_conv_wino4f(const ConvArgs &a, hipStream_t s);
 
+// classifier convolution (3x3, <= 16 classes) fused with Softmax + the f64 mean over the samples + argmax / max / entropy
+// (conv_cls_mc.hip): the logits never leave the chip
+struct ClsMcArgs {
+    const float *in;           // (T, Cin, H, W): the classifier's input for every sample
+    int64_t in_sample_stride;
+    const float *wt;           // cls_mc_pack_weights
+    const float *ep_scale;     // [C]  logit = ep_scale*acc + ep_shift
+    const float *ep_shift;     // [C]
+    int T, Cin, H, W, C;       // T = samples in this pass (the mean divides by it), C = classes
+    int relu;
+    int tiles_x, tiles_y;      // filled by the launcher
+    float *logits;             // optional (T, C, H, W): the logits the sums were formed from
+    float *prob_sum;           // optional fp32 sums over the samples, layout as launch_mc_reduce (sum_chunk)
+    int64_t sum_chunk;         // 0 = [class][pixel]
+    uint8_t *classes;          // optional maps (all three or none): argmax, max and entropy of the f64 mean
+    double *confidence;
+    double *entropy;
+};
+bool cls_mc_supported(int ks, int cin, int cout, int H, int W);
+void cls_mc_pack_weights(const float *W, int cin, int cout, std::vector<float> &out);
+void launch_conv_cls_mc(const ClsMcArgs &a, hipStream_t s);
+
 struct Wino4Plan {
     float *V, *M, *Vnext;    // disjoint buffers: this layer's transformed input, its GEMM output, the next layer's input
     bool skip_input;         // V was written by the previous layer's bridge

@@ -115,8 +115,15 @@ class BayesianSegNet:
                                          out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), _stream()))
         return out
 
-    def segment_into(self, d_bgr, seed, out):
-        """segmentImage on device-resident data: out = (classes u8, confidence f64, entropy f64) cuda tensors (H, W)."""
+    def segment_into(self, d_bgr, seed, out, logits=None):
+        """segmentImage on device-resident data: out = (classes u8, confidence f64, entropy f64) cuda tensors (H, W).
+        logits: optional cuda f32 tensor (T, classes, H, W) that receives the logits the maps were computed from."""
+        if logits is not None:
+            assert logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous()
+            assert tuple(logits.shape) == (self.T, self.classes, self.H, self.W)
+            check(lib().sivo_segnet_segment_logits_dev(self._h, d_bgr.data_ptr(), C.c_uint64(seed), out[0].data_ptr(),
+                                                       out[1].data_ptr(), out[2].data_ptr(), logits.data_ptr(), _stream()))
+            return out
         check(lib().sivo_segnet_segment_dev(self._h, d_bgr.data_ptr(), C.c_uint64(seed), out[0].data_ptr(), out[1].data_ptr(),
                                             out[2].data_ptr(), _stream()))
         return out
@@ -167,6 +174,18 @@ def mc_reduce(logits, prob_sum=None, want_prob=False, accumulate=False):
     check(lib().sivo_mc_reduce_dev(logits.data_ptr(), n, K, H * W, prob_sum.data_ptr(),
                                    prob.data_ptr() if want_prob else None, int(accumulate), _stream()))
     return prob_sum, prob
+
+
+def mc_segment(logits):
+    """The post-processing of segmentImage on given logits (T, classes, H, W): f64 mean of the per-sample softmax, then
+    classes (u8), confidence (f64), entropy (f64)."""
+    T, K, H, W = logits.shape
+    dev = logits.device
+    cls = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    conf = torch.empty((H, W), dtype=torch.float64, device=dev)
+    ent = torch.empty((H, W), dtype=torch.float64, device=dev)
+    check(lib().sivo_mc_segment_dev(logits.data_ptr(), T, K, H * W, cls.data_ptr(), conf.data_ptr(), ent.data_ptr(), _stream()))
+    return cls, conf, ent
 
 
 def mc_finalize(prob_sum, t_total):

@@ -12,7 +12,7 @@ import torch
 
 from oracle import prototxt as oproto
 from sivo_amd import netspec, weights as wts
-from sivo_amd.segnet import BayesianSegNet, mc_finalize, mc_reduce, mc_variance
+from sivo_amd.segnet import BayesianSegNet, mc_finalize, mc_reduce, mc_segment, mc_variance
 
 pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1e-3
@@ -320,6 +320,56 @@ def test_winograd_and_direct_conv_shapes(oracle, H, W, width):
             mism = (g == 0) != (o == 0)
             assert mism.mean() < 1e-4 and (np.abs(g[mism]) < 1e-4).all() and (np.abs(o[mism]) < 1e-4).all(), name
     np.testing.assert_allclose(logits.cpu().numpy(), ob["cls"], atol=LOGIT_TOL, rtol=0)
+
+
+def _classifier_prototxt(T, H, W, width, classes):
+    """data -> conv3x3(3->width)+ReLU+Dropout -> conv3x3(width->width)+BN+ReLU -> conv3x3(width->classes) -> Softmax: the tail
+    of SegNet-Standard (conv1_2_D, conv1_1_D, prob) behind a dropout, so that the classifier is per-sample."""
+    from sivo_amd.netspec import _bn, _conv, _drop, _relu, _softmax
+    out = [f'name: "classifier_tail"\ninput: "data"\ninput_dim: {T}\ninput_dim: 3\ninput_dim: {H}\ninput_dim: {W}\n']
+    out += [_conv("c0", "data", "c0", width, 3, 1), _relu("r0", "c0"), _drop("d0", "c0")]
+    out += [_conv("c1", "c0", "c1", width, 3, 1), _bn("c1_bn", "c1"), _relu("r1", "c1")]
+    out += [_conv("cls", "c1", "cls", classes, 3, 1), _softmax("cls")]
+    return "".join(out)
+
+
+@pytest.mark.parametrize("T,H,W,width,classes", [(4, 32, 64, 64, 15), (3, 40, 72, 64, 15), (2, 10, 24, 64, 11), (5, 8, 32, 66, 16),
+                                                 (12, 64, 128, 64, 15)])
+def test_classifier_fused_with_the_mc_postprocessing(oracle, T, H, W, width, classes):
+    """conv_cls_mc.hip: the 3x3 classifier convolution, the Softmax layer, the f64 mean over the samples and the maps in
+    one kernel (what segment / segment_dev / forward_dev without logits run).  Ragged tiles (H, W not multiples of the
+    8 x 32 workgroup tile), a channel count that is not a multiple of the K-chunk, 11 / 15 / 16 classes.
+      * its logits agree with the oracle's (1e-3) and with the separate classifier kernel's;
+      * its maps equal the post-processing kernel's on exactly these logits, bit for bit;
+      * its probability sums equal sivo_mc_reduce_dev of exactly these logits, bit for bit;
+      * maps against the oracle."""
+    text = _classifier_prototxt(T, H, W, width, classes)
+    net, w, sn = _make(text, T, seed=5)
+    img = _image(np.random.default_rng(T * H + W), H, W)
+    seed = 77
+    d_img = torch.from_numpy(img).cuda()
+    maps = (torch.empty((H, W), dtype=torch.uint8, device="cuda"), torch.empty((H, W), dtype=torch.float64, device="cuda"),
+            torch.empty((H, W), dtype=torch.float64, device="cuda"))
+    fl = torch.full((T, classes, H, W), float("nan"), dtype=torch.float32, device="cuda")
+    sn.segment_into(d_img, seed, maps, logits=fl)
+    plain = tuple(torch.empty_like(m) for m in maps)
+    sn.segment_into(d_img, seed, plain)                                   # the production entry point (no logits stored)
+    ps_fused = torch.full((classes, H, W), float("nan"), dtype=torch.float32, device="cuda")
+    sn.forward_into(d_img, seed, ps_fused)                                # fused, probability-sum form
+    ps_u, lg_u, _ = sn.forward(d_img, seed, want_logits=True)             # separate classifier kernel + mc_reduce
+    c2, f2, e2 = mc_segment(fl)
+    ps2, _ = mc_reduce(fl)
+    torch.cuda.synchronize()
+    assert torch.isfinite(fl).all()
+    for a, b in zip(maps, (c2, f2, e2)):
+        assert torch.equal(a, b)
+    for a, b in zip(maps, plain):
+        assert torch.equal(a, b)
+    assert torch.equal(ps_fused, ps2)
+    res = oracle.segment(net, w, img, seed, logits_name="cls")
+    np.testing.assert_allclose(fl.cpu().numpy(), res["logits"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(fl.cpu().numpy(), lg_u.cpu().numpy(), atol=2e-4, rtol=0)
+    _check_outputs(oracle, res, maps[0].cpu().numpy(), maps[1].cpu().numpy(), maps[2].cpu().numpy(), ps_fused.cpu().numpy(), T)
 
 
 def test_multi_device_handle_on_one_device(oracle, kitti_like_bgr):

@@ -24,7 +24,7 @@ from scipy import ndimage
 
 from oracle import prototxt as oproto
 from sivo_amd import netspec, weights as wts
-from sivo_amd.segnet import BayesianSegNet
+from sivo_amd.segnet import BayesianSegNet, mc_segment
 
 pytestmark = pytest.mark.gpu
 H, W = 352, 1024
@@ -144,7 +144,28 @@ def test_timed_configuration_against_the_oracle(oracle, kind, T, image, seed, ki
     assert err.max() < LOGIT_TOL
     np.testing.assert_allclose(conf, res["confidence"], atol=LOGIT_TOL / 2, rtol=0)
     np.testing.assert_allclose(ent, res["entropy"], atol=5e-3, rtol=0)
-    del res, err
+
+    # ---- the entry point bench.py times (segment_dev): classifier convolution + Softmax + mean over the samples in one
+    # kernel (conv_cls_mc.hip; SegNet-Basic's 1x1 classifier keeps the separate kernels).  Same seed, same switches, so the
+    # teacher-forced oracle run above is its reference too: every logit, and the maps == post-processing of these logits.
+    maps = (torch.empty((H, W), dtype=torch.uint8, device="cuda"), torch.empty((H, W), dtype=torch.float64, device="cuda"),
+            torch.empty((H, W), dtype=torch.float64, device="cuda"))
+    fl = torch.empty((T, sn.classes, H, W), dtype=torch.float32, device="cuda")
+    d_img = torch.from_numpy(img).cuda()
+    sn.segment_into(d_img, seed, maps, logits=fl)
+    plain = tuple(torch.empty_like(m) for m in maps)
+    sn.segment_into(d_img, seed, plain)
+    post = mc_segment(fl)
+    torch.cuda.synchronize()
+    for a, b, c in zip(maps, post, plain):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    ferr = np.abs(fl.cpu().numpy() - res["logits"])
+    print(f"[{kind} T={T} {image} seed={seed}] segment entry point: max|dlogit| {ferr.max():.3e} (mean {ferr.mean():.2e}), "
+          f"vs the separate classifier kernel {np.abs(fl.cpu().numpy() - lg).max():.2e}")
+    assert ferr.max() < LOGIT_TOL
+    np.testing.assert_allclose(maps[1].cpu().numpy(), res["confidence"], atol=LOGIT_TOL / 2, rtol=0)
+    np.testing.assert_allclose(maps[2].cpu().numpy(), res["entropy"], atol=5e-3, rtol=0)
+    del res, err, ferr, fl, maps, plain, post
 
     # ---- free-running: the oracle's own switches
     pre = [L["bottom"][0] for L in pools]
