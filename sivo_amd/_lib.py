@@ -133,6 +133,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first (make -C sivo_amd/csrc); "
                               "sivo_amd has no CPU fallback")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64.  Loaded first, libsivo_hip.so
+        # (linked against the same sonames) binds to that copy; loaded after /opt/rocm's, torch finds no device
+        # ("No HIP GPUs are available", seen when a test touched this library before anything had imported torch).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.sivo_last_error.restype = C.c_char_p
         for name, args in SIGNATURES.items():

@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "segnet_kernels.hpp"
@@ -209,94 +210,154 @@ __global__ __launch_bounds__(K_NTHR, 3) void conv_wino_cls_mc_kernel(ClsMcArgs a
         __syncthreads();
 
         if (chunk == nchunks - 1) {
-            // ---- output transform Y = A^T M A (lane-local): this lane's class li, rows 2 wm + {0,1}, columns 8 lk .. 8 lk + 7
-            float y[2][8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float sx[2][4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float m0 = acc[0 + c][r], m1 = acc[4 + c][r], m2 = acc[8 + c][r], m3 = acc[12 + c][r];
-                    sx[0][c] = m0 + m1 + m2;
-                    sx[1][c] = m1 - m2 - m3;
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    y[i][2 * r + 0] = sx[i][0] + sx[i][1] + sx[i][2];
-                    y[i][2 * r + 1] = sx[i][1] - sx[i][2] - sx[i][3];
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < 16; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // x[q] = logit of class li at pixel q = 8 i + j of this lane
-            float x[16];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float v = y[i][j] * ep_sc + ep_sh;
-                    if (a.relu) v = v > 0.f ? v : 0.f;
-                    x[8 * i + j] = v;
-                }
-            // 16 x 16 transpose over the 16 lanes of a group: afterwards x[c] = logit of class c at pixel li
-#pragma unroll
-            for (int k = 1; k < 16; k <<= 1) {
-                const bool up = (li & k) != 0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if ((r & k) == 0) {
-                        const float send = up ? x[r] : x[r | k];
-                        const float recv = __shfl_xor(send, k, 64);
-                        if (up) x[r] = recv; else x[r | k] = recv;
-                    }
-            }
-            // ---- Softmax over the classes of this lane's pixel + the f64 sum over the samples
-            if (a.logits && pix_ok) {
-                float *lp = a.logits + (int64_t)s * a.C * plane + pix;
-#pragma unroll
-                for (int c = 0; c < 16; ++c)
-                    if (c < a.C) lp[(int64_t)c * plane] = x[c];
-            }
-            float m = x[0];
-#pragma unroll
-            for (int c = 1; c < 16; ++c)
-                if (c < a.C) m = x[c] > m ? x[c] : m;
-            float den = 0.f;
-#pragma unroll
-            for (int c = 0; c < 16; ++c)
-                if (c < a.C) { x[c] = expf(x[c] - m); den = __fadd_rn(den, x[c]); }
-#pragma unroll
-            for (int c = 0; c < 16; ++c)
-                if (c < a.C) sum[c] += (double)__fdiv_rn(x[c], den);
+#include "conv_cls_mc_sample.inc"
         }
         s = s2; chunk = c2;
     }
     if (!pix_ok) return;
+#include "conv_cls_mc_maps.inc"
+}
 
-    if (a.prob_sum) {
-        // chunk == hw: [class][pixel]; otherwise pixel-chunk-major [pixel / chunk][class][pixel % chunk] (launch_mc_reduce)
-        float *dst = a.prob_sum + (pix / a.sum_chunk) * a.C * a.sum_chunk + (pix % a.sum_chunk);
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Second form of the same kernel: EVERYTHING is staged by LDS-DMA into a ring of NB stage buffers, D = NB - 1 K-chunks ahead.
+// The register-staged form above has its loads in flight for less than one K-chunk (they are issued at the top of an
+// iteration and must be in LDS at its end): measured on MI355X that is what bounds it — 0.70 ms per frame at T = 12 with the
+// matrix cores 33 % busy and 1.7 TB/s of input, i.e. one 5.9 KB patch per workgroup in flight against ~1.7 us of loaded
+// memory latency.  Here a stage is 6 dword-gather DMAs per wave for the patch (each instruction fills 64 consecutive LDS
+// dwords; the lanes' source offsets are chosen so that the LDS image IS the de-interleaved patch layout; halo positions
+// outside the image and padding slots pass an out-of-range offset and receive the buffer load's 0) + one 1 KiB weight DMA per wave: 7 vector-memory operations per
+// wave and stage, counted with s_waitcnt vmcnt(7 (D - 1)) — the stage needed now has landed, the D - 1 younger ones stay
+// in flight.  One fence-free barrier per K-chunk (s_waitcnt lgkmcnt(0) + s_barrier: __syncthreads() would drain vmcnt).
+// No staging registers, no LDS writes by the waves, D x 10 KB per workgroup in flight.  Requires Cin % 4 == 0.
+constexpr int D_PATCH = 1536;                  // dword slots of a stage's patch image: 4 channels x 368, padded to 24 x 64
+constexpr int D_WSLAB = cls_slab(4);
+constexpr int D_BUF = D_PATCH + D_WSLAB;       // 10 KiB
+constexpr int D_NI = 7;                        // vector-memory operations per wave and stage
+
+__device__ __forceinline__ void cls_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NB>
+__global__ __launch_bounds__(K_NTHR, 3) void conv_wino_cls_mc_dma_kernel(ClsMcArgs a) {
+    constexpr int D = NB - 1;
+    static_assert(D >= 1 && D_NI * (D - 1) < 64, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(16))) float lds[NB * D_BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int P = a.tiles_x * a.tiles_y, per = (P + 7) >> 3;
+    const int bid = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (bid >= P) return;
+    const int tx = bid % a.tiles_x, ty = bid / a.tiles_x;
+    const int x0 = tx * K_TW, y0 = ty * K_TH;
+    const int64_t plane = (int64_t)a.H * a.W;
+
+    const int a_base = lk * K_CS + (2 * wm) * K_PWp + li;
+    const int b_base = D_PATCH + lk * 16 + li;
+
+    // ---- DMA plan: instruction i of wave wm fills the LDS slots (4 i + wm) * 64 + lane of a stage's patch image.
+    // slot -> (channel c, patch row py, column col): col 0..16 = O[col] (q = 2 col + 1), col 19..35 = E[col - 19] (q = 2 (col - 19)),
+    // q = x - x0 + 1; everything else (row padding, channel padding, positions outside the image) reads the zero word.
+    // Byte offsets from the base of a stage's 4 input planes.  The DMAs are BUFFER loads (buffer_load_dword ... offen lds):
+    // a wave-uniform descriptor of the sample's input (base, Cin planes), the stage's plane offset in the scalar offset, the
+    // lane's part in a 32-bit VGPR — and the hardware bounds check returns 0 for an offset beyond the descriptor's range,
+    // which is what the lanes without a source (halo outside the image, padding slots) pass.
+    uint32_t d_off[6];
 #pragma unroll
-        for (int c = 0; c < 16; ++c)
-            if (c < a.C) dst[(int64_t)c * a.sum_chunk] = (float)sum[c];
+    for (int i = 0; i < 6; ++i) {
+        const int slot = (4 * i + wm) * 64 + lane;
+        const int c = slot / K_CS, rem = slot % K_CS;
+        const int py = rem / K_PWp, col = rem % K_PWp;
+        const int q = col < 17 ? 2 * col + 1 : 2 * (col - K_EOFF);
+        const int gyy = y0 + py - 1, gxx = x0 - 1 + q;
+        const bool ok = c < 4 && rem < K_PH * K_PWp && (col < 17 || col >= K_EOFF) && gyy >= 0 && gyy < a.H && gxx >= 0 && gxx < a.W;
+        d_off[i] = ok ? (uint32_t)((c * plane + (int64_t)gyy * a.W + gxx) * 4) : 0xfffffff0u;
     }
-    if (a.classes) {
-        // mean (f64) / argmax with first-wins ties / max / entropy in bits with the exact-zero guard (bayesian_segnet.cpp:38-44)
-        const double dT = (double)a.T;
-        int best = 0;
-        double bv = sum[0] / dT;
-        double ent = bv == 0 ? 0 : -1.0 * bv * log2(bv);
+    const uint32_t w_off = (uint32_t)((wm * 256 + lane * 4) * 4);
+    const int nchunks = a.Cin / 4;
+    const int total = a.T * nchunks;
+    const uint32_t in_bytes = (uint32_t)((int64_t)a.Cin * plane * 4);        // one sample's input (launcher: < 2^31)
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.wt, 0, nchunks * D_WSLAB * 4, 0x00020000);
+    // stage counter of the next stage to issue (sample, chunk)
+    int is = 0, ic = 0;
+    auto issue_stage = [&](int g) {
+        float *buf = lds + (g % NB) * D_BUF;
+        const __amdgpu_buffer_rsrc_t in_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (int64_t)is * a.in_sample_stride), 0, in_bytes, 0x00020000);
+        const int soff = (int)((int64_t)ic * 4 * plane * 4);
 #pragma unroll
-        for (int c = 1; c < 16; ++c)
-            if (c < a.C) {
-                const double v = sum[c] / dT;
-                if (v > bv) { bv = v; best = c; }
-                ent += v == 0 ? 0 : -1.0 * v * log2(v);
+        for (int i = 0; i < 6; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (__attribute__((address_space(3))) void *)(buf + (4 * i + wm) * 64), 4,
+                                                     (int)d_off[i], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void *)(buf + D_PATCH + wm * 256), 16,
+                                                 (int)w_off, ic * D_WSLAB * 4, 0, 0);
+        if (++ic == nchunks) { ic = 0; ++is; }
+    };
+
+    f32x4 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    double sum[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) sum[c] = 0.0;
+    const bool cok = li < a.C;
+    const float ep_sc = cok ? a.ep_scale[li] : 0.f, ep_sh = cok ? a.ep_shift[li] : 0.f;
+    const int prow = 2 * wm + (li >> 3), pcol = 8 * lk + (li & 7);
+    const int gy = y0 + prow, gx = x0 + pcol;
+    const bool pix_ok = gy < a.H && gx < a.W;
+    const int64_t pix = (int64_t)gy * a.W + gx;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the epilogue constants: nothing but stage DMAs is counted from here on
+
+#pragma unroll
+    for (int g = 0; g < D; ++g)
+        if (g < total) issue_stage(g);
+
+    int s = 0, chunk = 0;
+    for (int g = 0; g < total; ++g) {
+        // stage g has landed once at most the younger stages' DMAs are outstanding (vmcnt counts in issue order)
+        const int younger = total - 1 - g < D - 1 ? total - 1 - g : D - 1;
+        if (D >= 4 && younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D_NI * 3) : "memory");
+        else if (D >= 3 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D_NI * 2) : "memory");
+        else if (D >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D_NI * 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cls_barrier();       // every wave's part of stage g is in LDS; every wave is done reading stage g - 1
+        if (g + D < total) issue_stage(g + D);      // into the buffer stage g - 1 has just left
+        const float *sp = lds + (g % NB) * D_BUF;
+        {
+            float d[4][4], t[4][4], V[16];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) d[r][c] = sp[a_base + r * K_PWp + ((c & 1) ? 0 : K_EOFF) + (c >> 1)];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                t[0][c] = d[0][c] - d[2][c];
+                t[1][c] = d[1][c] + d[2][c];
+                t[2][c] = d[2][c] - d[1][c];
+                t[3][c] = d[1][c] - d[3][c];
             }
-        a.classes[pix] = (uint8_t)best;
-        a.confidence[pix] = bv;
-        a.entropy[pix] = ent;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                V[r * 4 + 0] = t[r][0] - t[r][2];
+                V[r * 4 + 1] = t[r][1] + t[r][2];
+                V[r * 4 + 2] = t[r][2] - t[r][1];
+                V[r * 4 + 3] = t[r][1] - t[r][3];
+            }
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const float bf = sp[b_base + p * 4 * 16];
+                acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[p], bf, acc[p], 0, 0, 0);
+            }
+        }
+        if (chunk == nchunks - 1) {
+#include "conv_cls_mc_sample.inc"
+            // (diagnostic logits stores share the vmcnt counter with the DMAs and may complete out of order with them)
+            if (a.logits) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (++chunk == nchunks) { chunk = 0; ++s; }
     }
+    if (!pix_ok) return;
+#include "conv_cls_mc_maps.inc"
 }
 
 bool cls_mc_supported(int ks, int cin, int cout, int H, int W) {
@@ -328,14 +389,32 @@ void cls_mc_pack_weights(const float *W, int cin, int cout, std::vector<float> &
         }
 }
 
+// Default: the register-staged form (K-chunk SIVO_CLS_KC = 4 | 8).  SIVO_CLS_MC=dma: the LDS-DMA ring of SIVO_CLS_NB = 3 | 4 | 5
+// stage buffers — bit-identical, measured 0.83 ms against 0.70 ms per frame whatever the depth (see the note at the kernel)
+static int cls_mc_ring() {
+    static const int nb = [] {
+        const char *m = std::getenv("SIVO_CLS_MC");
+        if (!m || std::string(m) != "dma") return 0;
+        const char *e = std::getenv("SIVO_CLS_NB");
+        const int v = e ? std::atoi(e) : 4;
+        return v == 3 || v == 5 ? v : 4;
+    }();
+    return nb;
+}
+
 void launch_conv_cls_mc(const ClsMcArgs &a0, hipStream_t s) {
     ClsMcArgs a = a0;
     a.tiles_x = (a.W + K_TW - 1) / K_TW;
     a.tiles_y = (a.H + K_TH - 1) / K_TH;
     if (a.sum_chunk <= 0 || a.sum_chunk > (int64_t)a.H * a.W) a.sum_chunk = (int64_t)a.H * a.W;
     const int P = a.tiles_x * a.tiles_y, per = (P + 7) / 8;
-    if (cls_mc_k_chunk() == 8) hipLaunchKernelGGL((conv_wino_cls_mc_kernel<8>), dim3((unsigned)(8 * per)), dim3(K_NTHR), 0, s, a);
-    else hipLaunchKernelGGL((conv_wino_cls_mc_kernel<4>), dim3((unsigned)(8 * per)), dim3(K_NTHR), 0, s, a);
+    const dim3 grid((unsigned)(8 * per)), block(K_NTHR);
+    const int ring = (a.Cin % 4 == 0 && cls_mc_k_chunk() == 4 && (int64_t)a.Cin * a.H * a.W * 4 < (1ll << 31)) ? cls_mc_ring() : 0;
+    if (ring == 3) hipLaunchKernelGGL((conv_wino_cls_mc_dma_kernel<3>), grid, block, 0, s, a);
+    else if (ring == 4) hipLaunchKernelGGL((conv_wino_cls_mc_dma_kernel<4>), grid, block, 0, s, a);
+    else if (ring == 5) hipLaunchKernelGGL((conv_wino_cls_mc_dma_kernel<5>), grid, block, 0, s, a);
+    else if (cls_mc_k_chunk() == 8) hipLaunchKernelGGL((conv_wino_cls_mc_kernel<8>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv_wino_cls_mc_kernel<4>), grid, block, 0, s, a);
 }
 
 }  // namespace sivo

@@ -602,6 +602,28 @@ __global__ __launch_bounds__(512, 1) void wino4_gemm_x6p_kernel(Wino4Args a, con
             int xi, pt, kt;
             item_of(k_item++, xi, pt, kt);
             float *Mg = a.M + ((int64_t)xi * a.Kp + (int64_t)kt * 128) * a.Pp + (int64_t)pt * 128;
+            if (ABL & 64) {
+                // M stores in 64-byte runs: a lane holds 16 consecutive tiles of one cout row as four 16-byte pieces
+                // (piece 4 lk + r); stored as they are, one instruction writes pieces 64 bytes apart.  A 4 x 4 transpose of
+                // the pieces over the four lanes li, li + 16, li + 32, li + 48 (v_permlane16_swap / v_permlane32_swap, two
+                // stages, no LDS) gives lane lk the pieces 4 j + lk: instruction j then writes 64 contiguous bytes per row.
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    float *row = Mg + (int64_t)(wn * 64 + 4 * li + nt) * a.Pp + wm * 64 + 4 * lk;
+                    f32x4 y[4];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mt][nt][0]), __float_as_uint(acc[mt][nt][1]), false, false);
+                        const auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mt][nt][2]), __float_as_uint(acc[mt][nt][3]), false, false);
+                        const auto t02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
+                        const auto t13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
+                        y[0][mt] = __uint_as_float(t02[0]); y[2][mt] = __uint_as_float(t02[1]);
+                        y[1][mt] = __uint_as_float(t13[0]); y[3][mt] = __uint_as_float(t13[1]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4 *>(row + 16 * j) = y[j];
+                }
+            } else
             if (!(ABL & 32) || acc[0][0][0] == 12345.678f)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
@@ -897,7 +919,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         for (const void *f : {(const void *)wino4_gemm_x6p_kernel<0>, (const void *)wino4_gemm_x6p_kernel<1>, (const void *)wino4_gemm_x6p_kernel<2>,
                               (const void *)wino4_gemm_x6p_kernel<3>, (const void *)wino4_gemm_x6p_kernel<4>, (const void *)wino4_gemm_x6p_kernel<7>,
                               (const void *)wino4_gemm_x6p_kernel<8>, (const void *)wino4_gemm_x6p_kernel<16>, (const void *)wino4_gemm_x6p_kernel<23>,
-                              (const void *)wino4_gemm_x6p_kernel<32>})
+                              (const void *)wino4_gemm_x6p_kernel<32>, (const void *)wino4_gemm_x6p_kernel<64>})
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_x6_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS);
         for (const void *f : {(const void *)wino4_gemm_x6_kernel<1>, (const void *)wino4_gemm_x6_kernel<2>, (const void *)wino4_gemm_x6_kernel<4>,
@@ -955,7 +977,10 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
             (void)abl;
             if (!x6_flat) {
                 const dim3 gp((unsigned)((n_cu / 8) * 8 > 0 ? (n_cu / 8) * 8 : 8));        // one persistent workgroup per CU, a multiple of the 8 XCDs
-                switch ((c.variant >> 12) & 63) {
+                // M stores transposed into 64-byte runs (ABL bit 64): GEMM time of a frame 5.51 -> 5.17 ms; SIVO_X6_MSTORE=0: as held
+                static const bool mstore64 = !(std::getenv("SIVO_X6_MSTORE") && std::atoi(std::getenv("SIVO_X6_MSTORE")) == 0);
+                switch (((c.variant >> 12) & 63) == 0 && mstore64 ? 64 : ((c.variant >> 12) & 63)) {
+                    case 64: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<64>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
                     case 1: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<1>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
                     case 2: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<2>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
                     case 3: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<3>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;

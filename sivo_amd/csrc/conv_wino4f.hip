@@ -21,9 +21,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
+#include "lds_dma.hpp"
 #include "segnet_kernels.hpp"
 
 namespace sivo {
@@ -73,7 +75,15 @@ __device__ __forceinline__ void w4f_at(const float m0, const float m1, const flo
     s[3] = q12 + 8.f * q34 + m5;
 }
 
-template <bool UNPOOL>
+// ABL (tools/conv_probe.py only; 0 in production): 1 no patch staging after the prologue, 2 no weight DMA after the prologue,
+// 4 no per-chunk barrier / wait, 8 no input transform (raw patch values as operands), 16 no output stage, 32 no MFMAs.
+// Workgroup barrier for the output stage: this wave's LDS traffic done + s_barrier.  __syncthreads() also waits for vmcnt(0),
+// i.e. for the output stores issued just before it to be acknowledged (1-2 us each time, eight times per workgroup: measured
+// 0.6 of the 1.65 ms of conv1_2_D); the exchange through LDS only needs lgkmcnt.
+__device__ __forceinline__ void w4f_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int ABL> __device__ __forceinline__ void w4f_out_barrier() { if (!(ABL & 256)) w4f_lds_barrier(); }
+
+template <bool UNPOOL, int ABL = 0>
 __global__ __launch_bounds__(F_NTHR, 1) void conv_wino4f_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // 2 * F_BUF floats
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -207,10 +217,199 @@ __global__ __launch_bounds__(F_NTHR, 1) void conv_wino4f_kernel(ConvArgs a) {
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int cur = chunk & 1;
         const bool more = chunk + 1 < nchunks;
-        if (more) { issue_patch(chunk + 1); dma_weights(chunk + 1, cur ^ 1); }
+        if (more && !(ABL & 1)) issue_patch(chunk + 1);
+        if (more && !(ABL & 2)) dma_weights(chunk + 1, cur ^ 1);
         const float *sp = lds + cur * F_BUF;
         // ---- row wi of B^T d, then the row transform: V[j] = (B^T d B)[wi][j]
         // (one raw row live at a time: t += B^T[wi][r] * d_r with a wave-uniform coefficient, zero rows skipped)
+        float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const float c = bt_row[r];
+            if (c != 0.f) {
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(sp + a_base + r * F_PC);
+                const float2 e = *reinterpret_cast<const float2 *>(sp + a_base + r * F_PC + 4);
+                t[0] = __builtin_fmaf(c, q[0], t[0]); t[1] = __builtin_fmaf(c, q[1], t[1]); t[2] = __builtin_fmaf(c, q[2], t[2]);
+                t[3] = __builtin_fmaf(c, q[3], t[3]); t[4] = __builtin_fmaf(c, e.x, t[4]); t[5] = __builtin_fmaf(c, e.y, t[5]);
+            }
+        }
+        float V[6];
+        if (ABL & 8) { V[0] = t[0]; V[1] = t[1]; V[2] = t[2]; V[3] = t[3]; V[4] = t[4]; V[5] = t[5]; }
+        else w4f_bt(t[0], t[1], t[2], t[3], t[4], t[5], V);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const f32x4 bq = *reinterpret_cast<const f32x4 *>(sp + b_base + j * 256);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                if (ABL & 32) acc[j][nb][0] += V[j] * bq[nb];
+                else acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[j], bq[nb], acc[j][nb], 0, 0, 0);
+            }
+            if (j == 3 && more && !(ABL & 1)) commit_patch(cur ^ 1);
+        }
+        if (!(ABL & 4)) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();
+        }
+    }
+    if (ABL & 16) {
+        if (acc[0][0][0] == 12345.678f) a.out[tid] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3] + acc[4][0][0] + acc[5][1][2];
+        return;
+    }
+
+#include "conv_wino4f_out.inc"
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same kernel with its memory traffic actually in flight during the matrix-core phase.  In the kernel above hipcc puts
+// `s_waitcnt vmcnt(0)` in front of the first LDS read behind the weight DMA (lds_dma.hpp), i.e. at the top of every K-chunk the
+// (single) workgroup of the CU waits for everything it has just requested for the NEXT chunk: measured on conv1_2_D
+// (tools/conv_probe.py w4f; 1.63 ms) 1.31 ms without the patch staging, 1.47 without the weight DMA, 1.10 without both.  Here
+//   * the weight DMA is issued through inline assembly (invisible to the waitcnt pass);
+//   * the patch loads are BUFFER loads (descriptor of the sample's planes, per-lane byte offset; an offset beyond the
+//     descriptor returns 0, which is exactly the zero padding outside the image and beyond Cin — no select, no branch, the
+//     same number of vector-memory instructions in every wave);
+//   * iteration c: write the patch of chunk c + 1 (requested a whole iteration ago) to LDS, start the DMA of its weights,
+//     request the patch of chunk c + 2, compute chunk c, then `s_waitcnt vmcnt(NL)` — vector-memory loads complete in issue
+//     order, so "at most the NL patch loads issued behind the DMA are outstanding" means the DMA has landed while those
+//     loads stay in flight — and a barrier without the vmcnt(0) drain of __syncthreads().
+template <bool UNPOOL>
+__global__ __launch_bounds__(F_NTHR, 1) void conv_wino4f_p_kernel(ConvArgs a) {
+    constexpr int ABL = 0;
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // 2 * F_BUF floats
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int mt = wave / 6, wi = wave % 6;
+
+    const int ntiles = a.CoutPad / 64;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ntile = slot % ntiles;
+    int bid = (slot / ntiles) * 8 + xcd;
+    if (bid >= a.tiles_x * a.tiles_y * a.N) return;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+    const int n = bid;
+    const int x0 = tx * F_TW, y0 = ty * F_TH;
+    const int n0 = ntile * 64;
+
+    const int64_t plane = (int64_t)a.H * a.W;
+    const int Wh = a.W >> 1;
+    const int64_t plane_in = UNPOOL ? (int64_t)(a.H >> 1) * Wh : plane;
+    // descriptors of this sample's input planes (and window codes): wave-uniform (kernel arguments and blockIdx only)
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (int64_t)n * a.in_sample_stride), 0, (int)(a.Cin * plane_in * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t mk_rsrc =
+        UNPOOL ? __builtin_amdgcn_make_buffer_rsrc((void *)(a.unpool_mask + (int64_t)n * a.unpool_mask_stride), 0, (int)(a.Cin * plane_in), 0x00020000)
+               : in_rsrc;
+    constexpr uint32_t INV = 0xfffffff0u;           // beyond any descriptor: the load returns 0
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    // ---- staging plan: one interior float4 per thread (4 ch x 10 rows x 16 segments = 640) + 80 halo scalars.
+    // v_idx / s_idx: element index inside the chunk's 4 planes (UNPOOL: of the pooled plane; bits 30 / 29 = window row / column)
+    constexpr int NV4 = 4 * F_PR * (F_TW / 4), NSC = 4 * F_PR * 2;
+    uint32_t v_idx = INV, s_idx = INV;
+    int v_dst = -1, s_dst = -1, v_code0 = 0, s_code = 0;
+    if (tid < NV4) {
+        const int seg = tid % (F_TW / 4), r = tid / (F_TW / 4);
+        const int py = r % F_PR, c = r / F_PR;
+        const int gy = y0 + py - 1, gx = x0 + seg * 4;
+        const bool ok = gy >= 0 && gy < a.H && gx + 3 < a.W;
+        if (UNPOOL) { if (ok) v_idx = (uint32_t)(c * plane_in + (int64_t)(gy >> 1) * Wh + (gx >> 1)); v_code0 = (gy & 1) << 1; }
+        else if (ok) v_idx = (uint32_t)(c * plane + (int64_t)gy * a.W + gx);
+        v_dst = c * F_CS + py * F_PC + seg * 4 + 1;
+    }
+    if (tid < NSC) {
+        const int h = tid % 2, r = tid / 2;
+        const int py = r % F_PR, c = r / F_PR;
+        const int gy = y0 + py - 1, gx = h == 0 ? x0 - 1 : x0 + F_TW;
+        const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        if (UNPOOL) { if (ok) s_idx = (uint32_t)(c * plane_in + (int64_t)(gy >> 1) * Wh + (gx >> 1)); s_code = (gy & 1) * 2 + (gx & 1); }
+        else if (ok) s_idx = (uint32_t)(c * plane + (int64_t)gy * a.W + gx);
+        s_dst = c * F_CS + py * F_PC + (h == 0 ? 0 : F_TW + 1);
+    }
+    constexpr int NL = UNPOOL ? 4 : 2;              // vector-memory loads per issue_patch, in every wave
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    struct PatchRegs { u32x4 v4; unsigned sc, vm, sm; };     // non-UNPOOL: v4 + sc; UNPOOL: v4.xy = two pooled values, vm / sm = codes
+    const int nchunks = (a.Cin + 3) / 4;
+
+    auto issue_patch = [&](int chunk, PatchRegs &R) {
+        const uint32_t cb = (uint32_t)(chunk * 4 * plane_in);
+        if (UNPOOL) {
+            const uint32_t vi = v_idx == INV ? INV : v_idx + cb, si = s_idx == INV ? INV : s_idx + cb;
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, (int)(vi == INV ? INV : vi * 4), 0, 0);
+            R.v4[0] = v[0]; R.v4[1] = v[1];
+            R.vm = __builtin_amdgcn_raw_buffer_load_b16(mk_rsrc, (int)vi, 0, 0);
+            R.sc = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (int)(si == INV ? INV : si * 4), 0, 0);
+            R.sm = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc, (int)si, 0, 0);
+        } else {
+            R.v4 = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)(v_idx == INV ? INV : (v_idx + cb) * 4), 0, 0);
+            R.sc = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (int)(s_idx == INV ? INV : (s_idx + cb) * 4), 0, 0);
+        }
+    };
+    auto commit_patch = [&](int buf, const PatchRegs &R) {
+        float *sp = lds + buf * F_BUF;
+        if (v_dst >= 0) {
+            float *q = sp + v_dst;
+            if (UNPOOL) {
+                const float vx = __uint_as_float(R.v4[0]), vy = __uint_as_float(R.v4[1]);
+                const int mx = (int)(R.vm & 0xffu), my = (int)((R.vm >> 8) & 0xffu);
+                q[0] = mx == v_code0 ? vx : 0.f; q[1] = mx == v_code0 + 1 ? vx : 0.f;
+                q[2] = my == v_code0 ? vy : 0.f; q[3] = my == v_code0 + 1 ? vy : 0.f;
+            } else {
+                q[0] = __uint_as_float(R.v4[0]); q[1] = __uint_as_float(R.v4[1]); q[2] = __uint_as_float(R.v4[2]); q[3] = __uint_as_float(R.v4[3]);
+            }
+        }
+        if (s_dst >= 0) sp[s_dst] = (!UNPOOL || (int)(R.sm & 0xffu) == s_code) ? __uint_as_float(R.sc) : 0.f;
+    };
+    const uint32_t slab_lds = lds_addr_uniform(lds + F_PATCH) + (uint32_t)wave_u * 1024u;      // this wave's first KiB of slab buffer 0
+    auto dma_weights = [&](int chunk, int buf) {
+        const float *wsrc = a.wt + ((int64_t)chunk * ntiles + ntile) * F_SLAB;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int kib = i * F_NW + wave;          // 36 KiB: three 1 KiB copies per wave
+            lds_dma16(wsrc + kib * 256 + lane * 4, slab_lds + (uint32_t)(buf * F_BUF * 4 + i * F_NW * 1024));
+        }
+    };
+
+    f32x4 acc[6][4];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[j][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int a_base = lk * F_CS + (4 * mt) * F_PC + 4 * li;
+    const int b_base = F_PATCH + (wi * 6 * 4 + lk) * 64 + li * 4;        // position (wi, j): + j * 256
+    float bt_row[6];
+    {
+        const float BT[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                                {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+#pragma unroll
+        for (int r = 0; r < 6; ++r) bt_row[r] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(BT[wi][r])));
+    }
+
+    PatchRegs R;
+    R.vm = 0; R.sm = 0; R.sc = 0; R.v4 = (u32x4){0u, 0u, 0u, 0u};
+    issue_patch(0, R);
+    dma_weights(0, 0);
+    commit_patch(0, R);
+    if (nchunks > 1) issue_patch(1, R);
+    if (nchunks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    w4f_lds_barrier();
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int cur = chunk & 1;
+        const bool more = chunk + 1 < nchunks, more2 = chunk + 2 < nchunks;
+        if (more) {
+            commit_patch(cur ^ 1, R);                 // chunk + 1: requested a whole iteration ago
+            // every wave (also one without a staging item) is done with R here: the compiler's own wait for these loads
+            // comes now, before the DMA it cannot see is in flight, and not at a later reuse of the registers
+            asm volatile("" ::"v"(R.v4), "v"(R.sc), "v"(R.vm), "v"(R.sm));
+            dma_weights(chunk + 1, cur ^ 1);
+            asm volatile("" ::: "memory");           // the DMA stays ahead of the loads in program order
+            if (more2) issue_patch(chunk + 2, R);
+        }
+        const float *sp = lds + cur * F_BUF;
         float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
@@ -229,53 +428,13 @@ __global__ __launch_bounds__(F_NTHR, 1) void conv_wino4f_kernel(ConvArgs a) {
             const f32x4 bq = *reinterpret_cast<const f32x4 *>(sp + b_base + j * 256);
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[j], bq[nb], acc[j][nb], 0, 0, 0);
-            if (j == 3 && more) commit_patch(cur ^ 1);
         }
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();
+        if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        w4f_lds_barrier();
     }
 
-    // ---- output transform.  acc[j][nb][r] = M_(wi,j)[tile 4 lk + r][cout nb*16 + li]
-    float *Rb = lds;                                  // [mt][i][q = tile*4 + j'][F_RS]
-    float *out_n = a.out + (int64_t)n * a.Cout * plane;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        // column half (over j), lane-local
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float s[4];
-            w4f_at(acc[0][nb][r], acc[1][nb][r], acc[2][nb][r], acc[3][nb][r], acc[4][nb][r], acc[5][nb][r], s);
-            float *dst = Rb + ((mt * 6 + wi) * 64 + (4 * lk + r) * 4) * F_RS + li;
-#pragma unroll
-            for (int jp = 0; jp < 4; ++jp) dst[jp * F_RS] = s[jp];
-        }
-        __syncthreads();
-        // row half (over i): one output column x = x0 + q of 4 rows per item, 64 consecutive q per wave
-        for (int it = wave; it < F_MT * 16; it += F_NW) {
-            const int m2 = it >> 4, c16 = it & 15, q = lane;
-            const int co = n0 + nb * 16 + c16, x = x0 + q;
-            const float *src = Rb + (m2 * 6 * 64 + q) * F_RS + c16;
-            float y4[4];
-            w4f_at(src[0], src[64 * F_RS], src[2 * 64 * F_RS], src[3 * 64 * F_RS], src[4 * 64 * F_RS], src[5 * 64 * F_RS], y4);
-            if (co < a.Cout && x < a.W) {
-                const float sc = a.ep_scale[co], sh = a.ep_shift[co];
-#pragma unroll
-                for (int ip = 0; ip < 4; ++ip) {
-                    const int y = y0 + 4 * m2 + ip;
-                    if (y >= a.H) break;
-                    float v = y4[ip] * sc + sh;
-                    if (a.relu) v = v > 0.f ? v : 0.f;
-                    if (a.drop_site >= 0) {
-                        const uint32_t e = (uint32_t)((co * a.H + y) * a.W + x);
-                        const uint32_t w = w4f_dropout_word(e, (uint32_t)a.drop_site, (uint32_t)(a.sample0 + n), a.seed);
-                        v = ((w >> (e & 31)) & 1u) ? v * 2.f : 0.f;
-                    }
-                    out_n[(int64_t)co * plane + (int64_t)y * a.W + x] = v;
-                }
-            }
-        }
-        __syncthreads();
-    }
+#include "conv_wino4f_out.inc"
 }
 
 bool wino4f_supported(int ks, int cin, int cout, int H, int W) {
@@ -310,12 +469,48 @@ void launch_conv_wino4f(const ConvArgs &a0, hipStream_t s) {
     if (first_use_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino4f_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F_BUF * 4);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino4f_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F_BUF * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino4f_p_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F_BUF * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino4f_p_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F_BUF * 4);
     }
     ConvArgs a = a0;
     a.tiles_x = (a.W + F_TW - 1) / F_TW;
     a.tiles_y = (a.H + F_TH - 1) / F_TH;
     const int ptiles = a.tiles_x * a.tiles_y * a.N;
     dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * (a.CoutPad / 64)));
+    const int abl = (a.variant >> 16) & 1023;
+    if (abl) {      // probe only
+        auto go = [&](auto kern) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F_BUF * 4);
+            hipLaunchKernelGGL(kern, grid, dim3(F_NTHR), 2 * F_BUF * 4, s, a);
+        };
+        switch (abl) {
+            case 1: return go(conv_wino4f_kernel<false, 1>);
+            case 2: return go(conv_wino4f_kernel<false, 2>);
+            case 3: return go(conv_wino4f_kernel<false, 3>);
+            case 7: return go(conv_wino4f_kernel<false, 7>);
+            case 8: return go(conv_wino4f_kernel<false, 8>);
+            case 16: return go(conv_wino4f_kernel<false, 16>);
+            case 19: return go(conv_wino4f_kernel<false, 19>);
+            case 23: return go(conv_wino4f_kernel<false, 23>);
+            case 32: return go(conv_wino4f_kernel<false, 32>);
+            case 48: return go(conv_wino4f_kernel<false, 48>);
+            case 31: return go(conv_wino4f_kernel<false, 31>);
+            case 64: return go(conv_wino4f_kernel<false, 64>);
+            case 128: return go(conv_wino4f_kernel<false, 128>);
+            case 192: return go(conv_wino4f_kernel<false, 192>);
+            case 256: return go(conv_wino4f_kernel<false, 256>);
+            case 448: return go(conv_wino4f_kernel<false, 448>);
+            default: break;
+        }
+    }
+    // SIVO_W4F_PIPE=0 (or variant bit 8192, or a sample of 2 GiB and more): the one-chunk-ahead kernel
+    static const bool pipe_env = !(std::getenv("SIVO_W4F_PIPE") && std::atoi(std::getenv("SIVO_W4F_PIPE")) == 0);
+    const bool pipe = pipe_env && !(a.variant & 8192) && (int64_t)a.Cin * a.H * a.W * 4 < (1ll << 31);
+    if (pipe) {
+        if (a.unpool_mask) hipLaunchKernelGGL(conv_wino4f_p_kernel<true>, grid, dim3(F_NTHR), 2 * F_BUF * 4, s, a);
+        else hipLaunchKernelGGL(conv_wino4f_p_kernel<false>, grid, dim3(F_NTHR), 2 * F_BUF * 4, s, a);
+        return;
+    }
     if (a.unpool_mask) hipLaunchKernelGGL(conv_wino4f_kernel<true>, grid, dim3(F_NTHR), 2 * F_BUF * 4, s, a);
     else hipLaunchKernelGGL(conv_wino4f_kernel<false>, grid, dim3(F_NTHR), 2 * F_BUF * 4, s, a);
 }

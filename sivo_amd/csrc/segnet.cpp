@@ -572,6 +572,8 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                     a.unpool_mask = mptr(bm); a.unpool_mask_stride = bm.shared ? 0 : bm.chw();
                 }
                 if (op.wino4f) {
+                    static const bool epi4 = !(std::getenv("SIVO_W4F_EPI") && std::atoi(std::getenv("SIVO_W4F_EPI")) == 0);
+                    if (epi4) a.variant |= 4096;      // float4 form of the output stage (conv_wino4f.hip)
                     launch_conv_wino4f(a, st);
                 } else if (op.wino4) {
                     hipEvent_t *sub = nullptr;
