@@ -312,21 +312,23 @@ def main():
         ex_l, ex_r = orb.ORBextractor(device=local), orb.ORBextractor(device=local)
     stats = {"kps": 0, "matches": 0}
 
+    # Frame.cc:126-129 runs two extractor threads; here they also overlap the network on the GPU, and a third task matches
+    # EVERY left keypoint (candidates, Hamming, SAD refinement) while the network still runs; only the median cull of
+    # ComputeStereoMatches needs the class map (sivo_stereo_match_begin / _cull).  The three workers are long-lived (a pool
+    # created once): starting three Python threads per frame cost 0.5 ms before the network was even enqueued
+    # (tools/frame_timeline.py), and the network is enqueued FIRST so that the GPU never waits for the host side of ORB.
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=3) if do_orb else None
+
     def orb_extract(res):
-        # Frame.cc:126-129: two extractor threads; here they also overlap the network on the GPU.  A third thread
-        # joins them and matches EVERY left keypoint (candidates, Hamming, SAD refinement) while the network still
-        # runs; only the median cull of ComputeStereoMatches needs the class map (sivo_stereo_match_begin / _cull).
-        th = [threading.Thread(target=lambda k=k, e=e, im=im: res.__setitem__(k, e(im)))
-              for k, e, im in (("l", ex_l, d_left), ("r", ex_r, d_right))]
-        [t.start() for t in th]
+        fl = pool.submit(lambda: res.__setitem__("l", ex_l(d_left)))
+        fr = pool.submit(lambda: res.__setitem__("r", ex_r(d_right)))
 
         def match():
-            [t.join() for t in th]
+            fl.result(); fr.result()
             (kl, dl), (kr, dr) = res["l"], res["r"]
             res["m"] = orb.stereo_match_begin(ex_l, ex_r, kl, dl, kr, dr, 386.1448, 386.1448 / 718.856)
-        tm = threading.Thread(target=match)
-        tm.start()
-        return [tm]
+        return [pool.submit(match)]
 
     def orb_finish(res, cls_host):
         kl = res["l"][0]
@@ -338,20 +340,21 @@ def main():
 
     def frame(seed):
         res = {}
-        th = orb_extract(res) if do_orb else []          # ORB of this frame runs beside the network
         if world == 1:
             # one device holds all T samples: segmentImage on device-resident data (f64 mean, no probability sum in memory)
-            sn.segment_into(d_bgr, seed, maps)
+            sn.segment_into(d_bgr, seed, maps)           # asynchronous: ~65 launches enqueued in ~0.5 ms
+            th = orb_extract(res) if do_orb else []      # ORB of this frame runs beside the network
         else:
             if n_local:
                 sn.forward_into(d_bgr, seed, prob_sum, n_samples=n_local, sample0=sample0)
             else:
                 prob_sum.zero_()                           # more ranks than samples: contribute nothing
+            th = orb_extract(res) if do_orb else []
             parallel.all_reduce_prob_sum(prob_sum)
             sn.finalize(prob_sum, t_total=T, out=maps)
         if do_orb:
             cls_host = maps[0].cpu().numpy()              # 360 KB D2H; waits for this frame's class map
-            [t.join() for t in th]
+            [t.result() for t in th]
             orb_finish(res, cls_host)
 
     def barrier():
