@@ -19,6 +19,7 @@
 //            blur of all levels (1 launch, overlaps the host quadtree)
 // -> H2D kept keypoints -> IC angle (1) -> rBRIEF (1) -> D2H.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include <algorithm>
@@ -725,6 +726,8 @@ extern "C" int sivo_orb_create(int nfeatures, float scale_factor, int nlevels, i
         // each of its launches queues behind a chip-filling convolution and the frame waits for ORB, not the network.
         int prio_lo = 0, prio_hi = 0;
         SIVO_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        if (const char *e = std::getenv("SIVO_ORB_PRIO"))       // experiments: 0 = default priority, 1 = lowest
+            prio_hi = std::atoi(e) == 0 ? 0 : std::atoi(e) == 1 ? prio_lo : prio_hi;
         SIVO_HIP(hipStreamCreateWithPriority(&o->stream, hipStreamNonBlocking, prio_hi));
         SIVO_HIP(hipStreamCreateWithPriority(&o->stream2, hipStreamNonBlocking, prio_hi));
         SIVO_HIP(hipEventCreateWithFlags(&o->ev_pyr, hipEventDisableTiming));

@@ -398,7 +398,7 @@ static int run_gpu(int argc, char **argv) {
         }
         SIVO::ORBextractor fl(500, 1.2f, 1, 20, 7), fr(500, 1.2f, 1, 20, 7);     // one level: the 64-row crop holds no second one
         {   // errors inside the worker threads come back as exceptions of the constructor
-            SIVO::ORBextractor bl(500, 1.2f, 4, 20, 7), br(500, 1.2f, 4, 20, 7);
+            SIVO::ORBextractor bl(500, 1.2f, 8, 20, 7), br(500, 1.2f, 8, 20, 7);      // level 7 of a 64-row crop has 17 rows: below the 33 the extractor needs
             SIVO::BayesianSegNetParams p3(proto, weights);
             SIVO::BayesianSegNet seg3(p3);
             bool threw2 = false;

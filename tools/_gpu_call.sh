@@ -1,8 +1,10 @@
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r02o
-O=gpurun_out/r02o
-timeout 600 python -m pytest tests/test_gpu_segnet.py -x -q > $O/t1.log 2>&1; echo "t1 rc=$?"; tail -3 $O/t1.log
-B="--steps 30 --configs none --no-cpu-baseline --per-layer"
-timeout 300 python bench.py $B > $O/bench.json 2> $O/bench.err; python -c "import json;d=json.load(open('$O/bench.json'));print('pipe',d['value'],d['ms_per_step'],d['roofline']['kernels_ms_per_frame'])"
-SIVO_WINO_PIPE=0 timeout 300 python bench.py $B > $O/bench0.json 2> $O/bench0.err; python -c "import json;d=json.load(open('$O/bench0.json'));print('old ',d['value'],d['ms_per_step'],d['roofline']['kernels_ms_per_frame'])"
-grep "conv_wino_kernel" $O/bench.err | head; grep "conv_wino_kernel" $O/bench0.err | head
+mkdir -p gpurun_out/r02q
+O=gpurun_out/r02q
+B="--steps 40 --configs none --no-cpu-baseline"
+for v in hi 0 1; do
+  if [ $v = hi ]; then unset SIVO_ORB_PRIO; else export SIVO_ORB_PRIO=$v; fi
+  SIVO_BENCH_NO_EVENTS=1 timeout 300 python bench.py $B > $O/bench_$v.json 2> $O/bench_$v.err; python -c "import json;d=json.load(open('$O/bench_$v.json'));print('orb prio $v',d['value'],d['ms_per_step'])"
+done
+unset SIVO_ORB_PRIO
+SIVO_BENCH_NO_EVENTS=1 timeout 300 python bench.py $B --no-orb > $O/bench_noorb.json 2>/dev/null; python -c "import json;d=json.load(open('$O/bench_noorb.json'));print('no orb',d['value'],d['ms_per_step'])"
