@@ -146,6 +146,105 @@ def test_caffemodel_reader_matches_layers_by_name(tmp_path):
     assert b"Git-LFS" in _lib.lib().sivo_last_error()
 
 
+def _caffe_messages():
+    """NetParameter / LayerParameter / V1LayerParameter / BlobProto / BlobShape of BVLC Caffe's caffe.proto — the fields a
+    .caffemodel of a trained net carries, with the field numbers of the published file (caffe-segnet keeps them) — as
+    message classes of Google's protobuf runtime.  caffe.proto itself is not in the reference tree (empty submodule)."""
+    from google.protobuf import descriptor_pb2 as D, descriptor_pool, message_factory
+    F = D.FieldDescriptorProto
+    fp = D.FileDescriptorProto(name="caffe_subset.proto", package="caffe", syntax="proto2")
+
+    def msg(name, fields):
+        m = fp.message_type.add(name=name)
+        for fname, num, typ, label, extra in fields:
+            f = m.field.add(name=fname, number=num, type=typ, label=label)
+            if extra.get("type_name"):
+                f.type_name = extra["type_name"]
+            if extra.get("packed"):
+                f.options.packed = True
+    OPT, REP = F.LABEL_OPTIONAL, F.LABEL_REPEATED
+    msg("BlobShape", [("dim", 1, F.TYPE_INT64, REP, {"packed": True})])
+    msg("BlobProto", [("num", 1, F.TYPE_INT32, OPT, {}), ("channels", 2, F.TYPE_INT32, OPT, {}), ("height", 3, F.TYPE_INT32, OPT, {}),
+                      ("width", 4, F.TYPE_INT32, OPT, {}), ("data", 5, F.TYPE_FLOAT, REP, {"packed": True}),
+                      ("diff", 6, F.TYPE_FLOAT, REP, {"packed": True}), ("shape", 7, F.TYPE_MESSAGE, OPT, {"type_name": ".caffe.BlobShape"}),
+                      ("double_data", 8, F.TYPE_DOUBLE, REP, {"packed": True})])
+    msg("LayerParameter", [("name", 1, F.TYPE_STRING, OPT, {}), ("type", 2, F.TYPE_STRING, OPT, {}), ("bottom", 3, F.TYPE_STRING, REP, {}),
+                           ("top", 4, F.TYPE_STRING, REP, {}), ("blobs", 7, F.TYPE_MESSAGE, REP, {"type_name": ".caffe.BlobProto"}),
+                           ("phase", 10, F.TYPE_INT32, OPT, {})])
+    msg("V1LayerParameter", [("bottom", 2, F.TYPE_STRING, REP, {}), ("top", 3, F.TYPE_STRING, REP, {}), ("name", 4, F.TYPE_STRING, OPT, {}),
+                             ("type", 5, F.TYPE_INT32, OPT, {}), ("blobs", 6, F.TYPE_MESSAGE, REP, {"type_name": ".caffe.BlobProto"})])
+    msg("NetParameter", [("name", 1, F.TYPE_STRING, OPT, {}), ("layers", 2, F.TYPE_MESSAGE, REP, {"type_name": ".caffe.V1LayerParameter"}),
+                         ("input", 3, F.TYPE_STRING, REP, {}), ("input_dim", 4, F.TYPE_INT32, REP, {}),
+                         ("layer", 100, F.TYPE_MESSAGE, REP, {"type_name": ".caffe.LayerParameter"})])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fp)
+    return {n: message_factory.GetMessageClass(pool.FindMessageTypeByName("caffe." + n))
+            for n in ("NetParameter", "LayerParameter", "V1LayerParameter", "BlobProto", "BlobShape")}
+
+
+@pytest.mark.parametrize("v1,legacy_dims,unpacked", [(False, False, False), (True, True, False), (False, True, True)])
+def test_caffemodel_reader_against_googles_protobuf_writer(v1, legacy_dims, unpacked):
+    """The library's .caffemodel reader (csrc/caffemodel.cpp, Net::CopyTrainedLayersFrom of bayesian_segnet.cpp:61) on
+    files serialised by Google's protobuf runtime from a restatement of caffe.proto's messages — a writer that shares no
+    code with this repository (test_caffemodel_reader_matches_layers_by_name uses the repository's own encoder).
+    Both encodings of the layer list, both encodings of the blob shape, packed float data, an extra `diff` field and a
+    double_data blob the reader has to skip / convert, layers in shuffled order with parameter-free ones in between."""
+    M = _caffe_messages()
+    text = netspec.basic_prototxt(6)
+    layers = oproto.parse(text)["layers"]
+    w = wts.synth_weights(layers, 9)
+    flat = wts.pack(layers, w)
+    net = M["NetParameter"](name="segnet_basic")
+    net.input.append("data"); net.input_dim.extend([6, 3, 352, 1024])
+    order = list(layers)
+    np.random.default_rng(4).shuffle(order)
+    first_conv = next(L["name"] for L in layers if L["type"] == "Convolution")
+    for L in order:
+        lp = net.layers.add() if v1 else net.layer.add()
+        lp.name = L["name"]
+        if v1:
+            lp.type = 4 if L["type"] == "Convolution" else 39
+        else:
+            lp.type = L["type"]; lp.phase = 1
+        lp.bottom.extend(L["bottom"]); lp.top.extend(L["top"])
+        for i, b in enumerate(w.get(L["name"], [])):
+            bp = lp.blobs.add()
+            b = np.ascontiguousarray(b, np.float32)
+            if legacy_dims:
+                dims = (1,) * (4 - b.ndim) + b.shape
+                bp.num, bp.channels, bp.height, bp.width = (int(d) for d in dims)
+            else:
+                bp.shape.dim.extend(int(d) for d in b.shape)
+            if L["name"] == first_conv and i == 1 and not v1:
+                bp.double_data.extend(float(x) for x in b.ravel())       # old Caffe snapshots of double nets
+            else:
+                bp.data.extend(float(x) for x in b.ravel())
+            if i == 0 and L["name"] == first_conv:
+                bp.diff.extend([0.0] * 5)                                 # a snapshot written with diffs: ignored on load
+    blob = net.SerializeToString()
+    if unpacked:
+        # protobuf parsers must accept both packed and unpacked encodings of a repeated scalar: re-encode one small blob
+        # (a bias) unpacked by hand — field 5, wire type 5 (32-bit) per element — and splice it in through the runtime
+        bias_layer = next(l for l in net.layer if l.name == first_conv)
+        raw = b"".join(bytes([5 << 3 | 5]) + np.float32(x).tobytes() for x in bias_layer.blobs[1].double_data)
+        shp = bias_layer.blobs[1].shape.SerializeToString() if not legacy_dims else b""
+        dims = b"".join(bytes([(n << 3) | 0, int(v)]) for n, v in ((1, 1), (2, 1), (3, 1))) if legacy_dims else b""
+        bp_bytes = dims + raw + (bytes([7 << 3 | 2, len(shp)]) + shp if shp else b"")
+        if legacy_dims:
+            n = len(bias_layer.blobs[1].double_data)
+            assert n < 128
+            bp_bytes += bytes([(4 << 3) | 0, n])
+        del bias_layer.blobs[1]
+        body = bias_layer.SerializeToString() + bytes([7 << 3 | 2]) + wts._varint(len(bp_bytes)) + bp_bytes
+        others = M["NetParameter"](); others.CopyFrom(net)
+        keep = [l for l in others.layer if l.name != first_conv]
+        del others.layer[:]
+        others.layer.extend(keep)
+        blob = others.SerializeToString() + b"\xa2\x06" + wts._varint(len(body)) + body        # field 100, wire type 2
+        assert M["NetParameter"].FromString(blob).layer[-1].blobs[1].data[:2] == list(np.float32(w[first_conv][1][:2]))
+    assert np.array_equal(wts.load_caffemodel(text, blob), flat)
+
+
 def test_host_quadtree_matches_oracle(oracle, kitti_like_bgr):
     ex = oracle.OrbExtractor()
     ex(oracle.bgr2gray(kitti_like_bgr))
