@@ -322,6 +322,33 @@ def test_winograd_and_direct_conv_shapes(oracle, H, W, width):
     np.testing.assert_allclose(logits.cpu().numpy(), ob["cls"], atol=LOGIT_TOL, rtol=0)
 
 
+@pytest.mark.parametrize("H,W", [(22, 64), (44, 136), (10, 24), (64, 192)])
+def test_persistent_fused_f4x4_kernel_is_bit_identical(H, W):
+    """conv_wino4f_pp_kernel (one workgroup per CU walking a list of pixel tiles; used where every workgroup gets at least 16
+    tiles, i.e. conv1_2_D at full size) against the one-workgroup-per-tile form, forced on small geometries: ragged tile rows
+    and columns, more tiles than workgroups and fewer, with and without the dropout epilogue.  Every blob bit for bit."""
+    T = 5
+    text = _conv_stack_prototxt(T, H, W, 64)
+    os.environ["SIVO_NO_FUSE_BRIDGE"] = "1"
+    try:
+        net, w, sn = _make(text, T, seed=3)
+    finally:
+        del os.environ["SIVO_NO_FUSE_BRIDGE"]
+    d_img = torch.from_numpy(_image(np.random.default_rng(H + W), H, W)).cuda()
+    got = {}
+    for mode in ("0", "2"):
+        os.environ["SIVO_W4F_PERSIST"] = mode
+        try:
+            _, logits, _ = sn.forward(d_img, 9, want_logits=True)
+            torch.cuda.synchronize()
+            got[mode] = [sn.blob(n) for n in ("c1", "c2")] + [logits.cpu().numpy()]
+        finally:
+            del os.environ["SIVO_W4F_PERSIST"]
+    for a, b in zip(got["0"], got["2"]):
+        assert np.array_equal(a, b)
+    assert np.abs(got["2"][1]).max() > 0
+
+
 def _classifier_prototxt(T, H, W, width, classes):
     """data -> conv3x3(3->width)+ReLU+Dropout -> conv3x3(width->width)+BN+ReLU -> conv3x3(width->classes) -> Softmax: the tail
     of SegNet-Standard (conv1_2_D, conv1_1_D, prob) behind a dropout, so that the classifier is per-sample."""

@@ -1,10 +1,6 @@
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r02q
-O=gpurun_out/r02q
-B="--steps 40 --configs none --no-cpu-baseline"
-for v in hi 0 1; do
-  if [ $v = hi ]; then unset SIVO_ORB_PRIO; else export SIVO_ORB_PRIO=$v; fi
-  SIVO_BENCH_NO_EVENTS=1 timeout 300 python bench.py $B > $O/bench_$v.json 2> $O/bench_$v.err; python -c "import json;d=json.load(open('$O/bench_$v.json'));print('orb prio $v',d['value'],d['ms_per_step'])"
-done
-unset SIVO_ORB_PRIO
-SIVO_BENCH_NO_EVENTS=1 timeout 300 python bench.py $B --no-orb > $O/bench_noorb.json 2>/dev/null; python -c "import json;d=json.load(open('$O/bench_noorb.json'));print('no orb',d['value'],d['ms_per_step'])"
+mkdir -p gpurun_out/r02v
+O=gpurun_out/r02v
+timeout 600 python -m pytest tests/test_gpu_segnet.py -x -q -k "persistent or winograd_and_direct or full_size" > $O/t1.log 2>&1; echo "t1 rc=$?"; tail -3 $O/t1.log
+B="--steps 30 --configs none --no-cpu-baseline"
+timeout 300 python bench.py $B > $O/bench.json 2> $O/bench.err; python -c "import json;d=json.load(open('$O/bench.json'));print('new',d['value'],d['ms_per_step'],d['roofline']['kernels_ms_per_frame'])"
