@@ -286,8 +286,12 @@ __global__ __launch_bounds__(F_NTHR, 1) void conv_wino4f_p_kernel(ConvArgs a) {
     const int ntiles = a.CoutPad / 64;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int ntile = slot % ntiles;
-    int bid = (slot / ntiles) * 8 + xcd;
-    if (bid >= a.tiles_x * a.tiles_y * a.N) return;
+    // one cout tile: every XCD owns a contiguous band of pixel tiles (row-major), so the cache lines two neighbouring tiles
+    // share (a pooled row of a tile is 132 bytes) are fetched into ONE L2; several cout tiles: the tiles of a pixel tile back
+    // to back on one XCD (the patch is what they share)
+    const int ptiles_all = a.tiles_x * a.tiles_y * a.N, band = ((ptiles_all + 7) >> 3);
+    int bid = ntiles == 1 ? xcd * band + slot : (slot / ntiles) * 8 + xcd;
+    if (bid >= ptiles_all || (ntiles == 1 && slot >= band)) return;
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
     const int ty = bid % a.tiles_y; bid /= a.tiles_y;
     const int n = bid;
@@ -491,12 +495,14 @@ __global__ __launch_bounds__(F_NTHR, 1) void conv_wino4f_pp_kernel(ConvArgs a) {
     const int mt = wave / 6, wi = wave % 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
-    // tiles of this workgroup: L = blockIdx.x + k * gridDim.x (gridDim.x is a multiple of 8: one XCD per workgroup);
-    // pixel tile of L as in the other kernels (ntiles == 1): bid = L
-    const int ptiles = a.tiles_x * a.tiles_y * a.N;
-    const int G = (int)gridDim.x, L0 = (int)blockIdx.x;
-    if (L0 >= ptiles) return;
-    const int my_tiles = (ptiles - L0 + G - 1) / G;
+    // every XCD owns a contiguous band of pixel tiles (row-major); its gridDim.x / 8 workgroups walk the band side by side, so
+    // neighbouring tiles are in flight on one XCD at the same time and share their cache lines in its L2
+    const int ptiles = a.tiles_x * a.tiles_y * a.N, band = (ptiles + 7) >> 3;
+    const int G = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, s0 = (int)blockIdx.x >> 3;      // G: workgroups per XCD
+    const int band_n = ptiles - xcd * band < band ? ptiles - xcd * band : band;                    // tiles in this XCD's band
+    if (s0 >= band_n) return;
+    const int L0 = xcd * band + s0;
+    const int my_tiles = (band_n - s0 + G - 1) / G;
     const int nchunks = (a.Cin + 3) / 4;
     const int total = my_tiles * nchunks;
     const int n0 = 0;
