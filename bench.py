@@ -115,7 +115,8 @@ def cpu_baseline(kind, T, H, W, text, w, bgr, left, right, budget_note):
 #   Winograd F(4x4,3x3) multiplies 36 instead of 144 per 4x4 outputs (1/4), F(2x2,3x3) 16 instead of 36 (1/2.25);
 #   the bf16x6 GEMM issues six bf16 MFMA products per fp32 product (6/4 of the algorithmic count, on the bf16 pipe).
 BF16_MFMA_PEAK_TFLOPS = 2500.0
-KERNEL_CLASS = [("wino4_gemm_x6", 6.0 / 4.0, BF16_MFMA_PEAK_TFLOPS, "bf16 MFMA (fp32 operands split into 3 bf16 planes, 6 products, fp32 accumulate)"),
+KERNEL_CLASS = [("conv7_x6", 6.0, BF16_MFMA_PEAK_TFLOPS, "bf16 MFMA (direct 7x7; fp32 operands split into 3 bf16 planes, 6 products, fp32 accumulate)"),
+                ("wino4_gemm_x6", 6.0 / 4.0, BF16_MFMA_PEAK_TFLOPS, "bf16 MFMA (fp32 operands split into 3 bf16 planes, 6 products, fp32 accumulate)"),
                 ("wino4_gemm", 1.0 / 4.0, FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA"),
                 ("conv_wino4f", 1.0 / 4.0, FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA"),
                 ("conv_wino", 1.0 / 2.25, FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA"),

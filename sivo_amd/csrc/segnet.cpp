@@ -62,6 +62,7 @@ struct Op {
     bool wino = false;         // conv_wino.hip kernel + pre-transformed weights
     int wino_cfg = 0;
     bool wino4f = false;       // conv_wino4f.hip: fused F(4x4,3x3), 64 couts per workgroup (narrow layers)
+    bool c7x6 = false;         // conv7_x6.hip: direct 7x7 on the bf16 matrix cores (bf16x6); weights in d_wx6
     bool wino4 = false;        // conv_wino4.hip: F(4x4,3x3) as input transform + batched GEMM + output transform
     int wino4_group = 1;       // samples per V/M workspace pass
     std::vector<hipEvent_t> w4_ev;                 // profiling: 4 events per group of the last launch
@@ -188,6 +189,16 @@ void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int 
     op.wino4f = !op.wino4 && f4_ok && !no_wino4f && wino4f_supported(ks, cin, cout, H, Wd);
     op.wino = !op.wino4 && !op.wino4f && !no_wino && wino_supported(ks, cin, cout, H, Wd);
     op.v2 = !op.wino4 && !op.wino4f && !op.wino && conv2_supported(ks) && !force_v1;
+    // SegNet-Basic's 64 -> 64 7x7 layers: bf16x6 on the bf16 matrix cores (SIVO_CONV7=f32 keeps the fp32-MFMA direct kernel)
+    static const bool conv7_f32 = std::getenv("SIVO_CONV7") && std::string(std::getenv("SIVO_CONV7")) == "f32";
+    op.c7x6 = !conv7_f32 && conv7_x6_supported(ks, cin, cout, H, Wd);
+    if (op.c7x6) {
+        std::vector<uint16_t> planes;
+        conv7_x6_pack_weights(W, cin, cout, planes);
+        op.d_wx6 = dev_alloc<uint16_t>(planes.size());
+        S.owned.push_back(op.d_wx6);
+        SIVO_HIP(hipMemcpy(op.d_wx6, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     if (op.wino4f) {
         wino4f_pack_weights(W, cin, cout, wt, &op.cout_pad);
     } else if (op.wino4) {
@@ -297,7 +308,9 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             {
                 char kn[96];
                 const int bn = conv_cout_tile(op.ks, op.cout), kc = conv_k_chunk(op.ks, op.cin);
-                if (op.wino4f)
+                if (op.c7x6)
+                    snprintf(kn, sizeof kn, "conv7_x6_kernel");
+                else if (op.wino4f)
                     snprintf(kn, sizeof kn, "conv_wino4f_kernel");
                 else if (op.wino4)
                     snprintf(kn, sizeof kn, "conv_wino4 (input + gemm + output kernels)");
@@ -601,6 +614,7 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                     }
                     launch_conv_wino4(a, ws, op.wino4_group, st, sub, S.profile_mfma_only, planned ? &plan : nullptr);
                 }
+                else if (op.c7x6) launch_conv7_x6(a, st);
                 else if (op.wino) launch_conv_wino(a, op.wino_cfg, st);
                 else if (op.v2) launch_conv2(a, op.ks, st);
                 else launch_conv(a, op.ks, st);
@@ -1103,6 +1117,7 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
 extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, int iters, int variant, double *ms_out) {
     return guarded([&] {
         if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device");
+        const bool c7x6 = (variant & 65536) && conv7_x6_supported(ks, Cin, Cout, H, W);
         const bool wino4f = (variant & 1024) && wino4f_supported(ks, Cin, Cout, H, W);
         const bool wino4 = !wino4f && (variant & 512) && wino4_supported(ks, Cin, Cout, H, W);
         const bool wino = !wino4 && !wino4f && (variant & 64) && wino_supported(ks, Cin, Cout, H, W);
@@ -1138,7 +1153,17 @@ extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, i
             a.wt_x6 = dx6;
         }
         if (wino4f) a.CoutPad = Cout;
-        auto go = [&] { if (wino4f) launch_conv_wino4f(a, nullptr); else if (wino4) launch_conv_wino4(a, dws, w4group, nullptr); else if (wino) launch_conv_wino(a, wcfg, nullptr); else if (v2) launch_conv2(a, ks, nullptr); else launch_conv(a, ks, nullptr); };
+        void *d7 = nullptr;
+        if (c7x6) {
+            std::vector<float> w7((size_t)Cout * Cin * 49);
+            for (auto &v : w7) v = rnd() * 0.05f;
+            std::vector<uint16_t> planes;
+            conv7_x6_pack_weights(w7.data(), Cin, Cout, planes);
+            d7 = dev_alloc<uint16_t>(planes.size());
+            SIVO_HIP(hipMemcpy(d7, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+            a.wt_x6 = d7;
+        }
+        auto go = [&] { if (c7x6) launch_conv7_x6(a, nullptr); else if (wino4f) launch_conv_wino4f(a, nullptr); else if (wino4) launch_conv_wino4(a, dws, w4group, nullptr); else if (wino) launch_conv_wino(a, wcfg, nullptr); else if (v2) launch_conv2(a, ks, nullptr); else launch_conv(a, ks, nullptr); };
         if (wino) a.CoutPad = Cout;
         for (int i = 0; i < 2; ++i) go();
         SIVO_HIP(hipEventRecord(e0, nullptr));
@@ -1148,7 +1173,7 @@ extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, i
         float ms = 0;
         SIVO_HIP(hipEventElapsedTime(&ms, e0, e1));
         *ms_out = ms / iters;
-        (void)hipFree(din); (void)hipFree(dout); (void)hipFree(dw); (void)hipFree(ds); (void)hipFree(dws); (void)hipFree(dx6);
+        (void)hipFree(din); (void)hipFree(dout); (void)hipFree(dw); (void)hipFree(ds); (void)hipFree(dws); (void)hipFree(dx6); (void)hipFree(d7);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         return SIVO_OK;
     });

@@ -58,6 +58,10 @@ int wino4_group(int N, int cin, int cout, int H, int W, size_t budget_bytes);
 bool wino4_x6_supported(int cin, int cout_pad);
 void wino4_x6_pack_weights(const std::vector<float> &U, int cin, int cout_pad, std::vector<uint16_t> &out);
 size_t wino4_workspace_floats(int group, int cin, int cout, int H, int W);
+// direct 7x7, 64 -> 64, on the bf16 matrix cores with fp32 operands as three bf16 planes (conv7_x6.hip); weights in ConvArgs::wt_x6
+bool conv7_x6_supported(int ks, int cin, int cout, int H, int W);
+void conv7_x6_pack_weights(const float *W, int cin, int cout, std::vector<uint16_t> &out);
+void launch_conv7_x6(const ConvArgs &a, hipStream_t s);
 // fused Winograd F(4x4,3x3), 64 couts per workgroup (conv_wino4f.hip)
 bool wino4f_supported(int ks, int cin, int cout, int H, int W);
 int wino4f_slab_floats();
