@@ -458,8 +458,11 @@ constexpr int X6P_LDS = (2 + 3) * 3 * X6_PLANE + 2 * X6P_VRAW;       // V planes
 
 // ABL (diagnostics): 1 no V DMA after stage 0, 2 no U DMA after stage 0, 4 no split after stage 0, 8 no MFMAs, 16 operand
 // fragments read from LDS in stage 0 only, 32 no M stores.
-template <int ABL>
-__global__ __launch_bounds__(512, 1) void wino4_gemm_x6p_kernel(Wino4Args a, const uint4 *__restrict__ Ux, int ptiles, int ktiles) {
+// NCW: consumer waves, 4 (one per SIMD, 64 x 64 each) or 8 (two per SIMD, 64 tiles x 32 couts each: the two MFMA row classes
+// 2h, 2h + 1 of a 64-cout range).  One wave per SIMD cannot keep the matrix pipe full — the MFMA-only ablation of the
+// 4-consumer form tops out at 1.22 PFLOP/s while conv7_x6.hip, two MFMA waves per SIMD, executes 1.42 with all its staging.
+template <int ABL, int NCW = 4>
+__global__ __launch_bounds__(NCW == 8 ? 768 : 512, 1) void wino4_gemm_x6p_kernel(Wino4Args a, const uint4 *__restrict__ Ux, int ptiles, int ktiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds6[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nchunks = a.C / X6_KC;
@@ -481,12 +484,12 @@ __global__ __launch_bounds__(512, 1) void wino4_gemm_x6p_kernel(Wino4Args a, con
     auto Ul = [&](int buf) { return lds6 + 3 * X6_PLANE * (2 + buf); };
     auto Vraw = [&](int buf) { return lds6 + 3 * X6_PLANE * 5 + X6P_VRAW * buf; };
 
-    if (wave >= 4) {
+    if (wave >= NCW) {
         // ------------------------------------------------------------------ producers
         // Everything a producer brings in comes by LDS-DMA, issued a whole stage ahead and waited for with vmcnt only:
         // the U image of the next stage (24 KB, 6 x 1 KiB per wave) and the raw fp32 V rows of the next stage — wave w
         // copies exactly the 8 channel rows it splits itself (4 x 1 KiB), so no producer depends on another one.
-        const int w = wave - 4, vh = lane >> 5, vtq = lane & 31;
+        const int w = wave - NCW, vh = lane >> 5, vtq = lane & 31;
         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
         int k_item = 0, chunk = 0;                  // the stage the NEXT DMA batch belongs to
         int xi, pt, kt;
@@ -556,26 +559,26 @@ __global__ __launch_bounds__(512, 1) void wino4_gemm_x6p_kernel(Wino4Args a, con
 
     // ---------------------------------------------------------------------- consumers
     const int li = lane & 15, lk = lane >> 4;
-    const int wm = wave & 1, wn = wave >> 1;
-    f32x4 acc[4][4];
+    constexpr int NT = NCW == 8 ? 2 : 4;         // 16-cout blocks per consumer
+    const int wm = wave & 1, wn = (wave >> 1) & 1, nh = NCW == 8 ? 2 * (wave >> 2) : 0;      // nh: first MFMA row class of this wave's couts
+    f32x4 acc[4][NT];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int a_off[4], b_off[4];
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int a_off[4], b_off[NT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        a_off[t] = x6_slot(64 * wm + 4 * li + t, lk) * 16;
-        b_off[t] = x6_slot(64 * wn + 4 * li + t, lk) * 16;
-    }
+    for (int t = 0; t < 4; ++t) a_off[t] = x6_slot(64 * wm + 4 * li + t, lk) * 16;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b_off[t] = x6_slot(64 * wn + 4 * li + nh + t, lk) * 16;
     int k_item = 0, chunk = 0;
     x6p_barrier();                                // stage 0 ready
-    bf16x8 bfrag[4][3], afr[4][3];
+    bf16x8 bfrag[NT][3], afr[4][3];
     for (int s = 0; s < nstages; ++s) {
         const unsigned char *Vs = Vl(s & 1), *Us = Ul(s % 3);
         if (!(ABL & 16) || s == 0) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) bfrag[nt][pl] = *reinterpret_cast<const bf16x8 *>(Us + pl * X6_PLANE + b_off[nt]);
         }
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(512, 1) void wino4_gemm_x6p_kernel(Wino4Args a, con
             for (int term = 0; term < 6; ++term) {
                 constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
+                for (int nt = 0; nt < NT; ++nt) {
                     if (ABL & 8) acc[mt][nt][0] += (float)af[PA[term]][0] + (float)bfrag[nt][PB[term]][1];
                     else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA[term]], bfrag[nt][PB[term]], acc[mt][nt], 0, 0, 0);
                 }
@@ -608,8 +611,8 @@ __global__ __launch_bounds__(512, 1) void wino4_gemm_x6p_kernel(Wino4Args a, con
                 // the pieces over the four lanes li, li + 16, li + 32, li + 48 (v_permlane16_swap / v_permlane32_swap, two
                 // stages, no LDS) gives lane lk the pieces 4 j + lk: instruction j then writes 64 contiguous bytes per row.
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    float *row = Mg + (int64_t)(wn * 64 + 4 * li + nt) * a.Pp + wm * 64 + 4 * lk;
+                for (int nt = 0; nt < NT; ++nt) {
+                    float *row = Mg + (int64_t)(wn * 64 + 4 * li + nh + nt) * a.Pp + wm * 64 + 4 * lk;
                     f32x4 y[4];
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) {
@@ -626,8 +629,8 @@ __global__ __launch_bounds__(512, 1) void wino4_gemm_x6p_kernel(Wino4Args a, con
             } else
             if (!(ABL & 32) || acc[0][0][0] == 12345.678f)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                float *row = Mg + (int64_t)(wn * 64 + 4 * li + nt) * a.Pp + wm * 64 + 16 * lk;
+            for (int nt = 0; nt < NT; ++nt) {
+                float *row = Mg + (int64_t)(wn * 64 + 4 * li + nh + nt) * a.Pp + wm * 64 + 16 * lk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     *reinterpret_cast<f32x4 *>(row + 4 * r) = f32x4{acc[0][nt][r], acc[1][nt][r], acc[2][nt][r], acc[3][nt][r]};
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(512, 1) void wino4_gemm_x6p_kernel(Wino4Args a, con
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         x6p_barrier();                            // done with stage s; stage s + 1 ready
     }
@@ -919,7 +922,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         for (const void *f : {(const void *)wino4_gemm_x6p_kernel<0>, (const void *)wino4_gemm_x6p_kernel<1>, (const void *)wino4_gemm_x6p_kernel<2>,
                               (const void *)wino4_gemm_x6p_kernel<3>, (const void *)wino4_gemm_x6p_kernel<4>, (const void *)wino4_gemm_x6p_kernel<7>,
                               (const void *)wino4_gemm_x6p_kernel<8>, (const void *)wino4_gemm_x6p_kernel<16>, (const void *)wino4_gemm_x6p_kernel<23>,
-                              (const void *)wino4_gemm_x6p_kernel<32>, (const void *)wino4_gemm_x6p_kernel<64>})
+                              (const void *)wino4_gemm_x6p_kernel<32>, (const void *)wino4_gemm_x6p_kernel<64>, (const void *)wino4_gemm_x6p_kernel<64, 8>})
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_x6_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS);
         for (const void *f : {(const void *)wino4_gemm_x6_kernel<1>, (const void *)wino4_gemm_x6_kernel<2>, (const void *)wino4_gemm_x6_kernel<4>,
@@ -979,8 +982,13 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
                 const dim3 gp((unsigned)((n_cu / 8) * 8 > 0 ? (n_cu / 8) * 8 : 8));        // one persistent workgroup per CU, a multiple of the 8 XCDs
                 // M stores transposed into 64-byte runs (ABL bit 64): GEMM time of a frame 5.51 -> 5.17 ms; SIVO_X6_MSTORE=0: as held
                 static const bool mstore64 = !(std::getenv("SIVO_X6_MSTORE") && std::atoi(std::getenv("SIVO_X6_MSTORE")) == 0);
+                // SIVO_X6_CONSUMERS=8: two consumer waves per SIMD (12-wave workgroup)
+                static const bool x6_consumers8 = std::getenv("SIVO_X6_CONSUMERS") && std::atoi(std::getenv("SIVO_X6_CONSUMERS")) == 8;
                 switch (((c.variant >> 12) & 63) == 0 && mstore64 ? 64 : ((c.variant >> 12) & 63)) {
-                    case 64: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<64>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
+                    case 64:
+                        if (x6_consumers8) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 8>), gp, dim3(768), X6P_LDS, s, a, u6, pt6, kt6);
+                        else hipLaunchKernelGGL(wino4_gemm_x6p_kernel<64>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6);
+                        break;
                     case 1: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<1>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
                     case 2: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<2>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
                     case 3: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<3>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;

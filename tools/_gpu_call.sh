@@ -1,5 +1,8 @@
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r02y
-O=gpurun_out/r02y
-timeout 1200 python -m pytest tests/test_gpu_segnet_fullsize.py -x -q -s -k "basic" > $O/t1.log 2>&1; echo "t1 rc=$?"; grep "^\[" $O/t1.log | head -12; tail -2 $O/t1.log
-timeout 300 python bench.py --net basic --T 6 --steps 20 --configs none --no-cpu-baseline --no-orb --per-layer > $O/bench_basic.json 2> $O/bench_basic.err; python -c "import json;d=json.load(open('$O/bench_basic.json'));print('basic',d['value'],d['ms_per_step'],d['roofline']['kernel'],d['roofline']['frac'],d['roofline']['kernels_ms_per_frame'])"; grep "N=" $O/bench_basic.err | awk '{print $1,$2,$3,$4,$5}' | head -20
+mkdir -p gpurun_out/r02z
+O=gpurun_out/r02z
+SIVO_X6_CONSUMERS=8 timeout 600 python -m pytest tests/test_gpu_segnet.py -x -q -k "bridged or pooling_fused or winograd_and_direct or reference_nets or fused_upsample" > $O/t1.log 2>&1; echo "t1 rc=$?"; tail -2 $O/t1.log
+timeout 200 python tools/x6_probe.py 2>&1 | grep -v amdgpu > $O/probe4.log; SIVO_X6_CONSUMERS=8 timeout 200 python tools/x6_probe.py 2>&1 | grep -v amdgpu > $O/probe8.log; paste -d'\n' $O/probe4.log $O/probe8.log | grep -v "^$"
+B="--steps 30 --configs none --no-cpu-baseline --per-layer"
+SIVO_X6_CONSUMERS=8 timeout 300 python bench.py $B > $O/bench8.json 2> $O/bench8.err; python -c "import json;d=json.load(open('$O/bench8.json'));print('cons8',d['value'],d['ms_per_step'],d['roofline']['kernels_ms_per_frame'])"
+timeout 300 python bench.py $B > $O/bench4.json 2> $O/bench4.err; python -c "import json;d=json.load(open('$O/bench4.json'));print('cons4',d['value'],d['ms_per_step'],d['roofline']['kernels_ms_per_frame'])"
