@@ -190,7 +190,7 @@ void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int 
     op.wino = !op.wino4 && !op.wino4f && !no_wino && wino_supported(ks, cin, cout, H, Wd);
     op.v2 = !op.wino4 && !op.wino4f && !op.wino && conv2_supported(ks) && !force_v1;
     // SegNet-Basic's 64 -> 64 7x7 layers: bf16x6 on the bf16 matrix cores (SIVO_CONV7=f32 keeps the fp32-MFMA direct kernel)
-    static const bool conv7_f32 = std::getenv("SIVO_CONV7") && std::string(std::getenv("SIVO_CONV7")) == "f32";
+    const bool conv7_f32 = std::getenv("SIVO_CONV7") && std::string(std::getenv("SIVO_CONV7")) == "f32";      // (read per handle: tests build both)
     op.c7x6 = !conv7_f32 && conv7_x6_supported(ks, cin, cout, H, Wd);
     if (op.c7x6) {
         std::vector<uint16_t> planes;

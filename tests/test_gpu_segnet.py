@@ -349,6 +349,51 @@ def test_persistent_fused_f4x4_kernel_is_bit_identical(H, W):
     assert np.abs(got["2"][1]).max() > 0
 
 
+def _conv7_stack_prototxt(T, H, W, width):
+    """data -> conv3x3(3->width)+ReLU+Dropout -> conv7x7(width->64)+BN+ReLU+Dropout -> conv7x7(64->64) -> conv1x1(64->15) -> Softmax:
+    SegNet-Basic's 7x7 layers behind a dropout (per-sample), with every epilogue option."""
+    from sivo_amd.netspec import _bn, _conv, _drop, _relu, _softmax
+    out = [f'name: "conv7_stack"\ninput: "data"\ninput_dim: {T}\ninput_dim: 3\ninput_dim: {H}\ninput_dim: {W}\n']
+    out += [_conv("c0", "data", "c0", width, 3, 1), _relu("r0", "c0"), _drop("d0", "c0")]
+    out += [_conv("c1", "c0", "c1", 64, 7, 3), _bn("c1_bn", "c1"), _relu("r1", "c1"), _drop("d1", "c1")]
+    out += [_conv("c2", "c1", "c2", 64, 7, 3)]
+    out += [_conv("cls", "c2", "cls", 15, 1, 0), _softmax("cls")]
+    return "".join(out)
+
+
+@pytest.mark.parametrize("H,W,width", [(22, 36, 64), (9, 12, 32), (40, 100, 96), (16, 64, 64)])
+def test_conv7_bf16x6_shapes(oracle, H, W, width):
+    """conv7_x6.hip (direct 7x7 on the bf16 matrix cores, fp32 operands as three bf16 planes): ragged tile rows and columns
+    (H not a multiple of 8, W a multiple of 4 only), images smaller than one workgroup tile, 32 / 64 / 96 input channels
+    (one to three 32-channel halves), BN + ReLU + dropout epilogue and none: every blob against the oracle, and against the
+    fp32-MFMA direct kernel (SIVO_CONV7=f32) to the rounding of two fp32 evaluations."""
+    T = 3
+    text = _conv7_stack_prototxt(T, H, W, width)
+    net, w, sn = _make(text, T, seed=21)
+    os.environ["SIVO_CONV7"] = "f32"
+    try:
+        _, _, sn32 = _make(text, T, seed=21)
+    finally:
+        del os.environ["SIVO_CONV7"]
+    img = _image(np.random.default_rng(H * W + width), H, W)
+    d_img = torch.from_numpy(img).cuda()
+    ob = oracle.run_net(net, w, oracle.preprocess(img, T, H, W), 13, sample0=1)
+    _, logits, _ = sn.forward(d_img, 13, sample0=1, want_logits=True)
+    torch.cuda.synchronize()
+    blobs = {n: sn.blob(n) for n in ("c1", "c2", "cls")}
+    _, logits32, _ = sn32.forward(d_img, 13, sample0=1, want_logits=True)
+    torch.cuda.synchronize()
+    for name in ("c1", "c2", "cls"):
+        g, o, g32 = blobs[name], ob[name], sn32.blob(name)
+        np.testing.assert_allclose(g, o, atol=LOGIT_TOL, rtol=0, err_msg=name)
+        np.testing.assert_allclose(g, g32, atol=2e-4 * max(1.0, float(np.abs(o).max())), rtol=0, err_msg=name)
+        if name == "c1":
+            mism = (g == 0) != (o == 0)        # dropout zero pattern: only ReLU outputs within rounding of 0 may differ
+            assert mism.mean() < 1e-4 and (np.abs(g[mism]) < 1e-4).all() and (np.abs(o[mism]) < 1e-4).all()
+    np.testing.assert_allclose(logits.cpu().numpy(), ob["cls"], atol=LOGIT_TOL, rtol=0)
+    assert np.abs(ob["c2"]).max() > 0.1
+
+
 def _classifier_prototxt(T, H, W, width, classes):
     """data -> conv3x3(3->width)+ReLU+Dropout -> conv3x3(width->width)+BN+ReLU -> conv3x3(width->classes) -> Softmax: the tail
     of SegNet-Standard (conv1_2_D, conv1_1_D, prob) behind a dropout, so that the classifier is per-sample."""
