@@ -461,8 +461,11 @@ constexpr int X6P_LDS = (2 + 3) * 3 * X6_PLANE + 2 * X6P_VRAW;       // V planes
 // NCW: consumer waves, 4 (one per SIMD, 64 x 64 each) or 8 (two per SIMD, 64 tiles x 32 couts each: the two MFMA row classes
 // 2h, 2h + 1 of a 64-cout range).  One wave per SIMD cannot keep the matrix pipe full — the MFMA-only ablation of the
 // 4-consumer form tops out at 1.22 PFLOP/s while conv7_x6.hip, two MFMA waves per SIMD, executes 1.42 with all its staging.
-template <int ABL, int NCW = 4>
-__global__ __launch_bounds__(NCW == 8 ? 768 : 512, 1) void wino4_gemm_x6p_kernel(Wino4Args a, const uint4 *__restrict__ Ux, int ptiles, int ktiles) {
+// NPW: producer waves, 4 (one channel octet each) or 8 (half an octet each: two of the octet's four row pairs; the bf16 pieces
+// are then written as 4-byte halves).  A stage waits for the slower of the two chains (tools/x6_probe.py ablate: consumers
+// alone 0.44 ms, everything but the MFMAs 0.43 ms, together 0.57 ms on conv4_2): eight producers halve the latency of theirs.
+template <int ABL, int NCW = 4, int NPW = 4>
+__global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Wino4Args a, const uint4 *__restrict__ Ux, int ptiles, int ktiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds6[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nchunks = a.C / X6_KC;
@@ -490,7 +493,10 @@ __global__ __launch_bounds__(NCW == 8 ? 768 : 512, 1) void wino4_gemm_x6p_kernel
         // the U image of the next stage (24 KB, 6 x 1 KiB per wave) and the raw fp32 V rows of the next stage — wave w
         // copies exactly the 8 channel rows it splits itself (4 x 1 KiB), so no producer depends on another one.
         const int w = wave - NCW, vh = lane >> 5, vtq = lane & 31;
+        constexpr int UPW = 24 / NPW, VPW = 16 / NPW;         // 1 KiB DMA pieces per wave and stage: U planes, raw V rows
+        const int oct = NPW == 8 ? w >> 1 : w, ih = NPW == 8 ? (w & 1) : 0;      // channel octet, half of it (row pairs 2 ih, 2 ih + 1)
         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
         int k_item = 0, chunk = 0;                  // the stage the NEXT DMA batch belongs to
         int xi, pt, kt;
         item_of(0, xi, pt, kt);
@@ -498,35 +504,37 @@ __global__ __launch_bounds__(NCW == 8 ? 768 : 512, 1) void wino4_gemm_x6p_kernel
             const uint4 *usrc = Ux + ((int64_t)(xi * ktiles + kt) * nchunks + chunk) * (3 * 512);
             unsigned char *udst = Ul(s % 3);
 #pragma unroll
-            for (int i = 0; i < ((ABL & 2) && s > 2 ? 0 : 6); ++i) {
-                const int kib = w * 6 + i;
+            for (int i = 0; i < ((ABL & 2) && s > 2 ? 0 : UPW); ++i) {
+                const int kib = w * UPW + i;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(usrc + kib * 64 + lane),
                                                  (__attribute__((address_space(3))) void *)(udst + kib * 1024), 16, 0, 0);
             }
             const float *Vg = a.V + ((int64_t)xi * a.C) * a.Pp + (int64_t)pt * 128;
-            unsigned char *vdst = Vraw(s & 1) + w * 4096;
+            unsigned char *vdst = Vraw(s & 1) + oct * 4096;
             if (!((ABL & 1) && s > 1))
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < VPW; ++i) {
+                const int ii = VPW * ih + i;        // row pair of the octet: channels 2 ii, 2 ii + 1
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(Vg + (int64_t)(chunk * X6_KC + w * 8 + 2 * i + vh) * a.Pp + 4 * vtq),
-                    (__attribute__((address_space(3))) void *)(vdst + i * 1024), 16, 0, 0);
+                    (const __attribute__((address_space(1))) void *)(Vg + (int64_t)(chunk * X6_KC + oct * 8 + 2 * ii + vh) * a.Pp + 4 * vtq),
+                    (__attribute__((address_space(3))) void *)(vdst + ii * 1024), 16, 0, 0);
+            }
             if (++chunk == nchunks) {
                 chunk = 0;
                 if (++k_item < my_items) item_of(k_item, xi, pt, kt);
             }
         };
         auto split_stage = [&](int s) {             // raw V rows of this wave -> three bf16 planes of V buffer s & 1
-            const unsigned char *src = Vraw(s & 1) + w * 4096 + lane * 16;
-            f32x4 vr[4];
+            const unsigned char *src = Vraw(s & 1) + oct * 4096 + lane * 16;
+            f32x4 vr[VPW];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vr[i] = *reinterpret_cast<const f32x4 *>(src + i * 1024);
+            for (int i = 0; i < VPW; ++i) vr[i] = *reinterpret_cast<const f32x4 *>(src + (VPW * ih + i) * 1024);
             unsigned char *Vb = Vl(s & 1);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                bf16x4 p1, p2, p3;
+                __bf16 p1[VPW], p2[VPW], p3[VPW];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < VPW; ++i) {
                     const float x = vr[i][t];
                     const __bf16 x1 = (__bf16)x;
                     const float r1 = x - (float)x1;
@@ -534,10 +542,17 @@ __global__ __launch_bounds__(NCW == 8 ? 768 : 512, 1) void wino4_gemm_x6p_kernel
                     const float r2 = r1 - (float)x2;
                     p1[i] = x1; p2[i] = x2; p3[i] = (__bf16)r2;
                 }
-                unsigned char *dst = Vb + x6_slot(4 * vtq + t, w) * 16 + 8 * vh;
-                *reinterpret_cast<bf16x4 *>(dst) = p1;
-                *reinterpret_cast<bf16x4 *>(dst + X6_PLANE) = p2;
-                *reinterpret_cast<bf16x4 *>(dst + 2 * X6_PLANE) = p3;
+                // element 4 vh + ii of the piece is channel 2 ii + vh: this wave's VPW elements start at 4 vh + VPW ih
+                unsigned char *dst = Vb + x6_slot(4 * vtq + t, oct) * 16 + 8 * vh + 2 * VPW * ih;
+                if (NPW == 8) {
+                    *reinterpret_cast<bf16x2 *>(dst) = bf16x2{p1[0], p1[1]};
+                    *reinterpret_cast<bf16x2 *>(dst + X6_PLANE) = bf16x2{p2[0], p2[1]};
+                    *reinterpret_cast<bf16x2 *>(dst + 2 * X6_PLANE) = bf16x2{p3[0], p3[1]};
+                } else {
+                    *reinterpret_cast<bf16x4 *>(dst) = bf16x4{p1[0], p1[1], p1[VPW - 2], p1[VPW - 1]};
+                    *reinterpret_cast<bf16x4 *>(dst + X6_PLANE) = bf16x4{p2[0], p2[1], p2[VPW - 2], p2[VPW - 1]};
+                    *reinterpret_cast<bf16x4 *>(dst + 2 * X6_PLANE) = bf16x4{p3[0], p3[1], p3[VPW - 2], p3[VPW - 1]};
+                }
             }
         };
         issue_stage(0);
@@ -546,7 +561,7 @@ __global__ __launch_bounds__(NCW == 8 ? 768 : 512, 1) void wino4_gemm_x6p_kernel
                 if (s + 1 < nstages) {
                     issue_stage(s + 1);                          // lands during the consumers' stage s - 1 .. s
                     if (ABL & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // all but that batch: stage s has landed
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UPW + VPW) : "memory");   // all but that batch: stage s has landed
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
@@ -922,7 +937,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         for (const void *f : {(const void *)wino4_gemm_x6p_kernel<0>, (const void *)wino4_gemm_x6p_kernel<1>, (const void *)wino4_gemm_x6p_kernel<2>,
                               (const void *)wino4_gemm_x6p_kernel<3>, (const void *)wino4_gemm_x6p_kernel<4>, (const void *)wino4_gemm_x6p_kernel<7>,
                               (const void *)wino4_gemm_x6p_kernel<8>, (const void *)wino4_gemm_x6p_kernel<16>, (const void *)wino4_gemm_x6p_kernel<23>,
-                              (const void *)wino4_gemm_x6p_kernel<32>, (const void *)wino4_gemm_x6p_kernel<64>, (const void *)wino4_gemm_x6p_kernel<64, 8>})
+                              (const void *)wino4_gemm_x6p_kernel<32>, (const void *)wino4_gemm_x6p_kernel<64>, (const void *)wino4_gemm_x6p_kernel<64, 8>, (const void *)wino4_gemm_x6p_kernel<64, 4, 8>})
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_x6_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS);
         for (const void *f : {(const void *)wino4_gemm_x6_kernel<1>, (const void *)wino4_gemm_x6_kernel<2>, (const void *)wino4_gemm_x6_kernel<4>,
@@ -984,9 +999,12 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
                 static const bool mstore64 = !(std::getenv("SIVO_X6_MSTORE") && std::atoi(std::getenv("SIVO_X6_MSTORE")) == 0);
                 // SIVO_X6_CONSUMERS=8: two consumer waves per SIMD (12-wave workgroup)
                 static const bool x6_consumers8 = std::getenv("SIVO_X6_CONSUMERS") && std::atoi(std::getenv("SIVO_X6_CONSUMERS")) == 8;
+                // SIVO_X6_PRODUCERS=8: eight producer waves (12-wave workgroup)
+                static const bool x6_producers8 = std::getenv("SIVO_X6_PRODUCERS") && std::atoi(std::getenv("SIVO_X6_PRODUCERS")) == 8;
                 switch (((c.variant >> 12) & 63) == 0 && mstore64 ? 64 : ((c.variant >> 12) & 63)) {
                     case 64:
-                        if (x6_consumers8) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 8>), gp, dim3(768), X6P_LDS, s, a, u6, pt6, kt6);
+                        if (x6_producers8) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 8>), gp, dim3(768), X6P_LDS, s, a, u6, pt6, kt6);
+                        else if (x6_consumers8) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 8>), gp, dim3(768), X6P_LDS, s, a, u6, pt6, kt6);
                         else hipLaunchKernelGGL(wino4_gemm_x6p_kernel<64>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6);
                         break;
                     case 1: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<1>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
