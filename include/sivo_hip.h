@@ -155,7 +155,10 @@ int sivo_mc_segment_dev(const float *d_logits, int T, int classes, int64_t hw, u
 
 /* Copy a named blob of the last forward to the host (fp32; pooling masks are
  * returned as the flat input-plane index Caffe stores, as fp32).  shape =
- * {N, C, H, W}.  Test/diagnostic entry point. */
+ * {N, C, H, W}.  Test/diagnostic entry point.  Blobs that only exist on chip (fused away) are refused; the logits blob
+ * (input of the Softmax layer) is written only by passes that ask for logits or per-sample probabilities
+ * (sivo_segnet_forward_dev with d_logits / d_prob): segment / segment_dev / forward_dev without them run the classifier
+ * fused with the Monte-Carlo post-processing and leave that blob as the last such pass wrote it. */
 int sivo_segnet_blob(sivo_segnet_t h, const char *name, float *host_out, size_t capacity, int32_t shape[4]);
 
 /* Algorithmic FLOPs of one forward (2*k*k*Cin*Cout*H*W per conv): shared =
