@@ -321,9 +321,16 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=3) if do_orb else None
 
+    orb_delay = float(os.environ.get("SIVO_BENCH_ORB_DELAY_MS", "0")) * 1e-3       # experiment: start ORB this long after the network
+    tail_probe = [] if os.environ.get("SIVO_BENCH_TAIL_PROBE") else None         # experiment: host time of the cull behind the class map
+
     def orb_extract(res):
-        fl = pool.submit(lambda: res.__setitem__("l", ex_l(d_left)))
-        fr = pool.submit(lambda: res.__setitem__("r", ex_r(d_right)))
+        def run(k, ex, im):
+            if orb_delay > 0:
+                time.sleep(orb_delay)
+            res[k] = ex(im)
+        fl = pool.submit(run, "l", ex_l, d_left)
+        fr = pool.submit(run, "r", ex_r, d_right)
 
         def match():
             fl.result(); fr.result()
@@ -356,7 +363,10 @@ def main():
         if do_orb:
             cls_host = maps[0].cpu().numpy()              # 360 KB D2H; waits for this frame's class map
             [t.result() for t in th]
-            orb_finish(res, cls_host)
+            if tail_probe is not None:
+                t0 = time.perf_counter(); orb_finish(res, cls_host); tail_probe.append(time.perf_counter() - t0)
+            else:
+                orb_finish(res, cls_host)
 
     def barrier():
         torch.cuda.synchronize()
@@ -382,6 +392,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    if rank == 0 and tail_probe:
+        print(f"host tail (semantic filter + median cull) mean {1e3 * float(np.mean(tail_probe)):.3f} ms over {len(tail_probe)} frames", file=sys.stderr)
     if rank == 0:
         fps = args.steps / elapsed
         ms_frame = 1e3 * elapsed / args.steps
