@@ -60,6 +60,10 @@ constexpr int C7_NTHR = 512;
 constexpr int C7_ITEMS = 4 * C7_NPIX;                      // (octet, pixel) staging items per half
 constexpr int C7_IT = (C7_ITEMS + C7_NTHR - 1) / C7_NTHR;  // 5
 
+// UNPOOL: `a.in` is the pooled tensor of an Upsample (scale 2) layer and `a.unpool_mask` its window codes: the patch loader
+// reads the pooled value and its code where it would read the unpooled pixel (value at the recorded position of the 2 x 2
+// window, zero elsewhere) — the unpooled tensor never exists and unpool2_kernel is not run.
+template <bool UNPOOL>
 __global__ __launch_bounds__(C7_NTHR, 1) void conv7_x6_kernel(ConvArgs a, const uint4 *__restrict__ Wx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds7[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,13 +80,18 @@ __global__ __launch_bounds__(C7_NTHR, 1) void conv7_x6_kernel(ConvArgs a, const 
     const int n = bid;
     const int x0 = tx * C7_TW, y0 = ty * C7_TH;
     const int64_t plane = (int64_t)a.H * a.W;
+    const int Wh = a.W >> 1;
+    const int64_t plane_in = UNPOOL ? (int64_t)(a.H >> 1) * Wh : plane;      // plane of the tensor that is actually read
     const __amdgpu_buffer_rsrc_t in_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (int64_t)n * a.in_sample_stride), 0, (int)(a.Cin * plane * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (int64_t)n * a.in_sample_stride), 0, (int)(a.Cin * plane_in * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t mk_rsrc =
+        UNPOOL ? __builtin_amdgcn_make_buffer_rsrc((void *)(a.unpool_mask + (int64_t)n * a.unpool_mask_stride), 0, (int)(a.Cin * plane_in), 0x00020000)
+               : in_rsrc;
     constexpr uint32_t INV = 0xfffffff0u;
 
     // staging items of this thread: (octet g, patch pixel q); element offset of the pixel inside a plane, INV outside the image
     uint32_t s_off[C7_IT];
-    int s_dst[C7_IT];
+    int s_dst[C7_IT], s_code[C7_IT];
 #pragma unroll
     for (int it = 0; it < C7_IT; ++it) {
         const int i = tid + it * C7_NTHR;
@@ -90,7 +99,8 @@ __global__ __launch_bounds__(C7_NTHR, 1) void conv7_x6_kernel(ConvArgs a, const 
         const int py = q / C7_PW, px = q % C7_PW;
         const int gy = y0 + py - 3, gx = x0 + px - 3;
         const bool ok = i < C7_ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        s_off[it] = ok ? (uint32_t)(g * 8 * plane + (int64_t)gy * a.W + gx) : INV;
+        s_off[it] = !ok ? INV : UNPOOL ? (uint32_t)(g * 8 * plane_in + (int64_t)(gy >> 1) * Wh + (gx >> 1)) : (uint32_t)(g * 8 * plane + (int64_t)gy * a.W + gx);
+        s_code[it] = (gy & 1) * 2 + (gx & 1);
         s_dst[it] = i < C7_ITEMS ? (g * C7_PIXP + q) * 16 : -1;
     }
 
@@ -116,13 +126,17 @@ __global__ __launch_bounds__(C7_NTHR, 1) void conv7_x6_kernel(ConvArgs a, const 
     for (int half = 0; half < nhalf; ++half) {
         // ---- the half's patch: 8 channels of a pixel per item, split into three bf16 planes, one 16-byte piece per plane
         float v[C7_IT][8];
-        const uint32_t hb = (uint32_t)(half * 32 * plane);
+        const uint32_t hb = (uint32_t)(half * 32 * plane_in);
 #pragma unroll
         for (int it = 0; it < C7_IT; ++it)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const uint32_t o = s_off[it] == INV ? INV : (s_off[it] + hb + (uint32_t)(e * plane)) * 4u;
-                v[it][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (int)o, 0, 0));
+                const uint32_t oe = s_off[it] == INV ? INV : s_off[it] + hb + (uint32_t)(e * plane_in);
+                v[it][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (int)(oe == INV ? INV : oe * 4u), 0, 0));
+                if (UNPOOL) {
+                    const int m = (int)(__builtin_amdgcn_raw_buffer_load_b8(mk_rsrc, (int)oe, 0, 0) & 0xffu);
+                    v[it][e] = m == s_code[it] ? v[it][e] : 0.f;
+                }
             }
         dma_weights(half * 49, 0);
 #pragma unroll
@@ -250,12 +264,16 @@ void conv7_x6_pack_weights(const float *W, int cin, int cout, std::vector<uint16
 void launch_conv7_x6(const ConvArgs &a0, hipStream_t s) {
     static int attr_set[64] = {0};
     if (first_use_on_device(attr_set))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv7_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C7_LDS);
+    {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv7_x6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, C7_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv7_x6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, C7_LDS);
+    }
     ConvArgs a = a0;
     a.tiles_x = (a.W + C7_TW - 1) / C7_TW;
     a.tiles_y = (a.H + C7_TH - 1) / C7_TH;
     const int P = a.tiles_x * a.tiles_y * a.N, band = (P + 7) / 8;
-    hipLaunchKernelGGL(conv7_x6_kernel, dim3((unsigned)(8 * band)), dim3(C7_NTHR), C7_LDS, s, a, reinterpret_cast<const uint4 *>(a.wt_x6));
+    if (a.unpool_mask) hipLaunchKernelGGL(conv7_x6_kernel<true>, dim3((unsigned)(8 * band)), dim3(C7_NTHR), C7_LDS, s, a, reinterpret_cast<const uint4 *>(a.wt_x6));
+    else hipLaunchKernelGGL(conv7_x6_kernel<false>, dim3((unsigned)(8 * band)), dim3(C7_NTHR), C7_LDS, s, a, reinterpret_cast<const uint4 *>(a.wt_x6));
 }
 
 }  // namespace sivo

@@ -433,7 +433,7 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             for (Op &c : S.ops)
                 if (c.in == u.out || c.in2 == u.out) { ++uses; consumer = &c; }
             if (uses != 1 || consumer->kind != OP_CONV || consumer->in != u.out) continue;
-            if (!consumer->wino4 && !consumer->wino4f && !(consumer->wino && consumer->wino_cfg == 0)) continue;   // every Winograd path reads through the pooling
+            if (!consumer->wino4 && !consumer->wino4f && !consumer->c7x6 && !(consumer->wino && consumer->wino_cfg == 0)) continue;   // every Winograd path and the 7x7 bf16x6 kernel read through the pooling
             const Blob &pooled = S.blobs[u.in], &mask = S.blobs[u.in2], &up = S.blobs[u.out];
             if (pooled.shared && !up.shared) continue;            // (not produced by the reference nets)
             if (up.H != 2 * pooled.H || up.W != 2 * pooled.W || (pooled.W & 1)) continue;
