@@ -20,14 +20,30 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
-bool first_use_on_device(int *flags) {
+static std::mutex &first_use_mutex() {
     static std::mutex mu;
+    return mu;
+}
+
+FirstUse::FirstUse(int *flags) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
-    std::lock_guard<std::mutex> lock(mu);
-    if (flags[dev]) return false;
-    flags[dev] = 1;
-    return true;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        always_ = true;
+        return;
+    }
+    if (__atomic_load_n(&flags[dev], __ATOMIC_ACQUIRE)) return;
+    first_use_mutex().lock();
+    if (__atomic_load_n(&flags[dev], __ATOMIC_RELAXED)) {
+        first_use_mutex().unlock();
+        return;
+    }
+    slot_ = &flags[dev];
+}
+
+FirstUse::~FirstUse() {
+    if (!slot_) return;
+    __atomic_store_n(slot_, 1, __ATOMIC_RELEASE);
+    first_use_mutex().unlock();
 }
 
 }  // namespace sivo

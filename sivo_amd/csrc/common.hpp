@@ -59,9 +59,22 @@ T *dev_alloc(size_t n) {
     return p;
 }
 
-// true the first time it is called on the current device (thread-safe): kernel attributes such as the dynamic-LDS opt-in are
-// per device, and a process may drive several (sivo_segnet_create_multi)
-bool first_use_on_device(int *flags /* 64 ints, zero-initialised, one array per call site */);
+// `if (FirstUse once(flags); once) { … }` runs the block the first time it is reached on the current device: kernel
+// attributes such as the dynamic-LDS opt-in are per device, and a process may drive several (sivo_segnet_create_multi).
+// The guard keeps the lock until the block has finished, so a second thread that finds the flag set also finds the
+// attributes set; afterwards the check is one atomic load.
+class FirstUse {
+ public:
+    explicit FirstUse(int *flags /* 64 ints, zero-initialised, one array per call site */);
+    ~FirstUse();
+    FirstUse(const FirstUse &) = delete;
+    FirstUse &operator=(const FirstUse &) = delete;
+    explicit operator bool() const { return slot_ != nullptr || always_; }
+
+ private:
+    int *slot_ = nullptr;      // non-null: this guard holds the lock and publishes the flag on destruction
+    bool always_ = false;      // device index unknown: run the block every time, unlocked
+};
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -263,7 +263,7 @@ void conv7_x6_pack_weights(const float *W, int cin, int cout, std::vector<uint16
 
 void launch_conv7_x6(const ConvArgs &a0, hipStream_t s) {
     static int attr_set[64] = {0};
-    if (first_use_on_device(attr_set))
+    if (FirstUse once(attr_set); once)
     {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv7_x6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, C7_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv7_x6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, C7_LDS);

@@ -933,7 +933,7 @@ size_t wino4_bridge_lds_bytes(int H, int W) { return (size_t)(4 * ((H + 3) / 4) 
 void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream_t s, hipEvent_t *ev, bool gemm_only_events,
                        const Wino4Plan *plan) {
     static int attr_set[64] = {0};
-    if (first_use_on_device(attr_set)) {
+    if (FirstUse once(attr_set); once) {
         for (const void *f : {(const void *)wino4_gemm_x6p_kernel<0>, (const void *)wino4_gemm_x6p_kernel<1>, (const void *)wino4_gemm_x6p_kernel<2>,
                               (const void *)wino4_gemm_x6p_kernel<3>, (const void *)wino4_gemm_x6p_kernel<4>, (const void *)wino4_gemm_x6p_kernel<7>,
                               (const void *)wino4_gemm_x6p_kernel<8>, (const void *)wino4_gemm_x6p_kernel<16>, (const void *)wino4_gemm_x6p_kernel<23>,

@@ -742,7 +742,7 @@ void wino4f_pack_weights(const float *W, int cin, int cout, std::vector<float> &
 
 void launch_conv_wino4f(const ConvArgs &a0, hipStream_t s) {
     static int attr_set[64] = {0};
-    if (first_use_on_device(attr_set)) {
+    if (FirstUse once(attr_set); once) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino4f_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F_BUF * 4);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino4f_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F_BUF * 4);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino4f_p_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F_BUF * 4);
@@ -805,7 +805,7 @@ void launch_conv_wino4f(const ConvArgs &a0, hipStream_t s) {
     if (pipe && persist_env && !abl && !(a.variant & 16384) && a.CoutPad == 64 && (ptiles >= 16 * n_cu || persist_force || (a.variant & 32768))) {
         static int attr_pp[64] = {0};
         const size_t lds_pp = (size_t)(2 * F_BUF + F_EXCH) * 4;
-        if (first_use_on_device(attr_pp)) {
+        if (FirstUse once(attr_pp); once) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino4f_pp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino4f_pp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp);
         }
