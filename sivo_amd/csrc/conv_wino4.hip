@@ -464,10 +464,24 @@ constexpr int X6P_LDS = (2 + 3) * 3 * X6_PLANE + 2 * X6P_VRAW;       // V planes
 // NPW: producer waves, 4 (one channel octet each) or 8 (half an octet each: two of the octet's four row pairs; the bf16 pieces
 // are then written as 4-byte halves).  A stage waits for the slower of the two chains (tools/x6_probe.py ablate: consumers
 // alone 0.44 ms, everything but the MFMAs 0.43 ms, together 0.57 ms on conv4_2): eight producers halve the latency of theirs.
-template <int ABL, int NCW = 4, int NPW = 4>
-__global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Wino4Args a, const uint4 *__restrict__ Ux, int ptiles, int ktiles) {
+// BG (experiment, SIVO_X6_BGLOBAL=1): the consumers take their U fragments straight from global memory (the U image is
+// stored in fragment order: the 64 pieces of one (cout block, plane) are 1 KiB contiguous), three loads per 16-cout block
+// issued as soon as the block's MFMAs of the current stage are issued — no U DMA, no U bytes through LDS (per stage 24 KB
+// written + 48 KB read of the 176 KB the LDS moves).
+template <int ABL, int NCW = 4, int NPW = 4, bool BG = false>
+__global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Wino4Args a, const uint4 *__restrict__ Ux, int ptiles, int ktiles_prio) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds6[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ktiles_prio: cout blocks | wave priorities << 16 (experiment SIVO_X6_PRIO: bits 0-1 consumers, bits 2-3 producers).
+    // s_setprio ignores EXEC, so the role test is made on a scalar.
+    const int ktiles = ktiles_prio & 0xffff;
+    {
+        const int prio = ktiles_prio >> 16;
+        const int want = __builtin_amdgcn_readfirstlane(tid >> 6) >= NCW ? (prio >> 2) & 3 : prio & 3;
+        if (want == 1) __builtin_amdgcn_s_setprio(1);
+        else if (want == 2) __builtin_amdgcn_s_setprio(2);
+        else if (want == 3) __builtin_amdgcn_s_setprio(3);
+    }
     const int nchunks = a.C / X6_KC;
     // item list of this XCD: pairs xcd, xcd + 8, ... (pair = position * ptiles + tile block), each with its ktiles cout
     // blocks back to back; the workgroups of the XCD (blockIdx.x >> 3 = 0 .. per_xcd - 1) take the items round-robin
@@ -485,7 +499,9 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
     };
     auto Vl = [&](int buf) { return lds6 + 3 * X6_PLANE * buf; };
     auto Ul = [&](int buf) { return lds6 + 3 * X6_PLANE * (2 + buf); };
-    auto Vraw = [&](int buf) { return lds6 + 3 * X6_PLANE * 5 + X6P_VRAW * buf; };
+    // BG: no U stages in LDS, so the raw V rows get a ring of PD + 1 buffers in that space and are requested PD stages ahead
+    constexpr int PD = BG ? 3 : 1, NRAW = PD + 1;
+    auto Vraw = [&](int buf) { return lds6 + 3 * X6_PLANE * (BG ? 2 : 5) + X6P_VRAW * buf; };
 
     if (wave >= NCW) {
         // ------------------------------------------------------------------ producers
@@ -493,7 +509,7 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
         // the U image of the next stage (24 KB, 6 x 1 KiB per wave) and the raw fp32 V rows of the next stage — wave w
         // copies exactly the 8 channel rows it splits itself (4 x 1 KiB), so no producer depends on another one.
         const int w = wave - NCW, vh = lane >> 5, vtq = lane & 31;
-        constexpr int UPW = 24 / NPW, VPW = 16 / NPW;         // 1 KiB DMA pieces per wave and stage: U planes, raw V rows
+        constexpr int UPW = BG ? 0 : 24 / NPW, VPW = 16 / NPW;         // 1 KiB DMA pieces per wave and stage: U planes, raw V rows
         const int oct = NPW == 8 ? w >> 1 : w, ih = NPW == 8 ? (w & 1) : 0;      // channel octet, half of it (row pairs 2 ih, 2 ih + 1)
         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -510,7 +526,7 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
                                                  (__attribute__((address_space(3))) void *)(udst + kib * 1024), 16, 0, 0);
             }
             const float *Vg = a.V + ((int64_t)xi * a.C) * a.Pp + (int64_t)pt * 128;
-            unsigned char *vdst = Vraw(s & 1) + oct * 4096;
+            unsigned char *vdst = Vraw(s % NRAW) + oct * 4096;
             if (!((ABL & 1) && s > 1))
 #pragma unroll
             for (int i = 0; i < VPW; ++i) {
@@ -525,7 +541,7 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
             }
         };
         auto split_stage = [&](int s) {             // raw V rows of this wave -> three bf16 planes of V buffer s & 1
-            const unsigned char *src = Vraw(s & 1) + oct * 4096 + lane * 16;
+            const unsigned char *src = Vraw(s % NRAW) + oct * 4096 + lane * 16;
             f32x4 vr[VPW];
 #pragma unroll
             for (int i = 0; i < VPW; ++i) vr[i] = *reinterpret_cast<const f32x4 *>(src + (VPW * ih + i) * 1024);
@@ -555,16 +571,19 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
                 }
             }
         };
-        issue_stage(0);
+#pragma unroll
+        for (int d = 0; d < PD; ++d)
+            if (d < nstages) issue_stage(d);
         for (int s = 0; s <= nstages; ++s) {
             if (s < nstages) {
-                if (s + 1 < nstages) {
-                    issue_stage(s + 1);                          // lands during the consumers' stage s - 1 .. s
-                    if (ABL & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UPW + VPW) : "memory");   // all but that batch: stage s has landed
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
+                if (s + PD < nstages) issue_stage(s + PD);       // lands during the consumers' stages s - 1 .. s + PD - 1
+                const int younger = nstages - 1 - s < PD ? nstages - 1 - s : PD;       // batches issued behind stage s's
+                // all but those batches: stage s has landed (vector-memory operations complete in issue order)
+                if (ABL & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (UPW + VPW)) : "memory");
+                else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (UPW + VPW)) : "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UPW + VPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (!((ABL & 4) && s > 1)) split_stage(s);
             }
             x6p_barrier();                          // stage s handed to the consumers, stage s - 1's buffers free again
@@ -587,6 +606,81 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
 #pragma unroll
     for (int t = 0; t < NT; ++t) b_off[t] = x6_slot(64 * wn + 4 * li + nh + t, lk) * 16;
     int k_item = 0, chunk = 0;
+    if constexpr (BG) {
+        static_assert(NCW == 4 && !(ABL & 16), "BG: four consumers, no fragment ablation");
+        int kb_item = 0, chunk_b = 0, bxi, bpt, bkt;        // the stage the NEXT U fragment loads belong to
+        item_of(0, bxi, bpt, bkt);
+        bf16x8 bq[NT][3], afr[4][3];
+        auto load_b = [&](int nt) {                 // U fragments of block nt for the stage at the cursor
+            const unsigned char *usrc = reinterpret_cast<const unsigned char *>(Ux + ((int64_t)(bxi * ktiles + bkt) * nchunks + chunk_b) * (3 * 512));
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bq[nt][pl] = *reinterpret_cast<const bf16x8 *>(usrc + pl * X6_PLANE + b_off[nt]);
+        };
+        // the cursor stops at the last stage: the loads are issued unconditionally (in the last stage they fetch that stage
+        // again and nobody uses them), so the loop body is straight-line code and hipcc's vmcnt waits are exact
+        // (behind an `if` every wait degraded to the loads just issued)
+        auto step_b = [&]() {
+            if (chunk_b + 1 == nchunks && kb_item + 1 == my_items) return;
+            if (++chunk_b == nchunks) {
+                chunk_b = 0;
+                item_of(++kb_item, bxi, bpt, bkt);
+            }
+        };
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) load_b(nt);
+        step_b();
+        x6p_barrier();                            // stage 0 ready
+        for (int s = 0; s < nstages; ++s) {
+            const unsigned char *Vs = Vl(s & 1);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) afr[mt][pl] = *reinterpret_cast<const bf16x8 *>(Vs + pl * X6_PLANE + a_off[mt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                // per accumulator the same order of terms as the LDS form: (3,1) (2,2) (1,3) (2,1) (1,2) (1,1)
+#pragma unroll
+                for (int term = 0; term < 6; ++term) {
+                    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[mt][PA[term]], bq[nt][PB[term]], acc[mt][nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // (left alone, the scheduler sinks all twelve loads to the end of the stage)
+                load_b(nt);                       // next stage's fragments of this block: in flight for the rest of the stage
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            step_b();
+            if (++chunk == nchunks) {
+                chunk = 0;
+                int xi, pt, kt;
+                item_of(k_item++, xi, pt, kt);
+                float *Mg = a.M + ((int64_t)xi * a.Kp + (int64_t)kt * 128) * a.Pp + (int64_t)pt * 128;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float *row = Mg + (int64_t)(wn * 64 + 4 * li + nh + nt) * a.Pp + wm * 64 + 4 * lk;
+                    f32x4 y[4];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mt][nt][0]), __float_as_uint(acc[mt][nt][1]), false, false);
+                        const auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mt][nt][2]), __float_as_uint(acc[mt][nt][3]), false, false);
+                        const auto t02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
+                        const auto t13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
+                        y[0][mt] = __uint_as_float(t02[0]); y[2][mt] = __uint_as_float(t02[1]);
+                        y[1][mt] = __uint_as_float(t13[0]); y[3][mt] = __uint_as_float(t13[1]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4 *>(row + 16 * j) = y[j];
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            x6p_barrier();                        // done with stage s; stage s + 1 ready
+        }
+        return;
+    }
     x6p_barrier();                                // stage 0 ready
     bf16x8 bfrag[NT][3], afr[4][3];
     for (int s = 0; s < nstages; ++s) {
@@ -937,7 +1031,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         for (const void *f : {(const void *)wino4_gemm_x6p_kernel<0>, (const void *)wino4_gemm_x6p_kernel<1>, (const void *)wino4_gemm_x6p_kernel<2>,
                               (const void *)wino4_gemm_x6p_kernel<3>, (const void *)wino4_gemm_x6p_kernel<4>, (const void *)wino4_gemm_x6p_kernel<7>,
                               (const void *)wino4_gemm_x6p_kernel<8>, (const void *)wino4_gemm_x6p_kernel<16>, (const void *)wino4_gemm_x6p_kernel<23>,
-                              (const void *)wino4_gemm_x6p_kernel<32>, (const void *)wino4_gemm_x6p_kernel<64>, (const void *)wino4_gemm_x6p_kernel<64, 8>, (const void *)wino4_gemm_x6p_kernel<64, 4, 8>})
+                              (const void *)wino4_gemm_x6p_kernel<32>, (const void *)wino4_gemm_x6p_kernel<64>, (const void *)wino4_gemm_x6p_kernel<64, 8>, (const void *)wino4_gemm_x6p_kernel<64, 4, 8>, (const void *)wino4_gemm_x6p_kernel<64, 4, 4, true>})
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_x6_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS);
         for (const void *f : {(const void *)wino4_gemm_x6_kernel<1>, (const void *)wino4_gemm_x6_kernel<2>, (const void *)wino4_gemm_x6_kernel<4>,
@@ -1005,7 +1099,13 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
                     case 64:
                         if (x6_producers8) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 8>), gp, dim3(768), X6P_LDS, s, a, u6, pt6, kt6);
                         else if (x6_consumers8) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 8>), gp, dim3(768), X6P_LDS, s, a, u6, pt6, kt6);
-                        else hipLaunchKernelGGL(wino4_gemm_x6p_kernel<64>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6);
+                        else {
+                            const char *pe = std::getenv("SIVO_X6_PRIO");          // experiment: wave priorities of the two roles
+                            const char *bg = std::getenv("SIVO_X6_BGLOBAL");       // experiment: U fragments from global memory
+                            const int kt_prio = kt6 | ((pe ? std::atoi(pe) & 15 : 0) << 16);
+                            if (bg && std::atoi(bg) == 1) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, true>), gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt_prio);
+                            else hipLaunchKernelGGL(wino4_gemm_x6p_kernel<64>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt_prio);
+                        }
                         break;
                     case 1: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<1>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
                     case 2: hipLaunchKernelGGL(wino4_gemm_x6p_kernel<2>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt6); break;
