@@ -455,6 +455,7 @@ __device__ __forceinline__ void x6p_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 constexpr int X6P_VRAW = 128 * X6_KC * 4;        // one fp32 V stage as the LDS-DMA leaves it (16 KB)
 constexpr int X6P_LDS = (2 + 3) * 3 * X6_PLANE + 2 * X6P_VRAW;       // V planes x 2, U planes x 3, raw V x 2 = 152 KB
+constexpr int X6P_LDS_SB2 = 4 * 3 * X6_PLANE + 4 * X6P_VRAW;          // BG, SB = 2: V planes x 4, raw V x 4 = 160 KB
 
 // ABL (diagnostics): 1 no V DMA after stage 0, 2 no U DMA after stage 0, 4 no split after stage 0, 8 no MFMAs, 16 operand
 // fragments read from LDS in stage 0 only, 32 no M stores.
@@ -468,7 +469,10 @@ constexpr int X6P_LDS = (2 + 3) * 3 * X6_PLANE + 2 * X6P_VRAW;       // V planes
 // stored in fragment order: the 64 pieces of one (cout block, plane) are 1 KiB contiguous), three loads per 16-cout block
 // issued as soon as the block's MFMAs of the current stage are issued — no U DMA, no U bytes through LDS (per stage 24 KB
 // written + 48 KB read of the 176 KB the LDS moves).
-template <int ABL, int NCW = 4, int NPW = 4, bool BG = false>
+// SB (with BG only, SIVO_X6_BGLOBAL=2): stages per workgroup barrier.  SB = 2: the consumers multiply two stages between
+// barriers while the producers split the next two (four V-plane buffers + the ring of four raw buffers = 160 KB): half as
+// many hand-overs, each covering twice the work of both roles.
+template <int ABL, int NCW = 4, int NPW = 4, bool BG = false, int SB = 1>
 __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Wino4Args a, const uint4 *__restrict__ Ux, int ptiles, int ktiles_prio) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds6[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -500,8 +504,9 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
     auto Vl = [&](int buf) { return lds6 + 3 * X6_PLANE * buf; };
     auto Ul = [&](int buf) { return lds6 + 3 * X6_PLANE * (2 + buf); };
     // BG: no U stages in LDS, so the raw V rows get a ring of PD + 1 buffers in that space and are requested PD stages ahead
-    constexpr int PD = BG ? 3 : 1, NRAW = PD + 1;
-    auto Vraw = [&](int buf) { return lds6 + 3 * X6_PLANE * (BG ? 2 : 5) + X6P_VRAW * buf; };
+    static_assert(SB == 1 || (BG && SB == 2), "SB = 2 needs the LDS the U stages occupy");
+    constexpr int PD = BG ? 3 : 1, NRAW = PD + 1, NVB = 2 * SB;
+    auto Vraw = [&](int buf) { return lds6 + 3 * X6_PLANE * (BG ? NVB : 5) + X6P_VRAW * buf; };
 
     if (wave >= NCW) {
         // ------------------------------------------------------------------ producers
@@ -545,7 +550,7 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
             f32x4 vr[VPW];
 #pragma unroll
             for (int i = 0; i < VPW; ++i) vr[i] = *reinterpret_cast<const f32x4 *>(src + (VPW * ih + i) * 1024);
-            unsigned char *Vb = Vl(s & 1);
+            unsigned char *Vb = Vl(s % NVB);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 __bf16 p1[VPW], p2[VPW], p3[VPW];
@@ -571,6 +576,27 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
                 }
             }
         };
+        if constexpr (SB == 2) {
+            // step f: request the raw rows of stages 2f + 2, 2f + 3 (into the ring slots of 2f - 2, 2f - 1, split in the
+            // previous step), wait for those of 2f, 2f + 1 (requested a step ago), split them, hand over
+            if (0 < nstages) issue_stage(0);
+            if (1 < nstages) issue_stage(1);
+            const int nsteps = (nstages + 1) / 2;
+            for (int f = 0; f <= nsteps; ++f) {
+                if (f < nsteps) {
+                    const int younger = (2 * f + 2 < nstages) + (2 * f + 3 < nstages);
+                    if (2 * f + 2 < nstages) issue_stage(2 * f + 2);
+                    if (2 * f + 3 < nstages) issue_stage(2 * f + 3);
+                    if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * VPW) : "memory");
+                    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VPW) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    split_stage(2 * f);
+                    if (2 * f + 1 < nstages) split_stage(2 * f + 1);
+                }
+                x6p_barrier();
+            }
+            return;
+        }
 #pragma unroll
         for (int d = 0; d < PD; ++d)
             if (d < nstages) issue_stage(d);
@@ -631,7 +657,7 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
         step_b();
         x6p_barrier();                            // stage 0 ready
         for (int s = 0; s < nstages; ++s) {
-            const unsigned char *Vs = Vl(s & 1);
+            const unsigned char *Vs = Vl(s % NVB);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -677,7 +703,7 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            x6p_barrier();                        // done with stage s; stage s + 1 ready
+            if (SB == 1 || (s & 1) || s + 1 == nstages) x6p_barrier();       // done with stage s (and s - 1); the next ones are ready
         }
         return;
     }
@@ -1033,6 +1059,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
                               (const void *)wino4_gemm_x6p_kernel<8>, (const void *)wino4_gemm_x6p_kernel<16>, (const void *)wino4_gemm_x6p_kernel<23>,
                               (const void *)wino4_gemm_x6p_kernel<32>, (const void *)wino4_gemm_x6p_kernel<64>, (const void *)wino4_gemm_x6p_kernel<64, 8>, (const void *)wino4_gemm_x6p_kernel<64, 4, 8>, (const void *)wino4_gemm_x6p_kernel<64, 4, 4, true>})
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS);
+        (void)hipFuncSetAttribute((const void *)wino4_gemm_x6p_kernel<64, 4, 4, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS_SB2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_x6_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS);
         for (const void *f : {(const void *)wino4_gemm_x6_kernel<1>, (const void *)wino4_gemm_x6_kernel<2>, (const void *)wino4_gemm_x6_kernel<4>,
                               (const void *)wino4_gemm_x6_kernel<8>, (const void *)wino4_gemm_x6_kernel<16>, (const void *)wino4_gemm_x6_kernel<7>})
@@ -1103,7 +1130,8 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
                             const char *pe = std::getenv("SIVO_X6_PRIO");          // experiment: wave priorities of the two roles
                             const char *bg = std::getenv("SIVO_X6_BGLOBAL");       // experiment: U fragments from global memory
                             const int kt_prio = kt6 | ((pe ? std::atoi(pe) & 15 : 0) << 16);
-                            if (bg && std::atoi(bg) == 1) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, true>), gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt_prio);
+                            if (bg && std::atoi(bg) == 2) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, true, 2>), gp, dim3(512), X6P_LDS_SB2, s, a, u6, pt6, kt_prio);
+                            else if (bg && std::atoi(bg) == 1) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, true>), gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt_prio);
                             else hipLaunchKernelGGL(wino4_gemm_x6p_kernel<64>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt_prio);
                         }
                         break;
