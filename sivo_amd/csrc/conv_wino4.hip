@@ -472,7 +472,10 @@ constexpr int X6P_LDS_SB2 = 4 * 3 * X6_PLANE + 4 * X6P_VRAW;          // BG, SB 
 // SB (with BG only, SIVO_X6_BGLOBAL=2): stages per workgroup barrier.  SB = 2: the consumers multiply two stages between
 // barriers while the producers split the next two (four V-plane buffers + the ring of four raw buffers = 160 KB): half as
 // many hand-overs, each covering twice the work of both roles.
-template <int ABL, int NCW = 4, int NPW = 4, bool BG = false, int SB = 1>
+// AP (with SB = 2, SIVO_X6_BGLOBAL=3; written at the end of round 2, compiled, NOT yet run on a GPU): the V fragments of an
+// interval's second stage are read under the MFMAs of its first stage (second register set), so only every other stage
+// starts with the twelve ds_read_b128 in front of its first MFMA.
+template <int ABL, int NCW = 4, int NPW = 4, bool BG = false, int SB = 1, bool AP = false>
 __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Wino4Args a, const uint4 *__restrict__ Ux, int ptiles, int ktiles_prio) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds6[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -656,6 +659,72 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
         for (int nt = 0; nt < NT; ++nt) load_b(nt);
         step_b();
         x6p_barrier();                            // stage 0 ready
+        if constexpr (AP) {
+            static_assert(SB == 2, "AP: the second stage of an interval is what can be read early");
+            bf16x8 afr2[4][3];
+            auto read_a = [&](bf16x8 (&fr)[4][3], int st) {
+                const unsigned char *Vs = Vl(st % NVB);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) fr[mt][pl] = *reinterpret_cast<const bf16x8 *>(Vs + pl * X6_PLANE + a_off[mt]);
+            };
+            auto item_end = [&]() {
+                if (++chunk == nchunks) {
+                    chunk = 0;
+                    int xi, pt, kt;
+                    item_of(k_item++, xi, pt, kt);
+                    float *Mg = a.M + ((int64_t)xi * a.Kp + (int64_t)kt * 128) * a.Pp + (int64_t)pt * 128;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        float *row = Mg + (int64_t)(wn * 64 + 4 * li + nh + nt) * a.Pp + wm * 64 + 4 * lk;
+                        f32x4 y[4];
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) {
+                            const auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mt][nt][0]), __float_as_uint(acc[mt][nt][1]), false, false);
+                            const auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mt][nt][2]), __float_as_uint(acc[mt][nt][3]), false, false);
+                            const auto t02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
+                            const auto t13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
+                            y[0][mt] = __uint_as_float(t02[0]); y[2][mt] = __uint_as_float(t02[1]);
+                            y[1][mt] = __uint_as_float(t13[0]); y[3][mt] = __uint_as_float(t13[1]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4 *>(row + 16 * j) = y[j];
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            };
+            // one stage on the fragments fr; early: the OTHER set is filled with the next stage's fragments behind the
+            // first block's MFMAs (an odd stage count reads an unused buffer there, harmlessly)
+            auto stage = [&](bf16x8 (&fr)[4][3], bf16x8 (&other)[4][3], int st, bool early) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                    for (int term = 0; term < 6; ++term) {
+                        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[mt][PA[term]], bq[nt][PB[term]], acc[mt][nt], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_b(nt);
+                    if (nt == 0 && early) read_a(other, st + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                step_b();
+                item_end();
+            };
+            for (int s = 0; s < nstages; s += 2) {
+                read_a(afr, s);
+                stage(afr, afr2, s, true);
+                if (s + 1 < nstages) stage(afr2, afr, s + 1, false);
+                x6p_barrier();                    // done with stages s, s + 1; the next two are ready
+            }
+            return;
+        }
         for (int s = 0; s < nstages; ++s) {
             const unsigned char *Vs = Vl(s % NVB);
 #pragma unroll
@@ -1060,6 +1129,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
                               (const void *)wino4_gemm_x6p_kernel<32>, (const void *)wino4_gemm_x6p_kernel<64>, (const void *)wino4_gemm_x6p_kernel<64, 8>, (const void *)wino4_gemm_x6p_kernel<64, 4, 8>, (const void *)wino4_gemm_x6p_kernel<64, 4, 4, true>})
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS);
         (void)hipFuncSetAttribute((const void *)wino4_gemm_x6p_kernel<64, 4, 4, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS_SB2);
+        (void)hipFuncSetAttribute((const void *)wino4_gemm_x6p_kernel<64, 4, 4, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS_SB2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_x6_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS);
         for (const void *f : {(const void *)wino4_gemm_x6_kernel<1>, (const void *)wino4_gemm_x6_kernel<2>, (const void *)wino4_gemm_x6_kernel<4>,
                               (const void *)wino4_gemm_x6_kernel<8>, (const void *)wino4_gemm_x6_kernel<16>, (const void *)wino4_gemm_x6_kernel<7>})
@@ -1130,7 +1200,8 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
                             const char *pe = std::getenv("SIVO_X6_PRIO");          // experiment: wave priorities of the two roles
                             const char *bg = std::getenv("SIVO_X6_BGLOBAL");       // experiment: U fragments from global memory
                             const int kt_prio = kt6 | ((pe ? std::atoi(pe) & 15 : 0) << 16);
-                            if (bg && std::atoi(bg) == 2) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, true, 2>), gp, dim3(512), X6P_LDS_SB2, s, a, u6, pt6, kt_prio);
+                            if (bg && std::atoi(bg) == 3) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, true, 2, true>), gp, dim3(512), X6P_LDS_SB2, s, a, u6, pt6, kt_prio);
+                            else if (bg && std::atoi(bg) == 2) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, true, 2>), gp, dim3(512), X6P_LDS_SB2, s, a, u6, pt6, kt_prio);
                             else if (bg && std::atoi(bg) == 1) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, true>), gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt_prio);
                             else hipLaunchKernelGGL(wino4_gemm_x6p_kernel<64>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt_prio);
                         }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wave priorities of the two roles of wino4_gemm_x6p_kernel (SIVO_X6_PRIO: bits 0-1 consumers, bits 2-3 producers) and, with
-the argument `bg`, the U fragments taken from global memory instead of LDS (SIVO_X6_BGLOBAL=1; 2: and two stages per barrier): whole-layer
+the argument `bg`, the U fragments taken from global memory instead of LDS (SIVO_X6_BGLOBAL=1; 2: and two stages per barrier; 3: and the second stage's V fragments read early): whole-layer
 times (input transform + GEMM + output transform, sivo_debug_conv) on the GEMM shapes of SegNet-Standard.  GPU box only."""
 import ctypes as C
 import os
@@ -21,7 +21,7 @@ def run(shape, iters=20):
 
 for s in SHAPES.values():
     run(s, 3)
-for label, prio, bg in (("base", 0, 0), ("bg2", 0, 2), ("bg", 0, 1), ("base", 0, 0), ("bg2", 0, 2), ("bg", 0, 1), ("bg2p1", 4, 2)) if "bg" in sys.argv[1:] else \
+for label, prio, bg in (("base", 0, 0), ("bg3", 0, 3), ("bg2", 0, 2), ("bg", 0, 1), ("base", 0, 0), ("bg3", 0, 3), ("bg2", 0, 2), ("bg", 0, 1)) if "bg" in sys.argv[1:] else \
         (("base", 0, 0), ("c1", 1, 0), ("c3", 3, 0), ("p1", 4, 0), ("p2", 8, 0), ("p3", 12, 0), ("c1p2", 9, 0), ("base", 0, 0)):
     os.environ["SIVO_X6_PRIO"] = str(prio)
     os.environ["SIVO_X6_BGLOBAL"] = str(bg)
