@@ -87,6 +87,21 @@ def test_mc_known_answers(oracle):
     assert np.allclose(var, 0.5)                           # sample variance of {1, 0} with n-1
 
 
+def test_argmax_semantics_of_the_reference_eigen_test(oracle):
+    """EigenTests.ArgmaxTest (tests/test_bayesian_segnet.cpp:43-136), the part computeClasses relies on (argmax over
+    dimension 0 of a (15, 352, 1024) tensor): values log(u + 0.5) with u in [0, 1) stay below 0.41, so a planted 10.0 in
+    the first class gives index 0 everywhere, a planted 20.0 in the last class then gives 14 everywhere, and the result has
+    352 * 1024 entries."""
+    rng = np.random.default_rng(5)
+    mean = np.log(rng.random((15, 352, 1024)) + 0.5)
+    mean[0] = 10.0
+    cls, conf, _ = oracle.mc_finalize(mean)
+    assert cls.size == 352 * 1024 and cls.dtype == np.uint8 and (cls == 0).all() and (conf == 10.0).all()
+    mean[14] = 20.0
+    cls, conf, _ = oracle.mc_finalize(mean)
+    assert (cls == 14).all() and (conf == 20.0).all()
+
+
 def test_mean_is_taken_in_f64(oracle):
     p = np.zeros((3, 2, 1, 1), np.float32); p[:, 0] = np.float32(0.1); p[:, 1] = np.float32(0.9)
     mean = oracle.mc_mean(p)
