@@ -453,6 +453,37 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_x6_kernel(Wino4Args a, cons
 // DMA of the stage it hands over with an explicit vmcnt before calling this.
 __device__ __forceinline__ void x6p_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Diagnostic (template flag TS, SIVO_X6_STAMPS=1, read with sivo_debug_x6_stamps): shader-clock cycles every wave spends
+// between its hand-overs (work: everything up to its own LDS operations being done) and inside them (wait: from there until
+// the slowest wave of the workgroup arrives), summed over the waves of a role and over all workgroups since the last reset.
+// [0] consumers work, [1] consumers wait, [2] producers work, [3] producers wait, [4] hand-overs counted (all waves).
+__device__ unsigned long long x6p_stamps[5];
+struct X6pClock {
+    unsigned long long work = 0, wait = 0, last = 0, n = 0;
+};
+template <bool TS>
+__device__ __forceinline__ void x6p_barrier_t(X6pClock &c) {
+    if constexpr (!TS) {
+        x6p_barrier();
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        asm volatile("s_barrier" ::: "memory");
+        const unsigned long long t1 = __builtin_readcyclecounter();
+        c.work += t0 - c.last; c.wait += t1 - t0; c.last = t1; ++c.n;
+    }
+}
+template <bool TS>
+__device__ __forceinline__ void x6p_clock_flush(const X6pClock &c, int role, int lane) {
+    if constexpr (TS) {
+        if (lane == 0) {
+            atomicAdd(&x6p_stamps[2 * role], c.work);
+            atomicAdd(&x6p_stamps[2 * role + 1], c.wait);
+            atomicAdd(&x6p_stamps[4], c.n);
+        }
+    }
+}
+
 constexpr int X6P_VRAW = 128 * X6_KC * 4;        // one fp32 V stage as the LDS-DMA leaves it (16 KB)
 constexpr int X6P_LDS = (2 + 3) * 3 * X6_PLANE + 2 * X6P_VRAW;       // V planes x 2, U planes x 3, raw V x 2 = 152 KB
 constexpr int X6P_LDS_SB2 = 4 * 3 * X6_PLANE + 4 * X6P_VRAW;          // BG, SB = 2: V planes x 4, raw V x 4 = 160 KB
@@ -475,7 +506,7 @@ constexpr int X6P_LDS_SB2 = 4 * 3 * X6_PLANE + 4 * X6P_VRAW;          // BG, SB 
 // AP (with SB = 2, SIVO_X6_BGLOBAL=3; written at the end of round 2, compiled, NOT yet run on a GPU): the V fragments of an
 // interval's second stage are read under the MFMAs of its first stage (second register set), so only every other stage
 // starts with the twelve ds_read_b128 in front of its first MFMA.
-template <int ABL, int NCW = 4, int NPW = 4, bool BG = false, int SB = 1, bool AP = false>
+template <int ABL, int NCW = 4, int NPW = 4, bool BG = false, int SB = 1, bool AP = false, bool TS = false>
 __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Wino4Args a, const uint4 *__restrict__ Ux, int ptiles, int ktiles_prio) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds6[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -600,6 +631,9 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
             }
             return;
         }
+        static_assert(!TS || (!BG && NCW == 4 && NPW == 4), "TS: the production form only");
+        X6pClock clk;
+        if constexpr (TS) clk.last = __builtin_readcyclecounter();
 #pragma unroll
         for (int d = 0; d < PD; ++d)
             if (d < nstages) issue_stage(d);
@@ -615,8 +649,9 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (!((ABL & 4) && s > 1)) split_stage(s);
             }
-            x6p_barrier();                          // stage s handed to the consumers, stage s - 1's buffers free again
+            x6p_barrier_t<TS>(clk);                 // stage s handed to the consumers, stage s - 1's buffers free again
         }
+        x6p_clock_flush<TS>(clk, 1, lane);
         return;
     }
 
@@ -776,7 +811,9 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
         }
         return;
     }
-    x6p_barrier();                                // stage 0 ready
+    X6pClock clk;
+    if constexpr (TS) clk.last = __builtin_readcyclecounter();
+    x6p_barrier_t<TS>(clk);                       // stage 0 ready
     bf16x8 bfrag[NT][3], afr[4][3];
     for (int s = 0; s < nstages; ++s) {
         const unsigned char *Vs = Vl(s & 1), *Us = Ul(s % 3);
@@ -844,7 +881,18 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        x6p_barrier();                            // done with stage s; stage s + 1 ready
+        x6p_barrier_t<TS>(clk);                   // done with stage s; stage s + 1 ready
+    }
+    x6p_clock_flush<TS>(clk, 0, lane);
+}
+
+// per-role cycle totals of the TS form since the last reset (segnet_kernels.hpp)
+void x6p_read_stamps(unsigned long long out[5], bool reset) {
+    SIVO_HIP(hipDeviceSynchronize());
+    SIVO_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(x6p_stamps), 5 * sizeof(unsigned long long)));
+    if (reset) {
+        const unsigned long long zero[5] = {0, 0, 0, 0, 0};
+        SIVO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(x6p_stamps), zero, sizeof zero));
     }
 }
 
@@ -1130,6 +1178,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS);
         (void)hipFuncSetAttribute((const void *)wino4_gemm_x6p_kernel<64, 4, 4, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS_SB2);
         (void)hipFuncSetAttribute((const void *)wino4_gemm_x6p_kernel<64, 4, 4, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS_SB2);
+        (void)hipFuncSetAttribute((const void *)wino4_gemm_x6p_kernel<64, 4, 4, false, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_x6_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS);
         for (const void *f : {(const void *)wino4_gemm_x6_kernel<1>, (const void *)wino4_gemm_x6_kernel<2>, (const void *)wino4_gemm_x6_kernel<4>,
                               (const void *)wino4_gemm_x6_kernel<8>, (const void *)wino4_gemm_x6_kernel<16>, (const void *)wino4_gemm_x6_kernel<7>})
@@ -1200,7 +1249,9 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
                             const char *pe = std::getenv("SIVO_X6_PRIO");          // experiment: wave priorities of the two roles
                             const char *bg = std::getenv("SIVO_X6_BGLOBAL");       // experiment: U fragments from global memory
                             const int kt_prio = kt6 | ((pe ? std::atoi(pe) & 15 : 0) << 16);
-                            if (bg && std::atoi(bg) == 3) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, true, 2, true>), gp, dim3(512), X6P_LDS_SB2, s, a, u6, pt6, kt_prio);
+                            const char *ts = std::getenv("SIVO_X6_STAMPS");        // diagnostic: per-role work / wait cycles (sivo_debug_x6_stamps)
+                            if (ts && std::atoi(ts) == 1) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, false, 1, false, true>), gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt_prio);
+                            else if (bg && std::atoi(bg) == 3) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, true, 2, true>), gp, dim3(512), X6P_LDS_SB2, s, a, u6, pt6, kt_prio);
                             else if (bg && std::atoi(bg) == 2) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, true, 2>), gp, dim3(512), X6P_LDS_SB2, s, a, u6, pt6, kt_prio);
                             else if (bg && std::atoi(bg) == 1) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, true>), gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt_prio);
                             else hipLaunchKernelGGL(wino4_gemm_x6p_kernel<64>, gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt_prio);

@@ -1112,6 +1112,20 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
     });
 }
 
+// Diagnostic: shader-clock cycles the consumer / producer waves of the bf16x6 GEMM spent working and waiting at their
+// hand-overs (launches made with SIVO_X6_STAMPS=1 since the last reset): out = consumers work, consumers wait, producers
+// work, producers wait, hand-overs counted.
+extern "C" int sivo_debug_x6_stamps(uint64_t *out5, int reset) {
+    return guarded([&] {
+        if (!out5) return fail(SIVO_ERR_INVALID_ARGUMENT, "null output");
+        if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device");
+        unsigned long long v[5];
+        x6p_read_stamps(v, reset != 0);
+        for (int i = 0; i < 5; ++i) out5[i] = v[i];
+        return SIVO_OK;
+    });
+}
+
 // Diagnostic: time one convolution shape in isolation (random data), `variant` switches parts of
 // the kernel off (see ConvArgs::variant).  Returns the mean launch time in ms.
 extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, int iters, int variant, double *ms_out) {
