@@ -191,9 +191,10 @@ int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int capacity, 
 int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, int iters, int variant, double *ms_out);
 
 /* Diagnostic: shader-clock cycles the consumer / producer waves of the bf16x6 GEMM spent working and waiting at their
- * hand-overs, summed over the launches made with SIVO_X6_STAMPS=1 since the last reset.  out5 = consumers work, consumers
- * wait, producers work, producers wait, hand-overs counted; reset != 0 clears the counters after reading. */
-int sivo_debug_x6_stamps(uint64_t *out5, int reset);
+ * hand-overs, summed over the launches made with SIVO_X6_STAMPS=1 since the last reset.  out8 = consumers work, consumers
+ * wait, producers work, producers wait, hand-overs counted, then the producers' work split into LDS-DMA issue, vmcnt wait
+ * and V split; reset != 0 clears the counters after reading. */
+int sivo_debug_x6_stamps(uint64_t *out8, int reset);
 
 /* ===========================================================================
  * ORB extractor — stands behind SIVO::ORBextractor

@@ -456,11 +456,24 @@ __device__ __forceinline__ void x6p_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // Diagnostic (template flag TS, SIVO_X6_STAMPS=1, read with sivo_debug_x6_stamps): shader-clock cycles every wave spends
 // between its hand-overs (work: everything up to its own LDS operations being done) and inside them (wait: from there until
 // the slowest wave of the workgroup arrives), summed over the waves of a role and over all workgroups since the last reset.
-// [0] consumers work, [1] consumers wait, [2] producers work, [3] producers wait, [4] hand-overs counted (all waves).
-__device__ unsigned long long x6p_stamps[5];
+// [0] consumers work, [1] consumers wait, [2] producers work, [3] producers wait, [4] hand-overs counted (all waves); the
+// producers' work split further: [5] issuing the LDS-DMA batch, [6] s_waitcnt vmcnt for the stage to land, [7] the split
+// (LDS reads, conversions, LDS stores, until lgkmcnt(0)).
+__device__ unsigned long long x6p_stamps[8];
 struct X6pClock {
-    unsigned long long work = 0, wait = 0, last = 0, n = 0;
+    unsigned long long work = 0, wait = 0, last = 0, n = 0, issue = 0, vmwait = 0, split = 0;
 };
+template <bool TS>
+__device__ __forceinline__ unsigned long long x6p_now() {
+    if constexpr (TS) {
+        asm volatile("" ::: "memory");
+        const unsigned long long t = __builtin_readcyclecounter();
+        asm volatile("" ::: "memory");
+        return t;
+    } else {
+        return 0;
+    }
+}
 template <bool TS>
 __device__ __forceinline__ void x6p_barrier_t(X6pClock &c) {
     if constexpr (!TS) {
@@ -480,6 +493,11 @@ __device__ __forceinline__ void x6p_clock_flush(const X6pClock &c, int role, int
             atomicAdd(&x6p_stamps[2 * role], c.work);
             atomicAdd(&x6p_stamps[2 * role + 1], c.wait);
             atomicAdd(&x6p_stamps[4], c.n);
+            if (role == 1) {
+                atomicAdd(&x6p_stamps[5], c.issue);
+                atomicAdd(&x6p_stamps[6], c.vmwait);
+                atomicAdd(&x6p_stamps[7], c.split);
+            }
         }
     }
 }
@@ -506,7 +524,10 @@ constexpr int X6P_LDS_SB2 = 4 * 3 * X6_PLANE + 4 * X6P_VRAW;          // BG, SB 
 // AP (with SB = 2, SIVO_X6_BGLOBAL=3; written at the end of round 2, compiled, NOT yet run on a GPU): the V fragments of an
 // interval's second stage are read under the MFMAs of its first stage (second register set), so only every other stage
 // starts with the twelve ds_read_b128 in front of its first MFMA.
-template <int ABL, int NCW = 4, int NPW = 4, bool BG = false, int SB = 1, bool AP = false, bool TS = false>
+// A2 (SIVO_X6_AFRAG=1; compiled, not yet run): the V fragments of the four MFMA blocks of a stage in four register sets, all
+// twelve read at the top of the stage — instead of one set refilled immediately in front of each block's first MFMA
+// (four exposed LDS latencies per stage).
+template <int ABL, int NCW = 4, int NPW = 4, bool BG = false, int SB = 1, bool AP = false, bool TS = false, bool A2 = false>
 __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Wino4Args a, const uint4 *__restrict__ Ux, int ptiles, int ktiles_prio) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds6[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -639,7 +660,9 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
             if (d < nstages) issue_stage(d);
         for (int s = 0; s <= nstages; ++s) {
             if (s < nstages) {
+                const unsigned long long ta = x6p_now<TS>();
                 if (s + PD < nstages) issue_stage(s + PD);       // lands during the consumers' stages s - 1 .. s + PD - 1
+                const unsigned long long tb = x6p_now<TS>();
                 const int younger = nstages - 1 - s < PD ? nstages - 1 - s : PD;       // batches issued behind stage s's
                 // all but those batches: stage s has landed (vector-memory operations complete in issue order)
                 if (ABL & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -647,7 +670,13 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
                 else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (UPW + VPW)) : "memory");
                 else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UPW + VPW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long tc = x6p_now<TS>();
                 if (!((ABL & 4) && s > 1)) split_stage(s);
+                if constexpr (TS) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const unsigned long long td = x6p_now<TS>();
+                    clk.issue += tb - ta; clk.vmwait += tc - tb; clk.split += td - tc;
+                }
             }
             x6p_barrier_t<TS>(clk);                 // stage s handed to the consumers, stage s - 1's buffers free again
         }
@@ -823,13 +852,20 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) bfrag[nt][pl] = *reinterpret_cast<const bf16x8 *>(Us + pl * X6_PLANE + b_off[nt]);
         }
+        if constexpr (A2) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) afr[mt][pl] = *reinterpret_cast<const bf16x8 *>(Vs + pl * X6_PLANE + a_off[mt]);
+            __builtin_amdgcn_sched_barrier(0);      // (left alone, the scheduler sinks every read back in front of its first use)
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            if (!(ABL & 16) || s == 0) {
+            if (!A2 && (!(ABL & 16) || s == 0)) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) afr[(ABL & 16) ? mt : 0][pl] = *reinterpret_cast<const bf16x8 *>(Vs + pl * X6_PLANE + a_off[mt]);
             }
-            const bf16x8 *af = afr[(ABL & 16) ? mt : 0];
+            const bf16x8 *af = afr[(A2 || (ABL & 16)) ? mt : 0];
             // smallest terms first: (3,1) (2,2) (1,3) (2,1) (1,2) (1,1)
 #pragma unroll
             for (int term = 0; term < 6; ++term) {
@@ -887,11 +923,11 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void wino4_gemm_x6p_kernel(Win
 }
 
 // per-role cycle totals of the TS form since the last reset (segnet_kernels.hpp)
-void x6p_read_stamps(unsigned long long out[5], bool reset) {
+void x6p_read_stamps(unsigned long long out[8], bool reset) {
     SIVO_HIP(hipDeviceSynchronize());
-    SIVO_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(x6p_stamps), 5 * sizeof(unsigned long long)));
+    SIVO_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(x6p_stamps), 8 * sizeof(unsigned long long)));
     if (reset) {
-        const unsigned long long zero[5] = {0, 0, 0, 0, 0};
+        const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         SIVO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(x6p_stamps), zero, sizeof zero));
     }
 }
@@ -1179,6 +1215,8 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         (void)hipFuncSetAttribute((const void *)wino4_gemm_x6p_kernel<64, 4, 4, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS_SB2);
         (void)hipFuncSetAttribute((const void *)wino4_gemm_x6p_kernel<64, 4, 4, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS_SB2);
         (void)hipFuncSetAttribute((const void *)wino4_gemm_x6p_kernel<64, 4, 4, false, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS);
+        (void)hipFuncSetAttribute((const void *)wino4_gemm_x6p_kernel<64, 4, 4, false, 1, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS);
+        (void)hipFuncSetAttribute((const void *)wino4_gemm_x6p_kernel<64, 4, 4, false, 1, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X6P_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_x6_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS);
         for (const void *f : {(const void *)wino4_gemm_x6_kernel<1>, (const void *)wino4_gemm_x6_kernel<2>, (const void *)wino4_gemm_x6_kernel<4>,
                               (const void *)wino4_gemm_x6_kernel<8>, (const void *)wino4_gemm_x6_kernel<16>, (const void *)wino4_gemm_x6_kernel<7>})
@@ -1250,7 +1288,11 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
                             const char *bg = std::getenv("SIVO_X6_BGLOBAL");       // experiment: U fragments from global memory
                             const int kt_prio = kt6 | ((pe ? std::atoi(pe) & 15 : 0) << 16);
                             const char *ts = std::getenv("SIVO_X6_STAMPS");        // diagnostic: per-role work / wait cycles (sivo_debug_x6_stamps)
-                            if (ts && std::atoi(ts) == 1) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, false, 1, false, true>), gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt_prio);
+                            const char *a2 = std::getenv("SIVO_X6_AFRAG");         // experiment: four V-fragment register sets
+                            const bool a2on = a2 && std::atoi(a2) == 1;
+                            if (ts && std::atoi(ts) == 1 && a2on) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, false, 1, false, true, true>), gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt_prio);
+                            else if (ts && std::atoi(ts) == 1) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, false, 1, false, true>), gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt_prio);
+                            else if (a2on) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, false, 1, false, false, true>), gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt_prio);
                             else if (bg && std::atoi(bg) == 3) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, true, 2, true>), gp, dim3(512), X6P_LDS_SB2, s, a, u6, pt6, kt_prio);
                             else if (bg && std::atoi(bg) == 2) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, true, 2>), gp, dim3(512), X6P_LDS_SB2, s, a, u6, pt6, kt_prio);
                             else if (bg && std::atoi(bg) == 1) hipLaunchKernelGGL((wino4_gemm_x6p_kernel<64, 4, 4, true>), gp, dim3(512), X6P_LDS, s, a, u6, pt6, kt_prio);

@@ -1114,14 +1114,14 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
 
 // Diagnostic: shader-clock cycles the consumer / producer waves of the bf16x6 GEMM spent working and waiting at their
 // hand-overs (launches made with SIVO_X6_STAMPS=1 since the last reset): out = consumers work, consumers wait, producers
-// work, producers wait, hand-overs counted.
-extern "C" int sivo_debug_x6_stamps(uint64_t *out5, int reset) {
+// work, producers wait, hand-overs counted, and the producers' work split into DMA issue, vmcnt wait, V split.
+extern "C" int sivo_debug_x6_stamps(uint64_t *out8, int reset) {
     return guarded([&] {
-        if (!out5) return fail(SIVO_ERR_INVALID_ARGUMENT, "null output");
+        if (!out8) return fail(SIVO_ERR_INVALID_ARGUMENT, "null output");
         if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device");
-        unsigned long long v[5];
+        unsigned long long v[8];
         x6p_read_stamps(v, reset != 0);
-        for (int i = 0; i < 5; ++i) out5[i] = v[i];
+        for (int i = 0; i < 8; ++i) out8[i] = v[i];
         return SIVO_OK;
     });
 }

@@ -56,7 +56,7 @@ void wino4_pack_weights(const float *W, int cin, int cout, std::vector<float> &o
 int wino4_group(int N, int cin, int cout, int H, int W, size_t budget_bytes);
 // bf16x6 GEMM (fp32 operands split into three bf16 planes, six products, fp32 accumulate)
 bool wino4_x6_supported(int cin, int cout_pad);
-void x6p_read_stamps(unsigned long long out[5], bool reset);       // diagnostic counters of wino4_gemm_x6p_kernel<..., TS = true>
+void x6p_read_stamps(unsigned long long out[8], bool reset);       // diagnostic counters of wino4_gemm_x6p_kernel<..., TS = true>
 void wino4_x6_pack_weights(const std::vector<float> &U, int cin, int cout_pad, std::vector<uint16_t> &out);
 size_t wino4_workspace_floats(int group, int cin, int cout, int H, int W);
 // direct 7x7, 64 -> 64, on the bf16 matrix cores with fp32 operands as three bf16 planes (conv7_x6.hip); weights in ConvArgs::wt_x6
