@@ -311,64 +311,34 @@ def main():
                 torch.empty((H, W), dtype=torch.float64, device="cuda"))
     maps = new_maps()
     do_orb = (rank == 0) and not args.no_orb
-    if do_orb:
-        ex_l, ex_r = orb.ORBextractor(device=local), orb.ORBextractor(device=local)
     stats = {"kps": 0, "matches": 0}
-
-    # Frame.cc:126-129 runs two extractor threads; here they also overlap the network on the GPU, and a third task matches
-    # EVERY left keypoint (candidates, Hamming, SAD refinement) while the network still runs; only the median cull of
-    # ComputeStereoMatches needs the class map (sivo_stereo_match_begin / _cull).  The three workers are long-lived (a pool
-    # created once): starting three Python threads per frame cost 0.5 ms before the network was even enqueued
-    # (tools/frame_timeline.py), and the network is enqueued FIRST so that the GPU never waits for the host side of ORB.
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=3) if do_orb else None
-
+    # Frame.cc:125-174 on the device (sivo_amd/frame.py): the network is enqueued FIRST, the two extractors and the matching of
+    # every left key run beside it, the semantic filter + median cull wait for the class map
+    from sivo_amd.frame import StereoFramePipeline
     orb_delay = float(os.environ.get("SIVO_BENCH_ORB_DELAY_MS", "0")) * 1e-3       # experiment: start ORB this long after the network
+    fp = StereoFramePipeline(device=local, start_delay_s=orb_delay) if do_orb else None
     tail_probe = [] if os.environ.get("SIVO_BENCH_TAIL_PROBE") else None         # experiment: host time of the cull behind the class map
 
-    def orb_extract(res):
-        def run(k, ex, im):
-            if orb_delay > 0:
-                time.sleep(orb_delay)
-            res[k] = ex(im)
-        fl = pool.submit(run, "l", ex_l, d_left)
-        fr = pool.submit(run, "r", ex_r, d_right)
-
-        def match():
-            fl.result(); fr.result()
-            (kl, dl), (kr, dr) = res["l"], res["r"]
-            res["m"] = orb.stereo_match_begin(ex_l, ex_r, kl, dl, kr, dr, 386.1448, 386.1448 / 718.856)
-        return [pool.submit(match)]
-
-    def orb_finish(res, cls_host):
-        kl = res["l"][0]
-        uR, depth, _, sad = res["m"]
-        # SelectSemanticKeys (Frame.cc:177-203): class <= TERRAIN(8) at the truncated keypoint position
-        keep = cls_host[kl["y"].astype(np.int32), kl["x"].astype(np.int32)] <= 8
-        orb.stereo_match_cull(keep, sad, uR, depth)
-        stats["kps"], stats["matches"] = int(keep.sum()), int((uR >= 0).sum())
-
     def frame(seed):
-        res = {}
         if world == 1:
             # one device holds all T samples: segmentImage on device-resident data (f64 mean, no probability sum in memory)
             sn.segment_into(d_bgr, seed, maps)           # asynchronous: ~65 launches enqueued in ~0.5 ms
-            th = orb_extract(res) if do_orb else []      # ORB of this frame runs beside the network
+            pending = fp.start_orb(d_left, d_right) if do_orb else None      # ORB of this frame runs beside the network
         else:
             if n_local:
                 sn.forward_into(d_bgr, seed, prob_sum, n_samples=n_local, sample0=sample0)
             else:
                 prob_sum.zero_()                           # more ranks than samples: contribute nothing
-            th = orb_extract(res) if do_orb else []
+            pending = fp.start_orb(d_left, d_right) if do_orb else None
             parallel.all_reduce_prob_sum(prob_sum)
             sn.finalize(prob_sum, t_total=T, out=maps)
         if do_orb:
             cls_host = maps[0].cpu().numpy()              # 360 KB D2H; waits for this frame's class map
-            [t.result() for t in th]
+            t0 = time.perf_counter()
+            r = fp.finish(pending, cls_host)
             if tail_probe is not None:
-                t0 = time.perf_counter(); orb_finish(res, cls_host); tail_probe.append(time.perf_counter() - t0)
-            else:
-                orb_finish(res, cls_host)
+                tail_probe.append(time.perf_counter() - t0)
+            stats["kps"], stats["matches"] = r["semantic_keys"], r["stereo_matches"]
 
     def barrier():
         torch.cuda.synchronize()

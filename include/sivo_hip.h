@@ -190,11 +190,23 @@ int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int capacity, 
  * parts of the kernel off to attribute time (0 = the production kernel).  Mean launch ms out. */
 int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, int iters, int variant, double *ms_out);
 
-/* Diagnostic: shader-clock cycles the consumer / producer waves of the bf16x6 GEMM spent working and waiting at their
- * hand-overs, summed over the launches made with SIVO_X6_STAMPS=1 since the last reset.  out8 = consumers work, consumers
- * wait, producers work, producers wait, hand-overs counted, then the producers' work split into LDS-DMA issue, vmcnt wait
- * and V split; reset != 0 clears the counters after reading. */
-int sivo_debug_x6_stamps(uint64_t *out8, int reset);
+/* The GEMM the F(4x4,3x3) layers of the handle run: *mode = 2 f16x3 (fp32 operands as fp16 hi + lo planes, three
+ * products: the default), 1 bf16x6 (three bf16 planes, six products: SIVO_GEMM=x6, and every handle after a frame
+ * raised the fp16 overflow flag), 0 fp32 MFMA (SIVO_GEMM=f32) or no such layer.  *overflow_frames = frames in which a
+ * transformed value left the fp16 range since the handle was created; sivo_segnet_segment recomputes such a frame on the
+ * bf16x6 path before it returns, the asynchronous *_dev entry points cannot: after one of them check this count.
+ * per_layer (optional): one row per f16x3-capable layer with the calibration frame's largest |V| and the powers of two
+ * chosen for V and U; *n_layers = rows available. */
+typedef struct SivoH3Layer {
+    char layer[48];
+    float vmax, vscale, uscale;
+} SivoH3Layer;
+int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow_frames, SivoH3Layer *per_layer, int capacity, int *n_layers);
+
+/* Diagnostic / test: the f16x3 GEMM alone on host operands.  V [36][C][Pp] fp32 (Pp = P rounded up to 128), U [36][C][Kp]
+ * fp32, M [36][Kp][Pp] out (fp32, scales multiplied back out); C % 32 == 0, Kp % 128 == 0.  iters > 0: mean launch time
+ * (ms) of `iters` further launches in *ms_out. */
+int sivo_debug_h3_gemm(int C, int Kp, int P, const float *V, const float *U, float vscale, float *M, int iters, double *ms_out);
 
 /* ===========================================================================
  * ORB extractor — stands behind SIVO::ORBextractor

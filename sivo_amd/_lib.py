@@ -83,7 +83,8 @@ SIGNATURES = {
     "sivo_segnet_profile": [_vp, _i],
     "sivo_segnet_profile_read": [_vp, _vp, _i, _pi32],
     "sivo_debug_conv": [_i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_d)],
-    "sivo_debug_x6_stamps": [C.POINTER(C.c_uint64), _i],
+    "sivo_segnet_gemm_status": [_vp, _pi32, _pi32, _vp, _i, _pi32],
+    "sivo_debug_h3_gemm": [_i, _i, _i, _vp, _vp, _f, _vp, _i, C.POINTER(_d)],
     "sivo_orb_create": [_i, _f, _i, _i, _i, _i, C.POINTER(_vp)],
     "sivo_orb_destroy": [_vp],
     "sivo_orb_tables": [_vp, _vp, _vp, _vp, _vp, _vp],

@@ -1,0 +1,328 @@
+// conv_wino4_h3.hip — the batched GEMM of the three-kernel F(4x4,3x3) path on the fp16 matrix cores: "f16x3".
+//
+//   M_xi[k][p] = sum_c U_xi[c][k] * V_xi[c][p]      36 independent GEMMs, fp32 in / fp32 out (conv_wino4.hip)
+//
+// An fp32 value x (scaled by a power of two so that it sits well inside the fp16 range) is hi + lo with hi = fp16(x),
+// lo = fp16(x - hi), exact to 2^-22 |x|; a product of two fp16 values is exact in fp32.  So
+//     v u  =  v_lo u_hi + v_hi u_lo + v_hi u_hi  +  O(2^-22 |v u|)
+// is THREE v_mfma_f32_32x32x16_f16 per 16 channels with fp32 accumulation — half the matrix-core work of the bf16x6 form
+// (three bf16 planes, six products) at the same accuracy: emulated on Winograd-domain data (K = 512) the rms error is
+// 1.9e-7 relative against 2.4e-7 for bf16x6 and 4.0e-7 for the sequential fp32 FMA chain (fewer roundings of the
+// accumulator).  What fp16 does not have is bf16's range: the transform kernels therefore write V already multiplied by a
+// per-layer power of two chosen at load time (calibration frame, 2^8 of headroom to 65504, an overflow flag that sends the
+// frame to the bf16x6 path), the weights are scaled per layer on the host, and the output transform multiplies the two
+// powers back out inside its per-channel affine — all exact.
+//
+// Data.  V' [36][C][Pp] has the layout the transform kernels always wrote, with 4-byte elements that are now the pair
+// (hi | lo << 16) instead of one fp32: no extra HBM bytes, no split in this kernel.  U' is split once on the host and
+// stored as the LDS image of its stages.  M stays fp32 [36][Kp][Pp].
+//
+// Kernel.  One persistent 512-thread workgroup per CU walks (position, tile group, cout group) items in an XCD-aware
+// order; workgroup tile BM tiles x BN couts (256 x 256; 128 x 256 for launches with few tiles; 256 x 128 for Kp = 128),
+// 8 waves = 2 per SIMD, wave tile (BM / WT) tiles x 64 couts as 32 x 32 MFMA blocks (128 / 64 accumulator registers).
+// A stage is 32 channels: 2 k-steps of v_mfma_f32_32x32x16_f16, 48 (24) MFMAs per wave against 24 (16) ds_read_b128.
+// Staging, two LDS buffers of (BM + BN) * 128 bytes, ONE barrier per stage:
+//   * U': LDS-DMA issued in inline assembly (lds_dma.hpp: invisible to hipcc's waitcnt pass), 1 KiB pieces that are
+//     already in fragment order — the 64 lanes of a ds_read_b128 read 1 KiB contiguous;
+//   * V': every lane loads the 8 (16) channel values of its tile with buffer loads (row offset in an SGPR, no address
+//     arithmetic), de-interleaves hi and lo with v_perm_b32 (one per register) and writes the two fragment pieces of a
+//     channel octet with ds_write_b128 — one stage behind the loads, right after the barrier ("write late, re-issue at
+//     once"): the loads of stage s + 2 and the DMA of stage s + 1 are in flight while stage s is multiplied.
+// Fragment order = [32-row block][plane][channel octet][row]: every ds_read_b128 / ds_write_b128 touches consecutive
+// 16-byte pieces in lane order, conflict-free without any swizzle.
+// C/D mapping of the 32 x 32 MFMA: column = lane & 31 = tile, so one accumulator register of a wave is two 128-byte
+// runs of M; rows = couts.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+#include "lds_dma.hpp"
+#include "segnet_kernels.hpp"
+
+namespace sivo {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int H3_KC = 32;                    // channels per stage
+
+struct H3Args {
+    const uint32_t *V;       // packed (hi | lo << 16) [36][C][Pp]
+    const unsigned char *U;  // [36][Kp / 32][C / 32][plane][octet][row][8] fp16
+    float *M;                // [36][Kp][Pp]
+    int C, Kp, P, Pp;
+    int ptiles, ktiles;      // tile groups (BM) and cout groups (BN) of the launch
+};
+
+// LDS-DMA with a scalar base: lane l copies the 16 bytes at sbase + voff to LDS address lds_byte_addr + 16 l.
+__device__ __forceinline__ void h3_dma16(const void *sbase, uint32_t voff, uint32_t lds_byte_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
+                 : "memory");
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_h3[];
+    constexpr int WT = BN == 256 ? 2 : 4, WC = 8 / WT;          // wave grid: tiles x couts (64 couts per wave)
+    constexpr int TB = BM / WT / 32;                             // 32-tile MFMA blocks per wave (4 or 2); 2 cout blocks
+    constexpr int VBYTES = BM * 128, UBYTES = BN * 128, STAGE = VBYTES + UBYTES;
+    constexpr int NQ = BM / 128;                                 // channel octets each lane stages per stage (2 or 1)
+    constexpr int NU = BN / 64;                                  // 1 KiB U pieces each wave copies per stage (4 or 2)
+    static_assert(BM == 256 || BM == 128, "tile");
+    static_assert(BN == 256 || BN == 128, "tile");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 31, lh = lane >> 5;
+    const int nst = a.C / H3_KC;
+
+    // items of this XCD: a contiguous range of the (position, tile group, cout group) list (cout groups of one V tile
+    // adjacent, positions in order: U_xi stays in this L2 while the XCD works through its tile groups); the workgroups of
+    // the XCD take them round-robin
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int per_pos = a.ptiles * a.ktiles, nitems = 36 * per_pos;
+    const int lo_it = (int)(((int64_t)nitems * xcd) >> 3), hi_it = (int)(((int64_t)nitems * (xcd + 1)) >> 3);
+    if (lo_it + wg >= hi_it) return;
+    const int my_items = (hi_it - lo_it - wg + per_xcd - 1) / per_xcd;
+    const int total = my_items * nst;
+
+    struct Cursor {          // a stage = (item, chunk); everything here is wave-uniform
+        int k = 0, chunk = 0, xi = 0, pt = 0, kt = 0;
+    };
+    auto locate = [&](Cursor &c) {
+        const int it = lo_it + wg + c.k * per_xcd;
+        c.xi = it / per_pos;
+        const int rem = it - c.xi * per_pos;
+        c.pt = rem / a.ktiles;
+        c.kt = rem - c.pt * a.ktiles;
+    };
+    auto advance = [&](Cursor &c) {
+        if (++c.chunk == nst) {
+            c.chunk = 0;
+            if (++c.k < my_items) locate(c);
+        }
+    };
+
+    // ---- V' staging: lane (tile ln of tile block vtb, octets vo0 + 2 q + lh) -------------------------------------------
+    const int vtb = BM == 256 ? wave : wave >> 1, vo0 = BM == 256 ? 0 : 2 * (wave & 1);
+    const uint32_t v_lane_off = (uint32_t)(((int64_t)(8 * (vo0 + lh)) * a.Pp + vtb * 32 + ln) * 4);
+    const uint32_t v_slab_bytes = (uint32_t)((int64_t)a.C * a.Pp * 4);
+    uint32_t vraw[NQ][8];
+    auto load_v = [&](const Cursor &c) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.V) + (int64_t)c.xi * a.C * a.Pp, 0, (int)v_slab_bytes, 0x00020000);
+        const uint32_t vo = v_lane_off + (uint32_t)c.pt * (BM * 4);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t so = (uint32_t)((int64_t)(c.chunk * H3_KC + 16 * q + e) * a.Pp * 4);
+                vraw[q][e] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0);
+            }
+    };
+    const uint32_t v_lds_off = (uint32_t)(vtb * 4096 + (vo0 + lh) * 512 + ln * 16);
+    auto write_v = [&](int buf) {
+        unsigned char *dst = lds_h3 + buf * STAGE + v_lds_off;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            u32x4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hi[j] = __builtin_amdgcn_perm(vraw[q][2 * j + 1], vraw[q][2 * j], 0x05040100u);
+                lo[j] = __builtin_amdgcn_perm(vraw[q][2 * j + 1], vraw[q][2 * j], 0x07060302u);
+            }
+            *reinterpret_cast<u32x4 *>(dst + q * 1024) = hi;
+            *reinterpret_cast<u32x4 *>(dst + q * 1024 + 2048) = lo;
+        }
+    };
+
+    // ---- U' staging: piece g = wave * NU + j of the stage: cout block g >> 2, quarter g & 3 ------------------------------
+    const uint32_t lds_base = lds_addr_uniform(lds_h3);
+    uint32_t u_voff[NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        const int g = wave * NU + j;
+        u_voff[j] = (uint32_t)((g >> 2) * nst * 4096 + (g & 3) * 1024 + lane * 16);
+    }
+    auto dma_u = [&](const Cursor &c, int buf) {
+        const unsigned char *sb = a.U + ((int64_t)(c.xi * (a.Kp / 32) + c.kt * (BN / 32)) * nst + c.chunk) * 4096;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) h3_dma16(sb, u_voff[j], lds_base + buf * STAGE + VBYTES + (wave * NU + j) * 1024);
+    };
+
+    // ---- MFMA phase ----------------------------------------------------------------------------------------------------
+    const int wc = wave % WC, wt = wave / WC;
+    f32x16 acc[2][TB];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < TB; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
+    const uint32_t a_off = (uint32_t)(VBYTES + wc * 2 * 4096 + lane * 16), b_off = (uint32_t)(wt * TB * 4096 + lane * 16);
+
+    Cursor cc, cu, cv;          // compute, U DMA (one stage ahead), V' loads (two stages ahead)
+    locate(cc);
+    cu = cc; cv = cc;
+    load_v(cv); advance(cv);
+    dma_u(cu, 0); advance(cu);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    write_v(0);
+    if (1 < total) { load_v(cv); advance(cv); }
+
+    for (int s = 0; s < total; ++s) {
+        const int cur = s & 1;
+        // stage s: its V' pieces were written by every wave one iteration ago (lgkmcnt), its U' pieces have landed (vmcnt);
+        // behind the barrier nobody reads buffer cur ^ 1 (stage s - 1) any more
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s + 1 < total) {
+            write_v(cur ^ 1);                                   // V'(s + 1): loaded during stage s - 1
+            if (s + 2 < total) { load_v(cv); advance(cv); }    // V'(s + 2) into the same registers
+            dma_u(cu, cur ^ 1); advance(cu);                    // U'(s + 1)
+        }
+        const unsigned char *st = lds_h3 + cur * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 A[2][2], B[TB][2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) A[c][pl] = *reinterpret_cast<const half8 *>(st + a_off + c * 4096 + pl * 2048 + kk * 1024);
+#pragma unroll
+            for (int t = 0; t < TB; ++t)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) B[t][pl] = *reinterpret_cast<const half8 *>(st + b_off + t * 4096 + pl * 2048 + kk * 1024);
+            // smallest terms first: (lo, hi) (hi, lo) (hi, hi); consecutive MFMAs on different accumulators
+#pragma unroll
+            for (int term = 0; term < 3; ++term) {
+                constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int t = 0; t < TB; ++t)
+                        acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][PA[term]], B[t][PB[term]], acc[c][t], 0, 0, 0);
+            }
+        }
+        if (++cc.chunk == nst) {
+            // item done: accumulator register r of block (c, t) is M[cout 32 (2 wc + c) + 8 (r >> 2) + 4 lh + (r & 3)][tile 32 (TB wt + t) + ln]
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.M + (int64_t)cc.xi * a.Kp * a.Pp, 0, (int)((int64_t)a.Kp * a.Pp * 4), 0x00020000);
+            const uint32_t vo = (uint32_t)(((int64_t)(4 * lh) * a.Pp + ln) * 4);
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                const int p0 = cc.pt * BM + (wt * TB + t) * 32;
+                if (p0 < a.Pp) {          // (a tile group may reach beyond the padded tile count: nothing to store there)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int k = cc.kt * BN + (2 * wc + c) * 32 + 8 * (r >> 2) + (r & 3);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[c][t][r]), rs, vo, (uint32_t)(((int64_t)k * a.Pp + p0) * 4), 0);
+                        }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int t = 0; t < TB; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
+            cc.chunk = 0;
+            if (++cc.k < my_items) locate(cc);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+bool wino4_h3_supported(int cin, int cout_pad) { return cin % H3_KC == 0 && cout_pad % 128 == 0; }
+
+static inline uint16_t f16_rne_bits(float x) {
+    const _Float16 h = (_Float16)x;
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    return b;
+}
+static inline float f16_bits_to_float(uint16_t b) {
+    _Float16 h;
+    std::memcpy(&h, &b, 2);
+    return (float)h;
+}
+
+// packed (hi | lo << 16) of x * scale — what the transform kernels write (host mirror, for tests and sivo_debug_h3_gemm)
+uint32_t wino4_h3_pack_value(float x, float scale) {
+    const float xs = x * scale;
+    const uint16_t hi = f16_rne_bits(xs);
+    const uint16_t lo = f16_rne_bits(xs - f16_bits_to_float(hi));
+    return (uint32_t)hi | ((uint32_t)lo << 16);
+}
+
+// U [36][Cin][Kp] fp32 -> fp16 hi / lo planes in stage order; returns the power of two the values were multiplied by
+// (max |U| * scale in [2^7, 2^8): 2^8 of headroom, full hi / lo precision down to max / 2^10)
+float wino4_h3_pack_weights(const std::vector<float> &U, int cin, int Kp, std::vector<uint16_t> &out) {
+    float umax = 0.f;
+    for (float v : U) umax = std::fmax(umax, std::fabs(v));
+    int e = 0;
+    if (umax > 0.f) (void)std::frexp(umax, &e);          // umax = m 2^e, m in [0.5, 1)
+    const float scale = std::ldexp(1.f, 8 - e);
+    const int nst = cin / H3_KC, ncb = Kp / 32;
+    out.assign((size_t)36 * ncb * nst * 2048, 0);
+    for (int xi = 0; xi < 36; ++xi)
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int s = 0; s < nst; ++s) {
+                uint16_t *img = out.data() + ((size_t)(xi * ncb + cb) * nst + s) * 2048;
+                for (int o = 0; o < 4; ++o)
+                    for (int r = 0; r < 32; ++r)
+                        for (int el = 0; el < 8; ++el) {
+                            const float x = U[((size_t)xi * cin + s * H3_KC + 8 * o + el) * Kp + cb * 32 + r];
+                            const uint32_t p = wino4_h3_pack_value(x, scale);
+                            const size_t at = (size_t)(o * 32 + r) * 8 + el;
+                            img[at] = (uint16_t)(p & 0xffffu);
+                            img[1024 + at] = (uint16_t)(p >> 16);
+                        }
+            }
+    return scale;
+}
+
+// tile choice: 256 x 256 by default; 128-tile groups when the launch would otherwise give the CUs fewer than ~3 items
+// each (the 22 x 64 layers: 360 items of 256 tiles against 648 of 128); 256 x 128 when the layer has 128 couts
+static int h3_config(int64_t P, int Kp) {
+    if (Kp % 256) return 2;
+    const int64_t items256 = 36 * ((P + 255) / 256) * (Kp / 256);
+    return items256 >= 3 * 256 ? 0 : 1;
+}
+
+void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int Kp, int P, int Pp, hipStream_t s) {
+    static int attr_set[64] = {0};
+    if (FirstUse once(attr_set); once) {
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<256, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128));
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<128, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 256) * 128));
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<256, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 128));
+    }
+    static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
+    const dim3 grid((unsigned)((n_cu / 8) * 8 > 0 ? (n_cu / 8) * 8 : 8));      // one persistent workgroup per CU, a multiple of the 8 XCDs
+    H3Args a{};
+    a.V = V; a.U = static_cast<const unsigned char *>(U); a.M = M; a.C = C; a.Kp = Kp; a.P = P; a.Pp = Pp;
+    switch (h3_config(P, Kp)) {
+        case 0:
+            a.ptiles = (P + 255) / 256; a.ktiles = Kp / 256;
+            hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256>), grid, dim3(512), 2 * (256 + 256) * 128, s, a);
+            break;
+        case 1:
+            a.ptiles = (P + 127) / 128; a.ktiles = Kp / 256;
+            hipLaunchKernelGGL((wino4_gemm_h3_kernel<128, 256>), grid, dim3(512), 2 * (128 + 256) * 128, s, a);
+            break;
+        default:
+            a.ptiles = (P + 255) / 256; a.ktiles = Kp / 128;
+            hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 128>), grid, dim3(512), 2 * (256 + 128) * 128, s, a);
+    }
+}
+
+}  // namespace sivo

@@ -55,6 +55,11 @@ struct Op {
     float *d_w = nullptr, *d_scale = nullptr, *d_shift = nullptr;
     size_t w_off = 0;          // offset of the layer's Caffe weights in the flat parameter array
     void *d_wx6 = nullptr;     // wino4: the transformed weights as three bf16 planes (bf16x6 GEMM); null = fp32 MFMA GEMM
+    void *d_wh3 = nullptr;     // wino4: the transformed weights as fp16 hi / lo planes times h3_uscale (f16x3 GEMM, the default)
+    float h3_uscale = 1.f;     // power of two
+    float h3_vscale = 0.f;     // power of two the layer's transformed input is multiplied with (set by the calibration pass; 0 = not calibrated)
+    float h3_vmax = 0.f;       // largest |V| of the calibration frame
+    int bridge_to = -1;        // w4_bridge: the op whose transformed input this layer's bridge kernel writes
     float *d_w_mc = nullptr;   // classifier: second copy of the weights in the layout of conv_cls_mc.hip (fused with the MC post-processing)
     bool mc_fused_last = false;   // profiling: the last timed launch of this op was the fused kernel
     bool relu = false;
@@ -115,6 +120,13 @@ struct sivo_segnet {
     int ws_lanes = 1;               // workspace regions allocated
     hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};      // [0] unused: lane 0 is the caller's stream
     hipEvent_t lane_fork = nullptr, lane_join[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    // f16x3 GEMM state (conv_wino4_h3.hip).  h3_on: the F(4x4) layers with fp16 weight planes and a calibrated V scale run
+    // the f16x3 GEMM; cleared for good when a frame raised the overflow flag (a transformed value left the fp16 range: the
+    // bf16x6 GEMM has fp32's range).  h3_flag: one word of pinned host memory the transform kernels store 1 into.
+    bool h3_on = false, calibrating = false;
+    volatile uint32_t *h3_flag = nullptr;
+    uint32_t *d_h3_vmax = nullptr;  // calibration: one word per op (bit pattern of the largest |V|)
+    int h3_overflow_frames = 0;     // frames that raised the flag (each was recomputed on the bf16x6 path when the entry point is synchronous)
     float *d_wino4_ws = nullptr;    // V + M workspace shared by every F(4x4,3x3) layer (one region per lane)
     size_t wino4_ws_floats = 0;
     size_t wino4_slot_floats = 0;   // three rotating slots (V, M, next V) for layers that run all samples in one pass
@@ -125,6 +137,7 @@ struct sivo_segnet {
             if (op.ev1) (void)hipEventDestroy(op.ev1);
         }
         for (void *p : owned) (void)hipFree(p);
+        if (h3_flag) (void)hipHostFree(const_cast<uint32_t *>(h3_flag));
         if (stream) (void)hipStreamDestroy(stream);
         for (int l = 0; l < MAX_LANES; ++l) {
             if (lane_stream[l]) (void)hipStreamDestroy(lane_stream[l]);
@@ -204,13 +217,24 @@ void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int 
     } else if (op.wino4) {
         wino4_pack_weights(W, cin, cout, wt, &op.cout_pad);
         // SIVO_GEMM=f32 keeps the batched GEMM on the fp32 matrix-core instructions; default: bf16x6 (conv_wino4.hip)
-        static const bool gemm_f32 = std::getenv("SIVO_GEMM") && std::string(std::getenv("SIVO_GEMM")) == "f32";
+        const bool gemm_f32 = std::getenv("SIVO_GEMM") && std::string(std::getenv("SIVO_GEMM")) == "f32";
         if (!gemm_f32 && wino4_x6_supported(cin, op.cout_pad)) {
             std::vector<uint16_t> planes;
             wino4_x6_pack_weights(wt, cin, op.cout_pad, planes);
             op.d_wx6 = dev_alloc<uint16_t>(planes.size());
             S.owned.push_back(op.d_wx6);
             SIVO_HIP(hipMemcpy(op.d_wx6, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
+        // SIVO_GEMM=x6 / f32 keep the bf16x6 / fp32 GEMM; default: f16x3 (conv_wino4_h3.hip), with the bf16 planes resident
+        // as well: they run the calibration pass and any frame whose values leave the fp16 range
+        const bool gemm_x6 = std::getenv("SIVO_GEMM") && std::string(std::getenv("SIVO_GEMM")) == "x6";      // (read per handle: tests build both)
+        const bool gemm_f32_now = std::getenv("SIVO_GEMM") && std::string(std::getenv("SIVO_GEMM")) == "f32";
+        if (!gemm_x6 && !gemm_f32_now && wino4_h3_supported(cin, op.cout_pad)) {
+            std::vector<uint16_t> planes;
+            op.h3_uscale = wino4_h3_pack_weights(wt, cin, op.cout_pad, planes);
+            op.d_wh3 = dev_alloc<uint16_t>(planes.size());
+            S.owned.push_back(op.d_wh3);
+            SIVO_HIP(hipMemcpy(op.d_wh3, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         }
         op.wino4_group = wino4_group(S.T, cin, cout, H, Wd, wino4_budget);
         S.wino4_ws_floats = std::max(S.wino4_ws_floats, wino4_workspace_floats(op.wino4_group, cin, cout, H, Wd));
@@ -256,6 +280,8 @@ void fold_bn(Op &op, const float *scale, const float *shift) {
     SIVO_HIP(hipMemcpy(op.d_scale, s0.data(), op.cout * sizeof(float), hipMemcpyHostToDevice));
     SIVO_HIP(hipMemcpy(op.d_shift, b0.data(), op.cout * sizeof(float), hipMemcpyHostToDevice));
 }
+
+void calibrate_h3(sivo_segnet &S);
 
 std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const float *weights, size_t n_weights,
                                    int device) {
@@ -462,6 +488,7 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
         if (bn.shared != bo.shared || bn.H != bo.H || bn.W != bo.W || B->wino4_group < N) continue;
         if (wino4_bridge_lds_bytes(bo.H, bo.W) > 150 * 1024) continue;
         A.w4_bridge = true; B->w4_bridged_in = true;
+        A.bridge_to = (int)(B - S.ops.data());
         S.blobs[A.out].fused_away = true;
     }
     if (S.wino4_slot_floats) S.wino4_ws_floats = std::max(S.wino4_ws_floats, 3 * S.wino4_slot_floats);
@@ -518,7 +545,93 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
     for (void *p : {(void *)S.d_image, (void *)S.d_prob_sum, (void *)S.d_classes, (void *)S.d_conf, (void *)S.d_ent})
         S.owned.push_back(p);
     SIVO_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    calibrate_h3(S);
     return Sp;
+}
+
+// The transform kernels of an f16x3 layer store 1 into the pinned flag word when a value times the layer's scale leaves
+// the fp16 range.  The frame that raised it is wrong (inf / NaN in that layer); from then on the handle runs those layers
+// on the bf16x6 GEMM, which has fp32's range.  Synchronous entry points recompute the frame before they return.
+bool h3_tripped(sivo_segnet &S) {
+    if (!S.h3_flag || !*S.h3_flag) return false;
+    *S.h3_flag = 0;
+    S.h3_on = false;
+    ++S.h3_overflow_frames;
+    return true;
+}
+
+// Deterministic frame for the calibration pass: rectangles of random colour over a gradient plus per-pixel noise — edges,
+// flat regions and texture, i.e. high-frequency content at least as strong as a camera frame's (the F(4x4) input transform
+// amplifies exactly that), independent of anything but the network geometry.
+std::vector<uint8_t> calibration_frame(int H, int W) {
+    std::vector<uint8_t> img((size_t)H * W * 3);
+    uint32_t st = 0x51f0u;
+    auto rnd = [&] { st = st * 1664525u + 1013904223u; return st >> 8; };
+    std::vector<int> acc((size_t)H * W * 3);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            for (int c = 0; c < 3; ++c) acc[((size_t)y * W + x) * 3 + c] = 40 + (c == 0 ? 120 * y / H : c == 1 ? 120 * x / W : 60);
+    for (int r = 0; r < 40; ++r) {
+        const int x0 = (int)(rnd() % (uint32_t)W), y0 = (int)(rnd() % (uint32_t)H);
+        const int w = 8 + (int)(rnd() % (uint32_t)(W / 3 + 1)), h = 8 + (int)(rnd() % (uint32_t)(H / 2 + 1));
+        const int col[3] = {(int)(rnd() % 256u), (int)(rnd() % 256u), (int)(rnd() % 256u)};
+        for (int y = y0; y < std::min(H, y0 + h); ++y)
+            for (int x = x0; x < std::min(W, x0 + w); ++x)
+                for (int c = 0; c < 3; ++c) acc[((size_t)y * W + x) * 3 + c] = col[c];
+    }
+    for (size_t i = 0; i < acc.size(); ++i) {
+        const int v = acc[i] + (int)(rnd() % 25u) - 12;
+        img[i] = (uint8_t)std::min(255, std::max(0, v));
+    }
+    return img;
+}
+
+struct McTargets;
+void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t seed, float *d_prob_sum, float *d_logits,
+             float *d_prob, hipStream_t st, const McTargets *mc = nullptr);
+
+// f16x3 GEMM: per-layer power-of-two scale of the transformed input, from one pass of the calibration frame (one MC
+// sample, fixed seed, bf16x6 GEMM) whose transform kernels record each layer's largest |V|.  The largest value is put at
+// [2^7, 2^8): 2^8 of headroom below fp16's 65504 for frames with larger activations, full hi + lo precision (2^-22) down
+// to 2^-10 of the maximum and an absolute error of 2^-25 below that.  The scales depend on the weights and the network
+// geometry only — not on T, the device or the frames seen — so every handle of one model computes identical bits.
+// SIVO_H3_BOOST=k multiplies the scales by 2^k (tests: k = 9 forces the overflow path).
+void calibrate_h3(sivo_segnet &S) {
+    bool any = false;
+    for (const Op &op : S.ops) any = any || op.d_wh3;
+    if (!any) return;
+    uint32_t *flag = nullptr;
+    SIVO_HIP(hipHostMalloc((void **)&flag, 64, hipHostMallocDefault));
+    *flag = 0;
+    S.h3_flag = flag;
+    S.d_h3_vmax = dev_alloc<uint32_t>(S.ops.size());
+    S.owned.push_back(S.d_h3_vmax);
+    SIVO_HIP(hipMemset(S.d_h3_vmax, 0, S.ops.size() * sizeof(uint32_t)));
+    const std::vector<uint8_t> img = calibration_frame(S.H, S.W);
+    SIVO_HIP(hipMemcpy(S.d_image, img.data(), img.size(), hipMemcpyHostToDevice));
+    S.calibrating = true;
+    try {
+        forward(S, S.d_image, 1, 0, 0x5157ca11b8a7e5ull, S.d_prob_sum, nullptr, nullptr, S.stream, nullptr);
+        SIVO_HIP(hipStreamSynchronize(S.stream));
+    } catch (...) {
+        S.calibrating = false;
+        throw;
+    }
+    S.calibrating = false;
+    std::vector<uint32_t> bits(S.ops.size());
+    SIVO_HIP(hipMemcpy(bits.data(), S.d_h3_vmax, bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const int boost = std::getenv("SIVO_H3_BOOST") ? std::atoi(std::getenv("SIVO_H3_BOOST")) : 0;
+    for (size_t i = 0; i < S.ops.size(); ++i) {
+        Op &op = S.ops[i];
+        if (!op.d_wh3) continue;
+        float v;
+        std::memcpy(&v, &bits[i], 4);
+        op.h3_vmax = v;
+        int e = 0;
+        if (v > 0.f && std::isfinite(v)) (void)std::frexp(v, &e);        // v = m 2^e, m in [0.5, 1)
+        op.h3_vscale = std::ldexp(1.f, (v > 0.f && std::isfinite(v) ? 8 - e : 0) + boost);
+    }
+    S.h3_on = true;
 }
 
 void harvest(sivo_segnet &S) {
@@ -574,6 +687,12 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                 a.N = N; a.Cin = op.cin; a.H = bi.H; a.W = bi.W; a.Cout = op.cout; a.CoutPad = op.cout_pad;
                 a.relu = op.relu; a.drop_site = op.drop_site; a.sample0 = sample0; a.seed = seed;
                 a.wt_x6 = op.d_wx6;
+                const auto h3_active = [&](const Op &o) { return S.h3_on && !S.calibrating && o.d_wh3 && o.h3_vscale > 0.f; };
+                if (op.wino4) {
+                    if (h3_active(op)) { a.wt_h3 = op.d_wh3; a.h3_vscale = op.h3_vscale; a.h3_uscale = op.h3_uscale; }
+                    a.h3_flag = const_cast<uint32_t *>(S.h3_flag);
+                    if (S.calibrating && S.d_h3_vmax && !op.w4_bridged_in) a.vmax = S.d_h3_vmax + oi;
+                }
                 if (op.pool_op >= 0) {
                     const Op &P = S.ops[op.pool_op];
                     a.pool_out = fptr(S.blobs[P.out]); a.pool_mask = mptr(S.blobs[P.out2]); a.pool_drop_site = P.drop_site;
@@ -610,7 +729,12 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                         plan.M = ws + (size_t)((w4_vslot + 1) % 3) * S.wino4_slot_floats;
                         plan.Vnext = ws + (size_t)((w4_vslot + 2) % 3) * S.wino4_slot_floats;
                         plan.skip_input = op.w4_bridged_in; plan.bridge = op.w4_bridge;
-                        if (op.w4_bridge) w4_vslot = (w4_vslot + 2) % 3;
+                        if (op.w4_bridge) {
+                            w4_vslot = (w4_vslot + 2) % 3;
+                            const Op &next = S.ops[op.bridge_to];
+                            plan.next_vscale = h3_active(next) ? next.h3_vscale : 0.f;
+                            plan.next_vmax = S.calibrating && S.d_h3_vmax ? S.d_h3_vmax + op.bridge_to : nullptr;
+                        }
                     }
                     launch_conv_wino4(a, ws, op.wino4_group, st, sub, S.profile_mfma_only, planned ? &plan : nullptr);
                 }
@@ -666,9 +790,10 @@ struct McTargets {
 // conv_cls_mc.hip supports and neither the per-sample probabilities nor (outside mc) the logits are asked for, that
 // convolution, the Softmax and the reduction over the samples are ONE kernel and the logits blob is not written.
 void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t seed, float *d_prob_sum,
-             float *d_logits, float *d_prob, hipStream_t st, const McTargets *mc = nullptr) {
+             float *d_logits, float *d_prob, hipStream_t st, const McTargets *mc) {
     const int64_t hw = (int64_t)S.H * S.W;
     if (S.profile) harvest(S);
+    (void)h3_tripped(S);        // an earlier (asynchronous) frame left the fp16 range: bf16x6 from here on
     const Blob &lg = S.blobs[S.logits_blob];
     if (lg.shared) throw std::runtime_error("the network has no test-time dropout: nothing to sample");
     launch_preprocess(d_bgr, (float *)S.blobs[S.input_blob].d, hw, st);
@@ -970,12 +1095,15 @@ extern "C" int sivo_segnet_segment(sivo_segnet_t h, const uint8_t *bgr, int rows
         SIVO_HIP(hipMemcpy2DAsync(h->d_image, (size_t)h->W * 3, bgr + ((size_t)y_tl * cols + x_tl) * 3, (size_t)cols * 3,
                                   (size_t)h->W * 3, (size_t)h->H, hipMemcpyHostToDevice, st));
         const McTargets mc{h->d_classes, h->d_conf, h->d_ent, nullptr};
-        forward(*h, h->d_image, h->T, 0, seed, nullptr, nullptr, nullptr, st, &mc);
         const int64_t hw = (int64_t)h->H * h->W;
-        if (classes) SIVO_HIP(hipMemcpyAsync(classes, h->d_classes, hw, hipMemcpyDeviceToHost, st));
-        if (confidence) SIVO_HIP(hipMemcpyAsync(confidence, h->d_conf, hw * sizeof(double), hipMemcpyDeviceToHost, st));
-        if (entropy) SIVO_HIP(hipMemcpyAsync(entropy, h->d_ent, hw * sizeof(double), hipMemcpyDeviceToHost, st));
-        SIVO_HIP(hipStreamSynchronize(st));
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            forward(*h, h->d_image, h->T, 0, seed, nullptr, nullptr, nullptr, st, &mc);
+            if (classes) SIVO_HIP(hipMemcpyAsync(classes, h->d_classes, hw, hipMemcpyDeviceToHost, st));
+            if (confidence) SIVO_HIP(hipMemcpyAsync(confidence, h->d_conf, hw * sizeof(double), hipMemcpyDeviceToHost, st));
+            if (entropy) SIVO_HIP(hipMemcpyAsync(entropy, h->d_ent, hw * sizeof(double), hipMemcpyDeviceToHost, st));
+            SIVO_HIP(hipStreamSynchronize(st));
+            if (!h3_tripped(*h)) break;       // a value left the fp16 range in this frame: once more, on the bf16x6 GEMM
+        }
         return SIVO_OK;
     });
 }
@@ -1075,7 +1203,8 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
         for (size_t i = 0; i < h->ops.size(); ++i) {
             const Op &op = h->ops[i];
             if (op.wino4) {
-                const char *kn[3] = {"wino4_input_kernel", op.d_wx6 ? ((std::getenv("SIVO_X6") && std::string(std::getenv("SIVO_X6")) == "flat") ? "wino4_gemm_x6_kernel" : "wino4_gemm_x6p_kernel") : "wino4_gemm_kernel", op.w4_bridge ? "wino4_bridge_kernel" : "wino4_output_kernel"};
+                const bool h3 = h->h3_on && op.d_wh3 && op.h3_vscale > 0.f;
+                const char *kn[3] = {"wino4_input_kernel", h3 ? "wino4_gemm_h3_kernel" : op.d_wx6 ? "wino4_gemm_x6p_kernel" : "wino4_gemm_kernel", op.w4_bridge ? "wino4_bridge_kernel" : "wino4_output_kernel"};
                 const Blob &bi = h->blobs[op.in];
                 const double tiles = (double)((bi.H + 3) / 4) * (bi.W / 4), kp = wino4_cout_pad(op.cout);
                 const double bytes[3] = {4.0 * (op.cin * (double)bi.H * bi.W + 36.0 * op.cin * tiles),
@@ -1112,16 +1241,76 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
     });
 }
 
-// Diagnostic: shader-clock cycles the consumer / producer waves of the bf16x6 GEMM spent working and waiting at their
-// hand-overs (launches made with SIVO_X6_STAMPS=1 since the last reset): out = consumers work, consumers wait, producers
-// work, producers wait, hand-overs counted, and the producers' work split into DMA issue, vmcnt wait, V split.
-extern "C" int sivo_debug_x6_stamps(uint64_t *out8, int reset) {
+// Which GEMM the F(4x4,3x3) layers of this handle run (2 = f16x3, 1 = bf16x6, 0 = fp32 MFMA / none) and how many frames
+// raised the fp16 overflow flag since the handle was created (the first one switched the handle to bf16x6 for good).
+// per_layer (optional, capacity rows): layer name, largest |V| of the calibration frame and the scale chosen.
+extern "C" int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow_frames, SivoH3Layer *per_layer, int capacity, int *n_layers) {
     return guarded([&] {
-        if (!out8) return fail(SIVO_ERR_INVALID_ARGUMENT, "null output");
+        if (!h) throw std::invalid_argument("null handle");
+        if (h->multi) throw std::invalid_argument("per-device state: query the handles of a multi-device handle one by one");
+        DeviceGuard dg(h->device);
+        (void)h3_tripped(*h);
+        bool any_h3 = false, any_x6 = false;
+        int rows = 0;
+        for (const Op &op : h->ops) {
+            if (!op.wino4) continue;
+            any_h3 = any_h3 || (op.d_wh3 && op.h3_vscale > 0.f);
+            any_x6 = any_x6 || op.d_wx6;
+            if (op.d_wh3) {
+                if (per_layer && rows < capacity) {
+                    SivoH3Layer &r = per_layer[rows];
+                    std::memset(&r, 0, sizeof r);
+                    std::snprintf(r.layer, sizeof r.layer, "%s", op.name.c_str());
+                    r.vmax = op.h3_vmax; r.vscale = op.h3_vscale; r.uscale = op.h3_uscale;
+                }
+                ++rows;
+            }
+        }
+        if (mode) *mode = (h->h3_on && any_h3) ? 2 : any_x6 ? 1 : 0;
+        if (overflow_frames) *overflow_frames = h->h3_overflow_frames;
+        if (n_layers) *n_layers = rows;
+        return SIVO_OK;
+    });
+}
+
+// Diagnostic / test: the f16x3 GEMM alone.  V [36][C][Pp] and U [36][C][Kp] fp32 on the host (Pp = P rounded up to 128),
+// M [36][Kp][Pp] out; V is packed with vscale, U with the scale wino4_h3_pack_weights chooses, M is scaled back.  iters > 0:
+// mean launch time in *ms_out.
+extern "C" int sivo_debug_h3_gemm(int C, int Kp, int P, const float *V, const float *U, float vscale, float *M, int iters, double *ms_out) {
+    return guarded([&] {
         if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device");
-        unsigned long long v[8];
-        x6p_read_stamps(v, reset != 0);
-        for (int i = 0; i < 8; ++i) out8[i] = v[i];
+        if (!V || !U || !M || !wino4_h3_supported(C, Kp) || P < 1 || !(vscale > 0.f)) throw std::invalid_argument("bad argument");
+        const int64_t Pp = ((int64_t)P + 127) / 128 * 128;
+        const size_t nv = (size_t)36 * C * Pp, nm = (size_t)36 * Kp * Pp;
+        std::vector<uint32_t> vp(nv);
+        for (size_t i = 0; i < nv; ++i) vp[i] = wino4_h3_pack_value(V[i], vscale);
+        std::vector<uint16_t> planes;
+        const float uscale = wino4_h3_pack_weights(std::vector<float>(U, U + (size_t)36 * C * Kp), C, Kp, planes);
+        uint32_t *dv = dev_alloc<uint32_t>(nv);
+        uint16_t *du = dev_alloc<uint16_t>(planes.size());
+        float *dm = dev_alloc<float>(nm);
+        SIVO_HIP(hipMemcpy(dv, vp.data(), nv * 4, hipMemcpyHostToDevice));
+        SIVO_HIP(hipMemcpy(du, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+        SIVO_HIP(hipMemset(dm, 0xff, nm * 4));
+        launch_wino4_gemm_h3(dv, du, dm, C, Kp, P, (int)Pp, nullptr);
+        SIVO_HIP(hipDeviceSynchronize());
+        if (iters > 0 && ms_out) {
+            hipEvent_t e0, e1;
+            SIVO_HIP(hipEventCreate(&e0)); SIVO_HIP(hipEventCreate(&e1));
+            SIVO_HIP(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < iters; ++i) launch_wino4_gemm_h3(dv, du, dm, C, Kp, P, (int)Pp, nullptr);
+            SIVO_HIP(hipEventRecord(e1, nullptr));
+            SIVO_HIP(hipEventSynchronize(e1));
+            float ms = 0;
+            SIVO_HIP(hipEventElapsedTime(&ms, e0, e1));
+            *ms_out = ms / iters;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        }
+        std::vector<float> hm(nm);
+        SIVO_HIP(hipMemcpy(hm.data(), dm, nm * 4, hipMemcpyDeviceToHost));
+        const float inv = 1.f / (vscale * uscale);
+        for (size_t i = 0; i < nm; ++i) M[i] = hm[i] * inv;
+        (void)hipFree(dv); (void)hipFree(du); (void)hipFree(dm);
         return SIVO_OK;
     });
 }

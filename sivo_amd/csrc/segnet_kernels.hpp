@@ -31,6 +31,13 @@ struct ConvArgs {
     uint8_t *pool_mask = nullptr;
     int pool_drop_site = -1;
     const void *wt_x6 = nullptr;   // F(4x4,3x3) three-kernel path: the weights split into three bf16 planes (bf16x6 GEMM), or null
+    // f16x3 GEMM (conv_wino4_h3.hip): the weights as fp16 hi / lo planes scaled by h3_uscale, the power of two this layer's
+    // transformed input is multiplied with before it is split (0 = run the layer on the bf16x6 / fp32 GEMM), the flag an
+    // out-of-range value raises, and (calibration passes) where the layer's largest |V| is recorded
+    const void *wt_h3 = nullptr;
+    float h3_vscale = 0.f, h3_uscale = 1.f;
+    uint32_t *h3_flag = nullptr;
+    uint32_t *vmax = nullptr;
     int variant;               // diagnostics only (sivo_debug_conv): bit0 no epilogue stores, bit1 no LDS commit, bit2 no global loads
 };
 int conv_cout_tile(int ks, int cout);  // BN the launcher will pick (CoutPad must be a multiple)
@@ -56,9 +63,13 @@ void wino4_pack_weights(const float *W, int cin, int cout, std::vector<float> &o
 int wino4_group(int N, int cin, int cout, int H, int W, size_t budget_bytes);
 // bf16x6 GEMM (fp32 operands split into three bf16 planes, six products, fp32 accumulate)
 bool wino4_x6_supported(int cin, int cout_pad);
-void x6p_read_stamps(unsigned long long out[8], bool reset);       // diagnostic counters of wino4_gemm_x6p_kernel<..., TS = true>
 void wino4_x6_pack_weights(const std::vector<float> &U, int cin, int cout_pad, std::vector<uint16_t> &out);
 size_t wino4_workspace_floats(int group, int cin, int cout, int H, int W);
+// f16x3 GEMM (fp32 operands as fp16 hi + lo, three products, fp32 accumulate; conv_wino4_h3.hip)
+bool wino4_h3_supported(int cin, int cout_pad);
+float wino4_h3_pack_weights(const std::vector<float> &U, int cin, int cout_pad, std::vector<uint16_t> &out);   // returns the scale applied
+uint32_t wino4_h3_pack_value(float x, float scale);
+void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int Kp, int P, int Pp, hipStream_t s);
 // direct 7x7, 64 -> 64, on the bf16 matrix cores with fp32 operands as three bf16 planes (conv7_x6.hip); weights in ConvArgs::wt_x6
 bool conv7_x6_supported(int ks, int cin, int cout, int H, int W);
 void conv7_x6_pack_weights(const float *W, int cin, int cout, std::vector<uint16_t> &out);
@@ -95,6 +106,8 @@ struct Wino4Plan {
     float *V, *M, *Vnext;    // disjoint buffers: this layer's transformed input, its GEMM output, the next layer's input
     bool skip_input;         // V was written by the previous layer's bridge
     bool bridge;             // fuse the output transform with the next layer's input transform (writes Vnext, not `out`)
+    float next_vscale = 0.f; // bridge: > 0 when the next layer runs the f16x3 GEMM (Vnext is written as packed fp16 pairs)
+    uint32_t *next_vmax = nullptr;   // bridge, calibration passes: where the next layer's largest |V| is recorded
 };
 size_t wino4_bridge_lds_bytes(int H, int W);
 void launch_conv_wino4(const ConvArgs &a, float *workspace, int group, hipStream_t s, hipEvent_t *stage_events = nullptr,

@@ -158,12 +158,39 @@ class BayesianSegNet:
                      kernel_launches=a.kernel_launches)
                 for a in arr]
 
+    def gemm_status(self):
+        """(mode, overflow_frames, layers): mode 2 = f16x3 GEMM in the F(4x4,3x3) layers (default), 1 = bf16x6, 0 = fp32 MFMA /
+        none; overflow_frames = frames in which a transformed value left the fp16 range (the handle switched to bf16x6);
+        layers = [(name, largest |V| of the calibration frame, V scale, U scale)]."""
+        class _Row(C.Structure):
+            _fields_ = [("layer", C.c_char * 48), ("vmax", C.c_float), ("vscale", C.c_float), ("uscale", C.c_float)]
+        mode, ov, n = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().sivo_segnet_gemm_status(self._h, C.byref(mode), C.byref(ov), None, 0, C.byref(n)))
+        rows = (_Row * max(n.value, 1))()
+        check(lib().sivo_segnet_gemm_status(self._h, C.byref(mode), C.byref(ov), rows, n.value, C.byref(n)))
+        return mode.value, ov.value, [(r.layer.decode(), r.vmax, r.vscale, r.uscale) for r in rows[:n.value]]
+
     def blob(self, name):
         shape = (C.c_int32 * 4)()
         check(lib().sivo_segnet_blob(self._h, name.encode(), None, 0, shape))
         out = np.empty(tuple(shape), np.float32)
         check(lib().sivo_segnet_blob(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), out.size, shape))
         return out
+
+
+def h3_gemm(V, U, P, vscale=None, iters=0):
+    """The f16x3 GEMM of the F(4x4,3x3) path alone (sivo_debug_h3_gemm): V (36, C, Pp) and U (36, C, Kp) fp32 numpy arrays,
+    Pp = P rounded up to 128.  Returns (M (36, Kp, Pp) fp32, mean launch ms or None)."""
+    V = np.ascontiguousarray(V, np.float32); U = np.ascontiguousarray(U, np.float32)
+    Cc, Pp, Kp = V.shape[1], V.shape[2], U.shape[2]
+    assert V.shape[0] == 36 and U.shape[:2] == (36, Cc) and Pp == (P + 127) // 128 * 128
+    if vscale is None:
+        vscale = float(2.0 ** (8 - np.frexp(float(np.abs(V).max()))[1]))
+    M = np.empty((36, Kp, Pp), np.float32)
+    ms = C.c_double(0)
+    check(lib().sivo_debug_h3_gemm(Cc, Kp, P, V.ctypes.data_as(C.c_void_p), U.ctypes.data_as(C.c_void_p), C.c_float(vscale),
+                                   M.ctypes.data_as(C.c_void_p), iters, C.byref(ms)))
+    return M, (ms.value if iters else None)
 
 
 def mc_reduce(logits, prob_sum=None, want_prob=False, accumulate=False):

@@ -465,3 +465,75 @@ def test_multi_device_handle_on_one_device(oracle, kitti_like_bgr):
         multi.forward(torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda"), 1)
     with pytest.raises(ValueError):
         BayesianSegNet(prototxt=text, weights=wts.pack(net["layers"], w), T=T, devices=[0, 0])
+
+
+def _make_env(text, T, seed, **env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return _make(text, T, seed=seed)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("H,W,width", [(44, 128, 128), (22, 64, 256), (9, 12, 512)])
+def test_f4x4_gemm_forms_agree(oracle, H, W, width):
+    """The three GEMMs of the three-kernel F(4x4,3x3) path on the same layers: f16x3 (default: fp16 hi + lo planes, three
+    products), bf16x6 (SIVO_GEMM=x6) and the fp32 MFMA kernel (SIVO_GEMM=f32).  Each against the oracle within the logit
+    tolerance, the split forms against the fp32 form much closer than that (the split is not the error, the F(4x4)
+    transforms are); gemm_status names the form and reports the calibrated scales."""
+    T = 3
+    text = _conv_stack_prototxt(T, H, W, width)
+    img_np = _image(np.random.default_rng(H * W + width), H, W)
+    img = torch.from_numpy(img_np).cuda()
+    lg = {}
+    for form, env in (("h3", {}), ("x6", {"SIVO_GEMM": "x6"}), ("f32", {"SIVO_GEMM": "f32"})):
+        net, w, sn = _make_env(text, T, 5, **env)
+        _, l, _ = sn.forward(img, 77, sample0=1, want_logits=True)
+        torch.cuda.synchronize()
+        lg[form] = l.cpu().numpy()
+        mode, overflow, layers = sn.gemm_status()
+        assert (mode, overflow) == ({"h3": 2, "x6": 1, "f32": 0}[form], 0)
+        if form == "h3":
+            assert [n for n, *_ in layers] == ["c1", "c2"]
+            for _, vmax, vscale, uscale in layers:
+                assert vmax > 0 and 128 <= vmax * vscale < 256 and np.log2(vscale) % 1 == 0 and np.log2(uscale) % 1 == 0
+    res = oracle.segment(net, w, img_np, 77, sample0=1, logits_name="cls")
+    for form in lg:
+        err = np.abs(lg[form] - res["logits"]).max()
+        print(f"[{H}x{W}x{width} {form}] max|dlogit| vs oracle {err:.2e}; vs fp32 GEMM {np.abs(lg[form] - lg['f32']).max():.2e}")
+        assert err < LOGIT_TOL
+    assert np.abs(lg["h3"] - lg["f32"]).max() < 1e-4 and np.abs(lg["x6"] - lg["f32"]).max() < 1e-4
+
+
+def test_fp16_overflow_sends_the_frame_to_the_bf16x6_gemm(oracle):
+    """A transformed value that leaves the fp16 range raises the flag of the transform kernels: sivo_segnet_segment
+    recomputes the frame on the bf16x6 GEMM before it returns and the handle stays there.  Forced with SIVO_H3_BOOST=9 (the
+    calibrated scales times 2^9: the calibration maximum itself lands at >= 65536).  The maps equal those of a handle built
+    with SIVO_GEMM=x6 bit for bit."""
+    T, H, W, width = 3, 22, 64, 256
+    text = _conv_stack_prototxt(T, H, W, width)
+    img = _image(np.random.default_rng(4), H, W)
+    _, _, boosted = _make_env(text, T, 5, SIVO_H3_BOOST=9)
+    _, _, x6 = _make_env(text, T, 5, SIVO_GEMM="x6")
+    assert boosted.gemm_status()[:2] == (2, 0)
+    got = boosted.segment_image(img, seed=3)
+    want = x6.segment_image(img, seed=3)
+    assert boosted.gemm_status()[:2] == (1, 1)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    assert np.isfinite(got[1]).all() and np.isfinite(got[2]).all()
+    # asynchronous entry point: the frame that overflowed is not recomputed, the handle reports it and switches
+    _, _, boosted2 = _make_env(text, T, 5, SIVO_H3_BOOST=9)
+    d = torch.from_numpy(img).cuda()
+    boosted2.forward(d, 3)
+    torch.cuda.synchronize()
+    assert boosted2.gemm_status()[:2] == (1, 1)
+    ps, _, _ = boosted2.forward(d, 3)
+    ps_x6, _, _ = x6.forward(d, 3)
+    torch.cuda.synchronize()
+    assert torch.equal(ps, ps_x6)

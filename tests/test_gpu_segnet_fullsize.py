@@ -205,6 +205,66 @@ def test_timed_configuration_against_the_oracle(oracle, kind, T, image, seed, ki
     np.testing.assert_allclose(conf[clean], free["confidence"][clean], atol=LOGIT_TOL / 2, rtol=0)
 
 
+def _oracle_one_sample(oracle, net, w, img, seed, s, masks, lname):
+    """Sample s of the frame on the oracle (the dropout masks are keyed by the global sample index), with the device's
+    switches of that sample imposed.  Returns (logits (1, K, H, W), flips)."""
+    one = dict(net, shape=[1] + list(net["shape"][1:]))
+    fm = {k: (v if v.shape[0] == 1 else v[s:s + 1]) for k, v in masks.items()}
+    flips = {}
+    res = oracle.segment(one, w, img, seed, sample0=s, logits_name=lname, force_masks=fm, flips=flips, shared_prefix=True)
+    return res["logits"], flips
+
+
+def test_t48_and_its_shards_at_full_size(oracle, kitti_like_bgr):
+    """BASELINE configs[3] as bench.py times it on one GPU (T = 48 in one handle) and as it shards (6 samples per rank,
+    sample0 = 6 r).  T is the prototxt's batch dimension (bayesian_segnet.cpp:67-70,174-177): at T = 48 a V / M slot of
+    conv2_2_D holds 5 GB — where a 32-bit offset would hide.
+      * samples 0-11 of the T = 48 frame are bit-identical to the T = 12 handle's (masks are keyed by the global sample);
+      * samples 0, 23 and 47: every logit within 1e-3 of the oracle (switches teacher-forced, each a near-tie);
+      * a 6-sample shard forward(n_samples = 6, sample0 = 18): logits bit-identical to samples 18-23 of the full pass;
+      * the probability sums of the 8 shards + finalize == the single pass: classes identical except at ties of the mean,
+        confidence and entropy to 1e-6 (fp32 sums added in another order)."""
+    net12, w, sn12 = _handle("standard", 12)
+    img = _images(kitti_like_bgr)["kitti"]
+    d_img = torch.from_numpy(img).cuda()
+    seed = 2024
+    _, lg12, _ = sn12.forward(d_img, seed, want_logits=True)
+    lg12 = lg12.cpu()
+    _cache.clear()                                   # the T = 12 handles: 22 GB each
+    torch.cuda.empty_cache()
+    net48, _, sn48 = _handle("standard", 48)
+    ps48, lg48, _ = sn48.forward(d_img, seed, want_logits=True)
+    maps48 = sn48.finalize(ps48)
+    torch.cuda.synchronize()
+    assert torch.equal(lg48[:12].cpu(), lg12)
+    masks = {L["top"][1]: sn48.blob(L["top"][1]) for L in _pool_layers(net48)}
+    for s in (0, 23, 47):
+        ref, flips = _oracle_one_sample(oracle, net48, w, img, seed, s, masks, "conv1_1_D")
+        for name, (count, gap, mag) in flips.items():
+            assert gap <= NEAR_TIE * max(mag, 1.0), (s, name, count, gap, mag)
+        err = float(np.abs(lg48[s:s + 1].cpu().numpy() - ref).max())
+        print(f"[standard T=48 sample {s}] max|dlogit| {err:.3e}, switches forced {sum(c for c, _, _ in flips.values())}")
+        assert err < LOGIT_TOL
+    lg48_host = lg48.cpu()
+    cls48, conf48, ent48 = (m.cpu().numpy() for m in maps48)
+    del lg48
+    # shards, in the handle that holds the T = 48 blobs (rank r of 8 runs samples 6 r .. 6 r + 5)
+    total = torch.zeros_like(ps48)
+    for r in range(8):
+        ps, lg, _ = sn48.forward(d_img, seed, n_samples=6, sample0=6 * r, want_logits=(r == 3))
+        total += ps
+        if r == 3:
+            torch.cuda.synchronize()
+            assert torch.equal(lg.cpu(), lg48_host[18:24])
+    cls, conf, ent = (m.cpu().numpy() for m in sn48.finalize(total, t_total=48))
+    np.testing.assert_allclose(conf, conf48, atol=1e-6, rtol=0)
+    np.testing.assert_allclose(ent, ent48, atol=1e-5, rtol=0)
+    assert (cls != cls48).mean() < 1e-5
+    assert sn48.gemm_status()[:2] == (2, 0)
+    _cache.clear()
+    torch.cuda.empty_cache()
+
+
 def _scale_weights(factor):
     """Convolution weights x factor, the BN that follows / factor: the same function with weights (and Winograd-domain
     products) of another magnitude.  factor is not a power of two, so the roundings differ."""
