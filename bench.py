@@ -115,9 +115,11 @@ def cpu_baseline(kind, T, H, W, text, w, bgr, left, right, budget_note):
 # Matrix-core work of a kernel family relative to the ALGORITHMIC (direct-convolution) FLOPs it is credited with, and the
 # dense peak of the instruction type it issues (/opt/skills/guides/MI355X_MICROARCH.md):
 #   Winograd F(4x4,3x3) multiplies 36 instead of 144 per 4x4 outputs (1/4), F(2x2,3x3) 16 instead of 36 (1/2.25);
-#   the bf16x6 GEMM issues six bf16 MFMA products per fp32 product (6/4 of the algorithmic count, on the bf16 pipe).
+#   the bf16x6 GEMM issues six bf16 MFMA products per fp32 product (6/4 of the algorithmic count, on the bf16 pipe), the
+#   f16x3 GEMM three fp16 products (3/4, on the fp16 pipe, same dense peak).
 BF16_MFMA_PEAK_TFLOPS = 2500.0
 KERNEL_CLASS = [("conv7_x6", 6.0, BF16_MFMA_PEAK_TFLOPS, "bf16 MFMA (direct 7x7; fp32 operands split into 3 bf16 planes, 6 products, fp32 accumulate)"),
+                ("wino4_gemm_h3", 3.0 / 4.0, BF16_MFMA_PEAK_TFLOPS, "fp16 MFMA (fp32 operands as fp16 hi + lo planes, 3 products, fp32 accumulate)"),
                 ("wino4_gemm_x6", 6.0 / 4.0, BF16_MFMA_PEAK_TFLOPS, "bf16 MFMA (fp32 operands split into 3 bf16 planes, 6 products, fp32 accumulate)"),
                 ("wino4_gemm", 1.0 / 4.0, FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA"),
                 ("conv_wino4f", 1.0 / 4.0, FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA"),
@@ -160,8 +162,9 @@ def traffic_from_profiles(dom_name):
 
 
 def mfma_roofline(prof_timed, prof_detail, n_timed_frames, n_detail, ms_per_frame, note):
-    """roofline object of a SegNet run.  frac = EXECUTED matrix-core FLOP/s of the dominant kernel / the dense peak of the
-    instruction type it issues (<= 1).  The algorithmic (direct-convolution) rate is reported beside it."""
+    """roofline object of a SegNet run.  achieved / frac = ALGORITHMIC (direct-convolution) FLOP/s of the dominant
+    kernel against the dense peak of the instruction type it issues; executed_tflops / executed_frac = the matrix-core
+    products it really issues (Winograd multiplies 1/4 of the direct products, the split arithmetic 3 or 6 per fp32 product)."""
     by_kernel = aggregate(prof_detail)
     timed = aggregate(prof_timed) if prof_timed else {}
     mfma = {k: v for k, v in timed.items() if v["flops"] > 0 and v["ms"] > 0 and kernel_class(k)}
@@ -181,8 +184,8 @@ def mfma_roofline(prof_timed, prof_detail, n_timed_frames, n_detail, ms_per_fram
             t_peak_ms += v["flops"] / n_detail * c[0] / (c[1] * 1e12) * 1e3
     traffic, tsrc = traffic_from_profiles(dom_name)
     return {"bound": "mfma", "kernel": "sivo::" + dom_name, "instruction": what,
-            "achieved": round(executed, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(executed / peak, 4),
-            "algorithmic_tflops": round(alg, 2), "algorithmic_ratio": round(1.0 / ratio, 4),
+            "achieved": round(alg, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(alg / peak, 4),
+            "executed_tflops": round(executed, 2), "executed_frac": round(executed / peak, 4), "executed_per_algorithmic": round(ratio, 4),
             "traffic": traffic, "traffic_source": f"{tsrc} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, mean bytes per launch)" if traffic else None,
             "launches_per_frame": dom["launches"] / max(frames, 1), "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
             "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
@@ -380,22 +383,26 @@ def main():
         n_timed = len(range(0, args.steps, PROFILE_EVERY))
         note = (f"dominant kernel: HIP events on its launch stream in every {PROFILE_EVERY}th of the {args.steps} timed frames (those frames run the forward in one "
                 f"lane, one launch per layer; the others split the samples over three lanes); kernels_ms_per_frame: {n_detail} further untimed single-lane "
-                "frames with every kernel bracketed.  achieved = EXECUTED matrix-core FLOP/s (the Winograd-domain GEMM of F(4x4,3x3) multiplies 1/4 of the direct "
-                "convolution's products; each fp32 product is six bf16 MFMA products); algorithmic_tflops = direct-convolution FLOPs (SURVEY 8d) / the same time")
+                "frames with every kernel bracketed.  achieved / frac = direct-convolution FLOPs (SURVEY 8d) / kernel time against the dense fp16 / bf16 peak; "
+                "executed_* = the matrix-core products issued (the Winograd-domain GEMM of F(4x4,3x3) multiplies 1/4 of the direct convolution's products; each fp32 "
+                "product is three fp16 MFMA products)")
         roofline = mfma_roofline(prof_timed, prof, n_timed, n_detail, ms_frame, note)
         out = {"metric": "frames/sec, SIVO per-frame path (ORB+SegNet T=%d+entropy) %dx%d" % (T, H, W),
                "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_frame, 3), "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "arithmetic": ("activations, weights, transforms, accumulators and outputs fp32; the batched GEMM of the Winograd F(4x4,3x3) layers multiplies fp32 operands "
-                              "as 3 + 3 bf16 planes / 6 bf16 MFMA products with fp32 accumulation (error at the level of the fp32 FMA chain it replaces: "
-                              "tests/test_gpu_segnet_fullsize.py; SIVO_GEMM=f32 selects the fp32 MFMA kernel); MC mean / confidence / entropy in f64"),
+                              "as fp16 hi + lo pairs (power-of-two layer scales, 2^-22 relative) / 3 fp16 MFMA products with fp32 accumulation (error at the level of the "
+                              "fp32 FMA chain it replaces: tests/test_gpu_h3_gemm.py, tests/test_gpu_segnet_fullsize.py; SIVO_GEMM=x6 / f32 select the bf16x6 / fp32 MFMA "
+                              "kernels); MC mean / confidence / entropy in f64"),
                "config": {"workload": f"full per-frame path: ORB 2000x8 stereo + SegNet-{args.net} T={T} MC-dropout + entropy maps + semantic key filter + stereo match, {H}x{W}, synthetic stereo pair, seeded random weights",
                           "T": T, "samples_per_rank": [parallel.shard_samples(T, world, r)[1] for r in range(world)],
                           "orb": bool(do_orb), "semantic_keys": stats["kps"], "stereo_matches": stats["matches"],
                           "algorithmic_gflop_per_frame": round((sn.flops_shared + T * sn.flops_per_sample) / 1e9, 2),
                           "reference_equivalent_gflop_per_frame": round(T * (sn.flops_shared + sn.flops_per_sample) / 1e9, 2),
-                          "parity": "tests/test_gpu_segnet_fullsize.py (this configuration, three lanes, oracle-checked), tests/test_gpu_orb.py, tests/test_gpu_match_ba.py"},
+                          "gemm": dict(zip(("mode", "fp16_overflow_frames"), sn.gemm_status()[:2])),
+                          "parity": "tests/test_gpu_frame_e2e.py (this frame end to end against the oracle pipeline), tests/test_gpu_segnet_fullsize.py (this network "
+                                    "configuration, every logit, oracle-checked), tests/test_gpu_orb.py, tests/test_gpu_match_ba.py"},
                "roofline": roofline}
 
     # ------------------------------------------------------------------------------------------ further configs (N = 1)
@@ -432,7 +439,7 @@ def main():
                                        "tests/test_gpu_segnet_fullsize.py [basic-6-*] (every logit within 1e-3 of the oracle, three lanes)"))
         if "t48" in want:
             extra.append(segnet_config("BASELINE configs[3] on ONE GPU: SegNet Standard T=48 (the 8-GPU form shards 6 samples per rank)", "standard", 48, 6,
-                                       "same kernels as the T=12 configuration; sharding: tests/test_gpu_segnet.py::test_sample_sharding_matches_single_pass, tests/test_distributed_cpu.py"))
+                                       "tests/test_gpu_segnet_fullsize.py::test_t48_and_its_shards_at_full_size (T = 48 in one handle and the 6-sample shards, oracle-checked), tests/test_distributed_cpu.py"))
         if "ba" in want:
             from sivo_amd import optimizer
             poses, pts, edges, intr = ba_scene()

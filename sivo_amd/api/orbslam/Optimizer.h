@@ -60,7 +60,29 @@ class Optimizer {
     static void BundleAdjustment(std::vector<double> &poses, const std::vector<uint8_t> &fixedPose, std::vector<double> &points,
                                  const std::vector<SivoEdge> &edges, const double intr[5], int nIterations = 5,
                                  const bool *pbStopFlag = nullptr, bool bRobust = true);
+
+    // ---- the reference's own static members over the SLAM object graph (reference include/orbslam/Optimizer.h:46-60), so
+    // that its callers compile against this class as they are: Tracking.cc:617,753,792,1329 `Optimizer::PoseOptimization(
+    // &mCurrentFrame)`, LocalMapping.cc:83 `Optimizer::LocalBundleAdjustment(mpCurrentKeyFrame, &mbAbortBA, mpMap)`,
+    // LoopClosing.cc:667 `Optimizer::GlobalBundleAdjustment(mpMap, 10, &mbStopGBA, nLoopKF, false)`, Tracking.cc
+    // `Optimizer::GlobalBundleAdjustment(mpMap, 20)`.  Member templates over the SLAM types (the data model is outside
+    // this library): any Frame / KeyFrame / MapPoint / Map exposing the members the reference's Optimizer.cc
+    // uses binds, the reference's own classes included.  Defined in OptimizerAdapter.h (included below): the graph walk
+    // of Optimizer.cc fills arrays, the array forms above run on the GPU, the results are written back as the reference does.
+    template <class FrameT>
+    static int PoseOptimization(FrameT *pFrame);
+    template <class KeyFrameT, class MapT>
+    static void LocalBundleAdjustment(KeyFrameT *pKF, bool *pbStopFlag, MapT *pMap);
+    template <class KeyFrameT, class MapPointT>
+    static void BundleAdjustment(const std::vector<KeyFrameT *> &vpKF, const std::vector<MapPointT *> &vpMP, int nIterations = 5,
+                                 bool *pbStopFlag = nullptr, const unsigned long nLoopKF = 0ul, const bool bRobust = true);
+    template <class MapT>
+    static void GlobalBundleAdjustment(MapT *pMap, int nIterations = 5, bool *pbStopFlag = nullptr, const unsigned long nLoopKF = 0ul,
+                                       const bool bRobust = true);
 };
 
 }  // namespace SIVO
+
+#include "OptimizerAdapter.h"
+
 #endif

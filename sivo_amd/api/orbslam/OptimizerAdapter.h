@@ -1,7 +1,9 @@
-// The reference signatures of SIVO::Optimizer over the SLAM object graph (reference include/orbslam/Optimizer.h:53-56):
+// The reference signatures of SIVO::Optimizer over the SLAM object graph (reference include/orbslam/Optimizer.h:46-60):
 //     int  Optimizer::PoseOptimization(Frame *pFrame)                                  Optimizer.cc:273-491
 //     void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *)    Optimizer.cc:493-926
-// as header-only templates: the graph walk the reference does in front of g2o (which observations become edges, mono
+//     void Optimizer::BundleAdjustment(vpKF, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust)      Optimizer.cc:49-271
+//     void Optimizer::GlobalBundleAdjustment(Map *, nIterations, pbStopFlag, nLoopKF, bRobust)     Optimizer.cc:37-47
+// as header-only templates (free functions, and the static members of class Optimizer that forward to them): the graph walk the reference does in front of g2o (which observations become edges, mono
 // or stereo by mvRight, information = mvInvLevelSigma2[octave], which keyframes are fixed) fills SivoEdge arrays, the
 // array-level Optimizer entry points (GPU: Levenberg-Marquardt + Schur, chi2 schedules, marginal covariance) do what
 // g2o + CHOLMOD do, and the results are written back the way the reference does (SetPose, mvbOutlier, SetCovariance,
@@ -225,6 +227,102 @@ void LocalBundleAdjustment(KeyFrameT *pKF, bool *pbStopFlag, MapT *pMap) {
         pMP->UpdateNormalAndDepth();
         ++pointIndex;
     }
+}
+
+// void Optimizer::BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust) (Optimizer.cc:49-271)
+template <class KeyFrameT, class MapPointT>
+void BundleAdjustment(const std::vector<KeyFrameT *> &vpKFs, const std::vector<MapPointT *> &vpMP, int nIterations = 5,
+                      bool *pbStopFlag = nullptr, const unsigned long nLoopKF = 0ul, const bool bRobust = true) {
+    using namespace optimizer_detail;
+    // keyframe vertices (:77-97): every keyframe that is not bad, the map's first one held fixed
+    std::map<KeyFrameT *, int> poseIndex;
+    std::vector<double> poses;
+    std::vector<uint8_t> fixedPose;
+    unsigned long maxKFid = 0;
+    for (KeyFrameT *pKF : vpKFs) {
+        if (pKF->isBad()) continue;
+        double p[12];
+        se3_from_cv(pKF->GetPose(), p);
+        poseIndex[pKF] = (int)fixedPose.size();
+        poses.insert(poses.end(), p, p + 12);
+        fixedPose.push_back(pKF->mnId == 0 ? 1 : 0);
+        if (pKF->mnId > maxKFid) maxKFid = pKF->mnId;
+    }
+    if (poseIndex.empty()) return;
+    // map point vertices and their observations (:102-211); a point without any edge is removed again (:204-210)
+    std::vector<int> pointIndex(vpMP.size(), -1);          // vbNotIncludedMP[i] <=> pointIndex[i] < 0
+    std::vector<double> points;
+    std::vector<SivoEdge> edges;
+    int nPoints = 0;
+    for (size_t i = 0; i < vpMP.size(); ++i) {
+        MapPointT *pMP = vpMP[i];
+        if (pMP->isBad()) continue;
+        const size_t first = edges.size();
+        for (const auto &ob : pMP->GetObservations()) {
+            KeyFrameT *pKF = ob.first;
+            if (pKF->isBad() || pKF->mnId > maxKFid) continue;
+            const auto it = poseIndex.find(pKF);
+            if (it == poseIndex.end()) continue;            // (no vertex of that id: g2o refuses the edge)
+            edges.push_back(observation(*pKF, ob.second, it->second, nPoints));
+        }
+        if (edges.size() == first) continue;
+        const cv::Mat Xw = pMP->GetWorldPos();
+        for (int r = 0; r < 3; ++r) points.push_back(Xw.at<float>(r, 0));
+        pointIndex[i] = nPoints++;
+    }
+    KeyFrameT *any = poseIndex.begin()->first;
+    const double intr[5] = {any->fx, any->fy, any->cx, any->cy, any->mbf};
+    if (!edges.empty()) Optimizer::BundleAdjustment(poses, fixedPose, points, edges, intr, nIterations, pbStopFlag, bRobust);   // :214-217
+    // keyframes (:219-235)
+    for (KeyFrameT *pKF : vpKFs) {
+        if (pKF->isBad()) continue;
+        const cv::Mat T = cv_from_se3(poses.data() + 12 * (size_t)poseIndex[pKF]);
+        if (nLoopKF == 0) {
+            pKF->SetPose(T);
+        } else {
+            pKF->mTcwGBA = T.clone();
+            pKF->mnBAGlobalForKF = nLoopKF;
+        }
+    }
+    // points (:237-260)
+    for (size_t i = 0; i < vpMP.size(); ++i) {
+        if (pointIndex[i] < 0) continue;
+        MapPointT *pMP = vpMP[i];
+        if (pMP->isBad()) continue;
+        cv::Mat X(3, 1, CV_32F);
+        for (int r = 0; r < 3; ++r) X.at<float>(r, 0) = (float)points[3 * (size_t)pointIndex[i] + r];
+        if (nLoopKF == 0) {
+            pMP->SetWorldPos(X);
+            pMP->UpdateNormalAndDepth();
+        } else {
+            pMP->mPosGBA = X.clone();
+            pMP->mnBAGlobalForKF = nLoopKF;
+        }
+    }
+}
+
+// void Optimizer::GlobalBundleAdjustment(Map *pMap, nIterations, pbStopFlag, nLoopKF, bRobust) (Optimizer.cc:37-47)
+template <class MapT>
+void GlobalBundleAdjustment(MapT *pMap, int nIterations = 5, bool *pbStopFlag = nullptr, const unsigned long nLoopKF = 0ul,
+                            const bool bRobust = true) {
+    const auto vpKFs = pMap->GetAllKeyFrames();
+    const auto vpMP = pMap->GetAllMapPoints();
+    BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust);
+}
+
+// the static members of class Optimizer (declared in Optimizer.h)
+template <class FrameT>
+int Optimizer::PoseOptimization(FrameT *pFrame) { return SIVO::PoseOptimization(pFrame); }
+template <class KeyFrameT, class MapT>
+void Optimizer::LocalBundleAdjustment(KeyFrameT *pKF, bool *pbStopFlag, MapT *pMap) { SIVO::LocalBundleAdjustment(pKF, pbStopFlag, pMap); }
+template <class KeyFrameT, class MapPointT>
+void Optimizer::BundleAdjustment(const std::vector<KeyFrameT *> &vpKF, const std::vector<MapPointT *> &vpMP, int nIterations, bool *pbStopFlag,
+                                 const unsigned long nLoopKF, const bool bRobust) {
+    SIVO::BundleAdjustment(vpKF, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust);
+}
+template <class MapT>
+void Optimizer::GlobalBundleAdjustment(MapT *pMap, int nIterations, bool *pbStopFlag, const unsigned long nLoopKF, const bool bRobust) {
+    SIVO::GlobalBundleAdjustment(pMap, nIterations, pbStopFlag, nLoopKF, bRobust);
 }
 
 }  // namespace SIVO

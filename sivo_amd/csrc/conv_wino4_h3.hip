@@ -36,6 +36,7 @@
 #include <stdint.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -68,7 +69,10 @@ __device__ __forceinline__ void h3_dma16(const void *sbase, uint32_t voff, uint3
                  : "memory");
 }
 
-template <int BM, int BN>
+// STG: the two waves of a SIMD (w and w + 4) stage their V' share at opposite ends of a stage — waves 0-3 right behind the
+// barrier, waves 4-7 behind their MFMAs — so that one wave's perms / LDS stores / load issue run beside the other's MFMAs
+// instead of all eight waves staging at once with the matrix cores idle.
+template <int BM, int BN, bool STG>
 __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_h3[];
     constexpr int WT = BN == 256 ? 2 : 4, WC = 8 / WT;          // wave grid: tiles x couts (64 couts per wave)
@@ -177,14 +181,22 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     write_v(0);
     if (1 < total) { load_v(cv); advance(cv); }
 
+    const bool late = STG && wave >= 4;
+    bool v_in_flight = false;         // late waves: V' loads were issued behind this stage's DMA and may stay in flight across the barrier
     for (int s = 0; s < total; ++s) {
         const int cur = s & 1;
-        // stage s: its V' pieces were written by every wave one iteration ago (lgkmcnt), its U' pieces have landed (vmcnt);
+        // stage s: its V' pieces were written by every wave one iteration ago (lgkmcnt), its U' pieces have landed (vmcnt:
+        // vector-memory operations complete in issue order, so a late wave leaves exactly its youngest V' loads in flight);
         // behind the barrier nobody reads buffer cur ^ 1 (stage s - 1) any more
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (s + 1 < total) {
-            write_v(cur ^ 1);                                   // V'(s + 1): loaded during stage s - 1
+        if (v_in_flight) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NQ * 8) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        v_in_flight = false;
+        auto stage_v = [&]() {
+            write_v(cur ^ 1);                                   // V'(s + 1): loaded a stage ago
             if (s + 2 < total) { load_v(cv); advance(cv); }    // V'(s + 2) into the same registers
+        };
+        if (s + 1 < total) {
+            if (!late) stage_v();
             dma_u(cu, cur ^ 1); advance(cu);                    // U'(s + 1)
         }
         const unsigned char *st = lds_h3 + cur * STAGE;
@@ -235,6 +247,10 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
                     for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
             cc.chunk = 0;
             if (++cc.k < my_items) locate(cc);
+        }
+        if (late && s + 1 < total) {
+            stage_v();
+            v_in_flight = s + 2 < total;
         }
     }
 }
@@ -302,26 +318,38 @@ static int h3_config(int64_t P, int Kp) {
 void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int Kp, int P, int Pp, hipStream_t s) {
     static int attr_set[64] = {0};
     if (FirstUse once(attr_set); once) {
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<256, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128));
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<128, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 256) * 128));
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<256, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 128));
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<256, 256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128));
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<128, 256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 256) * 128));
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<256, 128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 128));
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<256, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128));
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<128, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 256) * 128));
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<256, 128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 128));
     }
+    // SIVO_H3_STAGGER=0/1: all waves stage behind the barrier / the two waves of a SIMD stage at opposite ends of a stage
+    static const bool stagger = !(std::getenv("SIVO_H3_STAGGER") && std::atoi(std::getenv("SIVO_H3_STAGGER")) == 0);
+    // SIVO_H3_TILE=0/1/2 forces the workgroup tile (tests; 2 needs Kp = 128 per cout group and is otherwise ignored)
+    static const int force_tile = std::getenv("SIVO_H3_TILE") ? std::atoi(std::getenv("SIVO_H3_TILE")) : -1;
     static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
     const dim3 grid((unsigned)((n_cu / 8) * 8 > 0 ? (n_cu / 8) * 8 : 8));      // one persistent workgroup per CU, a multiple of the 8 XCDs
     H3Args a{};
     a.V = V; a.U = static_cast<const unsigned char *>(U); a.M = M; a.C = C; a.Kp = Kp; a.P = P; a.Pp = Pp;
-    switch (h3_config(P, Kp)) {
+    int cfg = h3_config(P, Kp);
+    if (cfg != 2 && (force_tile == 0 || force_tile == 1)) cfg = force_tile;
+    switch (cfg) {
         case 0:
             a.ptiles = (P + 255) / 256; a.ktiles = Kp / 256;
-            hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256>), grid, dim3(512), 2 * (256 + 256) * 128, s, a);
+            if (stagger) hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, true>), grid, dim3(512), 2 * (256 + 256) * 128, s, a);
+            else hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, false>), grid, dim3(512), 2 * (256 + 256) * 128, s, a);
             break;
         case 1:
             a.ptiles = (P + 127) / 128; a.ktiles = Kp / 256;
-            hipLaunchKernelGGL((wino4_gemm_h3_kernel<128, 256>), grid, dim3(512), 2 * (128 + 256) * 128, s, a);
+            if (stagger) hipLaunchKernelGGL((wino4_gemm_h3_kernel<128, 256, true>), grid, dim3(512), 2 * (128 + 256) * 128, s, a);
+            else hipLaunchKernelGGL((wino4_gemm_h3_kernel<128, 256, false>), grid, dim3(512), 2 * (128 + 256) * 128, s, a);
             break;
         default:
             a.ptiles = (P + 255) / 256; a.ktiles = Kp / 128;
-            hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 128>), grid, dim3(512), 2 * (256 + 128) * 128, s, a);
+            if (stagger) hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 128, true>), grid, dim3(512), 2 * (256 + 128) * 128, s, a);
+            else hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 128, false>), grid, dim3(512), 2 * (256 + 128) * 128, s, a);
     }
 }
 

@@ -98,7 +98,8 @@ struct TMapPoint {
     template <class KF> void AddObservation(KF *kf, size_t idx) { inKF[kf] = idx; ++obs; }
     void Replace(TMapPoint *other) { replacedBy = other; bad = true; }
     // what Optimizer::LocalBundleAdjustment reads / writes (Optimizer.cc:514-562, 863-925)
-    unsigned long mnBALocalForKF = ~0ul;
+    unsigned long mnBALocalForKF = ~0ul, mnBAGlobalForKF = 0, mnId = 0;
+    cv::Mat mPosGBA;
     std::map<TKeyFrame *, size_t> observations;
     std::map<TKeyFrame *, size_t> GetObservations() const { return observations; }
     void EraseObservation(TKeyFrame *kf) { observations.erase(kf); }
@@ -138,7 +139,8 @@ struct TFrame {
 };
 
 struct TKeyFrame : TFrame {
-    unsigned long mnId = 0, mnBALocalForKF = ~0ul, mnBAFixedForKF = ~0ul;
+    unsigned long mnId = 0, mnBALocalForKF = ~0ul, mnBAFixedForKF = ~0ul, mnBAGlobalForKF = 0;
+    cv::Mat mTcwGBA;
     std::vector<TKeyFrame *> covisible;
     std::vector<TKeyFrame *> GetVectorCovisibleKeyFrames() const { return covisible; }
     bool isBad() const { return false; }
@@ -267,7 +269,13 @@ static void run_matcher_templates(const std::vector<cv::KeyPoint> &keys, const c
     CHECK(nm > lvl0 / 2 && nm <= lvl0);
 }
 
-struct TMap { std::mutex mMutexMapUpdate; };
+struct TMap {
+    std::mutex mMutexMapUpdate;
+    std::vector<TKeyFrame *> keyframes;
+    std::vector<TMapPoint *> points;
+    std::vector<TKeyFrame *> GetAllKeyFrames() const { return keyframes; }
+    std::vector<TMapPoint *> GetAllMapPoints() const { return points; }
+};
 
 // Optimizer::PoseOptimization(Frame*) and LocalBundleAdjustment(KeyFrame*, bool*, Map*) through the adapter templates.
 static void run_optimizer_templates(const std::vector<cv::KeyPoint> &keys, const cv::Mat &desc, const SIVO::ORBextractor &ex, int rows, int cols) {
@@ -279,14 +287,14 @@ static void run_optimizer_templates(const std::vector<cv::KeyPoint> &keys, const
     for (int i = 0; i < n; i += 3) F.mvRight[i] = -1.f;                 // a third of the observations monocular
     for (int i = 1; i < 10; i += 3) F.mvKeysSemantic[i].pt.x += 25.f;   // stereo outliers
     F.setPose(0.05f, -0.02f, 0.03f);
-    const int inliers = SIVO::PoseOptimization(&F);
+    const int inliers = SIVO::Optimizer::PoseOptimization(&F);            // as Tracking.cc:617 calls it
     CHECK(inliers == n - 3 && F.mvbOutlier[1] && F.mvbOutlier[4] && F.mvbOutlier[7] && !F.mvbOutlier[2]);
     CHECK(std::fabs(F.mTcw.at<float>(0, 3)) < 2e-3f && std::fabs(F.mTcw.at<float>(1, 3)) < 2e-3f && std::fabs(F.mTcw.at<float>(2, 3)) < 5e-3f);
     CHECK(F.covarianceSet && F.mSigmacw[0] > 0 && F.mSigmacw[35] > 0);
     TFrame few;
     std::vector<TMapPoint> p2;
     fill_frame(few, std::vector<cv::KeyPoint>(keys.begin(), keys.begin() + 2), desc, ex, rows, cols, p2);
-    CHECK(SIVO::PoseOptimization(&few) == 0);                             // fewer than 3 correspondences (:409-411)
+    CHECK(SIVO::Optimizer::PoseOptimization(&few) == 0);                             // fewer than 3 correspondences (:409-411)
 
     // local BA: three keyframes 0.5 m apart seeing the same points; keyframe 0 is the map's first one (held fixed)
     std::vector<TMapPoint> mp;
@@ -316,7 +324,7 @@ static void run_optimizer_templates(const std::vector<cv::KeyPoint> &keys, const
     kf[1].mvKeysSemantic[3].pt.y += 40.f;                                 // one gross observation -> erased
     TMap map;
     bool stop = false;
-    SIVO::LocalBundleAdjustment(&kf[2], &stop, &map);
+    SIVO::Optimizer::LocalBundleAdjustment(&kf[2], &stop, &map);          // as LocalMapping.cc:83 calls it
     CHECK(std::fabs(kf[2].mTcw.at<float>(0, 3) - truth) < 5e-3f);
     CHECK(kf[0].mTcw.at<float>(0, 3) == 0.f);                             // keyframe 0 fixed
     CHECK(kf[1].mvpMapPoints[3] == nullptr && mp[3].observations.count(&kf[1]) == 0 && mp[3].observations.size() == 2);
@@ -325,8 +333,35 @@ static void run_optimizer_templates(const std::vector<cv::KeyPoint> &keys, const
     stop = true;
     const float before = kf[2].mTcw.at<float>(0, 3);
     kf[2].mTcw.at<float>(0, 3) += 0.04f;
-    SIVO::LocalBundleAdjustment(&kf[2], &stop, &map);                     // pbStopFlag set: returns before optimising (:757-761)
+    SIVO::Optimizer::LocalBundleAdjustment(&kf[2], &stop, &map);          // pbStopFlag set: returns before optimising (:757-761)
     CHECK(kf[2].mTcw.at<float>(0, 3) == before + 0.04f);
+
+    // BundleAdjustment / GlobalBundleAdjustment (Optimizer.cc:37-271) as LoopClosing.cc:667 and Tracking.cc call them: the
+    // same three keyframes, keyframe 2 and half of the points perturbed again; one map point is bad, one has no observation
+    stop = false;
+    kf[2].mTcw.at<float>(0, 3) = truth + 0.03f;
+    for (int i = 1; i < n; i += 2) mp[i].pos.at<float>(2, 0) = 20.08f;
+    mp[5].bad = true;
+    const float untouched = mp[5].pos.at<float>(2, 0);
+    TMapPoint lonely;
+    lonely.pos.at<float>(2, 0) = 7.f;
+    for (int k = 0; k < 3; ++k) map.keyframes.push_back(&kf[k]);
+    for (int i = 0; i < n; ++i) { mp[i].mnId = (unsigned long)i; mp[i].normalUpdates = 0; map.points.push_back(&mp[i]); }
+    map.points.push_back(&lonely);
+    SIVO::Optimizer::GlobalBundleAdjustment(&map, 10);                    // nLoopKF = 0: results written into the map
+    CHECK(std::fabs(kf[2].mTcw.at<float>(0, 3) - truth) < 5e-3f && kf[0].mTcw.at<float>(0, 3) == 0.f);
+    CHECK(std::fabs(mp[1].pos.at<float>(2, 0) - 20.f) < 0.05f && mp[1].normalUpdates == 1);
+    CHECK(mp[5].pos.at<float>(2, 0) == untouched && mp[5].normalUpdates == 0);           // bad point: no vertex
+    CHECK(lonely.pos.at<float>(2, 0) == 7.f && lonely.normalUpdates == 0);               // no edges: vbNotIncludedMP
+    kf[2].mTcw.at<float>(0, 3) = truth + 0.03f;
+    const float kept = kf[2].mTcw.at<float>(0, 3), zkept = mp[1].pos.at<float>(2, 0);
+    SIVO::Optimizer::GlobalBundleAdjustment(&map, 10, &stop, 7ul, false); // nLoopKF != 0: results parked in mTcwGBA / mPosGBA (:226-231, 251-259)
+    CHECK(kf[2].mTcw.at<float>(0, 3) == kept && mp[1].pos.at<float>(2, 0) == zkept);
+    CHECK(kf[2].mnBAGlobalForKF == 7ul && std::fabs(kf[2].mTcwGBA.at<float>(0, 3) - truth) < 5e-3f);
+    CHECK(mp[1].mnBAGlobalForKF == 7ul && std::fabs(mp[1].mPosGBA.at<float>(2, 0) - 20.f) < 0.05f && mp[5].mnBAGlobalForKF == 0);
+    std::vector<TKeyFrame *> two = {&kf[0], &kf[1]};
+    SIVO::Optimizer::BundleAdjustment(two, map.points, 5, &stop, 0ul, true);          // observations in keyframe 2 (mnId > maxKFid) are skipped (:131-133)
+    CHECK(kf[2].mTcw.at<float>(0, 3) == kept);
 }
 
 static int run_gpu(int argc, char **argv) {

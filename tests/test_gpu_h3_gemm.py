@@ -1,8 +1,10 @@
 """The f16x3 GEMM of the three-kernel F(4x4,3x3) path (sivo_amd/csrc/conv_wino4_h3.hip) alone, through the C ABI
 (sivo_debug_h3_gemm), against an fp64 evaluation of the same 36 products  M_xi = U_xi^T V_xi.
 
-fp32 operands are multiplied as fp16 hi + lo pairs (three v_mfma_f32_32x32x16_f16 products, fp32 accumulate): the error
-bound asserted is the one of an fp32 FMA chain, 2^-21 of sum |u| |v| per element.  Operands are random and asymmetric (a
+fp32 operands are multiplied as fp16 hi + lo pairs (three v_mfma_f32_32x32x16_f16 products, fp32 accumulate).  Error
+model: each operand is represented to 2^-22 relative and the lo x lo product (2^-22) is dropped, i.e. at most 3 * 2^-22 per
+product, plus the fp32 roundings of the accumulator; asserted: |err| <= 2^-20 * sum |u| |v| per element (measured worst
+case over all shapes: 1.0 * 2^-21; an fp32 FMA chain of C = 64 terms is allowed 64 * 2^-24 = 2^-18).  Operands are random and asymmetric (a
 transposed operand or a swapped output index cannot pass); the shapes exercise the three workgroup tiles (256 x 256,
 128 x 256 for launches with few tiles, 256 x 128 for 128 couts), ragged tile counts (P not a multiple of 32 / 128 / 256),
 several items per workgroup and item boundaries inside the software pipeline."""
@@ -35,9 +37,9 @@ def test_h3_gemm_against_fp64(C, Kp, P):
         assert np.isfinite(M[xi][:, :P]).all(), xi
         rel = float((err / np.maximum(bound[:, :P], 1e-30)).max())
         worst = max(worst, rel)
-        assert rel < 2.0 ** -21, (xi, rel)
+        assert rel < 2.0 ** -20, (xi, rel)
         assert np.abs(ref).max() > 1e-3
-    print(f"[h3 gemm C={C} Kp={Kp} P={P}] worst |err| / sum|u||v| = {worst:.2e} (2^-21 = {2.0 ** -21:.2e})")
+    print(f"[h3 gemm C={C} Kp={Kp} P={P}] worst |err| / sum|u||v| = {worst:.2e} (bound 2^-20 = {2.0 ** -20:.2e})")
 
 
 def test_h3_gemm_small_values_keep_their_precision():

@@ -484,8 +484,9 @@ def _make_env(text, T, seed, **env):
 def test_f4x4_gemm_forms_agree(oracle, H, W, width):
     """The three GEMMs of the three-kernel F(4x4,3x3) path on the same layers: f16x3 (default: fp16 hi + lo planes, three
     products), bf16x6 (SIVO_GEMM=x6) and the fp32 MFMA kernel (SIVO_GEMM=f32).  Each against the oracle within the logit
-    tolerance, the split forms against the fp32 form much closer than that (the split is not the error, the F(4x4)
-    transforms are); gemm_status names the form and reports the calibrated scales."""
+    tolerance; the split forms are at least as close to the oracle as the fp32 FMA chain of the MFMA kernel (measured:
+    2.1e-4 / 2.7e-4 / 2.8e-4 on the 512-channel case — fewer roundings of the accumulator), and the three forms agree with
+    each other within half the tolerance; gemm_status names the form and reports the calibrated scales."""
     T = 3
     text = _conv_stack_prototxt(T, H, W, width)
     img_np = _image(np.random.default_rng(H * W + width), H, W)
@@ -507,7 +508,8 @@ def test_f4x4_gemm_forms_agree(oracle, H, W, width):
         err = np.abs(lg[form] - res["logits"]).max()
         print(f"[{H}x{W}x{width} {form}] max|dlogit| vs oracle {err:.2e}; vs fp32 GEMM {np.abs(lg[form] - lg['f32']).max():.2e}")
         assert err < LOGIT_TOL
-    assert np.abs(lg["h3"] - lg["f32"]).max() < 1e-4 and np.abs(lg["x6"] - lg["f32"]).max() < 1e-4
+    assert np.abs(lg["h3"] - lg["f32"]).max() < LOGIT_TOL / 2 and np.abs(lg["x6"] - lg["h3"]).max() < LOGIT_TOL / 2
+    assert np.abs(lg["h3"] - res["logits"]).max() <= 1.1 * np.abs(lg["f32"] - res["logits"]).max()
 
 
 def test_fp16_overflow_sends_the_frame_to_the_bf16x6_gemm(oracle):

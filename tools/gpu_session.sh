@@ -1,0 +1,33 @@
+#!/bin/bash
+# One GPU-box session: the steps named on the command line, in order, every log under gpurun_out/<tag>/.
+#   bash tools/gpu_session.sh <tag> step...      steps: gemm segnet bench benchvar e2e fullsize alltests
+set -u
+TAG=$1; shift
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+bench() {   # name, env...
+  local name=$1; shift
+  env "$@" timeout 300 python bench.py --per-layer --configs none --no-cpu-baseline --steps 20 > $O/bench_$name.json 2> $O/bench_$name.err
+  echo "bench $name rc=$?"; python - <<PY
+import json
+try:
+    d=json.load(open("$O/bench_$name.json")); r=d["roofline"]
+    print("  ", d["value"], "fps", d["ms_per_step"], "ms; dom", r["kernel"], "avg", round(r["avg_launch_ms"],4), "ms frac", r["frac"], "exec", r.get("executed_frac"))
+    print("  ", {k: v for k, v in r["kernels_ms_per_frame"].items()})
+except Exception as e: print("  no line:", e)
+PY
+}
+for step in "$@"; do
+  case $step in
+    gemm) timeout 600 python -m pytest tests/test_gpu_h3_gemm.py -x -q -s > $O/gemm.log 2>&1; echo "gemm rc=$?"; grep -E "h3 gemm|passed|failed|Error|assert" $O/gemm.log | tail -15;;
+    segnet) timeout 900 python -m pytest tests/test_gpu_segnet.py -q -s > $O/segnet.log 2>&1; echo "segnet rc=$?"; grep -E "passed|failed|FAILED|dlogit" $O/segnet.log | tail -25;;
+    bench) bench default SIVO_DUMMY=1;;
+    benchvar) bench nostagger SIVO_H3_STAGGER=0; bench lanes1 SIVO_LANES=1; bench x6 SIVO_GEMM=x6;;
+    e2e) timeout 600 python -m pytest tests/test_gpu_frame_e2e.py -q -s > $O/e2e.log 2>&1; echo "e2e rc=$?"; grep -E "e2e|passed|failed|Error" $O/e2e.log | tail -8;;
+    fullsize) timeout 1500 python -m pytest tests/test_gpu_segnet_fullsize.py -q -s > $O/fullsize.log 2>&1; echo "fullsize rc=$?"; grep -E "dlogit|passed|failed|FAILED|Error" $O/fullsize.log | tail -40;;
+    alltests) timeout 1800 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; echo "alltests rc=$?"; tail -5 $O/gpu_tests.log;;
+  esac
+done
