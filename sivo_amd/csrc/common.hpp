@@ -52,6 +52,18 @@ struct DeviceGuard {
     }
 };
 
+// Restores the device that was current at construction, whatever the scope does with hipSetDevice in between (also
+// when it leaves by an exception).
+struct DeviceRestore {
+    int prev = -1;
+    DeviceRestore() { (void)hipGetDevice(&prev); }
+    ~DeviceRestore() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceRestore(const DeviceRestore &) = delete;
+    DeviceRestore &operator=(const DeviceRestore &) = delete;
+};
+
 template <class T>
 T *dev_alloc(size_t n) {
     T *p = nullptr;

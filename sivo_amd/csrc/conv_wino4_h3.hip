@@ -72,7 +72,9 @@ __device__ __forceinline__ void h3_dma16(const void *sbase, uint32_t voff, uint3
 // STG: the two waves of a SIMD (w and w + 4) stage their V' share at opposite ends of a stage — waves 0-3 right behind the
 // barrier, waves 4-7 behind their MFMAs — so that one wave's perms / LDS stores / load issue run beside the other's MFMAs
 // instead of all eight waves staging at once with the matrix cores idle.
-template <int BM, int BN, bool STG>
+// ABL (diagnostic builds only, -DSIVO_DIAG -> libsivo_hip_diag.so, tools/h3_probe.py; results are wrong by construction):
+// 1 no V' loads after the prologue, 2 no U' DMA after the prologue, 4 no M stores, 8 no MFMAs.
+template <int BM, int BN, bool STG, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_h3[];
     constexpr int WT = BN == 256 ? 2 : 4, WC = 8 / WT;          // wave grid: tiles x couts (64 couts per wave)
@@ -193,11 +195,12 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         v_in_flight = false;
         auto stage_v = [&]() {
             write_v(cur ^ 1);                                   // V'(s + 1): loaded a stage ago
-            if (s + 2 < total) { load_v(cv); advance(cv); }    // V'(s + 2) into the same registers
+            if (s + 2 < total) { if (!(ABL & 1)) load_v(cv); advance(cv); }    // V'(s + 2) into the same registers
         };
         if (s + 1 < total) {
             if (!late) stage_v();
-            dma_u(cu, cur ^ 1); advance(cu);                    // U'(s + 1)
+            if (!(ABL & 2)) dma_u(cu, cur ^ 1);                 // U'(s + 1)
+            advance(cu);
         }
         const unsigned char *st = lds_h3 + cur * STAGE;
 #pragma unroll
@@ -218,8 +221,10 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int t = 0; t < TB; ++t)
-                        acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][PA[term]], B[t][PB[term]], acc[c][t], 0, 0, 0);
+                    for (int t = 0; t < TB; ++t) {
+                        if (ABL & 8) acc[c][t][term] += (float)A[c][PA[term]][0] + (float)B[t][PB[term]][1];
+                        else acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][PA[term]], B[t][PB[term]], acc[c][t], 0, 0, 0);
+                    }
             }
         }
         if (++cc.chunk == nst) {
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
 #pragma unroll
             for (int t = 0; t < TB; ++t) {
                 const int p0 = cc.pt * BM + (wt * TB + t) * 32;
-                if (p0 < a.Pp) {          // (a tile group may reach beyond the padded tile count: nothing to store there)
+                if (p0 < a.Pp && (!(ABL & 4) || acc[0][0][0] == 12345.678f)) {          // (a tile group may reach beyond the padded tile count: nothing to store there)
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -333,6 +338,22 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
     const dim3 grid((unsigned)((n_cu / 8) * 8 > 0 ? (n_cu / 8) * 8 : 8));      // one persistent workgroup per CU, a multiple of the 8 XCDs
     H3Args a{};
     a.V = V; a.U = static_cast<const unsigned char *>(U); a.M = M; a.C = C; a.Kp = Kp; a.P = P; a.Pp = Pp;
+#ifdef SIVO_DIAG
+    if (const char *ab = std::getenv("SIVO_H3_ABL")) {          // diagnostic build: ablations of the 256 x 256 kernel
+        a.ptiles = (P + 255) / 256; a.ktiles = Kp / 256;
+        const size_t l = 2 * (256 + 256) * 128;
+#define H3_ABL_CASE(n)                                                                                                              \
+    case n:                                                                                                                         \
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<256, 256, false, n>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l)); \
+        hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, false, n>), grid, dim3(512), l, s, a);                                   \
+        return;
+        switch (std::atoi(ab)) {
+            H3_ABL_CASE(1) H3_ABL_CASE(2) H3_ABL_CASE(3) H3_ABL_CASE(4) H3_ABL_CASE(7) H3_ABL_CASE(8) H3_ABL_CASE(12)
+            default: break;
+        }
+#undef H3_ABL_CASE
+    }
+#endif
     int cfg = h3_config(P, Kp);
     if (cfg != 2 && (force_tile == 0 || force_tile == 1)) cfg = force_tile;
     switch (cfg) {

@@ -294,6 +294,11 @@ void run_search(sivo_mframe &F, const SivoSearchQuery *queries, const uint8_t *q
     if (match_train) for (int k = 0; k < F.n; ++k) match_train[k] = -1;
     if (nq <= 0) return;
     if (nq >= (1 << 22) || F.n >= (1 << 22) || n_cand >= (1 << 22)) throw std::invalid_argument("sivo_search: at most 2^22 - 1 queries / keypoints / list entries");
+    // explicit candidate lists index the frame's keypoints: a stale or foreign FeatureVector entry would be an out-of-bounds
+    // read of descriptors / keys and, through the pick, an out-of-bounds atomic on the scratch buffer
+    if (cand_idx)
+        for (int j = 0; j < n_cand; ++j)
+            if ((uint32_t)cand_idx[j] >= (uint32_t)F.n) throw std::invalid_argument("sivo_search: candidate index outside the frame's keypoints");
     DeviceGuard dg(F.device);
     const int n = F.n;
     const size_t need = 256 * 16 + (size_t)nq * (sizeof(SivoSearchQuery) + 32 + 8 + 4 * 4) + (size_t)(cand_idx ? n_cand : 0) * 4 +

@@ -110,6 +110,7 @@ struct sivo_segnet {
     double *d_conf = nullptr, *d_ent = nullptr;
     hipStream_t stream = nullptr;   // for the host-level entry point
     int64_t sum_chunk = 0;          // layout of the probability sum the next forward writes (0 = [class][pixel])
+    double *d_sum64 = nullptr;      // when set (segnet_forward_chunked): the next forward writes its f64 probability sums here
     double flops_shared = 0.0, flops_sample = 0.0;
     bool profile = false, pending = false;
     bool profile_mfma_only = false;   // bracket only the MFMA kernels (convolutions / the F(4x4) GEMM): fewer events in a timed run
@@ -797,7 +798,7 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
     const Blob &lg = S.blobs[S.logits_blob];
     if (lg.shared) throw std::runtime_error("the network has no test-time dropout: nothing to sample");
     launch_preprocess(d_bgr, (float *)S.blobs[S.input_blob].d, hw, st);
-    const bool fuse = S.cls_op >= 0 && !d_prob && !d_logits && (mc || d_prob_sum);
+    const bool fuse = S.cls_op >= 0 && !d_prob && !d_logits && (mc || d_prob_sum || S.d_sum64);
     const size_t last = fuse ? (size_t)S.cls_op : S.ops.size();
     // the sample-invariant ops form a prefix of the plan
     size_t fork = 0;
@@ -846,7 +847,7 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
         a.wt = op.d_w_mc; a.ep_scale = op.d_scale; a.ep_shift = op.d_shift;
         a.T = n; a.Cin = op.cin; a.H = bi.H; a.W = bi.W; a.C = op.cout; a.relu = op.relu;
         a.logits = mc ? mc->logits : nullptr;
-        a.prob_sum = d_prob_sum; a.sum_chunk = S.sum_chunk;
+        a.prob_sum = d_prob_sum; a.prob_sum64 = S.d_sum64; a.sum_chunk = S.sum_chunk;
         if (mc) { a.classes = mc->classes; a.confidence = mc->conf; a.entropy = mc->ent; }
         op.mc_fused_last = true;
         if (S.profile) {
@@ -858,7 +859,8 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
         if (S.profile) SIVO_HIP(hipEventRecord(op.ev1, st));
     } else {
         if (S.cls_op >= 0) S.ops[S.cls_op].mc_fused_last = false;
-        if (d_prob_sum || d_prob) launch_mc_reduce((const float *)lg.d, n, S.classes, hw, d_prob_sum ? d_prob_sum : S.d_prob_sum, d_prob, 0, st, S.sum_chunk);
+        if (d_prob_sum || d_prob || S.d_sum64)
+            launch_mc_reduce((const float *)lg.d, n, S.classes, hw, d_prob_sum ? d_prob_sum : S.d_sum64 ? nullptr : S.d_prob_sum, d_prob, 0, st, S.sum_chunk, S.d_sum64);
         if (mc) {
             launch_mc_reduce_finalize((const float *)lg.d, n, S.classes, hw, mc->classes, mc->conf, mc->ent, st);
             if (mc->logits) SIVO_HIP(hipMemcpyAsync(mc->logits, lg.d, (size_t)n * lg.chw() * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -881,18 +883,22 @@ std::string read_file(const char *path) {
 }  // namespace
 }  // namespace sivo
 
-void sivo::segnet_forward_chunked(sivo_segnet_t h, const uint8_t *d_bgr, int n, int sample0, uint64_t seed, float *d_sum_chunked,
+void sivo::segnet_forward_chunked(sivo_segnet_t h, const uint8_t *d_bgr, int n, int sample0, uint64_t seed, double *d_sum_chunked,
                                   int64_t chunk, hipStream_t st) {
     DeviceGuard dg(h->device);
     h->sum_chunk = chunk;
+    h->d_sum64 = d_sum_chunked;
     try {
-        forward(*h, d_bgr, n, sample0, seed, d_sum_chunked, nullptr, nullptr, st);
+        forward(*h, d_bgr, n, sample0, seed, nullptr, nullptr, nullptr, st);
     } catch (...) {
-        h->sum_chunk = 0;
+        h->sum_chunk = 0; h->d_sum64 = nullptr;
         throw;
     }
-    h->sum_chunk = 0;
+    h->sum_chunk = 0; h->d_sum64 = nullptr;
 }
+
+bool sivo::segnet_fp16_overflowed(sivo_segnet_t h) { return h3_tripped(*h); }
+void sivo::segnet_force_bf16x6(sivo_segnet_t h) { h->h3_on = false; }
 
 using namespace sivo;
 

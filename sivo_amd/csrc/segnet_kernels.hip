@@ -404,7 +404,7 @@ void launch_lrn(const float *in, float *out, int N, int C, int64_t hw, int local
 // coalesced VEC*4-byte access along the pixel axis.
 template <int VEC, int CMAX>
 __global__ void mc_reduce_kernel(const float *logits, int n, int C, int64_t hw, float *prob_sum, float *prob,
-                                 int accumulate, int64_t chunk) {
+                                 int accumulate, int64_t chunk, double *prob_sum64) {
     const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (p >= hw) return;
     double sum[CMAX][VEC];
@@ -455,7 +455,13 @@ __global__ void mc_reduce_kernel(const float *logits, int n, int C, int64_t hw, 
         if (c < C) {
             // chunk == hw: [class][pixel]; otherwise pixel-chunk-major [pixel / chunk][class][pixel % chunk] (the layout a
             // reduce-scatter over pixel ranges needs; chunk is even when VEC == 2, so a pixel pair never straddles chunks)
-            float *dst = prob_sum + ((p / chunk) * C + c) * chunk + (p % chunk);
+            const int64_t at = ((p / chunk) * C + c) * chunk + (p % chunk);
+            if (prob_sum64) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) prob_sum64[at + v] = accumulate ? prob_sum64[at + v] + sum[c][v] : sum[c][v];
+            }
+            if (!prob_sum) continue;
+            float *dst = prob_sum + at;
             if (VEC == 2) {
                 float2 o = make_float2((float)sum[c][0], (float)sum[c][1 % VEC]);
                 if (accumulate) { const float2 old = *reinterpret_cast<float2 *>(dst); o.x += old.x; o.y += old.y; }
@@ -469,16 +475,16 @@ __global__ void mc_reduce_kernel(const float *logits, int n, int C, int64_t hw, 
 }
 
 int launch_mc_reduce(const float *logits, int n, int C, int64_t hw, float *prob_sum, float *prob, int accumulate,
-                     hipStream_t s, int64_t chunk) {
+                     hipStream_t s, int64_t chunk, double *prob_sum64) {
     if (C > 16) return 1;
     if (chunk <= 0 || chunk > hw) chunk = hw;
     if ((hw & 1) == 0 && (chunk & 1) == 0) {
         const int64_t threads = hw / 2;
         hipLaunchKernelGGL((mc_reduce_kernel<2, 16>), dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, s, logits,
-                           n, C, hw, prob_sum, prob, accumulate, chunk);
+                           n, C, hw, prob_sum, prob, accumulate, chunk, prob_sum64);
     } else {
         hipLaunchKernelGGL((mc_reduce_kernel<1, 16>), dim3((unsigned)((hw + 127) / 128)), dim3(128), 0, s, logits, n, C,
-                           hw, prob_sum, prob, accumulate, chunk);
+                           hw, prob_sum, prob, accumulate, chunk, prob_sum64);
     }
     return 0;
 }
@@ -537,7 +543,8 @@ void launch_mc_reduce_finalize(const float *logits, int T, int C, int64_t hw, ui
 
 // mean = sum / T (f64); argmax with first-wins ties; max; entropy in bits with the
 // exact-zero guard of computeEntropy (bayesian_segnet.cpp:38-44).
-__global__ void mc_finalize_kernel(const float *prob_sum, int C, int64_t hw, int T, uint8_t *classes,
+template <class SumT>
+__global__ void mc_finalize_kernel(const SumT *prob_sum, int C, int64_t hw, int T, uint8_t *classes,
                                    double *confidence, double *entropy) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= hw) return;
@@ -556,8 +563,22 @@ __global__ void mc_finalize_kernel(const float *prob_sum, int C, int64_t hw, int
 }
 void launch_mc_finalize(const float *prob_sum, int C, int64_t hw, int T, uint8_t *classes, double *confidence,
                         double *entropy, hipStream_t s) {
-    hipLaunchKernelGGL(mc_finalize_kernel, dim3((unsigned)((hw + 255) / 256)), dim3(256), 0, s, prob_sum, C, hw, T,
+    hipLaunchKernelGGL(mc_finalize_kernel<float>, dim3((unsigned)((hw + 255) / 256)), dim3(256), 0, s, prob_sum, C, hw, T,
                        classes, confidence, entropy);
+}
+// the same on f64 sums: with the sums of all samples exact to an f64 rounding, sum / T is the reference's f64 mean
+// (bayesian_segnet.cpp:291-294) whatever the number of devices the samples were spread over
+void launch_mc_finalize64(const double *prob_sum, int C, int64_t hw, int T, uint8_t *classes, double *confidence,
+                          double *entropy, hipStream_t s) {
+    hipLaunchKernelGGL(mc_finalize_kernel<double>, dim3((unsigned)((hw + 255) / 256)), dim3(256), 0, s, prob_sum, C, hw, T,
+                       classes, confidence, entropy);
+}
+__global__ void add_f64_kernel(double *dst, const double *src, int64_t n, int init) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = init ? src[i] : dst[i] + src[i];
+}
+void launch_add_f64(double *dst, const double *src, int64_t n, bool init, hipStream_t s) {
+    hipLaunchKernelGGL(add_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, src, n, init ? 1 : 0);
 }
 
 // computeVariance (bayesian_segnet.cpp:205-260): sample variance over T of the winning class.

@@ -93,6 +93,7 @@ struct ClsMcArgs {
     int tiles_x, tiles_y;      // filled by the launcher
     float *logits;             // optional (T, C, H, W): the logits the sums were formed from
     float *prob_sum;           // optional fp32 sums over the samples, layout as launch_mc_reduce (sum_chunk)
+    double *prob_sum64 = nullptr;   // optional: the same sums as they are accumulated, in f64 (multi-device reduce-scatter)
     int64_t sum_chunk;         // 0 = [class][pixel]
     uint8_t *classes;          // optional maps (all three or none): argmax, max and entropy of the f64 mean
     double *confidence;
@@ -140,12 +141,16 @@ void launch_dropout(const float *in, int64_t in_sample_stride, float *out, int N
 void launch_lrn(const float *in, float *out, int N, int C, int64_t hw, int local_size, float alpha, float beta,
                 hipStream_t s);
 // chunk (0 = hw): pixel-chunk-major output [hw / chunk][C][chunk] for the multi-device reduce-scatter (segnet_multi.cpp)
+// prob_sum64 (optional, instead of or beside prob_sum): the f64 sums themselves, same layout
 int launch_mc_reduce(const float *logits, int n, int C, int64_t hw, float *prob_sum, float *prob, int accumulate,
-                     hipStream_t s, int64_t chunk = 0);
+                     hipStream_t s, int64_t chunk = 0, double *prob_sum64 = nullptr);
 void launch_mc_reduce_finalize(const float *logits, int T, int C, int64_t hw, uint8_t *classes, double *confidence,
                                double *entropy, hipStream_t s);
 void launch_mc_finalize(const float *prob_sum, int C, int64_t hw, int T, uint8_t *classes, double *confidence,
                         double *entropy, hipStream_t s);
+void launch_mc_finalize64(const double *prob_sum, int C, int64_t hw, int T, uint8_t *classes, double *confidence,
+                          double *entropy, hipStream_t s);
+void launch_add_f64(double *dst, const double *src, int64_t n, bool init, hipStream_t s);      // dst = src (init) or dst += src
 void launch_mc_variance(const float *prob, int T, int C, int64_t hw, const uint8_t *classes, double *variance,
                         hipStream_t s);
 void launch_mask_to_index(const uint8_t *mask, float *out, int64_t total, int Ho, int Wo, int Win, hipStream_t s);

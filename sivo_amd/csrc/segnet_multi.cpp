@@ -18,6 +18,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -41,17 +42,24 @@ struct Rccl {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
-Rccl &rccl() {
-    static Rccl r;
-    if (r.lib) return r;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+// Opened once, by a throwing factory behind a function-local static (thread-safe, and a failed dlsym leaves nothing half
+// filled: the next call tries again).  RTLD_NOLOAD first: a process that already runs RCCL (torch.distributed) keeps ONE.
+Rccl load_rccl() {
+    Rccl r;
+    for (int flags : {RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD, RTLD_NOW | RTLD_LOCAL}) {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, flags);
+            if (r.lib) break;
+        }
         if (r.lib) break;
     }
     if (!r.lib) throw std::runtime_error(std::string("cannot open librccl.so: ") + dlerror());
     auto sym = [&](const char *n) {
         void *p = dlsym(r.lib, n);
-        if (!p) throw std::runtime_error(std::string("librccl.so lacks ") + n);
+        if (!p) {
+            dlclose(r.lib);
+            throw std::runtime_error(std::string("librccl.so lacks ") + n);
+        }
         return p;
     };
     r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
@@ -61,6 +69,10 @@ Rccl &rccl() {
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    return r;
+}
+Rccl &rccl() {
+    static Rccl r = load_rccl();
     return r;
 }
 
@@ -77,13 +89,17 @@ struct MultiDevice {
     hipStream_t stream = nullptr;
     int sample0 = 0, n_samples = 0;
     uint8_t *d_image = nullptr;
-    float *d_sum = nullptr;             // [ndev][classes][chunk]: this device's sums for every pixel chunk
-    float *d_rs = nullptr;              // [classes][chunk]: all devices' sums for this device's pixel chunk
+    double *d_sum = nullptr;            // [ndev][classes][chunk]: this device's f64 sums for every pixel chunk
+    double *d_rs = nullptr;             // [classes][chunk]: all devices' sums for this device's pixel chunk
     uint8_t *d_cls_chunk = nullptr, *d_cls = nullptr;
     double *d_conf_chunk = nullptr, *d_conf = nullptr, *d_ent_chunk = nullptr, *d_ent = nullptr;
 };
 
 struct SegnetMulti {
+    // emulate (SIVO_MULTI_EMULATE=1, tests): the "devices" may be one physical GPU several times; the two collectives are
+    // then carried out by copies and f64 adds in device order instead of RCCL — everything else (sample shards, chunk-major
+    // sums, per-chunk finalize, gathered maps) is the code the real path runs.
+    bool emulate = false;
     int T = 0, H = 0, W = 0, classes = 0;
     int64_t hw = 0, chunk = 0;
     std::vector<MultiDevice> dev;
@@ -113,14 +129,14 @@ SegnetMulti *segnet_multi_create(const char *text, size_t len, int t_total, cons
     if (!device_ids || ndev < 1) throw std::invalid_argument("device_ids is empty");
     std::unique_ptr<SegnetMulti> M(new SegnetMulti);
     M->dev.resize((size_t)ndev);
-    int prev = 0;
-    SIVO_HIP(hipGetDevice(&prev));
+    M->emulate = std::getenv("SIVO_MULTI_EMULATE") && std::atoi(std::getenv("SIVO_MULTI_EMULATE")) == 1;
+    DeviceRestore restore;              // whatever happens below, the caller's device is current again on the way out
     // T from the prototxt unless overridden: build device 0 first to learn the shape
     for (int d = 0; d < ndev; ++d) {
         MultiDevice &D = M->dev[d];
         D.device = device_ids[d];
         for (int e = 0; e < d; ++e)
-            if (device_ids[e] == D.device) throw std::invalid_argument("device_ids holds a device twice (RCCL needs distinct devices)");
+            if (device_ids[e] == D.device && !M->emulate) throw std::invalid_argument("device_ids holds a device twice (RCCL needs distinct devices)");
     }
     {
         // the reference's constructor checks apply to the TOTAL sample count (bayesian_segnet.cpp:67-70)
@@ -147,16 +163,17 @@ SegnetMulti *segnet_multi_create(const char *text, size_t len, int t_total, cons
         SIVO_HIP(hipSetDevice(D.device));
         SIVO_HIP(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
         D.d_image = dev_alloc<uint8_t>((size_t)M->hw * 3);
-        D.d_sum = dev_alloc<float>((size_t)M->classes * M->hw);
-        D.d_rs = dev_alloc<float>((size_t)M->classes * M->chunk);
+        D.d_sum = dev_alloc<double>((size_t)M->classes * M->hw);
+        D.d_rs = dev_alloc<double>((size_t)M->classes * M->chunk);
         D.d_cls_chunk = dev_alloc<uint8_t>((size_t)M->chunk); D.d_cls = dev_alloc<uint8_t>((size_t)M->hw);
         D.d_conf_chunk = dev_alloc<double>((size_t)M->chunk); D.d_conf = dev_alloc<double>((size_t)M->hw);
         D.d_ent_chunk = dev_alloc<double>((size_t)M->chunk); D.d_ent = dev_alloc<double>((size_t)M->hw);
     }
-    std::vector<ncclComm_t> comms((size_t)ndev);
-    nccl_check(rccl().CommInitAll(comms.data(), ndev, device_ids), "ncclCommInitAll");
-    for (int d = 0; d < ndev; ++d) M->dev[d].comm = comms[d];
-    SIVO_HIP(hipSetDevice(prev));
+    if (!M->emulate) {
+        std::vector<ncclComm_t> comms((size_t)ndev);
+        nccl_check(rccl().CommInitAll(comms.data(), ndev, device_ids), "ncclCommInitAll");
+        for (int d = 0; d < ndev; ++d) M->dev[d].comm = comms[d];
+    }
     return M.release();
 }
 
@@ -170,38 +187,67 @@ void segnet_multi_shape(const SegnetMulti *M, int32_t *T, int32_t *H, int32_t *W
     if (ndev) *ndev = (int)M->dev.size();
 }
 
-void segnet_multi_segment(SegnetMulti *M, const uint8_t *bgr, int rows, int cols, uint64_t seed, uint8_t *classes, double *confidence,
-                          double *entropy) {
+static void multi_frame(SegnetMulti *M, const uint8_t *bgr, int rows, int cols, uint64_t seed, uint8_t *classes, double *confidence,
+                        double *entropy) {
     const int ndev = (int)M->dev.size();
     const int H = M->H, W = M->W;
     const int x_tl = (rows == H && cols == W) ? 0 : cols / 2 - W / 2, y_tl = (rows == H && cols == W) ? 0 : rows / 2 - H / 2;
-    int prev = 0;
-    SIVO_HIP(hipGetDevice(&prev));
-    Rccl &R = rccl();
-    // 1. every device: image up, its samples, chunk-major probability sums
+    const size_t csz = (size_t)M->classes * M->chunk;
+    // 1. every device: image up, its samples, chunk-major f64 probability sums
     for (MultiDevice &D : M->dev) {
         SIVO_HIP(hipSetDevice(D.device));
         SIVO_HIP(hipMemcpy2DAsync(D.d_image, (size_t)W * 3, bgr + ((size_t)y_tl * cols + x_tl) * 3, (size_t)cols * 3, (size_t)W * 3, (size_t)H,
                                   hipMemcpyHostToDevice, D.stream));
         segnet_forward_chunked(D.net, D.d_image, D.n_samples, D.sample0, seed, D.d_sum, M->chunk, D.stream);
     }
-    // 2. reduce-scatter over the pixel chunks
-    nccl_check(R.GroupStart(), "ncclGroupStart");
-    for (MultiDevice &D : M->dev)
-        nccl_check(R.ReduceScatter(D.d_sum, D.d_rs, (size_t)M->classes * M->chunk, ncclFloat, ncclSum, D.comm, D.stream), "ncclReduceScatter");
-    nccl_check(R.GroupEnd(), "ncclGroupEnd");
-    // 3. finalize the own chunk, 4. all-gather the three maps
+    if (M->emulate)
+        for (MultiDevice &D : M->dev) {
+            SIVO_HIP(hipSetDevice(D.device));
+            SIVO_HIP(hipStreamSynchronize(D.stream));
+        }
+    // 2. reduce-scatter over the pixel chunks (f64 sum: (ndev - 1) / ndev of 43 MB per device)
+    if (!M->emulate) {
+        Rccl &R = rccl();
+        nccl_check(R.GroupStart(), "ncclGroupStart");
+        for (MultiDevice &D : M->dev)
+            nccl_check(R.ReduceScatter(D.d_sum, D.d_rs, csz, ncclDouble, ncclSum, D.comm, D.stream), "ncclReduceScatter");
+        nccl_check(R.GroupEnd(), "ncclGroupEnd");
+    } else {
+        for (int d = 0; d < ndev; ++d) {
+            MultiDevice &D = M->dev[d];
+            SIVO_HIP(hipSetDevice(D.device));
+            for (int e = 0; e < ndev; ++e) launch_add_f64(D.d_rs, M->dev[e].d_sum + (size_t)d * csz, (int64_t)csz, e == 0, D.stream);
+        }
+    }
+    // 3. finalize the own chunk (f64 mean of ALL samples), 4. all-gather the three maps
     for (MultiDevice &D : M->dev) {
         SIVO_HIP(hipSetDevice(D.device));
-        launch_mc_finalize(D.d_rs, M->classes, M->chunk, M->T, D.d_cls_chunk, D.d_conf_chunk, D.d_ent_chunk, D.stream);
+        launch_mc_finalize64(D.d_rs, M->classes, M->chunk, M->T, D.d_cls_chunk, D.d_conf_chunk, D.d_ent_chunk, D.stream);
     }
-    nccl_check(R.GroupStart(), "ncclGroupStart");
-    for (MultiDevice &D : M->dev) {
-        nccl_check(R.AllGather(D.d_cls_chunk, D.d_cls, (size_t)M->chunk, ncclUint8, D.comm, D.stream), "ncclAllGather");
-        nccl_check(R.AllGather(D.d_conf_chunk, D.d_conf, (size_t)M->chunk, ncclDouble, D.comm, D.stream), "ncclAllGather");
-        nccl_check(R.AllGather(D.d_ent_chunk, D.d_ent, (size_t)M->chunk, ncclDouble, D.comm, D.stream), "ncclAllGather");
+    if (!M->emulate) {
+        Rccl &R = rccl();
+        nccl_check(R.GroupStart(), "ncclGroupStart");
+        for (MultiDevice &D : M->dev) {
+            nccl_check(R.AllGather(D.d_cls_chunk, D.d_cls, (size_t)M->chunk, ncclUint8, D.comm, D.stream), "ncclAllGather");
+            nccl_check(R.AllGather(D.d_conf_chunk, D.d_conf, (size_t)M->chunk, ncclDouble, D.comm, D.stream), "ncclAllGather");
+            nccl_check(R.AllGather(D.d_ent_chunk, D.d_ent, (size_t)M->chunk, ncclDouble, D.comm, D.stream), "ncclAllGather");
+        }
+        nccl_check(R.GroupEnd(), "ncclGroupEnd");
+    } else {
+        for (MultiDevice &D : M->dev) {
+            SIVO_HIP(hipSetDevice(D.device));
+            SIVO_HIP(hipStreamSynchronize(D.stream));
+        }
+        for (MultiDevice &D : M->dev) {
+            SIVO_HIP(hipSetDevice(D.device));
+            for (int e = 0; e < ndev; ++e) {
+                const MultiDevice &E = M->dev[e];
+                SIVO_HIP(hipMemcpyAsync(D.d_cls + (size_t)e * M->chunk, E.d_cls_chunk, (size_t)M->chunk, hipMemcpyDeviceToDevice, D.stream));
+                SIVO_HIP(hipMemcpyAsync(D.d_conf + (size_t)e * M->chunk, E.d_conf_chunk, (size_t)M->chunk * sizeof(double), hipMemcpyDeviceToDevice, D.stream));
+                SIVO_HIP(hipMemcpyAsync(D.d_ent + (size_t)e * M->chunk, E.d_ent_chunk, (size_t)M->chunk * sizeof(double), hipMemcpyDeviceToDevice, D.stream));
+            }
+        }
     }
-    nccl_check(R.GroupEnd(), "ncclGroupEnd");
     // 5. device 0 hands the maps over
     MultiDevice &D0 = M->dev[0];
     SIVO_HIP(hipSetDevice(D0.device));
@@ -212,8 +258,20 @@ void segnet_multi_segment(SegnetMulti *M, const uint8_t *bgr, int rows, int cols
         SIVO_HIP(hipSetDevice(D.device));
         SIVO_HIP(hipStreamSynchronize(D.stream));
     }
-    (void)ndev;
-    SIVO_HIP(hipSetDevice(prev));
+}
+
+void segnet_multi_segment(SegnetMulti *M, const uint8_t *bgr, int rows, int cols, uint64_t seed, uint8_t *classes, double *confidence,
+                          double *entropy) {
+    DeviceRestore restore;              // also when an RCCL or HIP error unwinds mid-frame
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        multi_frame(M, bgr, rows, cols, seed, classes, confidence, entropy);
+        // a value left the fp16 range on some device: every device's handle switches to the bf16x6 GEMM (the devices must
+        // run the same arithmetic for the maps not to depend on the sharding) and the frame is computed once more
+        bool tripped = false;
+        for (MultiDevice &D : M->dev) tripped = segnet_fp16_overflowed(D.net) || tripped;
+        if (!tripped) break;
+        for (MultiDevice &D : M->dev) segnet_force_bf16x6(D.net);
+    }
 }
 
 }  // namespace sivo

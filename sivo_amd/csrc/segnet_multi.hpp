@@ -16,6 +16,11 @@ void segnet_multi_segment(SegnetMulti *M, const uint8_t *bgr, int rows, int cols
                           double *entropy);
 // segnet.cpp: forward of n samples of a single-device handle, softmax + sum written pixel-chunk-major
 // ([hw / chunk][classes][chunk]); chunk == hw is the plain [classes][hw] layout.
-void segnet_forward_chunked(sivo_segnet_t h, const uint8_t *d_bgr, int n, int sample0, uint64_t seed, float *d_sum_chunked,
+// The sums are the f64 accumulators themselves (not rounded to fp32): added over the devices in f64 they give the
+// reference's f64 mean (bayesian_segnet.cpp:291-294) up to an f64 rounding, whatever the number of devices.
+void segnet_forward_chunked(sivo_segnet_t h, const uint8_t *d_bgr, int n, int sample0, uint64_t seed, double *d_sum_chunked,
                             int64_t chunk, hipStream_t st);
+// true once after a frame of the handle raised the fp16 overflow flag of the f16x3 GEMM (the handle is on bf16x6 from then on)
+bool segnet_fp16_overflowed(sivo_segnet_t h);
+void segnet_force_bf16x6(sivo_segnet_t h);
 }  // namespace sivo

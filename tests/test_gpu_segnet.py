@@ -446,8 +446,8 @@ def test_classifier_fused_with_the_mc_postprocessing(oracle, T, H, W, width, cla
 
 def test_multi_device_handle_on_one_device(oracle, kitti_like_bgr):
     """sivo_segnet_create_multi with device_ids = [0]: the whole multi-device path (chunk-major sums, RCCL communicator,
-    reduce-scatter, per-chunk finalize, all-gather, hand-over) runs, on one rank.  Same maps as the single-device handle up
-    to the fp32 rounding of the probability sums (the single-device entry point keeps them in f64)."""
+    reduce-scatter, per-chunk finalize, all-gather, hand-over) runs, on one rank.  The probability sums travel in f64 (the
+    accumulators themselves), so the maps equal the single-device handle's f64 mean."""
     T, H, W = 4, 32, 64
     text = netspec.tiny_prototxt(T, H, W)
     net, w, sn = _make(text, T)
@@ -456,15 +456,39 @@ def test_multi_device_handle_on_one_device(oracle, kitti_like_bgr):
     big = np.ascontiguousarray(kitti_like_bgr[:80, :150])
     cls_m, conf_m, ent_m = multi.segment_image(big, seed=5)
     cls_s, conf_s, ent_s = sn.segment_image(big, seed=5)
-    np.testing.assert_allclose(conf_m, conf_s, atol=2e-7, rtol=0)
-    np.testing.assert_allclose(ent_m, ent_s, atol=5e-6, rtol=0)
-    assert (cls_m == cls_s).mean() > 0.999
+    assert np.array_equal(conf_m, conf_s) and np.array_equal(ent_m, ent_s) and np.array_equal(cls_m, cls_s)
     res = oracle.segment(net, w, big, 5)
     np.testing.assert_allclose(conf_m, res["confidence"], atol=1e-5, rtol=0)
     with pytest.raises(ValueError):
         multi.forward(torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda"), 1)
     with pytest.raises(ValueError):
         BayesianSegNet(prototxt=text, weights=wts.pack(net["layers"], w), T=T, devices=[0, 0])
+
+
+@pytest.mark.parametrize("ndev,T", [(2, 4), (4, 6), (8, 12), (8, 9)])
+def test_multi_device_handle_emulated_on_one_gpu(ndev, T, kitti_like_bgr):
+    """The index arithmetic of the in-handle multi-GPU path with ndev > 1, without a second GPU: SIVO_MULTI_EMULATE=1 lets
+    device_ids name GPU 0 several times and carries the two collectives out as copies + f64 adds in device order; the rest
+    is the code the RCCL path runs — contiguous sample shards incl. uneven ones (T = 12 over 8 -> 1,1,1,1,2,2,2,2; T = 9 over
+    8), dropout keyed by the global sample, chunk-major f64 sums, reduce-scatter by pixel chunk, per-chunk f64 finalize,
+    gathered maps.  Against the single-device handle: confidence / entropy to 1e-12 (f64 sums added in another order),
+    classes identical except at ties of the mean."""
+    H, W = 32, 64
+    text = netspec.tiny_prototxt(T, H, W)
+    net, w, sn = _make(text, T)
+    os.environ["SIVO_MULTI_EMULATE"] = "1"
+    try:
+        multi = BayesianSegNet(prototxt=text, weights=wts.pack(net["layers"], w), T=T, devices=[0] * ndev)
+    finally:
+        del os.environ["SIVO_MULTI_EMULATE"]
+    big = np.ascontiguousarray(kitti_like_bgr[:80, :150])
+    for seed in (5, 6):
+        cls_m, conf_m, ent_m = multi.segment_image(big, seed=seed)
+        cls_s, conf_s, ent_s = sn.segment_image(big, seed=seed)
+        np.testing.assert_allclose(conf_m, conf_s, atol=1e-12, rtol=0)
+        np.testing.assert_allclose(ent_m, ent_s, atol=1e-11, rtol=0)
+        assert (cls_m != cls_s).sum() <= 2
+    assert torch.cuda.current_device() == 0
 
 
 def _make_env(text, T, seed, **env):

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Where the time of the f16x3 GEMM goes: the production kernel and its compile-time ablations (libsivo_hip_diag.so, `make -C
+sivo_amd/csrc diag`; SIVO_H3_ABL bits: 1 no V' loads, 2 no U' DMA, 4 no M stores, 8 no MFMAs) on the GEMM shapes of
+SegNet-Standard T = 12.  GPU box only.  Usage: python tools/h3_probe.py [iters]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+lib = C.CDLL(os.path.join(ROOT, "sivo_amd", "libsivo_hip_diag.so"))
+lib.sivo_debug_h3_gemm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+lib.sivo_last_error.restype = C.c_char_p
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+SHAPES = [("conv4_2  512->512 44x128", 512, 512, 4224), ("conv5_2  512->512 22x64", 512, 512, 1152),
+          ("conv3_3D 256->256 88x256", 256, 256, 16896), ("conv4_1D 512->256 44x128", 512, 256, 4224)]
+VARIANTS = [("as built", {}), ("no stagger", {"SIVO_H3_STAGGER": "0"}), ("no V loads", {"SIVO_H3_ABL": "1"}), ("no U DMA", {"SIVO_H3_ABL": "2"}),
+            ("no loads at all", {"SIVO_H3_ABL": "3"}), ("no M stores", {"SIVO_H3_ABL": "4"}), ("MFMA + LDS only", {"SIVO_H3_ABL": "7"}),
+            ("no MFMA", {"SIVO_H3_ABL": "8"}), ("no MFMA, no stores", {"SIVO_H3_ABL": "12"})]
+rng = np.random.default_rng(0)
+for name, Cc, Kp, P in SHAPES:
+    Pp = (P + 127) // 128 * 128
+    V = rng.standard_normal((36, Cc, Pp), dtype=np.float32)
+    U = (rng.standard_normal((36, Cc, Kp), dtype=np.float32) * 0.05).astype(np.float32)
+    M = np.empty((36, Kp, Pp), np.float32)
+    flop = 2.0 * 36 * Cc * Kp * P * 3          # executed fp16 products
+    for vname, env in VARIANTS:
+        if "SIVO_H3_STAGGER" in env:
+            continue                              # (static in the launcher: needs its own process; see bench SIVO_H3_STAGGER=0)
+        for k in ("SIVO_H3_ABL",):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        ms = C.c_double(0)
+        rc = lib.sivo_debug_h3_gemm(Cc, Kp, P, V.ctypes.data, U.ctypes.data, C.c_float(16.0), M.ctypes.data, iters, C.byref(ms))
+        if rc:
+            print(name, vname, "error", lib.sivo_last_error().decode()); continue
+        print(f"{name:26s} {vname:20s} {ms.value:8.4f} ms   {flop / ms.value / 1e9:8.1f} TFLOP/s executed", flush=True)
