@@ -775,6 +775,8 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                 break;
         }
         if (bracket) SIVO_HIP(hipEventRecord(op.ev1, st));
+        static const bool debug_sync = std::getenv("SIVO_DEBUG_SYNC") != nullptr;      // debugging aid: serialise every op of every lane
+        if (debug_sync) SIVO_HIP(hipDeviceSynchronize());
     }
 }
 

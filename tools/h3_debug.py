@@ -73,3 +73,36 @@ if what in ("net", "all"):
                 info = f" BIG {big.sum()} samples {sorted(set(ns.tolist()))} ch {cs.min()}-{cs.max()} ({len(set(cs.tolist()))}) y {ys.min()}-{ys.max()} x {xs.min()}-{xs.max()} tiles(y//4,x//4) {sorted(set(zip((ys // 4).tolist(), (xs // 4).tolist())))[:12]}"
             print(f"{name:10s} max|d| {d.max():.3e} at n{n} c{c} y{y} x{x}; max|x6| {np.abs(b).max():.2f} finite {np.isfinite(a).all()}{info}", flush=True)
         print("status after", h3.gemm_status()[:2])
+
+if what == "coresident":
+    # the GEMM alone, while a second thread keeps small-LDS workgroups (wino4_bridge_kernel of a narrow bridged stack) on the CUs
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_segnet import _conv_stack_prototxt
+    from oracle import prototxt as oproto
+    T2, H2, W2, width = 3, 22, 64, 256
+    t2 = _conv_stack_prototxt(T2, H2, W2, width)
+    n2 = oproto.parse(t2)
+    small = BayesianSegNet(prototxt=t2, weights=wts.pack(n2["layers"], wts.synth_weights(n2["layers"], 5)), T=T2)
+    img2 = torch.randint(0, 256, (H2, W2, 3), dtype=torch.uint8, device="cuda")
+    stop = [False]
+
+    def spam():
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            while not stop[0]:
+                for _ in range(20):
+                    small.forward(img2, 1)
+                st.synchronize()
+    th = threading.Thread(target=spam); th.start()
+    rng = np.random.default_rng(1)
+    for C, Kp, P in [(256, 512, 1408), (512, 512, 4224), (256, 128, 5632)]:
+        Pp = (P + 127) // 128 * 128
+        V = rng.standard_normal((36, C, Pp)).astype(np.float32); U = (rng.standard_normal((36, C, Kp)) * 0.05).astype(np.float32)
+        ref, _ = h3_gemm(V, U, P)
+        bad = 0
+        for it in range(8):
+            M, _ = h3_gemm(V, U, P)
+            bad += int(not np.array_equal(M, ref))
+        print(f"coresident gemm C={C} Kp={Kp} P={P}: {bad} of 8 runs differ from the first", flush=True)
+    stop[0] = True; th.join()
