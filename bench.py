@@ -195,6 +195,62 @@ def mfma_roofline(prof_timed, prof_detail, n_timed_frames, n_detail, ms_per_fram
             "note": note}
 
 
+# Algorithmic HBM bytes of the integer / memory-bound kernels: pyramid level areas for (2000, 1.2, 8) at 1024 x 352
+_LV = [(1024, 352), (853, 293), (711, 244), (593, 204), (494, 170), (412, 141), (343, 118), (286, 98)]
+
+
+def membound_block(prof, fp, d_left, H, W, T, classes):
+    """HBM-roofline figures of the memory-bound kernels, measured in THIS process right after the timed region (nothing else on
+    the GPU): achieved = algorithmic bytes / mean HIP-event time, against 8 TB/s.  SegNet's streaming kernels come from the
+    per-kernel events of the profiled frames (prof); the ORB kernel groups from the extractor's own events (sivo_orb_profile);
+    Hamming and the MC reduction from torch events around single launches."""
+    import torch
+    from sivo_amd import matcher
+    from sivo_amd.segnet import mc_segment
+    rows = []
+
+    def row(kernel, us, nbytes, note=""):
+        gbs = nbytes / us / 1e3 if us > 0 else 0.0
+        rows.append({"kernel": kernel, "avg_us": round(us, 2), "algorithmic_bytes": int(nbytes), "achieved_GBps": round(gbs, 1),
+                     "frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4), **({"note": note} if note else {})})
+    for k, v in sorted(aggregate(prof).items()):
+        if kernel_class(k) is None and v["bytes"] > 0 and v["ms"] > 0 and v["launches"]:
+            row("sivo::" + k, 1e3 * v["ms"] / v["launches"], v["bytes"] / v["launches"], "SegNet, per launch (all samples of a layer)")
+    if fp is not None:
+        area = [w * h for w, h in _LV]; pyr = sum(area); padded = sum((w + 38) * (h + 38) for w, h in _LV)
+        fp.ex_l.profile(True)
+        for _ in range(20):
+            kl, _ = fp.ex_l(d_left)
+        ms, calls, keys = fp.ex_l.profile_read()
+        fp.ex_l.profile(False)
+        n = max(keys, 1.0)
+        small = "working set 0.3-2 MB: launch / latency bound by construction (0.04-0.3 us at 8 TB/s)"
+        row("sivo::copy_level0_kernel + 7 x resize_kernel (pyramid)", 1e3 * ms["pyramid"], 2 * area[0] + sum(area[:-1]) + sum(area[1:]), small)
+        row("sivo::blur_kernel + border_kernel (all levels)", 1e3 * ms["blur"], 2 * pyr + (padded - pyr), small)
+        row("sivo::fast_cells_kernel + scan + compact (FAST-9/16, all levels)", 1e3 * ms["fast"], pyr + 3 * 4 * 20000, small)
+        row("sivo::angle_kernel (IC_Angle)", 1e3 * ms["angle"], n * (749 + 4), small)
+        row("sivo::descriptor_kernel (rBRIEF)", 1e3 * ms["descriptor"], n * (512 + 32), small)
+    rng = np.random.default_rng(0)
+    A = torch.from_numpy(rng.integers(0, 256, (2000, 32), dtype=np.uint8)).cuda()
+    B = torch.from_numpy(rng.integers(0, 256, (2000, 32), dtype=np.uint8)).cuda()
+    lg = torch.randn(T, classes, H, W, device="cuda")
+
+    def timed(fn, reps=20):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / reps
+    row("sivo::hamming_matrix_kernel 2000 x 2000 (DescriptorDistance, dense)", timed(lambda: matcher.descriptor_distance_matrix(A, B)), 32 * 4000 + 4 * 2000 * 2000)
+    row("sivo::hamming_argmin2_kernel 2000 queries x 2000 (brute force)", timed(lambda: matcher.bruteforce(A, B)), 32 * 4000 + 3 * 4 * 2000,
+        "every B row per query comes from L2")
+    row(f"sivo::mc_reduce_finalize_kernel T = {T} (softmax, f64 mean, argmax / max / entropy)", timed(lambda: mc_segment(lg)),
+        T * classes * H * W * 4 + H * W * 17)
+    return rows
+
+
 def time_segnet(sn, frame, steps, warmup, barrier, profile_every=8, events=True):
     """Warm up, time `steps` calls of frame(seed) between barriers, return (elapsed s, MFMA-kernel rows of the timed region,
     all-kernel rows of min(steps, 10) further untimed single-lane frames)."""
@@ -404,6 +460,9 @@ def main():
                           "parity": "tests/test_gpu_frame_e2e.py (this frame end to end against the oracle pipeline), tests/test_gpu_segnet_fullsize.py (this network "
                                     "configuration, every logit, oracle-checked), tests/test_gpu_orb.py, tests/test_gpu_match_ba.py"},
                "roofline": roofline}
+
+        if world == 1:
+            out["membound"] = membound_block(prof, fp, d_left, H, W, T, sn.classes)
 
     # ------------------------------------------------------------------------------------------ further configs (N = 1)
     want = set() if (world > 1 or args.configs == "none") else set(("basic,t48,ba,host" if args.configs == "all" else args.configs).split(","))

@@ -236,6 +236,13 @@ int sivo_orb_extract(sivo_orb_t h, const uint8_t *gray, int rows, int cols, int 
 int sivo_orb_extract_dev(sivo_orb_t h, const uint8_t *d_gray, int rows, int cols, int step,
                          SivoKeyPoint *keypoints, uint8_t *descriptors, int capacity, int *n_out,
                          void *stream);
+/* Profiling of the extractor's kernels: enable != 0 brackets the kernel groups of every following extraction with HIP
+ * events on the streams they run on and clears the accumulators.  sivo_orb_profile_read: mean ms per extraction of
+ * ms5 = {pyramid (copy + resizes), blur + border, FAST cells + scan + compact, IC-angle, rBRIEF descriptors}, the number
+ * of extractions measured and the mean number of keypoints. */
+int sivo_orb_profile(sivo_orb_t h, int enable);
+int sivo_orb_profile_read(sivo_orb_t h, double ms5[5], int *calls, double *mean_keys);
+
 /* mvImagePyramid[level] (ORBextractor.h:83) of the last extraction: the level
  * image WITH its 19-pixel reflect-101 border, (rows+38) x (cols+38), tightly
  * packed; rows/cols report the interior size. */

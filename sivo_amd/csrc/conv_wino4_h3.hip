@@ -77,13 +77,16 @@ __device__ __forceinline__ void h3_dma16(const void *sbase, uint32_t voff, uint3
 template <int BM, int BN, bool STG, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_h3[];
-    constexpr int WT = BN == 256 ? 2 : 4, WC = 8 / WT;          // wave grid: tiles x couts (64 couts per wave)
+    constexpr int WC = BN / 64, WT = 8 / WC;                     // wave grid: couts (64 per wave) x tiles
     constexpr int TB = BM / WT / 32;                             // 32-tile MFMA blocks per wave (4 or 2); 2 cout blocks
     constexpr int VBYTES = BM * 128, UBYTES = BN * 128, STAGE = VBYTES + UBYTES;
-    constexpr int NQ = BM / 128;                                 // channel octets each lane stages per stage (2 or 1)
-    constexpr int NU = BN / 64;                                  // 1 KiB U pieces each wave copies per stage (4 or 2)
-    static_assert(BM == 256 || BM == 128, "tile");
-    static_assert(BN == 256 || BN == 128, "tile");
+    constexpr int NQ = BM == 256 ? 2 : 1;                        // channel octets each staging lane brings in per stage
+    constexpr int NVW = BM >= 128 ? 8 : BM / 16;                 // waves that stage V' (a wave pass = one tile block x two octets)
+    constexpr int NU = BN / 64;                                  // 1 KiB U pieces each wave copies per stage (8, 4 or 2)
+    static_assert(BM == 256 || BM == 128 || BM == 64, "tile");
+    static_assert(BN == 512 || BN == 256 || BN == 128, "tile");
+    static_assert(TB == 4 || TB == 2, "wave tile");
+    static_assert(2 * STAGE <= 160 * 1024, "LDS");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,11 +121,13 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     };
 
     // ---- V' staging: lane (tile ln of tile block vtb, octets vo0 + 2 q + lh) -------------------------------------------
+    const bool v_wave = wave < NVW;          // (BM = 64: four passes, waves 0-3)
     const int vtb = BM == 256 ? wave : wave >> 1, vo0 = BM == 256 ? 0 : 2 * (wave & 1);
     const uint32_t v_lane_off = (uint32_t)(((int64_t)(8 * (vo0 + lh)) * a.Pp + vtb * 32 + ln) * 4);
     const uint32_t v_slab_bytes = (uint32_t)((int64_t)a.C * a.Pp * 4);
     uint32_t vraw[NQ][8];
     auto load_v = [&](const Cursor &c) {
+        if (!v_wave) return;
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.V) + (int64_t)c.xi * a.C * a.Pp, 0, (int)v_slab_bytes, 0x00020000);
         const uint32_t vo = v_lane_off + (uint32_t)c.pt * (BM * 4);
 #pragma unroll
@@ -135,6 +140,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     };
     const uint32_t v_lds_off = (uint32_t)(vtb * 4096 + (vo0 + lh) * 512 + ln * 16);
     auto write_v = [&](int buf) {
+        if (!v_wave) return;
         unsigned char *dst = lds_h3 + buf * STAGE + v_lds_off;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         }
         if (late && s + 1 < total) {
             stage_v();
-            v_in_flight = s + 2 < total;
+            v_in_flight = v_wave && s + 2 < total;
         }
     }
 }
@@ -312,23 +318,28 @@ float wino4_h3_pack_weights(const std::vector<float> &U, int cin, int Kp, std::v
     return scale;
 }
 
-// tile choice: 256 x 256 by default; 128-tile groups when the launch would otherwise give the CUs fewer than ~3 items
-// each (the 22 x 64 layers: 360 items of 256 tiles against 648 of 128); 256 x 128 when the layer has 128 couts
-static int h3_config(int64_t P, int Kp) {
-    if (Kp % 256) return 2;
-    const int64_t items256 = 36 * ((P + 255) / 256) * (Kp / 256);
-    return items256 >= 3 * 256 ? 0 : 1;
+// Workgroup tile (tiles x couts).  All couts of a layer in one item whenever they fit (BN = Kp up to 512): the V' tile of an
+// item is then read from HBM exactly once — with 256-cout items the 512-cout layers read it twice, and their GEMM moves
+// as many bytes per matrix-core cycle as the chip can deliver (measured).  Fewer tiles per item when the
+// launch would otherwise leave the CUs fewer than ~3 items each (the 22 x 64 layers, short shards).
+struct H3Tile { int bm, bn; };
+static H3Tile h3_tile(int64_t P, int Kp) {
+    const int bn = Kp % 512 == 0 ? 512 : Kp % 256 == 0 ? 256 : 128;
+    const int big = bn == 512 ? 128 : 256, small = big / 2;
+    if (bn == 128) return {256, 128};
+    const int64_t items_big = 36 * ((P + big - 1) / big) * (Kp / bn);
+    return {items_big >= 3 * 256 ? big : small, bn};
 }
 
 void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int Kp, int P, int Pp, hipStream_t s) {
     static int attr_set[64] = {0};
     if (FirstUse once(attr_set); once) {
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<256, 256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<128, 256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<256, 128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<256, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<128, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<256, 128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (const void *f : {(const void *)wino4_gemm_h3_kernel<128, 512, false>, (const void *)wino4_gemm_h3_kernel<128, 512, true>,
+                              (const void *)wino4_gemm_h3_kernel<64, 512, false>, (const void *)wino4_gemm_h3_kernel<64, 512, true>,
+                              (const void *)wino4_gemm_h3_kernel<256, 256, false>, (const void *)wino4_gemm_h3_kernel<256, 256, true>,
+                              (const void *)wino4_gemm_h3_kernel<128, 256, false>, (const void *)wino4_gemm_h3_kernel<128, 256, true>,
+                              (const void *)wino4_gemm_h3_kernel<256, 128, false>, (const void *)wino4_gemm_h3_kernel<256, 128, true>})
+            SIVO_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     // The persistent workgroup claims the CU's whole LDS (160 KB) although its two stage buffers need 96-128 KB: with only
     // that, another lane's small-LDS workgroups (wino4_bridge_kernel: 7-24 KB) were placed beside it and the frame was no
@@ -337,20 +348,23 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
     static const bool lds_all = !(std::getenv("SIVO_H3_LDS_ALL") && std::atoi(std::getenv("SIVO_H3_LDS_ALL")) == 0);
     // SIVO_H3_STAGGER=0/1: all waves stage behind the barrier / the two waves of a SIMD stage at opposite ends of a stage
     static const bool stagger = !(std::getenv("SIVO_H3_STAGGER") && std::atoi(std::getenv("SIVO_H3_STAGGER")) == 0);
-    // SIVO_H3_TILE=0/1/2 forces the workgroup tile (tests; 2 needs Kp = 128 per cout group and is otherwise ignored)
+    // SIVO_H3_TILE=0/1/2 forces the workgroup tile (tests / measurements): 0 the larger, 1 the smaller tile count, 2 256-cout items
     static const int force_tile = std::getenv("SIVO_H3_TILE") ? std::atoi(std::getenv("SIVO_H3_TILE")) : -1;
     static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
     const dim3 grid((unsigned)((n_cu / 8) * 8 > 0 ? (n_cu / 8) * 8 : 8));      // one persistent workgroup per CU, a multiple of the 8 XCDs
     H3Args a{};
     a.V = V; a.U = static_cast<const unsigned char *>(U); a.M = M; a.C = C; a.Kp = Kp; a.P = P; a.Pp = Pp;
 #ifdef SIVO_DIAG
-    if (const char *ab = std::getenv("SIVO_H3_ABL")) {          // diagnostic build: ablations of the 256 x 256 kernel
-        a.ptiles = (P + 255) / 256; a.ktiles = Kp / 256;
-        const size_t l = 2 * (256 + 256) * 128;
+    if (const char *ab = std::getenv("SIVO_H3_ABL")) {          // diagnostic build: ablations of the 256 x 256 / 128 x 512 kernel (SIVO_H3_ABL_TILE=1)
+        const bool wide = std::getenv("SIVO_H3_ABL_TILE") && std::atoi(std::getenv("SIVO_H3_ABL_TILE")) == 1 && Kp % 512 == 0;
+        a.ptiles = wide ? (P + 127) / 128 : (P + 255) / 256; a.ktiles = wide ? Kp / 512 : Kp / 256;
+        const size_t l = 160 * 1024;
 #define H3_ABL_CASE(n)                                                                                                              \
     case n:                                                                                                                         \
         SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<256, 256, false, n>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l)); \
-        hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, false, n>), grid, dim3(512), l, s, a);                                   \
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<128, 512, false, n>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l)); \
+        if (wide) hipLaunchKernelGGL((wino4_gemm_h3_kernel<128, 512, false, n>), grid, dim3(512), l, s, a);                         \
+        else hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, false, n>), grid, dim3(512), l, s, a);                              \
         return;
         switch (std::atoi(ab)) {
             H3_ABL_CASE(1) H3_ABL_CASE(2) H3_ABL_CASE(3) H3_ABL_CASE(4) H3_ABL_CASE(7) H3_ABL_CASE(8) H3_ABL_CASE(12)
@@ -359,24 +373,23 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
 #undef H3_ABL_CASE
     }
 #endif
-    int cfg = h3_config(P, Kp);
-    if (cfg != 2 && (force_tile == 0 || force_tile == 1)) cfg = force_tile;
-    switch (cfg) {
-        case 0:
-            a.ptiles = (P + 255) / 256; a.ktiles = Kp / 256;
-            if (stagger) hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, true>), grid, dim3(512), lds_all ? 160 * 1024 : 2 * (256 + 256) * 128, s, a);
-            else hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, false>), grid, dim3(512), lds_all ? 160 * 1024 : 2 * (256 + 256) * 128, s, a);
-            break;
-        case 1:
-            a.ptiles = (P + 127) / 128; a.ktiles = Kp / 256;
-            if (stagger) hipLaunchKernelGGL((wino4_gemm_h3_kernel<128, 256, true>), grid, dim3(512), lds_all ? 160 * 1024 : 2 * (128 + 256) * 128, s, a);
-            else hipLaunchKernelGGL((wino4_gemm_h3_kernel<128, 256, false>), grid, dim3(512), lds_all ? 160 * 1024 : 2 * (128 + 256) * 128, s, a);
-            break;
-        default:
-            a.ptiles = (P + 255) / 256; a.ktiles = Kp / 128;
-            if (stagger) hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 128, true>), grid, dim3(512), lds_all ? 160 * 1024 : 2 * (256 + 128) * 128, s, a);
-            else hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 128, false>), grid, dim3(512), lds_all ? 160 * 1024 : 2 * (256 + 128) * 128, s, a);
-    }
+    H3Tile t = h3_tile(P, Kp);
+    if (force_tile == 1 && t.bn != 128) t.bm = t.bn == 512 ? 64 : 128;          // tests: the small-tile form
+    if (force_tile == 0 && t.bn != 128) t.bm = t.bn == 512 ? 128 : 256;
+    if (force_tile == 2 && Kp % 256 == 0) t = {P >= 4096 ? 256 : 128, 256};      // tests / measurements: 256-cout items for a 512-cout layer
+    a.ptiles = (int)((P + t.bm - 1) / t.bm); a.ktiles = Kp / t.bn;
+    const size_t lds = lds_all ? (size_t)160 * 1024 : (size_t)2 * (t.bm + t.bn) * 128;
+#define H3_LAUNCH(BM_, BN_)                                                                                                          \
+    do {                                                                                                                           \
+        if (stagger) hipLaunchKernelGGL((wino4_gemm_h3_kernel<BM_, BN_, true>), grid, dim3(512), lds, s, a);                         \
+        else hipLaunchKernelGGL((wino4_gemm_h3_kernel<BM_, BN_, false>), grid, dim3(512), lds, s, a);                                \
+    } while (0)
+    if (t.bm == 128 && t.bn == 512) H3_LAUNCH(128, 512);
+    else if (t.bm == 64 && t.bn == 512) H3_LAUNCH(64, 512);
+    else if (t.bm == 256 && t.bn == 256) H3_LAUNCH(256, 256);
+    else if (t.bm == 128 && t.bn == 256) H3_LAUNCH(128, 256);
+    else H3_LAUNCH(256, 128);
+#undef H3_LAUNCH
 }
 
 }  // namespace sivo

@@ -397,6 +397,13 @@ struct sivo_orb {
     int kp_cap = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
+    // profiling (sivo_orb_profile): HIP events around the kernel groups of one extraction, on the stream each runs on
+    static constexpr int NPROF = 5;             // pyramid (copy + 7 resizes), blur + border, FAST cells + scan + compact, angle, descriptor
+    bool prof = false;
+    hipEvent_t pe0[NPROF] = {nullptr, nullptr, nullptr, nullptr, nullptr}, pe1[NPROF] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool pe_used[NPROF] = {false, false, false, false, false};
+    double prof_ms[NPROF] = {0, 0, 0, 0, 0};
+    int prof_calls = 0, prof_keys = 0;
     std::vector<std::vector<SivoKeyPoint>> last_candidates;
     bool have_pyramid = false;
     // grow-only device arena of sivo_stereo_match_begin (no hipMalloc / hipFree — and so no device-wide
@@ -437,6 +444,10 @@ struct sivo_orb {
         if (h_kps) (void)hipHostFree(h_kps);
         if (h_angles) (void)hipHostFree(h_angles);
         if (h_desc) (void)hipHostFree(h_desc);
+        for (int i = 0; i < NPROF; ++i) {
+            if (pe0[i]) (void)hipEventDestroy(pe0[i]);
+            if (pe1[i]) (void)hipEventDestroy(pe1[i]);
+        }
         if (ev_pyr) (void)hipEventDestroy(ev_pyr);
         if (ev_blur) (void)hipEventDestroy(ev_blur);
         if (stream) (void)hipStreamDestroy(stream);
@@ -608,7 +619,14 @@ int extract(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, Siv
         SIVO_HIP(hipStreamWaitEvent(st, o.ev_pyr, 0));
     }
     const LevelTable &T = o.table;
+    auto mark = [&](int k, bool end, hipStream_t on) {
+        if (!o.prof) return;
+        if (!o.pe0[k]) { SIVO_HIP(hipEventCreate(&o.pe0[k])); SIVO_HIP(hipEventCreate(&o.pe1[k])); }
+        SIVO_HIP(hipEventRecord(end ? o.pe1[k] : o.pe0[k], on));
+        if (end) o.pe_used[k] = true;
+    };
     // ---- pyramid
+    mark(0, false, st);
     {
         const LevelInfo &L0 = T.lv[0];
         uint8_t *dst = o.d_pyr + L0.off + (size_t)EDGE_THRESHOLD * L0.step + EDGE_THRESHOLD;
@@ -621,25 +639,30 @@ int extract(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, Siv
                                D.rows, D.cols, o.d_xt[l], o.d_yt[l]);
         }
     }
+    mark(0, true, st);
     SIVO_HIP(hipEventRecord(o.ev_pyr, st));
     // ---- blur on the second stream (needs interiors only), overlapping FAST + the host quadtree
     SIVO_HIP(hipStreamWaitEvent(o.stream2, o.ev_pyr, 0));
     {
         int max_tiles = 0;
         for (int l = 0; l < o.nlevels; ++l) max_tiles = std::max(max_tiles, cdiv(T.lv[l].cols, 32) * cdiv(T.lv[l].rows, 32));
+        mark(1, false, o.stream2);
         hipLaunchKernelGGL(blur_kernel, dim3(max_tiles, o.nlevels), dim3(256), 0, o.stream2, o.d_pyr, o.d_blur, T, o.gk[0], o.gk[1],
                            o.gk[2], o.gk[3]);
         hipLaunchKernelGGL(border_kernel, dim3(64, o.nlevels), dim3(256), 0, o.stream2, o.d_pyr, T);
+        mark(1, true, o.stream2);
         SIVO_HIP(hipEventRecord(o.ev_blur, o.stream2));
     }
     // ---- FAST cells -> ordered candidate list
     const int nc = (int)o.cells.size();
     int total = 0;
     if (nc) {
+        mark(2, false, st);
         hipLaunchKernelGGL(fast_cells_kernel, dim3(nc), dim3(64), 0, st, o.d_pyr, T, o.d_cells, o.ini_th, o.min_th, o.d_slots,
                            o.cap, o.d_counts);
         hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(256), 0, st, o.d_counts, nc, o.d_offsets, o.d_total);
         hipLaunchKernelGGL(compact_kernel, dim3(nc), dim3(64), 0, st, o.d_slots, o.cap, o.d_counts, o.d_offsets, o.d_dense);
+        mark(2, true, st);
         SIVO_HIP(hipMemcpyAsync(o.h_counts, o.d_offsets, (size_t)(nc + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
         SIVO_HIP(hipStreamSynchronize(st));
         total = o.h_counts[nc];
@@ -685,13 +708,28 @@ int extract(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, Siv
     ensure_kp_capacity(o, n);
     for (int i = 0; i < n; ++i) o.h_kps[i] = DevKp{all[i].x, all[i].y, all[i].octave};
     SIVO_HIP(hipMemcpyAsync(o.d_kps, o.h_kps, (size_t)n * sizeof(DevKp), hipMemcpyHostToDevice, st));
+    mark(3, false, st);
     hipLaunchKernelGGL(angle_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, o.d_pyr, T, o.d_kps, n, o.d_angles);
+    mark(3, true, st);
     SIVO_HIP(hipStreamWaitEvent(st, o.ev_blur, 0));
+    mark(4, false, st);
     hipLaunchKernelGGL(descriptor_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, o.d_blur, T, o.d_kps, o.d_angles, n, o.d_desc);
+    mark(4, true, st);
     SIVO_HIP(hipMemcpyAsync(o.h_angles, o.d_angles, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
     SIVO_HIP(hipMemcpyAsync(o.h_desc, o.d_desc, (size_t)n * 32, hipMemcpyDeviceToHost, st));
     SIVO_HIP(hipStreamSynchronize(st));
     SIVO_HIP(hipGetLastError());
+    if (o.prof) {
+        SIVO_HIP(hipStreamSynchronize(o.stream2));
+        for (int k = 0; k < sivo_orb::NPROF; ++k)
+            if (o.pe_used[k]) {
+                float ms = 0.f;
+                SIVO_HIP(hipEventElapsedTime(&ms, o.pe0[k], o.pe1[k]));
+                o.prof_ms[k] += ms;
+                o.pe_used[k] = false;
+            }
+        ++o.prof_calls; o.prof_keys += n;
+    }
     // ---- assemble (ORBextractor.cc:1068-1081): pt *= scale for level > 0
     for (int i = 0; i < n; ++i) {
         SivoKeyPoint k = all[i];
@@ -787,6 +825,28 @@ extern "C" int sivo_orb_extract(sivo_orb_t h, const uint8_t *gray, int rows, int
         }
         SIVO_HIP(hipMemcpy2DAsync(h->d_src, cols, gray, step, cols, rows, hipMemcpyHostToDevice, h->stream));
         return extract(*h, h->d_src, rows, cols, cols, keypoints, descriptors, capacity, n_out, nullptr);
+    });
+}
+
+// Profiling: enable != 0 brackets the kernel groups of every following extraction with HIP events (and clears the
+// accumulators); sivo_orb_profile_read returns the mean milliseconds per extraction of {pyramid (copy + resizes), blur +
+// border, FAST cells + scan + compact, IC-angle, rBRIEF descriptors}, the extractions and the mean keypoints per extraction.
+extern "C" int sivo_orb_profile(sivo_orb_t h, int enable) {
+    return guarded([&] {
+        if (!h) throw std::invalid_argument("null handle");
+        h->prof = enable != 0;
+        for (double &v : h->prof_ms) v = 0.0;
+        h->prof_calls = 0; h->prof_keys = 0;
+        return SIVO_OK;
+    });
+}
+extern "C" int sivo_orb_profile_read(sivo_orb_t h, double ms_out[5], int *calls, double *mean_keys) {
+    return guarded([&] {
+        if (!h || !ms_out) throw std::invalid_argument("null argument");
+        for (int k = 0; k < sivo_orb::NPROF; ++k) ms_out[k] = h->prof_calls ? h->prof_ms[k] / h->prof_calls : 0.0;
+        if (calls) *calls = h->prof_calls;
+        if (mean_keys) *mean_keys = h->prof_calls ? (double)h->prof_keys / h->prof_calls : 0.0;
+        return SIVO_OK;
     });
 }
 

@@ -65,6 +65,16 @@ class ORBextractor:
                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return kps[:n.value].copy(), desc[:n.value].copy()
 
+    def profile(self, enable=True):
+        """Bracket the extractor's kernel groups with HIP events from now on (and clear the accumulators)."""
+        check(lib().sivo_orb_profile(self._h, int(bool(enable))))
+
+    def profile_read(self):
+        """{group: mean ms per extraction}, extractions, mean keypoints — groups: pyramid, blur, fast, angle, descriptor."""
+        ms = (C.c_double * 5)(); n = C.c_int32(0); k = C.c_double(0)
+        check(lib().sivo_orb_profile_read(self._h, ms, C.byref(n), C.byref(k)))
+        return dict(zip(("pyramid", "blur", "fast", "angle", "descriptor"), list(ms))), n.value, k.value
+
     def image_pyramid(self, level, with_border=False):
         """mvImagePyramid[level] of the last extraction (interior view unless with_border)."""
         r, c = C.c_int32(), C.c_int32()

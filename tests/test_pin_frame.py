@@ -29,6 +29,14 @@ def _check(pipeline):
         assert int((got["right"] >= 0).sum()) == want["matched"] > 20, name
         if HAVE_REF:
             ref = P.reference_frame(left, right, classes, cfg, pr)
+            if P.digest(ref, P.FRAME_FIELDS) != {k: want[k] for k in ("n_semantic",) + P.FRAME_FIELDS}:
+                # The reference constructor runs its two extractors on two std::threads (Frame.cc:126-129).  Once in three runs
+                # of the GPU suite on the 256-core GPU box (never on the 8-core build box) the reference library returned an
+                # mvuRight that differs from its own committed digest for the first scene while `got` equalled the digest; say so
+                # and run the reference once more — a real regression fails both times and fails the digest comparison above
+                bad = [f for f in P.FRAME_FIELDS if P.digest(ref, (f,))[f] != want[f]]
+                print(f"[pin_frame] reference build deviates from its committed digest on {name}: {bad}; running it again")
+                ref = P.reference_frame(left, right, classes, cfg, pr)
             assert ref["keys"].tobytes() == got["keys"].tobytes() and np.array_equal(ref["desc"], got["desc"]), name
             assert np.array_equal(ref["right"].view(np.uint32), got["right"].view(np.uint32)), name
             assert np.array_equal(ref["depth"].view(np.uint32), got["depth"].view(np.uint32)), name
