@@ -21,13 +21,13 @@
 // order; workgroup tile BM tiles x BN couts (256 x 256; 128 x 256 for launches with few tiles; 256 x 128 for Kp = 128),
 // 8 waves = 2 per SIMD, wave tile (BM / WT) tiles x 64 couts as 32 x 32 MFMA blocks (128 / 64 accumulator registers).
 // A stage is 32 channels: 2 k-steps of v_mfma_f32_32x32x16_f16, 48 (24) MFMAs per wave against 24 (16) ds_read_b128.
-// Staging, two LDS buffers of (BM + BN) * 128 bytes, ONE barrier per stage:
+// Staging (two V' and three U' buffers in LDS, loads two stages deep — see the kernel), ONE barrier per stage:
 //   * U': LDS-DMA issued in inline assembly (lds_dma.hpp: invisible to hipcc's waitcnt pass), 1 KiB pieces that are
 //     already in fragment order — the 64 lanes of a ds_read_b128 read 1 KiB contiguous;
 //   * V': every lane loads the 8 (16) channel values of its tile with buffer loads (row offset in an SGPR, no address
 //     arithmetic), de-interleaves hi and lo with v_perm_b32 (one per register) and writes the two fragment pieces of a
-//     channel octet with ds_write_b128 — one stage behind the loads, right after the barrier ("write late, re-issue at
-//     once"): the loads of stage s + 2 and the DMA of stage s + 1 are in flight while stage s is multiplied.
+//     channel octet with ds_write_b128 — two stages behind the loads, right after the barrier ("write late, re-issue at
+//     once"): the loads of stages s + 2, s + 3 and the DMA of stages s + 1, s + 2 are in flight while stage s is multiplied.
 // Fragment order = [32-row block][plane][channel octet][row]: every ds_read_b128 / ds_write_b128 touches consecutive
 // 16-byte pieces in lane order, conflict-free without any swizzle.
 // C/D mapping of the 32 x 32 MFMA: column = lane & 31 = tile, so one accumulator register of a wave is two 128-byte
@@ -49,6 +49,7 @@ namespace sivo {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int H3_KC = 32;                    // channels per stage
 
@@ -69,24 +70,31 @@ __device__ __forceinline__ void h3_dma16(const void *sbase, uint32_t voff, uint3
                  : "memory");
 }
 
-// STG: the two waves of a SIMD (w and w + 4) stage their V' share at opposite ends of a stage — waves 0-3 right behind the
-// barrier, waves 4-7 behind their MFMAs — so that one wave's perms / LDS stores / load issue run beside the other's MFMAs
-// instead of all eight waves staging at once with the matrix cores idle.
+// Pipeline, two stages deep (round 3, after the ablations of tools/h3_probe.py: with ONE stage of loads in flight the memory
+// side of a stage — 64 KB per CU — took as long as its MFMAs and the two did not overlap: 0.31 ms as built against 0.20 ms
+// with the loads removed and 0.21 ms with the MFMAs removed, conv4_2; bytes in flight / latency is what a CU gets):
+//   iteration s:  wait until only the operations issued in iteration s - 1 are still in flight (vector-memory operations
+//                 complete in issue order)  ->  barrier  ->  M stores of an item that ended with stage s - 1  ->  V'(s + 1)
+//                 registers -> LDS  ->  issue V'(s + 3) loads into those registers  ->  issue U'(s + 2) DMA  ->  multiply stage s.
+// LDS: two V' buffers + THREE U' buffers ((2 BM + 3 BN) * 128 bytes: 160 KB for 256 x 256); two V' register sets, indexed
+// statically (the stage loop is unrolled by two).  The M stores of an item are issued at the top of the NEXT iteration,
+// ahead of its loads, so that they have a whole stage to drain and never stand between a wait and the loads it leaves in flight.
 // ABL (diagnostic builds only, -DSIVO_DIAG -> libsivo_hip_diag.so, tools/h3_probe.py; results are wrong by construction):
 // 1 no V' loads after the prologue, 2 no U' DMA after the prologue, 4 no M stores, 8 no MFMAs.
-template <int BM, int BN, bool STG, int ABL = 0>
+template <int BM, int BN, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_h3[];
     constexpr int WC = BN / 64, WT = 8 / WC;                     // wave grid: couts (64 per wave) x tiles
     constexpr int TB = BM / WT / 32;                             // 32-tile MFMA blocks per wave (4 or 2); 2 cout blocks
-    constexpr int VBYTES = BM * 128, UBYTES = BN * 128, STAGE = VBYTES + UBYTES;
-    constexpr int NQ = BM == 256 ? 2 : 1;                        // channel octets each staging lane brings in per stage
-    constexpr int NVW = BM >= 128 ? 8 : BM / 16;                 // waves that stage V' (a wave pass = one tile block x two octets)
-    constexpr int NU = BN / 64;                                  // 1 KiB U pieces each wave copies per stage (8, 4 or 2)
-    static_assert(BM == 256 || BM == 128 || BM == 64, "tile");
-    static_assert(BN == 512 || BN == 256 || BN == 128, "tile");
+    constexpr int VBYTES = BM * 128, UBYTES = BN * 128;
+    constexpr int U0 = 2 * VBYTES;                               // LDS: V' buffers 0, 1 then U' buffers 0, 1, 2
+    constexpr int NQ = BM == 256 ? 2 : 1;                        // channel octets each lane brings in per stage
+    constexpr int NU = BN / 64;                                  // 1 KiB U pieces each wave copies per stage (4 or 2)
+    constexpr int NV = NQ * 8;                                   // V' loads per lane and stage
+    static_assert(BM == 256 || BM == 128, "tile");
+    static_assert(BN == 256 || BN == 128, "tile");
     static_assert(TB == 4 || TB == 2, "wave tile");
-    static_assert(2 * STAGE <= 160 * 1024, "LDS");
+    static_assert(2 * VBYTES + 3 * UBYTES <= 160 * 1024, "LDS");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -106,14 +114,14 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     struct Cursor {          // a stage = (item, chunk); everything here is wave-uniform
         int k = 0, chunk = 0, xi = 0, pt = 0, kt = 0;
     };
-    auto locate = [&](Cursor &c) {
+    auto locate = [&](Cursor &c) __attribute__((always_inline)) {
         const int it = lo_it + wg + c.k * per_xcd;
         c.xi = it / per_pos;
         const int rem = it - c.xi * per_pos;
         c.pt = rem / a.ktiles;
         c.kt = rem - c.pt * a.ktiles;
     };
-    auto advance = [&](Cursor &c) {
+    auto advance = [&](Cursor &c) __attribute__((always_inline)) {
         if (++c.chunk == nst) {
             c.chunk = 0;
             if (++c.k < my_items) locate(c);
@@ -121,34 +129,46 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     };
 
     // ---- V' staging: lane (tile ln of tile block vtb, octets vo0 + 2 q + lh) -------------------------------------------
-    const bool v_wave = wave < NVW;          // (BM = 64: four passes, waves 0-3)
     const int vtb = BM == 256 ? wave : wave >> 1, vo0 = BM == 256 ? 0 : 2 * (wave & 1);
     const uint32_t v_lane_off = (uint32_t)(((int64_t)(8 * (vo0 + lh)) * a.Pp + vtb * 32 + ln) * 4);
     const uint32_t v_slab_bytes = (uint32_t)((int64_t)a.C * a.Pp * 4);
-    uint32_t vraw[NQ][8];
-    auto load_v = [&](const Cursor &c) {
-        if (!v_wave) return;
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.V) + (int64_t)c.xi * a.C * a.Pp, 0, (int)v_slab_bytes, 0x00020000);
+    typedef uint32_t VSet[NQ][8];
+    // The V' loads are issued in inline assembly: hipcc's waitcnt pass cannot keep two register sets of loads in flight
+    // beside the (to it invisible) LDS-DMA — it drained every outstanding load, the other set's included, in front of the
+    // first use of a set (seen in the .s of the first two-stage form of this kernel: vmcnt(14) ... vmcnt(0) where vmcnt(20) was
+    // right) — so the counting is done by hand: vector-memory operations complete in issue order, this wave issues per
+    // iteration [M stores of an item end] [NV loads] [NU DMA], and the one wait at the top of an iteration leaves exactly the
+    // previous iteration's loads + DMA in flight.  The destinations are the elements of the register set themselves (no
+    // temporaries: a compiler copy between load and wait would copy stale bytes — checked in the .s: no v_mov reads them).
+    auto load_v = [&](const Cursor &c, VSet &r) __attribute__((always_inline)) {
+        const uint64_t base = (uint64_t)(uintptr_t)(a.V + (int64_t)c.xi * a.C * a.Pp);
+        const i32x4 rs = {(int)(uint32_t)base, (int)(uint32_t)((base >> 32) & 0xffffu), (int)v_slab_bytes, 0x00020000};
         const uint32_t vo = v_lane_off + (uint32_t)c.pt * (BM * 4);
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const uint32_t so = (uint32_t)((int64_t)(c.chunk * H3_KC + 16 * q + e) * a.Pp * 4);
-                vraw[q][e] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0);
+                asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=&v"(r[q][e]) : "v"(vo), "s"(rs), "s"(so) : "memory");
             }
     };
+    // the loads of a set have landed (the caller's s_waitcnt): from here on its registers may be read
+    auto landed = [&](VSet &r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(r[q][e]));
+    };
     const uint32_t v_lds_off = (uint32_t)(vtb * 4096 + (vo0 + lh) * 512 + ln * 16);
-    auto write_v = [&](int buf) {
-        if (!v_wave) return;
-        unsigned char *dst = lds_h3 + buf * STAGE + v_lds_off;
+    auto write_v = [&](int buf, const VSet &r) __attribute__((always_inline)) {
+        unsigned char *dst = lds_h3 + buf * VBYTES + v_lds_off;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             u32x4 hi, lo;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                hi[j] = __builtin_amdgcn_perm(vraw[q][2 * j + 1], vraw[q][2 * j], 0x05040100u);
-                lo[j] = __builtin_amdgcn_perm(vraw[q][2 * j + 1], vraw[q][2 * j], 0x07060302u);
+                hi[j] = __builtin_amdgcn_perm(r[q][2 * j + 1], r[q][2 * j], 0x05040100u);
+                lo[j] = __builtin_amdgcn_perm(r[q][2 * j + 1], r[q][2 * j], 0x07060302u);
             }
             *reinterpret_cast<u32x4 *>(dst + q * 1024) = hi;
             *reinterpret_cast<u32x4 *>(dst + q * 1024 + 2048) = lo;
@@ -163,63 +183,96 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         const int g = wave * NU + j;
         u_voff[j] = (uint32_t)((g >> 2) * nst * 4096 + (g & 3) * 1024 + lane * 16);
     }
-    auto dma_u = [&](const Cursor &c, int buf) {
+    auto dma_u = [&](const Cursor &c, int ubuf) __attribute__((always_inline)) {
         const unsigned char *sb = a.U + ((int64_t)(c.xi * (a.Kp / 32) + c.kt * (BN / 32)) * nst + c.chunk) * 4096;
 #pragma unroll
-        for (int j = 0; j < NU; ++j) h3_dma16(sb, u_voff[j], lds_base + buf * STAGE + VBYTES + (wave * NU + j) * 1024);
+        for (int j = 0; j < NU; ++j) h3_dma16(sb, u_voff[j], lds_base + U0 + ubuf * UBYTES + (wave * NU + j) * 1024);
     };
 
     // ---- MFMA phase ----------------------------------------------------------------------------------------------------
     const int wc = wave % WC, wt = wave / WC;
     f32x16 acc[2][TB];
+    auto clear_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int t = 0; t < TB; ++t)
+            for (int t = 0; t < TB; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
-    const uint32_t a_off = (uint32_t)(VBYTES + wc * 2 * 4096 + lane * 16), b_off = (uint32_t)(wt * TB * 4096 + lane * 16);
+                for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
+    };
+    clear_acc();
+    const uint32_t a_off = (uint32_t)(wc * 2 * 4096 + lane * 16), b_off = (uint32_t)(wt * TB * 4096 + lane * 16);
+    // accumulator register r of block (c, t) is M[cout 32 (2 wc + c) + 8 (r >> 2) + 4 lh + (r & 3)][tile 32 (TB wt + t) + ln]
+    auto store_item = [&](int xi, int pt, int kt) __attribute__((always_inline)) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.M + (int64_t)xi * a.Kp * a.Pp, 0, (int)((int64_t)a.Kp * a.Pp * 4), 0x00020000);
+        const uint32_t vo = (uint32_t)(((int64_t)(4 * lh) * a.Pp + ln) * 4);
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            const int p0 = pt * BM + (wt * TB + t) * 32;
+            if (p0 < a.Pp && (!(ABL & 4) || acc[0][0][0] == 12345.678f)) {          // (a tile group may reach beyond the padded tile count: nothing to store there)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int k = kt * BN + (2 * wc + c) * 32 + 8 * (r >> 2) + (r & 3);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[c][t][r]), rs, vo, (uint32_t)(((int64_t)k * a.Pp + p0) * 4), 0);
+                    }
+            }
+        }
+        clear_acc();
+    };
 
-    Cursor cc, cu, cv;          // compute, U DMA (one stage ahead), V' loads (two stages ahead)
+    Cursor cc, cu, cv;          // compute; U' DMA (two stages ahead); V' loads (three stages ahead)
     locate(cc);
     cu = cc; cv = cc;
-    load_v(cv); advance(cv);
+    VSet vA, vB;                // even iterations: vB holds V'(s + 1) and is refilled with V'(s + 3); odd iterations: vA
+    // prologue: V'(0) -> LDS; V'(1) in vB, V'(2) in flight into vA; U'(0), U'(1) in flight
+    load_v(cv, vA); advance(cv);
     dma_u(cu, 0); advance(cu);
+    if (1 < total) { load_v(cv, vB); advance(cv); dma_u(cu, 1); advance(cu); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    write_v(0);
-    if (1 < total) { load_v(cv); advance(cv); }
+    landed(vA); landed(vB);
+    write_v(0, vA);
+    if (2 < total) { load_v(cv, vA); advance(cv); }
+    int prev_ops = 2 < total ? NV : 0;              // vector-memory operations this wave issued behind the last full wait
+    bool pend = false;                              // an item ended with the previous stage: its M stores are due
+    int pxi = 0, ppt = 0, pkt = 0;
 
-    const bool late = STG && wave >= 4;
-    bool v_in_flight = false;         // late waves: V' loads were issued behind this stage's DMA and may stay in flight across the barrier
-    for (int s = 0; s < total; ++s) {
-        const int cur = s & 1;
-        // stage s: its V' pieces were written by every wave one iteration ago (lgkmcnt), its U' pieces have landed (vmcnt:
-        // vector-memory operations complete in issue order, so a late wave leaves exactly its youngest V' loads in flight);
-        // behind the barrier nobody reads buffer cur ^ 1 (stage s - 1) any more
-        if (v_in_flight) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NQ * 8) : "memory");
+    int ub_cur = 0, ub_next2 = 2;                   // U' buffers: of stage s, and the one the DMA of stage s + 2 fills (s % 3, (s + 2) % 3)
+    auto iteration = [&](const int s, VSet &r) __attribute__((always_inline)) {
+        // Everything but what the previous iteration issued has landed: U'(s) (DMA of iteration s - 2) and V'(s + 1) (loads of
+        // iteration s - 2, in r).  This wave's V'(s) pieces are written (lgkmcnt).  Behind the barrier nobody reads V' buffer
+        // (s + 1) & 1 or U' buffer (s + 2) % 3 (stage s - 1) any more.
+        if (prev_ops == NV + NU) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NV + NU) : "memory");
+        else if (prev_ops == NV) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NV) : "memory");
+        else if (prev_ops == NU) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NU) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        v_in_flight = false;
-        auto stage_v = [&]() {
-            write_v(cur ^ 1);                                   // V'(s + 1): loaded a stage ago
-            if (s + 2 < total) { if (!(ABL & 1)) load_v(cv); advance(cv); }    // V'(s + 2) into the same registers
-        };
-        if (s + 1 < total) {
-            if (!late) stage_v();
-            if (!(ABL & 2)) dma_u(cu, cur ^ 1);                 // U'(s + 1)
+        prev_ops = 0;
+        landed(r);
+        if (pend) { store_item(pxi, ppt, pkt); pend = false; }        // (older than this iteration's loads: a whole stage to drain)
+        if (s + 1 < total) write_v((s + 1) & 1, r);
+        if (s + 3 < total) {
+            if (!(ABL & 1)) { load_v(cv, r); prev_ops += NV; }
+            advance(cv);
+        }
+        if (s + 2 < total) {
+            if (!(ABL & 2)) { dma_u(cu, ub_next2); prev_ops += NU; }
             advance(cu);
         }
-        const unsigned char *st = lds_h3 + cur * STAGE;
+        const unsigned char *vs = lds_h3 + (s & 1) * VBYTES, *us = lds_h3 + U0 + ub_cur * UBYTES;
+        ub_cur = ub_cur == 2 ? 0 : ub_cur + 1;
+        ub_next2 = ub_next2 == 2 ? 0 : ub_next2 + 1;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             half8 A[2][2], B[TB][2];
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) A[c][pl] = *reinterpret_cast<const half8 *>(st + a_off + c * 4096 + pl * 2048 + kk * 1024);
+                for (int pl = 0; pl < 2; ++pl) A[c][pl] = *reinterpret_cast<const half8 *>(us + a_off + c * 4096 + pl * 2048 + kk * 1024);
 #pragma unroll
             for (int t = 0; t < TB; ++t)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) B[t][pl] = *reinterpret_cast<const half8 *>(st + b_off + t * 4096 + pl * 2048 + kk * 1024);
+                for (int pl = 0; pl < 2; ++pl) B[t][pl] = *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048 + kk * 1024);
             // smallest terms first: (lo, hi) (hi, lo) (hi, hi); consecutive MFMAs on different accumulators
 #pragma unroll
             for (int term = 0; term < 3; ++term) {
@@ -234,36 +287,16 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
             }
         }
         if (++cc.chunk == nst) {
-            // item done: accumulator register r of block (c, t) is M[cout 32 (2 wc + c) + 8 (r >> 2) + 4 lh + (r & 3)][tile 32 (TB wt + t) + ln]
-            const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.M + (int64_t)cc.xi * a.Kp * a.Pp, 0, (int)((int64_t)a.Kp * a.Pp * 4), 0x00020000);
-            const uint32_t vo = (uint32_t)(((int64_t)(4 * lh) * a.Pp + ln) * 4);
-#pragma unroll
-            for (int t = 0; t < TB; ++t) {
-                const int p0 = cc.pt * BM + (wt * TB + t) * 32;
-                if (p0 < a.Pp && (!(ABL & 4) || acc[0][0][0] == 12345.678f)) {          // (a tile group may reach beyond the padded tile count: nothing to store there)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int k = cc.kt * BN + (2 * wc + c) * 32 + 8 * (r >> 2) + (r & 3);
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[c][t][r]), rs, vo, (uint32_t)(((int64_t)k * a.Pp + p0) * 4), 0);
-                        }
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int t = 0; t < TB; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
+            pend = true; pxi = cc.xi; ppt = cc.pt; pkt = cc.kt;
             cc.chunk = 0;
             if (++cc.k < my_items) locate(cc);
         }
-        if (late && s + 1 < total) {
-            stage_v();
-            v_in_flight = v_wave && s + 2 < total;
-        }
+    };
+    for (int s = 0; s < total; s += 2) {
+        iteration(s, vB);
+        if (s + 1 < total) iteration(s + 1, vA);
     }
+    if (pend) store_item(pxi, ppt, pkt);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -318,53 +351,48 @@ float wino4_h3_pack_weights(const std::vector<float> &U, int cin, int Kp, std::v
     return scale;
 }
 
-// Workgroup tile (tiles x couts).  All couts of a layer in one item whenever they fit (BN = Kp up to 512): the V' tile of an
-// item is then read from HBM exactly once — with 256-cout items the 512-cout layers read it twice, and their GEMM moves
-// as many bytes per matrix-core cycle as the chip can deliver (measured).  Fewer tiles per item when the
-// launch would otherwise leave the CUs fewer than ~3 items each (the 22 x 64 layers, short shards).
+// Workgroup tile (tiles x couts): 256 x 256; 128-tile groups when the launch would otherwise leave the CUs fewer than ~3
+// items each (the 22 x 64 layers, short shards); 256 x 128 when the layer has 128 couts.  (Items holding all 512 couts of a
+// layer — 128 x 512 tiles, the V' tile read from HBM once instead of twice — were built, verified and measured in round 3:
+// 3.19 against 3.00 ms of GEMM per frame; twice the U' bytes per stage through a CU's load path cost more than the
+// halved V' traffic saves.  Removed; numbers in DESIGN 3.1e.)
 struct H3Tile { int bm, bn; };
 static H3Tile h3_tile(int64_t P, int Kp) {
-    const int bn = Kp % 512 == 0 ? 512 : Kp % 256 == 0 ? 256 : 128;
-    const int big = bn == 512 ? 128 : 256, small = big / 2;
-    if (bn == 128) return {256, 128};
-    const int64_t items_big = 36 * ((P + big - 1) / big) * (Kp / bn);
-    return {items_big >= 3 * 256 ? big : small, bn};
+    if (Kp % 256) return {256, 128};
+    const int64_t items_big = 36 * ((P + 255) / 256) * (Kp / 256);
+    return {items_big >= 3 * 256 ? 256 : 128, 256};
 }
 
 void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int Kp, int P, int Pp, hipStream_t s) {
+    // The persistent workgroup claims the CU's whole LDS (160 KB) whatever its five stage buffers need (112 - 160 KB): with
+    // the exact size (96 - 128 KB in the first form of the kernel) another lane's small-LDS workgroups (wino4_bridge_kernel:
+    // 7 - 24 KB) were placed beside it and the frame was no longer reproducible run to run (measured, round 3: three lanes !=
+    // one lane, the same handle twice != itself; with every workgroup alone on its CU, or with no LDS user beside it,
+    // bit-identical; the GEMM alone beside such workgroups stays bit-exact, so the victim is presumably the neighbour — the
+    // mechanism was not isolated).  SIVO_H3_LDS_ALL=0 requests the exact size (debugging).
+    static const bool lds_all = !(std::getenv("SIVO_H3_LDS_ALL") && std::atoi(std::getenv("SIVO_H3_LDS_ALL")) == 0);
+    // SIVO_H3_TILE=0/1 forces the larger / smaller tile count per item (tests)
+    static const int force_tile = std::getenv("SIVO_H3_TILE") ? std::atoi(std::getenv("SIVO_H3_TILE")) : -1;
     static int attr_set[64] = {0};
     if (FirstUse once(attr_set); once) {
-        for (const void *f : {(const void *)wino4_gemm_h3_kernel<128, 512, false>, (const void *)wino4_gemm_h3_kernel<128, 512, true>,
-                              (const void *)wino4_gemm_h3_kernel<64, 512, false>, (const void *)wino4_gemm_h3_kernel<64, 512, true>,
-                              (const void *)wino4_gemm_h3_kernel<256, 256, false>, (const void *)wino4_gemm_h3_kernel<256, 256, true>,
-                              (const void *)wino4_gemm_h3_kernel<128, 256, false>, (const void *)wino4_gemm_h3_kernel<128, 256, true>,
-                              (const void *)wino4_gemm_h3_kernel<256, 128, false>, (const void *)wino4_gemm_h3_kernel<256, 128, true>})
+        for (const void *f : {(const void *)wino4_gemm_h3_kernel<256, 256>, (const void *)wino4_gemm_h3_kernel<128, 256>, (const void *)wino4_gemm_h3_kernel<256, 128>})
             SIVO_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    // The persistent workgroup claims the CU's whole LDS (160 KB) although its two stage buffers need 96-128 KB: with only
-    // that, another lane's small-LDS workgroups (wino4_bridge_kernel: 7-24 KB) were placed beside it and the frame was no
-    // longer reproducible run to run (measured, round 3: three lanes != one lane, same handle twice != itself; with every
-    // workgroup alone on its CU, or without LDS users beside it, bit-identical).  SIVO_H3_LDS_ALL=0 requests the exact size.
-    static const bool lds_all = !(std::getenv("SIVO_H3_LDS_ALL") && std::atoi(std::getenv("SIVO_H3_LDS_ALL")) == 0);
-    // SIVO_H3_STAGGER=0/1: all waves stage behind the barrier / the two waves of a SIMD stage at opposite ends of a stage
-    static const bool stagger = !(std::getenv("SIVO_H3_STAGGER") && std::atoi(std::getenv("SIVO_H3_STAGGER")) == 0);
-    // SIVO_H3_TILE=0/1/2 forces the workgroup tile (tests / measurements): 0 the larger, 1 the smaller tile count, 2 256-cout items
-    static const int force_tile = std::getenv("SIVO_H3_TILE") ? std::atoi(std::getenv("SIVO_H3_TILE")) : -1;
     static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
     const dim3 grid((unsigned)((n_cu / 8) * 8 > 0 ? (n_cu / 8) * 8 : 8));      // one persistent workgroup per CU, a multiple of the 8 XCDs
     H3Args a{};
     a.V = V; a.U = static_cast<const unsigned char *>(U); a.M = M; a.C = C; a.Kp = Kp; a.P = P; a.Pp = Pp;
+    H3Tile t = h3_tile(P, Kp);
+    if (t.bn == 256 && (force_tile == 0 || force_tile == 1)) t.bm = force_tile == 0 ? 256 : 128;
+    a.ptiles = (int)((P + t.bm - 1) / t.bm); a.ktiles = Kp / t.bn;
+    const size_t lds = lds_all ? (size_t)160 * 1024 : (size_t)(2 * t.bm + 3 * t.bn) * 128;
 #ifdef SIVO_DIAG
-    if (const char *ab = std::getenv("SIVO_H3_ABL")) {          // diagnostic build: ablations of the 256 x 256 / 128 x 512 kernel (SIVO_H3_ABL_TILE=1)
-        const bool wide = std::getenv("SIVO_H3_ABL_TILE") && std::atoi(std::getenv("SIVO_H3_ABL_TILE")) == 1 && Kp % 512 == 0;
-        a.ptiles = wide ? (P + 127) / 128 : (P + 255) / 256; a.ktiles = wide ? Kp / 512 : Kp / 256;
-        const size_t l = 160 * 1024;
+    if (const char *ab = std::getenv("SIVO_H3_ABL")) {          // diagnostic build: ablations of the 256 x 256 kernel
+        a.ptiles = (P + 255) / 256; a.ktiles = Kp / 256;
 #define H3_ABL_CASE(n)                                                                                                              \
     case n:                                                                                                                         \
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<256, 256, false, n>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l)); \
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<128, 512, false, n>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l)); \
-        if (wide) hipLaunchKernelGGL((wino4_gemm_h3_kernel<128, 512, false, n>), grid, dim3(512), l, s, a);                         \
-        else hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, false, n>), grid, dim3(512), l, s, a);                              \
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<256, 256, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, n>), grid, dim3(512), (size_t)160 * 1024, s, a);                         \
         return;
         switch (std::atoi(ab)) {
             H3_ABL_CASE(1) H3_ABL_CASE(2) H3_ABL_CASE(3) H3_ABL_CASE(4) H3_ABL_CASE(7) H3_ABL_CASE(8) H3_ABL_CASE(12)
@@ -373,23 +401,9 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
 #undef H3_ABL_CASE
     }
 #endif
-    H3Tile t = h3_tile(P, Kp);
-    if (force_tile == 1 && t.bn != 128) t.bm = t.bn == 512 ? 64 : 128;          // tests: the small-tile form
-    if (force_tile == 0 && t.bn != 128) t.bm = t.bn == 512 ? 128 : 256;
-    if (force_tile == 2 && Kp % 256 == 0) t = {P >= 4096 ? 256 : 128, 256};      // tests / measurements: 256-cout items for a 512-cout layer
-    a.ptiles = (int)((P + t.bm - 1) / t.bm); a.ktiles = Kp / t.bn;
-    const size_t lds = lds_all ? (size_t)160 * 1024 : (size_t)2 * (t.bm + t.bn) * 128;
-#define H3_LAUNCH(BM_, BN_)                                                                                                          \
-    do {                                                                                                                           \
-        if (stagger) hipLaunchKernelGGL((wino4_gemm_h3_kernel<BM_, BN_, true>), grid, dim3(512), lds, s, a);                         \
-        else hipLaunchKernelGGL((wino4_gemm_h3_kernel<BM_, BN_, false>), grid, dim3(512), lds, s, a);                                \
-    } while (0)
-    if (t.bm == 128 && t.bn == 512) H3_LAUNCH(128, 512);
-    else if (t.bm == 64 && t.bn == 512) H3_LAUNCH(64, 512);
-    else if (t.bm == 256 && t.bn == 256) H3_LAUNCH(256, 256);
-    else if (t.bm == 128 && t.bn == 256) H3_LAUNCH(128, 256);
-    else H3_LAUNCH(256, 128);
-#undef H3_LAUNCH
+    if (t.bm == 256 && t.bn == 256) hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256>), grid, dim3(512), lds, s, a);
+    else if (t.bm == 128 && t.bn == 256) hipLaunchKernelGGL((wino4_gemm_h3_kernel<128, 256>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 128>), grid, dim3(512), lds, s, a);
 }
 
 }  // namespace sivo

@@ -26,6 +26,8 @@ for step in "$@"; do
     segnet) timeout 900 python -m pytest tests/test_gpu_segnet.py -q -s > $O/segnet.log 2>&1; echo "segnet rc=$?"; grep -E "passed|failed|FAILED|dlogit" $O/segnet.log | tail -25;;
     bench) bench default SIVO_DUMMY=1;;
     benchvar) bench nostagger SIVO_H3_STAGGER=0; bench lanes1 SIVO_LANES=1; bench x6 SIVO_GEMM=x6;;
+    probe) timeout 600 python tools/h3_probe.py 20 > $O/probe_256.log 2>&1; cat $O/probe_256.log;;
+    lanes) timeout 300 python tools/h3_debug2.py default > $O/lanes.log 2>&1; grep "lanes ==" $O/lanes.log;;
     e2e) timeout 600 python -m pytest tests/test_gpu_frame_e2e.py -q -s > $O/e2e.log 2>&1; echo "e2e rc=$?"; grep -E "e2e|passed|failed|Error" $O/e2e.log | tail -8;;
     fullsize) timeout 1500 python -m pytest tests/test_gpu_segnet_fullsize.py -q -s > $O/fullsize.log 2>&1; echo "fullsize rc=$?"; grep -E "dlogit|passed|failed|FAILED|Error" $O/fullsize.log | tail -40;;
     alltests) timeout 1800 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; echo "alltests rc=$?"; tail -5 $O/gpu_tests.log;;
