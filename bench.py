@@ -148,7 +148,7 @@ def aggregate(rows):
 
 def traffic_from_profiles(dom_name):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (bench cannot collect PMC itself)."""
-    for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json")), reverse=True):
+    for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if "pmc_traffic" in f and f.endswith(".json")), reverse=True):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
             hits = [v for k, v in tj.items() if k.split("<")[0] == dom_name.split("<")[0] and isinstance(v, dict) and v.get("bytes")]

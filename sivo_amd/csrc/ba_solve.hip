@@ -560,11 +560,13 @@ template <bool LDS_COPY>
 __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_kernel(BaDev d) {
     __shared__ int s_ok;
     __shared__ double s_x[6];
-    extern __shared__ double s_mat[];
+    __shared__ double s_rhs[LDS_COPY ? 128 : 1];          // LDS_COPY: the right-hand side / solution lives in LDS too: the two
+    extern __shared__ double s_mat[];                     // triangular solves are 2 nF dependent steps, one L2 round trip each otherwise
     const int nb = d.nF, n = 6 * nb, tid = threadIdx.x;
-    double *S = LDS_COPY ? s_mat : d.S, *x = d.xs;
+    double *S = LDS_COPY ? s_mat : d.S, *x = LDS_COPY ? s_rhs : d.xs;
     if (LDS_COPY) {
         for (int i = tid; i < n * n; i += BA_SOLVE_T) s_mat[i] = d.S[i];
+        for (int i = tid; i < n; i += BA_SOLVE_T) s_rhs[i] = d.xs[i];
     }
     if (tid == 0) s_ok = 1;
     __syncthreads();
@@ -600,16 +602,15 @@ __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_kernel(BaDev d) {
         }
         __syncthreads();
         // trailing update of the lower triangle: rows i >= j0 + 6, columns j0 + 6 <= k <= i
-        const int m = n - j0 - 6;
-        for (int idx = tid; idx < m * m; idx += BA_SOLVE_T) {
-            const int i = j0 + 6 + idx / m, k = j0 + 6 + idx % m;
-            if (k <= i) {
+        // (thread (tid >> 4, tid & 15) walks rows / columns with stride 16: no integer division in the loop; every element
+        // is one 6-term sum in the same order as before)
+        for (int i = j0 + 6 + (tid >> 4); i < n; i += BA_SOLVE_T / 16)
+            for (int k = j0 + 6 + (tid & 15); k <= i; k += 16) {
                 double v = 0;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) v += S[(int64_t)i * n + j0 + c] * S[(int64_t)k * n + j0 + c];
                 S[(int64_t)i * n + k] -= v;
             }
-        }
         __syncthreads();
     }
     if (s_ok) {
@@ -652,6 +653,8 @@ __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_kernel(BaDev d) {
             __syncthreads();
         }
     }
+    if (LDS_COPY && s_ok)
+        for (int i = tid; i < n; i += BA_SOLVE_T) d.xs[i] = s_rhs[i];
     if (tid == 0) d.scal[3] = s_ok ? 1.0 : 0.0;
 }
 
@@ -862,20 +865,27 @@ class BaSolver {
         const bool landmarks = !points_fixed_ && nX_ > 0;
         double lambda = 0, ni = 2;
         int it = 0;
+        bool linearized = false;
         for (; it < iterations; ++it) {
             if (stop && *stop) break;
             const double *P = poses_[cur_].as<double>(), *X = points_[cur_].as<double>();
             if (nE_) hipLaunchKernelGGL(ba_edge_kernel<true>, dim3(gE), dim3(BA_T), 0, 0, d_, P, X);
-            hipLaunchKernelGGL(ba_sum_kernel, dim3(1), dim3(1024), 0, 0, d_.rchi, nE_, d_.scal);
+            hipLaunchKernelGGL(ba_sum_kernel, dim3(1), dim3(1024), 0, 0, d_.rchi, nE_, d_.scal + 6);      // chi2 at the current estimate: scal[6]
             if (landmarks) hipLaunchKernelGGL(ba_point_kernel, dim3(gX), dim3(BA_T), 0, 0, d_);
             if (nF_) hipLaunchKernelGGL(ba_pose_kernel, dim3(nF_), dim3(BA_T), 0, 0, d_);
-            hipLaunchKernelGGL(ba_maxdiag_kernel, dim3(1), dim3(1024), 0, 0, d_, landmarks ? 1 : 0);
-            SIVO_HIP(hipGetLastError());
-            double sc[4];
-            SIVO_HIP(hipMemcpy(sc, d_.scal, sizeof sc, hipMemcpyDeviceToHost));
-            if (nF_) SIVO_HIP(hipMemcpy(hpp_last_.data(), d_.Hpp, (size_t)nF_ * 288, hipMemcpyDeviceToHost));
-            double current = sc[0];
-            if (it == 0) { lambda = 1e-5 * sc[2]; ni = 2; }
+            linearized = true;
+            // The host needs lambda before the first trial only in the first iteration (computeLambdaInit: 1e-5 max |diag H|);
+            // afterwards the chi2 of the linearisation point is read together with the trial's result: ONE host read per trial
+            // instead of two per iteration plus a 288-byte-per-keyframe copy of H_pp (now fetched once, behind the loop).
+            if (it == 0) {
+                hipLaunchKernelGGL(ba_maxdiag_kernel, dim3(1), dim3(1024), 0, 0, d_, landmarks ? 1 : 0);
+                SIVO_HIP(hipGetLastError());
+                double sc[4];
+                SIVO_HIP(hipMemcpy(sc, d_.scal, sizeof sc, hipMemcpyDeviceToHost));
+                lambda = 1e-5 * sc[2]; ni = 2;
+            }
+            double current = 0;
+            bool have_current = false;
             double rho = 0;
             int qmax = 0;
             do {
@@ -905,8 +915,9 @@ class BaSolver {
                 hipLaunchKernelGGL(ba_sum_kernel, dim3(1), dim3(1024), 0, 0, d_.rchi, nE_, d_.scal);
                 if (landmarks) hipLaunchKernelGGL(ba_sum_kernel, dim3(1), dim3(1024), 0, 0, d_.sc_pt, (int64_t)nX_, d_.scal + 4);
                 SIVO_HIP(hipGetLastError());
-                double r[5];
+                double r[7];
                 SIVO_HIP(hipMemcpy(r, d_.scal, sizeof r, hipMemcpyDeviceToHost));
+                if (!have_current) { current = r[6]; have_current = true; }
                 const bool ok = r[3] != 0.0;
                 double temp = ok ? r[0] : DBL_MAX;
                 const double scale = ok ? r[1] + (landmarks ? r[4] : 0.0) : 0.0;
@@ -926,6 +937,8 @@ class BaSolver {
             } while (rho < 0 && qmax < 10 && !(stop && *stop));
             if (qmax == 10 || rho == 0) { ++it; break; }
         }
+        // H_pp of the last linearisation (computeMarginals inverts its block, Optimizer.cc:482-487, 900-907)
+        if (linearized && nF_) SIVO_HIP(hipMemcpy(hpp_last_.data(), d_.Hpp, (size_t)nF_ * 288, hipMemcpyDeviceToHost));
         return it;
     }
 
