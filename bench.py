@@ -146,22 +146,25 @@ def aggregate(rows):
     return agg
 
 
-def traffic_from_profiles(dom_name):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (bench cannot collect PMC itself)."""
-    for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if "pmc_traffic" in f and f.endswith(".json")), reverse=True):
+def traffic_from_profiles(dom_name, tag="main"):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of the same configuration
+    (profiles/*pmc_traffic_<tag>.json, tools/profile_round.sh; bench cannot collect PMC itself): the dispatch-weighted mean
+    over the kernel's template instantiations — the same set of launches `achieved` averages over."""
+    files = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if "pmc_traffic" in f and f.endswith(".json")), reverse=True)
+    files = [f for f in files if f"pmc_traffic_{tag}" in f] + [f for f in files if f"pmc_traffic_{tag}" not in f and tag == "main" and f.endswith("pmc_traffic.json")]
+    for cand in files:
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
-            hits = [v for k, v in tj.items() if k.split("<")[0] == dom_name.split("<")[0] and isinstance(v, dict) and v.get("bytes")]
-            if dom_name in tj and tj[dom_name].get("bytes"):
-                hits = [tj[dom_name]]
+            hits = [v for k, v in tj.items() if k.split("<")[0] == dom_name.split("<")[0] and isinstance(v, dict) and v.get("bytes") and v.get("dispatches")]
             if hits:
-                return max(hits, key=lambda v: v.get("dispatches", 0))["bytes"], "profiles/" + cand
+                n = sum(v["dispatches"] for v in hits)
+                return int(sum(v["bytes"] * v["dispatches"] for v in hits) / n), "profiles/" + cand
         except Exception:
             pass
     return None, None
 
 
-def mfma_roofline(prof_timed, prof_detail, n_timed_frames, n_detail, ms_per_frame, note):
+def mfma_roofline(prof_timed, prof_detail, n_timed_frames, n_detail, ms_per_frame, note, tag="main"):
     """roofline object of a SegNet run.  achieved / frac = ALGORITHMIC (direct-convolution) FLOP/s of the dominant
     kernel against the dense peak of the instruction type it issues; executed_tflops / executed_frac = the matrix-core
     products it really issues (Winograd multiplies 1/4 of the direct products, the split arithmetic 3 or 6 per fp32 product)."""
@@ -182,7 +185,7 @@ def mfma_roofline(prof_timed, prof_detail, n_timed_frames, n_detail, ms_per_fram
         c = kernel_class(k)
         if c and v["flops"] > 0:
             t_peak_ms += v["flops"] / n_detail * c[0] / (c[1] * 1e12) * 1e3
-    traffic, tsrc = traffic_from_profiles(dom_name)
+    traffic, tsrc = traffic_from_profiles(dom_name, tag)
     return {"bound": "mfma", "kernel": "sivo::" + dom_name, "instruction": what,
             "achieved": round(alg, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(alg / peak, 4),
             "executed_tflops": round(executed, 2), "executed_frac": round(executed / peak, 4), "executed_per_algorithmic": round(ratio, 4),
@@ -482,12 +485,12 @@ def main():
         del sn
         torch.cuda.empty_cache()
 
-        def segnet_config(name, kind, t, steps, parity):
+        def segnet_config(name, kind, t, steps, parity, tag):
             _, _, net = build_net(kind, t)
             m = new_maps()
             el, pt_, pd_, nd = time_segnet(net, lambda seed: net.segment_into(d_bgr, seed, m), steps, 2, barrier, 4, events)
             ms = 1e3 * el / steps
-            r = mfma_roofline(pt_, pd_, len(range(0, steps, 4)), nd, ms, "as the main roofline; SegNet only (no ORB)")
+            r = mfma_roofline(pt_, pd_, len(range(0, steps, 4)), nd, ms, "as the main roofline; SegNet only (no ORB)", tag)
             alg = (net.flops_shared + t * net.flops_per_sample) / 1e9
             del net
             torch.cuda.empty_cache()
@@ -495,10 +498,10 @@ def main():
                     "algorithmic_gflop_per_frame": round(alg, 2), "roofline": r, "parity": parity}
         if "basic" in want:
             extra.append(segnet_config("BASELINE configs[1]: Bayesian SegNet Basic, T=6, 352x1024, 1 MI355X (SegNet + MC maps)", "basic", 6, 20,
-                                       "tests/test_gpu_segnet_fullsize.py [basic-6-*] (every logit within 1e-3 of the oracle, three lanes)"))
+                                       "tests/test_gpu_segnet_fullsize.py [basic-6-*] (every logit within 1e-3 of the oracle, three lanes)", "basic"))
         if "t48" in want:
             extra.append(segnet_config("BASELINE configs[3] on ONE GPU: SegNet Standard T=48 (the 8-GPU form shards 6 samples per rank)", "standard", 48, 6,
-                                       "tests/test_gpu_segnet_fullsize.py::test_t48_and_its_shards_at_full_size (T = 48 in one handle and the 6-sample shards, oracle-checked), tests/test_distributed_cpu.py"))
+                                       "tests/test_gpu_segnet_fullsize.py::test_t48_and_its_shards_at_full_size (T = 48 in one handle and the 6-sample shards, oracle-checked), tests/test_distributed_cpu.py", "t48"))
         if "ba" in want:
             from sivo_amd import optimizer
             poses, pts, edges, intr = ba_scene()
