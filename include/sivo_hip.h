@@ -208,6 +208,16 @@ int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow_frames, Si
  * (ms) of `iters` further launches in *ms_out. */
 int sivo_debug_h3_gemm(int C, int Kp, int P, const float *V, const float *U, float vscale, float *M, int iters, double *ms_out);
 
+/* Diagnostic / test: the direct 3x3 convolution on the fp16 matrix cores (f16x3, conv3_h3.hip) alone.  d_in, d_mask, d_out:
+ * DEVICE pointers — d_mask null: d_in is (N, Cin, H, W); else d_in is the pooled tensor (N, Cin, H/2, W/2) and d_mask its
+ * u8 window codes (dy * 2 + dx), the layer reading through the Upsample as in the network.  Wt (Cout, Cin, 3, 3), scale,
+ * shift (Cout): HOST arrays; out = act(scale * conv + shift).  vscale: the power of two the input is multiplied with before
+ * it is split (max |in| * vscale well below 65504).  Cin % 16 == 0, Cin >= 32, Cout % 64 == 0.  *overflowed = 1 when a scaled
+ * input left the fp16 range.  iters > 0: mean launch time (ms) of `iters` further launches in *ms_out. */
+int sivo_debug_conv3_h3_dev(int N, int Cin, int Cout, int H, int W, const float *d_in, const uint8_t *d_mask, const float *Wt,
+                            const float *scale, const float *shift, int relu, float vscale, float *d_out, int iters,
+                            double *ms_out, int *overflowed);
+
 /* ===========================================================================
  * ORB extractor — stands behind SIVO::ORBextractor
  * (reference include/orbslam/ORBextractor.h:46-123, src/orbslam/ORBextractor.cc).

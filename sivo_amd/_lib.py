@@ -85,6 +85,7 @@ SIGNATURES = {
     "sivo_debug_conv": [_i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_d)],
     "sivo_segnet_gemm_status": [_vp, _pi32, _pi32, _vp, _i, _pi32],
     "sivo_debug_h3_gemm": [_i, _i, _i, _vp, _vp, _f, _vp, _i, C.POINTER(_d)],
+    "sivo_debug_conv3_h3_dev": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _i, C.POINTER(_d), C.POINTER(_i)],
     "sivo_orb_create": [_i, _f, _i, _i, _i, _i, C.POINTER(_vp)],
     "sivo_orb_destroy": [_vp],
     "sivo_orb_tables": [_vp, _vp, _vp, _vp, _vp, _vp],

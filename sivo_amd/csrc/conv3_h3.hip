@@ -1,0 +1,433 @@
+// conv3_h3.hip — DIRECT 3x3 convolution on the fp16 matrix cores with fp32 operands split as fp16 hi + lo ("f16x3", the
+// arithmetic of conv_wino4_h3.hip) for the narrow layers (<= 128 channels at >= 176 x 512: conv2_2_D, conv2_1_D, conv1_2_D).
+//
+// Why direct.  A fused Winograd F(4x4) kernel has to keep 36 transform positions of a tile on chip: 2.25 accumulators per
+// output and 36 weight matrices per channel chunk; conv_wino4f.hip does that on the fp32 matrix pipe (k = 4 per MFMA: a
+// 36 KB weight slab per 4 channels).  The fp16 instructions take k = 16: the same slab would be 147 KB per step.  On the
+// fp16 pipe a direct product costs 3 MFMA flops where the fp32 pipe pays 16, so the 4x of F(4x4) is no longer needed to
+// get under the HBM time of these layers — and a direct kernel has ONE accumulator per output (a workgroup owns four times
+// the pixels), 9 weight matrices per chunk, no transforms, no exchange stage, and no Winograd error: its results carry the
+// 2^-22 of the split and the fp32 accumulation only.  The three-kernel F(4x4) path moved 5.7 GB through HBM for conv2_2_D
+// (V and M, 2.25x the activation each way); this kernel moves the activation once (0.7 GB).
+//
+//   out[n][co][y][x] = act( ep_scale[co] * sum_{ci,ky,kx} W[co][ci][ky][kx] * in[n][ci][y+ky-1][x+kx-1] + ep_shift[co] )
+//
+// Implicit GEMM per tap: D[cout][pixel] += A_tap[cout][ci] * B[ci][pixel shifted by the tap].  The input patch of an item
+// (8 x 64 output pixels: 10 x 66 with its halo) is staged ONCE per 16-channel chunk as fp16 hi / lo fragments, pixel-major;
+// the nine taps are nine shifted ds_read_b128 windows of the same LDS image.
+//
+// Kernel.  One persistent 512-thread workgroup per CU walks (sample, pixel tile, 64-cout group) items in an XCD-aware
+// order (each XCD a contiguous range of the pixel-tile-major list: halos and the cout groups of a tile meet in one L2);
+// 8 waves = 4 row pairs x 2 column halves, wave tile 2 rows x 32 px x 64 couts = 2 x 2 MFMA blocks of 32 x 32 (64
+// accumulator registers).  A stage is 16 channels = one k-step per tap: 9 x 12 = 108 v_mfma_f32_32x32x16_f16 per wave
+// against 9 x 8 ds_read_b128.  (item, chunk) form one stream of stages, LDS double-buffered:
+//   iteration s:  barrier -> output stage of an item that ended with stage s - 1 (its stores have a whole stage to drain)
+//                 -> issue the patch loads (registers) and the weight LDS-DMA of stage s + 1 -> multiply stage s ->
+//                 s_waitcnt vmcnt(0) -> split the patch of stage s + 1 into the other buffer.
+//   * weights: split once on the host, stored as the LDS image of a stage ([cout group][chunk][tap][32-cout block][plane]
+//     [octet][cout][8 ch]: 36 KiB), copied by LDS-DMA issued in inline assembly (lds_dma.hpp);
+//   * patch: lane = (pixel, channel octet): 8 buffer loads (one per channel; out-of-image pixels carry an offset beyond the
+//     descriptor and read 0 — the zero padding), x vscale, hi = fp16(x), lo = fp16(x - hi), v_perm_b32 to separate the
+//     planes, two ds_write_b128.  UNPOOL: the loads go to the pooled tensor and its window codes (the Upsample in front of
+//     the layer is never materialised).  The loads are inline assembly as in conv_wino4_h3.hip (hipcc's waitcnt pass would
+//     otherwise drain them, and the DMA, in front of the first LDS read).
+// LDS: 2 x 42,240 (patch) + 2 x 36,864 (weights) + 1 KiB (epilogue affine of two items) = 159,232 bytes.
+// Fragment order [plane][octet][patch row][patch column] / [plane][octet][cout]: every ds_read_b128 / ds_write_b128 touches
+// consecutive 16-byte pieces in lane order (conflict-free, any tap shift).  C/D of the 32 x 32 MFMA: column = lane & 31 =
+// pixel, so an accumulator register of a wave is two 128-byte runs of an output row.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include "common.hpp"
+#include "h3_split.hpp"
+#include "lds_dma.hpp"
+#include "segnet_kernels.hpp"
+
+namespace sivo {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int D_TH = 8, D_TW = 64;                 // output pixels of an item
+constexpr int D_PR = D_TH + 2, D_PW = D_TW + 2;    // patch rows / columns (halo of one)
+constexpr int D_KC = 16;                           // channels per stage
+constexpr int D_NPX = D_PR * D_PW;                 // 660 patch pixels
+constexpr int D_PLANE = 2 * D_NPX * 16;            // bytes of the hi (or lo) plane of a patch stage: two channel octets
+constexpr int D_PBYTES = 2 * D_PLANE;              // 42,240
+constexpr int D_UBYTES = 9 * 4096;                 // 36,864: nine taps x (2 cout blocks x 2 planes x 2 octets x 32 couts x 16 B)
+constexpr int D_U0 = 2 * D_PBYTES;
+constexpr int D_EP0 = D_U0 + 2 * D_UBYTES;         // epilogue affine: [item parity][scale 64 | shift 64] floats
+constexpr int D_LDS = D_EP0 + 1024;
+constexpr int D_NIT = 3;                           // patch pieces per thread: ceil(2 * 660 / 512)
+constexpr int D_NPIECE = 2 * D_NPX;                // 1320
+constexpr uint32_t D_INV = 0xfffffff0u;            // beyond any descriptor: loads return 0, stores are dropped
+static_assert(D_LDS <= 160 * 1024, "LDS");
+
+// ABL (diagnostic builds only, -DSIVO_DIAG; results are wrong by construction): 1 no patch loads after the prologue,
+// 2 no weight DMA after the prologue, 4 no output stores, 8 no MFMAs, 16 no patch split / LDS writes after the prologue.
+template <bool UNPOOL, int ABL = 0>
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3_h3_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_d[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 31, lh = lane >> 5;
+    const int nst = a.Cin / D_KC;
+    const int ngroups = a.CoutPad / 64;
+
+    // items of this XCD: a contiguous range of the (sample, tile row, tile column, cout group) list; the workgroups of the
+    // XCD take them round-robin (neighbouring workgroups work on neighbouring tiles at the same time)
+    const int nitems = a.tiles_x * a.tiles_y * a.N * ngroups;
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int lo_it = (int)(((int64_t)nitems * xcd) >> 3), hi_it = (int)(((int64_t)nitems * (xcd + 1)) >> 3);
+    if (lo_it + wg >= hi_it) return;
+    const int my_items = (hi_it - lo_it - wg + per_xcd - 1) / per_xcd;
+    const int total = my_items * nst;
+
+    const int64_t plane = (int64_t)a.H * a.W;
+    const int Wh = a.W >> 1;
+    const int64_t plane_in = UNPOOL ? (int64_t)(a.H >> 1) * Wh : plane;
+    const float mscale = 1.f / (a.h3_vscale * a.h3_uscale);
+
+    struct Cursor {          // a stage = (item, chunk); wave-uniform
+        int k = 0, chunk = 0, n = 0, ty = 0, tx = 0, g = 0;
+    };
+    auto locate = [&](Cursor &c) __attribute__((always_inline)) {
+        const int it = lo_it + wg + c.k * per_xcd;
+        const int pt = it / ngroups;
+        c.g = it - pt * ngroups;
+        const int q = pt / a.tiles_x;
+        c.tx = pt - q * a.tiles_x;
+        c.n = q / a.tiles_y;
+        c.ty = q - c.n * a.tiles_y;
+    };
+    auto advance = [&](Cursor &c) __attribute__((always_inline)) {
+        if (++c.chunk == nst) {
+            c.chunk = 0;
+            if (++c.k < my_items) locate(c);
+        }
+    };
+
+    // ---- patch staging: piece p = tid + 512 r = (octet o, patch row py, patch column px); LDS byte p * 16 in each plane ----
+    int p_py[D_NIT], p_px[D_NIT], p_o[D_NIT];
+    bool p_valid[D_NIT];
+#pragma unroll
+    for (int r = 0; r < D_NIT; ++r) {
+        const int p = tid + 512 * r;
+        p_valid[r] = p < D_NPIECE;
+        const int pc = p_valid[r] ? p : 0;
+        p_o[r] = pc / D_NPX;
+        const int rem = pc - p_o[r] * D_NPX;
+        p_py[r] = rem / D_PW;
+        p_px[r] = rem - p_py[r] * D_PW;
+    }
+    typedef uint32_t PSet[D_NIT][8];
+    auto load_patch = [&](const Cursor &c, PSet &pv, PSet &pm) __attribute__((always_inline)) {
+        const uint64_t base = (uint64_t)(uintptr_t)(a.in + (int64_t)c.n * a.in_sample_stride);
+        const i32x4 rs = {(int)(uint32_t)base, (int)(uint32_t)((base >> 32) & 0xffffu), (int)(a.Cin * plane_in * 4), 0x00020000};
+        const uint64_t mbase = UNPOOL ? (uint64_t)(uintptr_t)(a.unpool_mask + (int64_t)c.n * a.unpool_mask_stride) : base;
+        const i32x4 mrs = {(int)(uint32_t)mbase, (int)(uint32_t)((mbase >> 32) & 0xffffu), (int)(a.Cin * plane_in), 0x00020000};
+        const int y0 = c.ty * D_TH, x0 = c.tx * D_TW;
+#pragma unroll
+        for (int r = 0; r < D_NIT; ++r) {
+            const int gy = y0 + p_py[r] - 1, gx = x0 + p_px[r] - 1;
+            const bool inside = p_valid[r] && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const uint32_t idx = (uint32_t)(p_o[r] * 8 * plane_in) + (UNPOOL ? (uint32_t)((gy >> 1) * Wh + (gx >> 1)) : (uint32_t)(gy * a.W + gx));
+            const uint32_t vo = inside ? idx * 4u : D_INV, mo = inside ? idx : D_INV;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t so = (uint32_t)((int64_t)(c.chunk * D_KC + e) * plane_in * 4);
+                asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=&v"(pv[r][e]) : "v"(vo), "s"(rs), "s"(so) : "memory");
+                if (UNPOOL) {
+                    const uint32_t sm = (uint32_t)((int64_t)(c.chunk * D_KC + e) * plane_in);
+                    asm volatile("buffer_load_ubyte %0, %1, %2, %3 offen" : "=&v"(pm[r][e]) : "v"(mo), "s"(mrs), "s"(sm) : "memory");
+                }
+            }
+        }
+    };
+    // the loads of a set have landed (the caller's s_waitcnt): from here on its registers may be read
+    auto landed = [&](PSet &pv, PSet &pm) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < D_NIT; ++r)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                asm volatile("" : "+v"(pv[r][e]));
+                if (UNPOOL) asm volatile("" : "+v"(pm[r][e]));
+            }
+    };
+    bool bad = false;
+    auto split_patch = [&](int buf, const PSet &pv, const PSet &pm) __attribute__((always_inline)) {
+        unsigned char *dst = lds_d + buf * D_PBYTES + tid * 16;
+#pragma unroll
+        for (int r = 0; r < D_NIT; ++r) {
+            if (r == D_NIT - 1 && !p_valid[r]) break;
+            // window code of this piece's pixel (item origins are even): rows / columns of the image alternate 0, 1
+            const uint32_t code = (uint32_t)((((p_py[r] + 1) & 1) << 1) | ((p_px[r] + 1) & 1));
+            uint32_t q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = __uint_as_float(pv[r][e]);
+                if (UNPOOL) x = pm[r][e] == code ? x : 0.f;
+                q[e] = wino4_pack_h3(x, a.h3_vscale, bad);
+            }
+            u32x4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hi[j] = __builtin_amdgcn_perm(q[2 * j + 1], q[2 * j], 0x05040100u);
+                lo[j] = __builtin_amdgcn_perm(q[2 * j + 1], q[2 * j], 0x07060302u);
+            }
+            *reinterpret_cast<u32x4 *>(dst + r * 8192) = hi;
+            *reinterpret_cast<u32x4 *>(dst + r * 8192 + D_PLANE) = lo;
+        }
+    };
+
+    // ---- weights: 36 pieces of 1 KiB per stage, wave w copies pieces w, w + 8, ... ------------------------------------------
+    const uint32_t lds_base = lds_addr_uniform(lds_d);
+    auto dma_u = [&](const Cursor &c, int buf) __attribute__((always_inline)) {
+        const unsigned char *sb = static_cast<const unsigned char *>(a.wt_h3) + ((int64_t)c.g * nst + c.chunk) * D_UBYTES;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int piece = wave + 8 * j;
+            if (piece < 36) lds_dma16_s(sb, (uint32_t)(piece * 1024 + lane * 16), lds_base + D_U0 + buf * D_UBYTES + piece * 1024);
+        }
+    };
+
+    // ---- MFMA phase: wave (rp, ch) owns output rows 2 rp, 2 rp + 1, columns 32 ch .. 32 ch + 31 of the item, all 64 couts ----
+    const int rp = wave >> 1, ch = wave & 1;
+    f32x16 acc[2][2];           // [cout block][row]
+    auto clear_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[b][sg][r] = 0.f;
+    };
+    clear_acc();
+    const uint32_t b_off = (uint32_t)((lh * D_NPX + (2 * rp) * D_PW + ch * 32 + ln) * 16), a_off = (uint32_t)(lane * 16);
+    auto multiply = [&](int buf) __attribute__((always_inline)) {
+        const unsigned char *ps = lds_d + buf * D_PBYTES + b_off, *us = lds_d + D_U0 + buf * D_UBYTES + a_off;
+        half8 A[2][2][2], B[2][2][2];       // [tap parity][block / row][plane]
+        auto fetch = [&](int t, int par) __attribute__((always_inline)) {
+            const int ky = t / 3, kx = t - 3 * ky;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) A[par][b][pl] = *reinterpret_cast<const half8 *>(us + t * 4096 + b * 2048 + pl * 1024);
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) B[par][sg][pl] = *reinterpret_cast<const half8 *>(ps + pl * D_PLANE + ((sg + ky) * D_PW + kx) * 16);
+        };
+        // fragments one tap ahead: [8 ds_read_b128 of tap t + 1][12 MFMAs of tap t] (hipcc on its own places each read right
+        // in front of its first use — seen in the .s — and the wave then waits out the LDS latency four times per tap)
+        fetch(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int par = t & 1;
+            if (t + 1 < 9) {
+                fetch(t + 1, par ^ 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            // smallest terms first: (lo, hi) (hi, lo) (hi, hi); consecutive MFMAs on different accumulators
+#pragma unroll
+            for (int term = 0; term < 3; ++term) {
+                constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int sg = 0; sg < 2; ++sg) {
+                        if (ABL & 8) acc[b][sg][term] += (float)A[par][b][PA[term]][0] + (float)B[par][sg][PB[term]][1];
+                        else acc[b][sg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[par][b][PA[term]], B[par][sg][PB[term]], acc[b][sg], 0, 0, 0);
+                    }
+            }
+        }
+    };
+
+    // ---- output stage: register r of block (b, sg) is out[cout 64 g + 32 b + 8 (r >> 2) + 4 lh + (r & 3)][row y0 + 2 rp + sg][col x0 + 32 ch + ln]
+    auto store_item = [&](int n, int ty, int tx, int g, int par) __attribute__((always_inline)) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.out + (int64_t)n * a.Cout * plane, 0, (int)((int64_t)a.Cout * plane * 4), 0x00020000);
+        const float *epl = reinterpret_cast<const float *>(lds_d + D_EP0) + par * 128;
+        const int x = tx * D_TW + ch * 32 + ln;
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+            const int y = ty * D_TH + 2 * rp + sg;
+            const uint32_t vo = (y < a.H && x < a.W && (!(ABL & 4) || acc[0][0][0] == 12345.678f)) ? (uint32_t)(((int64_t)(4 * lh) * plane + (int64_t)y * a.W + x) * 4) : D_INV;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(epl + b * 32 + 8 * q + 4 * lh);
+                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(epl + 64 + b * 32 + 8 * q + 4 * lh);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[b][sg][4 * q + i] * sc[i] + sh[i];
+                        if (a.relu) v = v > 0.f ? v : 0.f;
+                        const int co = g * 64 + b * 32 + 8 * q + i;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, vo, (uint32_t)((int64_t)co * plane * 4), 0);
+                    }
+                }
+        }
+        clear_acc();
+    };
+
+    // ---- the stream of stages ----------------------------------------------------------------------------------------------
+    Cursor cc, cl;              // compute; loads (one stage ahead)
+    locate(cc);
+    cl = cc;
+    PSet pv, pm;
+    float epv = 0.f;            // waves 0 / 1: the epilogue scale / shift of the item whose first stage is being loaded
+    const float *ep_src = wave == 0 ? a.ep_scale : a.ep_shift;
+    bool l_first = false;       // the stage in the registers is the first of its item ...
+    int l_par = 0;              // ... of this parity
+    auto issue = [&](int buf, bool with_loads, bool with_dma) __attribute__((always_inline)) {
+        l_first = cl.chunk == 0;
+        l_par = cl.k & 1;
+        if (l_first && wave < 2) epv = ep_src[cl.g * 64 + lane];        // (used in commit: no wait here)
+        if (with_loads) load_patch(cl, pv, pm);
+        if (with_dma) dma_u(cl, buf);
+        advance(cl);
+    };
+    auto commit = [&](int buf, bool with_split) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        landed(pv, pm);
+        if (with_split) split_patch(buf, pv, pm);
+        if (l_first && wave < 2) reinterpret_cast<float *>(lds_d + D_EP0)[l_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
+    };
+    issue(0, true, true);
+    commit(0, true);
+
+    bool pend = false;          // an item ended with the previous stage: its output stage is due
+    int pn = 0, pty = 0, ptx = 0, pg = 0, ppar = 0;
+    for (int s = 0; s < total; ++s) {
+        // this wave's pieces of stage s are written (lgkmcnt), its DMA has landed (vmcnt(0) in commit); behind the barrier
+        // everybody's are, and nobody reads the buffers of stage s - 1 any more
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (pend) { store_item(pn, pty, ptx, pg, ppar); pend = false; }
+        const bool more = s + 1 < total;
+        if (more) issue((s + 1) & 1, !(ABL & 1), !(ABL & 2));
+        multiply(s & 1);
+        if (++cc.chunk == nst) {
+            pend = true; pn = cc.n; pty = cc.ty; ptx = cc.tx; pg = cc.g; ppar = cc.k & 1;
+            cc.chunk = 0;
+            if (++cc.k < my_items) locate(cc);
+        }
+        if (more) commit((s + 1) & 1, !(ABL & 16));
+    }
+    if (pend) store_item(pn, pty, ptx, pg, ppar);
+    if (bad) atomicOr(a.h3_flag, 1u);
+}
+
+// largest |x| of a tensor (calibration passes only): atomicMax on the bit pattern (non-negative floats order like their bits)
+__global__ __launch_bounds__(256) void absmax_kernel(const float *x, int64_t n, uint32_t *out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t b = __float_as_uint(m);
+        if (b > *out) atomicMax(out, b);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+bool conv3_h3_supported(int ks, int cin, int cout, int H, int W, bool unpool) {
+    if (ks != 3 || cin % D_KC || cin < 2 * D_KC || cout % 64 || H < 1 || W < 1) return false;
+    if (unpool && ((H | W) & 1)) return false;
+    return (int64_t)cin * H * W * 4 < (1ll << 31) && (int64_t)cout * H * W * 4 < (1ll << 31);
+}
+
+static inline uint16_t d3_f16_bits(float x) {
+    const _Float16 h = (_Float16)x;
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    return b;
+}
+static inline float d3_f16_value(uint16_t b) {
+    _Float16 h;
+    std::memcpy(&h, &b, 2);
+    return (float)h;
+}
+
+// Caffe (Cout,Cin,3,3) -> fp16 hi / lo planes in stage order [cout / 64][Cin / 16][tap][32-cout block][plane][octet][cout][8];
+// returns the power of two the weights were multiplied by (max |W| * scale in [2^7, 2^8))
+float conv3_h3_pack_weights(const float *W, int cin, int cout, std::vector<uint16_t> &out) {
+    float wmax = 0.f;
+    for (size_t i = 0; i < (size_t)cout * cin * 9; ++i) wmax = std::fmax(wmax, std::fabs(W[i]));
+    int ex = 0;
+    if (wmax > 0.f) (void)std::frexp(wmax, &ex);
+    const float scale = std::ldexp(1.f, 8 - ex);
+    const int nst = cin / D_KC, ng = cout / 64;
+    out.assign((size_t)ng * nst * 9 * 2048, 0);
+    for (int g = 0; g < ng; ++g)
+        for (int c = 0; c < nst; ++c)
+            for (int t = 0; t < 9; ++t)
+                for (int b = 0; b < 2; ++b) {
+                    uint16_t *img = out.data() + ((((size_t)g * nst + c) * 9 + t) * 2 + b) * 1024;      // hi plane: 512 halfs, then lo
+                    for (int o = 0; o < 2; ++o)
+                        for (int r = 0; r < 32; ++r)
+                            for (int e = 0; e < 8; ++e) {
+                                const float x = W[((size_t)(g * 64 + b * 32 + r) * cin + c * D_KC + o * 8 + e) * 9 + t] * scale;
+                                const uint16_t hi = d3_f16_bits(x);
+                                const uint16_t lo = d3_f16_bits(x - d3_f16_value(hi));
+                                const size_t at = (size_t)(o * 32 + r) * 8 + e;
+                                img[at] = hi;
+                                img[512 + at] = lo;
+                            }
+                }
+    return scale;
+}
+
+void launch_conv3_h3(const ConvArgs &a0, hipStream_t s) {
+    const bool unpool = a0.unpool_mask != nullptr;
+    if (!a0.wt_h3 || !(a0.h3_vscale > 0.f) || !a0.h3_flag || a0.drop_site >= 0 || a0.pool_out || a0.CoutPad != a0.Cout ||
+        !conv3_h3_supported(3, a0.Cin, a0.Cout, a0.H, a0.W, unpool))
+        throw std::invalid_argument("launch_conv3_h3: unsupported layer");
+    static int attr_set[64] = {0};
+    if (FirstUse once(attr_set); once) {
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_h3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_h3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
+    const dim3 grid((unsigned)((n_cu / 8) * 8 > 0 ? (n_cu / 8) * 8 : 8));      // one persistent workgroup per CU, a multiple of the 8 XCDs
+    ConvArgs a = a0;
+    a.tiles_x = (a.W + D_TW - 1) / D_TW;
+    a.tiles_y = (a.H + D_TH - 1) / D_TH;
+    // the whole LDS of the CU, as conv_wino4_h3.hip (no other workgroup beside a persistent one)
+    const size_t lds = (size_t)160 * 1024;
+#ifdef SIVO_DIAG
+    if (const char *ab = std::getenv("SIVO_D3_ABL")) {
+#define D3_ABL_CASE(n)                                                                                                                      \
+    case n:                                                                                                                                 \
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_h3_kernel<false, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((conv3_h3_kernel<false, n>), grid, dim3(512), lds, s, a);                                                        \
+        return;
+        if (!unpool) switch (std::atoi(ab)) {
+            D3_ABL_CASE(1) D3_ABL_CASE(2) D3_ABL_CASE(3) D3_ABL_CASE(4) D3_ABL_CASE(8) D3_ABL_CASE(16) D3_ABL_CASE(19) D3_ABL_CASE(23)
+            default: break;
+        }
+#undef D3_ABL_CASE
+    }
+#endif
+    if (unpool) hipLaunchKernelGGL(conv3_h3_kernel<true>, grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(conv3_h3_kernel<false>, grid, dim3(512), lds, s, a);
+}
+
+void launch_absmax(const float *x, int64_t n, uint32_t *out_bits, hipStream_t s) {
+    const int blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3(256), 0, s, x, n, out_bits);
+}
+
+}  // namespace sivo

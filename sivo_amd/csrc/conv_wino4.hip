@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "h3_split.hpp"
 #include "segnet_kernels.hpp"
 
 namespace sivo {
@@ -76,14 +77,6 @@ struct Wino4Args {
     uint32_t *vmax;             // calibration pass: atomicMax of the bit pattern of |V| (the layer's largest transformed value), or null
 };
 
-// fp32 -> packed fp16 pair (hi | lo << 16) of x * scale: hi = fp16(xs), lo = fp16(xs - hi); exact to 2^-22 |xs|
-__device__ __forceinline__ uint32_t wino4_pack_h3(float x, float scale, bool &bad) {
-    const float xs = x * scale;
-    const _Float16 hi = (_Float16)xs;
-    const _Float16 lo = (_Float16)(xs - (float)hi);
-    bad |= !(__builtin_fabsf(xs) <= 65504.f);
-    return (uint32_t)__builtin_bit_cast(unsigned short, hi) | ((uint32_t)__builtin_bit_cast(unsigned short, lo) << 16);
-}
 // end of a transform thread: report an overflow / the calibration maximum (rare / calibration only)
 __device__ __forceinline__ void wino4_report(const Wino4Args &a, bool bad, float vmax) {
     if (bad) atomicOr(a.h3_flag, 1u);

@@ -27,6 +27,15 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, uint32_t lds_byte_ad
                  : "memory");
 }
 
+// The same with a scalar base: lane l copies the 16 bytes at sbase + voff (its own byte offset) to lds_byte_addr + 16 l.
+__device__ __forceinline__ void lds_dma16_s(const void *sbase, uint32_t voff, uint32_t lds_byte_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
+                 : "memory");
+}
+
 // Workgroup barrier without the vmcnt(0) drain of __syncthreads(): this wave's LDS traffic done + s_barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 

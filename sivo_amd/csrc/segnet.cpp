@@ -1323,6 +1323,52 @@ extern "C" int sivo_debug_h3_gemm(int C, int Kp, int P, const float *V, const fl
     });
 }
 
+// Diagnostic / test: the direct f16x3 3x3 convolution (conv3_h3.hip) alone.  d_in / d_mask / d_out are device pointers
+// (d_mask null: d_in is (N, Cin, H, W); else d_in is the pooled tensor (N, Cin, H/2, W/2) and d_mask its window codes), the
+// weights (Caffe layout) and the per-channel affine are host arrays.
+extern "C" int sivo_debug_conv3_h3_dev(int N, int Cin, int Cout, int H, int W, const float *d_in, const uint8_t *d_mask,
+                                       const float *Wt, const float *scale, const float *shift, int relu, float vscale,
+                                       float *d_out, int iters, double *ms_out, int *overflowed) {
+    return guarded([&] {
+        if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device");
+        if (!d_in || !Wt || !scale || !shift || !d_out || N < 1 || !(vscale > 0.f) || !conv3_h3_supported(3, Cin, Cout, H, W, d_mask != nullptr))
+            throw std::invalid_argument("sivo_debug_conv3_h3_dev: bad argument / unsupported shape");
+        std::vector<uint16_t> planes;
+        const float uscale = conv3_h3_pack_weights(Wt, Cin, Cout, planes);
+        uint16_t *du = dev_alloc<uint16_t>(planes.size());
+        float *dsc = dev_alloc<float>(Cout), *dsh = dev_alloc<float>(Cout);
+        uint32_t *flag = nullptr;
+        SIVO_HIP(hipHostMalloc((void **)&flag, 64, hipHostMallocDefault));
+        *flag = 0;
+        SIVO_HIP(hipMemcpy(du, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+        SIVO_HIP(hipMemcpy(dsc, scale, Cout * 4, hipMemcpyHostToDevice));
+        SIVO_HIP(hipMemcpy(dsh, shift, Cout * 4, hipMemcpyHostToDevice));
+        ConvArgs a{};
+        const int64_t plane_in = d_mask ? (int64_t)(H / 2) * (W / 2) : (int64_t)H * W;
+        a.in = d_in; a.in_sample_stride = (int64_t)Cin * plane_in; a.ep_scale = dsc; a.ep_shift = dsh; a.out = d_out;
+        a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.CoutPad = Cout; a.relu = relu; a.drop_site = -1;
+        a.unpool_mask = d_mask; a.unpool_mask_stride = d_mask ? (int64_t)Cin * plane_in : 0;
+        a.wt_h3 = du; a.h3_vscale = vscale; a.h3_uscale = uscale; a.h3_flag = flag;
+        launch_conv3_h3(a, nullptr);
+        SIVO_HIP(hipDeviceSynchronize());
+        if (iters > 0 && ms_out) {
+            hipEvent_t e0, e1;
+            SIVO_HIP(hipEventCreate(&e0)); SIVO_HIP(hipEventCreate(&e1));
+            SIVO_HIP(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < iters; ++i) launch_conv3_h3(a, nullptr);
+            SIVO_HIP(hipEventRecord(e1, nullptr));
+            SIVO_HIP(hipEventSynchronize(e1));
+            float ms = 0;
+            SIVO_HIP(hipEventElapsedTime(&ms, e0, e1));
+            *ms_out = ms / iters;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        }
+        if (overflowed) *overflowed = (int)*flag;
+        (void)hipFree(du); (void)hipFree(dsc); (void)hipFree(dsh); (void)hipHostFree(flag);
+        return SIVO_OK;
+    });
+}
+
 // Diagnostic: time one convolution shape in isolation (random data), `variant` switches parts of
 // the kernel off (see ConvArgs::variant).  Returns the mean launch time in ms.
 extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, int iters, int variant, double *ms_out) {

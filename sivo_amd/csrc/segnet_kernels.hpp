@@ -70,6 +70,12 @@ bool wino4_h3_supported(int cin, int cout_pad);
 float wino4_h3_pack_weights(const std::vector<float> &U, int cin, int cout_pad, std::vector<uint16_t> &out);   // returns the scale applied
 uint32_t wino4_h3_pack_value(float x, float scale);
 void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int Kp, int P, int Pp, hipStream_t s);
+// direct 3x3 on the fp16 matrix cores, f16x3 (conv3_h3.hip): weights in ConvArgs::wt_h3, h3_vscale = the power of two the
+// INPUT ACTIVATION is multiplied with before it is split (calibrated), h3_uscale the weights' power of two, h3_flag the overflow flag
+bool conv3_h3_supported(int ks, int cin, int cout, int H, int W, bool unpool);
+float conv3_h3_pack_weights(const float *W, int cin, int cout, std::vector<uint16_t> &out);      // returns the scale applied
+void launch_conv3_h3(const ConvArgs &a, hipStream_t s);
+void launch_absmax(const float *x, int64_t n, uint32_t *out_bits, hipStream_t s);                 // atomicMax of the bit pattern of |x|
 // direct 7x7, 64 -> 64, on the bf16 matrix cores with fp32 operands as three bf16 planes (conv7_x6.hip); weights in ConvArgs::wt_x6
 bool conv7_x6_supported(int ks, int cin, int cout, int H, int W);
 void conv7_x6_pack_weights(const float *W, int cin, int cout, std::vector<uint16_t> &out);

@@ -193,6 +193,32 @@ def h3_gemm(V, U, P, vscale=None, iters=0):
     return M, (ms.value if iters else None)
 
 
+def conv3_h3(x, weight, scale, shift, relu=True, mask=None, vscale=None, iters=0):
+    """The direct f16x3 3x3 convolution alone (sivo_debug_conv3_h3_dev).  x: cuda fp32 (N, Cin, H, W), or with `mask` (cuda
+    u8 window codes of the same shape) the POOLED tensor (N, Cin, H/2, W/2) the layer reads through; weight (Cout, Cin, 3, 3),
+    scale / shift (Cout) numpy.  Returns (out cuda (N, Cout, H, W), mean launch ms or None, overflowed)."""
+    x = x.contiguous()
+    N, Cin, h, w = x.shape
+    H, W = (2 * h, 2 * w) if mask is not None else (h, w)
+    weight = np.ascontiguousarray(weight, np.float32)
+    scale = np.ascontiguousarray(scale, np.float32); shift = np.ascontiguousarray(shift, np.float32)
+    Cout = weight.shape[0]
+    assert weight.shape == (Cout, Cin, 3, 3) and scale.shape == (Cout,) and shift.shape == (Cout,)
+    if mask is not None:
+        mask = mask.contiguous()
+        assert mask.shape == x.shape and mask.dtype == torch.uint8
+    if vscale is None:
+        vscale = float(2.0 ** (8 - np.frexp(float(x.abs().max()))[1]))
+    out = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device)
+    ms = C.c_double(0)
+    ov = C.c_int(0)
+    check(lib().sivo_debug_conv3_h3_dev(N, Cin, Cout, H, W, x.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                        weight.ctypes.data_as(C.c_void_p), scale.ctypes.data_as(C.c_void_p),
+                                        shift.ctypes.data_as(C.c_void_p), int(relu), C.c_float(vscale), out.data_ptr(), iters,
+                                        C.byref(ms), C.byref(ov)))
+    return out, (ms.value if iters else None), bool(ov.value)
+
+
 def mc_reduce(logits, prob_sum=None, want_prob=False, accumulate=False):
     n, K, H, W = logits.shape
     if prob_sum is None:
