@@ -72,9 +72,19 @@ constexpr int D_NPIECE = 2 * D_NPX;                // 1320
 constexpr uint32_t D_INV = 0xfffffff0u;            // beyond any descriptor: loads return 0, stores are dropped
 static_assert(D_LDS <= 160 * 1024, "LDS");
 
+// Two forms of the stage loop (FORM; bit-identical results — same products, same order):
+//   0  "phased": barrier -> output stage -> issue loads / DMA of stage s + 1 -> multiply stage s -> wait -> split stage s + 1.
+//      Everything but the multiply runs with the matrix cores idle (all eight waves are in the same phase).  Measured on
+//      conv1_2_D (tools/d3_probe.py): 1.03 ms as built, 0.65 ms with loads, split and stores removed.
+//   1  "interleaved" (default): the multiply of stage s is cut into 36 slots of 3 MFMAs, and the other work of the iteration
+//      is dealt over the slots in source order, pinned by __builtin_amdgcn_sched_barrier(0): slots 0-4 the weight DMA of
+//      stage s + 1, slots 5-16 the patch loads of stage s + 2 (a second register set: they land during the rest of this
+//      multiply and the next top-of-iteration wait finds them done), slots 17-34 the split of stage s + 1 (loaded during the
+//      previous iteration) into the other patch buffer.  The VALU / VMEM / LDS-write instructions issue in the shadow of the
+//      MFMAs (an MFMA occupies the pipe for 32 cycles, its issue 4).
 // ABL (diagnostic builds only, -DSIVO_DIAG; results are wrong by construction): 1 no patch loads after the prologue,
 // 2 no weight DMA after the prologue, 4 no output stores, 8 no MFMAs, 16 no patch split / LDS writes after the prologue.
-template <bool UNPOOL, int ABL = 0>
+template <bool UNPOOL, int FORM, int ABL = 0>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3_h3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_d[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -130,74 +140,85 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         p_px[r] = rem - p_py[r] * D_PW;
     }
     typedef uint32_t PSet[D_NIT][8];
-    auto load_patch = [&](const Cursor &c, PSet &pv, PSet &pm) __attribute__((always_inline)) {
+    struct LoadPlan {        // what the loads of one stage need: descriptors (wave-uniform) and this lane's offsets
+        i32x4 rs, mrs;
+        uint32_t vo[D_NIT], mo[D_NIT];
+        int chunk;
+    };
+    auto plan_loads = [&](const Cursor &c, LoadPlan &lp) __attribute__((always_inline)) {
         const uint64_t base = (uint64_t)(uintptr_t)(a.in + (int64_t)c.n * a.in_sample_stride);
-        const i32x4 rs = {(int)(uint32_t)base, (int)(uint32_t)((base >> 32) & 0xffffu), (int)(a.Cin * plane_in * 4), 0x00020000};
+        lp.rs = (i32x4){(int)(uint32_t)base, (int)(uint32_t)((base >> 32) & 0xffffu), (int)(a.Cin * plane_in * 4), 0x00020000};
         const uint64_t mbase = UNPOOL ? (uint64_t)(uintptr_t)(a.unpool_mask + (int64_t)c.n * a.unpool_mask_stride) : base;
-        const i32x4 mrs = {(int)(uint32_t)mbase, (int)(uint32_t)((mbase >> 32) & 0xffffu), (int)(a.Cin * plane_in), 0x00020000};
+        lp.mrs = (i32x4){(int)(uint32_t)mbase, (int)(uint32_t)((mbase >> 32) & 0xffffu), (int)(a.Cin * plane_in), 0x00020000};
+        lp.chunk = c.chunk;
         const int y0 = c.ty * D_TH, x0 = c.tx * D_TW;
 #pragma unroll
         for (int r = 0; r < D_NIT; ++r) {
             const int gy = y0 + p_py[r] - 1, gx = x0 + p_px[r] - 1;
             const bool inside = p_valid[r] && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
             const uint32_t idx = (uint32_t)(p_o[r] * 8 * plane_in) + (UNPOOL ? (uint32_t)((gy >> 1) * Wh + (gx >> 1)) : (uint32_t)(gy * a.W + gx));
-            const uint32_t vo = inside ? idx * 4u : D_INV, mo = inside ? idx : D_INV;
+            lp.vo[r] = inside ? idx * 4u : D_INV;
+            lp.mo[r] = inside ? idx : D_INV;
+        }
+    };
+    // load number L (0 .. 23) of a stage: channel e = L % 8 of piece r = L / 8 (value, and with UNPOOL its window code)
+    auto load_one = [&](const LoadPlan &lp, int L, PSet &pv, PSet &pm) __attribute__((always_inline)) {
+        const int r = L >> 3, e = L & 7;
+        // (readfirstlane: the value is wave-uniform, but hipcc may have computed it on the vector ALU, and an "s" operand of an
+        // asm statement is not legalised — the assembler then rejects a VGPR in the soffset position)
+        const uint32_t sm = (uint32_t)__builtin_amdgcn_readfirstlane((lp.chunk * D_KC + e) * (int)plane_in);
+        const uint32_t so = sm * 4u;
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=&v"(pv[r][e]) : "v"(lp.vo[r]), "s"(lp.rs), "s"(so) : "memory");
+        if (UNPOOL) {
+            asm volatile("buffer_load_ubyte %0, %1, %2, %3 offen" : "=&v"(pm[r][e]) : "v"(lp.mo[r]), "s"(lp.mrs), "s"(sm) : "memory");
+        }
+    };
+    // the loads of a set have landed (the caller's s_waitcnt): from here on its registers may be read.  UNPOOL: the value
+    // stays where its window code says this pixel is the window's maximum, else 0 (the codes' registers are free again)
+    auto landed = [&](PSet &pv, PSet &pm) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < D_NIT; ++r) {
+            // window code of this piece's pixel (item origins are even): rows / columns of the image alternate 0, 1
+            const uint32_t code = (uint32_t)((((p_py[r] + 1) & 1) << 1) | ((p_px[r] + 1) & 1));
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const uint32_t so = (uint32_t)((int64_t)(c.chunk * D_KC + e) * plane_in * 4);
-                asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=&v"(pv[r][e]) : "v"(vo), "s"(rs), "s"(so) : "memory");
+                asm volatile("" : "+v"(pv[r][e]));
                 if (UNPOOL) {
-                    const uint32_t sm = (uint32_t)((int64_t)(c.chunk * D_KC + e) * plane_in);
-                    asm volatile("buffer_load_ubyte %0, %1, %2, %3 offen" : "=&v"(pm[r][e]) : "v"(mo), "s"(mrs), "s"(sm) : "memory");
+                    asm volatile("" : "+v"(pm[r][e]));
+                    pv[r][e] = pm[r][e] == code ? pv[r][e] : 0u;
                 }
             }
         }
     };
-    // the loads of a set have landed (the caller's s_waitcnt): from here on its registers may be read
-    auto landed = [&](PSet &pv, PSet &pm) __attribute__((always_inline)) {
+    bool bad = false;
+    // split of piece r, in steps: 0..3 -> channels 2 step, 2 step + 1 become (hi | lo << 16) in place; 4 -> the hi plane's
+    // piece is written; 5 -> the lo plane's
+    auto split_step = [&](int buf, PSet &pv, int r, int step) __attribute__((always_inline)) {
+        if (r == D_NIT - 1 && !p_valid[r]) return;
+        unsigned char *dst = lds_d + buf * D_PBYTES + tid * 16 + r * 8192;
+        if (step < 4) {
+#pragma unroll
+            for (int e = 2 * step; e < 2 * step + 2; ++e) pv[r][e] = wino4_pack_h3(__uint_as_float(pv[r][e]), a.h3_vscale, bad);
+        } else {
+            u32x4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = __builtin_amdgcn_perm(pv[r][2 * j + 1], pv[r][2 * j], step == 4 ? 0x05040100u : 0x07060302u);
+            *reinterpret_cast<u32x4 *>(dst + (step == 4 ? 0 : D_PLANE)) = w;
+        }
+    };
+    auto split_all = [&](int buf, PSet &pv) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < D_NIT; ++r)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                asm volatile("" : "+v"(pv[r][e]));
-                if (UNPOOL) asm volatile("" : "+v"(pm[r][e]));
-            }
-    };
-    bool bad = false;
-    auto split_patch = [&](int buf, const PSet &pv, const PSet &pm) __attribute__((always_inline)) {
-        unsigned char *dst = lds_d + buf * D_PBYTES + tid * 16;
-#pragma unroll
-        for (int r = 0; r < D_NIT; ++r) {
-            if (r == D_NIT - 1 && !p_valid[r]) break;
-            // window code of this piece's pixel (item origins are even): rows / columns of the image alternate 0, 1
-            const uint32_t code = (uint32_t)((((p_py[r] + 1) & 1) << 1) | ((p_px[r] + 1) & 1));
-            uint32_t q[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float x = __uint_as_float(pv[r][e]);
-                if (UNPOOL) x = pm[r][e] == code ? x : 0.f;
-                q[e] = wino4_pack_h3(x, a.h3_vscale, bad);
-            }
-            u32x4 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                hi[j] = __builtin_amdgcn_perm(q[2 * j + 1], q[2 * j], 0x05040100u);
-                lo[j] = __builtin_amdgcn_perm(q[2 * j + 1], q[2 * j], 0x07060302u);
-            }
-            *reinterpret_cast<u32x4 *>(dst + r * 8192) = hi;
-            *reinterpret_cast<u32x4 *>(dst + r * 8192 + D_PLANE) = lo;
-        }
+            for (int step = 0; step < 6; ++step) split_step(buf, pv, r, step);
     };
 
     // ---- weights: 36 pieces of 1 KiB per stage, wave w copies pieces w, w + 8, ... ------------------------------------------
     const uint32_t lds_base = lds_addr_uniform(lds_d);
-    auto dma_u = [&](const Cursor &c, int buf) __attribute__((always_inline)) {
+    auto dma_piece = [&](const Cursor &c, int buf, int j) __attribute__((always_inline)) {
         const unsigned char *sb = static_cast<const unsigned char *>(a.wt_h3) + ((int64_t)c.g * nst + c.chunk) * D_UBYTES;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int piece = wave + 8 * j;
-            if (piece < 36) lds_dma16_s(sb, (uint32_t)(piece * 1024 + lane * 16), lds_base + D_U0 + buf * D_UBYTES + piece * 1024);
-        }
+        const int piece = wave + 8 * j;
+        if (piece < 36) lds_dma16_s(sb, (uint32_t)(piece * 1024 + lane * 16), lds_base + D_U0 + buf * D_UBYTES + piece * 1024);
     };
 
     // ---- MFMA phase: wave (rp, ch) owns output rows 2 rp, 2 rp + 1, columns 32 ch .. 32 ch + 31 of the item, all 64 couts ----
@@ -213,44 +234,28 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     };
     clear_acc();
     const uint32_t b_off = (uint32_t)((lh * D_NPX + (2 * rp) * D_PW + ch * 32 + ln) * 16), a_off = (uint32_t)(lane * 16);
-    auto multiply = [&](int buf) __attribute__((always_inline)) {
+    half8 A[2][2][2], B[2][2][2];       // [tap parity][block / row][plane]
+    auto fetch = [&](int buf, int t, int par) __attribute__((always_inline)) {
         const unsigned char *ps = lds_d + buf * D_PBYTES + b_off, *us = lds_d + D_U0 + buf * D_UBYTES + a_off;
-        half8 A[2][2][2], B[2][2][2];       // [tap parity][block / row][plane]
-        auto fetch = [&](int t, int par) __attribute__((always_inline)) {
-            const int ky = t / 3, kx = t - 3 * ky;
+        const int ky = t / 3, kx = t - 3 * ky;
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) A[par][b][pl] = *reinterpret_cast<const half8 *>(us + t * 4096 + b * 2048 + pl * 1024);
+            for (int pl = 0; pl < 2; ++pl) A[par][b][pl] = *reinterpret_cast<const half8 *>(us + t * 4096 + b * 2048 + pl * 1024);
 #pragma unroll
-            for (int sg = 0; sg < 2; ++sg)
+        for (int sg = 0; sg < 2; ++sg)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) B[par][sg][pl] = *reinterpret_cast<const half8 *>(ps + pl * D_PLANE + ((sg + ky) * D_PW + kx) * 16);
-        };
-        // fragments one tap ahead: [8 ds_read_b128 of tap t + 1][12 MFMAs of tap t] (hipcc on its own places each read right
-        // in front of its first use — seen in the .s — and the wave then waits out the LDS latency four times per tap)
-        fetch(0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            for (int pl = 0; pl < 2; ++pl) B[par][sg][pl] = *reinterpret_cast<const half8 *>(ps + pl * D_PLANE + ((sg + ky) * D_PW + kx) * 16);
+    };
+    // MFMAs 3 q .. 3 q + 2 of a tap's twelve: smallest terms first — (lo, hi) (hi, lo) (hi, hi) — consecutive MFMAs on
+    // different accumulators
+    auto mfma3 = [&](int par, int q) __attribute__((always_inline)) {
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int par = t & 1;
-            if (t + 1 < 9) {
-                fetch(t + 1, par ^ 1);
-                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-            // smallest terms first: (lo, hi) (hi, lo) (hi, hi); consecutive MFMAs on different accumulators
-#pragma unroll
-            for (int term = 0; term < 3; ++term) {
-                constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int sg = 0; sg < 2; ++sg) {
-                        if (ABL & 8) acc[b][sg][term] += (float)A[par][b][PA[term]][0] + (float)B[par][sg][PB[term]][1];
-                        else acc[b][sg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[par][b][PA[term]], B[par][sg][PB[term]], acc[b][sg], 0, 0, 0);
-                    }
-            }
+        for (int m = 3 * q; m < 3 * q + 3; ++m) {
+            const int term = m >> 2, b = (m >> 1) & 1, sg = m & 1;
+            if (ABL & 8) acc[b][sg][term] += (float)A[par][b][PA[term]][0] + (float)B[par][sg][PB[term]][1];
+            else acc[b][sg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[par][b][PA[term]], B[par][sg][PB[term]], acc[b][sg], 0, 0, 0);
         }
     };
 
@@ -282,50 +287,166 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     };
 
     // ---- the stream of stages ----------------------------------------------------------------------------------------------
-    Cursor cc, cl;              // compute; loads (one stage ahead)
+    Cursor cc;                  // compute
     locate(cc);
-    cl = cc;
-    PSet pv, pm;
-    float epv = 0.f;            // waves 0 / 1: the epilogue scale / shift of the item whose first stage is being loaded
+    float epv = 0.f;            // waves 0 / 1: the epilogue scale / shift of an item, on its way to LDS
     const float *ep_src = wave == 0 ? a.ep_scale : a.ep_shift;
-    bool l_first = false;       // the stage in the registers is the first of its item ...
-    int l_par = 0;              // ... of this parity
-    auto issue = [&](int buf, bool with_loads, bool with_dma) __attribute__((always_inline)) {
-        l_first = cl.chunk == 0;
-        l_par = cl.k & 1;
-        if (l_first && wave < 2) epv = ep_src[cl.g * 64 + lane];        // (used in commit: no wait here)
-        if (with_loads) load_patch(cl, pv, pm);
-        if (with_dma) dma_u(cl, buf);
-        advance(cl);
-    };
-    auto commit = [&](int buf, bool with_split) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        landed(pv, pm);
-        if (with_split) split_patch(buf, pv, pm);
-        if (l_first && wave < 2) reinterpret_cast<float *>(lds_d + D_EP0)[l_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
-    };
-    issue(0, true, true);
-    commit(0, true);
-
     bool pend = false;          // an item ended with the previous stage: its output stage is due
     int pn = 0, pty = 0, ptx = 0, pg = 0, ppar = 0;
-    for (int s = 0; s < total; ++s) {
-        // this wave's pieces of stage s are written (lgkmcnt), its DMA has landed (vmcnt(0) in commit); behind the barrier
-        // everybody's are, and nobody reads the buffers of stage s - 1 any more
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (pend) { store_item(pn, pty, ptx, pg, ppar); pend = false; }
-        const bool more = s + 1 < total;
-        if (more) issue((s + 1) & 1, !(ABL & 1), !(ABL & 2));
-        multiply(s & 1);
+    auto end_of_stage = [&]() __attribute__((always_inline)) {
         if (++cc.chunk == nst) {
             pend = true; pn = cc.n; pty = cc.ty; ptx = cc.tx; pg = cc.g; ppar = cc.k & 1;
             cc.chunk = 0;
             if (++cc.k < my_items) locate(cc);
         }
-        if (more) commit((s + 1) & 1, !(ABL & 16));
+    };
+
+    // ABL & 64 (diagnostic builds): shader-clock stamps around the parts of an iteration, summed per wave into a.vmax[0..4]
+    // (wait for the previous iteration's memory traffic, barrier, output stage, multiply + interleaved work, iterations)
+    auto stamp = [&]() __attribute__((always_inline)) -> uint32_t {
+        uint64_t t = 0;
+        if (ABL & 64) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return (uint32_t)t;
+    };
+    uint32_t st_wait = 0, st_bar = 0, st_out = 0, st_mul = 0;
+    const uint32_t st_begin = stamp();
+    if (FORM == 0) {
+        Cursor cl = cc;         // loads, one stage ahead
+        PSet pv, pm;
+        bool l_first = false;   // the stage in the registers is the first of its item ...
+        int l_par = 0;          // ... of this parity
+        auto issue = [&](int buf, bool with_loads, bool with_dma) __attribute__((always_inline)) {
+            l_first = cl.chunk == 0;
+            l_par = cl.k & 1;
+            if (l_first && wave < 2) epv = ep_src[cl.g * 64 + lane];        // (used in commit: no wait here)
+            if (with_loads) {
+                LoadPlan lp;
+                plan_loads(cl, lp);
+#pragma unroll
+                for (int L = 0; L < 8 * D_NIT; ++L) load_one(lp, L, pv, pm);
+            }
+            if (with_dma)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) dma_piece(cl, buf, j);
+            advance(cl);
+        };
+        auto commit = [&](int buf, bool with_split) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            landed(pv, pm);
+            if (with_split) split_all(buf, pv);
+            if (l_first && wave < 2) reinterpret_cast<float *>(lds_d + D_EP0)[l_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
+        };
+        issue(0, true, true);
+        commit(0, true);
+        for (int s = 0; s < total; ++s) {
+            // this wave's pieces of stage s are written (lgkmcnt), its DMA has landed (vmcnt(0) in commit); behind the barrier
+            // everybody's are, and nobody reads the buffers of stage s - 1 any more
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (pend) { store_item(pn, pty, ptx, pg, ppar); pend = false; }
+            const bool more = s + 1 < total;
+            if (more) issue((s + 1) & 1, !(ABL & 1), !(ABL & 2));
+            // fragments one tap ahead: [8 ds_read_b128 of tap t + 1][12 MFMAs of tap t] (hipcc on its own places each read right
+            // in front of its first use — seen in the .s — and the wave then waits out the LDS latency four times per tap)
+            fetch(s & 1, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (t + 1 < 9) {
+                    fetch(s & 1, t + 1, (t + 1) & 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mfma3(t & 1, q);
+            }
+            end_of_stage();
+            if (more) commit((s + 1) & 1, !(ABL & 16));
+        }
+    } else {
+        Cursor cu = cc, cl = cc;    // weight DMA (one stage ahead of the multiply); patch loads (two stages ahead)
+        PSet vA, vB, pm;            // even iterations split vA (stage s + 1) and load stage s + 2 into vB; odd ones the reverse
+        bool ep_due = false;        // epv holds the affine of an item whose first stage's DMA was issued in the previous iteration
+        int ep_par = 0;
+        LoadPlan lp;
+        // prologue: patch(0) -> LDS, weights(0) in flight, patch(1) in flight into vA
+        plan_loads(cl, lp);
+#pragma unroll
+        for (int L = 0; L < 8 * D_NIT; ++L) load_one(lp, L, vB, pm);
+        advance(cl);
+        if (wave < 2) { epv = ep_src[cu.g * 64 + lane]; }
+        ep_due = true; ep_par = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) dma_piece(cu, 0, j);
+        advance(cu);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        landed(vB, pm);
+        split_all(0, vB);
+        if (1 < total) {
+            plan_loads(cl, lp);
+#pragma unroll
+            for (int L = 0; L < 8 * D_NIT; ++L) load_one(lp, L, vA, pm);
+            advance(cl);
+        }
+        auto iteration = [&](const int s, PSet &vs, PSet &vl) __attribute__((always_inline)) {
+            // Everything this wave issued in the previous iteration has had a whole multiply to complete: the weights of stage s
+            // (DMA), the patch of stage s + 1 (registers vs), the stores of an output stage.  This wave's pieces of the patch of
+            // stage s are written (lgkmcnt).  Behind the barrier nobody reads the buffers of stage s - 1 any more.
+            const uint32_t t0 = stamp();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t t1 = stamp();
+            if (ep_due && wave < 2) reinterpret_cast<float *>(lds_d + D_EP0)[ep_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
+            ep_due = false;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const uint32_t t2 = stamp();
+            if (pend) { store_item(pn, pty, ptx, pg, ppar); pend = false; }
+            const uint32_t t3 = stamp();
+            const bool more = s + 1 < total, more2 = s + 2 < total;
+            if (more) landed(vs, pm);
+            const int nb = (s + 1) & 1;
+            if (more2) plan_loads(cl, lp);
+            if (more && cu.chunk == 0) {
+                ep_due = true; ep_par = cu.k & 1;
+                if (wave < 2) epv = ep_src[cu.g * 64 + lane];
+            }
+            fetch(s & 1, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int slot = 0; slot < 36; ++slot) {
+                const int t = slot >> 2, q = slot & 3;
+                if (q == 0 && t + 1 < 9) fetch(s & 1, t + 1, (t + 1) & 1);
+                mfma3(t & 1, q);
+                if (slot < 5) {
+                    if (more && !(ABL & 2)) dma_piece(cu, nb, slot);
+                } else if (slot < 17) {
+                    if (more2 && !(ABL & 1)) {
+                        load_one(lp, 2 * (slot - 5), vl, pm);
+                        load_one(lp, 2 * (slot - 5) + 1, vl, pm);
+                    }
+                } else if (slot < 35) {
+                    if (more && !(ABL & 16)) split_step(nb, vs, (slot - 17) / 6, (slot - 17) % 6);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ABL & 64) {
+                const uint32_t t4 = stamp();
+                st_wait += (t1 - t0) & 0xfffffu; st_bar += (t2 - t1) & 0xfffffu; st_out += (t3 - t2) & 0xfffffu; st_mul += (t4 - t3) & 0xfffffu;
+            }
+            if (more) advance(cu);
+            if (more2) advance(cl);
+            end_of_stage();
+        };
+        for (int s = 0; s < total; s += 2) {
+            iteration(s, vA, vB);
+            if (s + 1 < total) iteration(s + 1, vB, vA);
+        }
     }
     if (pend) store_item(pn, pty, ptx, pg, ppar);
     if (bad) atomicOr(a.h3_flag, 1u);
+    if ((ABL & 64) && a.vmax && lane == 0) {
+        atomicAdd(a.vmax + 0, st_wait >> 4); atomicAdd(a.vmax + 1, st_bar >> 4); atomicAdd(a.vmax + 2, st_out >> 4); atomicAdd(a.vmax + 3, st_mul >> 4);
+        atomicAdd(a.vmax + 4, (uint32_t)total);
+        atomicMax(a.vmax + 5, stamp() - st_begin);
+    }
 }
 
 // largest |x| of a tensor (calibration passes only): atomicMax on the bit pattern (non-negative floats order like their bits)
@@ -397,8 +518,8 @@ void launch_conv3_h3(const ConvArgs &a0, hipStream_t s) {
         throw std::invalid_argument("launch_conv3_h3: unsupported layer");
     static int attr_set[64] = {0};
     if (FirstUse once(attr_set); once) {
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_h3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_h3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (const void *f : {(const void *)conv3_h3_kernel<false, 0>, (const void *)conv3_h3_kernel<true, 0>, (const void *)conv3_h3_kernel<false, 1>, (const void *)conv3_h3_kernel<true, 1>})
+            SIVO_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
     const dim3 grid((unsigned)((n_cu / 8) * 8 > 0 ? (n_cu / 8) * 8 : 8));      // one persistent workgroup per CU, a multiple of the 8 XCDs
@@ -407,22 +528,34 @@ void launch_conv3_h3(const ConvArgs &a0, hipStream_t s) {
     a.tiles_y = (a.H + D_TH - 1) / D_TH;
     // the whole LDS of the CU, as conv_wino4_h3.hip (no other workgroup beside a persistent one)
     const size_t lds = (size_t)160 * 1024;
+    // SIVO_D3_FORM=0: the phased stage loop (read at every launch: tests compare the two forms bit for bit)
+    const int form = std::getenv("SIVO_D3_FORM") && std::atoi(std::getenv("SIVO_D3_FORM")) == 0 ? 0 : 1;
 #ifdef SIVO_DIAG
     if (const char *ab = std::getenv("SIVO_D3_ABL")) {
 #define D3_ABL_CASE(n)                                                                                                                      \
     case n:                                                                                                                                 \
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_h3_kernel<false, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        hipLaunchKernelGGL((conv3_h3_kernel<false, n>), grid, dim3(512), lds, s, a);                                                        \
+        if (form == 0) {                                                                                                                    \
+            SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_h3_kernel<false, 0, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            hipLaunchKernelGGL((conv3_h3_kernel<false, 0, n>), grid, dim3(512), lds, s, a);                                                 \
+        } else {                                                                                                                            \
+            SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_h3_kernel<false, 1, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            hipLaunchKernelGGL((conv3_h3_kernel<false, 1, n>), grid, dim3(512), lds, s, a);                                                 \
+        }                                                                                                                                   \
         return;
         if (!unpool) switch (std::atoi(ab)) {
-            D3_ABL_CASE(1) D3_ABL_CASE(2) D3_ABL_CASE(3) D3_ABL_CASE(4) D3_ABL_CASE(8) D3_ABL_CASE(16) D3_ABL_CASE(19) D3_ABL_CASE(23)
+            D3_ABL_CASE(1) D3_ABL_CASE(2) D3_ABL_CASE(3) D3_ABL_CASE(4) D3_ABL_CASE(8) D3_ABL_CASE(16) D3_ABL_CASE(19) D3_ABL_CASE(23) D3_ABL_CASE(64) D3_ABL_CASE(65) D3_ABL_CASE(68)
             default: break;
         }
 #undef D3_ABL_CASE
     }
 #endif
-    if (unpool) hipLaunchKernelGGL(conv3_h3_kernel<true>, grid, dim3(512), lds, s, a);
-    else hipLaunchKernelGGL(conv3_h3_kernel<false>, grid, dim3(512), lds, s, a);
+    if (form == 0) {
+        if (unpool) hipLaunchKernelGGL((conv3_h3_kernel<true, 0>), grid, dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((conv3_h3_kernel<false, 0>), grid, dim3(512), lds, s, a);
+    } else {
+        if (unpool) hipLaunchKernelGGL((conv3_h3_kernel<true, 1>), grid, dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((conv3_h3_kernel<false, 1>), grid, dim3(512), lds, s, a);
+    }
 }
 
 void launch_absmax(const float *x, int64_t n, uint32_t *out_bits, hipStream_t s) {

@@ -59,6 +59,11 @@ struct Op {
     float h3_uscale = 1.f;     // power of two
     float h3_vscale = 0.f;     // power of two the layer's transformed input is multiplied with (set by the calibration pass; 0 = not calibrated)
     float h3_vmax = 0.f;       // largest |V| of the calibration frame
+    // conv3_h3.hip: the narrow 3x3 layers as a DIRECT convolution on the fp16 matrix cores (f16x3).  The flags below (wino4f /
+    // wino / v2) then describe the layer's fp32 kernel, which runs the calibration frame and every frame after an fp16 overflow
+    bool d3 = false;
+    void *d_wd3 = nullptr;     // Caffe weights as fp16 hi / lo planes times d3_uscale, in the kernel's stage order
+    float d3_uscale = 1.f, d3_vscale = 0.f, d3_vmax = 0.f;   // d3_vscale: power of two for the INPUT ACTIVATION (calibrated; 0 = not yet)
     int bridge_to = -1;        // w4_bridge: the op whose transformed input this layer's bridge kernel writes
     float *d_w_mc = nullptr;   // classifier: second copy of the weights in the layout of conv_cls_mc.hip (fused with the MC post-processing)
     bool mc_fused_last = false;   // profiling: the last timed launch of this op was the fused kernel
@@ -197,7 +202,23 @@ void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int 
     // switches at pool1, 0.46 % instead of 0.04 % of the final class map differing from the oracle.  The prefix runs once
     // per frame, so keeping it on F(2x2) costs 0.13 ms.
     const bool f4_ok = !no_wino && !keep_ties;
-    op.wino4 = f4_ok && !no_wino4 && wino4_supported(ks, cin, cout, H, Wd);
+    // Narrow layers (<= SIVO_D3_MAXC = 128 channels in and out): the direct f16x3 kernel (conv3_h3.hip), whenever the handle
+    // runs its F(4x4) GEMMs on f16x3 as well (SIVO_GEMM unset) — SIVO_D3=0 disables.  A direct kernel treats every output
+    // position alike, so it also keeps the exact pooling ties of the prefix.
+    const char *gemm_env = std::getenv("SIVO_GEMM");
+    const bool gemm_default = !(gemm_env && (std::string(gemm_env) == "x6" || std::string(gemm_env) == "f32"));      // (read per handle: tests build several)
+    const bool no_d3 = std::getenv("SIVO_D3") && std::atoi(std::getenv("SIVO_D3")) == 0;
+    const int d3_maxc = std::getenv("SIVO_D3_MAXC") ? std::atoi(std::getenv("SIVO_D3_MAXC")) : 128;
+    const bool d3_prefix = !(std::getenv("SIVO_D3_PREFIX") && std::atoi(std::getenv("SIVO_D3_PREFIX")) == 0);
+    op.d3 = !no_d3 && !no_wino && gemm_default && (d3_prefix || !keep_ties) && cin <= d3_maxc && cout <= d3_maxc && conv3_h3_supported(ks, cin, cout, H, Wd, false);
+    if (op.d3) {
+        std::vector<uint16_t> planes;
+        op.d3_uscale = conv3_h3_pack_weights(W, cin, cout, planes);
+        op.d_wd3 = dev_alloc<uint16_t>(planes.size());
+        S.owned.push_back(op.d_wd3);
+        SIVO_HIP(hipMemcpy(op.d_wd3, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    op.wino4 = !op.d3 && f4_ok && !no_wino4 && wino4_supported(ks, cin, cout, H, Wd);
     // narrow layers (below the F(4x4) GEMM threshold): the fused F(4x4) kernel — SIVO_NO_WINO4F falls back to fused F(2x2)
     static const bool no_wino4f = std::getenv("SIVO_NO_WINO4F") != nullptr;
     op.wino4f = !op.wino4 && f4_ok && !no_wino4f && wino4f_supported(ks, cin, cout, H, Wd);
@@ -599,15 +620,15 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
 // SIVO_H3_BOOST=k multiplies the scales by 2^k (tests: k = 9 forces the overflow path).
 void calibrate_h3(sivo_segnet &S) {
     bool any = false;
-    for (const Op &op : S.ops) any = any || op.d_wh3;
+    for (const Op &op : S.ops) any = any || op.d_wh3 || op.d3;
     if (!any) return;
     uint32_t *flag = nullptr;
     SIVO_HIP(hipHostMalloc((void **)&flag, 64, hipHostMallocDefault));
     *flag = 0;
     S.h3_flag = flag;
-    S.d_h3_vmax = dev_alloc<uint32_t>(S.ops.size());
+    S.d_h3_vmax = dev_alloc<uint32_t>(2 * S.ops.size());         // [op]: largest |V| of an F(4x4) layer; [ops + op]: largest |input| of a direct f16x3 layer
     S.owned.push_back(S.d_h3_vmax);
-    SIVO_HIP(hipMemset(S.d_h3_vmax, 0, S.ops.size() * sizeof(uint32_t)));
+    SIVO_HIP(hipMemset(S.d_h3_vmax, 0, 2 * S.ops.size() * sizeof(uint32_t)));
     const std::vector<uint8_t> img = calibration_frame(S.H, S.W);
     SIVO_HIP(hipMemcpy(S.d_image, img.data(), img.size(), hipMemcpyHostToDevice));
     S.calibrating = true;
@@ -619,18 +640,21 @@ void calibrate_h3(sivo_segnet &S) {
         throw;
     }
     S.calibrating = false;
-    std::vector<uint32_t> bits(S.ops.size());
+    std::vector<uint32_t> bits(2 * S.ops.size());
     SIVO_HIP(hipMemcpy(bits.data(), S.d_h3_vmax, bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     const int boost = std::getenv("SIVO_H3_BOOST") ? std::atoi(std::getenv("SIVO_H3_BOOST")) : 0;
-    for (size_t i = 0; i < S.ops.size(); ++i) {
-        Op &op = S.ops[i];
-        if (!op.d_wh3) continue;
+    auto scale_for = [&](uint32_t b, float *vmax) {
         float v;
-        std::memcpy(&v, &bits[i], 4);
-        op.h3_vmax = v;
+        std::memcpy(&v, &b, 4);
+        *vmax = v;
         int e = 0;
         if (v > 0.f && std::isfinite(v)) (void)std::frexp(v, &e);        // v = m 2^e, m in [0.5, 1)
-        op.h3_vscale = std::ldexp(1.f, (v > 0.f && std::isfinite(v) ? 8 - e : 0) + boost);
+        return std::ldexp(1.f, (v > 0.f && std::isfinite(v) ? 8 - e : 0) + boost);
+    };
+    for (size_t i = 0; i < S.ops.size(); ++i) {
+        Op &op = S.ops[i];
+        if (op.d_wh3) op.h3_vscale = scale_for(bits[i], &op.h3_vmax);
+        if (op.d3) op.d3_vscale = scale_for(bits[S.ops.size() + i], &op.d3_vmax);
     }
     S.h3_on = true;
 }
@@ -704,7 +728,19 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                     a.in = fptr(bp); a.in_sample_stride = bp.shared ? 0 : bp.chw();
                     a.unpool_mask = mptr(bm); a.unpool_mask_stride = bm.shared ? 0 : bm.chw();
                 }
-                if (op.wino4f) {
+                const bool d3_now = op.d3 && S.h3_on && !S.calibrating && op.d3_vscale > 0.f && a.drop_site < 0 && !a.pool_out &&
+                                    conv3_h3_supported(op.ks, op.cin, op.cout, a.H, a.W, a.unpool_mask != nullptr);
+                if (op.d3 && S.calibrating && S.d_h3_vmax) {
+                    // the layer's largest |input| (the pooled tensor holds the same values as its Upsample)
+                    const int64_t plane_in = a.unpool_mask ? (int64_t)(a.H / 2) * (a.W / 2) : (int64_t)a.H * a.W;
+                    launch_absmax(a.in, (int64_t)(a.in_sample_stride ? N : 1) * op.cin * plane_in, S.d_h3_vmax + S.ops.size() + oi, st);
+                }
+                if (d3_now) {
+                    ConvArgs b = a;
+                    b.wt_h3 = op.d_wd3; b.h3_vscale = op.d3_vscale; b.h3_uscale = op.d3_uscale; b.h3_flag = const_cast<uint32_t *>(S.h3_flag);
+                    b.CoutPad = op.cout;
+                    launch_conv3_h3(b, st);
+                } else if (op.wino4f) {
                     static const bool epi4 = !(std::getenv("SIVO_W4F_EPI") && std::atoi(std::getenv("SIVO_W4F_EPI")) == 0);
                     if (epi4) a.variant |= 4096;      // float4 form of the output stage (conv_wino4f.hip)
                     launch_conv_wino4f(a, st);
@@ -1237,7 +1273,8 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
             SivoOpProfile &p = out[r++];
             std::memset(&p, 0, sizeof p);
             std::snprintf(p.layer, sizeof p.layer, "%s", op.name.c_str());
-            std::snprintf(p.kernel, sizeof p.kernel, "%s", op.mc_fused_last ? "conv_wino_cls_mc_kernel" : op.kernel.c_str());
+            const bool d3_on = op.d3 && h->h3_on && op.d3_vscale > 0.f && op.drop_site < 0 && op.pool_op < 0;
+            std::snprintf(p.kernel, sizeof p.kernel, "%s", op.mc_fused_last ? "conv_wino_cls_mc_kernel" : d3_on ? "conv3_h3_kernel" : op.kernel.c_str());
             p.samples = op.last_n;
             p.flops_per_sample = op.flops;
             p.bytes_per_sample = op.bytes;
@@ -1261,6 +1298,17 @@ extern "C" int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow
         bool any_h3 = false, any_x6 = false;
         int rows = 0;
         for (const Op &op : h->ops) {
+            if (op.d3) {        // direct f16x3 layer: vmax / vscale are those of its input activation
+                any_h3 = any_h3 || op.d3_vscale > 0.f;
+                if (per_layer && rows < capacity) {
+                    SivoH3Layer &r = per_layer[rows];
+                    std::memset(&r, 0, sizeof r);
+                    std::snprintf(r.layer, sizeof r.layer, "%s", op.name.c_str());
+                    r.vmax = op.d3_vmax; r.vscale = op.d3_vscale; r.uscale = op.d3_uscale;
+                }
+                ++rows;
+                continue;
+            }
             if (!op.wino4) continue;
             any_h3 = any_h3 || (op.d_wh3 && op.h3_vscale > 0.f);
             any_x6 = any_x6 || op.d_wx6;
@@ -1349,8 +1397,23 @@ extern "C" int sivo_debug_conv3_h3_dev(int N, int Cin, int Cout, int H, int W, c
         a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.CoutPad = Cout; a.relu = relu; a.drop_site = -1;
         a.unpool_mask = d_mask; a.unpool_mask_stride = d_mask ? (int64_t)Cin * plane_in : 0;
         a.wt_h3 = du; a.h3_vscale = vscale; a.h3_uscale = uscale; a.h3_flag = flag;
+        uint32_t *stamps = nullptr;         // diagnostic build + SIVO_D3_STAMPS=1: cycle sums of the kernel's ABL & 64 form
+        if (std::getenv("SIVO_D3_STAMPS")) {
+            stamps = dev_alloc<uint32_t>(8);
+            SIVO_HIP(hipMemset(stamps, 0, 32));
+            a.vmax = stamps;
+        }
         launch_conv3_h3(a, nullptr);
         SIVO_HIP(hipDeviceSynchronize());
+        auto report = [&](const char *what) {
+            if (!stamps) return;
+            uint32_t h[8];
+            SIVO_HIP(hipMemcpy(h, stamps, 32, hipMemcpyDeviceToHost));
+            if (h[4]) std::fprintf(stderr, "d3 stamps, %s (cycles per wave and stage): wait %.0f barrier %.0f output %.0f multiply %.0f; longest wave %u cycles; %u wave-stages\n",
+                                   what, 16.0 * h[0] / h[4], 16.0 * h[1] / h[4], 16.0 * h[2] / h[4], 16.0 * h[3] / h[4], h[5], h[4]);
+            SIVO_HIP(hipMemset(stamps, 0, 32));
+        };
+        report("first launch");
         if (iters > 0 && ms_out) {
             hipEvent_t e0, e1;
             SIVO_HIP(hipEventCreate(&e0)); SIVO_HIP(hipEventCreate(&e1));
@@ -1362,9 +1425,10 @@ extern "C" int sivo_debug_conv3_h3_dev(int N, int Cin, int Cout, int H, int W, c
             SIVO_HIP(hipEventElapsedTime(&ms, e0, e1));
             *ms_out = ms / iters;
             (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            report("timed launches");
         }
         if (overflowed) *overflowed = (int)*flag;
-        (void)hipFree(du); (void)hipFree(dsc); (void)hipFree(dsh); (void)hipHostFree(flag);
+        (void)hipFree(du); (void)hipFree(dsc); (void)hipFree(dsh); (void)hipHostFree(flag); (void)hipFree(stamps);
         return SIVO_OK;
     });
 }

@@ -80,6 +80,30 @@ def test_direct_f16x3_convolution_against_fp64(N, Cin, Cout, H, W, relu, unpool)
     assert worst <= 2.0 ** -20
 
 
+@pytest.mark.parametrize("unpool", [False, True])
+def test_the_two_stage_loops_agree_bit_for_bit(unpool, monkeypatch):
+    """FORM 1 (default: loads, split and DMA dealt over the MFMA slots, patch two stages ahead) against FORM 0 (phased): the same
+    products in the same order, so every output bit must agree — at a shape with several items per workgroup, partial
+    items and two cout groups."""
+    from sivo_amd import segnet
+    g = torch.Generator(device="cuda").manual_seed(77)
+    N, Cin, Cout, H, W = 6, 64, 128, 180, 520
+    h, w = (H // 2, W // 2) if unpool else (H, W)
+    x = torch.randn((N, Cin, h, w), generator=g, device="cuda", dtype=torch.float32)
+    mask = torch.randint(0, 4, (N, Cin, h, w), generator=g, device="cuda", dtype=torch.uint8) if unpool else None
+    rng = np.random.default_rng(5)
+    wt = (rng.standard_normal((Cout, Cin, 3, 3)) * 0.05).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.uniform(-0.2, 0.2, Cout).astype(np.float32)
+    outs = []
+    for form in ("0", "1"):
+        monkeypatch.setenv("SIVO_D3_FORM", form)
+        out, _, ov = segnet.conv3_h3(x, wt, scale, shift, relu=False, mask=mask)
+        assert not ov
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_large_activations_and_the_overflow_flag():
     from sivo_amd import segnet
     worst, emax, rmax = _case(2, 64, 64, 16, 64, True, False, seed=5, amp=700.0, nonneg=True)
