@@ -142,12 +142,13 @@ def test_full_size_frame_logits_within_tolerance(oracle, kind, kitti_like_bgr):
 
 
 @pytest.mark.parametrize("H,W,width", [(22, 64, 256), (9, 12, 128), (44, 128, 128)])
-def test_bridged_convolutions_are_bit_identical(H, W, width):
+def test_bridged_convolutions_are_bit_identical(H, W, width, monkeypatch):
     """conv -> conv at >= 128 channels: output transform + epilogue (BN, ReLU, dropout) + next input transform in one
     kernel through an LDS image of the channel plane, vs the three-kernel path that writes the activation to HBM.
     Same arithmetic in the same order -> identical logits; ragged tile rows (22, 9) included."""
     T = 3
     text = _conv_stack_prototxt(T, H, W, width)
+    monkeypatch.setenv("SIVO_D3", "0")          # (128-channel layers would otherwise run the direct f16x3 kernel, which has no transforms to bridge)
     net, w, sn = _make(text, T, seed=5)
     img = torch.from_numpy(_image(np.random.default_rng(H + W), H, W)).cuda()
     _, lg_fused, _ = sn.forward(img, 77, sample0=1, want_logits=True)
