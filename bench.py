@@ -120,6 +120,7 @@ def cpu_baseline(kind, T, H, W, text, w, bgr, left, right, budget_note):
 BF16_MFMA_PEAK_TFLOPS = 2500.0
 KERNEL_CLASS = [("conv7_x6", 6.0, BF16_MFMA_PEAK_TFLOPS, "bf16 MFMA (direct 7x7; fp32 operands split into 3 bf16 planes, 6 products, fp32 accumulate)"),
                 ("wino4_gemm_h3", 3.0 / 4.0, BF16_MFMA_PEAK_TFLOPS, "fp16 MFMA (fp32 operands as fp16 hi + lo planes, 3 products, fp32 accumulate)"),
+                ("conv3_h3", 3.0, BF16_MFMA_PEAK_TFLOPS, "fp16 MFMA (direct 3x3; fp32 operands as fp16 hi + lo planes, 3 products per fp32 product, fp32 accumulate)"),
                 ("wino4_gemm_x6", 6.0 / 4.0, BF16_MFMA_PEAK_TFLOPS, "bf16 MFMA (fp32 operands split into 3 bf16 planes, 6 products, fp32 accumulate)"),
                 ("wino4_gemm", 1.0 / 4.0, FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA"),
                 ("conv_wino4f", 1.0 / 4.0, FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA"),
@@ -193,6 +194,12 @@ def mfma_roofline(prof_timed, prof_detail, n_timed_frames, n_detail, ms_per_fram
             "launches_per_frame": dom["launches"] / max(frames, 1), "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
             "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
             "whole_frame_mfma_util": round(t_peak_ms / ms_per_frame, 4),
+            # every matrix-core kernel of the frame (the dominant one above is the largest of these by time)
+            "mfma_kernels": [{"kernel": "sivo::" + k, "ms_per_frame": round(v["ms"] / n_detail, 3), "launches_per_frame": round(v["launches"] / n_detail, 2),
+                              "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "peak": kernel_class(k)[1],
+                              "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / kernel_class(k)[1], 4),
+                              "executed_frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 * kernel_class(k)[0] / kernel_class(k)[1], 4)}
+                             for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"]) if kernel_class(k) and v["flops"] > 0 and v["ms"] > 0],
             "kernels_ms_per_frame": {k: round(v["ms"] / n_detail, 3) for k, v in sorted(by_kernel.items())},
             "segnet_kernel_ms_per_frame": round(sum(v["ms"] for v in by_kernel.values()) / n_detail, 3),
             "note": note}
@@ -450,10 +457,11 @@ def main():
                "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_frame, 3), "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "arithmetic": ("activations, weights, transforms, accumulators and outputs fp32; the batched GEMM of the Winograd F(4x4,3x3) layers multiplies fp32 operands "
-                              "as fp16 hi + lo pairs (power-of-two layer scales, 2^-22 relative) / 3 fp16 MFMA products with fp32 accumulation (error at the level of the "
-                              "fp32 FMA chain it replaces: tests/test_gpu_h3_gemm.py, tests/test_gpu_segnet_fullsize.py; SIVO_GEMM=x6 / f32 select the bf16x6 / fp32 MFMA "
-                              "kernels); MC mean / confidence / entropy in f64"),
+               "arithmetic": ("activations, weights, transforms, accumulators and outputs fp32; the batched GEMM of the Winograd F(4x4,3x3) layers and the direct "
+                              "3x3 kernel of the layers with <= 128 channels (<= 256 in the sample-invariant prefix) multiply fp32 operands as fp16 hi + lo pairs "
+                              "(power-of-two layer scales, 2^-22 relative) / 3 fp16 MFMA products with fp32 accumulation (error at the level of the fp32 FMA chain "
+                              "they replace: tests/test_gpu_h3_gemm.py, tests/test_gpu_conv3_h3.py, tests/test_gpu_segnet_fullsize.py; SIVO_GEMM=x6 / f32 select the "
+                              "bf16x6 / fp32 MFMA kernels, SIVO_D3=0 the fp32 fused Winograd kernels); MC mean / confidence / entropy in f64"),
                "config": {"workload": f"full per-frame path: ORB 2000x8 stereo + SegNet-{args.net} T={T} MC-dropout + entropy maps + semantic key filter + stereo match, {H}x{W}, synthetic stereo pair, seeded random weights",
                           "T": T, "samples_per_rank": [parallel.shard_samples(T, world, r)[1] for r in range(world)],
                           "orb": bool(do_orb), "semantic_keys": stats["kps"], "stereo_matches": stats["matches"],

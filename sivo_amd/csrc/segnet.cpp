@@ -208,7 +208,10 @@ void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int 
     const char *gemm_env = std::getenv("SIVO_GEMM");
     const bool gemm_default = !(gemm_env && (std::string(gemm_env) == "x6" || std::string(gemm_env) == "f32"));      // (read per handle: tests build several)
     const bool no_d3 = std::getenv("SIVO_D3") && std::atoi(std::getenv("SIVO_D3")) == 0;
-    const int d3_maxc = std::getenv("SIVO_D3_MAXC") ? std::atoi(std::getenv("SIVO_D3_MAXC")) : 128;
+    // (the sample-invariant prefix runs once per frame with N = 1: there the alternative is the fused F(2x2) kernel on the fp32
+    // pipe, not the F(4x4) GEMM, and the direct kernel wins up to 256 channels — SIVO_D3_MAXC_SHARED)
+    const int d3_maxc = keep_ties ? (std::getenv("SIVO_D3_MAXC_SHARED") ? std::atoi(std::getenv("SIVO_D3_MAXC_SHARED")) : 256)
+                                  : (std::getenv("SIVO_D3_MAXC") ? std::atoi(std::getenv("SIVO_D3_MAXC")) : 128);
     const bool d3_prefix = !(std::getenv("SIVO_D3_PREFIX") && std::atoi(std::getenv("SIVO_D3_PREFIX")) == 0);
     op.d3 = !no_d3 && !no_wino && gemm_default && (d3_prefix || !keep_ties) && cin <= d3_maxc && cout <= d3_maxc && conv3_h3_supported(ks, cin, cout, H, Wd, false);
     if (op.d3) {
