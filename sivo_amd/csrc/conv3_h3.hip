@@ -260,6 +260,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     };
 
     // ---- output stage: register r of block (b, sg) is out[cout 64 g + 32 b + 8 (r >> 2) + 4 lh + (r & 3)][row y0 + 2 rp + sg][col x0 + 32 ch + ln]
+    // (Tried in round 3, slower, removed: a 4 x 4 transpose of the four cout registers of a pixel across the lanes of a quad —
+    // select + DPP quad_perm + two selects per register pair, twice — so that a lane holds four consecutive pixels of one cout
+    // and the item takes 16 buffer_store_dwordx4 instead of 64 dword stores: output stage 2.2k instead of 1.4k cycles per
+    // stage on conv1_2_D, tools/d3_stamps.py.  The dword stores already write whole 128-byte runs; what the stage waits for
+    // is the write path's bytes, not its instruction count.)
     auto store_item = [&](int n, int ty, int tx, int g, int par) __attribute__((always_inline)) {
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.out + (int64_t)n * a.Cout * plane, 0, (int)((int64_t)a.Cout * plane * 4), 0x00020000);
         const float *epl = reinterpret_cast<const float *>(lds_d + D_EP0) + par * 128;

@@ -1254,9 +1254,12 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
                 const char *kn[3] = {"wino4_input_kernel", h3 ? "wino4_gemm_h3_kernel" : op.d_wx6 ? "wino4_gemm_x6p_kernel" : "wino4_gemm_kernel", op.w4_bridge ? "wino4_bridge_kernel" : "wino4_output_kernel"};
                 const Blob &bi = h->blobs[op.in];
                 const double tiles = (double)((bi.H + 3) / 4) * (bi.W / 4), kp = wino4_cout_pad(op.cout);
+                // input transform: activation in, V out; GEMM: V in, M out; output transform: M in, activation out — a bridge
+                // (output transform + the next layer's input transform) reads M and writes the next V (36 positions x cout
+                // channels) instead of the activation
                 const double bytes[3] = {4.0 * (op.cin * (double)bi.H * bi.W + 36.0 * op.cin * tiles),
                                          4.0 * 36.0 * tiles * (op.cin + kp),
-                                         4.0 * (36.0 * kp * tiles + op.cout * (double)bi.H * bi.W)};
+                                         op.w4_bridge ? 4.0 * 36.0 * tiles * (kp + op.cout) : 4.0 * (36.0 * kp * tiles + op.cout * (double)bi.H * bi.W)};
                 const int groups = op.launches ? op.w4_launches / op.launches : 1;
                 for (int k = op.w4_bridged_in ? 1 : 0; k < 3; ++k) {
                     SivoOpProfile &p = out[r++];
