@@ -359,7 +359,7 @@ struct BaDev {
     // per edge
     double *err, *Jp, *Jx, *wo, *rchi, *W, *Y;
     // per point / pose
-    double *Hll, *bl, *Hinv, *xl, *sc_pt;
+    double *Hll, *bl, *xl, *sc_pt;
     double *Hpp, *bp;
     // reduced system
     double *S, *xs;
@@ -367,9 +367,60 @@ struct BaDev {
 };
 
 // errors (+ Jacobians, W) of the active edges at (poses, points)
+// JAC = false (a trial estimate) with `partial`: the sums the host reads after a trial are formed here instead of by a launch
+// of their own — every block leaves the sum of its edges' robustified chi2 in partial[block]; the block that finishes last
+// (atomic counter) adds the partials in block order (scal[0]) and, with_points, the per-point shares of computeScale
+// (sc_pt, written by the update kernel before this launch: scal[4]).  Fixed order of additions, whichever block is last.
 template <bool JAC>
-__global__ __launch_bounds__(BA_T) void ba_edge_kernel(BaDev d, const double *poses, const double *points) {
+__global__ __launch_bounds__(BA_T) void ba_edge_kernel(BaDev d, const double *poses, const double *points, double *partial = nullptr,
+                                                      unsigned *counter = nullptr, int with_points = 0) {
     const int64_t e = (int64_t)blockIdx.x * BA_T + threadIdx.x;
+    if (!JAC && partial) {
+        __shared__ double s_red[BA_T / 64], s_out[1];
+        __shared__ int s_last;
+        double v[1] = {0.0};
+        if (e < d.nE) {
+            if (d.level[e]) {
+                d.rchi[e] = 0.0;
+            } else {
+                const SivoEdge ed = d.edges[e];
+                double er[3], jp[18], jx[9];
+                bool dok;
+                edge_eval<false>(poses + 12 * (int64_t)ed.pose, points + 3 * (int64_t)ed.point, ed, d.K, er, jp, jx, dok);
+                d.err[3 * e] = er[0]; d.err[3 * e + 1] = er[1]; d.err[3 * e + 2] = er[2];
+                const double c2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * ed.inv_sigma2;
+                double r = c2, w = 1.0;
+                if (d.robust[e]) huber(c2, ed.stereo ? d.delta_stereo : d.delta_mono, r, w);
+                d.rchi[e] = r;
+                v[0] = r;
+            }
+        }
+        block_sum<1, BA_T>(v, s_red, s_out);
+        if (threadIdx.x == 0) {
+            partial[blockIdx.x] = s_out[0];
+            __threadfence();
+            s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();
+        double p[1] = {0.0};
+        for (unsigned i = threadIdx.x; i < gridDim.x; i += BA_T) p[0] += __builtin_nontemporal_load(partial + i);
+        block_sum<1, BA_T>(p, s_red, s_out);
+        if (threadIdx.x == 0) { d.scal[0] = s_out[0]; *counter = 0u; }
+        if (with_points) {
+            double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+            int i = threadIdx.x;
+            for (; i + 3 * BA_T < d.nX; i += 4 * BA_T) { q0 += d.sc_pt[i]; q1 += d.sc_pt[i + BA_T]; q2 += d.sc_pt[i + 2 * BA_T]; q3 += d.sc_pt[i + 3 * BA_T]; }
+            for (; i < d.nX; i += BA_T) q0 += d.sc_pt[i];
+            double q[1] = {(q0 + q1) + (q2 + q3)};
+            block_sum<1, BA_T>(q, s_red, s_out);
+            if (threadIdx.x == 0) d.scal[4] = s_out[0];
+        }
+        // (Tried in round 3 and removed: the seven scalars written straight into pinned host memory and a stream wait instead
+        // of the hipMemcpy below — no faster per trial, and the pinned allocation costs a BA call 0.2 ms.)
+        return;
+    }
     if (e >= d.nE) return;
     if (d.level[e]) { d.rchi[e] = 0.0; return; }
     const SivoEdge ed = d.edges[e];
@@ -398,21 +449,39 @@ __global__ __launch_bounds__(BA_T) void ba_edge_kernel(BaDev d, const double *po
     }
 }
 
-// out[0] = sum(in[0..n)) in a fixed order; one workgroup
-__global__ __launch_bounds__(1024) void ba_sum_kernel(const double *in, int64_t n, double *out) {
+// out[0] = sum(in[0..n)) in a fixed order; one workgroup per sum (blockIdx.x = 1: the second sum, when given).  Four independent
+// partial sums per thread: the loop is a chain of dependent additions behind L2 loads otherwise (9.4 us for 36 k values).
+__global__ __launch_bounds__(1024) void ba_sum_kernel(const double *in, int64_t n, double *out, const double *in2 = nullptr, int64_t n2 = 0,
+                                                      double *out2 = nullptr) {
     __shared__ double s_red[16], s_out[1];
-    double v[1] = {0.0};
-    for (int64_t i = threadIdx.x; i < n; i += 1024) v[0] += in[i];
+    if (blockIdx.x == 1) { in = in2; n = n2; out = out2; }
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+    int64_t i = threadIdx.x;
+    for (; i + 3072 < n; i += 4096) { p0 += in[i]; p1 += in[i + 1024]; p2 += in[i + 2048]; p3 += in[i + 3072]; }
+    for (; i < n; i += 1024) p0 += in[i];
+    double v[1] = {(p0 + p1) + (p2 + p3)};
     block_sum<1, 1024>(v, s_red, s_out);
     if (threadIdx.x == 0) out[0] = s_out[0];
 }
 
 // Hll, bl of every point from its active edges (CSR order)
-__global__ __launch_bounds__(BA_T) void ba_point_kernel(BaDev d) {
-    const int q = blockIdx.x * BA_T + threadIdx.x;
-    if (q >= d.nX) return;
+// (BA_PL = 4 lanes per point, each walking every fourth edge of the point's list, partial sums combined by a butterfly over
+// the four lanes: the list is a chain of dependent loads — index, edge, Jacobian — and a point has ~12 edges)
+constexpr int BA_PL = 4;
+template <int K>
+__device__ __forceinline__ void ba_lanes_sum(double (&v)[K]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        v[k] += __shfl_xor(v[k], 1, 64);
+        v[k] += __shfl_xor(v[k], 2, 64);
+    }
+}
+__device__ __forceinline__ void ba_point_body(const BaDev &d, int block) {
+    const int t = block * BA_T + threadIdx.x, sub = t & (BA_PL - 1);
+    const int q = t / BA_PL < d.nX ? t / BA_PL : d.nX - 1;          // (surplus lanes repeat the last point and do not store: every lane takes part in the butterfly)
+    const bool mine = t / BA_PL < d.nX && sub == 0;
     double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-    for (int64_t i = d.pt_off[q]; i < d.pt_off[q + 1]; ++i) {
+    for (int64_t i = d.pt_off[q] + sub; i < d.pt_off[q + 1]; i += BA_PL) {
         const int e = d.pt_edges[i];
         if (d.level[e]) continue;
         const double wo = d.wo[e];
@@ -425,15 +494,17 @@ __global__ __launch_bounds__(BA_T) void ba_point_kernel(BaDev d) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) b[a] -= wo * (jx[a] * er[0] + jx[3 + a] * er[1] + jx[6 + a] * er[2]);
     }
+    ba_lanes_sum<6>(H);
+    ba_lanes_sum<3>(b);
+    if (!mine) return;
     double *Hq = d.Hll + 9 * (int64_t)q;
     Hq[0] = H[0]; Hq[1] = H[1]; Hq[2] = H[2]; Hq[3] = H[1]; Hq[4] = H[3]; Hq[5] = H[4]; Hq[6] = H[2]; Hq[7] = H[4]; Hq[8] = H[5];
     d.bl[3 * q] = b[0]; d.bl[3 * q + 1] = b[1]; d.bl[3 * q + 2] = b[2];
 }
 
 // Hpp, bp of one free pose per workgroup
-__global__ __launch_bounds__(BA_T) void ba_pose_kernel(BaDev d) {
+__device__ __forceinline__ void ba_pose_body(const BaDev &d, int s) {
     __shared__ double s_red[(BA_T / 64) * 27], s_out[27];
-    const int s = blockIdx.x;
     double acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0.0;
@@ -459,6 +530,23 @@ __global__ __launch_bounds__(BA_T) void ba_pose_kernel(BaDev d) {
     }
 }
 
+// One launch behind the edge kernel for the three independent reductions of a linearisation: blocks [0, point_blocks) the
+// points' Hll / bl, the next nF blocks the free poses' Hpp / bp, the last block chi2 of the linearisation point (scal[6]).
+// (Three launches before: 9 + 21 + 25 us back to back on a 36 k-edge problem, each mostly latency.)
+__global__ __launch_bounds__(BA_T) void ba_build_kernel(BaDev d, int point_blocks) {
+    const int b = blockIdx.x;
+    if (b < point_blocks) { ba_point_body(d, b); return; }
+    if (b < point_blocks + d.nF) { ba_pose_body(d, b - point_blocks); return; }
+    __shared__ double s_red[BA_T / 64], s_out[1];
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+    int64_t i = threadIdx.x;
+    for (; i + 3 * BA_T < d.nE; i += 4 * BA_T) { p0 += d.rchi[i]; p1 += d.rchi[i + BA_T]; p2 += d.rchi[i + 2 * BA_T]; p3 += d.rchi[i + 3 * BA_T]; }
+    for (; i < d.nE; i += BA_T) p0 += d.rchi[i];
+    double v[1] = {(p0 + p1) + (p2 + p3)};
+    block_sum<1, BA_T>(v, s_red, s_out);
+    if (threadIdx.x == 0) d.scal[6] = s_out[0];
+}
+
 // scal[2] = max |diag| over Hpp and Hll (computeLambdaInit)
 __global__ __launch_bounds__(1024) void ba_maxdiag_kernel(BaDev d, int with_points) {
     __shared__ double s_m[1024];
@@ -475,34 +563,29 @@ __global__ __launch_bounds__(1024) void ba_maxdiag_kernel(BaDev d, int with_poin
     if (threadIdx.x == 0) d.scal[2] = s_m[0];
 }
 
-// (Hll + lambda I)^-1 per point
-__global__ __launch_bounds__(BA_T) void ba_point_inverse_kernel(BaDev d, double lambda) {
-    const int q = blockIdx.x * BA_T + threadIdx.x;
-    if (q >= d.nX) return;
+// (Hll_q + lambda I)^-1 — formed where it is used (every edge of the point, and the point's update) instead of by a launch of
+// its own: 9 loads and ~40 flops
+__device__ __forceinline__ void ba_point_inverse(const BaDev &d, int q, double lambda, double (&Ai)[9]) {
     double A[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) A[i] = d.Hll[9 * (int64_t)q + i];
     A[0] += lambda; A[4] += lambda; A[8] += lambda;
     const double c0 = A[4] * A[8] - A[5] * A[7], c1 = A[5] * A[6] - A[3] * A[8], c2 = A[3] * A[7] - A[4] * A[6];
     const double det = A[0] * c0 + A[1] * c1 + A[2] * c2, id = 1.0 / det;
-    double Ai[9];
     Ai[0] = c0 * id; Ai[1] = (A[2] * A[7] - A[1] * A[8]) * id; Ai[2] = (A[1] * A[5] - A[2] * A[4]) * id;
     Ai[3] = c1 * id; Ai[4] = (A[0] * A[8] - A[2] * A[6]) * id; Ai[5] = (A[2] * A[3] - A[0] * A[5]) * id;
     Ai[6] = c2 * id; Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id; Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) d.Hinv[9 * (int64_t)q + i] = Ai[i];
 }
 
 // Y_e = W_e Hll^-1 for every active edge that touches a free keyframe (one thread per edge)
-__global__ __launch_bounds__(BA_T) void ba_edge_y_kernel(BaDev d) {
+__global__ __launch_bounds__(BA_T) void ba_edge_y_kernel(BaDev d, double lambda) {
     const int64_t e = (int64_t)blockIdx.x * BA_T + threadIdx.x;
     if (e >= d.nE || d.level[e]) return;
     const SivoEdge ed = d.edges[e];
     if (d.slot[ed.pose] < 0) return;
-    const double *W = d.W + 18 * e, *Ai = d.Hinv + 9 * (int64_t)ed.point;
+    const double *W = d.W + 18 * e;
     double A9[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) A9[i] = Ai[i];
+    ba_point_inverse(d, ed.point, lambda, A9);
     double *Y = d.Y + 18 * e;
 #pragma unroll
     for (int a = 0; a < 6; ++a)
@@ -511,8 +594,11 @@ __global__ __launch_bounds__(BA_T) void ba_edge_y_kernel(BaDev d) {
 }
 
 // S block (i, j), i <= j:  [i == j] (Hpp_i + lambda I)  -  sum_q Y_{e(i,q)} W_{e(j,q)}' ; rhs_i = bp_i - sum_q Y_{e(i,q)} bl_q
-__global__ __launch_bounds__(BA_T) void ba_schur_kernel(BaDev d, double lambda) {
-    __shared__ double s_red[(BA_T / 64) * 42], s_out[42];
+// (1024 threads per block — 3 points per thread instead of 12 — was measured in round 3: the whole call went from 3.4 to 3.9 ms;
+// the 42-value block reduction over 16 waves costs more than the shorter chains of dependent loads save)
+constexpr int BA_SCHUR_T = 256;
+__global__ __launch_bounds__(BA_SCHUR_T) void ba_schur_kernel(BaDev d, double lambda) {
+    __shared__ double s_red[(BA_SCHUR_T / 64) * 42], s_out[42];
     // block index -> (i, j) of the upper triangle
     int i = 0, rem = blockIdx.x;
     while (rem >= d.nF - i) { rem -= d.nF - i; ++i; }
@@ -521,7 +607,7 @@ __global__ __launch_bounds__(BA_T) void ba_schur_kernel(BaDev d, double lambda) 
     double acc[42];
 #pragma unroll
     for (int k = 0; k < 42; ++k) acc[k] = 0.0;
-    for (int q = threadIdx.x; q < d.nX; q += BA_T) {
+    for (int q = threadIdx.x; q < d.nX; q += BA_SCHUR_T) {
         const int e1 = ti[q];
         if (e1 < 0 || d.level[e1]) continue;
         const double *Y = d.Y + 18 * (int64_t)e1;
@@ -538,7 +624,7 @@ __global__ __launch_bounds__(BA_T) void ba_schur_kernel(BaDev d, double lambda) 
 #pragma unroll
             for (int b = 0; b < 6; ++b) acc[6 * a + b] += Y[3 * a] * W[3 * b] + Y[3 * a + 1] * W[3 * b + 1] + Y[3 * a + 2] * W[3 * b + 2];
     }
-    block_sum<42, BA_T>(acc, s_red, s_out);
+    block_sum<42, BA_SCHUR_T>(acc, s_red, s_out);
     const int n6 = 6 * d.nF;
     if (threadIdx.x < 36) {
         const int a = threadIdx.x / 6, b = threadIdx.x % 6;
@@ -658,15 +744,147 @@ __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_kernel(BaDev d) {
     if (tid == 0) d.scal[3] = s_ok ? 1.0 : 0.0;
 }
 
+// The reduced system of a local BA (n = 6 nF <= 126) solved entirely in LDS — round 3's second form (the first, above with
+// LDS_COPY, took 151 of an LM iteration's 367 us: rocprofv3, profiles/r03_a_kernel_stats_ba.csv).  What that one spent its time
+// on was hand-overs: thread 0 factorised the 6 x 6 diagonal block through ~100 dependent LDS round trips while 255 threads
+// waited, 3 barriers per keyframe, then 2 x nF more steps of 2 barriers for the triangular solves.  Here
+//   * EVERY thread factorises the diagonal block in registers (21 broadcast reads, ~100 FMAs, 6 sqrt, 6 divisions) and inverts
+//     the factor: no hand-over and no barrier in front of the panel, whose rows become one 6-term product each (no divisions);
+//   * the right-hand side is row n of the matrix: its "panel" and "trailing update" ARE the forward substitution;
+//   * the backward substitution takes one barrier per keyframe (every thread forms x_j = L_jj^-T y_j itself from the stored
+//     inverse).
+// 3 barriers per keyframe in all instead of 7.  LDS: (n + 1)^2 + 21 nF doubles <= 133 KB.
+__global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_lds_kernel(BaDev d) {
+    extern __shared__ double s_mat[];          // rows 0 .. n - 1: the matrix (lower triangle); row n: the right-hand side
+    __shared__ double s_li[21 * 21];           // inverse of each diagonal block's Cholesky factor, packed lower triangle
+    const int nb = d.nF, n = 6 * nb, tid = threadIdx.x;
+    // row stride n + 1 doubles (odd): the trailing update reads element (k, j0 + c) of 16 consecutive rows k at once, and with a
+    // stride of n = 6 nF doubles those fall on 4 bank pairs (48 k mod 64), a 4-way conflict on the kernel's dominant access
+    const int ld = n + 1;
+    for (int i = tid >> 4; i < n; i += BA_SOLVE_T / 16)
+        for (int k = tid & 15; k <= i; k += 16) s_mat[i * ld + k] = d.S[(int64_t)i * n + k];
+    for (int i = tid; i < n; i += BA_SOLVE_T) s_mat[n * ld + i] = d.xs[i];
+    __syncthreads();
+    bool ok = true;
+    for (int jb = 0; jb < nb && ok; ++jb) {
+        const int j0 = 6 * jb;
+        double l[6][6], li[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int k = 0; k <= i; ++k) l[i][k] = s_mat[(j0 + i) * ld + j0 + k];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double dj = l[j][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) dj -= l[j][k] * l[j][k];
+            if (!(dj > 0.0)) ok = false;                 // (the same value in every thread: uniform)
+            const double sd = sqrt(dj), inv = 1.0 / sd;
+            l[j][j] = sd;
+            li[j][j] = inv;
+#pragma unroll
+            for (int i = j + 1; i < 6; ++i) {
+                double v = l[i][j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) v -= l[i][k] * l[j][k];
+                l[i][j] = v * inv;
+            }
+        }
+        if (!ok) break;
+        // inverse of the lower-triangular factor: Li L = I
+#pragma unroll
+        for (int i = 1; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < i; ++j) {
+                double sum = 0;
+#pragma unroll
+                for (int k = j; k < i; ++k) sum += l[i][k] * li[k][j];
+                li[i][j] = -sum * li[i][i];
+            }
+        if (tid == 0) {
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) s_li[21 * jb + k++] = li[i][j];
+        }
+        // panel: L_ij = S_ij L_jj^-T for the rows below the block, and for the right-hand side (row n): y_j = L_jj^-1 b_j
+        for (int i = j0 + 6 + tid; i <= n; i += BA_SOLVE_T) {
+            double *row = s_mat + i * ld + j0;
+            double sv[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) sv[c] = row[c];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double r = 0;
+#pragma unroll
+                for (int k = 0; k <= c; ++k) r += sv[k] * li[c][k];
+                row[c] = r;
+            }
+        }
+        __syncthreads();
+        // trailing update, rows j0 + 6 .. n (the right-hand side included), columns j0 + 6 .. min(row, n - 1)
+        for (int i = j0 + 6 + (tid >> 4); i <= n; i += BA_SOLVE_T / 16) {
+            double ri[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) ri[c] = s_mat[i * ld + j0 + c];
+            const int kend = i < n ? i : n - 1;
+            for (int k = j0 + 6 + (tid & 15); k <= kend; k += 16) {
+                double v = 0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v += ri[c] * s_mat[k * ld + j0 + c];
+                s_mat[i * ld + k] -= v;
+            }
+        }
+        __syncthreads();
+    }
+    if (ok) {
+        double *y = s_mat + n * ld;
+        for (int jb = nb - 1; jb >= 0; --jb) {         // L' x = y, one keyframe per step
+            const int j0 = 6 * jb;
+            double yj[6], x6[6], li[6][6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) yj[c] = y[j0 + c];
+            {
+                int k = 0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) li[i][j] = s_li[21 * jb + k++];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double v = 0;
+#pragma unroll
+                for (int k = c; k < 6; ++k) v += li[k][c] * yj[k];
+                x6[c] = v;
+            }
+            for (int i = tid; i < j0; i += BA_SOLVE_T) {
+                double v = y[i];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v -= s_mat[(j0 + c) * ld + i] * x6[c];
+                y[i] = v;
+            }
+            if (tid == 0) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) d.xs[j0 + c] = x6[c];
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) d.scal[3] = ok ? 1.0 : 0.0;
+}
+
 // dx_l = Hll^-1 (bl - sum_e W_e' dx_p), points_trial = points + dx_l, per-point share of computeScale
-__global__ __launch_bounds__(BA_T) void ba_point_update_kernel(BaDev d, double lambda, const double *points, double *points_trial) {
-    const int q = blockIdx.x * BA_T + threadIdx.x;
-    if (q >= d.nX) return;
+__device__ __forceinline__ void ba_point_update_body(const BaDev &d, int block, double lambda, const double *points, double *points_trial) {
+    const int t = block * BA_T + threadIdx.x, sub = t & (BA_PL - 1);
+    const int q = t / BA_PL < d.nX ? t / BA_PL : d.nX - 1;
+    const bool mine = t / BA_PL < d.nX && sub == 0;
     const bool ok = d.scal[3] != 0.0;
     const double *bl = d.bl + 3 * (int64_t)q;
-    double v[3] = {bl[0], bl[1], bl[2]}, x[3] = {0, 0, 0};
+    double v[3] = {0, 0, 0}, x[3] = {0, 0, 0};
     if (ok) {
-        for (int64_t i = d.pt_off[q]; i < d.pt_off[q + 1]; ++i) {
+        for (int64_t i = d.pt_off[q] + sub; i < d.pt_off[q + 1]; i += BA_PL) {
             const int e = d.pt_edges[i];
             if (d.level[e]) continue;
             const int s = d.slot[d.edges[e].pose];
@@ -677,7 +895,14 @@ __global__ __launch_bounds__(BA_T) void ba_point_update_kernel(BaDev d, double l
 #pragma unroll
                 for (int a = 0; a < 6; ++a) v[b] -= W[3 * a + b] * xp[a];
         }
-        const double *Ai = d.Hinv + 9 * (int64_t)q;
+    }
+    ba_lanes_sum<3>(v);
+    if (!mine) return;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) v[b] += bl[b];
+    if (ok) {
+        double Ai[9];
+        ba_point_inverse(d, q, lambda, Ai);
 #pragma unroll
         for (int a = 0; a < 3; ++a) x[a] = Ai[3 * a] * v[0] + Ai[3 * a + 1] * v[1] + Ai[3 * a + 2] * v[2];
     }
@@ -691,7 +916,7 @@ __global__ __launch_bounds__(BA_T) void ba_point_update_kernel(BaDev d, double l
 }
 
 // poses_trial = exp(dx) * poses for the free poses (copy for the fixed ones); scal[1] = pose share of computeScale
-__global__ __launch_bounds__(BA_T) void ba_pose_update_kernel(BaDev d, double lambda, const double *poses, double *poses_trial) {
+__device__ __forceinline__ void ba_pose_update_body(const BaDev &d, double lambda, const double *poses, double *poses_trial) {
     __shared__ double s_red[BA_T / 64], s_out[1];
     const bool ok = d.scal[3] != 0.0;
     double sc[1] = {0.0};
@@ -709,6 +934,13 @@ __global__ __launch_bounds__(BA_T) void ba_pose_update_kernel(BaDev d, double la
     }
     block_sum<1, BA_T>(sc, s_red, s_out);
     if (threadIdx.x == 0) d.scal[1] = s_out[0];
+}
+
+// the trial estimates in one launch: block 0 the poses, the others the points
+__global__ __launch_bounds__(BA_T) void ba_update_kernel(BaDev d, double lambda, const double *poses, double *poses_trial, const double *points,
+                                                        double *points_trial) {
+    if (blockIdx.x == 0) ba_pose_update_body(d, lambda, poses, poses_trial);
+    else ba_point_update_body(d, (int)blockIdx.x - 1, lambda, points, points_trial);
 }
 
 // pose-only variant of the reduced system (no landmarks in the state): S = blockdiag(Hpp + lambda I), xs = bp
@@ -779,8 +1011,8 @@ static bool dense_solve_lds_ok() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     std::lock_guard<std::mutex> lock(mu);
     if (state[dev] == 0)
-        state[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(ba_dense_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         126 * 126 * 8) == hipSuccess ? 1 : -1;
+        state[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(ba_dense_solve_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         127 * 127 * 8) == hipSuccess ? 1 : -1;
     return state[dev] == 1;
 }
 
@@ -833,11 +1065,12 @@ class BaSolver {
         for (int k = 0; k < 2; ++k) { poses_[k].upload(poses, (size_t)nP * 96); points_[k].upload(points, (size_t)nX * 24); }
         err_.zero((size_t)nE * 24); Jp_.alloc((size_t)nE * 144); Jx_.alloc((size_t)nE * 72); wo_.alloc((size_t)nE * 8);
         rchi_.zero((size_t)nE * 8); W_.alloc((size_t)nE * 144); Y_.alloc((size_t)nE * 144);
-        Hll_.alloc((size_t)nX * 72); bl_.alloc((size_t)nX * 24); Hinv_.alloc((size_t)nX * 72); xl_.alloc((size_t)nX * 24);
+        Hll_.alloc((size_t)nX * 72); bl_.alloc((size_t)nX * 24); xl_.alloc((size_t)nX * 24);
         sc_pt_.zero((size_t)nX * 8);
         Hpp_.zero((size_t)nF_ * 288); bp_.zero((size_t)nF_ * 48);
         S_.alloc((size_t)36 * nF_ * nF_ * 8); xs_.zero((size_t)nF_ * 48);
         scal_.zero(8 * 8);
+        partial_.zero((size_t)cdiv64(std::max<int64_t>(nE, 1), BA_T) * 8); counter_.zero(8);
         hpp_last_.assign((size_t)std::max(nF_, 1) * 36, 0.0);
         d_.edges = edges_.as<SivoEdge>(); d_.nE = nE; d_.slot = slot_.as<int32_t>();
         d_.level = level_.as<uint8_t>(); d_.robust = robust_.as<uint8_t>();
@@ -847,7 +1080,7 @@ class BaSolver {
         d_.ps_off = ps_off_.as<int64_t>(); d_.ps_edges = ps_edges_.as<int32_t>(); d_.table = table_.as<int32_t>();
         d_.err = err_.as<double>(); d_.Jp = Jp_.as<double>(); d_.Jx = Jx_.as<double>(); d_.wo = wo_.as<double>();
         d_.rchi = rchi_.as<double>(); d_.W = W_.as<double>(); d_.Y = Y_.as<double>();
-        d_.Hll = Hll_.as<double>(); d_.bl = bl_.as<double>(); d_.Hinv = Hinv_.as<double>(); d_.xl = xl_.as<double>();
+        d_.Hll = Hll_.as<double>(); d_.bl = bl_.as<double>(); d_.xl = xl_.as<double>();
         d_.sc_pt = sc_pt_.as<double>(); d_.Hpp = Hpp_.as<double>(); d_.bp = bp_.as<double>();
         d_.S = S_.as<double>(); d_.xs = xs_.as<double>(); d_.scal = scal_.as<double>();
         slot_host_ = slot;
@@ -861,7 +1094,7 @@ class BaSolver {
 
     // g2o::SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg
     int optimize(int iterations, const volatile uint8_t *stop, int *trials) {
-        const unsigned gE = (unsigned)cdiv64(std::max<int64_t>(nE_, 1), BA_T), gX = (unsigned)cdiv(std::max(nX_, 1), BA_T);
+        const unsigned gE = (unsigned)cdiv64(std::max<int64_t>(nE_, 1), BA_T), gX4 = (unsigned)cdiv(std::max(nX_, 1) * BA_PL, BA_T);
         const bool landmarks = !points_fixed_ && nX_ > 0;
         double lambda = 0, ni = 2;
         int it = 0;
@@ -870,9 +1103,8 @@ class BaSolver {
             if (stop && *stop) break;
             const double *P = poses_[cur_].as<double>(), *X = points_[cur_].as<double>();
             if (nE_) hipLaunchKernelGGL(ba_edge_kernel<true>, dim3(gE), dim3(BA_T), 0, 0, d_, P, X);
-            hipLaunchKernelGGL(ba_sum_kernel, dim3(1), dim3(1024), 0, 0, d_.rchi, nE_, d_.scal + 6);      // chi2 at the current estimate: scal[6]
-            if (landmarks) hipLaunchKernelGGL(ba_point_kernel, dim3(gX), dim3(BA_T), 0, 0, d_);
-            if (nF_) hipLaunchKernelGGL(ba_pose_kernel, dim3(nF_), dim3(BA_T), 0, 0, d_);
+            // Hll / bl of the points, Hpp / bp of the free poses, chi2 at the current estimate (scal[6])
+            hipLaunchKernelGGL(ba_build_kernel, dim3((landmarks ? gX4 : 0u) + (unsigned)nF_ + 1u), dim3(BA_T), 0, 0, d_, landmarks ? (int)gX4 : 0);
             linearized = true;
             // The host needs lambda before the first trial only in the first iteration (computeLambdaInit: 1e-5 max |diag H|);
             // afterwards the chi2 of the linearisation point is read together with the trial's result: ONE host read per trial
@@ -892,28 +1124,25 @@ class BaSolver {
                 double *Pt = poses_[cur_ ^ 1].as<double>(), *Xt = points_[cur_ ^ 1].as<double>();
                 if (nF_) {
                     if (landmarks) {
-                        hipLaunchKernelGGL(ba_point_inverse_kernel, dim3(gX), dim3(BA_T), 0, 0, d_, lambda);
-                        if (nE_) hipLaunchKernelGGL(ba_edge_y_kernel, dim3(gE), dim3(BA_T), 0, 0, d_);
-                        hipLaunchKernelGGL(ba_schur_kernel, dim3((unsigned)(nF_ * (nF_ + 1) / 2)), dim3(BA_T), 0, 0, d_, lambda);
+                        if (nE_) hipLaunchKernelGGL(ba_edge_y_kernel, dim3(gE), dim3(BA_T), 0, 0, d_, lambda);
+                        hipLaunchKernelGGL(ba_schur_kernel, dim3((unsigned)(nF_ * (nF_ + 1) / 2)), dim3(BA_SCHUR_T), 0, 0, d_, lambda);
                     } else {
                         hipLaunchKernelGGL(ba_pose_only_system_kernel, dim3(64), dim3(256), 0, 0, d_, lambda);
                     }
                     if (6 * nF_ <= 126 && dense_solve_lds_ok()) {
-                        hipLaunchKernelGGL(ba_dense_solve_kernel<true>, dim3(1), dim3(BA_SOLVE_T), (size_t)36 * nF_ * nF_ * 8, 0, d_);
+                        hipLaunchKernelGGL(ba_dense_solve_lds_kernel, dim3(1), dim3(BA_SOLVE_T), (size_t)(6 * nF_ + 1) * (6 * nF_ + 1) * 8, 0, d_);
                     } else {
                         hipLaunchKernelGGL(ba_dense_solve_kernel<false>, dim3(1), dim3(BA_SOLVE_T), 0, 0, d_);
                     }
                 } else {
-                    if (landmarks) hipLaunchKernelGGL(ba_point_inverse_kernel, dim3(gX), dim3(BA_T), 0, 0, d_, lambda);
                     const double one = 1.0;
                     SIVO_HIP(hipMemcpy(d_.scal + 3, &one, 8, hipMemcpyHostToDevice));
                 }
-                hipLaunchKernelGGL(ba_pose_update_kernel, dim3(1), dim3(BA_T), 0, 0, d_, lambda, P, Pt);
-                if (landmarks) hipLaunchKernelGGL(ba_point_update_kernel, dim3(gX), dim3(BA_T), 0, 0, d_, lambda, X, Xt);
-                else if (nX_) SIVO_HIP(hipMemcpyAsync(Xt, X, (size_t)nX_ * 24, hipMemcpyDeviceToDevice, 0));
-                if (nE_) hipLaunchKernelGGL(ba_edge_kernel<false>, dim3(gE), dim3(BA_T), 0, 0, d_, (const double *)Pt, (const double *)Xt);
-                hipLaunchKernelGGL(ba_sum_kernel, dim3(1), dim3(1024), 0, 0, d_.rchi, nE_, d_.scal);
-                if (landmarks) hipLaunchKernelGGL(ba_sum_kernel, dim3(1), dim3(1024), 0, 0, d_.sc_pt, (int64_t)nX_, d_.scal + 4);
+                hipLaunchKernelGGL(ba_update_kernel, dim3(1u + (landmarks ? gX4 : 0u)), dim3(BA_T), 0, 0, d_, lambda, P, Pt, X, Xt);
+                if (!landmarks && nX_) SIVO_HIP(hipMemcpyAsync(Xt, X, (size_t)nX_ * 24, hipMemcpyDeviceToDevice, 0));
+                if (nE_) hipLaunchKernelGGL(ba_edge_kernel<false>, dim3(gE), dim3(BA_T), 0, 0, d_, (const double *)Pt, (const double *)Xt, partial_.as<double>(),
+                                            counter_.as<unsigned>(), landmarks ? 1 : 0);        // + the sums the host reads: scal[0], scal[4]
+                else hipLaunchKernelGGL(ba_sum_kernel, dim3(landmarks ? 2 : 1), dim3(1024), 0, 0, d_.rchi, nE_, d_.scal, (const double *)d_.sc_pt, (int64_t)nX_, d_.scal + 4);
                 SIVO_HIP(hipGetLastError());
                 double r[7];
                 SIVO_HIP(hipMemcpy(r, d_.scal, sizeof r, hipMemcpyDeviceToHost));
@@ -970,7 +1199,7 @@ class BaSolver {
     bool points_fixed_;
     int cur_ = 0;
     Buf slot_, pt_off_, pt_edges_, ps_off_, ps_edges_, table_, edges_, level_, robust_, poses_[2], points_[2];
-    Buf err_, Jp_, Jx_, wo_, rchi_, W_, Y_, Hll_, bl_, Hinv_, xl_, sc_pt_, Hpp_, bp_, S_, xs_, scal_;
+    Buf err_, Jp_, Jx_, wo_, rchi_, W_, Y_, Hll_, bl_, xl_, sc_pt_, Hpp_, bp_, S_, xs_, scal_, partial_, counter_;
     std::vector<double> hpp_last_;
     std::vector<int32_t> slot_host_;
     BaDev d_{};
