@@ -198,7 +198,8 @@ def mfma_roofline(prof_timed, prof_detail, n_timed_frames, n_detail, ms_per_fram
             "mfma_kernels": [{"kernel": "sivo::" + k, "ms_per_frame": round(v["ms"] / n_detail, 3), "launches_per_frame": round(v["launches"] / n_detail, 2),
                               "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "peak": kernel_class(k)[1],
                               "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / kernel_class(k)[1], 4),
-                              "executed_frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 * kernel_class(k)[0] / kernel_class(k)[1], 4)}
+                              "executed_frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 * kernel_class(k)[0] / kernel_class(k)[1], 4),
+                              "flops_per_launch": v["flops"] / max(v["launches"], 1), "traffic": traffic_from_profiles(k, tag)[0]}
                              for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"]) if kernel_class(k) and v["flops"] > 0 and v["ms"] > 0],
             "kernels_ms_per_frame": {k: round(v["ms"] / n_detail, 3) for k, v in sorted(by_kernel.items())},
             "segnet_kernel_ms_per_frame": round(sum(v["ms"] for v in by_kernel.values()) / n_detail, 3),

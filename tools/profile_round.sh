@@ -13,6 +13,25 @@ O=$R/gpurun_out
 mkdir -p $O
 cd $R
 if [ "$WITH_TESTS" = onlytests ]; then timeout 1700 python -m pytest tests -m gpu -q > $O/${TAG}_gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/${TAG}_gpu_tests.log; exit 0; fi
+pmc() {   # name, bench args
+  local name=$1 args=$2
+  for pass in "f FETCH_SIZE" "w WRITE_SIZE" "m SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    set -- $pass; p=$1; shift
+    rm -rf /tmp/pmc_${name}_$p
+    (cd /tmp && SIVO_LANES=1 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_${name}_$p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-orb --configs none $args > /dev/null 2>&1)
+  done
+  python tools/pmc_summary.py $O/${TAG}_pmc_traffic_$name.json /tmp/pmc_${name}_f /tmp/pmc_${name}_w /tmp/pmc_${name}_m > /dev/null && python - <<PY
+import json
+d=json.load(open("$O/${TAG}_pmc_traffic_$name.json"))
+for k,v in d.items():
+    if isinstance(v,dict) and v.get("bytes",0)>5e7: print("$name", k[:60], v.get("dispatches"), "MB", round(v["bytes"]/1e6,1), "mfma_busy", round(v.get("mfma_busy_frac",0),3))
+PY
+}
+pmc main ""
+pmc basic "--net basic --T 6"
+pmc t48 "--T 48"
+# the line reads its `traffic` from profiles/: the PMC passes of THIS build first
+cp $O/${TAG}_pmc_traffic_*.json $R/profiles/ 2>/dev/null
 timeout 600 python bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"
 python - <<PY
 import json
@@ -31,27 +50,11 @@ stats main "--steps 20" SIVO_DUMMY=1
 stats onelane "--steps 20" SIVO_LANES=1
 stats basic "--net basic --T 6 --steps 20 --no-orb" SIVO_LANES=1
 stats t48 "--T 48 --steps 4 --warmup 1 --no-orb" SIVO_LANES=1
+timeout 200 python tools/layer_times.py 10 > $O/${TAG}_layer_times.txt 2>&1; tail -3 $O/${TAG}_layer_times.txt
 rm -rf /tmp/prof_ba
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ba -o ba -- python $R/tests/tools/ba_bench.py > $O/${TAG}_ba_bench_under_rocprof.json 2>/dev/null)
 f=$(find /tmp/prof_ba -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_kernel_stats_ba.csv && head -6 $O/${TAG}_kernel_stats_ba.csv | cut -c1-150
 timeout 300 python tests/tools/ba_bench.py > $O/${TAG}_ba_bench.json 2>/dev/null; cut -c1-400 $O/${TAG}_ba_bench.json
-pmc() {   # name, bench args
-  local name=$1 args=$2
-  for pass in "f FETCH_SIZE" "w WRITE_SIZE" "m SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
-    set -- $pass; p=$1; shift
-    rm -rf /tmp/pmc_${name}_$p
-    (cd /tmp && SIVO_LANES=1 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_${name}_$p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-orb --configs none $args > /dev/null 2>&1)
-  done
-  python tools/pmc_summary.py $O/${TAG}_pmc_traffic_$name.json /tmp/pmc_${name}_f /tmp/pmc_${name}_w /tmp/pmc_${name}_m > /dev/null && python - <<PY
-import json
-d=json.load(open("$O/${TAG}_pmc_traffic_$name.json"))
-for k,v in d.items():
-    if isinstance(v,dict) and v.get("bytes",0)>5e7: print("$name", k[:60], v.get("dispatches"), "MB", round(v["bytes"]/1e6,1), "mfma_busy", round(v.get("mfma_busy_frac",0),3))
-PY
-}
-pmc main ""
-pmc basic "--net basic --T 6"
-pmc t48 "--T 48"
 if [ "$WITH_TESTS" = tests ]; then
   timeout 1700 python -m pytest tests -m gpu -q > $O/${TAG}_gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/${TAG}_gpu_tests.log
 fi
