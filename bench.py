@@ -451,8 +451,10 @@ def main():
         note = (f"dominant kernel: HIP events on its launch stream in every {PROFILE_EVERY}th of the {args.steps} timed frames (those frames run the forward in one "
                 f"lane, one launch per layer; the others split the samples over three lanes); kernels_ms_per_frame: {n_detail} further untimed single-lane "
                 "frames with every kernel bracketed.  achieved / frac = direct-convolution FLOPs (SURVEY 8d) / kernel time against the dense fp16 / bf16 peak; "
-                "executed_* = the matrix-core products issued (the Winograd-domain GEMM of F(4x4,3x3) multiplies 1/4 of the direct convolution's products; each fp32 "
-                "product is three fp16 MFMA products)")
+                "executed_* = the matrix-core products issued (the Winograd-domain GEMM of F(4x4,3x3) multiplies 1/4 of the direct convolution's products, the direct "
+                "f16x3 kernel all of them; each fp32 product is three fp16 MFMA products — so executed = 3/4 of algorithmic for the GEMM and 3x for the direct "
+                "kernel).  mfma_kernels lists every matrix-core kernel of the frame with the same figures: the two f16x3 kernels take about the same time, and "
+                "which of them is 'dominant' can change from run to run")
         roofline = mfma_roofline(prof_timed, prof, n_timed, n_detail, ms_frame, note)
         out = {"metric": "frames/sec, SIVO per-frame path (ORB+SegNet T=%d+entropy) %dx%d" % (T, H, W),
                "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
