@@ -83,3 +83,50 @@ def test_pose_optimization_recovers_pose_and_flags_planted_outliers(oracle):
     # fewer than 3 correspondences: nothing happens (:409-411)
     r0 = oracle.pose_optimize(p0, pts, ek[:2], intr)
     assert r0["inliers"] == 0 and np.array_equal(r0["pose"], p0)
+
+
+def test_converged_bundle_adjustment_equals_minpack_on_the_same_residuals(oracle):
+    """Second opinion for the unpinned g2o solve: the state the LM / Schur restatement converges to must minimise the same sum of
+    squares as a solver that shares no code with it — MINPACK's Levenberg-Marquardt (scipy.optimize.least_squares, method
+    'lm', finite-difference Jacobian) on whitened residuals written here from the projection equations, poses moved by the
+    se(3) exponential (scipy's expm of the twist).  Kernels off (robust = 0: a smooth problem; the Huber weights have their own
+    test, test_oracle_match_ba.py::test_ba_chi2_and_huber), noisy observations, two fixed and two free keyframes."""
+    from scipy.linalg import expm
+    from scipy.optimize import least_squares
+    poses, pts, edges, intr = make_ba_scene(seed=5, n_kf=4, n_pts=40, stereo_frac=1.0)
+    fx, fy, cx, cy, bf = intr
+    rng = np.random.default_rng(1)
+    fixed = np.zeros(4, np.uint8); fixed[:2] = 1
+    P0 = poses.copy(); P0[2:, 9:] += rng.normal(0, 0.02, (2, 3)); X0 = pts + rng.normal(0, 0.05, pts.shape)
+    r = oracle.ba_optimize(P0, fixed, X0, edges, intr, 200, robust=np.zeros(len(edges), np.uint8))
+    assert r["iterations"] < 200                                   # stopped by its own criterion, not by the cap
+
+    def unpack(x):
+        P = P0.copy()
+        for s in range(2):
+            w, u = x[6 * s:6 * s + 3], x[6 * s + 3:6 * s + 6]
+            xi = np.zeros((4, 4)); xi[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]; xi[:3, 3] = u
+            T = np.eye(4); T[:3, :3] = P0[2 + s, :9].reshape(3, 3); T[:3, 3] = P0[2 + s, 9:]
+            Tn = expm(xi) @ T
+            P[2 + s, :9] = Tn[:3, :3].ravel(); P[2 + s, 9:] = Tn[:3, 3]
+        return P, X0 + x[12:].reshape(-1, 3)
+
+    def residuals(P, X):
+        R = P[edges["pose"], :9].reshape(-1, 3, 3); t = P[edges["pose"], 9:]
+        pc = np.einsum("eij,ej->ei", R, X[edges["point"]]) + t
+        u = fx * pc[:, 0] / pc[:, 2] + cx
+        proj = np.stack([u, fy * pc[:, 1] / pc[:, 2] + cy, u - bf / pc[:, 2]], 1)
+        return ((edges["obs"] - proj) * np.sqrt(edges["inv_sigma2"])[:, None]).ravel()
+
+    sol = least_squares(lambda x: residuals(*unpack(x)), np.zeros(12 + 3 * len(pts)), method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15,
+                        max_nfev=200000)
+    Ps, Xs = unpack(sol.x)
+    c_oracle, c_minpack = float((residuals(r["poses"], r["points"]) ** 2).sum()), float((residuals(Ps, Xs) ** 2).sum())
+    start = float((residuals(P0, X0) ** 2).sum())
+    assert c_oracle < 0.9 * start                                  # there was something to optimise
+    assert abs(c_oracle - c_minpack) <= 1e-7 * c_minpack, (c_oracle, c_minpack)
+    assert np.abs(r["poses"] - Ps).max() < 1e-3                      # (far points' depth is a flat direction: compare what is observable)
+    assert np.abs(residuals(r["poses"], r["points"]) - residuals(Ps, Xs)).max() < 1e-2
+    # and the oracle's own chi2 is the sum of squares written here
+    np.testing.assert_allclose(oracle.ba_linearize(r["poses"], r["points"], edges, intr)["chi2"],
+                               (residuals(r["poses"], r["points"]).reshape(-1, 3) ** 2).sum(1), rtol=1e-10, atol=1e-12)
