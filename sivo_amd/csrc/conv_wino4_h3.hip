@@ -274,6 +274,10 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) B[t][pl] = *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048 + kk * 1024);
             // smallest terms first: (lo, hi) (hi, lo) (hi, hi); consecutive MFMAs on different accumulators
+            // (Tried in round 3 and removed: the second k-step's fragments under the first one's MFMAs — tile blocks in pairs, the
+            // V' registers of a pair refilled behind its last use, a second U' set, pinned by sched_group_barrier; 234 VGPRs,
+            // bit-identical, the lgkmcnt(0) waits behind freshly issued reads gone from the .s — and the GEMM took 2.65 instead of
+            // 2.63 ms per frame: with two waves per SIMD the other wave already covers those waits.)
 #pragma unroll
             for (int term = 0; term < 3; ++term) {
                 constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
