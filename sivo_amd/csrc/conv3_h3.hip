@@ -42,6 +42,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
         }
     };
-    bool bad = false;
+    uint32_t ovf = 0u;          // largest |scaled input| seen by this lane, as bits << 1
     // split of piece r, in steps: 0..3 -> channels 2 step, 2 step + 1 become (hi | lo << 16) in place; 4 -> the hi plane's
     // piece is written; 5 -> the lo plane's
     auto split_step = [&](int buf, PSet &pv, int r, int step) __attribute__((always_inline)) {
@@ -198,7 +199,16 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         unsigned char *dst = lds_d + buf * D_PBYTES + tid * 16 + r * 8192;
         if (step < 4) {
 #pragma unroll
-            for (int e = 2 * step; e < 2 * step + 2; ++e) pv[r][e] = wino4_pack_h3(__uint_as_float(pv[r][e]), a.h3_vscale, bad);
+            for (int e = 2 * step; e < 2 * step + 2; ++e) {
+                // as wino4_pack_h3 (h3_split.hpp); the range check is a running maximum of the bit pattern of |xs| (sign shifted
+                // out; inf and NaN order above every finite value) instead of a compare + mask update per value
+                const float xs = __uint_as_float(pv[r][e]) * a.h3_vscale;
+                const _Float16 hi = (_Float16)xs;
+                const _Float16 lo = (_Float16)(xs - (float)hi);
+                const uint32_t mag = __float_as_uint(xs) << 1;
+                ovf = mag > ovf ? mag : ovf;
+                pv[r][e] = (uint32_t)__builtin_bit_cast(unsigned short, hi) | ((uint32_t)__builtin_bit_cast(unsigned short, lo) << 16);
+            }
         } else {
             u32x4 w;
 #pragma unroll
@@ -265,7 +275,10 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // and the item takes 16 buffer_store_dwordx4 instead of 64 dword stores: output stage 2.2k instead of 1.4k cycles per
     // stage on conv1_2_D, tools/d3_stamps.py.  The dword stores already write whole 128-byte runs; what the stage waits for
     // is the write path's bytes, not its instruction count.)
-    auto store_item = [&](int n, int ty, int tx, int g, int par) __attribute__((always_inline)) {
+    // (relu_tag: the layer's ReLU flag as a compile-time constant — tested per element it cost a mask update and a wait state
+    // in front of every select)
+    auto store_item_as = [&](int n, int ty, int tx, int g, int par, auto relu_tag) __attribute__((always_inline)) {
+        constexpr bool RELU = decltype(relu_tag)::value;
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.out + (int64_t)n * a.Cout * plane, 0, (int)((int64_t)a.Cout * plane * 4), 0x00020000);
         const float *epl = reinterpret_cast<const float *>(lds_d + D_EP0) + par * 128;
         const int x = tx * D_TW + ch * 32 + ln;
@@ -282,13 +295,17 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float v = acc[b][sg][4 * q + i] * sc[i] + sh[i];
-                        if (a.relu) v = v > 0.f ? v : 0.f;
+                        if (RELU) v = v > 0.f ? v : 0.f;
                         const int co = g * 64 + b * 32 + 8 * q + i;
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, vo, (uint32_t)((int64_t)co * plane * 4), 0);
                     }
                 }
         }
         clear_acc();
+    };
+    auto store_item = [&](int n, int ty, int tx, int g, int par) __attribute__((always_inline)) {
+        if (a.relu) store_item_as(n, ty, tx, g, par, std::true_type{});
+        else store_item_as(n, ty, tx, g, par, std::false_type{});
     };
 
     // ---- the stream of stages ----------------------------------------------------------------------------------------------
@@ -446,7 +463,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
     }
     if (pend) store_item(pn, pty, ptx, pg, ppar);
-    if (bad) atomicOr(a.h3_flag, 1u);
+    if (ovf > (0x477fe000u << 1)) atomicOr(a.h3_flag, 1u);          // !(|xs| <= 65504): a scaled input left the fp16 range (or was not finite)
     if ((ABL & 64) && a.vmax && lane == 0) {
         atomicAdd(a.vmax + 0, st_wait >> 4); atomicAdd(a.vmax + 1, st_bar >> 4); atomicAdd(a.vmax + 2, st_out >> 4); atomicAdd(a.vmax + 3, st_mul >> 4);
         atomicAdd(a.vmax + 4, (uint32_t)total);
