@@ -638,22 +638,15 @@ __global__ __launch_bounds__(BA_SCHUR_T) void ba_schur_kernel(BaDev d, double la
 
 // dense Cholesky solve S x = xs (single workgroup); scal[3] = 1 on success.  The system is a grid of 6x6 keyframe blocks,
 // and the factorisation is blocked accordingly (factor the diagonal block, solve the panel, update the trailing
-// matrix: 3 barriers per keyframe instead of 3 per column), as are the two triangular solves.  LDS_COPY: the reduced
-// system of a local BA (<= 21 free keyframes: n <= 126, n*n*8 <= 127 KB) is factorised in LDS — the loop is a chain of
-// dependent steps, i.e. pure latency, and LDS answers ~20x faster than L2.
+// matrix: 3 barriers per keyframe instead of 3 per column), as are the two triangular solves.  This is the form for systems
+// that do not fit in LDS (more than 21 free keyframes: a global bundle adjustment); it works in global memory.  A local BA
+// (n <= 126) takes ba_dense_solve_lds_kernel below.
 constexpr int BA_SOLVE_T = 256;
-template <bool LDS_COPY>
 __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_kernel(BaDev d) {
     __shared__ int s_ok;
     __shared__ double s_x[6];
-    __shared__ double s_rhs[LDS_COPY ? 128 : 1];          // LDS_COPY: the right-hand side / solution lives in LDS too: the two
-    extern __shared__ double s_mat[];                     // triangular solves are 2 nF dependent steps, one L2 round trip each otherwise
     const int nb = d.nF, n = 6 * nb, tid = threadIdx.x;
-    double *S = LDS_COPY ? s_mat : d.S, *x = LDS_COPY ? s_rhs : d.xs;
-    if (LDS_COPY) {
-        for (int i = tid; i < n * n; i += BA_SOLVE_T) s_mat[i] = d.S[i];
-        for (int i = tid; i < n; i += BA_SOLVE_T) s_rhs[i] = d.xs[i];
-    }
+    double *S = d.S, *x = d.xs;
     if (tid == 0) s_ok = 1;
     __syncthreads();
     for (int jb = 0; jb < nb; ++jb) {
@@ -739,13 +732,11 @@ __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_kernel(BaDev d) {
             __syncthreads();
         }
     }
-    if (LDS_COPY && s_ok)
-        for (int i = tid; i < n; i += BA_SOLVE_T) d.xs[i] = s_rhs[i];
     if (tid == 0) d.scal[3] = s_ok ? 1.0 : 0.0;
 }
 
-// The reduced system of a local BA (n = 6 nF <= 126) solved entirely in LDS — round 3's second form (the first, above with
-// LDS_COPY, took 151 of an LM iteration's 367 us: rocprofv3, profiles/r03_a_kernel_stats_ba.csv).  What that one spent its time
+// The reduced system of a local BA (n = 6 nF <= 126) solved entirely in LDS — round 3's second form (the first, the kernel above
+// on an LDS copy of the matrix, took 151 of an LM iteration's 367 us: rocprofv3, profiles/r03_a_kernel_stats_ba.csv).  What that one spent its time
 // on was hand-overs: thread 0 factorised the 6 x 6 diagonal block through ~100 dependent LDS round trips while 255 threads
 // waited, 3 barriers per keyframe, then 2 x nF more steps of 2 barriers for the triangular solves.  Here
 //   * EVERY thread factorises the diagonal block in registers (21 broadcast reads, ~100 FMAs, 6 sqrt, 6 divisions) and inverts
@@ -1132,7 +1123,7 @@ class BaSolver {
                     if (6 * nF_ <= 126 && dense_solve_lds_ok()) {
                         hipLaunchKernelGGL(ba_dense_solve_lds_kernel, dim3(1), dim3(BA_SOLVE_T), (size_t)(6 * nF_ + 1) * (6 * nF_ + 1) * 8, 0, d_);
                     } else {
-                        hipLaunchKernelGGL(ba_dense_solve_kernel<false>, dim3(1), dim3(BA_SOLVE_T), 0, 0, d_);
+                        hipLaunchKernelGGL(ba_dense_solve_kernel, dim3(1), dim3(BA_SOLVE_T), 0, 0, d_);
                     }
                 } else {
                     const double one = 1.0;
