@@ -186,10 +186,6 @@ typedef struct {
 int sivo_segnet_profile(sivo_segnet_t h, int enable);
 int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int capacity, int *n_out);
 
-/* Diagnostic micro-benchmark of one convolution shape (random data); `variant` bit flags switch
- * parts of the kernel off to attribute time (0 = the production kernel).  Mean launch ms out. */
-int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, int iters, int variant, double *ms_out);
-
 /* The GEMM the F(4x4,3x3) layers of the handle run: *mode = 2 f16x3 (fp32 operands as fp16 hi + lo planes, three
  * products: the default), 1 bf16x6 (three bf16 planes, six products: SIVO_GEMM=x6, and every handle after a frame
  * raised the fp16 overflow flag), 0 fp32 MFMA (SIVO_GEMM=f32) or no such layer.  *overflow_frames = frames in which a
@@ -202,21 +198,6 @@ typedef struct SivoH3Layer {
     float vmax, vscale, uscale;
 } SivoH3Layer;
 int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow_frames, SivoH3Layer *per_layer, int capacity, int *n_layers);
-
-/* Diagnostic / test: the f16x3 GEMM alone on host operands.  V [36][C][Pp] fp32 (Pp = P rounded up to 128), U [36][C][Kp]
- * fp32, M [36][Kp][Pp] out (fp32, scales multiplied back out); C % 32 == 0, Kp % 128 == 0.  iters > 0: mean launch time
- * (ms) of `iters` further launches in *ms_out. */
-int sivo_debug_h3_gemm(int C, int Kp, int P, const float *V, const float *U, float vscale, float *M, int iters, double *ms_out);
-
-/* Diagnostic / test: the direct 3x3 convolution on the fp16 matrix cores (f16x3, conv3_h3.hip) alone.  d_in, d_mask, d_out:
- * DEVICE pointers — d_mask null: d_in is (N, Cin, H, W); else d_in is the pooled tensor (N, Cin, H/2, W/2) and d_mask its
- * u8 window codes (dy * 2 + dx), the layer reading through the Upsample as in the network.  Wt (Cout, Cin, 3, 3), scale,
- * shift (Cout): HOST arrays; out = act(scale * conv + shift).  vscale: the power of two the input is multiplied with before
- * it is split (max |in| * vscale well below 65504).  Cin % 16 == 0, Cin >= 32, Cout % 64 == 0.  *overflowed = 1 when a scaled
- * input left the fp16 range.  iters > 0: mean launch time (ms) of `iters` further launches in *ms_out. */
-int sivo_debug_conv3_h3_dev(int N, int Cin, int Cout, int H, int W, const float *d_in, const uint8_t *d_mask, const float *Wt,
-                            const float *scale, const float *shift, int relu, float vscale, float *d_out, int iters,
-                            double *ms_out, int *overflowed);
 
 /* ===========================================================================
  * ORB extractor — stands behind SIVO::ORBextractor

@@ -82,10 +82,7 @@ SIGNATURES = {
     "sivo_segnet_flops": [_vp, C.POINTER(_d), C.POINTER(_d)],
     "sivo_segnet_profile": [_vp, _i],
     "sivo_segnet_profile_read": [_vp, _vp, _i, _pi32],
-    "sivo_debug_conv": [_i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_d)],
     "sivo_segnet_gemm_status": [_vp, _pi32, _pi32, _vp, _i, _pi32],
-    "sivo_debug_h3_gemm": [_i, _i, _i, _vp, _vp, _f, _vp, _i, C.POINTER(_d)],
-    "sivo_debug_conv3_h3_dev": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _i, C.POINTER(_d), C.POINTER(_i)],
     "sivo_orb_create": [_i, _f, _i, _i, _i, _i, C.POINTER(_vp)],
     "sivo_orb_destroy": [_vp],
     "sivo_orb_tables": [_vp, _vp, _vp, _vp, _vp, _vp],
@@ -128,7 +125,34 @@ SIGNATURES = {
     "sivo_ba_linearize": [_vp, _i, _vp, _i, _vp, _i64, C.POINTER(_d), _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 
+# test / diagnostic entry points (include/sivo_hip_debug.h): libsivo_hip_dbg.so, a thin library over the product's kernels
+DEBUG_SIGNATURES = {
+    "sivo_debug_conv": [_i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_d)],
+    "sivo_debug_h3_gemm": [_i, _i, _i, _vp, _vp, _f, _vp, _i, C.POINTER(_d)],
+    "sivo_debug_conv3_h3_dev": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _i, C.POINTER(_d), C.POINTER(_i)],
+    "sivo_debug_conv3_h3_pk_dev": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _i, _vp, _i, C.POINTER(_d), C.POINTER(_i)],
+}
+DBG_PATH = os.path.join(_HERE, "libsivo_hip_dbg.so")
+
 _lib = None
+_dbg = None
+
+
+def dbg():
+    """Load libsivo_hip_dbg.so (`make -C sivo_amd/csrc dbg`): the sivo_debug_* entry points the kernel tests and tools call.  It
+    links libsivo_hip.so (loaded first, so that both share one copy) and runs the product's kernels."""
+    global _dbg
+    if _dbg is None:
+        lib()
+        if not os.path.exists(DBG_PATH):
+            raise ImportError(f"{DBG_PATH} is missing: make -C sivo_amd/csrc dbg")
+        L = C.CDLL(DBG_PATH)
+        for name, args in DEBUG_SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        _dbg = L
+    return _dbg
 
 
 def lib():

@@ -35,6 +35,24 @@
 // Fragment order [plane][octet][patch row][patch column] / [plane][octet][cout]: every ds_read_b128 / ds_write_b128 touches
 // consecutive 16-byte pieces in lane order (conflict-free, any tap shift).  C/D of the 32 x 32 MFMA: column = lane & 31 =
 // pixel, so an accumulator register of a wave is two 128-byte runs of an output row.
+//
+// Packed activations (round 4).  Between two layers of this kernel the activation does not have to be fp32 NCHW: the
+// producer holds every output beside its channel neighbours and knows the consumer's power of two, so its output stage can
+// write the consumer's LDS pieces directly —
+//     P[n][C / 8][plane: hi, lo][Hp][Wp][8 halfs]      (the same 4 bytes per element as fp32)
+// with the image at rows / columns 1 .. of a ZERO-BORDERED (Hp, Wp) plane (Hp >= 8 tiles_y + 2, Wp >= 64 tiles_x + 2: the
+// halo and the overhang of partial items read zeros that are simply there; producers write the interior only).  A value is
+// then split ONCE (by its producer) instead of once per (consumer workgroup, cout group, halo overlap), and
+//   * IN_PK: the consumer's patch staging is 42 LDS-DMA pieces per workgroup and stage (1 KiB each: 64 consecutive pieces
+//     of a plane-octet row run) and no VALU at all;
+//   * IN_PK_UNPOOL (the layer reads through an Upsample): the POOLED tensor is packed, and the window codes come as one dword
+//     per (pooled pixel, channel octet) whose byte k has bit e set when channel e's maximum sat at window position k
+//     (pool_bits_kernel, pk_format.hip).  A lane loads one pooled piece (hi, lo: two 16-byte loads) and its dword, and
+//     writes up to four unpooled pieces: piece & LUT[byte k] (256 x 16-byte table in LDS: bit e -> 0xffff in half e).
+//   * OUT_PK: the output stage multiplies by the consumer's power of two, splits, and stores 8-byte half pieces (a lane
+//     holds four consecutive channels of an octet); it also raises the overflow flag the consumer can no longer raise.
+// The split is the same arithmetic in the same order as the fp32 form's (x * scale, hi = fp16, lo = fp16(rest)), so a
+// chain of packed layers computes bit for bit what the chain of fp32 blobs computes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -72,6 +90,17 @@ constexpr int D_NIT = 3;                           // patch pieces per thread: c
 constexpr int D_NPIECE = 2 * D_NPX;                // 1320
 constexpr uint32_t D_INV = 0xfffffff0u;            // beyond any descriptor: loads return 0, stores are dropped
 static_assert(D_LDS <= 160 * 1024, "LDS");
+// packed input by LDS-DMA: 2 * D_NPIECE = 2640 pieces per stage in 42 DMA instructions of 64; the 48 pieces the last one
+// writes beyond the patch land in a pad behind each buffer
+constexpr int D_PK_DMA = 42;
+constexpr int D_PBYTES_DMA = D_PK_DMA * 1024;      // 43,008
+// packed input through an Upsample: pooled pieces of a stage = 2 octets x 6 rows x 34 columns, one per thread
+constexpr int D_QR = D_TH / 2 + 2, D_QC = D_TW / 2 + 2, D_NQ = 2 * D_QR * D_QC;      // 408
+static_assert(D_NQ <= 512, "one pooled piece per thread");
+static_assert(2 * D_PBYTES_DMA + 2 * D_UBYTES + 1024 <= 160 * 1024, "LDS (IN_PK)");
+static_assert(D_LDS + 4096 <= 160 * 1024, "LDS (IN_PK_UNPOOL)");
+
+enum : int { IN_F32 = 0, IN_F32_UNPOOL = 1, IN_PK = 2, IN_PK_UNPOOL = 3 };
 
 // Two forms of the stage loop (FORM; bit-identical results — same products, same order):
 //   0  "phased": barrier -> output stage -> issue loads / DMA of stage s + 1 -> multiply stage s -> wait -> split stage s + 1.
@@ -85,9 +114,15 @@ static_assert(D_LDS <= 160 * 1024, "LDS");
 //      MFMAs (an MFMA occupies the pipe for 32 cycles, its issue 4).
 // ABL (diagnostic builds only, -DSIVO_DIAG; results are wrong by construction): 1 no patch loads after the prologue,
 // 2 no weight DMA after the prologue, 4 no output stores, 8 no MFMAs, 16 no patch split / LDS writes after the prologue.
-template <bool UNPOOL, int FORM, int ABL = 0>
+template <int IN, bool OUT_PK, int FORM, int ABL = 0>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3_h3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_d[];
+    constexpr bool F32IN = IN == IN_F32 || IN == IN_F32_UNPOOL;
+    constexpr bool UNPOOL = IN == IN_F32_UNPOOL;               // (the fp32 staging code below; the packed forms have their own)
+    static_assert(F32IN || (FORM == 1 && ABL == 0), "the packed inputs exist in the interleaved form only");
+    // LDS map: two patch buffers, two weight buffers, the epilogue affine of two items, (IN_PK_UNPOOL) the 256 x 16-byte mask table
+    constexpr int PB = IN == IN_PK ? D_PBYTES_DMA : D_PBYTES;
+    constexpr int U0 = 2 * PB, EP0 = U0 + 2 * D_UBYTES, LUT0 = EP0 + 1024;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane & 31, lh = lane >> 5;
@@ -196,7 +231,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // piece is written; 5 -> the lo plane's
     auto split_step = [&](int buf, PSet &pv, int r, int step) __attribute__((always_inline)) {
         if (r == D_NIT - 1 && !p_valid[r]) return;
-        unsigned char *dst = lds_d + buf * D_PBYTES + tid * 16 + r * 8192;
+        unsigned char *dst = lds_d + buf * PB + tid * 16 + r * 8192;
         if (step < 4) {
 #pragma unroll
             for (int e = 2 * step; e < 2 * step + 2; ++e) {
@@ -228,7 +263,16 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     auto dma_piece = [&](const Cursor &c, int buf, int j) __attribute__((always_inline)) {
         const unsigned char *sb = static_cast<const unsigned char *>(a.wt_h3) + ((int64_t)c.g * nst + c.chunk) * D_UBYTES;
         const int piece = wave + 8 * j;
-        if (piece < 36) lds_dma16_s(sb, (uint32_t)(piece * 1024 + lane * 16), lds_base + D_U0 + buf * D_UBYTES + piece * 1024);
+        if (piece < 36) lds_dma16_s(sb, (uint32_t)(piece * 1024 + lane * 16), lds_base + U0 + buf * D_UBYTES + piece * 1024);
+    };
+    // the same with the stage's base computed once by the caller (the packed forms: a slot has nothing else to do, so the 64-bit
+    // address arithmetic per piece was most of its scalar work); pieces 0 .. 31 exist for every wave: no branch for j < 4
+    const uint32_t w_voff = (uint32_t)(wave * 1024 + lane * 16);
+    auto stage_weights = [&](const Cursor &c) __attribute__((always_inline)) {
+        return static_cast<const unsigned char *>(a.wt_h3) + ((int64_t)c.g * nst + c.chunk) * D_UBYTES;
+    };
+    auto dma_piece_at = [&](const unsigned char *sb, int buf, int j) __attribute__((always_inline)) {
+        if (j < 4 || wave < 4) lds_dma16_s(sb + j * 8192, w_voff, lds_base + U0 + buf * D_UBYTES + (wave + 8 * j) * 1024);
     };
 
     // ---- MFMA phase: wave (rp, ch) owns output rows 2 rp, 2 rp + 1, columns 32 ch .. 32 ch + 31 of the item, all 64 couts ----
@@ -246,7 +290,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const uint32_t b_off = (uint32_t)((lh * D_NPX + (2 * rp) * D_PW + ch * 32 + ln) * 16), a_off = (uint32_t)(lane * 16);
     half8 A[2][2][2], B[2][2][2];       // [tap parity][block / row][plane]
     auto fetch = [&](int buf, int t, int par) __attribute__((always_inline)) {
-        const unsigned char *ps = lds_d + buf * D_PBYTES + b_off, *us = lds_d + D_U0 + buf * D_UBYTES + a_off;
+        const unsigned char *ps = lds_d + buf * PB + b_off, *us = lds_d + U0 + buf * D_UBYTES + a_off;
         const int ky = t / 3, kx = t - 3 * ky;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -280,7 +324,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     auto store_item_as = [&](int n, int ty, int tx, int g, int par, auto relu_tag) __attribute__((always_inline)) {
         constexpr bool RELU = decltype(relu_tag)::value;
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.out + (int64_t)n * a.Cout * plane, 0, (int)((int64_t)a.Cout * plane * 4), 0x00020000);
-        const float *epl = reinterpret_cast<const float *>(lds_d + D_EP0) + par * 128;
+        const float *epl = reinterpret_cast<const float *>(lds_d + EP0) + par * 128;
         const int x = tx * D_TW + ch * 32 + ln;
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) {
@@ -303,9 +347,54 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
         clear_acc();
     };
+    // OUT_PK: the consumer's pieces.  A lane holds channels 4 lh .. 4 lh + 3 of octet 8 g + 4 b + q for its pixel: the 8 bytes at
+    // offset 8 lh of that pixel's hi piece and of its lo piece; the 32 pixels of a wave row are 512 contiguous bytes per store.
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    auto store_item_pk_as = [&](int n, int ty, int tx, int g, int par, auto relu_tag) __attribute__((always_inline)) {
+        constexpr bool RELU = decltype(relu_tag)::value;
+        const int64_t opl = (int64_t)a.out_Hp * a.out_Wp * 16;          // bytes of one plane of one channel octet
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(static_cast<unsigned char *>(a.out_pk) + (int64_t)n * (a.Cout / 8) * 2 * opl, 0, (int)((a.Cout / 8) * 2 * opl), 0x00020000);
+        const float *epl = reinterpret_cast<const float *>(lds_d + EP0) + par * 128;
+        const int x = tx * D_TW + ch * 32 + ln;
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+            const int y = ty * D_TH + 2 * rp + sg;
+            const uint32_t vo = (y < a.H && x < a.W) ? (uint32_t)((((y + 1) * a.out_Wp) + x + 1) * 16 + lh * 8) : D_INV;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(epl + b * 32 + 8 * q + 4 * lh);
+                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(epl + 64 + b * 32 + 8 * q + 4 * lh);
+                    uint32_t pr[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[b][sg][4 * q + i] * sc[i] + sh[i];
+                        if (RELU) v = v > 0.f ? v : 0.f;
+                        const float xs = v * a.out_vscale;              // as the consumer's split_step does with the fp32 blob
+                        const _Float16 hi = (_Float16)xs;
+                        const _Float16 lo = (_Float16)(xs - (float)hi);
+                        const uint32_t mag = __float_as_uint(xs) << 1;
+                        ovf = mag > ovf ? mag : ovf;
+                        pr[i] = (uint32_t)__builtin_bit_cast(unsigned short, hi) | ((uint32_t)__builtin_bit_cast(unsigned short, lo) << 16);
+                    }
+                    const u32x2 hv = {__builtin_amdgcn_perm(pr[1], pr[0], 0x05040100u), __builtin_amdgcn_perm(pr[3], pr[2], 0x05040100u)};
+                    const u32x2 lv = {__builtin_amdgcn_perm(pr[1], pr[0], 0x07060302u), __builtin_amdgcn_perm(pr[3], pr[2], 0x07060302u)};
+                    const uint32_t so = (uint32_t)((int64_t)((g * 8 + b * 4 + q) * 2) * opl);
+                    __builtin_amdgcn_raw_buffer_store_b64(hv, rs, vo, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(lv, rs, vo, so + (uint32_t)opl, 0);
+                }
+        }
+        clear_acc();
+    };
     auto store_item = [&](int n, int ty, int tx, int g, int par) __attribute__((always_inline)) {
-        if (a.relu) store_item_as(n, ty, tx, g, par, std::true_type{});
-        else store_item_as(n, ty, tx, g, par, std::false_type{});
+        if constexpr (OUT_PK) {
+            if (a.relu) store_item_pk_as(n, ty, tx, g, par, std::true_type{});
+            else store_item_pk_as(n, ty, tx, g, par, std::false_type{});
+        } else {
+            if (a.relu) store_item_as(n, ty, tx, g, par, std::true_type{});
+            else store_item_as(n, ty, tx, g, par, std::false_type{});
+        }
     };
 
     // ---- the stream of stages ----------------------------------------------------------------------------------------------
@@ -332,7 +421,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     };
     uint32_t st_wait = 0, st_bar = 0, st_out = 0, st_mul = 0;
     const uint32_t st_begin = stamp();
-    if (FORM == 0) {
+    if constexpr (FORM == 0) {
         Cursor cl = cc;         // loads, one stage ahead
         PSet pv, pm;
         bool l_first = false;   // the stage in the registers is the first of its item ...
@@ -356,7 +445,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             landed(pv, pm);
             if (with_split) split_all(buf, pv);
-            if (l_first && wave < 2) reinterpret_cast<float *>(lds_d + D_EP0)[l_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
+            if (l_first && wave < 2) reinterpret_cast<float *>(lds_d + EP0)[l_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
         };
         issue(0, true, true);
         commit(0, true);
@@ -384,7 +473,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             end_of_stage();
             if (more) commit((s + 1) & 1, !(ABL & 16));
         }
-    } else {
+    } else if constexpr (F32IN) {
         Cursor cu = cc, cl = cc;    // weight DMA (one stage ahead of the multiply); patch loads (two stages ahead)
         PSet vA, vB, pm;            // even iterations split vA (stage s + 1) and load stage s + 2 into vB; odd ones the reverse
         bool ep_due = false;        // epv holds the affine of an item whose first stage's DMA was issued in the previous iteration
@@ -416,7 +505,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const uint32_t t0 = stamp();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const uint32_t t1 = stamp();
-            if (ep_due && wave < 2) reinterpret_cast<float *>(lds_d + D_EP0)[ep_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
+            if (ep_due && wave < 2) reinterpret_cast<float *>(lds_d + EP0)[ep_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
             ep_due = false;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             const uint32_t t2 = stamp();
@@ -461,6 +550,190 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             iteration(s, vA, vB);
             if (s + 1 < total) iteration(s + 1, vB, vA);
         }
+    } else if constexpr (IN == IN_PK) {
+        // ---- packed input, no Upsample: the patch of a stage is 42 LDS-DMA pieces, one stage ahead like the weights ----------
+        // piece j = wave + 8 i; lane l copies piece q = 64 j + l of the stage image [plane][octet][patch row][patch column]
+        // (q >= 2640: the pad behind the buffer, from a valid address)
+        Cursor cu = cc;
+        bool ep_due = false;
+        int ep_par = 0;
+        uint32_t pk_voff[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int q = (wave + 8 * i) * 64 + lane;
+            const int qq = q < 2 * D_NPIECE ? q : 0;
+            const int pl = qq / D_NPIECE, rem = qq - pl * D_NPIECE, o = rem / D_NPX, r2 = rem - o * D_NPX, py = r2 / D_PW, px = r2 - py * D_PW;
+            pk_voff[i] = (uint32_t)((((o * 2 + pl) * a.in_Hp + py) * a.in_Wp + px) * 16);
+        }
+        // patch row 0 = image row y0 - 1 = padded row y0, patch column 0 = padded column x0
+        auto stage_patch = [&](const Cursor &c) __attribute__((always_inline)) {
+            return static_cast<const unsigned char *>(a.in_pk) + (int64_t)c.n * a.in_pk_sample_bytes +
+                   (((int64_t)c.chunk * 4 * a.in_Hp + c.ty * D_TH) * a.in_Wp + c.tx * D_TW) * 16;
+        };
+        auto dma_patch = [&](const unsigned char *sb, int buf, int i) __attribute__((always_inline)) {      // (pieces 0 .. 39 exist for every wave)
+            if (i < 5 || wave < D_PK_DMA - 40) lds_dma16_s(sb, pk_voff[i], lds_base + buf * PB + (wave + 8 * i) * 1024);
+        };
+        // prologue: patch(0) and weights(0) in flight (the top of iteration 0 waits for them)
+        {
+            const unsigned char *sbp = stage_patch(cu), *sbw = stage_weights(cu);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dma_patch(sbp, 0, i);
+            if (wave < 2) { epv = ep_src[cu.g * 64 + lane]; }
+            ep_due = true; ep_par = 0;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) dma_piece_at(sbw, 0, j);
+        }
+        advance(cu);
+        // MORE: stage s + 1 exists (every iteration but the last: peeled, so that the loop body is one straight block)
+        auto iteration = [&](const int s, auto more_tag) __attribute__((always_inline)) {
+            constexpr bool MORE = decltype(more_tag)::value;
+            // everything this wave issued in the previous iteration has had a whole multiply to complete: patch and weights of
+            // stage s (DMA), the stores of an output stage.  Behind the barrier nobody reads the buffers of stage s - 1 any more.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ep_due && wave < 2) reinterpret_cast<float *>(lds_d + EP0)[ep_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
+            ep_due = false;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (pend) { store_item(pn, pty, ptx, pg, ppar); pend = false; }
+            const int nb = (s + 1) & 1;
+            if (MORE && cu.chunk == 0) {
+                ep_due = true; ep_par = cu.k & 1;
+                if (wave < 2) epv = ep_src[cu.g * 64 + lane];
+            }
+            const unsigned char *sbp = MORE ? stage_patch(cu) : nullptr, *sbw = MORE ? stage_weights(cu) : nullptr;
+            fetch(s & 1, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int slot = 0; slot < 36; ++slot) {
+                const int t = slot >> 2, q = slot & 3;
+                if (q == 0 && t + 1 < 9) fetch(s & 1, t + 1, (t + 1) & 1);
+                mfma3(t & 1, q);
+                if (MORE) {
+                    if (slot < 5) dma_piece_at(sbw, nb, slot);
+                    else if (slot < 11) dma_patch(sbp, nb, slot - 5);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (MORE) advance(cu);
+            end_of_stage();
+        };
+        for (int s = 0; s + 1 < total; ++s) iteration(s, std::true_type{});
+        iteration(total - 1, std::false_type{});
+    } else {
+        // ---- packed input through an Upsample: pooled pieces through registers, one stage ahead --------------------------------
+        // thread t < 408 = (octet o, pooled row r of 6, pooled column c of 34): pooled pixel (y0 / 2 - 1 + r, x0 / 2 - 1 + c),
+        // i.e. padded row y0 / 2 + r, padded column x0 / 2 + c; its window position (dy, dx) is patch pixel (2 r - 1 + dy, 2 c - 1 + dx)
+        const bool q_valid = tid < D_NQ;
+        const int qt = q_valid ? tid : 0;
+        const int q_o = qt / (D_QR * D_QC), q_rem = qt - q_o * (D_QR * D_QC), q_r = q_rem / D_QC, q_c = q_rem - q_r * D_QC;
+        const uint32_t q_voff = q_valid ? (uint32_t)((((q_o * 2) * a.in_Hp + q_r) * a.in_Wp + q_c) * 16) : D_INV;      // hi plane; lo: + one plane, in the scalar offset
+        const uint32_t q_moff = q_valid ? (uint32_t)(((q_o * a.in_Hp + q_r) * a.in_Wp + q_c) * 4) : D_INV;
+        uint32_t q_dst[4];          // LDS byte offset of window position k's piece inside a patch buffer's hi plane; q_ok bit k: it exists
+        uint32_t q_ok = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int py = 2 * q_r - 1 + (k >> 1), px = 2 * q_c - 1 + (k & 1);
+            const bool ok = q_valid && (unsigned)py < (unsigned)D_PR && (unsigned)px < (unsigned)D_PW;
+            q_dst[k] = ok ? (uint32_t)((q_o * D_NPX + py * D_PW + px) * 16) : 0u;
+            q_ok |= ok ? (1u << k) : 0u;
+        }
+        struct QSet { u32x4 hi, lo; uint32_t m; };
+        struct QPlan { i32x4 rs, mrs; uint32_t so_hi, so_lo, so_m; };
+        auto plan_q = [&](const Cursor &c, QPlan &lp) __attribute__((always_inline)) {
+            const int64_t pl = (int64_t)a.in_Hp * a.in_Wp;              // pooled pieces of one plane of one octet
+            const uint64_t base = (uint64_t)(uintptr_t)(static_cast<const unsigned char *>(a.in_pk) + (int64_t)c.n * a.in_pk_sample_bytes);
+            lp.rs = (i32x4){(int)(uint32_t)base, (int)(uint32_t)((base >> 32) & 0xffffu), (int)(a.Cin * pl * 4), 0x00020000};
+            const uint64_t mbase = (uint64_t)(uintptr_t)(a.unpool_bits + (int64_t)c.n * a.unpool_bits_stride);
+            lp.mrs = (i32x4){(int)(uint32_t)mbase, (int)(uint32_t)((mbase >> 32) & 0xffffu), (int)((a.Cin / 8) * pl * 4), 0x00020000};
+            const int64_t org = (int64_t)(c.ty * (D_TH / 2)) * a.in_Wp + c.tx * (D_TW / 2);
+            lp.so_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((int64_t)c.chunk * 4 * pl + org) * 16));
+            lp.so_lo = lp.so_hi + (uint32_t)__builtin_amdgcn_readfirstlane((int)(pl * 16));
+            lp.so_m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((int64_t)c.chunk * 2 * pl + org) * 4));
+        };
+        // load L (0 .. 2) of a stage: hi piece, lo piece, mask dword.  (s_nop 4: a scalar operand may come straight out of a
+        // v_readfirstlane, and nothing pads a VALU-written SGPR -> VMEM hazard inside an asm statement)
+        auto load_q = [&](const QPlan &lp, int L, QSet &qs) __attribute__((always_inline)) {
+            if (L == 0) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(qs.hi) : "v"(q_voff), "s"(lp.rs), "s"(lp.so_hi) : "memory");
+            else if (L == 1) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(qs.lo) : "v"(q_voff), "s"(lp.rs), "s"(lp.so_lo) : "memory");
+            else asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=&v"(qs.m) : "v"(q_moff), "s"(lp.mrs), "s"(lp.so_m) : "memory");
+        };
+        // (the wait is part of the statement that makes the registers readable: nothing can be scheduled between the two)
+        auto landed_q = [&](QSet &qs) __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(qs.hi), "+v"(qs.lo), "+v"(qs.m)::"memory"); };
+        // step 2 k + plane: window position k's piece of that plane = pooled piece & mask of the channels whose maximum sat at k
+        auto expand_step = [&](int buf, const QSet &qs, int step) __attribute__((always_inline)) {
+            const int k = step >> 1, plane = step & 1;
+            const uint32_t byte = (qs.m >> (8 * k)) & 0xffu;
+            const u32x4 msk = *reinterpret_cast<const u32x4 *>(lds_d + LUT0 + byte * 16);
+            if (q_ok & (1u << k)) {
+                const u32x4 v = plane == 0 ? qs.hi : qs.lo;
+                *reinterpret_cast<u32x4 *>(lds_d + buf * PB + plane * D_PLANE + q_dst[k]) = v & msk;
+            }
+        };
+        // the mask table: entry b = halves e of the piece are 0xffff where bit e of b is set
+        if (tid < 256) {
+            u32x4 e;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = (((uint32_t)tid >> (2 * j)) & 1u ? 0xffffu : 0u) | (((uint32_t)tid >> (2 * j + 1)) & 1u ? 0xffff0000u : 0u);
+            *reinterpret_cast<u32x4 *>(lds_d + LUT0 + tid * 16) = e;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        Cursor cu = cc;             // weight DMA and pooled loads, one stage ahead of the multiply
+        QSet qs;
+        bool ep_due = false;
+        int ep_par = 0;
+        QPlan lp;
+        // prologue: patch(0) -> LDS, weights(0) in flight
+        plan_q(cu, lp);
+#pragma unroll
+        for (int L = 0; L < 3; ++L) load_q(lp, L, qs);
+        if (wave < 2) { epv = ep_src[cu.g * 64 + lane]; }
+        ep_due = true; ep_par = 0;
+        {
+            const unsigned char *sbw = stage_weights(cu);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) dma_piece_at(sbw, 0, j);
+        }
+        advance(cu);
+        landed_q(qs);
+#pragma unroll
+        for (int st = 0; st < 8; ++st) expand_step(0, qs, st);
+        // Iteration s: slots 0-4 the weight DMA of stage s + 1, slots 5-7 its three pooled loads; slot 23 waits for everything this
+        // wave has in flight (the loads have had 16 slots of MFMAs to land; the DMA and an item's output stores are older), slots
+        // 24-31 expand the pieces into the other patch buffer.  ONE register set: the second one of the fp32 form (loads two
+        // stages ahead) bought SGPR spills here and nothing else — a pooled stage is 3 loads per lane, not 24.
+        auto iteration = [&](const int s, auto more_tag) __attribute__((always_inline)) {
+            constexpr bool MORE = decltype(more_tag)::value;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ep_due && wave < 2) reinterpret_cast<float *>(lds_d + EP0)[ep_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
+            ep_due = false;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (pend) { store_item(pn, pty, ptx, pg, ppar); pend = false; }
+            const int nb = (s + 1) & 1;
+            if (MORE) plan_q(cu, lp);
+            const unsigned char *sbw = MORE ? stage_weights(cu) : nullptr;
+            if (MORE && cu.chunk == 0) {
+                ep_due = true; ep_par = cu.k & 1;
+                if (wave < 2) epv = ep_src[cu.g * 64 + lane];
+            }
+            fetch(s & 1, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int slot = 0; slot < 36; ++slot) {
+                const int t = slot >> 2, q = slot & 3;
+                if (q == 0 && t + 1 < 9) fetch(s & 1, t + 1, (t + 1) & 1);
+                mfma3(t & 1, q);
+                if (MORE) {
+                    if (slot < 5) dma_piece_at(sbw, nb, slot);
+                    else if (slot < 8) load_q(lp, slot - 5, qs);
+                    else if (slot == 23) landed_q(qs);
+                    else if (slot >= 24 && slot < 32) expand_step(nb, qs, slot - 24);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (MORE) advance(cu);
+            end_of_stage();
+        };
+        for (int s = 0; s + 1 < total; ++s) iteration(s, std::true_type{});
+        iteration(total - 1, std::false_type{});
     }
     if (pend) store_item(pn, pty, ptx, pg, ppar);
     if (ovf > (0x477fe000u << 1)) atomicOr(a.h3_flag, 1u);          // !(|xs| <= 65504): a scaled input left the fp16 range (or was not finite)
@@ -533,14 +806,32 @@ float conv3_h3_pack_weights(const float *W, int cin, int cout, std::vector<uint1
     return scale;
 }
 
+// Which instantiation a launch takes: IN from the input form (a0.in_pk set: packed, with a0.unpool_bits through an Upsample;
+// else fp32, with a0.unpool_mask through an Upsample), OUT from a0.out_pk.
+template <int IN, bool OUT_PK>
+static void launch_d3_form(const ConvArgs &a, int form, dim3 grid, size_t lds, hipStream_t s) {
+    if constexpr (IN == IN_F32 || IN == IN_F32_UNPOOL) {
+        if (form == 0 && !OUT_PK) {
+            hipLaunchKernelGGL((conv3_h3_kernel<IN, false, 0>), grid, dim3(512), lds, s, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((conv3_h3_kernel<IN, OUT_PK, 1>), grid, dim3(512), lds, s, a);
+}
+
 void launch_conv3_h3(const ConvArgs &a0, hipStream_t s) {
-    const bool unpool = a0.unpool_mask != nullptr;
+    const bool pk_in = a0.in_pk != nullptr, pk_out = a0.out_pk != nullptr;
+    const bool unpool = pk_in ? a0.unpool_bits != nullptr : a0.unpool_mask != nullptr;
     if (!a0.wt_h3 || !(a0.h3_vscale > 0.f) || !a0.h3_flag || a0.drop_site >= 0 || a0.pool_out || a0.CoutPad != a0.Cout ||
         !conv3_h3_supported(3, a0.Cin, a0.Cout, a0.H, a0.W, unpool))
         throw std::invalid_argument("launch_conv3_h3: unsupported layer");
     static int attr_set[64] = {0};
     if (FirstUse once(attr_set); once) {
-        for (const void *f : {(const void *)conv3_h3_kernel<false, 0>, (const void *)conv3_h3_kernel<true, 0>, (const void *)conv3_h3_kernel<false, 1>, (const void *)conv3_h3_kernel<true, 1>})
+        for (const void *f : {(const void *)conv3_h3_kernel<IN_F32, false, 0>, (const void *)conv3_h3_kernel<IN_F32_UNPOOL, false, 0>,
+                              (const void *)conv3_h3_kernel<IN_F32, false, 1>, (const void *)conv3_h3_kernel<IN_F32_UNPOOL, false, 1>,
+                              (const void *)conv3_h3_kernel<IN_F32, true, 1>,
+                              (const void *)conv3_h3_kernel<IN_PK, false, 1>, (const void *)conv3_h3_kernel<IN_PK_UNPOOL, false, 1>,
+                              (const void *)conv3_h3_kernel<IN_PK, true, 1>, (const void *)conv3_h3_kernel<IN_PK_UNPOOL, true, 1>})
             SIVO_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
@@ -548,35 +839,47 @@ void launch_conv3_h3(const ConvArgs &a0, hipStream_t s) {
     ConvArgs a = a0;
     a.tiles_x = (a.W + D_TW - 1) / D_TW;
     a.tiles_y = (a.H + D_TH - 1) / D_TH;
+    // packed tensors: the zero border and the overhang of partial items must exist (see the file header)
+    if (pk_in) {
+        const int need_h = unpool ? a.tiles_y * (D_TH / 2) + 2 : a.tiles_y * D_TH + 2, need_w = unpool ? a.tiles_x * (D_TW / 2) + 2 : a.tiles_x * D_TW + 2;
+        if (a.in_Hp < need_h || a.in_Wp < need_w || (int64_t)a.Cin * a.in_Hp * a.in_Wp * 4 >= (1ll << 31))
+            throw std::invalid_argument("launch_conv3_h3: packed input plane too small for the layer's tiling");
+    }
+    if (pk_out && (a.out_Hp < a.H + 2 || a.out_Wp < a.W + 2 || !(a.out_vscale > 0.f) || (int64_t)a.Cout * a.out_Hp * a.out_Wp * 4 >= (1ll << 31)))
+        throw std::invalid_argument("launch_conv3_h3: packed output plane too small / no scale");
     // the whole LDS of the CU, as conv_wino4_h3.hip (no other workgroup beside a persistent one)
     const size_t lds = (size_t)160 * 1024;
-    // SIVO_D3_FORM=0: the phased stage loop (read at every launch: tests compare the two forms bit for bit)
+    // SIVO_D3_FORM=0: the phased stage loop of the fp32-input forms (read at every launch: tests compare the two forms bit for bit)
     const int form = std::getenv("SIVO_D3_FORM") && std::atoi(std::getenv("SIVO_D3_FORM")) == 0 ? 0 : 1;
 #ifdef SIVO_DIAG
     if (const char *ab = std::getenv("SIVO_D3_ABL")) {
 #define D3_ABL_CASE(n)                                                                                                                      \
     case n:                                                                                                                                 \
         if (form == 0) {                                                                                                                    \
-            SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_h3_kernel<false, 0, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            hipLaunchKernelGGL((conv3_h3_kernel<false, 0, n>), grid, dim3(512), lds, s, a);                                                 \
+            SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_h3_kernel<IN_F32, false, 0, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            hipLaunchKernelGGL((conv3_h3_kernel<IN_F32, false, 0, n>), grid, dim3(512), lds, s, a);                                         \
         } else {                                                                                                                            \
-            SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_h3_kernel<false, 1, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            hipLaunchKernelGGL((conv3_h3_kernel<false, 1, n>), grid, dim3(512), lds, s, a);                                                 \
+            SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_h3_kernel<IN_F32, false, 1, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            hipLaunchKernelGGL((conv3_h3_kernel<IN_F32, false, 1, n>), grid, dim3(512), lds, s, a);                                         \
         }                                                                                                                                   \
         return;
-        if (!unpool) switch (std::atoi(ab)) {
+        if (!unpool && !pk_in && !pk_out) switch (std::atoi(ab)) {
             D3_ABL_CASE(1) D3_ABL_CASE(2) D3_ABL_CASE(3) D3_ABL_CASE(4) D3_ABL_CASE(8) D3_ABL_CASE(16) D3_ABL_CASE(19) D3_ABL_CASE(23) D3_ABL_CASE(64) D3_ABL_CASE(65) D3_ABL_CASE(68)
             default: break;
         }
 #undef D3_ABL_CASE
     }
 #endif
-    if (form == 0) {
-        if (unpool) hipLaunchKernelGGL((conv3_h3_kernel<true, 0>), grid, dim3(512), lds, s, a);
-        else hipLaunchKernelGGL((conv3_h3_kernel<false, 0>), grid, dim3(512), lds, s, a);
-    } else {
-        if (unpool) hipLaunchKernelGGL((conv3_h3_kernel<true, 1>), grid, dim3(512), lds, s, a);
-        else hipLaunchKernelGGL((conv3_h3_kernel<false, 1>), grid, dim3(512), lds, s, a);
+    const int in = pk_in ? (unpool ? IN_PK_UNPOOL : IN_PK) : (unpool ? IN_F32_UNPOOL : IN_F32);
+    switch (in * 2 + (pk_out ? 1 : 0)) {
+        case 0: launch_d3_form<IN_F32, false>(a, form, grid, lds, s); break;
+        case 1: launch_d3_form<IN_F32, true>(a, form, grid, lds, s); break;
+        case 2: launch_d3_form<IN_F32_UNPOOL, false>(a, form, grid, lds, s); break;
+        case 3: throw std::invalid_argument("launch_conv3_h3: fp32 input through an Upsample with packed output is not built (it spills)");
+        case 4: launch_d3_form<IN_PK, false>(a, form, grid, lds, s); break;
+        case 5: launch_d3_form<IN_PK, true>(a, form, grid, lds, s); break;
+        case 6: launch_d3_form<IN_PK_UNPOOL, false>(a, form, grid, lds, s); break;
+        default: launch_d3_form<IN_PK_UNPOOL, true>(a, form, grid, lds, s); break;
     }
 }
 

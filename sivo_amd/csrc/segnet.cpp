@@ -42,6 +42,18 @@ struct Blob {
     int src_W = 0;         // masks: width of the pooled input plane (for index reconstruction)
     void *d = nullptr;
     bool fused_away = false;   // an Upsample output read straight through its pooled input by the next convolution
+    // Packed form (conv3_h3.hip / pk_format.hip): the blob between two direct f16x3 layers as fp16 hi / lo pieces in zero-bordered
+    // (pk_Hp, pk_Wp) planes, times the consumer's power of two.  pk_fresh: the last forward wrote ONLY this form (the fp32 array
+    // is stale; sivo_segnet_blob unpacks).  Masks: d_bits = the window codes re-laid per channel octet for a consumer that
+    // reads a packed pooled tensor through its Upsample (planes padded like that tensor's).
+    void *d_pk = nullptr;
+    int pk_Hp = 0, pk_Wp = 0;
+    bool pk_fresh = false;
+    float pk_scale = 0.f;
+    uint32_t *d_bits = nullptr;
+    int bits_Hp = 0, bits_Wp = 0;
+    int64_t pk_sample_bytes() const { return (int64_t)(C / 8) * 2 * pk_Hp * pk_Wp * 16; }
+    int64_t bits_sample_dwords() const { return (int64_t)(C / 8) * bits_Hp * bits_Wp; }
     int64_t chw() const { return (int64_t)C * H * W; }
 };
 
@@ -64,6 +76,10 @@ struct Op {
     bool d3 = false;
     void *d_wd3 = nullptr;     // Caffe weights as fp16 hi / lo planes times d3_uscale, in the kernel's stage order
     float d3_uscale = 1.f, d3_vscale = 0.f, d3_vmax = 0.f;   // d3_vscale: power of two for the INPUT ACTIVATION (calibrated; 0 = not yet)
+    // packed activations between direct f16x3 layers (decided at plan time, used while the handle runs f16x3):
+    bool pk_in = false;        // this d3 layer reads its input (through its Upsample, if any) in the packed form
+    int pk_to = -1;            // producer side: the d3 op that reads this layer's output in the packed form (its d3_vscale is the scale)
+    bool make_bits = false;    // pooling: a packed consumer reads through this pooling's switches -> also write them per channel octet
     int bridge_to = -1;        // w4_bridge: the op whose transformed input this layer's bridge kernel writes
     float *d_w_mc = nullptr;   // classifier: second copy of the weights in the layout of conv_cls_mc.hip (fused with the MC post-processing)
     bool mc_fused_last = false;   // profiling: the last timed launch of this op was the fused kernel
@@ -130,6 +146,7 @@ struct sivo_segnet {
     // the f16x3 GEMM; cleared for good when a frame raised the overflow flag (a transformed value left the fp16 range: the
     // bf16x6 GEMM has fp32's range).  h3_flag: one word of pinned host memory the transform kernels store 1 into.
     bool h3_on = false, calibrating = false;
+    bool pk_on = true;              // packed activations between direct f16x3 layers (SIVO_D3_PK=0 at construction: fp32 blobs everywhere)
     volatile uint32_t *h3_flag = nullptr;
     uint32_t *d_h3_vmax = nullptr;  // calibration: one word per op (bit pattern of the largest |V|)
     int h3_overflow_frames = 0;     // frames that raised the flag (each was recomputed on the bf16x6 path when the entry point is synchronous)
@@ -548,12 +565,65 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             S.cls_op = (int)S.ops.size() - 1;
         }
     }
+    // Direct f16x3 layer <- direct f16x3 layer (or an F(4x4) layer's output transform): the activation in between goes in the
+    // consumer's packed form (conv3_h3.hip header).  The fp32 blob stays allocated: the calibration pass and every frame after
+    // an fp16 overflow run the fp32 kernels.  SIVO_D3_PK=0 disables (read per handle: the tests build both).
+    S.pk_on = !(std::getenv("SIVO_D3_PK") && std::atoi(std::getenv("SIVO_D3_PK")) == 0);
+    if (S.pk_on)
+        for (size_t bi_ = 0; bi_ < S.ops.size(); ++bi_) {
+            Op &B = S.ops[bi_];
+            if (B.kind != OP_CONV || !B.d3 || B.skip || B.drop_site >= 0 || B.pool_op >= 0) continue;
+            const bool unpool = B.unpool_in >= 0;
+            const int X = unpool ? B.unpool_in : B.in;
+            if (X == S.input_blob || X == S.logits_blob || S.blobs[X].fused_away || S.blobs[X].C % 16) continue;
+            int uses = 0, ai = -1, pi = -1;
+            for (size_t k = 0; k < S.ops.size(); ++k) {
+                const Op &c = S.ops[k];
+                if (c.out == X && !c.skip) ai = (int)k;
+                if (c.skip) continue;
+                if ((c.in == X && c.unpool_in < 0) || c.in2 == X || c.unpool_in == X) ++uses;
+                if (unpool && c.kind == OP_POOL && c.out2 == B.unpool_mask) pi = (int)k;
+            }
+            if (uses != 1 || ai < 0 || (unpool && pi < 0)) continue;
+            Op &A = S.ops[ai];
+            if (A.kind != OP_CONV || A.pool_op >= 0 || A.w4_bridge) continue;
+            // (a direct producer must itself run whenever the handle runs f16x3 — the conditions of d3_now in run_ops —, and fp32
+            // through an Upsample + packed output is not built)
+            const bool a_direct = A.d3 && A.drop_site < 0 && !(A.unpool_in >= 0 && !A.pk_in) &&
+                                  conv3_h3_supported(A.ks, A.cin, A.cout, S.blobs[A.in].H, S.blobs[A.in].W, A.unpool_in >= 0);
+            if (!a_direct && !A.wino4) continue;
+            const Blob &bin = S.blobs[B.in];                       // the layer's input geometry (the Upsample's output when it reads through one)
+            if (!conv3_h3_supported(B.ks, B.cin, B.cout, bin.H, bin.W, unpool)) continue;
+            const int tx = (bin.W + 63) / 64, ty = (bin.H + 7) / 8;
+            Blob &bx = S.blobs[X];
+            bx.pk_Hp = (unpool ? ty * 4 : ty * 8) + 2; bx.pk_Wp = (unpool ? tx * 32 : tx * 64) + 2;
+            if (bx.pk_Hp < bx.H + 2 || bx.pk_Wp < bx.W + 2 || (int64_t)bx.C * bx.pk_Hp * bx.pk_Wp * 4 >= (1ll << 31)) { bx.pk_Hp = bx.pk_Wp = 0; continue; }
+            if (unpool) {
+                Blob &bm = S.blobs[B.unpool_mask];
+                bm.bits_Hp = bx.pk_Hp; bm.bits_Wp = bx.pk_Wp;
+                S.ops[pi].make_bits = true;
+            }
+            B.pk_in = true;
+            A.pk_to = (int)bi_;
+        }
     // allocate
     for (Blob &b : S.blobs) {
         if (b.fused_away) continue;
         const size_t n = (size_t)(b.shared ? 1 : S.T) * b.chw();
         b.d = b.is_mask ? (void *)dev_alloc<uint8_t>(n) : (void *)dev_alloc<float>(n);
         S.owned.push_back(b.d);
+        if (b.pk_Hp) {          // zeroed once: producers write the interior only, the border stays zero for good
+            const size_t nb = pk_bytes(b.shared ? 1 : S.T, b.C, b.pk_Hp, b.pk_Wp);
+            SIVO_HIP(hipMalloc(&b.d_pk, nb));
+            S.owned.push_back(b.d_pk);
+            SIVO_HIP(hipMemset(b.d_pk, 0, nb));
+        }
+        if (b.bits_Hp) {
+            const size_t nd = (size_t)(b.shared ? 1 : S.T) * b.bits_sample_dwords();
+            b.d_bits = dev_alloc<uint32_t>(nd);
+            S.owned.push_back(b.d_bits);
+            SIVO_HIP(hipMemset(b.d_bits, 0, nd * sizeof(uint32_t)));
+        }
     }
     if (S.wino4_ws_floats) {
         const int env_lanes = std::getenv("SIVO_LANES") ? std::atoi(std::getenv("SIVO_LANES")) : 3;
@@ -733,6 +803,12 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                 }
                 const bool d3_now = op.d3 && S.h3_on && !S.calibrating && op.d3_vscale > 0.f && a.drop_site < 0 && !a.pool_out &&
                                     conv3_h3_supported(op.ks, op.cin, op.cout, a.H, a.W, a.unpool_mask != nullptr);
+                // packed links (decided at plan time from static conditions only) are live while the handle runs f16x3
+                const bool pk_live = S.pk_on && S.h3_on && !S.calibrating;
+                const bool pk_out_now = pk_live && op.pk_to >= 0;
+                if (pk_live && (op.pk_in || (op.pk_to >= 0 && !op.wino4)) && !d3_now)
+                    throw std::runtime_error("layer '" + op.name + "': planned for packed activations but not running its f16x3 kernel");
+                Blob &bo_w = S.blobs[op.out];
                 if (op.d3 && S.calibrating && S.d_h3_vmax) {
                     // the layer's largest |input| (the pooled tensor holds the same values as its Upsample)
                     const int64_t plane_in = a.unpool_mask ? (int64_t)(a.H / 2) * (a.W / 2) : (int64_t)a.H * a.W;
@@ -742,6 +818,25 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                     ConvArgs b = a;
                     b.wt_h3 = op.d_wd3; b.h3_vscale = op.d3_vscale; b.h3_uscale = op.d3_uscale; b.h3_flag = const_cast<uint32_t *>(S.h3_flag);
                     b.CoutPad = op.cout;
+                    if (op.pk_in && pk_live) {
+                        // the producer wrote the packed form this frame (the same condition on its side): read it
+                        const Blob &bx = S.blobs[op.unpool_in >= 0 ? op.unpool_in : op.in];
+                        b.in_pk = static_cast<unsigned char *>(bx.d_pk) + (bx.shared ? 0 : (int64_t)n0 * bx.pk_sample_bytes());
+                        b.in_pk_sample_bytes = bx.shared ? 0 : bx.pk_sample_bytes();
+                        b.in_Hp = bx.pk_Hp; b.in_Wp = bx.pk_Wp;
+                        if (op.unpool_in >= 0) {
+                            const Blob &bm = S.blobs[op.unpool_mask];
+                            b.unpool_bits = bm.d_bits + (bm.shared ? 0 : (int64_t)n0 * bm.bits_sample_dwords());
+                            b.unpool_bits_stride = bm.shared ? 0 : bm.bits_sample_dwords();
+                        }
+                    }
+                    if (pk_out_now) {
+                        b.out_pk = static_cast<unsigned char *>(bo_w.d_pk) + (bo_w.shared ? 0 : (int64_t)n0 * bo_w.pk_sample_bytes());
+                        b.out_Hp = bo_w.pk_Hp; b.out_Wp = bo_w.pk_Wp; b.out_vscale = S.ops[op.pk_to].d3_vscale;
+                        bo_w.pk_fresh = true; bo_w.pk_scale = b.out_vscale;
+                    } else {
+                        bo_w.pk_fresh = false;
+                    }
                     launch_conv3_h3(b, st);
                 } else if (op.wino4f) {
                     static const bool epi4 = !(std::getenv("SIVO_W4F_EPI") && std::atoi(std::getenv("SIVO_W4F_EPI")) == 0);
@@ -777,11 +872,19 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                         }
                     }
                     launch_conv_wino4(a, ws, op.wino4_group, st, sub, S.profile_mfma_only, planned ? &plan : nullptr);
+                    if (pk_out_now) {
+                        // the F(4x4) output transform writes fp32; the next layer (direct f16x3) reads the packed form
+                        launch_pk_pack(a.out, bo_w.chw(), static_cast<unsigned char *>(bo_w.d_pk) + (bo_w.shared ? 0 : (int64_t)n0 * bo_w.pk_sample_bytes()), N, bo_w.C,
+                                       bo_w.H, bo_w.W, bo_w.pk_Hp, bo_w.pk_Wp, S.ops[op.pk_to].d3_vscale, const_cast<uint32_t *>(S.h3_flag), st);
+                        bo_w.pk_scale = S.ops[op.pk_to].d3_vscale;
+                    }
+                    bo_w.pk_fresh = false;
                 }
                 else if (op.c7x6) launch_conv7_x6(a, st);
                 else if (op.wino) launch_conv_wino(a, op.wino_cfg, st);
                 else if (op.v2) launch_conv2(a, op.ks, st);
                 else launch_conv(a, op.ks, st);
+                if (!d3_now) bo_w.pk_fresh = false;
                 break;
             }
             case OP_POOL: {
@@ -792,6 +895,10 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                 a.N = N; a.C = bi.C; a.H = bi.H; a.W = bi.W; a.Ho = bo.H; a.Wo = bo.W;
                 a.drop_site = op.drop_site; a.sample0 = sample0; a.seed = seed;
                 launch_maxpool2(a, st);
+                if (op.make_bits && S.pk_on && S.h3_on && !S.calibrating) {
+                    const Blob &bm = S.blobs[op.out2];
+                    launch_pool_bits(a.mask, bm.d_bits + (bm.shared ? 0 : (int64_t)n0 * bm.bits_sample_dwords()), a.mask_N, bi.C, bo.H, bo.W, bm.bits_Hp, bm.bits_Wp, st);
+                }
                 break;
             }
             case OP_UNPOOL: {
@@ -1213,6 +1320,12 @@ extern "C" int sivo_segnet_blob(sivo_segnet_t h, const char *name, float *host_o
             launch_mask_to_index((const uint8_t *)b.d, tmp, (int64_t)n, b.H, b.W, b.src_W, nullptr);
             SIVO_HIP(hipMemcpy(host_out, tmp, n * sizeof(float), hipMemcpyDeviceToHost));
             SIVO_HIP(hipFree(tmp));
+        } else if (b.pk_fresh) {
+            // the last forward wrote this blob in its packed form only: (hi + lo) / scale, exact to 2^-22 of the fp32 value
+            float *tmp = dev_alloc<float>(n);
+            launch_pk_unpack(b.d_pk, tmp, N, b.C, b.H, b.W, b.pk_Hp, b.pk_Wp, b.pk_scale, nullptr);
+            SIVO_HIP(hipMemcpy(host_out, tmp, n * sizeof(float), hipMemcpyDeviceToHost));
+            SIVO_HIP(hipFree(tmp));
         } else {
             SIVO_HIP(hipMemcpy(host_out, b.d, n * sizeof(float), hipMemcpyDeviceToHost));
         }
@@ -1331,177 +1444,6 @@ extern "C" int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow
         if (mode) *mode = (h->h3_on && any_h3) ? 2 : any_x6 ? 1 : 0;
         if (overflow_frames) *overflow_frames = h->h3_overflow_frames;
         if (n_layers) *n_layers = rows;
-        return SIVO_OK;
-    });
-}
-
-// Diagnostic / test: the f16x3 GEMM alone.  V [36][C][Pp] and U [36][C][Kp] fp32 on the host (Pp = P rounded up to 128),
-// M [36][Kp][Pp] out; V is packed with vscale, U with the scale wino4_h3_pack_weights chooses, M is scaled back.  iters > 0:
-// mean launch time in *ms_out.
-extern "C" int sivo_debug_h3_gemm(int C, int Kp, int P, const float *V, const float *U, float vscale, float *M, int iters, double *ms_out) {
-    return guarded([&] {
-        if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device");
-        if (!V || !U || !M || !wino4_h3_supported(C, Kp) || P < 1 || !(vscale > 0.f)) throw std::invalid_argument("bad argument");
-        const int64_t Pp = ((int64_t)P + 127) / 128 * 128;
-        const size_t nv = (size_t)36 * C * Pp, nm = (size_t)36 * Kp * Pp;
-        std::vector<uint32_t> vp(nv);
-        for (size_t i = 0; i < nv; ++i) vp[i] = wino4_h3_pack_value(V[i], vscale);
-        std::vector<uint16_t> planes;
-        const float uscale = wino4_h3_pack_weights(std::vector<float>(U, U + (size_t)36 * C * Kp), C, Kp, planes);
-        uint32_t *dv = dev_alloc<uint32_t>(nv);
-        uint16_t *du = dev_alloc<uint16_t>(planes.size());
-        float *dm = dev_alloc<float>(nm);
-        SIVO_HIP(hipMemcpy(dv, vp.data(), nv * 4, hipMemcpyHostToDevice));
-        SIVO_HIP(hipMemcpy(du, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
-        SIVO_HIP(hipMemset(dm, 0xff, nm * 4));
-        launch_wino4_gemm_h3(dv, du, dm, C, Kp, P, (int)Pp, nullptr);
-        SIVO_HIP(hipDeviceSynchronize());
-        if (iters > 0 && ms_out) {
-            hipEvent_t e0, e1;
-            SIVO_HIP(hipEventCreate(&e0)); SIVO_HIP(hipEventCreate(&e1));
-            SIVO_HIP(hipEventRecord(e0, nullptr));
-            for (int i = 0; i < iters; ++i) launch_wino4_gemm_h3(dv, du, dm, C, Kp, P, (int)Pp, nullptr);
-            SIVO_HIP(hipEventRecord(e1, nullptr));
-            SIVO_HIP(hipEventSynchronize(e1));
-            float ms = 0;
-            SIVO_HIP(hipEventElapsedTime(&ms, e0, e1));
-            *ms_out = ms / iters;
-            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        }
-        std::vector<float> hm(nm);
-        SIVO_HIP(hipMemcpy(hm.data(), dm, nm * 4, hipMemcpyDeviceToHost));
-        const float inv = 1.f / (vscale * uscale);
-        for (size_t i = 0; i < nm; ++i) M[i] = hm[i] * inv;
-        (void)hipFree(dv); (void)hipFree(du); (void)hipFree(dm);
-        return SIVO_OK;
-    });
-}
-
-// Diagnostic / test: the direct f16x3 3x3 convolution (conv3_h3.hip) alone.  d_in / d_mask / d_out are device pointers
-// (d_mask null: d_in is (N, Cin, H, W); else d_in is the pooled tensor (N, Cin, H/2, W/2) and d_mask its window codes), the
-// weights (Caffe layout) and the per-channel affine are host arrays.
-extern "C" int sivo_debug_conv3_h3_dev(int N, int Cin, int Cout, int H, int W, const float *d_in, const uint8_t *d_mask,
-                                       const float *Wt, const float *scale, const float *shift, int relu, float vscale,
-                                       float *d_out, int iters, double *ms_out, int *overflowed) {
-    return guarded([&] {
-        if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device");
-        if (!d_in || !Wt || !scale || !shift || !d_out || N < 1 || !(vscale > 0.f) || !conv3_h3_supported(3, Cin, Cout, H, W, d_mask != nullptr))
-            throw std::invalid_argument("sivo_debug_conv3_h3_dev: bad argument / unsupported shape");
-        std::vector<uint16_t> planes;
-        const float uscale = conv3_h3_pack_weights(Wt, Cin, Cout, planes);
-        uint16_t *du = dev_alloc<uint16_t>(planes.size());
-        float *dsc = dev_alloc<float>(Cout), *dsh = dev_alloc<float>(Cout);
-        uint32_t *flag = nullptr;
-        SIVO_HIP(hipHostMalloc((void **)&flag, 64, hipHostMallocDefault));
-        *flag = 0;
-        SIVO_HIP(hipMemcpy(du, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
-        SIVO_HIP(hipMemcpy(dsc, scale, Cout * 4, hipMemcpyHostToDevice));
-        SIVO_HIP(hipMemcpy(dsh, shift, Cout * 4, hipMemcpyHostToDevice));
-        ConvArgs a{};
-        const int64_t plane_in = d_mask ? (int64_t)(H / 2) * (W / 2) : (int64_t)H * W;
-        a.in = d_in; a.in_sample_stride = (int64_t)Cin * plane_in; a.ep_scale = dsc; a.ep_shift = dsh; a.out = d_out;
-        a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.CoutPad = Cout; a.relu = relu; a.drop_site = -1;
-        a.unpool_mask = d_mask; a.unpool_mask_stride = d_mask ? (int64_t)Cin * plane_in : 0;
-        a.wt_h3 = du; a.h3_vscale = vscale; a.h3_uscale = uscale; a.h3_flag = flag;
-        uint32_t *stamps = nullptr;         // diagnostic build + SIVO_D3_STAMPS=1: cycle sums of the kernel's ABL & 64 form
-        if (std::getenv("SIVO_D3_STAMPS")) {
-            stamps = dev_alloc<uint32_t>(8);
-            SIVO_HIP(hipMemset(stamps, 0, 32));
-            a.vmax = stamps;
-        }
-        launch_conv3_h3(a, nullptr);
-        SIVO_HIP(hipDeviceSynchronize());
-        auto report = [&](const char *what) {
-            if (!stamps) return;
-            uint32_t h[8];
-            SIVO_HIP(hipMemcpy(h, stamps, 32, hipMemcpyDeviceToHost));
-            if (h[4]) std::fprintf(stderr, "d3 stamps, %s (cycles per wave and stage): wait %.0f barrier %.0f output %.0f multiply %.0f; longest wave %u cycles; %u wave-stages\n",
-                                   what, 16.0 * h[0] / h[4], 16.0 * h[1] / h[4], 16.0 * h[2] / h[4], 16.0 * h[3] / h[4], h[5], h[4]);
-            SIVO_HIP(hipMemset(stamps, 0, 32));
-        };
-        report("first launch");
-        if (iters > 0 && ms_out) {
-            hipEvent_t e0, e1;
-            SIVO_HIP(hipEventCreate(&e0)); SIVO_HIP(hipEventCreate(&e1));
-            SIVO_HIP(hipEventRecord(e0, nullptr));
-            for (int i = 0; i < iters; ++i) launch_conv3_h3(a, nullptr);
-            SIVO_HIP(hipEventRecord(e1, nullptr));
-            SIVO_HIP(hipEventSynchronize(e1));
-            float ms = 0;
-            SIVO_HIP(hipEventElapsedTime(&ms, e0, e1));
-            *ms_out = ms / iters;
-            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-            report("timed launches");
-        }
-        if (overflowed) *overflowed = (int)*flag;
-        (void)hipFree(du); (void)hipFree(dsc); (void)hipFree(dsh); (void)hipHostFree(flag); (void)hipFree(stamps);
-        return SIVO_OK;
-    });
-}
-
-// Diagnostic: time one convolution shape in isolation (random data), `variant` switches parts of
-// the kernel off (see ConvArgs::variant).  Returns the mean launch time in ms.
-extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, int iters, int variant, double *ms_out) {
-    return guarded([&] {
-        if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device");
-        const bool c7x6 = (variant & 65536) && conv7_x6_supported(ks, Cin, Cout, H, W);
-        const bool wino4f = (variant & 1024) && wino4f_supported(ks, Cin, Cout, H, W);
-        const bool wino4 = !wino4f && (variant & 512) && wino4_supported(ks, Cin, Cout, H, W);
-        const bool wino = !wino4 && !wino4f && (variant & 64) && wino_supported(ks, Cin, Cout, H, W);
-        const int wcfg = (variant & 128) ? ((variant & 32) ? 2 : 1) : 0;
-        const bool v2 = !wino && (variant & 16) && conv2_supported(ks);
-        const int KC = v2 ? 4 : conv_k_chunk(ks, Cin), BN = conv_cout_tile(ks, Cout);
-        const int cout_pad = cdiv(Cout, BN) * BN, nchunks = cdiv(Cin, KC);
-        const size_t nin = (size_t)N * Cin * H * W, nout = (size_t)N * Cout * H * W;
-        const int w4group = wino4 ? wino4_group(N, Cin, Cout, H, W, (size_t)(std::getenv("SIVO_WINO4_MB") ? std::atoi(std::getenv("SIVO_WINO4_MB")) : 16384) << 20) : 0;
-        const size_t nw = wino4f ? (size_t)((Cin + 3) / 4) * (Cout / 64) * wino4f_slab_floats() : wino4 ? (size_t)36 * Cin * wino4_cout_pad(Cout) : wino ? (size_t)wino_chunks(wcfg, Cin) * (Cout / wino_cout_tile(wcfg)) * wino_slab_floats(wcfg) : v2 ? (size_t)nchunks * (cout_pad / BN) * conv2_slab_floats(ks, Cout) : (size_t)nchunks * ks * ks * KC * cout_pad;
-        std::vector<float> hin(nin), hw(nw), hs(Cout, 1.f);
-        uint32_t st = 12345;
-        auto rnd = [&] { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
-        for (auto &v : hin) v = rnd();
-        for (auto &v : hw) v = rnd() * 0.05f;
-        float *din = dev_alloc<float>(nin), *dout = dev_alloc<float>(nout), *dw = dev_alloc<float>(nw), *ds = dev_alloc<float>(Cout);
-        SIVO_HIP(hipMemcpy(din, hin.data(), nin * 4, hipMemcpyHostToDevice));
-        SIVO_HIP(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
-        SIVO_HIP(hipMemcpy(ds, hs.data(), Cout * 4, hipMemcpyHostToDevice));
-        ConvArgs a{};
-        a.in = din; a.in_sample_stride = (int64_t)Cin * H * W; a.wt = dw; a.ep_scale = ds; a.ep_shift = ds; a.out = dout;
-        a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.CoutPad = cout_pad; a.relu = 1; a.drop_site = -1; a.variant = variant;
-        hipEvent_t e0, e1;
-        SIVO_HIP(hipEventCreate(&e0)); SIVO_HIP(hipEventCreate(&e1));
-        float *dws = wino4 ? dev_alloc<float>(wino4_workspace_floats(w4group, Cin, Cout, H, W)) : nullptr;
-        if (wino4) a.CoutPad = wino4_cout_pad(Cout);
-        void *dx6 = nullptr;
-        if (wino4 && (variant & 2048) && wino4_x6_supported(Cin, a.CoutPad)) {      // bf16x6 GEMM on the same (random) U
-            std::vector<uint16_t> planes;
-            wino4_x6_pack_weights(hw, Cin, a.CoutPad, planes);
-            dx6 = dev_alloc<uint16_t>(planes.size());
-            SIVO_HIP(hipMemcpy(dx6, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
-            a.wt_x6 = dx6;
-        }
-        if (wino4f) a.CoutPad = Cout;
-        void *d7 = nullptr;
-        if (c7x6) {
-            std::vector<float> w7((size_t)Cout * Cin * 49);
-            for (auto &v : w7) v = rnd() * 0.05f;
-            std::vector<uint16_t> planes;
-            conv7_x6_pack_weights(w7.data(), Cin, Cout, planes);
-            d7 = dev_alloc<uint16_t>(planes.size());
-            SIVO_HIP(hipMemcpy(d7, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
-            a.wt_x6 = d7;
-        }
-        auto go = [&] { if (c7x6) launch_conv7_x6(a, nullptr); else if (wino4f) launch_conv_wino4f(a, nullptr); else if (wino4) launch_conv_wino4(a, dws, w4group, nullptr); else if (wino) launch_conv_wino(a, wcfg, nullptr); else if (v2) launch_conv2(a, ks, nullptr); else launch_conv(a, ks, nullptr); };
-        if (wino) a.CoutPad = Cout;
-        for (int i = 0; i < 2; ++i) go();
-        SIVO_HIP(hipEventRecord(e0, nullptr));
-        for (int i = 0; i < iters; ++i) go();
-        SIVO_HIP(hipEventRecord(e1, nullptr));
-        SIVO_HIP(hipEventSynchronize(e1));
-        float ms = 0;
-        SIVO_HIP(hipEventElapsedTime(&ms, e0, e1));
-        *ms_out = ms / iters;
-        (void)hipFree(din); (void)hipFree(dout); (void)hipFree(dw); (void)hipFree(ds); (void)hipFree(dws); (void)hipFree(dx6); (void)hipFree(d7);
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         return SIVO_OK;
     });
 }

@@ -38,6 +38,19 @@ struct ConvArgs {
     float h3_vscale = 0.f, h3_uscale = 1.f;
     uint32_t *h3_flag = nullptr;
     uint32_t *vmax = nullptr;
+    // conv3_h3.hip, packed activations: fp16 hi / lo planes [N][C / 8][plane][Hp][Wp][8], the image at rows / columns 1.. of a
+    // zero-bordered (Hp, Wp) plane, values times the CONSUMER's power of two (pk_format.hip packs / unpacks).
+    //   in_pk: this layer's input in that form (scaled by h3_vscale); with unpool_bits the POOLED tensor the layer reads through
+    //          an Upsample, unpool_bits = [C / 8][Hp][Wp] dwords, byte k = channels whose maximum sat at window position k
+    //   out_pk: write the output in that form for the next layer (times out_vscale) instead of `out`
+    const void *in_pk = nullptr;
+    int64_t in_pk_sample_bytes = 0;        // 0 when the input is shared by all samples
+    int in_Hp = 0, in_Wp = 0;
+    const uint32_t *unpool_bits = nullptr;
+    int64_t unpool_bits_stride = 0;        // dwords per sample; 0 when shared
+    void *out_pk = nullptr;
+    int out_Hp = 0, out_Wp = 0;
+    float out_vscale = 0.f;
     int variant;               // diagnostics only (sivo_debug_conv): bit0 no epilogue stores, bit1 no LDS commit, bit2 no global loads
 };
 int conv_cout_tile(int ks, int cout);  // BN the launcher will pick (CoutPad must be a multiple)
@@ -76,6 +89,14 @@ bool conv3_h3_supported(int ks, int cin, int cout, int H, int W, bool unpool);
 float conv3_h3_pack_weights(const float *W, int cin, int cout, std::vector<uint16_t> &out);      // returns the scale applied
 void launch_conv3_h3(const ConvArgs &a, hipStream_t s);
 void launch_absmax(const float *x, int64_t n, uint32_t *out_bits, hipStream_t s);                 // atomicMax of the bit pattern of |x|
+// packed activation format of conv3_h3.hip (pk_format.hip).  Planes are (Hp, Wp) with the image at [1 .. H][1 .. W]; the
+// border is never written (allocate zeroed).
+size_t pk_bytes(int N, int C, int Hp, int Wp);
+void launch_pk_pack(const float *in, int64_t in_sample_stride, void *out, int N, int C, int H, int W, int Hp, int Wp, float scale,
+                    uint32_t *h3_flag, hipStream_t s);                                            // fp32 NCHW -> packed (x * scale split as fp16 hi + lo)
+void launch_pk_unpack(const void *in, float *out, int N, int C, int H, int W, int Hp, int Wp, float scale, hipStream_t s);   // (hi + lo) / scale
+// window codes [N][C][Hq][Wq] (u8, dy * 2 + dx) -> [N][C / 8][Hp][Wp] dwords: byte k, bit e = channel 8 o + e has code k
+void launch_pool_bits(const uint8_t *codes, uint32_t *bits, int N, int C, int Hq, int Wq, int Hp, int Wp, hipStream_t s);
 // direct 7x7, 64 -> 64, on the bf16 matrix cores with fp32 operands as three bf16 planes (conv7_x6.hip); weights in ConvArgs::wt_x6
 bool conv7_x6_supported(int ks, int cin, int cout, int H, int W);
 void conv7_x6_pack_weights(const float *W, int cin, int cout, std::vector<uint16_t> &out);

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import check, lib
+from ._lib import check, dbg, lib
 
 # bayesian_segnet.hpp:67-83
 CLASSES = ["ROAD", "SIDEWALK", "BUILDING", "WALL", "POLE", "TRAFFIC_LIGHT", "TRAFFIC_SIGN", "VEGETATION",
@@ -188,7 +188,7 @@ def h3_gemm(V, U, P, vscale=None, iters=0):
         vscale = float(2.0 ** (8 - np.frexp(float(np.abs(V).max()))[1]))
     M = np.empty((36, Kp, Pp), np.float32)
     ms = C.c_double(0)
-    check(lib().sivo_debug_h3_gemm(Cc, Kp, P, V.ctypes.data_as(C.c_void_p), U.ctypes.data_as(C.c_void_p), C.c_float(vscale),
+    check(dbg().sivo_debug_h3_gemm(Cc, Kp, P, V.ctypes.data_as(C.c_void_p), U.ctypes.data_as(C.c_void_p), C.c_float(vscale),
                                    M.ctypes.data_as(C.c_void_p), iters, C.byref(ms)))
     return M, (ms.value if iters else None)
 
@@ -212,11 +212,40 @@ def conv3_h3(x, weight, scale, shift, relu=True, mask=None, vscale=None, iters=0
     out = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device)
     ms = C.c_double(0)
     ov = C.c_int(0)
-    check(lib().sivo_debug_conv3_h3_dev(N, Cin, Cout, H, W, x.data_ptr(), mask.data_ptr() if mask is not None else None,
+    check(dbg().sivo_debug_conv3_h3_dev(N, Cin, Cout, H, W, x.data_ptr(), mask.data_ptr() if mask is not None else None,
                                         weight.ctypes.data_as(C.c_void_p), scale.ctypes.data_as(C.c_void_p),
                                         shift.ctypes.data_as(C.c_void_p), int(relu), C.c_float(vscale), out.data_ptr(), iters,
                                         C.byref(ms), C.byref(ov)))
     return out, (ms.value if iters else None), bool(ov.value)
+
+
+def conv3_h3_pk(x, weight, scale, shift, relu=True, mask=None, vscale=None, out_vscale=None, pk_in=True, pk_out=False, extra_pad=False,
+                iters=0):
+    """The direct f16x3 convolution with packed activations (sivo_debug_conv3_h3_pk_dev): as conv3_h3, but the input is packed
+    on the device first (pk_in; through an Upsample: the pooled tensor + the window codes re-laid per octet) and / or the output
+    is written packed with out_vscale and unpacked afterwards (pk_out).  Returns (out fp32, ms or None, overflowed,
+    border_dirty): border_dirty = the zero border of the packed output was written to."""
+    x = x.contiguous()
+    N, Cin, h, w = x.shape
+    H, W = (2 * h, 2 * w) if mask is not None else (h, w)
+    weight = np.ascontiguousarray(weight, np.float32)
+    scale = np.ascontiguousarray(scale, np.float32); shift = np.ascontiguousarray(shift, np.float32)
+    Cout = weight.shape[0]
+    assert weight.shape == (Cout, Cin, 3, 3) and scale.shape == (Cout,) and shift.shape == (Cout,)
+    if mask is not None:
+        mask = mask.contiguous()
+        assert mask.shape == x.shape and mask.dtype == torch.uint8
+    if vscale is None:
+        vscale = float(2.0 ** (8 - np.frexp(float(x.abs().max()))[1]))
+    out = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device)
+    ms = C.c_double(0)
+    ov = C.c_int(0)
+    mode = (1 if pk_in else 0) | (2 if pk_out else 0) | (4 if extra_pad else 0)
+    check(dbg().sivo_debug_conv3_h3_pk_dev(N, Cin, Cout, H, W, x.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                           weight.ctypes.data_as(C.c_void_p), scale.ctypes.data_as(C.c_void_p),
+                                           shift.ctypes.data_as(C.c_void_p), int(relu), C.c_float(vscale),
+                                           C.c_float(out_vscale if out_vscale else 0.0), mode, out.data_ptr(), iters, C.byref(ms), C.byref(ov)))
+    return out, (ms.value if iters else None), bool(ov.value & 1), bool(ov.value & 2)
 
 
 def mc_reduce(logits, prob_sum=None, want_prob=False, accumulate=False):

@@ -271,6 +271,16 @@ def test_abi_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert declared >= set(_lib.SIGNATURES)                 # the Python binding binds only declared symbols
+    # the test / diagnostic entry points are NOT product ABI: declared in sivo_hip_debug.h, exported by libsivo_hip_dbg.so only
+    assert not [s for s in declared if s.startswith("sivo_debug_")]
+    dheader = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "sivo_hip_debug.h")).read(), flags=re.S)
+    ddeclared = set(re.findall(r"\b(sivo_debug_[a-z0-9_]+)\s*\(", dheader))
+    assert ddeclared == set(_lib.DEBUG_SIGNATURES) and len(ddeclared) >= 4
+    dbg = C.CDLL(_lib.DBG_PATH)
+    assert not [s for s in sorted(ddeclared) if not hasattr(dbg, s)]
+    import subprocess
+    exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "sivo_debug_" not in exported
 
 
 def test_struct_layouts_match_reference_types():

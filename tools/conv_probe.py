@@ -4,7 +4,7 @@ with parts of the kernel switched off (variant bits).  GPU box only."""
 import ctypes as C
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from sivo_amd._lib import lib, check
+from sivo_amd._lib import dbg, check
 
 SHAPES = {"conv4_2": (12, 512, 512, 44, 128), "conv5_2": (12, 512, 512, 22, 64), "conv3_2_D": (12, 256, 256, 88, 256),
           "conv2_2_D": (12, 128, 128, 176, 512), "conv1_2_D": (12, 64, 64, 352, 1024), "conv3_2": (1, 256, 256, 88, 256),
@@ -15,7 +15,7 @@ VARIANTS = {64: "wino F(2x2)", 512: "wino4 F(4x4)", 1024 + 4096 + 8192: "fused F
 def run(name, variant, iters=10):
     N, ci, co, H, W = SHAPES[name]
     ms = C.c_double()
-    check(lib().sivo_debug_conv(N, ci, co, H, W, 3, iters, variant, C.byref(ms)))
+    check(dbg().sivo_debug_conv(N, ci, co, H, W, 3, iters, variant, C.byref(ms)))
     fl = 2.0 * 9 * ci * co * H * W * N
     return ms.value, fl / ms.value / 1e9
 

@@ -22,6 +22,9 @@ PY
 }
 for step in "$@"; do
   case $step in
+    pk) timeout 900 python -m pytest tests/test_gpu_conv3_pk.py -q -s > $O/pk.log 2>&1; echo "pk rc=$?"; grep -E "packed|passed|failed|FAILED|Error|assert" $O/pk.log | tail -70;;
+    d3) timeout 600 python -m pytest tests/test_gpu_conv3_h3.py -q -s > $O/d3.log 2>&1; echo "d3 rc=$?"; grep -E "TFLOP|passed|failed|FAILED|Error" $O/d3.log | tail -20;;
+    smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $O/smoke.log;;
     gemm) timeout 600 python -m pytest tests/test_gpu_h3_gemm.py -x -q -s > $O/gemm.log 2>&1; echo "gemm rc=$?"; grep -E "h3 gemm|passed|failed|Error|assert" $O/gemm.log | tail -15;;
     segnet) timeout 900 python -m pytest tests/test_gpu_segnet.py -q -s > $O/segnet.log 2>&1; echo "segnet rc=$?"; grep -E "passed|failed|FAILED|dlogit" $O/segnet.log | tail -25;;
     bench) bench default SIVO_DUMMY=1;;
