@@ -119,7 +119,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_d[];
     constexpr bool F32IN = IN == IN_F32 || IN == IN_F32_UNPOOL;
     constexpr bool UNPOOL = IN == IN_F32_UNPOOL;               // (the fp32 staging code below; the packed forms have their own)
-    static_assert(F32IN || (FORM == 1 && ABL == 0), "the packed inputs exist in the interleaved form only");
+    static_assert(F32IN || FORM == 1, "the packed inputs exist in the interleaved form only");
     // LDS map: two patch buffers, two weight buffers, the epilogue affine of two items, (IN_PK_UNPOOL) the 256 x 16-byte mask table
     constexpr int PB = IN == IN_PK ? D_PBYTES_DMA : D_PBYTES;
     constexpr int U0 = 2 * PB, EP0 = U0 + 2 * D_UBYTES, LUT0 = EP0 + 1024;
@@ -268,9 +268,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // the same with the stage's base computed once by the caller (the packed forms: a slot has nothing else to do, so the 64-bit
     // address arithmetic per piece was most of its scalar work); pieces 0 .. 31 exist for every wave: no branch for j < 4
     const uint32_t w_voff = (uint32_t)(wave * 1024 + lane * 16);
-    auto stage_weights = [&](const Cursor &c) __attribute__((always_inline)) {
-        return static_cast<const unsigned char *>(a.wt_h3) + ((int64_t)c.g * nst + c.chunk) * D_UBYTES;
-    };
     auto dma_piece_at = [&](const unsigned char *sb, int buf, int j) __attribute__((always_inline)) {
         if (j < 4 || wave < 4) lds_dma16_s(sb + j * 8192, w_voff, lds_base + U0 + buf * D_UBYTES + (wave + 8 * j) * 1024);
     };
@@ -359,7 +356,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) {
             const int y = ty * D_TH + 2 * rp + sg;
-            const uint32_t vo = (y < a.H && x < a.W) ? (uint32_t)((((y + 1) * a.out_Wp) + x + 1) * 16 + lh * 8) : D_INV;
+            const uint32_t vo = (y < a.H && x < a.W && (!(ABL & 4) || acc[0][0][0] == 12345.678f)) ? (uint32_t)((((y + 1) * a.out_Wp) + x + 1) * 16 + lh * 8) : D_INV;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -566,40 +563,53 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             pk_voff[i] = (uint32_t)((((o * 2 + pl) * a.in_Hp + py) * a.in_Wp + px) * 16);
         }
         // patch row 0 = image row y0 - 1 = padded row y0, patch column 0 = padded column x0
-        auto stage_patch = [&](const Cursor &c) __attribute__((always_inline)) {
-            return static_cast<const unsigned char *>(a.in_pk) + (int64_t)c.n * a.in_pk_sample_bytes +
-                   (((int64_t)c.chunk * 4 * a.in_Hp + c.ty * D_TH) * a.in_Wp + c.tx * D_TW) * 16;
+        // running source pointers of the DMA cursor's stage (patch origin, weight image): one addition per stage, the full
+        // address arithmetic only when the item changes
+        const unsigned char *sbp = nullptr, *sbw = nullptr;
+        const int64_t p_stride = (int64_t)4 * a.in_Hp * a.in_Wp * 16;           // one 16-channel chunk of the packed input
+        auto run_locate = [&](const Cursor &c) __attribute__((always_inline)) {
+            sbp = static_cast<const unsigned char *>(a.in_pk) + (int64_t)c.n * a.in_pk_sample_bytes + ((int64_t)(c.ty * D_TH) * a.in_Wp + c.tx * D_TW) * 16;
+            sbw = static_cast<const unsigned char *>(a.wt_h3) + (int64_t)c.g * nst * D_UBYTES;
+        };
+        auto run_advance = [&](Cursor &c) __attribute__((always_inline)) {
+            if (++c.chunk == nst) {
+                c.chunk = 0;
+                if (++c.k < my_items) { locate(c); run_locate(c); }
+            } else {
+                sbp += p_stride; sbw += D_UBYTES;
+            }
         };
         auto dma_patch = [&](const unsigned char *sb, int buf, int i) __attribute__((always_inline)) {      // (pieces 0 .. 39 exist for every wave)
             if (i < 5 || wave < D_PK_DMA - 40) lds_dma16_s(sb, pk_voff[i], lds_base + buf * PB + (wave + 8 * i) * 1024);
         };
         // prologue: patch(0) and weights(0) in flight (the top of iteration 0 waits for them)
-        {
-            const unsigned char *sbp = stage_patch(cu), *sbw = stage_weights(cu);
+        run_locate(cu);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) dma_patch(sbp, 0, i);
-            if (wave < 2) { epv = ep_src[cu.g * 64 + lane]; }
-            ep_due = true; ep_par = 0;
+        for (int i = 0; i < 6; ++i) dma_patch(sbp, 0, i);
+        if (wave < 2) { epv = ep_src[cu.g * 64 + lane]; }
+        ep_due = true; ep_par = 0;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) dma_piece_at(sbw, 0, j);
-        }
-        advance(cu);
+        for (int j = 0; j < 5; ++j) dma_piece_at(sbw, 0, j);
+        run_advance(cu);
         // MORE: stage s + 1 exists (every iteration but the last: peeled, so that the loop body is one straight block)
         auto iteration = [&](const int s, auto more_tag) __attribute__((always_inline)) {
             constexpr bool MORE = decltype(more_tag)::value;
             // everything this wave issued in the previous iteration has had a whole multiply to complete: patch and weights of
             // stage s (DMA), the stores of an output stage.  Behind the barrier nobody reads the buffers of stage s - 1 any more.
+            const uint32_t t0 = stamp();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t t1 = stamp();
             if (ep_due && wave < 2) reinterpret_cast<float *>(lds_d + EP0)[ep_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
             ep_due = false;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const uint32_t t2 = stamp();
             if (pend) { store_item(pn, pty, ptx, pg, ppar); pend = false; }
+            const uint32_t t3 = stamp();
             const int nb = (s + 1) & 1;
             if (MORE && cu.chunk == 0) {
                 ep_due = true; ep_par = cu.k & 1;
                 if (wave < 2) epv = ep_src[cu.g * 64 + lane];
             }
-            const unsigned char *sbp = MORE ? stage_patch(cu) : nullptr, *sbw = MORE ? stage_weights(cu) : nullptr;
             fetch(s & 1, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -608,12 +618,16 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 if (q == 0 && t + 1 < 9) fetch(s & 1, t + 1, (t + 1) & 1);
                 mfma3(t & 1, q);
                 if (MORE) {
-                    if (slot < 5) dma_piece_at(sbw, nb, slot);
-                    else if (slot < 11) dma_patch(sbp, nb, slot - 5);
+                    if (slot < 5) { if (!(ABL & 2)) dma_piece_at(sbw, nb, slot); }
+                    else if (slot < 11) { if (!(ABL & 1)) dma_patch(sbp, nb, slot - 5); }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (MORE) advance(cu);
+            if (ABL & 64) {
+                const uint32_t t4 = stamp();
+                st_wait += (t1 - t0) & 0xfffffu; st_bar += (t2 - t1) & 0xfffffu; st_out += (t3 - t2) & 0xfffffu; st_mul += (t4 - t3) & 0xfffffu;
+            }
+            if (MORE) run_advance(cu);
             end_of_stage();
         };
         for (int s = 0; s + 1 < total; ++s) iteration(s, std::true_type{});
@@ -625,8 +639,10 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const bool q_valid = tid < D_NQ;
         const int qt = q_valid ? tid : 0;
         const int q_o = qt / (D_QR * D_QC), q_rem = qt - q_o * (D_QR * D_QC), q_r = q_rem / D_QC, q_c = q_rem - q_r * D_QC;
-        const uint32_t q_voff = q_valid ? (uint32_t)((((q_o * 2) * a.in_Hp + q_r) * a.in_Wp + q_c) * 16) : D_INV;      // hi plane; lo: + one plane, in the scalar offset
-        const uint32_t q_moff = q_valid ? (uint32_t)(((q_o * a.in_Hp + q_r) * a.in_Wp + q_c) * 4) : D_INV;
+        // (lanes without a piece load from offset 0 — the padded tensors make every address of the patch valid — and store nothing)
+        const uint32_t q_voff = (uint32_t)((((q_o * 2) * a.in_Hp + q_r) * a.in_Wp + q_c) * 16);                          // hi plane
+        const uint32_t q_voff_lo = q_voff + (uint32_t)(a.in_Hp * a.in_Wp * 16);                                       // lo plane: one plane further
+        const uint32_t q_moff = (uint32_t)(((q_o * a.in_Hp + q_r) * a.in_Wp + q_c) * 4);
         uint32_t q_dst[4];          // LDS byte offset of window position k's piece inside a patch buffer's hi plane; q_ok bit k: it exists
         uint32_t q_ok = 0u;
 #pragma unroll
@@ -637,24 +653,31 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             q_ok |= ok ? (1u << k) : 0u;
         }
         struct QSet { u32x4 hi, lo; uint32_t m; };
-        struct QPlan { i32x4 rs, mrs; uint32_t so_hi, so_lo, so_m; };
-        auto plan_q = [&](const Cursor &c, QPlan &lp) __attribute__((always_inline)) {
-            const int64_t pl = (int64_t)a.in_Hp * a.in_Wp;              // pooled pieces of one plane of one octet
-            const uint64_t base = (uint64_t)(uintptr_t)(static_cast<const unsigned char *>(a.in_pk) + (int64_t)c.n * a.in_pk_sample_bytes);
-            lp.rs = (i32x4){(int)(uint32_t)base, (int)(uint32_t)((base >> 32) & 0xffffu), (int)(a.Cin * pl * 4), 0x00020000};
-            const uint64_t mbase = (uint64_t)(uintptr_t)(a.unpool_bits + (int64_t)c.n * a.unpool_bits_stride);
-            lp.mrs = (i32x4){(int)(uint32_t)mbase, (int)(uint32_t)((mbase >> 32) & 0xffffu), (int)((a.Cin / 8) * pl * 4), 0x00020000};
+        // running scalar bases of the load cursor's stage: pooled patch origin in the packed tensor, the same in the mask tensor,
+        // the weight image; one addition per stage, the full address arithmetic only when the item changes
+        const unsigned char *sbq = nullptr, *sbm = nullptr, *sbw = nullptr;
+        const int64_t q_plane = (int64_t)a.in_Hp * a.in_Wp;              // pooled pieces of one plane of one octet
+        auto run_locate = [&](const Cursor &c) __attribute__((always_inline)) {
             const int64_t org = (int64_t)(c.ty * (D_TH / 2)) * a.in_Wp + c.tx * (D_TW / 2);
-            lp.so_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((int64_t)c.chunk * 4 * pl + org) * 16));
-            lp.so_lo = lp.so_hi + (uint32_t)__builtin_amdgcn_readfirstlane((int)(pl * 16));
-            lp.so_m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((int64_t)c.chunk * 2 * pl + org) * 4));
+            sbq = static_cast<const unsigned char *>(a.in_pk) + (int64_t)c.n * a.in_pk_sample_bytes + org * 16;
+            sbm = reinterpret_cast<const unsigned char *>(a.unpool_bits + (int64_t)c.n * a.unpool_bits_stride) + org * 4;
+            sbw = static_cast<const unsigned char *>(a.wt_h3) + (int64_t)c.g * nst * D_UBYTES;
         };
-        // load L (0 .. 2) of a stage: hi piece, lo piece, mask dword.  (s_nop 4: a scalar operand may come straight out of a
-        // v_readfirstlane, and nothing pads a VALU-written SGPR -> VMEM hazard inside an asm statement)
-        auto load_q = [&](const QPlan &lp, int L, QSet &qs) __attribute__((always_inline)) {
-            if (L == 0) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(qs.hi) : "v"(q_voff), "s"(lp.rs), "s"(lp.so_hi) : "memory");
-            else if (L == 1) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(qs.lo) : "v"(q_voff), "s"(lp.rs), "s"(lp.so_lo) : "memory");
-            else asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=&v"(qs.m) : "v"(q_moff), "s"(lp.mrs), "s"(lp.so_m) : "memory");
+        auto run_advance = [&](Cursor &c) __attribute__((always_inline)) {
+            if (++c.chunk == nst) {
+                c.chunk = 0;
+                if (++c.k < my_items) { locate(c); run_locate(c); }
+            } else {
+                sbq += 4 * q_plane * 16; sbm += 2 * q_plane * 4; sbw += D_UBYTES;
+            }
+        };
+        // load L (0 .. 2) of a stage: hi piece, lo piece, mask dword (global loads with a scalar base: two SGPRs each where a
+        // buffer descriptor takes four).  (s_nop 4: a scalar operand may come straight out of a v_readlane, and nothing pads a
+        // VALU-written SGPR -> VMEM hazard inside an asm statement)
+        auto load_q = [&](int L, QSet &qs) __attribute__((always_inline)) {
+            if (L == 0) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(qs.hi) : "v"(q_voff), "s"(sbq) : "memory");
+            else if (L == 1) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(qs.lo) : "v"(q_voff_lo), "s"(sbq) : "memory");
+            else asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=&v"(qs.m) : "v"(q_moff), "s"(sbm) : "memory");
         };
         // (the wait is part of the statement that makes the registers readable: nothing can be scheduled between the two)
         auto landed_q = [&](QSet &qs) __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(qs.hi), "+v"(qs.lo), "+v"(qs.m)::"memory"); };
@@ -680,19 +703,15 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         QSet qs;
         bool ep_due = false;
         int ep_par = 0;
-        QPlan lp;
         // prologue: patch(0) -> LDS, weights(0) in flight
-        plan_q(cu, lp);
+        run_locate(cu);
 #pragma unroll
-        for (int L = 0; L < 3; ++L) load_q(lp, L, qs);
+        for (int L = 0; L < 3; ++L) load_q(L, qs);
         if (wave < 2) { epv = ep_src[cu.g * 64 + lane]; }
         ep_due = true; ep_par = 0;
-        {
-            const unsigned char *sbw = stage_weights(cu);
 #pragma unroll
-            for (int j = 0; j < 5; ++j) dma_piece_at(sbw, 0, j);
-        }
-        advance(cu);
+        for (int j = 0; j < 5; ++j) dma_piece_at(sbw, 0, j);
+        run_advance(cu);
         landed_q(qs);
 #pragma unroll
         for (int st = 0; st < 8; ++st) expand_step(0, qs, st);
@@ -702,14 +721,16 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         // stages ahead) bought SGPR spills here and nothing else — a pooled stage is 3 loads per lane, not 24.
         auto iteration = [&](const int s, auto more_tag) __attribute__((always_inline)) {
             constexpr bool MORE = decltype(more_tag)::value;
+            const uint32_t t0 = stamp();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t t1 = stamp();
             if (ep_due && wave < 2) reinterpret_cast<float *>(lds_d + EP0)[ep_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
             ep_due = false;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const uint32_t t2 = stamp();
             if (pend) { store_item(pn, pty, ptx, pg, ppar); pend = false; }
+            const uint32_t t3 = stamp();
             const int nb = (s + 1) & 1;
-            if (MORE) plan_q(cu, lp);
-            const unsigned char *sbw = MORE ? stage_weights(cu) : nullptr;
             if (MORE && cu.chunk == 0) {
                 ep_due = true; ep_par = cu.k & 1;
                 if (wave < 2) epv = ep_src[cu.g * 64 + lane];
@@ -722,14 +743,18 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 if (q == 0 && t + 1 < 9) fetch(s & 1, t + 1, (t + 1) & 1);
                 mfma3(t & 1, q);
                 if (MORE) {
-                    if (slot < 5) dma_piece_at(sbw, nb, slot);
-                    else if (slot < 8) load_q(lp, slot - 5, qs);
+                    if (slot < 5) { if (!(ABL & 2)) dma_piece_at(sbw, nb, slot); }
+                    else if (slot < 8) { if (!(ABL & 1)) load_q(slot - 5, qs); }
                     else if (slot == 23) landed_q(qs);
-                    else if (slot >= 24 && slot < 32) expand_step(nb, qs, slot - 24);
+                    else if (slot >= 24 && slot < 32) { if (!(ABL & 16)) expand_step(nb, qs, slot - 24); }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (MORE) advance(cu);
+            if (ABL & 64) {
+                const uint32_t t4 = stamp();
+                st_wait += (t1 - t0) & 0xfffffu; st_bar += (t2 - t1) & 0xfffffu; st_out += (t3 - t2) & 0xfffffu; st_mul += (t4 - t3) & 0xfffffu;
+            }
+            if (MORE) run_advance(cu);
             end_of_stage();
         };
         for (int s = 0; s + 1 < total; ++s) iteration(s, std::true_type{});
@@ -741,6 +766,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         atomicAdd(a.vmax + 0, st_wait >> 4); atomicAdd(a.vmax + 1, st_bar >> 4); atomicAdd(a.vmax + 2, st_out >> 4); atomicAdd(a.vmax + 3, st_mul >> 4);
         atomicAdd(a.vmax + 4, (uint32_t)total);
         atomicMax(a.vmax + 5, stamp() - st_begin);
+        if (wave == 0) { a.vmax[8 + 2 * blockIdx.x] = stamp() - st_begin; a.vmax[9 + 2 * blockIdx.x] = (uint32_t)total; }      // per workgroup: cycles, stages
     }
 }
 
@@ -863,6 +889,17 @@ void launch_conv3_h3(const ConvArgs &a0, hipStream_t s) {
             hipLaunchKernelGGL((conv3_h3_kernel<IN_F32, false, 1, n>), grid, dim3(512), lds, s, a);                                         \
         }                                                                                                                                   \
         return;
+#define D3PK_ABL_CASE(IN_, OUT_, n)                                                                                                         \
+    case n:                                                                                                                                 \
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_h3_kernel<IN_, OUT_, 1, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((conv3_h3_kernel<IN_, OUT_, 1, n>), grid, dim3(512), lds, s, a);                                                 \
+        return;
+#define D3PK_ABL_SET(IN_, OUT_) switch (std::atoi(ab)) { D3PK_ABL_CASE(IN_, OUT_, 1) D3PK_ABL_CASE(IN_, OUT_, 2) D3PK_ABL_CASE(IN_, OUT_, 3) D3PK_ABL_CASE(IN_, OUT_, 4) D3PK_ABL_CASE(IN_, OUT_, 7) D3PK_ABL_CASE(IN_, OUT_, 8) D3PK_ABL_CASE(IN_, OUT_, 16) D3PK_ABL_CASE(IN_, OUT_, 23) D3PK_ABL_CASE(IN_, OUT_, 64) default: break; }
+        if (pk_in && !unpool && pk_out) D3PK_ABL_SET(IN_PK, true)
+        if (pk_in && unpool && !pk_out) D3PK_ABL_SET(IN_PK_UNPOOL, false)
+        if (pk_in && unpool && pk_out) D3PK_ABL_SET(IN_PK_UNPOOL, true)
+#undef D3PK_ABL_SET
+#undef D3PK_ABL_CASE
         if (!unpool && !pk_in && !pk_out) switch (std::atoi(ab)) {
             D3_ABL_CASE(1) D3_ABL_CASE(2) D3_ABL_CASE(3) D3_ABL_CASE(4) D3_ABL_CASE(8) D3_ABL_CASE(16) D3_ABL_CASE(19) D3_ABL_CASE(23) D3_ABL_CASE(64) D3_ABL_CASE(65) D3_ABL_CASE(68)
             default: break;

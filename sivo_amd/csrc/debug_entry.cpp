@@ -83,8 +83,8 @@ extern "C" int sivo_debug_conv3_h3_dev(int N, int Cin, int Cout, int H, int W, c
         a.wt_h3 = du; a.h3_vscale = vscale; a.h3_uscale = uscale; a.h3_flag = flag;
         uint32_t *stamps = nullptr;         // diagnostic build + SIVO_D3_STAMPS=1: cycle sums of the kernel's ABL & 64 form
         if (std::getenv("SIVO_D3_STAMPS")) {
-            stamps = dev_alloc<uint32_t>(8);
-            SIVO_HIP(hipMemset(stamps, 0, 32));
+            stamps = dev_alloc<uint32_t>(8 + 2 * 1024);      // [0 .. 5] sums, then per workgroup (cycles, stages)
+            SIVO_HIP(hipMemset(stamps, 0, 32 + 8 * 1024));
             a.vmax = stamps;
         }
         launch_conv3_h3(a, nullptr);
@@ -238,8 +238,15 @@ extern "C" int sivo_debug_conv3_h3_pk_dev(int N, int Cin, int Cout, int H, int W
             SIVO_HIP(hipMemset(d_pout, 0, nb));
             a.out_pk = d_pout; a.out_vscale = out_vscale; a.out = nullptr;
         }
+        uint32_t *stamps = nullptr;         // diagnostic build + SIVO_D3_STAMPS=1: cycle sums of the kernel's ABL & 64 form
+        if (std::getenv("SIVO_D3_STAMPS")) {
+            stamps = dev_alloc<uint32_t>(8 + 2 * 1024);
+            SIVO_HIP(hipMemset(stamps, 0, 32 + 8 * 1024));
+            a.vmax = stamps;
+        }
         launch_conv3_h3(a, nullptr);
         SIVO_HIP(hipDeviceSynchronize());
+        if (stamps) SIVO_HIP(hipMemset(stamps, 0, 32 + 8 * 1024));
         if (iters > 0 && ms_out) {
             hipEvent_t e0, e1;
             SIVO_HIP(hipEventCreate(&e0)); SIVO_HIP(hipEventCreate(&e1));
@@ -251,7 +258,26 @@ extern "C" int sivo_debug_conv3_h3_pk_dev(int N, int Cin, int Cout, int H, int W
             SIVO_HIP(hipEventElapsedTime(&ms, e0, e1));
             *ms_out = ms / iters;
             (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            if (stamps) {
+                uint32_t h[8];
+                SIVO_HIP(hipMemcpy(h, stamps, 32, hipMemcpyDeviceToHost));
+                if (h[4]) std::fprintf(stderr, "d3 stamps (cycles per wave and stage): wait %.0f barrier %.0f output %.0f multiply %.0f; longest wave %u cycles; %u wave-stages\n",
+                                       16.0 * h[0] / h[4], 16.0 * h[1] / h[4], 16.0 * h[2] / h[4], 16.0 * h[3] / h[4], h[5], h[4]);
+                // per workgroup of the LAST launch: cycles from start to end, stages — by XCD (workgroup b runs on XCD b % 8)
+                std::vector<uint32_t> wg(2 * 1024);
+                SIVO_HIP(hipMemcpy(wg.data(), stamps + 8, wg.size() * 4, hipMemcpyDeviceToHost));
+                for (int x = 0; x < 8; ++x) {
+                    double cmin = 1e30, cmax = 0, csum = 0, ssum = 0; int n = 0;
+                    for (int b2 = x; b2 < 1024; b2 += 8) {
+                        if (!wg[2 * b2 + 1]) continue;
+                        const double c = wg[2 * b2], st = wg[2 * b2 + 1];
+                        cmin = std::fmin(cmin, c / st); cmax = std::fmax(cmax, c / st); csum += c; ssum += st; ++n;
+                    }
+                    if (n) std::fprintf(stderr, "  xcd %d: %d workgroups, %.0f stages each on average, cycles per stage mean %.0f min %.0f max %.0f, longest workgroup %.0f cycles\n", x, n, ssum / n, csum / ssum, cmin, cmax, [&] { double m = 0; for (int b2 = x; b2 < 1024; b2 += 8) m = std::fmax(m, wg[2 * b2]); return m; }());
+                }
+            }
         }
+        (void)hipFree(stamps);
         if (pk_out) {
             // the border of the packed output must still be zero: count what is not (returned through *overflowed bit 1)
             launch_pk_unpack(d_pout, d_out, N, Cout, H, W, a.out_Hp, a.out_Wp, out_vscale, nullptr);
