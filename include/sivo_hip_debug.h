@@ -39,6 +39,15 @@ int sivo_debug_conv3_h3_pk_dev(int N, int Cin, int Cout, int H, int W, const flo
                                const float *scale, const float *shift, int relu, float vscale, float out_vscale, int mode,
                                float *d_out, int iters, double *ms_out, int *overflowed);
 
+/* The classifier convolution fused with the Monte-Carlo post-processing on the fp16 matrix cores (conv_cls_h3.hip) alone.
+ * d_in: DEVICE fp32 (T, Cin, H, W), packed on the device with vscale first (Cin % 32 == 0, Cin <= 96); Wt (C, Cin, 3, 3), scale,
+ * shift (C): HOST arrays; outputs on the DEVICE: d_logits (T, C, H, W) fp32 and the maps of the f64 mean over the T samples
+ * (d_classes u8, d_confidence / d_entropy f64, each H x W).  iters > 0: mean launch time (ms) of `iters` further launches
+ * without the logits output. */
+int sivo_debug_conv_cls_h3_dev(int T, int Cin, int C, int H, int W, const float *d_in, const float *Wt, const float *scale,
+                               const float *shift, int relu, float vscale, float *d_logits, uint8_t *d_classes,
+                               double *d_confidence, double *d_entropy, int iters, double *ms_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,6 +131,7 @@ DEBUG_SIGNATURES = {
     "sivo_debug_h3_gemm": [_i, _i, _i, _vp, _vp, _f, _vp, _i, C.POINTER(_d)],
     "sivo_debug_conv3_h3_dev": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _i, C.POINTER(_d), C.POINTER(_i)],
     "sivo_debug_conv3_h3_pk_dev": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _i, _vp, _i, C.POINTER(_d), C.POINTER(_i)],
+    "sivo_debug_conv_cls_h3_dev": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, C.POINTER(_d)],
 }
 DBG_PATH = os.path.join(_HERE, "libsivo_hip_dbg.so")
 

@@ -301,3 +301,54 @@ extern "C" int sivo_debug_conv3_h3_pk_dev(int N, int Cin, int Cout, int H, int W
         return SIVO_OK;
     });
 }
+
+// The f16x3 classifier + MC kernel alone (see include/sivo_hip_debug.h).
+extern "C" int sivo_debug_conv_cls_h3_dev(int T, int Cin, int C, int H, int W, const float *d_in, const float *Wt, const float *scale,
+                                          const float *shift, int relu, float vscale, float *d_logits, uint8_t *d_classes,
+                                          double *d_confidence, double *d_entropy, int iters, double *ms_out) {
+    return guarded([&] {
+        if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device");
+        if (!d_in || !Wt || !scale || !shift || !d_logits || !d_classes || !d_confidence || !d_entropy || T < 1 || !(vscale > 0.f) ||
+            !cls_h3_supported(3, Cin, C, H, W))
+            throw std::invalid_argument("sivo_debug_conv_cls_h3_dev: bad argument / unsupported shape");
+        std::vector<uint16_t> planes;
+        const float uscale = cls_h3_pack_weights(Wt, Cin, C, planes);
+        uint16_t *du = dev_alloc<uint16_t>(planes.size());
+        float *dsc = dev_alloc<float>(16), *dsh = dev_alloc<float>(16);
+        SIVO_HIP(hipMemcpy(du, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+        SIVO_HIP(hipMemset(dsc, 0, 64)); SIVO_HIP(hipMemset(dsh, 0, 64));
+        SIVO_HIP(hipMemcpy(dsc, scale, C * 4, hipMemcpyHostToDevice));
+        SIVO_HIP(hipMemcpy(dsh, shift, C * 4, hipMemcpyHostToDevice));
+        int th, tw;
+        cls_h3_tile(&th, &tw);
+        ClsMcArgs a{};
+        a.in_Hp = (H + th - 1) / th * th + 2; a.in_Wp = (W + tw - 1) / tw * tw + 2;
+        const size_t nb = pk_bytes(T, Cin, a.in_Hp, a.in_Wp);
+        void *d_pin = nullptr;
+        SIVO_HIP(hipMalloc(&d_pin, nb));
+        SIVO_HIP(hipMemset(d_pin, 0, nb));
+        launch_pk_pack(d_in, (int64_t)Cin * H * W, d_pin, T, Cin, H, W, a.in_Hp, a.in_Wp, vscale, nullptr, nullptr);
+        a.in_pk = d_pin; a.in_pk_sample_bytes = (int64_t)pk_bytes(1, Cin, a.in_Hp, a.in_Wp);
+        a.wt_h3 = du; a.h3_vscale = vscale; a.h3_uscale = uscale;
+        a.ep_scale = dsc; a.ep_shift = dsh;
+        a.T = T; a.Cin = Cin; a.H = H; a.W = W; a.C = C; a.relu = relu;
+        a.logits = d_logits; a.classes = d_classes; a.confidence = d_confidence; a.entropy = d_entropy;
+        launch_conv_cls_h3(a, nullptr);
+        SIVO_HIP(hipDeviceSynchronize());
+        if (iters > 0 && ms_out) {
+            a.logits = nullptr;
+            hipEvent_t e0, e1;
+            SIVO_HIP(hipEventCreate(&e0)); SIVO_HIP(hipEventCreate(&e1));
+            SIVO_HIP(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < iters; ++i) launch_conv_cls_h3(a, nullptr);
+            SIVO_HIP(hipEventRecord(e1, nullptr));
+            SIVO_HIP(hipEventSynchronize(e1));
+            float ms = 0;
+            SIVO_HIP(hipEventElapsedTime(&ms, e0, e1));
+            *ms_out = ms / iters;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        }
+        (void)hipFree(du); (void)hipFree(dsc); (void)hipFree(dsh); (void)hipFree(d_pin);
+        return SIVO_OK;
+    });
+}

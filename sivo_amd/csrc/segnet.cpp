@@ -82,6 +82,10 @@ struct Op {
     bool make_bits = false;    // pooling: a packed consumer reads through this pooling's switches -> also write them per channel octet
     int bridge_to = -1;        // w4_bridge: the op whose transformed input this layer's bridge kernel writes
     float *d_w_mc = nullptr;   // classifier: second copy of the weights in the layout of conv_cls_mc.hip (fused with the MC post-processing)
+    // classifier on the fp16 matrix cores (conv_cls_h3.hip), fed by its producer's packed output: weights in d_wd3 (cls_h3_pack_weights),
+    // d3_uscale / d3_vscale / d3_vmax as for a direct f16x3 layer (input scale calibrated)
+    bool c3 = false;
+    bool cls_h3_last = false;  // profiling: the last fused launch was conv_cls_h3_kernel
     bool mc_fused_last = false;   // profiling: the last timed launch of this op was the fused kernel
     bool relu = false;
     bool v2 = false;           // conv_v2.hip kernel + weight layout
@@ -147,6 +151,7 @@ struct sivo_segnet {
     // bf16x6 GEMM has fp32's range).  h3_flag: one word of pinned host memory the transform kernels store 1 into.
     bool h3_on = false, calibrating = false;
     bool pk_on = true;              // packed activations between direct f16x3 layers (SIVO_D3_PK=0 at construction: fp32 blobs everywhere)
+    bool cls_pk_now = false;        // this forward hands the classifier its input packed (fused classifier + MC kernel on f16x3)
     volatile uint32_t *h3_flag = nullptr;
     uint32_t *d_h3_vmax = nullptr;  // calibration: one word per op (bit pattern of the largest |V|)
     int h3_overflow_frames = 0;     // frames that raised the flag (each was recomputed on the bf16x6 path when the entry point is synchronous)
@@ -563,6 +568,17 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             S.owned.push_back(L.d_w_mc);
             SIVO_HIP(hipMemcpy(L.d_w_mc, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
             S.cls_op = (int)S.ops.size() - 1;
+            // the f16x3 form (conv_cls_h3.hip), when the handle runs f16x3 at all (SIVO_GEMM unset, SIVO_D3 not 0)
+            const char *ge = std::getenv("SIVO_GEMM");
+            const bool f16x3_handle = !(ge && (std::string(ge) == "x6" || std::string(ge) == "f32")) && !(std::getenv("SIVO_D3") && std::atoi(std::getenv("SIVO_D3")) == 0);
+            if (f16x3_handle && cls_h3_supported(L.ks, L.cin, L.cout, bi.H, bi.W)) {
+                std::vector<uint16_t> planes;
+                L.d3_uscale = cls_h3_pack_weights(weights + L.w_off, L.cin, L.cout, planes);
+                L.d_wd3 = dev_alloc<uint16_t>(planes.size());
+                S.owned.push_back(L.d_wd3);
+                SIVO_HIP(hipMemcpy(L.d_wd3, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+                L.c3 = true;
+            }
         }
     }
     // Direct f16x3 layer <- direct f16x3 layer (or an F(4x4) layer's output transform): the activation in between goes in the
@@ -572,8 +588,10 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
     if (S.pk_on)
         for (size_t bi_ = 0; bi_ < S.ops.size(); ++bi_) {
             Op &B = S.ops[bi_];
-            if (B.kind != OP_CONV || !B.d3 || B.skip || B.drop_site >= 0 || B.pool_op >= 0) continue;
+            const bool b_cls = B.c3 && (int)bi_ == S.cls_op;          // the fused classifier + MC kernel on f16x3 (conv_cls_h3.hip)
+            if (B.kind != OP_CONV || !(B.d3 || b_cls) || B.skip || B.drop_site >= 0 || B.pool_op >= 0) continue;
             const bool unpool = B.unpool_in >= 0;
+            if (b_cls && unpool) continue;
             const int X = unpool ? B.unpool_in : B.in;
             if (X == S.input_blob || X == S.logits_blob || S.blobs[X].fused_away || S.blobs[X].C % 16) continue;
             int uses = 0, ai = -1, pi = -1;
@@ -593,10 +611,12 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
                                   conv3_h3_supported(A.ks, A.cin, A.cout, S.blobs[A.in].H, S.blobs[A.in].W, A.unpool_in >= 0);
             if (!a_direct && !A.wino4) continue;
             const Blob &bin = S.blobs[B.in];                       // the layer's input geometry (the Upsample's output when it reads through one)
-            if (!conv3_h3_supported(B.ks, B.cin, B.cout, bin.H, bin.W, unpool)) continue;
-            const int tx = (bin.W + 63) / 64, ty = (bin.H + 7) / 8;
+            if (!b_cls && !conv3_h3_supported(B.ks, B.cin, B.cout, bin.H, bin.W, unpool)) continue;
+            int tile_h = 8, tile_w = 64;
+            if (b_cls) cls_h3_tile(&tile_h, &tile_w);
+            const int tx = (bin.W + tile_w - 1) / tile_w, ty = (bin.H + tile_h - 1) / tile_h;
             Blob &bx = S.blobs[X];
-            bx.pk_Hp = (unpool ? ty * 4 : ty * 8) + 2; bx.pk_Wp = (unpool ? tx * 32 : tx * 64) + 2;
+            bx.pk_Hp = (unpool ? ty * 4 : ty * tile_h) + 2; bx.pk_Wp = (unpool ? tx * 32 : tx * tile_w) + 2;
             if (bx.pk_Hp < bx.H + 2 || bx.pk_Wp < bx.W + 2 || (int64_t)bx.C * bx.pk_Hp * bx.pk_Wp * 4 >= (1ll << 31)) { bx.pk_Hp = bx.pk_Wp = 0; continue; }
             if (unpool) {
                 Blob &bm = S.blobs[B.unpool_mask];
@@ -693,7 +713,7 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
 // SIVO_H3_BOOST=k multiplies the scales by 2^k (tests: k = 9 forces the overflow path).
 void calibrate_h3(sivo_segnet &S) {
     bool any = false;
-    for (const Op &op : S.ops) any = any || op.d_wh3 || op.d3;
+    for (const Op &op : S.ops) any = any || op.d_wh3 || op.d3 || op.c3;
     if (!any) return;
     uint32_t *flag = nullptr;
     SIVO_HIP(hipHostMalloc((void **)&flag, 64, hipHostMallocDefault));
@@ -727,7 +747,7 @@ void calibrate_h3(sivo_segnet &S) {
     for (size_t i = 0; i < S.ops.size(); ++i) {
         Op &op = S.ops[i];
         if (op.d_wh3) op.h3_vscale = scale_for(bits[i], &op.h3_vmax);
-        if (op.d3) op.d3_vscale = scale_for(bits[S.ops.size() + i], &op.d3_vmax);
+        if (op.d3 || op.c3) op.d3_vscale = scale_for(bits[S.ops.size() + i], &op.d3_vmax);
     }
     S.h3_on = true;
 }
@@ -805,8 +825,8 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                                     conv3_h3_supported(op.ks, op.cin, op.cout, a.H, a.W, a.unpool_mask != nullptr);
                 // packed links (decided at plan time from static conditions only) are live while the handle runs f16x3
                 const bool pk_live = S.pk_on && S.h3_on && !S.calibrating;
-                const bool pk_out_now = pk_live && op.pk_to >= 0;
-                if (pk_live && (op.pk_in || (op.pk_to >= 0 && !op.wino4)) && !d3_now)
+                const bool pk_out_now = pk_live && op.pk_to >= 0 && (op.pk_to != S.cls_op || S.cls_pk_now);
+                if (pk_live && ((op.pk_in && (int)oi != S.cls_op) || (pk_out_now && !op.wino4)) && !d3_now)
                     throw std::runtime_error("layer '" + op.name + "': planned for packed activations but not running its f16x3 kernel");
                 Blob &bo_w = S.blobs[op.out];
                 if (op.d3 && S.calibrating && S.d_h3_vmax) {
@@ -948,6 +968,9 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
     launch_preprocess(d_bgr, (float *)S.blobs[S.input_blob].d, hw, st);
     const bool fuse = S.cls_op >= 0 && !d_prob && !d_logits && (mc || d_prob_sum || S.d_sum64);
     const size_t last = fuse ? (size_t)S.cls_op : S.ops.size();
+    // the fused classifier on f16x3 takes its input packed from its producer: decided per forward (an unfused pass runs the
+    // classifier as a plain convolution on the fp32 blob)
+    S.cls_pk_now = fuse && S.ops[S.cls_op].c3 && S.ops[S.cls_op].pk_in && S.ops[S.cls_op].d3_vscale > 0.f && S.pk_on && S.h3_on && !S.calibrating;
     // the sample-invariant ops form a prefix of the plan
     size_t fork = 0;
     while (fork < last && (S.ops[fork].skip || S.blobs[S.ops[fork].out].shared)) ++fork;
@@ -998,12 +1021,20 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
         a.prob_sum = d_prob_sum; a.prob_sum64 = S.d_sum64; a.sum_chunk = S.sum_chunk;
         if (mc) { a.classes = mc->classes; a.confidence = mc->conf; a.entropy = mc->ent; }
         op.mc_fused_last = true;
+        op.cls_h3_last = S.cls_pk_now;
+        if (S.cls_pk_now) {
+            a.in_pk = bi.d_pk; a.in_pk_sample_bytes = bi.pk_sample_bytes(); a.in_Hp = bi.pk_Hp; a.in_Wp = bi.pk_Wp;
+            a.wt_h3 = op.d_wd3; a.h3_vscale = op.d3_vscale; a.h3_uscale = op.d3_uscale;
+        }
+        if (S.calibrating && op.c3 && S.d_h3_vmax)       // the classifier's largest |input| (calibration runs the fp32 chain)
+            launch_absmax((const float *)bi.d, (int64_t)n * bi.chw(), S.d_h3_vmax + S.ops.size() + S.cls_op, st);
         if (S.profile) {
             op.timed_last = true; op.w4_gemm_only_last = false; op.w4_groups_last = 0; op.last_n = n;
             if (!op.ev0) { SIVO_HIP(hipEventCreate(&op.ev0)); SIVO_HIP(hipEventCreate(&op.ev1)); }
             SIVO_HIP(hipEventRecord(op.ev0, st));
         }
-        launch_conv_cls_mc(a, st);
+        if (S.cls_pk_now) launch_conv_cls_h3(a, st);
+        else launch_conv_cls_mc(a, st);
         if (S.profile) SIVO_HIP(hipEventRecord(op.ev1, st));
     } else {
         if (S.cls_op >= 0) S.ops[S.cls_op].mc_fused_last = false;
@@ -1393,7 +1424,7 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
             std::memset(&p, 0, sizeof p);
             std::snprintf(p.layer, sizeof p.layer, "%s", op.name.c_str());
             const bool d3_on = op.d3 && h->h3_on && op.d3_vscale > 0.f && op.drop_site < 0 && op.pool_op < 0;
-            std::snprintf(p.kernel, sizeof p.kernel, "%s", op.mc_fused_last ? "conv_wino_cls_mc_kernel" : d3_on ? "conv3_h3_kernel" : op.kernel.c_str());
+            std::snprintf(p.kernel, sizeof p.kernel, "%s", op.mc_fused_last ? (op.cls_h3_last ? "conv_cls_h3_kernel" : "conv_wino_cls_mc_kernel") : d3_on ? "conv3_h3_kernel" : op.kernel.c_str());
             p.samples = op.last_n;
             p.flops_per_sample = op.flops;
             p.bytes_per_sample = op.bytes;
@@ -1417,7 +1448,7 @@ extern "C" int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow
         bool any_h3 = false, any_x6 = false;
         int rows = 0;
         for (const Op &op : h->ops) {
-            if (op.d3) {        // direct f16x3 layer: vmax / vscale are those of its input activation
+            if (op.d3 || op.c3) {        // direct f16x3 layer / classifier: vmax / vscale are those of its input activation
                 any_h3 = any_h3 || op.d3_vscale > 0.f;
                 if (per_layer && rows < capacity) {
                     SivoH3Layer &r = per_layer[rows];

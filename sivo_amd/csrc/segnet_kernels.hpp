@@ -125,8 +125,21 @@ struct ClsMcArgs {
     uint8_t *classes;          // optional maps (all three or none): argmax, max and entropy of the f64 mean
     double *confidence;
     double *entropy;
+    // conv_cls_h3.hip: the same layer on the fp16 matrix cores, reading the PACKED input its producer wrote (conv3_h3.hip
+    // OUT_PK: [T][Cin / 8][plane][in_Hp][in_Wp][8], times h3_vscale) — then `in` / `wt` are unused
+    const void *in_pk = nullptr;
+    int64_t in_pk_sample_bytes = 0;
+    int in_Hp = 0, in_Wp = 0;
+    const void *wt_h3 = nullptr;   // cls_h3_pack_weights
+    float h3_vscale = 0.f, h3_uscale = 1.f;
 };
 bool cls_mc_supported(int ks, int cin, int cout, int H, int W);
+// the f16x3 form (conv_cls_h3.hip): Cin % 32 == 0, Cin <= 96; tile = the workgroup's output pixels (its packed input plane must
+// hold ceil(H / th) * th + 2 rows and ceil(W / tw) * tw + 2 columns)
+bool cls_h3_supported(int ks, int cin, int cout, int H, int W);
+void cls_h3_tile(int *th, int *tw);
+float cls_h3_pack_weights(const float *W, int cin, int cout, std::vector<uint16_t> &out);      // returns the scale applied
+void launch_conv_cls_h3(const ClsMcArgs &a, hipStream_t s);
 void cls_mc_pack_weights(const float *W, int cin, int cout, std::vector<float> &out);
 void launch_conv_cls_mc(const ClsMcArgs &a, hipStream_t s);
 

@@ -248,6 +248,28 @@ def conv3_h3_pk(x, weight, scale, shift, relu=True, mask=None, vscale=None, out_
     return out, (ms.value if iters else None), bool(ov.value & 1), bool(ov.value & 2)
 
 
+def conv_cls_h3(x, weight, scale, shift, relu=False, vscale=None, iters=0):
+    """The classifier + MC kernel on the fp16 matrix cores alone (sivo_debug_conv_cls_h3_dev).  x: cuda fp32 (T, Cin, H, W);
+    weight (C, Cin, 3, 3), scale / shift (C) numpy.  Returns (logits (T, C, H, W), (classes u8, confidence f64, entropy f64), ms)."""
+    x = x.contiguous()
+    T, Cin, H, W = x.shape
+    weight = np.ascontiguousarray(weight, np.float32)
+    scale = np.ascontiguousarray(scale, np.float32); shift = np.ascontiguousarray(shift, np.float32)
+    Cc = weight.shape[0]
+    assert weight.shape == (Cc, Cin, 3, 3) and scale.shape == (Cc,) and shift.shape == (Cc,)
+    if vscale is None:
+        vscale = float(2.0 ** (8 - np.frexp(float(x.abs().max()))[1]))
+    logits = torch.empty((T, Cc, H, W), dtype=torch.float32, device=x.device)
+    cls = torch.empty((H, W), dtype=torch.uint8, device=x.device)
+    conf = torch.empty((H, W), dtype=torch.float64, device=x.device)
+    ent = torch.empty((H, W), dtype=torch.float64, device=x.device)
+    ms = C.c_double(0)
+    check(dbg().sivo_debug_conv_cls_h3_dev(T, Cin, Cc, H, W, x.data_ptr(), weight.ctypes.data_as(C.c_void_p), scale.ctypes.data_as(C.c_void_p),
+                                           shift.ctypes.data_as(C.c_void_p), int(relu), C.c_float(vscale), logits.data_ptr(), cls.data_ptr(),
+                                           conf.data_ptr(), ent.data_ptr(), iters, C.byref(ms)))
+    return logits, (cls, conf, ent), (ms.value if iters else None)
+
+
 def mc_reduce(logits, prob_sum=None, want_prob=False, accumulate=False):
     n, K, H, W = logits.shape
     if prob_sum is None:

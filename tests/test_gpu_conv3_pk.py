@@ -153,3 +153,42 @@ def test_the_network_with_packed_activations_is_bit_identical_to_fp32_blobs(monk
         rel = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
         print(f"[{name}] packed blob vs fp32 blob: max |d| / max |x| = {rel / 2.0 ** -22:.3f} x 2^-22")
         assert rel <= 2.0 ** -21
+
+
+@pytest.mark.parametrize("T,Cin,classes,H,W", [(2, 64, 15, 8, 32), (3, 64, 15, 20, 72), (2, 32, 11, 10, 24), (4, 96, 16, 16, 40), (12, 64, 15, 352, 1024)])
+def test_classifier_on_the_fp16_matrix_cores(T, Cin, classes, H, W):
+    """conv_cls_h3.hip alone: the 3x3 classifier on f16x3 from a packed input + Softmax + f64 mean + maps.  Its logits against
+    an fp64 convolution (bound as for the direct kernel: 2^-20 of sum |w||x|), its maps bit for bit the post-processing kernel's
+    on exactly these logits; whole and ragged tiles, 1 - 3 k-steps, 11 / 15 / 16 classes; the network's shape with its launch time."""
+    from sivo_amd import segnet
+    g = torch.Generator(device="cuda").manual_seed(T * 100 + H)
+    x = (torch.randn((T, Cin, H, W), generator=g, device="cuda", dtype=torch.float32) * 2.0).clamp_min(0)
+    rng = np.random.default_rng(H + W)
+    wt = (rng.standard_normal((classes, Cin, 3, 3)) * (2.0 / (9 * Cin)) ** 0.5).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, classes).astype(np.float32)
+    shift = rng.uniform(-0.5, 0.5, classes).astype(np.float32)
+    big = H * W > 100000
+    logits, maps, ms = segnet.conv_cls_h3(x, wt, scale, shift, iters=10 if big else 0)
+    post = segnet.mc_segment(logits)
+    torch.cuda.synchronize()
+    for a, b in zip(maps, post):
+        assert torch.equal(a, b)
+    xp = torch.nn.functional.pad(x.double(), (1, 1, 1, 1))
+    wd = torch.from_numpy(wt).cuda().double()
+    worst = 0.0
+    for n in sorted({0, T - 1}):
+        ref = torch.zeros((classes, H, W), dtype=torch.float64, device="cuda")
+        mag = torch.zeros_like(ref)
+        for ky in range(3):
+            for kx in range(3):
+                ref += torch.einsum("kc,chw->khw", wd[:, :, ky, kx], xp[n, :, ky:ky + H, kx:kx + W])
+                mag += torch.einsum("kc,chw->khw", wd[:, :, ky, kx].abs(), xp[n, :, ky:ky + H, kx:kx + W].abs())
+        sc = torch.from_numpy(scale).cuda().double()[:, None, None]
+        sh = torch.from_numpy(shift).cuda().double()[:, None, None]
+        err = (logits[n].double() - (ref * sc + sh)).abs()
+        worst = max(worst, float((err / (mag * sc.abs() + sh.abs()).clamp_min(1e-30)).max()))
+    line = f"[cls {T}x{Cin}->{classes} {H}x{W}] worst |err| / sum|w||x| = {worst / 2.0 ** -24:.2f} x 2^-24"
+    if ms:
+        line += f"; {ms:.3f} ms = {T * Cin * H * W * 4 / ms / 1e9:.2f} TB/s of input, {2.0 * 9 * Cin * 16 * H * W * T * 3 / ms / 1e9:.0f} TFLOP/s executed"
+    print(line)
+    assert worst <= 2.0 ** -20
