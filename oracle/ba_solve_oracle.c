@@ -153,7 +153,9 @@ typedef struct {
     int nF;
     double *Hpp_last;            /* 36 per free pose: Hpp blocks of the last buildSystem */
     const volatile int *stop;
+    const volatile uint8_t *stop8;   /* the same as one byte (the reference's `bool *pbStopFlag`, read while the solve runs) */
 } Problem;
+#define STOPPED(p) (((p)->stop && *(p)->stop) || ((p)->stop8 && *(p)->stop8))
 
 static double active_errors(Problem *p) {
     double chi = 0;
@@ -181,7 +183,7 @@ static int lm_optimize(Problem *p, int iterations, int *trials_out) {
     double lambda = 0, ni = 2;
     int it = 0, trials = 0;
     for (; it < iterations; ++it) {
-        if (p->stop && *p->stop) break;
+        if (STOPPED(p)) break;
         double current = active_errors(p);
         /* buildSystem */
         memset(Hpp, 0, (size_t)(nF ? nF : 1) * 36 * 8); memset(bp, 0, (size_t)(n6 ? n6 : 1) * 8);
@@ -309,7 +311,7 @@ static int lm_optimize(Problem *p, int iterations, int *trials_out) {
                 if (nX) memcpy(p->points, bk_pts, (size_t)p->nX * 24);
             }
             ++qmax; ++trials;
-        } while (rho < 0 && qmax < 10 && !(p->stop && *p->stop));
+        } while (rho < 0 && qmax < 10 && !STOPPED(p));
         if (qmax == 10 || rho == 0) { ++it; break; }
     }
     free(Hpp); free(bp); free(Hll); free(bl); free(W); free(Hinv); free(S); free(xs); free(xl); free(bk_pose); free(bk_pts);
@@ -464,4 +466,39 @@ int orc_ba_optimize(double *poses, const uint8_t *fixed, int nP, double *points,
     if (!err) free(p.err);
     free(p.slot);
     return n;
+}
+
+/* One g2o::SparseOptimizer::optimize(iterations) call for the g2o stand-in of oracle/ref_shims_g2o (the reference's own
+ * Optimizer.cc compiled against it drives the schedule: which edges are active, which carry a kernel, how many iterations,
+ * when the error vectors are read).  As orc_ba_optimize, plus: points_fixed (the only-pose edges of PoseOptimization hold
+ * their map point as a constant: nothing is marginalised), err is IN/OUT (inactive edges keep the vector the previous call
+ * left, as g2o's computeActiveErrors does), the stop flag is the caller's `bool *` read as a byte while the solve runs. */
+int orc_g2o_optimize(double *poses, const uint8_t *fixed, int nP, double *points, int nX, int points_fixed, const OrcEdge *edges, int64_t nE,
+                     const double *intr, double delta_mono, double delta_stereo, const uint8_t *level, const uint8_t *robust, int iterations,
+                     double *err, double *hpp_last, const volatile uint8_t *stop_byte, int *trials) {
+    Problem p;
+    memset(&p, 0, sizeof p);
+    p.poses = poses; p.fixed = fixed; p.nP = nP; p.points = points; p.nX = nX; p.points_fixed = points_fixed; p.edges = edges; p.nE = nE; p.intr = intr;
+    p.delta_mono = delta_mono; p.delta_stereo = delta_stereo;
+    p.level = (uint8_t *)level; p.robust = (uint8_t *)robust;
+    p.err = err;
+    p.slot = malloc((size_t)(nP ? nP : 1) * sizeof(int));
+    int nF = 0;
+    for (int i = 0; i < nP; ++i) p.slot[i] = fixed[i] ? -1 : nF++;
+    p.nF = nF; p.Hpp_last = hpp_last;
+    p.stop8 = stop_byte;
+    int tr = 0;
+    const int n = lm_optimize(&p, iterations, &tr);
+    if (trials) *trials = tr;
+    free(p.slot);
+    return n;
+}
+
+/* inverse of a symmetric positive definite 6 x 6 block (BlockSolver::computeMarginals on a block-diagonal Hpp); 0 when the
+ * Cholesky factorisation fails */
+int orc_inv6_spd(const double *H, double *out) { return inv6_spd(H, out); }
+
+/* the error vector / depth test of one edge at the current estimates (EdgeSE3ProjectXYZ::computeError, isDepthPositive) */
+void orc_edge_error(const double *pose, const double *point, const OrcEdge *edge, const double *intr, double *err3, int *depth_positive) {
+    edge_eval(pose, point, edge, intr, err3, 0, 0, depth_positive);
 }

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
@@ -26,6 +27,7 @@ class Matrix {
  public:
     Matrix() : rows_(R > 0 ? R : 0), cols_(C > 0 ? C : 0), v_((size_t)(rows_ * cols_)) {}
     Matrix(int r, int c) : rows_(r), cols_(c), v_((size_t)(r * c)) {}
+    Matrix(T a, T b, T c) : rows_(R > 0 ? R : 3), cols_(C > 0 ? C : 1), v_((size_t)(rows_ * cols_)) { v_[0] = a; v_[1] = b; v_[2] = c; }   // Vector3d(x, y, z)
     template <int R2, int C2>
     Matrix(const Matrix<T, R2, C2> &o) : rows_(o.rows()), cols_(o.cols()), v_((size_t)(o.rows() * o.cols())) {
         if ((R > 0 && R != rows_) || (C > 0 && C != cols_)) std::abort();
@@ -39,6 +41,7 @@ class Matrix {
     T &operator()(int i) { return v_[(size_t)i]; }
     const T &operator()(int i) const { return v_[(size_t)i]; }
 
+    Matrix &operator*=(T s) { for (T &x : v_) x *= s; return *this; }
     static Matrix Zero() { return Matrix(); }
     static Matrix Identity() {
         Matrix m;
@@ -188,6 +191,11 @@ template <class T, int R, int C> Matrix<T, R, C> operator*(T s, const Matrix<T, 
         for (int j = 0; j < a.cols(); ++j) out(i, j) = s * a(i, j);
     return out;
 }
+// a scalar of another arithmetic type (Eigen converts it to the matrix's scalar type first): `Matrix2d::Identity() * invSigma2` with a float
+template <class T, int R, int C, class S, class = typename std::enable_if<std::is_arithmetic<S>::value && !std::is_same<S, T>::value>::type>
+Matrix<T, R, C> operator*(const Matrix<T, R, C> &a, S s) { return a * (T)s; }
+template <class T, int R, int C, class S, class = typename std::enable_if<std::is_arithmetic<S>::value && !std::is_same<S, T>::value>::type>
+Matrix<T, R, C> operator*(S s, const Matrix<T, R, C> &a) { return (T)s * a; }
 template <class T, int R1, int C1, int R2, int C2>
 Matrix<T, R1, C1> operator+(const Matrix<T, R1, C1> &a, const Matrix<T, R2, C2> &b) {
     Matrix<T, R1, C1> out(a.rows(), a.cols());

@@ -1,0 +1,2 @@
+#pragma once
+#include "../../../g2o_standin.hpp"

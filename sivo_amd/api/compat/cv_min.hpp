@@ -45,6 +45,13 @@ struct Rect {
 typedef Point_<float> Point2f;
 typedef Point_<int> Point2i;
 typedef Point2i Point;
+template <class T>
+struct Point3_ {
+    T x = 0, y = 0, z = 0;
+    Point3_() {}
+    Point3_(T x_, T y_, T z_) : x(x_), y(y_), z(z_) {}
+};
+typedef Point3_<float> Point3f;
 
 struct KeyPoint {   // 28 bytes, the layout SivoKeyPoint mirrors
     Point2f pt;
@@ -158,6 +165,12 @@ class Mat {
             for (int c = 0; c < n; ++c) o[c] = depth() == CV_8U ? (float)ptr<uchar>(r)[c] : ptr<float>(r)[c];
         }
         dst = out;
+    }
+    static Mat eye(int r, int c, int type) {          // CV_32F
+        Mat m(r, c, type);
+        for (int i = 0; i < r; ++i)
+            for (int j = 0; j < c; ++j) m.at<float>(i, j) = i == j ? 1.0f : 0.0f;
+        return m;
     }
     static Mat ones(int r, int c, int type) {
         Mat m(r, c, type);

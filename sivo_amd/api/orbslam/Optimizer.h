@@ -6,8 +6,9 @@
 // estimates are recovered" is provided here on arrays and runs on the GPU: per-edge computeError +
 // linearizeOplus + chi2 + Huber, the Levenberg-Marquardt / Schur-complement loops with the reference's
 // iteration and re-classification schedules, and the marginal pose covariance (Optimizer.cc:409-491, 757-926).
-#ifndef OPTIMIZER_H
-#define OPTIMIZER_H
+// (guard: NOT the reference's OPTIMIZER_H — a translation unit may include the reference's include/orbslam/Optimizer.h beside this one)
+#ifndef SIVO_AMD_API_OPTIMIZER_H
+#define SIVO_AMD_API_OPTIMIZER_H
 
 #include <cstdint>
 #include <vector>

@@ -209,12 +209,18 @@ void LocalBundleAdjustment(KeyFrameT *pKF, bool *pbStopFlag, MapT *pMap) {
     bool covOk = false;
     Optimizer::LocalBundleAdjustment(poses, fixedPose, points, edges, intr, pbStopFlag, erase, /*covariancePose=*/0, cov, &covOk);
 
+    // vToErase (:824-858): the monocular edges in edge order, THEN the stereo ones; a map point's isBad() is read while the list
+    // is built, i.e. before anything is erased (an erasure can turn a point bad: its later entries are still erased).  Both
+    // pinned against the reference's own Optimizer.cc by tests/cpp/pin_optimizer.cpp.
+    std::vector<size_t> vToErase;
+    for (int stereo = 0; stereo < 2; ++stereo)
+        for (size_t e = 0; e < edges.size(); ++e)
+            if ((edges[e].stereo != 0) == (stereo != 0) && erase[e] && !edgeMP[e]->isBad()) vToErase.push_back(e);
     std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);                    // :860-861
-    for (size_t e = 0; e < edges.size(); ++e)                                    // :824-858, 863-871
-        if (erase[e] && !edgeMP[e]->isBad()) {
-            edgeKF[e]->EraseMapPointMatch(edgeMP[e]);
-            edgeMP[e]->EraseObservation(edgeKF[e]);
-        }
+    for (size_t e : vToErase) {                                                  // :863-871
+        edgeKF[e]->EraseMapPointMatch(edgeMP[e]);
+        edgeMP[e]->EraseObservation(edgeKF[e]);
+    }
     for (KeyFrameT *k : lLocalKeyFrames) {                                       // :884-910
         k->SetPose(cv_from_se3(poses.data() + 12 * (size_t)poseIndex[k]));
         if (k->mnId == pKF->mnId && covOk) set_covariance(pKF, cov);

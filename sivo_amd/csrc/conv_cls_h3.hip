@@ -31,6 +31,7 @@
 #include <stdint.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <vector>
@@ -53,9 +54,16 @@ constexpr int C_NDMA = 8 * C_OST / 64;                     // 44 DMA instruction
 constexpr int C_WKS = 9 * 2 * 4 * 16 * 16;                 // weight bytes per 32-channel k-step: [tap][plane][octet][cout 16][8 halfs] = 18,432
 constexpr int C_W0 = 2 * C_STAGE;
 static_assert(C_NDMA == 44 && C_NDMA % 4 == 0, "DMA pieces per wave");
-static_assert(C_W0 + 3 * C_WKS <= 160 * 1024, "LDS");
+static_assert(C_W0 + 3 * C_WKS <= 160 * 1024 - 2048, "LDS (the last 2 KiB are the prefetch probes' scratch)");
 
-__global__ __launch_bounds__(256) void conv_cls_h3_kernel(ClsMcArgs a) {
+// NW = 4: one wave per SIMD, wave w owns rows 2 w, 2 w + 1 (four blocks of 16 pixels).  NW = 8 (the default): two waves per SIMD,
+// wave w owns row w (two blocks) — with one wave per SIMD nothing runs while a wave issues its 13 DMA pieces of the next stage,
+// waits at the stage barrier or does a sample's Softmax; the second wave's multiply fills those gaps (at the price of the
+// weight fragments being read once per two blocks instead of once per four).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv_cls_h3_kernel(ClsMcArgs a) {
+    constexpr int NB = 16 / NW;                 // 16-pixel blocks per wave: block b = (row b / 2 of the wave's rows, half b % 2)
+    constexpr int NDW = (C_NDMA + NW - 1) / NW; // DMA pieces per wave and stage
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_c[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,15 +82,15 @@ __global__ __launch_bounds__(256) void conv_cls_h3_kernel(ClsMcArgs a) {
     // ---- the filter bank: nks x 18 pieces of 1 KiB, wave w copies pieces w, w + 4, ...
     {
         const unsigned char *wsrc = static_cast<const unsigned char *>(a.wt_h3);
-        for (int pc = wave; pc < 18 * nks; pc += 4) lds_dma16_s(wsrc, (uint32_t)(pc * 1024 + lane * 16), lds_base + C_W0 + pc * 1024);
+        for (int pc = wave; pc < 18 * nks; pc += NW) lds_dma16_s(wsrc, (uint32_t)(pc * 1024 + lane * 16), lds_base + C_W0 + pc * 1024);
     }
     // ---- patch DMA plan: instruction j = wave + 4 i (i = 0 .. 10) fills pieces 64 j .. 64 j + 63 of the stage image
     // [plane][octet][352]: piece q = (plane * 4 + octet) * 352 + r, r < 340: patch pixel (r / 34, r % 34); pad pieces copy a
     // valid address.  Source: [n][C / 8][plane][Hp][Wp] pieces, patch row 0 = image row y0 - 1 = padded row y0.
-    uint32_t voff[11];
+    uint32_t voff[NDW];
 #pragma unroll
-    for (int i = 0; i < 11; ++i) {
-        const int q = (wave + 4 * i) * 64 + lane;
+    for (int i = 0; i < NDW; ++i) {
+        const int q0 = (wave + NW * i) * 64 + lane, q = q0 < 8 * C_OST ? q0 : 0;
         const int po = q / C_OST, r = q - po * C_OST;
         const int pl = po >> 2, o = po & 3;
         const int rr = r < C_NPX ? r : 0;
@@ -94,13 +102,40 @@ __global__ __launch_bounds__(256) void conv_cls_h3_kernel(ClsMcArgs a) {
     auto issue_stage = [&](int s, int ks, int buf) __attribute__((always_inline)) {
         const unsigned char *sb = tile_src + (int64_t)s * a.in_pk_sample_bytes + ks * ks_stride;
 #pragma unroll
-        for (int i = 0; i < 11; ++i) lds_dma16_s(sb, voff[i], lds_base + buf * C_STAGE + (wave + 4 * i) * 1024);
+        for (int i = 0; i < NDW; ++i)
+            if ((i + 1) * NW <= C_NDMA || wave + NW * i < C_NDMA) lds_dma16_s(sb, voff[i], lds_base + buf * C_STAGE + (wave + NW * i) * 1024);
+    };
+
+    // ---- L2 prefetch of the stage AFTER the one whose DMA is in flight.  With two patch buffers only one stage (44 KB per CU) can
+    // be on its way into LDS, and a stage's DMA is issued when its buffer becomes free: measured 0.55 ms = 2.0 TB/s with a stage
+    // waiting ~3 us for its data.  Touching every 128-byte line of the NEXT stage's source rows (80 rows of 544 bytes: 6 probes
+    // each, two dword LDS-DMAs per wave into a scratch corner of LDS: loads without a register destination, so nothing the
+    // compiler could copy or reuse while they are in flight — a first form with register destinations corrupted the frame)
+    // brings it into this XCD's L2 a stage earlier, so the DMA that follows is an L2 hit.  The probes are issued BEHIND the
+    // stage's DMA and complete in issue order, so the wait at the top of the next iteration is vmcnt(2): everything but the two
+    // probes.
+    uint32_t pf_off[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = NW == 4 ? tid + 256 * k : (tid & 255) + 256 * k, row = i / 6 < 80 ? i / 6 : 79, seg = i - (i / 6) * 6;
+        const int po = row / C_PR, py = row - po * C_PR;                  // po = plane * 4 + octet as in the stage image
+        const int byte = seg * 128 < 540 ? seg * 128 : 540;
+        pf_off[k] = (uint32_t)((((po & 3) * 2 + (po >> 2)) * a.in_Hp + py) * a.in_Wp * 16 + byte);
+    }
+    const uint32_t pf_lds = lds_base + (uint32_t)(160 * 1024 - 2048) + (uint32_t)(wave & 3) * 512;       // 2 x 256 bytes of scratch per probing wave
+    constexpr int NPROBE = 2;                   // probes per probing wave (waves 0 .. 3) and stage
+    auto prefetch_stage = [&](int s, int ks) __attribute__((always_inline)) {
+        const unsigned char *sb = tile_src + (int64_t)s * a.in_pk_sample_bytes + ks * ks_stride;
+        if (wave < 4) {
+            lds_dma4_s(sb, pf_off[0], pf_lds);
+            lds_dma4_s(sb, pf_off[1], pf_lds + 256);
+        }
     };
 
     // ---- MFMA operands: A = weights [cout = lane & 15][octet = lane >> 4], B = patch [octet = lane >> 4][pixel = lane & 15]
     const uint32_t a_off = (uint32_t)(C_W0 + lane * 16);
-    // block b = 2 rr + h of wave w: row 2 w + rr, columns 16 h .. 16 h + 15
-    const uint32_t b_off = (uint32_t)((lg * C_OST + (2 * wave) * C_PW + lp) * 16);
+    // block b = 2 rr + h of wave w: row (NB / 2) w + rr, columns 16 h .. 16 h + 15
+    const uint32_t b_off = (uint32_t)((lg * C_OST + ((NB / 2) * wave) * C_PW + lp) * 16);
     f32x4 acc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -108,41 +143,64 @@ __global__ __launch_bounds__(256) void conv_cls_h3_kernel(ClsMcArgs a) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) sum[c] = 0.0;
 
-    // the pixel this lane post-processes: pixel lp of block lg of its wave
-    const int prow = 2 * wave + (lg >> 1), pcol = 16 * (lg & 1) + lp;
+    // the pixel this lane post-processes: pixel lp of block lg of its wave (NW = 8: blocks 0, 1 exist — the lanes of rows 2, 3 idle)
+    const int prow = (NB / 2) * wave + (lg >> 1), pcol = 16 * (lg & 1) + lp;
     const int gy = y0 + prow, gx = x0 + pcol;
-    const bool pix_ok = gy < a.H && gx < a.W;
+    const bool pix_ok = lg < NB && gy < a.H && gx < a.W;
     const int64_t pix = (int64_t)gy * a.W + gx;
     const float mscale = 1.f / (a.h3_vscale * a.h3_uscale);
 
     issue_stage(0, 0, 0);
     const int total = a.T * nks;
     int s = 0, ks = 0;
+    bool probes_behind = false;         // the newest two vector-memory operations of this wave are prefetch probes
+    if (1 < total) { prefetch_stage(nks > 1 ? 0 : 1, nks > 1 ? 1 : 0); probes_behind = true; }
     for (int g = 0; g < total; ++g) {
         // this wave's DMA of stage g (and, g = 0, of the filter bank) has landed; behind the barrier everybody's has, and nobody
-        // reads the other buffer (stage g - 1) any more
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // reads the other buffer (stage g - 1) any more.  (a.logits: the diagnostic stores of a sample's epilogue sit behind the
+        // probes in the queue — wait for everything then)
+        if (probes_behind && !a.logits && wave < 4) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(NPROBE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        probes_behind = false;
         int s2 = s, k2 = ks + 1;
         if (k2 == nks) { k2 = 0; ++s2; }
+        int s3 = s2, k3 = k2 + 1;
+        if (k3 == nks) { k3 = 0; ++s3; }
         if (g + 1 < total) issue_stage(s2, k2, (g + 1) & 1);
+        if (g + 2 < total) {
+            prefetch_stage(s3, k3);
+            probes_behind = true;
+        }
         const unsigned char *ps = lds_c + (g & 1) * C_STAGE + b_off, *ws = lds_c + a_off + ks * C_WKS;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        // fragments one tap ahead: [10 ds_read_b128 of tap t + 1][12 MFMAs of tap t].  With ONE wave per SIMD nothing else covers an
+        // LDS round trip: left alone, hipcc placed every read right in front of its first use (35 lgkmcnt waits per stage in the
+        // .s) and a stage took ~8 k cycles for ~1.8 k cycles of MFMAs.
+        half8 A[2][2], B[2][NB][2];
+        auto fetch = [&](int t, int par) __attribute__((always_inline)) {
             const int ky = t / 3, kx = t - 3 * ky;
-            half8 A[2], B[4][2];
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) A[pl] = *reinterpret_cast<const half8 *>(ws + (t * 2 + pl) * 1024);
+            for (int pl = 0; pl < 2; ++pl) A[par][pl] = *reinterpret_cast<const half8 *>(ws + (t * 2 + pl) * 1024);
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
-                    B[b][pl] = *reinterpret_cast<const half8 *>(ps + pl * (4 * C_OST * 16) + (((b >> 1) + ky) * C_PW + (b & 1) * 16 + kx) * 16);
+                    B[par][b][pl] = *reinterpret_cast<const half8 *>(ps + pl * (4 * C_OST * 16) + (((b >> 1) + ky) * C_PW + (b & 1) * 16 + kx) * 16);
+        };
+        fetch(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * NB, 0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t + 1 < 9) {
+                fetch(t + 1, (t + 1) & 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * NB, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NB, 0);
             // smallest terms first: (lo, hi) (hi, lo) (hi, hi); consecutive MFMAs on different accumulators
 #pragma unroll
             for (int term = 0; term < 3; ++term) {
                 constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[PA[term]], B[b][PB[term]], acc[b], 0, 0, 0);
+                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t & 1][PA[term]], B[t & 1][b][PB[term]], acc[b], 0, 0, 0);
             }
         }
         if (ks == nks - 1) {
@@ -170,6 +228,7 @@ __global__ __launch_bounds__(256) void conv_cls_h3_kernel(ClsMcArgs a) {
         }
         s = s2; ks = k2;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the last probes: no LDS-DMA may be in flight when the workgroup ends)
     if (!pix_ok) return;
 #include "conv_cls_mc_maps.inc"
 }
@@ -229,10 +288,18 @@ void launch_conv_cls_h3(const ClsMcArgs &a0, hipStream_t s) {
         throw std::invalid_argument("launch_conv_cls_h3: unsupported layer / packed input plane too small");
     if (a.sum_chunk <= 0 || a.sum_chunk > (int64_t)a.H * a.W) a.sum_chunk = (int64_t)a.H * a.W;
     static int attr_set[64] = {0};
-    if (FirstUse once(attr_set); once)
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_cls_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (FirstUse once(attr_set); once) {
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_cls_h3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_cls_h3_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     const int P = a.tiles_x * a.tiles_y, per = (P + 7) / 8;
-    hipLaunchKernelGGL(conv_cls_h3_kernel, dim3((unsigned)(8 * per)), dim3(256), (size_t)160 * 1024, s, a);
+#ifdef SIVO_DIAG
+    if (std::getenv("SIVO_CLS_NW") && std::atoi(std::getenv("SIVO_CLS_NW")) == 4) {        // diagnostic build: the one-wave-per-SIMD form
+        hipLaunchKernelGGL(conv_cls_h3_kernel<4>, dim3((unsigned)(8 * per)), dim3(256), (size_t)160 * 1024, s, a);
+        return;
+    }
+#endif
+    hipLaunchKernelGGL(conv_cls_h3_kernel<8>, dim3((unsigned)(8 * per)), dim3(512), (size_t)160 * 1024, s, a);
 }
 
 }  // namespace sivo

@@ -36,6 +36,16 @@ __device__ __forceinline__ void lds_dma16_s(const void *sbase, uint32_t voff, ui
                  : "memory");
 }
 
+// 64 lanes x 4 bytes with a scalar base: lane l copies the dword at sbase + voff to LDS address lds_byte_addr + 4 l (used as an
+// L2 prefetch probe: a load without a register destination — nothing the compiler could move or reuse while it is in flight).
+__device__ __forceinline__ void lds_dma4_s(const void *sbase, uint32_t voff, uint32_t lds_byte_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
+                 : "memory");
+}
+
 // Workgroup barrier without the vmcnt(0) drain of __syncthreads(): this wave's LDS traffic done + s_barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 

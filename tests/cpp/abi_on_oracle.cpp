@@ -39,6 +39,14 @@ int orc_search_by_bow_kf_frame(int n_nodes, const int32_t *off1, const int32_t *
 int orc_search_by_bow_kf_kf(int n_nodes, const int32_t *off1, const int32_t *idx1, const int32_t *off2, const int32_t *idx2,
                             const uint8_t *valid1, const OrcKp *keys1, const uint8_t *desc1, int n1, const uint8_t *valid2, const OrcKp *keys2,
                             const uint8_t *desc2, int n2, float mfNNratio, int mbCheckOrientation, int32_t *matches12);
+struct OrcEdge;
+int orc_pose_optimize(const double *pose0, const double *points, const OrcEdge *edges_in, int64_t nE, const double *intr, uint8_t *outlier,
+                      double *pose_out, double *cov, int *cov_ok, double *chi2_out, int *iters, int *trials);
+int orc_local_ba(double *poses, const uint8_t *fixed, int nP, double *points, int nX, const OrcEdge *edges, int64_t nE, const double *intr,
+                 const int *stop, uint8_t *outlier, int cov_pose, double *cov, int *cov_ok, int *iters, int *trials);
+int orc_g2o_optimize(double *poses, const uint8_t *fixed, int nP, double *points, int nX, int points_fixed, const OrcEdge *edges, int64_t nE,
+                     const double *intr, double delta_mono, double delta_stereo, const uint8_t *level, const uint8_t *robust, int iterations,
+                     double *err, double *hpp_last, const volatile uint8_t *stop_byte, int *trials);
 int orc_search_for_triangulation(int n_nodes, const int32_t *off1, const int32_t *idx1, const int32_t *off2, const int32_t *idx2,
                                  const OrcKp *keys1, const float *mvRight1, const uint8_t *has_mp1, const uint8_t *desc1, int n1,
                                  const OrcKp *keys2, const float *mvRight2, const uint8_t *has_mp2, const uint8_t *desc2, int n2,
@@ -149,6 +157,44 @@ int sivo_search_for_triangulation(int n_nodes, const int32_t *off1, const int32_
                                               n1, kf2->kp(), kf2->right.data(), has_mp2, kf2->desc.data(), (int)kf2->keys.size(), F12, ex, ey,
                                               kf2->scale.data(), kf2->sigma2.data(), only_stereo, check_orientation, matches12);
     return SIVO_OK;
+}
+// ---- the optimisation loops (include/sivo_hip.h: sivo_pose_optimize / sivo_local_ba / sivo_ba_optimize) over
+// oracle/ba_solve_oracle.c, for tests/cpp/pin_optimizer.cpp: the SIVO::Optimizer member templates (gather -> C ABI -> scatter) run
+// without a GPU and are compared with the reference's own Optimizer.cc (oracle/_ref/ref_optimizer.o over the g2o stand-in).
+int sivo_pose_optimize(const double pose0[12], const double *points, int, const SivoEdge *edges, int64_t n_edges, const double intr[5],
+                       uint8_t *outlier, double pose_out[12], double cov[36], int *cov_ok, double *chi2, int *n_inliers, int *iterations,
+                       int *trials) {
+    const int n = orc_pose_optimize(pose0, points, reinterpret_cast<const OrcEdge *>(edges), n_edges, intr, outlier, pose_out, cov, cov_ok, chi2,
+                                    iterations, trials);
+    if (n_inliers) *n_inliers = n;
+    return SIVO_OK;
+}
+int sivo_local_ba(double *poses, const uint8_t *pose_fixed, int n_poses, double *points, int n_points, const SivoEdge *edges, int64_t n_edges,
+                  const double intr[5], const volatile uint8_t *stop_flag, uint8_t *outlier, int cov_pose, double *cov, int *cov_ok,
+                  int *iterations, int *trials) {
+    // (the oracle entry point polls an int; the reference's flag is a bool that the tests here never raise mid-solve)
+    int stop = stop_flag && *stop_flag ? 1 : 0;
+    orc_local_ba(poses, pose_fixed, n_poses, points, n_points, reinterpret_cast<const OrcEdge *>(edges), n_edges, intr, stop_flag ? &stop : nullptr,
+                 outlier, cov_pose, cov, cov_ok, iterations, trials);
+    return SIVO_OK;
+}
+int sivo_ba_optimize(double *poses, const uint8_t *pose_fixed, int n_poses, double *points, int n_points, const SivoEdge *edges, int64_t n_edges,
+                     const double intr[5], double delta_mono, double delta_stereo, const uint8_t *level, const uint8_t *robust, int iterations,
+                     const volatile uint8_t *stop_flag, double *err_out, double *hpp_last_out, int *iterations_run, int *trials) {
+    std::vector<uint8_t> lv(level ? level : nullptr, level ? level + n_edges : nullptr), rb(robust ? robust : nullptr, robust ? robust + n_edges : nullptr);
+    if (!level) lv.assign((size_t)n_edges, 0);
+    if (!robust) rb.assign((size_t)n_edges, 1);
+    std::vector<double> err((size_t)(n_edges ? n_edges : 1) * 3, 0.0);
+    const int n = orc_g2o_optimize(poses, pose_fixed, n_poses, points, n_points, 0, reinterpret_cast<const OrcEdge *>(edges), n_edges, intr, delta_mono,
+                                   delta_stereo, lv.data(), rb.data(), iterations, err.data(), hpp_last_out, stop_flag, trials);
+    if (err_out) std::memcpy(err_out, err.data(), (size_t)n_edges * 24);
+    if (iterations_run) *iterations_run = n;
+    return SIVO_OK;
+}
+// SIVO::Optimizer::LinearizeEdges is not part of this comparison.
+int sivo_ba_linearize(const double *, int, const double *, int, const SivoEdge *, int64_t, const double *, double, double, double *, double *, double *,
+                      double *, double *, double *, uint8_t *) {
+    std::abort();
 }
 // SIVO::ORBmatcher::BestTwo is not part of this comparison.
 int sivo_hamming_argmin2(const uint8_t *, int, const uint8_t *, int, const int32_t *, const int32_t *, int32_t *, int32_t *, int32_t *,

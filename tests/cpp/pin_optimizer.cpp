@@ -1,0 +1,443 @@
+// pin_optimizer.cpp — SIVO::Optimizer of this repository (sivo_amd/api/orbslam/Optimizer.h + OptimizerAdapter.h: the reference's
+// static members as templates over the SLAM types: graph walk -> arrays -> C ABI -> write-back) against the reference's OWN
+// src/orbslam/Optimizer.cc, compiled untouched over the g2o stand-in of oracle/ref_shims_g2o (oracle/_ref/ref_optimizer.o;
+// class renamed RefOptimizer).  Both run on identical, separately built copies of deterministic scenes:
+//     PoseOptimization(Frame *)                          Optimizer.cc:273-491   (Tracking.cc:617,753,792)
+//     LocalBundleAdjustment(KeyFrame *, bool *, Map *)   Optimizer.cc:493-926   (LocalMapping.cc:83)
+//     BundleAdjustment / GlobalBundleAdjustment          Optimizer.cc:37-271    (LoopClosing.cc:667, Tracking.cc)
+// mono + stereo observations over all pyramid levels, planted outliers, bad map points and a bad keyframe, fixed keyframes
+// (seeing local points without being covisible), the map's first keyframe inside and outside the window, pbStopFlag null /
+// clear / raised before the call, fewer than 3 and fewer than 10 correspondences, nLoopKF = 0 and != 0, bRobust on and off.
+// Compared per case: the return value, the ORDERED log of every mutation of the object graph (SetPose, SetCovariance,
+// EraseMapPointMatch, EraseObservation, SetWorldPos, UpdateNormalAndDepth), mvbOutlier, the surviving observations, the BA marks
+// (mnBALocalForKF / mnBAFixedForKF / mnBAGlobalForKF), poses and points (float matrices: <= 2e-6 relative; bitwise-equal
+// counts are printed), covariances (1e-7 relative).
+//   link variants (tests/cpp/Makefile): *_cpu = the C ABI over the CPU oracle (abi_on_oracle.cpp), *_gpu = libsivo_hip.so.
+//   pin_optimizer_*     with the reference (oracle/_ref/, needs /root/reference at build time); --write-golden <file> records
+//                       the reference's results
+//   golden_optimizer_*  without the reference (-DPIN_NO_REFERENCE): this repository's side against tests/golden/optimizer_reference.txt
+#include <cinttypes>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#ifndef PIN_NO_REFERENCE
+#define Optimizer RefOptimizer
+#include "include/orbslam/Optimizer.h"      // oracle/ref_shims_g2o: the reference's declaration over the stand-in types
+#undef Optimizer
+#else
+#include "optimizer_standins.h"
+#endif
+std::mutex SIVO::MapPoint::mGlobalMutex;
+
+#include "orbslam/Optimizer.h"              // sivo_amd/api: this repository's class (+ OptimizerAdapter.h)
+
+using namespace SIVO;
+
+namespace {
+
+struct Rng {
+    uint64_t s;
+    explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull) {}
+    uint32_t u32() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 16); }
+    double uni() { return (u32() & 0xffffff) / 16777216.0; }
+    double range(double a, double b) { return a + (b - a) * uni(); }
+    double gauss() { double v = 0; for (int i = 0; i < 12; ++i) v += uni(); return v - 6.0; }
+};
+
+const float FX = 718.856f, FY = 718.856f, CX = 607.1928f, CY = 185.2157f, BF = 386.1448f;
+const int IMG_W = 1241, IMG_H = 376;
+
+struct SceneSpec {
+    uint64_t seed;
+    int nKF, nMP;
+    unsigned long firstId;        // mnId of the oldest keyframe (0: the map's first keyframe takes part)
+    int covisible;                // how many predecessors of the current keyframe are covisible with it
+    double outlierFrac, monoFrac;
+    int badPoints;
+    bool badKeyFrame;
+};
+
+// (vectors reserved up front: the reference keys std::map by KeyFrame *, i.e. iterates observations in ADDRESS order — both copies
+// of a scene must therefore place their keyframes in the same relative order, which a contiguous array guarantees)
+struct Scene {
+    std::vector<KeyFrame> kfs;
+    std::vector<MapPoint> mps;
+    Map map;
+};
+
+cv::Mat pose_mat(double yaw, double pitch, double tx, double ty, double tz) {
+    const double cyw = std::cos(yaw), syw = std::sin(yaw), cp = std::cos(pitch), sp = std::sin(pitch);
+    const double R[9] = {cyw, 0, syw, sp * syw, cp, -sp * cyw, -cp * syw, sp, cp * cyw};
+    cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) T.at<float>(r, c) = (float)R[3 * r + c];
+    T.at<float>(0, 3) = (float)tx; T.at<float>(1, 3) = (float)ty; T.at<float>(2, 3) = (float)tz;
+    return T;
+}
+
+// a keyframe trajectory moving forward, points in front of it, every keyframe observing what falls into its image
+void build_scene(const SceneSpec &sp, Scene &S) {
+    Rng rng(sp.seed);
+    std::vector<float> invSigma2(8);
+    for (int l = 0; l < 8; ++l) invSigma2[(size_t)l] = 1.0f / (float)std::pow(1.2 * 1.2, l);
+    std::vector<cv::Mat> truePose((size_t)sp.nKF);
+    S.kfs.reserve((size_t)sp.nKF);
+    S.mps.reserve((size_t)sp.nMP);
+    for (int k = 0; k < sp.nKF; ++k) {
+        S.kfs.emplace_back();
+        KeyFrame &kf = S.kfs.back();
+        kf.mnId = sp.firstId + (unsigned long)k;
+        kf.Frame::mnId = (long)kf.mnId;
+        kf.fx = FX; kf.fy = FY; kf.cx = CX; kf.cy = CY; kf.mbf = BF;
+        kf.mvInvLevelSigma2 = invSigma2;
+        // Tcw of a camera that has moved k * 0.8 m forward (world z), with a slow yaw
+        const double yaw = 0.01 * k + rng.range(-0.004, 0.004), pitch = rng.range(-0.003, 0.003);
+        truePose[(size_t)k] = pose_mat(yaw, pitch, rng.range(-0.05, 0.05), rng.range(-0.02, 0.02), -0.8 * k);
+        // the estimate the optimizer starts from: the truth, slightly off
+        cv::Mat est = pose_mat(yaw + rng.range(-0.002, 0.002), pitch + rng.range(-0.002, 0.002), truePose[(size_t)k].at<float>(0, 3) + rng.range(-0.03, 0.03),
+                               truePose[(size_t)k].at<float>(1, 3) + rng.range(-0.02, 0.02), truePose[(size_t)k].at<float>(2, 3) + rng.range(-0.04, 0.04));
+        kf.mTcw = est;
+        S.map.keyframes.push_back(&kf);
+    }
+    for (int m = 0; m < sp.nMP; ++m) {
+        S.mps.emplace_back();
+        MapPoint &mp = S.mps.back();
+        mp.mnId = 1000 + (unsigned long)m;
+        const double X = rng.range(-14, 14), Y = rng.range(-2.5, 2.5), Z = rng.range(4, 30) + 0.4 * sp.nKF;
+        cv::Mat P(3, 1, CV_32F);
+        P.at<float>(0) = (float)(X + 0.05 * rng.gauss()); P.at<float>(1) = (float)(Y + 0.03 * rng.gauss()); P.at<float>(2) = (float)(Z + 0.08 * rng.gauss());
+        mp.mWorldPos = P;
+        S.map.points.push_back(&mp);
+        for (int k = 0; k < sp.nKF; ++k) {
+            KeyFrame &kf = S.kfs[(size_t)k];
+            const cv::Mat &T = truePose[(size_t)k];
+            const double x = T.at<float>(0, 0) * X + T.at<float>(0, 1) * Y + T.at<float>(0, 2) * Z + T.at<float>(0, 3);
+            const double y = T.at<float>(1, 0) * X + T.at<float>(1, 1) * Y + T.at<float>(1, 2) * Z + T.at<float>(1, 3);
+            const double z = T.at<float>(2, 0) * X + T.at<float>(2, 1) * Y + T.at<float>(2, 2) * Z + T.at<float>(2, 3);
+            if (z < 1.0) continue;
+            double u = FX * x / z + CX, v = FY * y / z + CY;
+            if (u < 20 || u > IMG_W - 20 || v < 20 || v > IMG_H - 20) continue;
+            if (rng.uni() < 0.25) continue;                       // not every keyframe that could see a point has matched it
+            const int oct = (int)(rng.u32() % 8);
+            const double sigma = 0.7 * std::pow(1.2, oct);
+            u += sigma * rng.gauss(); v += sigma * rng.gauss();
+            double ur = u - BF / z + sigma * rng.gauss();
+            if (rng.uni() < sp.outlierFrac) { u += rng.range(12, 40) * (rng.uni() < 0.5 ? -1 : 1); v += rng.range(-25, 25); ur += rng.range(-30, 30); }
+            cv::KeyPoint kp((float)u, (float)v, 31.f, -1, 0, oct);
+            const size_t idx = kf.mvKeysSemantic.size();
+            kf.mvKeysSemantic.push_back(kp);
+            kf.mvRight.push_back(rng.uni() < sp.monoFrac ? -1.f : (float)ur);
+            kf.mvpMapPoints.push_back(&mp);
+            kf.mvbOutlier.push_back(false);
+            mp.mObservations[&kf] = idx;
+            mp.nObs += kf.mvRight.back() >= 0 ? 2 : 1;
+            if (!mp.mpRefKF) mp.mpRefKF = &kf;
+        }
+    }
+    for (KeyFrame &kf : S.kfs) kf.numSemanticKeys = (int)kf.mvKeysSemantic.size();
+    for (int b = 0; b < sp.badPoints && b < sp.nMP; ++b) S.mps[(size_t)((b * 37 + 5) % sp.nMP)].mbBad = true;
+    if (sp.badKeyFrame && sp.nKF > 4) S.kfs[(size_t)(sp.nKF - 3)].mbBad = true;
+    // covisibility of the current (= newest) keyframe: its predecessors, nearest first
+    KeyFrame &cur = S.kfs.back();
+    for (int c = 1; c <= sp.covisible && c < sp.nKF; ++c) {
+        KeyFrame *o = &S.kfs[(size_t)(sp.nKF - 1 - c)];
+        cur.mvpOrderedConnectedKeyFrames.push_back(o);
+        cur.mConnectedKeyFrameWeights[o] = 200 - c;
+    }
+}
+
+// ---- the state both sides are compared on ------------------------------------------------------------------------------------
+struct Snapshot {
+    long ret = 0;
+    std::vector<OptEvent> log;
+    std::vector<int> discrete;           // outlier flags, marks, surviving observations ...
+    std::vector<float> floats;           // poses, points (what the reference stores as CV_32F)
+    std::vector<double> doubles;         // covariances
+};
+
+void snap_mat(const cv::Mat &m, std::vector<float> &out) {
+    for (int r = 0; r < m.rows; ++r)
+        for (int c = 0; c < m.cols; ++c) out.push_back(m.at<float>(r, c));
+}
+
+Snapshot snap_scene(const Scene &S, long ret) {
+    Snapshot s;
+    s.ret = ret;
+    s.log = opt_log();
+    for (const KeyFrame &kf : S.kfs) {
+        snap_mat(kf.mTcw, s.floats);
+        if (!kf.mTcwGBA.empty()) snap_mat(kf.mTcwGBA, s.floats);
+        s.discrete.push_back((int)kf.mnBALocalForKF); s.discrete.push_back((int)kf.mnBAFixedForKF); s.discrete.push_back((int)kf.mnBAGlobalForKF);
+        s.discrete.push_back(kf.covarianceSet ? 1 : 0);
+        if (kf.covarianceSet) s.doubles.insert(s.doubles.end(), kf.mSigmacw, kf.mSigmacw + 36);
+        for (const MapPoint *p : kf.mvpMapPoints) s.discrete.push_back(p ? (int)p->mnId : -1);
+    }
+    for (const MapPoint &mp : S.mps) {
+        snap_mat(mp.mWorldPos, s.floats);
+        if (!mp.mPosGBA.empty()) snap_mat(mp.mPosGBA, s.floats);
+        s.discrete.push_back((int)mp.mnBALocalForKF); s.discrete.push_back((int)mp.mnBAGlobalForKF); s.discrete.push_back(mp.mbBad ? 1 : 0);
+        s.discrete.push_back(mp.normalUpdates); s.discrete.push_back(mp.nObs);
+        for (const auto &o : mp.mObservations) { s.discrete.push_back((int)o.first->mnId); s.discrete.push_back((int)o.second); }
+    }
+    return s;
+}
+
+Snapshot snap_frame(const Frame &F, long ret) {
+    Snapshot s;
+    s.ret = ret;
+    s.log = opt_log();
+    snap_mat(F.mTcw, s.floats);
+    for (bool b : F.mvbOutlier) s.discrete.push_back(b ? 1 : 0);
+    s.discrete.push_back(F.covarianceSet ? 1 : 0);
+    if (F.covarianceSet) s.doubles.insert(s.doubles.end(), F.mSigmacw, F.mSigmacw + 36);
+    return s;
+}
+
+int failures = 0;
+#define CHECK(cond, ...)                                                                            \
+    do {                                                                                            \
+        if (!(cond)) { std::printf("FAIL %s:%d %s  ", __FILE__, __LINE__, #cond); std::printf(__VA_ARGS__); std::printf("\n"); ++failures; } \
+    } while (0)
+
+uint64_t fnv(const void *p, size_t n, uint64_t h = 1469598103934665603ull) {
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+uint64_t discrete_hash(const Snapshot &s) {
+    uint64_t h = fnv(&s.ret, sizeof s.ret);
+    for (const OptEvent &e : s.log) { h = fnv(&e.kind, sizeof e.kind, h); h = fnv(&e.a, sizeof e.a, h); h = fnv(&e.b, sizeof e.b, h); }
+    if (!s.discrete.empty()) h = fnv(s.discrete.data(), s.discrete.size() * sizeof(int), h);
+    return h;
+}
+
+// this repository's result against the reference's
+void compare(const char *name, const Snapshot &ref, const Snapshot &got) {
+    CHECK(ref.ret == got.ret, "%s: return value %ld vs %ld", name, ref.ret, got.ret);
+    CHECK(ref.log.size() == got.log.size(), "%s: %zu vs %zu logged mutations", name, ref.log.size(), got.log.size());
+    if (ref.log.size() != got.log.size()) {
+        int nr[8] = {0}, ng[8] = {0};
+        for (const OptEvent &e : ref.log) ++nr[e.kind & 7];
+        for (const OptEvent &e : got.log) ++ng[e.kind & 7];
+        for (int k = 0; k < 8; ++k) if (nr[k] != ng[k]) std::printf("    mutation kind %d: %d vs %d\n", k, nr[k], ng[k]);
+    }
+    size_t first_bad = ref.log.size();
+    for (size_t i = 0; i < ref.log.size() && i < got.log.size(); ++i)
+        if (!(ref.log[i] == got.log[i])) { first_bad = i; break; }
+    CHECK(first_bad == ref.log.size() || ref.log.size() != got.log.size(), "%s: mutation %zu differs: kind %d (%ld, %ld) vs kind %d (%ld, %ld)", name, first_bad,
+          ref.log[first_bad].kind, ref.log[first_bad].a, ref.log[first_bad].b, got.log[first_bad].kind, got.log[first_bad].a, got.log[first_bad].b);
+    CHECK(ref.discrete == got.discrete, "%s: outlier flags / marks / observations differ", name);
+    CHECK(ref.floats.size() == got.floats.size() && ref.doubles.size() == got.doubles.size(), "%s: result sizes differ", name);
+    double worst_f = 0, worst_d = 0;
+    size_t equal = 0;
+    for (size_t i = 0; i < ref.floats.size() && i < got.floats.size(); ++i) {
+        equal += ref.floats[i] == got.floats[i];
+        worst_f = std::fmax(worst_f, std::fabs((double)ref.floats[i] - got.floats[i]) / std::fmax(1.0, std::fabs((double)ref.floats[i])));
+    }
+    for (size_t i = 0; i < ref.doubles.size() && i < got.doubles.size(); ++i)
+        worst_d = std::fmax(worst_d, std::fabs(ref.doubles[i] - got.doubles[i]) / std::fmax(1e-300, std::fmax(std::fabs(ref.doubles[i]), 1e-9)));
+    CHECK(worst_f <= 2e-6, "%s: poses / points differ by %.3e", name, worst_f);
+    CHECK(worst_d <= 1e-7, "%s: covariances differ by %.3e relative", name, worst_d);
+    std::printf("%-44s return %4ld  %4zu mutations  %5zu flags  floats %zu / %zu bitwise equal (max rel diff %.1e)  covariance max rel diff %.1e\n", name,
+                ref.ret, ref.log.size(), ref.discrete.size(), equal, ref.floats.size(), worst_f, worst_d);
+}
+
+struct Case {
+    std::string name;
+    Snapshot ref, got;
+};
+std::vector<Case> cases;
+
+// ---- PoseOptimization --------------------------------------------------------------------------------------------------------
+struct PoseSpec { uint64_t seed; int nKeys; double nullFrac, monoFrac, outlierFrac; };
+
+void build_frame(const PoseSpec &sp, Frame &F, std::deque<MapPoint> &mps) {
+    Rng rng(sp.seed);
+    F.mnId = (long)sp.seed;
+    F.fx = FX; F.fy = FY; F.cx = CX; F.cy = CY; F.mbf = BF;
+    F.mvInvLevelSigma2.resize(8);
+    for (int l = 0; l < 8; ++l) F.mvInvLevelSigma2[(size_t)l] = 1.0f / (float)std::pow(1.2 * 1.2, l);
+    const cv::Mat T = pose_mat(0.03, -0.01, 0.2, -0.05, -1.1);
+    F.mTcw = pose_mat(0.03 + rng.range(-0.01, 0.01), -0.01 + rng.range(-0.005, 0.005), 0.2 + rng.range(-0.1, 0.1), -0.05 + rng.range(-0.05, 0.05), -1.1 + rng.range(-0.15, 0.15));
+    for (int i = 0; i < sp.nKeys; ++i) {
+        const double X = rng.range(-12, 12), Y = rng.range(-2.5, 2.5), Z = rng.range(4, 35);
+        const double x = T.at<float>(0, 0) * X + T.at<float>(0, 1) * Y + T.at<float>(0, 2) * Z + T.at<float>(0, 3);
+        const double y = T.at<float>(1, 0) * X + T.at<float>(1, 1) * Y + T.at<float>(1, 2) * Z + T.at<float>(1, 3);
+        const double z = T.at<float>(2, 0) * X + T.at<float>(2, 1) * Y + T.at<float>(2, 2) * Z + T.at<float>(2, 3);
+        const int oct = (int)(rng.u32() % 8);
+        const double sigma = 0.7 * std::pow(1.2, oct);
+        double u = FX * x / z + CX + sigma * rng.gauss(), v = FY * y / z + CY + sigma * rng.gauss(), ur = u - BF / z + sigma * rng.gauss();
+        if (rng.uni() < sp.outlierFrac) { u += rng.range(10, 35) * (rng.uni() < 0.5 ? -1 : 1); v += rng.range(-20, 20); ur += rng.range(-25, 25); }
+        F.mvKeysSemantic.push_back(cv::KeyPoint((float)u, (float)v, 31.f, -1, 0, oct));
+        F.mvRight.push_back(rng.uni() < sp.monoFrac ? -1.f : (float)ur);
+        F.mvbOutlier.push_back(rng.uni() < 0.3);              // stale flags from the previous call: PoseOptimization must reset them
+        if (rng.uni() < sp.nullFrac) { F.mvpMapPoints.push_back(nullptr); continue; }
+        mps.emplace_back();
+        MapPoint &mp = mps.back();
+        mp.mnId = 5000 + (unsigned long)i;
+        cv::Mat P(3, 1, CV_32F);
+        P.at<float>(0) = (float)X; P.at<float>(1) = (float)Y; P.at<float>(2) = (float)Z;
+        mp.mWorldPos = P;
+        F.mvpMapPoints.push_back(&mp);
+    }
+    F.numSemanticKeys = sp.nKeys;
+}
+
+template <class Fn>
+Snapshot run_pose(const PoseSpec &sp, Fn &&fn) {
+    Frame F;
+    std::deque<MapPoint> mps;
+    build_frame(sp, F, mps);
+    opt_log().clear();
+    const int r = fn(&F);
+    return snap_frame(F, r);
+}
+
+template <class Fn>
+Snapshot run_scene(const SceneSpec &sp, Fn &&fn) {
+    Scene S;
+    build_scene(sp, S);
+    opt_log().clear();
+    fn(S);
+    return snap_scene(S, 0);
+}
+
+size_t golden_stride(size_t n) { return n / 300 > 0 ? n / 300 : 1; }
+void write_snapshot(std::ostream &os, const std::string &name, const Snapshot &s) {
+    os << name << ' ' << s.ret << ' ' << s.log.size() << ' ' << s.discrete.size() << ' ' << std::hex << discrete_hash(s) << std::dec << ' ' << s.floats.size() << ' '
+       << s.doubles.size();
+    char buf[40];
+    const size_t stride = golden_stride(s.floats.size());          // (a sample of the floats keeps the fixture small; all of them are compared live)
+    for (size_t i = 0; i < s.floats.size(); i += stride) { std::snprintf(buf, sizeof buf, " %.9g", (double)s.floats[i]); os << buf; }
+    for (double d : s.doubles) { std::snprintf(buf, sizeof buf, " %.17g", d); os << buf; }
+    os << '\n';
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    const char *golden_out = nullptr, *golden_in = nullptr;
+    for (int i = 1; i + 1 < argc; ++i) {
+        if (!std::strcmp(argv[i], "--write-golden")) golden_out = argv[i + 1];
+        if (!std::strcmp(argv[i], "--golden")) golden_in = argv[i + 1];
+    }
+    // ---------------------------------------------------------------- the cases
+    const PoseSpec poses[] = {
+        {11, 900, 0.30, 0.20, 0.08}, {12, 1500, 0.10, 0.00, 0.15}, {13, 600, 0.50, 1.00, 0.05}, {14, 400, 0.20, 0.50, 0.30},
+        {15, 12, 0.40, 0.25, 0.10},        // fewer than 10 edges: one round only (Optimizer.cc:463-465)
+        {16, 2, 0.00, 0.00, 0.00},         // fewer than 3 correspondences: returns 0, nothing is written (:409-411)
+        {17, 2000, 0.05, 0.10, 0.02},
+    };
+    const SceneSpec scenes[] = {
+        //  seed KF  MP  firstId covis outl  mono bad badKF
+        {21, 12, 700, 0, 11, 0.05, 0.20, 9, false},       // the map's first keyframe is local (held fixed, first_frame bookkeeping)
+        {22, 16, 900, 3, 7, 0.06, 0.15, 12, true},        // older keyframes become fixed ones; one local keyframe is bad
+        {23, 20, 1200, 40, 9, 0.10, 0.00, 20, false},     // stereo only, more outliers
+        {24, 8, 300, 0, 4, 0.03, 1.00, 3, false},         // monocular observations only; keyframe 0 is a FIXED one
+        {25, 10, 500, 7, 9, 0.00, 0.30, 0, false},        // no outliers at all
+    };
+    bool stop_clear = false, stop_set = true;
+    struct BaSpec { SceneSpec sc; int its; bool *stop; unsigned long loopKF; bool robust; bool global; };
+    const BaSpec bas[] = {
+        {{31, 9, 400, 0, 8, 0.04, 0.2, 6, false}, 5, nullptr, 0, true, false},
+        {{32, 11, 500, 0, 10, 0.05, 0.1, 8, true}, 10, &stop_clear, 7, false, true},
+        {{33, 7, 250, 2, 6, 0.02, 0.5, 4, false}, 20, nullptr, 0, true, true},
+    };
+
+    for (const PoseSpec &sp : poses) {
+        Case c;
+        c.name = "PoseOptimization seed " + std::to_string(sp.seed);
+#ifndef PIN_NO_REFERENCE
+        c.ref = run_pose(sp, [](Frame *F) { return RefOptimizer::PoseOptimization(F); });
+#endif
+        c.got = run_pose(sp, [](Frame *F) { return Optimizer::PoseOptimization(F); });
+        cases.push_back(c);
+    }
+    for (const SceneSpec &sp : scenes)
+        for (int stop_mode = 0; stop_mode < 3; ++stop_mode) {
+            if (stop_mode == 2 && sp.seed != 21 && sp.seed != 22) continue;
+            bool *stop = stop_mode == 0 ? nullptr : stop_mode == 1 ? &stop_clear : &stop_set;
+            Case c;
+            c.name = "LocalBundleAdjustment seed " + std::to_string(sp.seed) + (stop_mode == 0 ? " stop null" : stop_mode == 1 ? " stop clear" : " stop raised");
+#ifndef PIN_NO_REFERENCE
+            c.ref = run_scene(sp, [&](Scene &S) { RefOptimizer::LocalBundleAdjustment(&S.kfs.back(), stop, &S.map); });
+#endif
+            c.got = run_scene(sp, [&](Scene &S) { Optimizer::LocalBundleAdjustment(&S.kfs.back(), stop, &S.map); });
+            cases.push_back(c);
+        }
+    for (const BaSpec &b : bas) {
+        Case c;
+        c.name = std::string(b.global ? "GlobalBundleAdjustment" : "BundleAdjustment") + " seed " + std::to_string(b.sc.seed);
+#ifndef PIN_NO_REFERENCE
+        c.ref = run_scene(b.sc, [&](Scene &S) {
+            if (b.global) RefOptimizer::GlobalBundleAdjustment(&S.map, b.its, b.stop, b.loopKF, b.robust);
+            else RefOptimizer::BundleAdjustment(S.map.keyframes, S.map.points, b.its, b.stop, b.loopKF, b.robust);
+        });
+#endif
+        c.got = run_scene(b.sc, [&](Scene &S) {
+            if (b.global) Optimizer::GlobalBundleAdjustment(&S.map, b.its, b.stop, b.loopKF, b.robust);
+            else Optimizer::BundleAdjustment(S.map.keyframes, S.map.points, b.its, b.stop, b.loopKF, b.robust);
+        });
+        cases.push_back(c);
+    }
+
+#ifndef PIN_NO_REFERENCE
+    for (const Case &c : cases) compare(c.name.c_str(), c.ref, c.got);
+    if (golden_out) {
+        std::ofstream os(golden_out);
+        os << "# tests/golden/optimizer_reference.txt — results of the reference's own src/orbslam/Optimizer.cc (over the g2o stand-in) on the scenes of\n"
+              "# tests/cpp/pin_optimizer.cpp; written by oracle/_ref/pin_optimizer_cpu --write-golden.  Per case: name words, return value, logged\n"
+              "# mutations, discrete values, hash of (return, ordered mutation log, discrete values), floats, doubles, then the values.\n";
+        for (const Case &c : cases) {
+            std::string n = c.name;
+            for (char &ch : n) if (ch == ' ') ch = '_';
+            write_snapshot(os, n, c.ref);
+        }
+        std::printf("golden written: %s\n", golden_out);
+    }
+#else
+    // without the reference: this repository's side against the recorded results of the reference
+    if (!golden_in) { std::printf("usage: golden_optimizer_* --golden tests/golden/optimizer_reference.txt\n"); return 2; }
+    std::ifstream is(golden_in);
+    std::string line;
+    size_t ci = 0;
+    while (std::getline(is, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream ls(line);
+        std::string name, hash;
+        Snapshot ref;
+        size_t nlog, ndisc, nf, nd;
+        ls >> name >> ref.ret >> nlog >> ndisc >> hash >> nf >> nd;
+        ref.floats.assign(nf, 0.f); ref.doubles.resize(nd);
+        const size_t stride = golden_stride(nf);
+        for (size_t i = 0; i < nf; i += stride) ls >> ref.floats[i];
+        for (double &d : ref.doubles) ls >> d;
+        CHECK(ci < cases.size(), "more golden cases than cases");
+        if (ci >= cases.size()) break;
+        const Case &c = cases[ci++];
+        std::string n = c.name;
+        for (char &ch : n) if (ch == ' ') ch = '_';
+        CHECK(n == name, "case order: %s vs %s", n.c_str(), name.c_str());
+        char hb[32];
+        std::snprintf(hb, sizeof hb, "%" PRIx64, discrete_hash(c.got));
+        CHECK(hash == hb && c.got.log.size() == nlog && c.got.discrete.size() == ndisc && c.got.ret == ref.ret, "%s: return / mutation log / flags differ from the reference's", name.c_str());
+        double worst_f = 0, worst_d = 0;
+        CHECK(c.got.floats.size() == nf && c.got.doubles.size() == nd, "%s: result sizes", name.c_str());
+        for (size_t i = 0; i < nf && i < c.got.floats.size(); i += stride) worst_f = std::fmax(worst_f, std::fabs((double)ref.floats[i] - c.got.floats[i]) / std::fmax(1.0, std::fabs((double)ref.floats[i])));
+        for (size_t i = 0; i < nd && i < c.got.doubles.size(); ++i) worst_d = std::fmax(worst_d, std::fabs(ref.doubles[i] - c.got.doubles[i]) / std::fmax(std::fabs(ref.doubles[i]), 1e-9));
+        CHECK(worst_f <= 2e-6 && worst_d <= 1e-7, "%s: floats %.2e doubles %.2e", name.c_str(), worst_f, worst_d);
+        std::printf("%-44s return %4ld  %4zu mutations  max rel diff: poses / points %.1e, covariance %.1e\n", c.name.c_str(), ref.ret, nlog, worst_f, worst_d);
+    }
+    CHECK(ci == cases.size(), "%zu golden cases for %zu cases", ci, cases.size());
+#endif
+    if (failures) std::printf("pin_optimizer: %d FAILED\n", failures);
+    else std::printf("pin_optimizer: all %zu cases agree\n", cases.size());
+    return failures ? 1 : 0;
+}
