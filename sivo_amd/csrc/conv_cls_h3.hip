@@ -39,6 +39,7 @@
 #include "common.hpp"
 #include "lds_dma.hpp"
 #include "segnet_kernels.hpp"
+#include "softmax.hpp"
 
 namespace sivo {
 
@@ -60,7 +61,9 @@ static_assert(C_W0 + 3 * C_WKS <= 160 * 1024 - 2048, "LDS (the last 2 KiB are th
 // wave w owns row w (two blocks) — with one wave per SIMD nothing runs while a wave issues its 13 DMA pieces of the next stage,
 // waits at the stage barrier or does a sample's Softmax; the second wave's multiply fills those gaps (at the price of the
 // weight fragments being read once per two blocks instead of once per four).
-template <int NW>
+// ABL (diagnostic builds only, -DSIVO_DIAG; results are wrong by construction): 1 no MFMAs, 2 no Softmax / sum at the end of a sample,
+// 4 no patch DMA after the first stage, 8 no fragment reads after the first tap.
+template <int NW, int ABL = 0>
 __global__ __launch_bounds__(NW * 64) void conv_cls_h3_kernel(ClsMcArgs a) {
     constexpr int NB = 16 / NW;                 // 16-pixel blocks per wave: block b = (row b / 2 of the wave's rows, half b % 2)
     constexpr int NDW = (C_NDMA + NW - 1) / NW; // DMA pieces per wave and stage
@@ -166,8 +169,8 @@ __global__ __launch_bounds__(NW * 64) void conv_cls_h3_kernel(ClsMcArgs a) {
         if (k2 == nks) { k2 = 0; ++s2; }
         int s3 = s2, k3 = k2 + 1;
         if (k3 == nks) { k3 = 0; ++s3; }
-        if (g + 1 < total) issue_stage(s2, k2, (g + 1) & 1);
-        if (g + 2 < total) {
+        if (g + 1 < total && !(ABL & 4)) issue_stage(s2, k2, (g + 1) & 1);
+        if (g + 2 < total && !(ABL & 4)) {
             prefetch_stage(s3, k3);
             probes_behind = true;
         }
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(NW * 64) void conv_cls_h3_kernel(ClsMcArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * NB, 0);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            if (t + 1 < 9) {
+            if (t + 1 < 9 && !(ABL & 8)) {
                 fetch(t + 1, (t + 1) & 1);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * NB, 0);
             }
@@ -200,10 +203,13 @@ __global__ __launch_bounds__(NW * 64) void conv_cls_h3_kernel(ClsMcArgs a) {
             for (int term = 0; term < 3; ++term) {
                 constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
-                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t & 1][PA[term]], B[t & 1][b][PB[term]], acc[b], 0, 0, 0);
+                for (int b = 0; b < NB; ++b) {
+                    if (ABL & 1) acc[b][term] += (float)A[t & 1][PA[term]][0] + (float)B[t & 1][b][PB[term]][1];
+                    else acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[(ABL & 8) ? 0 : (t & 1)][PA[term]], B[(ABL & 8) ? 0 : (t & 1)][b][PB[term]], acc[b], 0, 0, 0);
+                }
             }
         }
-        if (ks == nks - 1) {
+        if (ks == nks - 1 && !(ABL & 2)) {
             // ---- end of sample s: acc[b][j] = class 4 lg + j at pixel lp of block b.  4 x 4 transpose over the four 16-lane rows
             // (register index b <-> row lg), per j: afterwards w[c] = class 4 c + j at pixel lp of block lg.
             float x[16];
@@ -294,12 +300,21 @@ void launch_conv_cls_h3(const ClsMcArgs &a0, hipStream_t s) {
     }
     const int P = a.tiles_x * a.tiles_y, per = (P + 7) / 8;
 #ifdef SIVO_DIAG
+    if (const char *ab = std::getenv("SIVO_CLS_ABL")) {                                     // diagnostic build: ablations of the default form
+#define CLS_ABL_CASE(n)                                                                                                                             \
+    case n:                                                                                                                                         \
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_cls_h3_kernel<8, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((conv_cls_h3_kernel<8, n>), dim3((unsigned)(8 * per)), dim3(512), (size_t)160 * 1024, s, a);                            \
+        return;
+        switch (std::atoi(ab)) { CLS_ABL_CASE(1) CLS_ABL_CASE(2) CLS_ABL_CASE(3) CLS_ABL_CASE(4) CLS_ABL_CASE(6) CLS_ABL_CASE(8) CLS_ABL_CASE(9) CLS_ABL_CASE(11) CLS_ABL_CASE(15) default: break; }
+#undef CLS_ABL_CASE
+    }
     if (std::getenv("SIVO_CLS_NW") && std::atoi(std::getenv("SIVO_CLS_NW")) == 4) {        // diagnostic build: the one-wave-per-SIMD form
-        hipLaunchKernelGGL(conv_cls_h3_kernel<4>, dim3((unsigned)(8 * per)), dim3(256), (size_t)160 * 1024, s, a);
+        hipLaunchKernelGGL((conv_cls_h3_kernel<4>), dim3((unsigned)(8 * per)), dim3(256), (size_t)160 * 1024, s, a);
         return;
     }
 #endif
-    hipLaunchKernelGGL(conv_cls_h3_kernel<8>, dim3((unsigned)(8 * per)), dim3(512), (size_t)160 * 1024, s, a);
+    hipLaunchKernelGGL((conv_cls_h3_kernel<8>), dim3((unsigned)(8 * per)), dim3(512), (size_t)160 * 1024, s, a);
 }
 
 }  // namespace sivo

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "segnet_kernels.hpp"
+#include "softmax.hpp"
 
 namespace sivo {
 

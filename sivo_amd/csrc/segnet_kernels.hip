@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include "segnet_kernels.hpp"
+#include "softmax.hpp"
 
 namespace sivo {
 
@@ -435,10 +436,11 @@ __global__ void mc_reduce_kernel(const float *logits, int n, int C, int64_t hw, 
             float den = 0.f;
 #pragma unroll
             for (int c = 0; c < CMAX; ++c)
-                if (c < C) { x[c][v] = expf(x[c][v] - m); den = __fadd_rn(den, x[c][v]); }
+                if (c < C) { x[c][v] = softmax_exp(x[c][v] - m); den = __fadd_rn(den, x[c][v]); }
+            const float rden = softmax_rcp(den);
 #pragma unroll
             for (int c = 0; c < CMAX; ++c)
-                if (c < C) { x[c][v] = __fdiv_rn(x[c][v], den); sum[c][v] += (double)x[c][v]; }
+                if (c < C) { x[c][v] = __fmul_rn(x[c][v], rden); sum[c][v] += (double)x[c][v]; }
         }
         if (prob) {
             float *pp = prob + (int64_t)s * C * hw + p;
@@ -515,10 +517,11 @@ __global__ __launch_bounds__(256) void mc_reduce_finalize_kernel(const float *__
         float den = 0.f;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c)
-            if (c < C) { x[c] = expf(x[c] - m); den = __fadd_rn(den, x[c]); }
+            if (c < C) { x[c] = softmax_exp(x[c] - m); den = __fadd_rn(den, x[c]); }
+        const float rden = softmax_rcp(den);
 #pragma unroll
         for (int c = 0; c < CMAX; ++c)
-            if (c < C) sum[c] += (double)__fdiv_rn(x[c], den);
+            if (c < C) sum[c] += (double)__fmul_rn(x[c], rden);
     }
     const double dT = (double)T;
     int best = 0;
