@@ -80,6 +80,21 @@ class Optimizer {
     template <class MapT>
     static void GlobalBundleAdjustment(MapT *pMap, int nIterations = 5, bool *pbStopFlag = nullptr, const unsigned long nLoopKF = 0ul,
                                        const bool bRobust = true);
+
+    // ---- loop closing (reference include/orbslam/Optimizer.h:64-79; called at LoopClosing.cc:333 `Optimizer::OptimizeSim3(mpCurrentKF,
+    // pKF, vpMapPointMatches, gScm, 10, mbFixScale)` and :582 `Optimizer::OptimizeEssentialGraph(mpMap, mpMatchedKF, mpCurrentKF,
+    // NonCorrectedSim3, CorrectedSim3, LoopConnections, mbFixScale)`).  Sim3 pose-graph optimisation: sequential sparse algebra over a
+    // pointer graph, a handful of calls per loop closure — SLAM back end, outside the per-frame path this library accelerates
+    // (out of scope).  The members exist so that LoopClosing.cc compiles against this class unchanged: with
+    // -DSIVO_HAVE_G2O they forward to SIVO_G2O_BACKEND (a class with these two static members: the reference's own Optimizer.cc
+    // compiled under another name is one — tests/cpp/pin_optimizer.cpp links exactly that); without it, instantiating them is a
+    // compile-time error that says so.
+    template <class MapT, class KeyFrameT, class KFPoseMapT, class ConnectionsT>
+    static void OptimizeEssentialGraph(MapT *pMap, KeyFrameT *pLoopKF, KeyFrameT *pCurKF, const KFPoseMapT &NonCorrectedSim3,
+                                       const KFPoseMapT &CorrectedSim3, const ConnectionsT &LoopConnections, const bool &bFixScale);
+    template <class KeyFrameT, class MapPointT, class Sim3T>
+    static int OptimizeSim3(KeyFrameT *pKF1, KeyFrameT *pKF2, std::vector<MapPointT *> &vpMatches1, Sim3T &g2oS12, const float th2,
+                            const bool bFixScale);
 };
 
 }  // namespace SIVO

@@ -28,6 +28,9 @@
 #else
 #include "../compat/cv_min.hpp"
 #endif
+#ifdef SIVO_HAVE_EIGEN
+#include <Eigen/Core>      // Frame / KeyFrame::SetCovariance(Eigen::MatrixXd) (reference Frame.cc:254-260)
+#endif
 
 namespace SIVO {
 namespace optimizer_detail {
@@ -330,6 +333,31 @@ template <class MapT>
 void Optimizer::GlobalBundleAdjustment(MapT *pMap, int nIterations, bool *pbStopFlag, const unsigned long nLoopKF, const bool bRobust) {
     SIVO::GlobalBundleAdjustment(pMap, nIterations, pbStopFlag, nLoopKF, bRobust);
 }
+
+// Loop closing: Optimizer::OptimizeEssentialGraph / OptimizeSim3 (declared in Optimizer.h)
+#ifdef SIVO_HAVE_G2O
+template <class MapT, class KeyFrameT, class KFPoseMapT, class ConnectionsT>
+void Optimizer::OptimizeEssentialGraph(MapT *pMap, KeyFrameT *pLoopKF, KeyFrameT *pCurKF, const KFPoseMapT &NonCorrectedSim3, const KFPoseMapT &CorrectedSim3,
+                                       const ConnectionsT &LoopConnections, const bool &bFixScale) {
+    SIVO_G2O_BACKEND::OptimizeEssentialGraph(pMap, pLoopKF, pCurKF, NonCorrectedSim3, CorrectedSim3, LoopConnections, bFixScale);
+}
+template <class KeyFrameT, class MapPointT, class Sim3T>
+int Optimizer::OptimizeSim3(KeyFrameT *pKF1, KeyFrameT *pKF2, std::vector<MapPointT *> &vpMatches1, Sim3T &g2oS12, const float th2, const bool bFixScale) {
+    return SIVO_G2O_BACKEND::OptimizeSim3(pKF1, pKF2, vpMatches1, g2oS12, th2, bFixScale);
+}
+#else
+template <class MapT, class KeyFrameT, class KFPoseMapT, class ConnectionsT>
+void Optimizer::OptimizeEssentialGraph(MapT *, KeyFrameT *, KeyFrameT *, const KFPoseMapT &, const KFPoseMapT &, const ConnectionsT &, const bool &) {
+    static_assert(sizeof(MapT) == 0, "Optimizer::OptimizeEssentialGraph (Sim3 pose graph, g2o) is outside this library: build with -DSIVO_HAVE_G2O and "
+                                     "-DSIVO_G2O_BACKEND=<a class providing it, e.g. the reference's Optimizer.cc compiled under another name>");
+}
+template <class KeyFrameT, class MapPointT, class Sim3T>
+int Optimizer::OptimizeSim3(KeyFrameT *, KeyFrameT *, std::vector<MapPointT *> &, Sim3T &, const float, const bool) {
+    static_assert(sizeof(KeyFrameT) == 0, "Optimizer::OptimizeSim3 (Sim3 alignment, g2o) is outside this library: build with -DSIVO_HAVE_G2O and "
+                                          "-DSIVO_G2O_BACKEND=<a class providing it>");
+    return 0;
+}
+#endif
 
 }  // namespace SIVO
 #endif

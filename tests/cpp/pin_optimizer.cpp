@@ -36,6 +36,11 @@
 #endif
 std::mutex SIVO::MapPoint::mGlobalMutex;
 
+#ifndef PIN_NO_REFERENCE
+// the loop-closing members of this repository's class forward to a g2o-based backend: here the reference's own class
+#define SIVO_HAVE_G2O
+#define SIVO_G2O_BACKEND RefOptimizer
+#endif
 #include "orbslam/Optimizer.h"              // sivo_amd/api: this repository's class (+ OptimizerAdapter.h)
 
 using namespace SIVO;
@@ -322,12 +327,25 @@ void write_snapshot(std::ostream &os, const std::string &name, const Snapshot &s
 
 }  // namespace
 
+#ifndef PIN_NO_REFERENCE
+// LoopClosing.cc:333 and :582 as they are written, against this repository's class: must compile and link (the Sim3 solve itself is
+// g2o's and is not run here — the stand-in does not implement it)
+int (*const pin_optimize_sim3)(KeyFrame *, KeyFrame *, std::vector<MapPoint *> &, g2o::Sim3 &, const float, const bool) =
+    &Optimizer::OptimizeSim3<KeyFrame, MapPoint, g2o::Sim3>;
+void (*const pin_optimize_essential)(Map *, KeyFrame *, KeyFrame *, const LoopClosing::KeyFrameAndPose &, const LoopClosing::KeyFrameAndPose &,
+                                     const std::map<KeyFrame *, std::set<KeyFrame *>> &, const bool &) =
+    &Optimizer::OptimizeEssentialGraph<Map, KeyFrame, LoopClosing::KeyFrameAndPose, std::map<KeyFrame *, std::set<KeyFrame *>>>;
+#endif
+
 int main(int argc, char **argv) {
     const char *golden_out = nullptr, *golden_in = nullptr;
     for (int i = 1; i + 1 < argc; ++i) {
         if (!std::strcmp(argv[i], "--write-golden")) golden_out = argv[i + 1];
         if (!std::strcmp(argv[i], "--golden")) golden_in = argv[i + 1];
     }
+#ifndef PIN_NO_REFERENCE
+    if (!pin_optimize_sim3 || !pin_optimize_essential) return 3;
+#endif
     // ---------------------------------------------------------------- the cases
     const PoseSpec poses[] = {
         {11, 900, 0.30, 0.20, 0.08}, {12, 1500, 0.10, 0.00, 0.15}, {13, 600, 0.50, 1.00, 0.05}, {14, 400, 0.20, 0.50, 0.30},
