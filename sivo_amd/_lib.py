@@ -135,14 +135,27 @@ DEBUG_SIGNATURES = {
 }
 DBG_PATH = os.path.join(_HERE, "libsivo_hip_dbg.so")
 
-_lib = None
+DIAG_PATH = os.path.join(_HERE, "libsivo_hip_diag.so")
+
+_libs = {}            # "product" / "diag" -> CDLL
+_current = "product"
 _dbg = None
 
 
 def dbg():
-    """Load libsivo_hip_dbg.so (`make -C sivo_amd/csrc dbg`): the sivo_debug_* entry points the kernel tests and tools call.  It
-    links libsivo_hip.so (loaded first, so that both share one copy) and runs the product's kernels."""
+    """The sivo_debug_* entry points the kernel tests and tools call: libsivo_hip_dbg.so (`make -C sivo_amd/csrc dbg`), a thin library
+    that links libsivo_hip.so (loaded first, so that both share one copy) and runs the PRODUCT's kernels — or, inside
+    `with use("diag")`, the diagnostic build itself, which carries the same entry points."""
     global _dbg
+    if _current == "diag":
+        L = lib()
+        if not getattr(L, "_sivo_debug_bound", False):
+            for name, args in DEBUG_SIGNATURES.items():
+                fn = getattr(L, name)
+                fn.argtypes = args
+                fn.restype = C.c_int
+            L._sivo_debug_bound = True
+        return L
     if _dbg is None:
         lib()
         if not os.path.exists(DBG_PATH):
@@ -156,28 +169,53 @@ def dbg():
     return _dbg
 
 
+def _load(path):
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build the HIP extension first (make -C sivo_amd/csrc all); "
+                          "sivo_amd has no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64.  Loaded first, libsivo_hip.so
+    # (linked against the same sonames) binds to that copy; loaded after /opt/rocm's, torch finds no device
+    # ("No HIP GPUs are available", seen when a test touched this library before anything had imported torch).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(path)
+    L.sivo_last_error.restype = C.c_char_p
+    for name, args in SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    return L
+
+
 def lib():
-    """Load libsivo_hip.so (build it with `python -c 'import __graft_entry__ as g; g.build()'`)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first (make -C sivo_amd/csrc); "
-                              "sivo_amd has no CPU fallback")
-        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64.  Loaded first, libsivo_hip.so
-        # (linked against the same sonames) binds to that copy; loaded after /opt/rocm's, torch finds no device
-        # ("No HIP GPUs are available", seen when a test touched this library before anything had imported torch).
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
-        L = C.CDLL(LIB_PATH)
-        L.sivo_last_error.restype = C.c_char_p
-        for name, args in SIGNATURES.items():
-            fn = getattr(L, name)
-            fn.argtypes = args
-            fn.restype = C.c_int
-        _lib = L
-    return _lib
+    """The library the calling code should use: libsivo_hip.so (build it with `python -c 'import __graft_entry__ as g; g.build()'`),
+    or — inside a `with use("diag")` block — libsivo_hip_diag.so, the same sources compiled with -DSIVO_DIAG: the only build that
+    reads the A/B / fault-injection switches (SIVO_NO_FUSE_*, SIVO_D3_FORM, SIVO_H3_BOOST, SIVO_MULTI_EMULATE, ...; the product
+    reads eight documented ones).  Objects (BayesianSegNet, ORBextractor, ...) keep the library they were created with."""
+    if _current not in _libs:
+        _libs[_current] = _load(LIB_PATH if _current == "product" else DIAG_PATH)
+    return _libs[_current]
+
+
+class use:
+    """Context manager: `with _lib.use("diag"):` makes lib() return the diagnostic build inside the block (tests that compare kernel
+    forms bit for bit, force the fp16 overflow path or emulate several devices on one)."""
+
+    def __init__(self, which):
+        assert which in ("product", "diag")
+        self.which = which
+
+    def __enter__(self):
+        global _current
+        self.prev, _current = _current, self.which
+        return lib()
+
+    def __exit__(self, *exc):
+        global _current
+        _current = self.prev
+        return False
 
 
 def check(rc):

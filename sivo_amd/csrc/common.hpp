@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/sivo_hip.h"
@@ -87,6 +88,16 @@ class FirstUse {
     int *slot_ = nullptr;      // non-null: this guard holds the lock and publishes the flag on destruction
     bool always_ = false;      // device index unknown: run the block every time, unlocked
 };
+
+// Environment switches.  The product library reads EIGHT: SIVO_LANES, SIVO_GEMM, SIVO_D3, SIVO_D3_PK, SIVO_CONV7,
+// SIVO_WINO4_MB, SIVO_ORB_PRIO, SIVO_DEBUG_SYNC.  Every other one selects between kernel forms for A/B measurements, bit-identity tests
+// and fault injection (SIVO_H3_BOOST, SIVO_MULTI_EMULATE ...): those exist only in libsivo_hip_diag.so (`make diag`: every source
+// compiled with -DSIVO_DIAG) — in the product build the macro is a null pointer and the name is not even in the binary.
+#ifdef SIVO_DIAG
+#define SIVO_DIAG_ENV(name) std::getenv(name)
+#else
+#define SIVO_DIAG_ENV(name) (static_cast<const char *>(nullptr))
+#endif
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -876,9 +876,9 @@ void launch_conv3_h3(const ConvArgs &a0, hipStream_t s) {
     // the whole LDS of the CU, as conv_wino4_h3.hip (no other workgroup beside a persistent one)
     const size_t lds = (size_t)160 * 1024;
     // SIVO_D3_FORM=0: the phased stage loop of the fp32-input forms (read at every launch: tests compare the two forms bit for bit)
-    const int form = std::getenv("SIVO_D3_FORM") && std::atoi(std::getenv("SIVO_D3_FORM")) == 0 ? 0 : 1;
+    const int form = SIVO_DIAG_ENV("SIVO_D3_FORM") && std::atoi(SIVO_DIAG_ENV("SIVO_D3_FORM")) == 0 ? 0 : 1;
 #ifdef SIVO_DIAG
-    if (const char *ab = std::getenv("SIVO_D3_ABL")) {
+    if (const char *ab = SIVO_DIAG_ENV("SIVO_D3_ABL")) {
 #define D3_ABL_CASE(n)                                                                                                                      \
     case n:                                                                                                                                 \
         if (form == 0) {                                                                                                                    \

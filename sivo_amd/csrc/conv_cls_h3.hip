@@ -300,7 +300,7 @@ void launch_conv_cls_h3(const ClsMcArgs &a0, hipStream_t s) {
     }
     const int P = a.tiles_x * a.tiles_y, per = (P + 7) / 8;
 #ifdef SIVO_DIAG
-    if (const char *ab = std::getenv("SIVO_CLS_ABL")) {                                     // diagnostic build: ablations of the default form
+    if (const char *ab = SIVO_DIAG_ENV("SIVO_CLS_ABL")) {                                     // diagnostic build: ablations of the default form
 #define CLS_ABL_CASE(n)                                                                                                                             \
     case n:                                                                                                                                         \
         SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_cls_h3_kernel<8, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
@@ -309,7 +309,7 @@ void launch_conv_cls_h3(const ClsMcArgs &a0, hipStream_t s) {
         switch (std::atoi(ab)) { CLS_ABL_CASE(1) CLS_ABL_CASE(2) CLS_ABL_CASE(3) CLS_ABL_CASE(4) CLS_ABL_CASE(6) CLS_ABL_CASE(8) CLS_ABL_CASE(9) CLS_ABL_CASE(11) CLS_ABL_CASE(15) default: break; }
 #undef CLS_ABL_CASE
     }
-    if (std::getenv("SIVO_CLS_NW") && std::atoi(std::getenv("SIVO_CLS_NW")) == 4) {        // diagnostic build: the one-wave-per-SIMD form
+    if (SIVO_DIAG_ENV("SIVO_CLS_NW") && std::atoi(SIVO_DIAG_ENV("SIVO_CLS_NW")) == 4) {        // diagnostic build: the one-wave-per-SIMD form
         hipLaunchKernelGGL((conv_cls_h3_kernel<4>), dim3((unsigned)(8 * per)), dim3(256), (size_t)160 * 1024, s, a);
         return;
     }

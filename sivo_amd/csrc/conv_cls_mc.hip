@@ -29,6 +29,7 @@
 #include <string>
 #include <vector>
 
+#include "common.hpp"
 #include "segnet_kernels.hpp"
 #include "softmax.hpp"
 
@@ -366,7 +367,7 @@ bool cls_mc_supported(int ks, int cin, int cout, int H, int W) {
 }
 int cls_mc_k_chunk() {
     static const int kc = [] {
-        const char *e = std::getenv("SIVO_CLS_KC");
+        const char *e = SIVO_DIAG_ENV("SIVO_CLS_KC");
         return (e && std::atoi(e) == 8) ? 8 : 4;
     }();
     return kc;
@@ -394,9 +395,9 @@ void cls_mc_pack_weights(const float *W, int cin, int cout, std::vector<float> &
 // stage buffers — bit-identical, measured 0.83 ms against 0.70 ms per frame whatever the depth (see the note at the kernel)
 static int cls_mc_ring() {
     static const int nb = [] {
-        const char *m = std::getenv("SIVO_CLS_MC");
+        const char *m = SIVO_DIAG_ENV("SIVO_CLS_MC");
         if (!m || std::string(m) != "dma") return 0;
-        const char *e = std::getenv("SIVO_CLS_NB");
+        const char *e = SIVO_DIAG_ENV("SIVO_CLS_NB");
         const int v = e ? std::atoi(e) : 4;
         return v == 3 || v == 5 ? v : 4;
     }();

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "lds_dma.hpp"
+#include "common.hpp"
 #include "segnet_kernels.hpp"
 
 namespace sivo {
@@ -625,7 +626,7 @@ static void launch_wino_p(const ConvArgs &a0, hipStream_t s) {
 
 void launch_conv_wino(const ConvArgs &a, int cfg, hipStream_t s) {
     // default tiling (cfg 0), no probe variant: the form with its memory traffic in flight (SIVO_WINO_PIPE=0: the older one)
-    static const bool pipe_env = !(std::getenv("SIVO_WINO_PIPE") && std::atoi(std::getenv("SIVO_WINO_PIPE")) == 0);
+    static const bool pipe_env = !(SIVO_DIAG_ENV("SIVO_WINO_PIPE") && std::atoi(SIVO_DIAG_ENV("SIVO_WINO_PIPE")) == 0);
     if (pipe_env && cfg == 0 && (a.variant >> 8) == 0 && (int64_t)a.Cin * a.H * a.W * 4 < (1ll << 31))
         return a.unpool_mask ? launch_wino_p<true>(a, s) : launch_wino_p<false>(a, s);
     if (a.unpool_mask) return launch_wino_cfg<2, 2, 2, 4, 0, true>(a, s);     // Upsample fused into the patch loader (cfg 0 only)

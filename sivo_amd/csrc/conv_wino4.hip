@@ -713,7 +713,7 @@ bool wino4_supported(int ks, int cin, int cout, int H, int W) {
     // below 128 channels a transform-position GEMM is HBM-bound on V and M (C*K / (2 (C + K)) < 32 flop/byte; couts are
     // padded to 128 as well) and the fused F(2x2) kernel wins — measured on the Standard shapes: 256->128 0.69 vs 0.92 ms,
     // 128->128 1.52 vs 1.74 ms, but 128->64 1.37 vs 0.95 ms and 64->64 3.2 vs 1.9 ms.  SIVO_WINO4_MINC moves the threshold.
-    static const int minc = std::getenv("SIVO_WINO4_MINC") ? std::atoi(std::getenv("SIVO_WINO4_MINC")) : 128;
+    static const int minc = SIVO_DIAG_ENV("SIVO_WINO4_MINC") ? std::atoi(SIVO_DIAG_ENV("SIVO_WINO4_MINC")) : 128;
     return ks == 3 && cin % G_KC == 0 && cin >= minc && cout >= minc && W % 4 == 0 && H >= 4 && W >= 4;
 }
 
@@ -853,7 +853,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         if (e) (void)hipEventRecord(e[1], s);
         auto nblocks = [&](int bm, int bn) { return (int64_t)36 * ((a.P + bm - 1) / bm) * (a.Kp / bn); };
         // bf16x6 (128 x 128 items): whenever the layer has the split weights and the launch is not tiny
-        static const int x6_min_blocks = std::getenv("SIVO_X6_MINBLOCKS") ? std::atoi(std::getenv("SIVO_X6_MINBLOCKS")) : 128;
+        static const int x6_min_blocks = SIVO_DIAG_ENV("SIVO_X6_MINBLOCKS") ? std::atoi(SIVO_DIAG_ENV("SIVO_X6_MINBLOCKS")) : 128;
         if (h3) {
             launch_wino4_gemm_h3(reinterpret_cast<const uint32_t *>(a.V), c.wt_h3, a.M, a.C, a.Kp, a.P, a.Pp, s);
         } else if (c.wt_x6 && nblocks(128, 128) >= x6_min_blocks) {
@@ -863,7 +863,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
             hipLaunchKernelGGL(wino4_gemm_x6p_kernel, gp, dim3(512), X6P_LDS, s, a, reinterpret_cast<const uint4 *>(c.wt_x6), pt6, kt6);
         } else {
             // fp32 MFMA: the largest tile that still gives every CU ~4 workgroups (256 CUs)
-            static const int min_blocks = std::getenv("SIVO_WINO4_MINBLOCKS") ? std::atoi(std::getenv("SIVO_WINO4_MINBLOCKS")) : 1024;
+            static const int min_blocks = SIVO_DIAG_ENV("SIVO_WINO4_MINBLOCKS") ? std::atoi(SIVO_DIAG_ENV("SIVO_WINO4_MINBLOCKS")) : 1024;
             const int tile = nblocks(128, 128) >= min_blocks ? 0 : nblocks(64, 128) >= min_blocks ? 1 : 2;
             const int bm = tile == 0 ? 128 : 64, bn = tile == 2 ? 64 : 128;
             const int pt_n = (a.P + bm - 1) / bm, kt_n = a.Kp / bn, pairs8 = (36 * pt_n + 7) / 8;

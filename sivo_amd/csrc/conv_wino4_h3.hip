@@ -374,9 +374,9 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
     // one lane, the same handle twice != itself; with every workgroup alone on its CU, or with no LDS user beside it,
     // bit-identical; the GEMM alone beside such workgroups stays bit-exact, so the victim is presumably the neighbour — the
     // mechanism was not isolated).  SIVO_H3_LDS_ALL=0 requests the exact size (debugging).
-    static const bool lds_all = !(std::getenv("SIVO_H3_LDS_ALL") && std::atoi(std::getenv("SIVO_H3_LDS_ALL")) == 0);
+    static const bool lds_all = !(SIVO_DIAG_ENV("SIVO_H3_LDS_ALL") && std::atoi(SIVO_DIAG_ENV("SIVO_H3_LDS_ALL")) == 0);
     // SIVO_H3_TILE=0/1 forces the larger / smaller tile count per item (tests)
-    static const int force_tile = std::getenv("SIVO_H3_TILE") ? std::atoi(std::getenv("SIVO_H3_TILE")) : -1;
+    static const int force_tile = SIVO_DIAG_ENV("SIVO_H3_TILE") ? std::atoi(SIVO_DIAG_ENV("SIVO_H3_TILE")) : -1;
     static int attr_set[64] = {0};
     if (FirstUse once(attr_set); once) {
         for (const void *f : {(const void *)wino4_gemm_h3_kernel<256, 256>, (const void *)wino4_gemm_h3_kernel<128, 256>, (const void *)wino4_gemm_h3_kernel<256, 128>})
@@ -391,7 +391,7 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
     a.ptiles = (int)((P + t.bm - 1) / t.bm); a.ktiles = Kp / t.bn;
     const size_t lds = lds_all ? (size_t)160 * 1024 : (size_t)(2 * t.bm + 3 * t.bn) * 128;
 #ifdef SIVO_DIAG
-    if (const char *ab = std::getenv("SIVO_H3_ABL")) {          // diagnostic build: ablations of the 256 x 256 kernel
+    if (const char *ab = SIVO_DIAG_ENV("SIVO_H3_ABL")) {          // diagnostic build: ablations of the 256 x 256 kernel
         a.ptiles = (P + 255) / 256; a.ktiles = Kp / 256;
 #define H3_ABL_CASE(n)                                                                                                              \
     case n:                                                                                                                         \

@@ -755,7 +755,7 @@ void launch_conv_wino4f(const ConvArgs &a0, hipStream_t s) {
     dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * (a.CoutPad / 64)));
     const int abl = (a.variant >> 16) & 1023;
     // SIVO_W4F_PIPE=0 (or variant bit 8192, or a sample of 2 GiB and more): the one-chunk-ahead kernel
-    static const bool pipe_env = !(std::getenv("SIVO_W4F_PIPE") && std::atoi(std::getenv("SIVO_W4F_PIPE")) == 0);
+    static const bool pipe_env = !(SIVO_DIAG_ENV("SIVO_W4F_PIPE") && std::atoi(SIVO_DIAG_ENV("SIVO_W4F_PIPE")) == 0);
     const bool pipe = pipe_env && !(a.variant & 8192) && (int64_t)a.Cin * a.H * a.W * 4 < (1ll << 31);
     if (abl && !pipe) {      // probe only
         auto go = [&](auto kern) {
@@ -797,7 +797,7 @@ void launch_conv_wino4f(const ConvArgs &a0, hipStream_t s) {
     }
     // persistent form (one cout tile, default; SIVO_W4F_PERSIST=0 or variant bit 16384: one workgroup per pixel tile)
     // (read at every launch: tests switch it; 0 = never, 2 = always, default = where the deal is even)
-    const char *pe = std::getenv("SIVO_W4F_PERSIST");
+    const char *pe = SIVO_DIAG_ENV("SIVO_W4F_PERSIST");
     const bool persist_env = !(pe && std::atoi(pe) == 0), persist_force = pe && std::atoi(pe) == 2;
     // Measured: conv1_2_D (8448 tiles = 33 per CU) 1.354 -> 1.307 ms; conv2_1_D (2112 tiles = 8.25 per CU: a quarter of the CUs
     // gets a ninth tile) 0.675 -> 0.683 ms.  Hence only where the static deal is even enough: at least 16 tiles per workgroup.

@@ -210,10 +210,10 @@ int new_blob(sivo_segnet &S, const std::string &name, int C, int H, int W, bool 
 void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int H, int Wd, bool keep_ties) {
     const int ks = op.ks, cin = op.cin, cout = op.cout;
     std::vector<float> wt;
-    static const bool force_v1 = std::getenv("SIVO_CONV_V1") != nullptr;
-    static const bool no_wino = std::getenv("SIVO_NO_WINOGRAD") != nullptr;
+    static const bool force_v1 = SIVO_DIAG_ENV("SIVO_CONV_V1") != nullptr;
+    static const bool no_wino = SIVO_DIAG_ENV("SIVO_NO_WINOGRAD") != nullptr;
     // F(4x4,3x3) for the wide layers (4x fewer MFMA flops; costs ~2e-4 of the 1e-3 logit budget) — SIVO_NO_WINO4 disables
-    static const bool no_wino4 = std::getenv("SIVO_NO_WINO4") != nullptr;
+    static const bool no_wino4 = SIVO_DIAG_ENV("SIVO_NO_WINO4") != nullptr;
     static const size_t wino4_budget = (size_t)(std::getenv("SIVO_WINO4_MB") ? std::atoi(std::getenv("SIVO_WINO4_MB")) : 16384) << 20;
     // keep_ties: the layer belongs to the sample-invariant encoder prefix (conv1_1 .. conv3_3), whose outputs decide the
     // switches of pool1..pool3.  Over a flat image region (sky, saturated pixels) the four elements of a pooling window
@@ -232,9 +232,9 @@ void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int 
     const bool no_d3 = std::getenv("SIVO_D3") && std::atoi(std::getenv("SIVO_D3")) == 0;
     // (the sample-invariant prefix runs once per frame with N = 1: there the alternative is the fused F(2x2) kernel on the fp32
     // pipe, not the F(4x4) GEMM, and the direct kernel wins up to 256 channels — SIVO_D3_MAXC_SHARED)
-    const int d3_maxc = keep_ties ? (std::getenv("SIVO_D3_MAXC_SHARED") ? std::atoi(std::getenv("SIVO_D3_MAXC_SHARED")) : 256)
-                                  : (std::getenv("SIVO_D3_MAXC") ? std::atoi(std::getenv("SIVO_D3_MAXC")) : 128);
-    const bool d3_prefix = !(std::getenv("SIVO_D3_PREFIX") && std::atoi(std::getenv("SIVO_D3_PREFIX")) == 0);
+    const int d3_maxc = keep_ties ? (SIVO_DIAG_ENV("SIVO_D3_MAXC_SHARED") ? std::atoi(SIVO_DIAG_ENV("SIVO_D3_MAXC_SHARED")) : 256)
+                                  : (SIVO_DIAG_ENV("SIVO_D3_MAXC") ? std::atoi(SIVO_DIAG_ENV("SIVO_D3_MAXC")) : 128);
+    const bool d3_prefix = !(SIVO_DIAG_ENV("SIVO_D3_PREFIX") && std::atoi(SIVO_DIAG_ENV("SIVO_D3_PREFIX")) == 0);
     op.d3 = !no_d3 && !no_wino && gemm_default && (d3_prefix || !keep_ties) && cin <= d3_maxc && cout <= d3_maxc && conv3_h3_supported(ks, cin, cout, H, Wd, false);
     if (op.d3) {
         std::vector<uint16_t> planes;
@@ -245,7 +245,7 @@ void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int 
     }
     op.wino4 = !op.d3 && f4_ok && !no_wino4 && wino4_supported(ks, cin, cout, H, Wd);
     // narrow layers (below the F(4x4) GEMM threshold): the fused F(4x4) kernel — SIVO_NO_WINO4F falls back to fused F(2x2)
-    static const bool no_wino4f = std::getenv("SIVO_NO_WINO4F") != nullptr;
+    static const bool no_wino4f = SIVO_DIAG_ENV("SIVO_NO_WINO4F") != nullptr;
     op.wino4f = !op.wino4 && f4_ok && !no_wino4f && wino4f_supported(ks, cin, cout, H, Wd);
     op.wino = !op.wino4 && !op.wino4f && !no_wino && wino_supported(ks, cin, cout, H, Wd);
     op.v2 = !op.wino4 && !op.wino4f && !op.wino && conv2_supported(ks) && !force_v1;
@@ -286,7 +286,7 @@ void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int 
         op.wino4_group = wino4_group(S.T, cin, cout, H, Wd, wino4_budget);
         S.wino4_ws_floats = std::max(S.wino4_ws_floats, wino4_workspace_floats(op.wino4_group, cin, cout, H, Wd));
     } else if (op.wino) {
-        static const int env_cfg = std::getenv("SIVO_WINO_CFG") ? std::atoi(std::getenv("SIVO_WINO_CFG")) : 0;
+        static const int env_cfg = SIVO_DIAG_ENV("SIVO_WINO_CFG") ? std::atoi(SIVO_DIAG_ENV("SIVO_WINO_CFG")) : 0;
         op.wino_cfg = env_cfg;
         wino_pack_weights(W, cin, cout, op.wino_cfg, wt, &op.cout_pad);
     } else if (op.v2) {
@@ -371,7 +371,7 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             op.out = new_blob(S, L.top[0], L.num_output, b.H, b.W, b.shared);
             const size_t nw = (size_t)op.cout * op.cin * op.ks * op.ks;
             bool keep_ties = b.shared;
-            if (const char *extra = std::getenv("SIVO_KEEP_TIES_LAYERS"))        // comma-separated layer names (experiments)
+            if (const char *extra = SIVO_DIAG_ENV("SIVO_KEEP_TIES_LAYERS"))        // comma-separated layer names (experiments)
                 keep_ties = keep_ties || ("," + std::string(extra) + ",").find("," + L.name + ",") != std::string::npos;
             op.w_off = woff;
             upload_conv(S, op, weights + woff, weights + woff + nw, b.H, b.W, keep_ties);
@@ -498,7 +498,7 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
     // Upsample -> Winograd convolution: the F(4x4) input transform / the F(2x2) patch loader reads the pooled tensor and
     // the window codes directly (4x fewer input bytes, no unpool kernel, the unpooled tensor is never written).
     // SIVO_NO_FUSE_UNPOOL disables.
-    if (!std::getenv("SIVO_NO_FUSE_UNPOOL"))
+    if (!SIVO_DIAG_ENV("SIVO_NO_FUSE_UNPOOL"))
         for (Op &u : S.ops) {
             if (u.kind != OP_UNPOOL) continue;
             Op *consumer = nullptr;
@@ -525,7 +525,7 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
         if (A.wino4_group < N) continue;                           // several passes over the workspace: plain path
         const int64_t P = (int64_t)N * ((bo.H + 3) / 4) * (bo.W / 4), Pp = (P + 127) / 128 * 128;
         S.wino4_slot_floats = std::max(S.wino4_slot_floats, (size_t)(36 * Pp * std::max<int64_t>(A.cin, A.cout_pad)));
-        if (std::getenv("SIVO_NO_FUSE_BRIDGE") || A.out == S.logits_blob) continue;
+        if (SIVO_DIAG_ENV("SIVO_NO_FUSE_BRIDGE") || A.out == S.logits_blob) continue;
         Op *B = nullptr;
         int uses = 0;
         for (Op &c : S.ops)
@@ -542,7 +542,7 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
     // F(4x4) conv -> MAX 2x2 pooling (per-sample part: conv4_3 -> pool4, conv5_3 -> pool5): the output transform holds
     // whole pooling windows, so it writes the pooled tensor + window codes (+ the pooling layer's dropout) directly.
     // SIVO_NO_FUSE_POOL disables.
-    if (!std::getenv("SIVO_NO_FUSE_POOL"))
+    if (!SIVO_DIAG_ENV("SIVO_NO_FUSE_POOL"))
         for (size_t i = 0; i < S.ops.size(); ++i) {
             Op &A = S.ops[i];
             if (A.kind != OP_CONV || !A.wino4 || A.w4_bridge || A.out == S.logits_blob || S.blobs[A.out].shared) continue;
@@ -557,7 +557,7 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
         }
     // classifier convolution -> Softmax -> mean over the samples -> argmax / max / entropy in one kernel (conv_cls_mc.hip):
     // the logits stay on chip whenever the caller asks for the maps or the probability sums only.  SIVO_NO_FUSE_MC disables.
-    if (!std::getenv("SIVO_NO_FUSE_MC") && !S.ops.empty()) {
+    if (!SIVO_DIAG_ENV("SIVO_NO_FUSE_MC") && !S.ops.empty()) {
         Op &L = S.ops.back();
         const Blob &bi = S.blobs[L.in], &bo = S.blobs[L.out];
         if (L.kind == OP_CONV && L.out == S.logits_blob && !bo.shared && !bi.shared && !bi.fused_away && L.pool_op < 0 &&
@@ -735,7 +735,7 @@ void calibrate_h3(sivo_segnet &S) {
     S.calibrating = false;
     std::vector<uint32_t> bits(2 * S.ops.size());
     SIVO_HIP(hipMemcpy(bits.data(), S.d_h3_vmax, bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    const int boost = std::getenv("SIVO_H3_BOOST") ? std::atoi(std::getenv("SIVO_H3_BOOST")) : 0;
+    const int boost = SIVO_DIAG_ENV("SIVO_H3_BOOST") ? std::atoi(SIVO_DIAG_ENV("SIVO_H3_BOOST")) : 0;
     auto scale_for = [&](uint32_t b, float *vmax) {
         float v;
         std::memcpy(&v, &b, 4);
@@ -859,7 +859,7 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                     }
                     launch_conv3_h3(b, st);
                 } else if (op.wino4f) {
-                    static const bool epi4 = !(std::getenv("SIVO_W4F_EPI") && std::atoi(std::getenv("SIVO_W4F_EPI")) == 0);
+                    static const bool epi4 = !(SIVO_DIAG_ENV("SIVO_W4F_EPI") && std::atoi(SIVO_DIAG_ENV("SIVO_W4F_EPI")) == 0);
                     if (epi4) a.variant |= 4096;      // float4 form of the output stage (conv_wino4f.hip)
                     launch_conv_wino4f(a, st);
                 } else if (op.wino4) {
@@ -1338,7 +1338,7 @@ extern "C" int sivo_segnet_blob(sivo_segnet_t h, const char *name, float *host_o
         if (it == h->blob_id.end()) throw std::invalid_argument(std::string("no blob named '") + name + "'");
         const Blob &b = h->blobs[it->second];
         if (b.fused_away)
-            throw std::invalid_argument(std::string("blob '") + name + "' is not materialised: it only exists on chip, fused into the next convolution (SIVO_NO_FUSE_UNPOOL=1 / SIVO_NO_FUSE_BRIDGE=1 / SIVO_NO_FUSE_POOL=1 keep Upsample outputs / conv-to-conv activations / pooled convolutions in HBM)");
+            throw std::invalid_argument(std::string("blob '") + name + "' is not materialised: it only exists on chip, fused into the next convolution (the diagnostic library libsivo_hip_diag.so has switches that keep Upsample outputs / conv-to-conv activations / pooled convolutions in HBM: DESIGN.md appendix)");
         const int N = b.shared ? 1 : h->T;
         if (shape) { shape[0] = N; shape[1] = b.C; shape[2] = b.H; shape[3] = b.W; }
         const size_t n = (size_t)N * b.chw();

@@ -129,7 +129,7 @@ SegnetMulti *segnet_multi_create(const char *text, size_t len, int t_total, cons
     if (!device_ids || ndev < 1) throw std::invalid_argument("device_ids is empty");
     std::unique_ptr<SegnetMulti> M(new SegnetMulti);
     M->dev.resize((size_t)ndev);
-    M->emulate = std::getenv("SIVO_MULTI_EMULATE") && std::atoi(std::getenv("SIVO_MULTI_EMULATE")) == 1;
+    M->emulate = SIVO_DIAG_ENV("SIVO_MULTI_EMULATE") && std::atoi(SIVO_DIAG_ENV("SIVO_MULTI_EMULATE")) == 1;
     DeviceRestore restore;              // whatever happens below, the caller's device is current again on the way out
     // T from the prototxt unless overridden: build device 0 first to learn the shape
     for (int d = 0; d < ndev; ++d) {

@@ -33,6 +33,7 @@ class BayesianSegNet:
         """devices: list of HIP device ids -> the T samples of a frame are spread over them inside the handle
         (sivo_segnet_create_multi: RCCL reduce-scatter / all-gather); only segment_image works on such a handle."""
         h = C.c_void_p()
+        self._L = lib()          # the library this object lives in (product, or the diagnostic build inside `with _lib.use("diag")`)
         self.devices = list(devices) if devices is not None else None
         if params is not None:
             if not params.model_file:
@@ -43,39 +44,39 @@ class BayesianSegNet:
                 raise _lib.SivoError(_lib.ERR_UNSUPPORTED, "use_gpu=false: this library has no CPU path")
             if self.devices is not None:
                 ids = (C.c_int32 * len(self.devices))(*self.devices)
-                rc = lib().sivo_segnet_create_multi_from_files(params.model_file.encode(), params.weights_file.encode(), T,
+                rc = self._L.sivo_segnet_create_multi_from_files(params.model_file.encode(), params.weights_file.encode(), T,
                                                                ids, len(self.devices), C.byref(h))
                 device = self.devices[0] if self.devices else 0
             else:
-                rc = lib().sivo_segnet_create_from_files(params.model_file.encode(), params.weights_file.encode(), T,
+                rc = self._L.sivo_segnet_create_from_files(params.model_file.encode(), params.weights_file.encode(), T,
                                                          device, C.byref(h))
         elif self.devices is not None:
             text = prototxt.encode() if isinstance(prototxt, str) else (prototxt or b"")
             w = np.ascontiguousarray(weights if weights is not None else np.zeros(0), np.float32)
             ids = (C.c_int32 * len(self.devices))(*self.devices)
-            rc = lib().sivo_segnet_create_multi(text, len(text), T, w.ctypes.data_as(C.c_void_p), w.size, ids, len(self.devices), C.byref(h))
+            rc = self._L.sivo_segnet_create_multi(text, len(text), T, w.ctypes.data_as(C.c_void_p), w.size, ids, len(self.devices), C.byref(h))
             device = self.devices[0] if self.devices else 0
         else:
             text = prototxt.encode() if isinstance(prototxt, str) else (prototxt or b"")
             w = np.ascontiguousarray(weights if weights is not None else np.zeros(0), np.float32)
-            rc = lib().sivo_segnet_create(text, len(text), T, w.ctypes.data_as(C.c_void_p), w.size, device, C.byref(h))
+            rc = self._L.sivo_segnet_create(text, len(text), T, w.ctypes.data_as(C.c_void_p), w.size, device, C.byref(h))
         if rc == _lib.ERR_INVALID_ARGUMENT:
-            raise ValueError(lib().sivo_last_error().decode())                     # std::invalid_argument
+            raise ValueError(self._L.sivo_last_error().decode())                     # std::invalid_argument
         check(rc)
         self._h = h
         self.device = device
         T_, C_, H_, W_, K_ = (C.c_int32() for _ in range(5))
-        check(lib().sivo_segnet_shape(h, T_, C_, H_, W_, K_))
+        check(self._L.sivo_segnet_shape(h, T_, C_, H_, W_, K_))
         self.T, self.C, self.H, self.W, self.classes = T_.value, C_.value, H_.value, W_.value, K_.value
         a, b = C.c_double(), C.c_double()
-        check(lib().sivo_segnet_flops(h, C.byref(a), C.byref(b)))
+        check(self._L.sivo_segnet_flops(h, C.byref(a), C.byref(b)))
         self.flops_shared, self.flops_per_sample = a.value, b.value
 
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
             try:
-                lib().sivo_segnet_destroy(h)
+                self._L.sivo_segnet_destroy(h)
             except Exception:      # interpreter shutdown: the module globals may already be gone
                 pass
             self._h = None
@@ -93,14 +94,14 @@ class BayesianSegNet:
         prob_sum = torch.empty((self.classes, self.H, self.W), dtype=torch.float32, device=dev)
         logits = torch.empty((n, self.classes, self.H, self.W), dtype=torch.float32, device=dev) if want_logits else None
         prob = torch.empty((n, self.classes, self.H, self.W), dtype=torch.float32, device=dev) if want_prob else None
-        check(lib().sivo_segnet_forward_dev(self._h, d_bgr.data_ptr(), n, sample0, C.c_uint64(seed), prob_sum.data_ptr(),
+        check(self._L.sivo_segnet_forward_dev(self._h, d_bgr.data_ptr(), n, sample0, C.c_uint64(seed), prob_sum.data_ptr(),
                                             logits.data_ptr() if want_logits else None,
                                             prob.data_ptr() if want_prob else None, _stream()))
         return prob_sum, logits, prob
 
     def forward_into(self, d_bgr, seed, prob_sum, n_samples=None, sample0=0):
         n = self.T if n_samples is None else n_samples
-        check(lib().sivo_segnet_forward_dev(self._h, d_bgr.data_ptr(), n, sample0, C.c_uint64(seed), prob_sum.data_ptr(),
+        check(self._L.sivo_segnet_forward_dev(self._h, d_bgr.data_ptr(), n, sample0, C.c_uint64(seed), prob_sum.data_ptr(),
                                             None, None, _stream()))
 
     def finalize(self, prob_sum, t_total=None, out=None):
@@ -111,7 +112,7 @@ class BayesianSegNet:
             out = (torch.empty((self.H, self.W), dtype=torch.uint8, device=dev),
                    torch.empty((self.H, self.W), dtype=torch.float64, device=dev),
                    torch.empty((self.H, self.W), dtype=torch.float64, device=dev))
-        check(lib().sivo_mc_finalize_dev(prob_sum.data_ptr(), self.classes, self.H * self.W, t_total,
+        check(self._L.sivo_mc_finalize_dev(prob_sum.data_ptr(), self.classes, self.H * self.W, t_total,
                                          out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), _stream()))
         return out
 
@@ -121,10 +122,10 @@ class BayesianSegNet:
         if logits is not None:
             assert logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous()
             assert tuple(logits.shape) == (self.T, self.classes, self.H, self.W)
-            check(lib().sivo_segnet_segment_logits_dev(self._h, d_bgr.data_ptr(), C.c_uint64(seed), out[0].data_ptr(),
+            check(self._L.sivo_segnet_segment_logits_dev(self._h, d_bgr.data_ptr(), C.c_uint64(seed), out[0].data_ptr(),
                                                        out[1].data_ptr(), out[2].data_ptr(), logits.data_ptr(), _stream()))
             return out
-        check(lib().sivo_segnet_segment_dev(self._h, d_bgr.data_ptr(), C.c_uint64(seed), out[0].data_ptr(), out[1].data_ptr(),
+        check(self._L.sivo_segnet_segment_dev(self._h, d_bgr.data_ptr(), C.c_uint64(seed), out[0].data_ptr(), out[1].data_ptr(),
                                             out[2].data_ptr(), _stream()))
         return out
 
@@ -135,7 +136,7 @@ class BayesianSegNet:
         classes = np.empty((self.H, self.W), np.uint8)
         conf = np.empty((self.H, self.W), np.float64)
         ent = np.empty((self.H, self.W), np.float64)
-        check(lib().sivo_segnet_segment(self._h, img.ctypes.data_as(C.c_void_p), img.shape[0], img.shape[1],
+        check(self._L.sivo_segnet_segment(self._h, img.ctypes.data_as(C.c_void_p), img.shape[0], img.shape[1],
                                         C.c_uint64(seed), classes.ctypes.data_as(C.c_void_p),
                                         conf.ctypes.data_as(C.c_void_p), ent.ctypes.data_as(C.c_void_p)))
         return classes, conf, ent
@@ -144,15 +145,15 @@ class BayesianSegNet:
         """Bracket every kernel of the forward with HIP events on its launch stream (mfma_only: just the convolution
         kernels / the F(4x4,3x3) GEMM — a handful of events per forward, for use inside a timed run)."""
         mode = (3 if reset else 4) if (enable and mfma_only) else 2 if (enable and reset) else int(bool(enable))
-        check(lib().sivo_segnet_profile(self._h, mode))
+        check(self._L.sivo_segnet_profile(self._h, mode))
 
     def profile_read(self):
         """List of dicts: layer, kernel, samples, launches (forward passes), kernel_launches, flops_per_sample,
         bytes_per_sample, ms_total."""
         n = C.c_int32(0)
-        check(lib().sivo_segnet_profile_read(self._h, None, 0, C.byref(n)))
+        check(self._L.sivo_segnet_profile_read(self._h, None, 0, C.byref(n)))
         arr = (_lib.OpProfile * n.value)()
-        check(lib().sivo_segnet_profile_read(self._h, arr, n.value, C.byref(n)))
+        check(self._L.sivo_segnet_profile_read(self._h, arr, n.value, C.byref(n)))
         return [dict(layer=a.layer.decode(), kernel=a.kernel.decode(), samples=a.samples, launches=a.launches,
                      flops_per_sample=a.flops_per_sample, bytes_per_sample=a.bytes_per_sample, ms_total=a.ms_total,
                      kernel_launches=a.kernel_launches)
@@ -165,16 +166,16 @@ class BayesianSegNet:
         class _Row(C.Structure):
             _fields_ = [("layer", C.c_char * 48), ("vmax", C.c_float), ("vscale", C.c_float), ("uscale", C.c_float)]
         mode, ov, n = C.c_int32(), C.c_int32(), C.c_int32()
-        check(lib().sivo_segnet_gemm_status(self._h, C.byref(mode), C.byref(ov), None, 0, C.byref(n)))
+        check(self._L.sivo_segnet_gemm_status(self._h, C.byref(mode), C.byref(ov), None, 0, C.byref(n)))
         rows = (_Row * max(n.value, 1))()
-        check(lib().sivo_segnet_gemm_status(self._h, C.byref(mode), C.byref(ov), rows, n.value, C.byref(n)))
+        check(self._L.sivo_segnet_gemm_status(self._h, C.byref(mode), C.byref(ov), rows, n.value, C.byref(n)))
         return mode.value, ov.value, [(r.layer.decode(), r.vmax, r.vscale, r.uscale) for r in rows[:n.value]]
 
     def blob(self, name):
         shape = (C.c_int32 * 4)()
-        check(lib().sivo_segnet_blob(self._h, name.encode(), None, 0, shape))
+        check(self._L.sivo_segnet_blob(self._h, name.encode(), None, 0, shape))
         out = np.empty(tuple(shape), np.float32)
-        check(lib().sivo_segnet_blob(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), out.size, shape))
+        check(self._L.sivo_segnet_blob(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), out.size, shape))
         return out
 
 

@@ -96,11 +96,15 @@ def test_the_two_stage_loops_agree_bit_for_bit(unpool, monkeypatch):
     scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
     shift = rng.uniform(-0.2, 0.2, Cout).astype(np.float32)
     outs = []
+    from sivo_amd import _lib
     for form in ("0", "1"):
-        monkeypatch.setenv("SIVO_D3_FORM", form)
-        out, _, ov = segnet.conv3_h3(x, wt, scale, shift, relu=False, mask=mask)
+        monkeypatch.setenv("SIVO_D3_FORM", form)          # (a switch of the diagnostic build: libsivo_hip_diag.so, the same sources with -DSIVO_DIAG)
+        with _lib.use("diag"):
+            out, _, ov = segnet.conv3_h3(x, wt, scale, shift, relu=False, mask=mask)
         assert not ov
         outs.append(out)
+    ref, _, _ = segnet.conv3_h3(x, wt, scale, shift, relu=False, mask=mask)       # the product library's kernel
+    assert torch.equal(outs[1], ref)
     assert torch.equal(outs[0], outs[1])
 
 

@@ -4,6 +4,7 @@ Tolerances: logits max-abs 1e-3 (BASELINE.json north_star: "segmentation logits 
 1e-3 fp32"); probabilities / confidence / entropy 1e-5 (fp32 softmax, expf 1-ulp
 differences between libm and the device); classes exact except where the top-2 mean
 probabilities are closer than 1e-5."""
+import contextlib
 import os
 
 import numpy as np
@@ -17,6 +18,27 @@ from sivo_amd.segnet import BayesianSegNet, mc_finalize, mc_reduce, mc_segment, 
 pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1e-3
 
+
+
+# The product library reads eight environment switches; every A/B or fault-injection switch exists in the
+# diagnostic build only (libsivo_hip_diag.so: the same sources compiled with -DSIVO_DIAG).  Objects created inside the block live there.
+_PRODUCT_SWITCHES = {"SIVO_LANES", "SIVO_GEMM", "SIVO_D3", "SIVO_D3_PK", "SIVO_CONV7", "SIVO_WINO4_MB", "SIVO_ORB_PRIO", "SIVO_DEBUG_SYNC"}
+
+
+@contextlib.contextmanager
+def _diag(**env):
+    from sivo_amd import _lib
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        with _lib.use("diag"):
+            yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 def _make(text, T, seed=42):
     net = oproto.parse(text)
@@ -154,11 +176,8 @@ def test_bridged_convolutions_are_bit_identical(H, W, width, monkeypatch):
     _, lg_fused, _ = sn.forward(img, 77, sample0=1, want_logits=True)
     with pytest.raises(ValueError, match="not materialised"):
         sn.blob("c1")
-    os.environ["SIVO_NO_FUSE_BRIDGE"] = "1"
-    try:
+    with _diag(SIVO_NO_FUSE_BRIDGE="1"):
         _, _, sn2 = _make(text, T, seed=5)
-    finally:
-        del os.environ["SIVO_NO_FUSE_BRIDGE"]
     _, lg_plain, _ = sn2.forward(img, 77, sample0=1, want_logits=True)
     torch.cuda.synchronize()
     assert sn2.blob("c1").shape == (T, width, H, W)
@@ -175,11 +194,8 @@ def test_pooling_fused_into_the_output_transform_is_bit_identical():
     _, lg_fused, _ = sn.forward(img, 321, sample0=2, want_logits=True)
     with pytest.raises(ValueError, match="not materialised"):
         sn.blob("conv4_3")
-    os.environ["SIVO_NO_FUSE_POOL"] = "1"
-    try:
+    with _diag(SIVO_NO_FUSE_POOL="1"):
         _, _, sn2 = _make(text, T)
-    finally:
-        del os.environ["SIVO_NO_FUSE_POOL"]
     _, lg_plain, _ = sn2.forward(img, 321, sample0=2, want_logits=True)
     torch.cuda.synchronize()
     assert sn2.blob("conv4_3").shape == (T, 512, H // 8, W // 8)
@@ -200,11 +216,8 @@ def test_fused_upsample_is_bit_identical_to_the_materialised_one():
     _, lg_fused, _ = sn.forward(img, 123, want_logits=True)
     with pytest.raises(ValueError, match="not materialised"):
         sn.blob("pool4_D")
-    os.environ["SIVO_NO_FUSE_UNPOOL"] = "1"
-    try:
+    with _diag(SIVO_NO_FUSE_UNPOOL="1"):
         _, _, sn2 = _make(text, T)
-    finally:
-        del os.environ["SIVO_NO_FUSE_UNPOOL"]
     _, lg_plain, _ = sn2.forward(img, 123, want_logits=True)
     torch.cuda.synchronize()
     assert sn2.blob("pool4_D").shape == (T, 512, H // 8, W // 8)
@@ -304,11 +317,8 @@ def test_winograd_and_direct_conv_shapes(oracle, H, W, width):
     width 256 takes the F(4x4,3x3) path (conv_wino4.hip): ragged and odd tile rows, W a multiple of 4 only, one tile."""
     T = 3
     text = _conv_stack_prototxt(T, H, W, width)
-    os.environ["SIVO_NO_FUSE_BRIDGE"] = "1"          # every intermediate blob is inspected below
-    try:
+    with _diag(SIVO_NO_FUSE_BRIDGE="1"):          # every intermediate blob is inspected below
         net, w, sn = _make(text, T, seed=11)
-    finally:
-        del os.environ["SIVO_NO_FUSE_BRIDGE"]
     img = _image(np.random.default_rng(H * W), H, W)
     ob = oracle.run_net(net, w, oracle.preprocess(img, T, H, W), 31, sample0=2)
     _, logits, _ = sn.forward(torch.from_numpy(img).cuda(), 31, sample0=2, want_logits=True)
@@ -330,21 +340,15 @@ def test_persistent_fused_f4x4_kernel_is_bit_identical(H, W):
     and columns, more tiles than workgroups and fewer, with and without the dropout epilogue.  Every blob bit for bit."""
     T = 5
     text = _conv_stack_prototxt(T, H, W, 64)
-    os.environ["SIVO_NO_FUSE_BRIDGE"] = "1"
-    try:
+    with _diag(SIVO_NO_FUSE_BRIDGE="1"):
         net, w, sn = _make(text, T, seed=3)
-    finally:
-        del os.environ["SIVO_NO_FUSE_BRIDGE"]
     d_img = torch.from_numpy(_image(np.random.default_rng(H + W), H, W)).cuda()
     got = {}
     for mode in ("0", "2"):
-        os.environ["SIVO_W4F_PERSIST"] = mode
-        try:
+        with _diag(SIVO_W4F_PERSIST=mode):
             _, logits, _ = sn.forward(d_img, 9, want_logits=True)
             torch.cuda.synchronize()
             got[mode] = [sn.blob(n) for n in ("c1", "c2")] + [logits.cpu().numpy()]
-        finally:
-            del os.environ["SIVO_W4F_PERSIST"]
     for a, b in zip(got["0"], got["2"]):
         assert np.array_equal(a, b)
     assert np.abs(got["2"][1]).max() > 0
@@ -477,11 +481,8 @@ def test_multi_device_handle_emulated_on_one_gpu(ndev, T, kitti_like_bgr):
     H, W = 32, 64
     text = netspec.tiny_prototxt(T, H, W)
     net, w, sn = _make(text, T)
-    os.environ["SIVO_MULTI_EMULATE"] = "1"
-    try:
+    with _diag(SIVO_MULTI_EMULATE="1"):
         multi = BayesianSegNet(prototxt=text, weights=wts.pack(net["layers"], w), T=T, devices=[0] * ndev)
-    finally:
-        del os.environ["SIVO_MULTI_EMULATE"]
     big = np.ascontiguousarray(kitti_like_bgr[:80, :150])
     for seed in (5, 6):
         cls_m, conf_m, ent_m = multi.segment_image(big, seed=seed)
@@ -493,6 +494,9 @@ def test_multi_device_handle_emulated_on_one_gpu(ndev, T, kitti_like_bgr):
 
 
 def _make_env(text, T, seed, **env):
+    if set(env) - _PRODUCT_SWITCHES:
+        with _diag(**env):
+            return _make(text, T, seed=seed)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update({k: str(v) for k, v in env.items()})
     try:

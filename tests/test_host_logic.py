@@ -283,6 +283,20 @@ def test_abi_exports_every_declared_symbol():
     assert "sivo_debug_" not in exported
 
 
+def test_product_library_reads_eight_documented_switches():
+    """Every A/B, ablation and fault-injection switch lives behind SIVO_DIAG_ENV (sivo_amd/csrc/common.hpp) and exists in
+    libsivo_hip_diag.so only; the product binary does not even contain their names."""
+    import subprocess
+    names = sorted(set(l.strip() for l in subprocess.run(["strings", _lib.LIB_PATH], capture_output=True, text=True).stdout.splitlines() if "SIVO_" in l))
+    assert names == ["SIVO_CONV7", "SIVO_D3", "SIVO_D3_PK", "SIVO_DEBUG_SYNC", "SIVO_GEMM", "SIVO_LANES", "SIVO_ORB_PRIO", "SIVO_WINO4_MB"], names
+    diag = subprocess.run(["strings", _lib.DIAG_PATH], capture_output=True, text=True).stdout
+    for name in ("SIVO_H3_BOOST", "SIVO_MULTI_EMULATE", "SIVO_NO_FUSE_BRIDGE", "SIVO_D3_FORM", "SIVO_D3_ABL"):
+        assert name in diag, name
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for name in names:
+        assert name in design, name
+
+
 def test_struct_layouts_match_reference_types():
     assert C.sizeof(_lib.KeyPoint) == 28 and orb.KP_DTYPE.itemsize == 28      # cv::KeyPoint
     assert C.sizeof(_lib.Edge) == 48
