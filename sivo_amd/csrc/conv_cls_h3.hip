@@ -57,10 +57,10 @@ constexpr int C_W0 = 2 * C_STAGE;
 static_assert(C_NDMA == 44 && C_NDMA % 4 == 0, "DMA pieces per wave");
 static_assert(C_W0 + 3 * C_WKS <= 160 * 1024 - 2048, "LDS (the last 2 KiB are the prefetch probes' scratch)");
 
-// NW = 4: one wave per SIMD, wave w owns rows 2 w, 2 w + 1 (four blocks of 16 pixels).  NW = 8 (the default): two waves per SIMD,
-// wave w owns row w (two blocks) — with one wave per SIMD nothing runs while a wave issues its 13 DMA pieces of the next stage,
-// waits at the stage barrier or does a sample's Softmax; the second wave's multiply fills those gaps (at the price of the
-// weight fragments being read once per two blocks instead of once per four).
+// NW = 4 (the default): one wave per SIMD, wave w owns rows 2 w, 2 w + 1 (four blocks of 16 pixels).  NW = 8 (diagnostic build,
+// SIVO_CLS_NW=8): two waves per SIMD, wave w owns row w (two blocks) — written to fill the gaps of the one-wave form (DMA issue,
+// stage barrier, a sample's Softmax) and measured SLOWER (0.54 against 0.46 ms, tools/cls_probe.py): the weight fragments are read
+// once per two blocks instead of once per four, and half the lanes idle through every sample's Softmax.
 // ABL (diagnostic builds only, -DSIVO_DIAG; results are wrong by construction): 1 no MFMAs, 2 no Softmax / sum at the end of a sample,
 // 4 no patch DMA after the first stage, 8 no fragment reads after the first tap.
 template <int NW, int ABL = 0>
@@ -303,18 +303,18 @@ void launch_conv_cls_h3(const ClsMcArgs &a0, hipStream_t s) {
     if (const char *ab = SIVO_DIAG_ENV("SIVO_CLS_ABL")) {                                     // diagnostic build: ablations of the default form
 #define CLS_ABL_CASE(n)                                                                                                                             \
     case n:                                                                                                                                         \
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_cls_h3_kernel<8, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        hipLaunchKernelGGL((conv_cls_h3_kernel<8, n>), dim3((unsigned)(8 * per)), dim3(512), (size_t)160 * 1024, s, a);                            \
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_cls_h3_kernel<4, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((conv_cls_h3_kernel<4, n>), dim3((unsigned)(8 * per)), dim3(256), (size_t)160 * 1024, s, a);                            \
         return;
         switch (std::atoi(ab)) { CLS_ABL_CASE(1) CLS_ABL_CASE(2) CLS_ABL_CASE(3) CLS_ABL_CASE(4) CLS_ABL_CASE(6) CLS_ABL_CASE(8) CLS_ABL_CASE(9) CLS_ABL_CASE(11) CLS_ABL_CASE(15) default: break; }
 #undef CLS_ABL_CASE
     }
-    if (SIVO_DIAG_ENV("SIVO_CLS_NW") && std::atoi(SIVO_DIAG_ENV("SIVO_CLS_NW")) == 4) {        // diagnostic build: the one-wave-per-SIMD form
-        hipLaunchKernelGGL((conv_cls_h3_kernel<4>), dim3((unsigned)(8 * per)), dim3(256), (size_t)160 * 1024, s, a);
+    if (SIVO_DIAG_ENV("SIVO_CLS_NW") && std::atoi(SIVO_DIAG_ENV("SIVO_CLS_NW")) == 8) {        // diagnostic build: the two-waves-per-SIMD form
+        hipLaunchKernelGGL((conv_cls_h3_kernel<8>), dim3((unsigned)(8 * per)), dim3(512), (size_t)160 * 1024, s, a);
         return;
     }
 #endif
-    hipLaunchKernelGGL((conv_cls_h3_kernel<8>), dim3((unsigned)(8 * per)), dim3(512), (size_t)160 * 1024, s, a);
+    hipLaunchKernelGGL((conv_cls_h3_kernel<4>), dim3((unsigned)(8 * per)), dim3(256), (size_t)160 * 1024, s, a);
 }
 
 }  // namespace sivo

@@ -93,6 +93,8 @@ struct Op {
     int wino_cfg = 0;
     bool wino4f = false;       // conv_wino4f.hip: fused F(4x4,3x3), 64 couts per workgroup (narrow layers)
     bool c7x6 = false;         // conv7_x6.hip: direct 7x7 on the bf16 matrix cores (bf16x6); weights in d_wx6
+    bool c7h3 = false;         // conv7_h3.hip: the same layer on the fp16 matrix cores (f16x3: the default while the handle runs f16x3); weights
+                               // in d_wd3, d3_uscale / d3_vscale / d3_vmax as for a direct f16x3 layer.  The bf16x6 form stays resident (fallback)
     bool wino4 = false;        // conv_wino4.hip: F(4x4,3x3) as input transform + batched GEMM + output transform
     int wino4_group = 1;       // samples per V/M workspace pass
     std::vector<hipEvent_t> w4_ev;                 // profiling: 4 events per group of the last launch
@@ -258,6 +260,14 @@ void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int 
         op.d_wx6 = dev_alloc<uint16_t>(planes.size());
         S.owned.push_back(op.d_wx6);
         SIVO_HIP(hipMemcpy(op.d_wx6, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        if (!no_d3 && gemm_default && conv7_h3_supported(ks, cin, cout, H, Wd)) {
+            std::vector<uint16_t> hp;
+            op.d3_uscale = conv7_h3_pack_weights(W, cin, cout, hp);
+            op.d_wd3 = dev_alloc<uint16_t>(hp.size());
+            S.owned.push_back(op.d_wd3);
+            SIVO_HIP(hipMemcpy(op.d_wd3, hp.data(), hp.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            op.c7h3 = true;
+        }
     }
     if (op.wino4f) {
         wino4f_pack_weights(W, cin, cout, wt, &op.cout_pad);
@@ -381,7 +391,9 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             {
                 char kn[96];
                 const int bn = conv_cout_tile(op.ks, op.cout), kc = conv_k_chunk(op.ks, op.cin);
-                if (op.c7x6)
+                if (op.c7h3)
+                    snprintf(kn, sizeof kn, "conv7_h3_kernel");
+                else if (op.c7x6)
                     snprintf(kn, sizeof kn, "conv7_x6_kernel");
                 else if (op.wino4f)
                     snprintf(kn, sizeof kn, "conv_wino4f_kernel");
@@ -713,7 +725,7 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
 // SIVO_H3_BOOST=k multiplies the scales by 2^k (tests: k = 9 forces the overflow path).
 void calibrate_h3(sivo_segnet &S) {
     bool any = false;
-    for (const Op &op : S.ops) any = any || op.d_wh3 || op.d3 || op.c3;
+    for (const Op &op : S.ops) any = any || op.d_wh3 || op.d3 || op.c3 || op.c7h3;
     if (!any) return;
     uint32_t *flag = nullptr;
     SIVO_HIP(hipHostMalloc((void **)&flag, 64, hipHostMallocDefault));
@@ -747,7 +759,7 @@ void calibrate_h3(sivo_segnet &S) {
     for (size_t i = 0; i < S.ops.size(); ++i) {
         Op &op = S.ops[i];
         if (op.d_wh3) op.h3_vscale = scale_for(bits[i], &op.h3_vmax);
-        if (op.d3 || op.c3) op.d3_vscale = scale_for(bits[S.ops.size() + i], &op.d3_vmax);
+        if (op.d3 || op.c3 || op.c7h3) op.d3_vscale = scale_for(bits[S.ops.size() + i], &op.d3_vmax);
     }
     S.h3_on = true;
 }
@@ -829,7 +841,7 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                 if (pk_live && ((op.pk_in && (int)oi != S.cls_op) || (pk_out_now && !op.wino4)) && !d3_now)
                     throw std::runtime_error("layer '" + op.name + "': planned for packed activations but not running its f16x3 kernel");
                 Blob &bo_w = S.blobs[op.out];
-                if (op.d3 && S.calibrating && S.d_h3_vmax) {
+                if ((op.d3 || op.c7h3) && S.calibrating && S.d_h3_vmax) {
                     // the layer's largest |input| (the pooled tensor holds the same values as its Upsample)
                     const int64_t plane_in = a.unpool_mask ? (int64_t)(a.H / 2) * (a.W / 2) : (int64_t)a.H * a.W;
                     launch_absmax(a.in, (int64_t)(a.in_sample_stride ? N : 1) * op.cin * plane_in, S.d_h3_vmax + S.ops.size() + oi, st);
@@ -899,6 +911,11 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                         bo_w.pk_scale = S.ops[op.pk_to].d3_vscale;
                     }
                     bo_w.pk_fresh = false;
+                }
+                else if (op.c7h3 && S.h3_on && !S.calibrating && op.d3_vscale > 0.f) {
+                    ConvArgs b = a;
+                    b.wt_h3 = op.d_wd3; b.h3_vscale = op.d3_vscale; b.h3_uscale = op.d3_uscale; b.h3_flag = const_cast<uint32_t *>(S.h3_flag);
+                    launch_conv7_h3(b, st);
                 }
                 else if (op.c7x6) launch_conv7_x6(a, st);
                 else if (op.wino) launch_conv_wino(a, op.wino_cfg, st);
@@ -1424,7 +1441,7 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
             std::memset(&p, 0, sizeof p);
             std::snprintf(p.layer, sizeof p.layer, "%s", op.name.c_str());
             const bool d3_on = op.d3 && h->h3_on && op.d3_vscale > 0.f && op.drop_site < 0 && op.pool_op < 0;
-            std::snprintf(p.kernel, sizeof p.kernel, "%s", op.mc_fused_last ? (op.cls_h3_last ? "conv_cls_h3_kernel" : "conv_wino_cls_mc_kernel") : d3_on ? "conv3_h3_kernel" : op.kernel.c_str());
+            std::snprintf(p.kernel, sizeof p.kernel, "%s", op.mc_fused_last ? (op.cls_h3_last ? "conv_cls_h3_kernel" : "conv_wino_cls_mc_kernel") : d3_on ? "conv3_h3_kernel" : (op.c7h3 && !(h->h3_on && op.d3_vscale > 0.f)) ? "conv7_x6_kernel" : op.kernel.c_str());
             p.samples = op.last_n;
             p.flops_per_sample = op.flops;
             p.bytes_per_sample = op.bytes;
@@ -1448,7 +1465,7 @@ extern "C" int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow
         bool any_h3 = false, any_x6 = false;
         int rows = 0;
         for (const Op &op : h->ops) {
-            if (op.d3 || op.c3) {        // direct f16x3 layer / classifier: vmax / vscale are those of its input activation
+            if (op.d3 || op.c3 || op.c7h3) {        // direct f16x3 layer / classifier: vmax / vscale are those of its input activation
                 any_h3 = any_h3 || op.d3_vscale > 0.f;
                 if (per_layer && rows < capacity) {
                     SivoH3Layer &r = per_layer[rows];

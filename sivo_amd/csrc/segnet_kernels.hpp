@@ -101,6 +101,11 @@ void launch_pool_bits(const uint8_t *codes, uint32_t *bits, int N, int C, int Hq
 bool conv7_x6_supported(int ks, int cin, int cout, int H, int W);
 void conv7_x6_pack_weights(const float *W, int cin, int cout, std::vector<uint16_t> &out);
 void launch_conv7_x6(const ConvArgs &a, hipStream_t s);
+// the same layers on the fp16 matrix cores, f16x3 (conv7_h3.hip): weights in ConvArgs::wt_h3, h3_vscale = the calibrated power of two of
+// the INPUT, h3_uscale the weights' (returned by the packer), h3_flag the overflow flag (a frame that raises it is recomputed on bf16x6)
+bool conv7_h3_supported(int ks, int cin, int cout, int H, int W);
+float conv7_h3_pack_weights(const float *W, int cin, int cout, std::vector<uint16_t> &out);
+void launch_conv7_h3(const ConvArgs &a, hipStream_t s);
 // fused Winograd F(4x4,3x3), 64 couts per workgroup (conv_wino4f.hip)
 bool wino4f_supported(int ks, int cin, int cout, int H, int W);
 int wino4f_slab_floats();

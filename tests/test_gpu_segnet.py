@@ -280,7 +280,9 @@ def test_mc_reduce_random(oracle, T, K, H, W):
     d = torch.from_numpy(lg).cuda()
     ps, prob = mc_reduce(d, want_prob=True)
     cls, conf, ent = mc_finalize(ps, T)
-    np.testing.assert_allclose(prob.cpu().numpy(), prob_o, atol=2e-7, rtol=0)
+    # (device Softmax: v_exp_f32 of (x - max) log2 e and one reciprocal per pixel, sivo_amd/csrc/softmax.hpp: the exponent's rounding
+    # adds |x - max| 2^-24 relative to a probability — at most ~4e-7 absolute here — where libm's expf and a division per class gave 2e-7)
+    np.testing.assert_allclose(prob.cpu().numpy(), prob_o, atol=1e-6, rtol=0)
     np.testing.assert_allclose(ps.cpu().numpy() / T, mean_o, atol=1e-6, rtol=0)
     np.testing.assert_allclose(conf.cpu().numpy(), conf_o, atol=1e-6, rtol=0)
     np.testing.assert_allclose(ent.cpu().numpy(), ent_o, atol=2e-5, rtol=0)

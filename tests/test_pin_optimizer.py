@@ -5,7 +5,7 @@ oracle/Makefile compiles /root/reference/src/orbslam/Optimizer.cc (and Converter
 restatement of g2o) and stand-in Frame / KeyFrame / MapPoint / Map.  tests/cpp/pin_optimizer.cpp runs PoseOptimization,
 LocalBundleAdjustment, BundleAdjustment and GlobalBundleAdjustment of that code and of this repository's SIVO::Optimizer member
 templates (sivo_amd/api/orbslam/OptimizerAdapter.h) on identical scenes — 22 cases — and requires identical return values,
-ordered mutation logs, outlier flags, surviving observations and BA marks, poses / points to 2e-6 and covariances to 1e-7.
+ordered mutation logs, outlier flags, surviving observations and BA marks, poses / points to 1e-5 (CPU leg: bitwise) and covariances to 1e-7.
 What this pins: the graph walk and the schedules of Optimizer.cc:273-491 and :493-926 (which observations become which edges,
 fixed keyframes, 4 x optimize(10) with the stereo-only re-classification, 5 + 10 iterations with the outlier pass, the erasure
 order, the write-back); g2o's own numerics stay a restatement (oracle/ba_solve_oracle.c).  Writing the test found two

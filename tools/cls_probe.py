@@ -23,7 +23,7 @@ logits = torch.empty((T, K, H, W), device="cuda")
 cls = torch.empty((H, W), dtype=torch.uint8, device="cuda")
 conf = torch.empty((H, W), dtype=torch.float64, device="cuda")
 ent = torch.empty((H, W), dtype=torch.float64, device="cuda")
-for name, env in [("as built (8 waves)", {}), ("4 waves", {"SIVO_CLS_NW": "4"}), ("no MFMA", {"SIVO_CLS_ABL": "1"}), ("no softmax", {"SIVO_CLS_ABL": "2"}),
+for name, env in [("as built (4 waves)", {}), ("8 waves", {"SIVO_CLS_NW": "8"}), ("no MFMA", {"SIVO_CLS_ABL": "1"}), ("no softmax", {"SIVO_CLS_ABL": "2"}),
                   ("no patch DMA", {"SIVO_CLS_ABL": "4"}), ("no fragment reads", {"SIVO_CLS_ABL": "8"}), ("no MFMA, no reads", {"SIVO_CLS_ABL": "9"}),
                   ("DMA + barriers only", {"SIVO_CLS_ABL": "11"}), ("barriers only", {"SIVO_CLS_ABL": "15"}), ("MFMA + reads only", {"SIVO_CLS_ABL": "6"})]:
     for k in ("SIVO_CLS_NW", "SIVO_CLS_ABL"):
