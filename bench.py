@@ -118,7 +118,9 @@ def cpu_baseline(kind, T, H, W, text, w, bgr, left, right, budget_note):
 #   the bf16x6 GEMM issues six bf16 MFMA products per fp32 product (6/4 of the algorithmic count, on the bf16 pipe), the
 #   f16x3 GEMM three fp16 products (3/4, on the fp16 pipe, same dense peak).
 BF16_MFMA_PEAK_TFLOPS = 2500.0
-KERNEL_CLASS = [("conv7_x6", 6.0, BF16_MFMA_PEAK_TFLOPS, "bf16 MFMA (direct 7x7; fp32 operands split into 3 bf16 planes, 6 products, fp32 accumulate)"),
+KERNEL_CLASS = [("conv7_h3", 3.0, BF16_MFMA_PEAK_TFLOPS, "fp16 MFMA (direct 7x7; fp32 operands as fp16 hi + lo planes, 3 products per fp32 product, fp32 accumulate)"),
+                ("conv_cls_h3", 3.0, BF16_MFMA_PEAK_TFLOPS, "fp16 MFMA (direct 3x3 classifier + Softmax + MC statistics; fp16 hi + lo planes, 3 products, fp32 accumulate)"),
+                ("conv7_x6", 6.0, BF16_MFMA_PEAK_TFLOPS, "bf16 MFMA (direct 7x7; fp32 operands split into 3 bf16 planes, 6 products, fp32 accumulate)"),
                 ("wino4_gemm_h3", 3.0 / 4.0, BF16_MFMA_PEAK_TFLOPS, "fp16 MFMA (fp32 operands as fp16 hi + lo planes, 3 products, fp32 accumulate)"),
                 ("conv3_h3", 3.0, BF16_MFMA_PEAK_TFLOPS, "fp16 MFMA (direct 3x3; fp32 operands as fp16 hi + lo planes, 3 products per fp32 product, fp32 accumulate)"),
                 ("wino4_gemm_x6", 6.0 / 4.0, BF16_MFMA_PEAK_TFLOPS, "bf16 MFMA (fp32 operands split into 3 bf16 planes, 6 products, fp32 accumulate)"),

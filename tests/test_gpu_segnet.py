@@ -295,7 +295,9 @@ def test_mc_reduce_random(oracle, T, K, H, W):
         mc_reduce(d[T // 2:], prob_sum=ps2, accumulate=True)
         np.testing.assert_allclose(ps2.cpu().numpy(), ps.cpu().numpy(), atol=1e-6, rtol=0)
     var = mc_variance(prob, cls)
-    np.testing.assert_allclose(var.cpu().numpy(), oracle.mc_variance(prob_o, cls.cpu().numpy()), atol=1e-7, rtol=0)
+    # the variance kernel on the SAME probabilities (the device's), then end to end with the Softmax difference above in its input
+    np.testing.assert_allclose(var.cpu().numpy(), oracle.mc_variance(prob.cpu().numpy(), cls.cpu().numpy()), atol=1e-7, rtol=0)
+    np.testing.assert_allclose(var.cpu().numpy(), oracle.mc_variance(prob_o, cls.cpu().numpy()), atol=1e-6, rtol=0)
 
 
 def _conv_stack_prototxt(T, H, W, width):
