@@ -320,6 +320,75 @@ def ba_scene(seed=99, n_kf=20, n_pts=3000):
     return poses, pts, np.concatenate(parts), (fx, fy, cx, cy, bf)
 
 
+def tracking_config(last, fp, intr, device, reps=20):
+    """The tracking thread's per-frame solver work on the timed frame's own keys (Tracking::TrackWithMotionModel, reference
+    src/orbslam/Tracking.cc:603-617): ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th = 7, bMono = false) and
+    Optimizer::PoseOptimization(&mCurrentFrame).  The last frame's map points are its stereo keys unprojected (UnprojectStereo),
+    the current frame holds the same keys seen from a pose 5 cm / 0.2 deg away; the motion model predicts that pose with a 1 cm
+    error.  Mean ms per call over `reps` calls, each search on a NEWLY built frame view (a frame is new every image)."""
+    from sivo_amd import matcher, optimizer
+    from sivo_amd.optimizer import EDGE_DTYPE
+    fx, fy, cx, cy, bf = intr
+    keys, desc, right, depth = last["keys"], last["desc"], last["right"], last["depth"]
+    ex = fp.ex_l
+    scale, sigma2, inv_sigma2 = ex.GetScaleFactors(), ex.GetScaleSigmaSquares(), ex.GetInverseScaleSigmaSquares()
+    has = depth > 0
+    Xw = np.stack([(keys["x"] - cx) * depth / fx, (keys["y"] - cy) * depth / fy, depth], 1).astype(np.float64)      # last frame at the origin
+    # the current camera: yaw 0.2 deg, 5 cm forward; its keys = the projections of the points (+ the keys without depth as they are)
+    yaw = np.deg2rad(0.2)
+    Rcw = np.array([[np.cos(yaw), 0, -np.sin(yaw)], [0, 1, 0], [np.sin(yaw), 0, np.cos(yaw)]]); tcw = np.array([0.0, 0.0, -0.05])
+    Xc = Xw @ Rcw.T + tcw
+    cur = keys.copy(); cur_right = right.copy()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cur["x"][has] = (fx * Xc[has, 0] / Xc[has, 2] + cx).astype(np.float32); cur["y"][has] = (fy * Xc[has, 1] / Xc[has, 2] + cy).astype(np.float32)
+        cur_right[has] = (cur["x"][has] - bf / Xc[has, 2]).astype(np.float32)
+    inside = (cur["x"] >= 0) & (cur["x"] < 1024) & (cur["y"] >= 0) & (cur["y"] < 352)
+    cur, cur_desc, cur_right = cur[inside], desc[inside], cur_right[inside]
+    # motion-model prediction: 1 cm off
+    t_pred = tcw + np.array([0.01, 0.0, 0.0])
+    Xp = (Xw @ Rcw.T + t_pred).astype(np.float32)
+    valid = (has & (Xp[:, 2] > 0)).astype(np.uint8)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv_z = np.where(valid, 1.0 / Xp[:, 2], 0).astype(np.float32)
+        u = (fx * Xp[:, 0] * inv_z + cx).astype(np.float32); v = (fy * Xp[:, 1] * inv_z + cy).astype(np.float32)
+    bounds = (0.0, 1024.0, 0.0, 352.0)
+    occ = np.full(len(cur), -1, np.int32); obs = np.ones(len(keys), np.int32)
+    args = (valid, u, v, inv_z, keys["octave"], keys["angle"], desc, obs, 7.0, False, False, bf, True, occ)
+
+    def search():
+        F = matcher.MatchFrame(cur, cur_right, cur_desc, bounds, scale, sigma2, inv_sigma2, device=device)
+        return matcher.search_by_projection_frame(F, *args)
+    nm, match, _ = search()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        search()
+    t_search = (time.perf_counter() - t0) / reps
+    # PoseOptimization on those matches (Optimizer.cc:273-491: stereo edge where mvuRight >= 0, else mono)
+    k = np.nonzero(match >= 0)[0]
+    edges = np.zeros(len(k), EDGE_DTYPE)
+    edges["point"] = match[k]; edges["stereo"] = cur_right[k] >= 0
+    edges["obs"][:, 0] = cur["x"][k]; edges["obs"][:, 1] = cur["y"][k]; edges["obs"][:, 2] = np.where(cur_right[k] >= 0, cur_right[k], 0)
+    edges["inv_sigma2"] = inv_sigma2[cur["octave"][k]]
+    pose0 = np.concatenate([Rcw.ravel(), t_pred])
+    g = optimizer.pose_optimize(pose0, Xw, edges, intr)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g = optimizer.pose_optimize(pose0, Xw, edges, intr)
+    t_pose = (time.perf_counter() - t0) / reps
+    return {"name": "tracking thread, per frame (Tracking::TrackWithMotionModel, Tracking.cc:603-617) on the timed frame's semantic keys: "
+                    "ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, 7, false) + Optimizer::PoseOptimization(&mCurrentFrame)",
+            "metric": "ms per call (mean of %d, through the Python bindings; host gather of the projections not included)" % reps,
+            "search_by_projection_ms": round(1e3 * t_search, 4), "pose_optimization_ms": round(1e3 * t_pose, 4),
+            "value": round(1e3 * (t_search + t_pose), 4),
+            "last_frame_map_points": int(valid.sum()), "current_frame_keys": int(len(cur)), "matches": int(nm),
+            "pose_edges": int(len(k)), "pose_inliers": int(g["inliers"]), "lm_iterations": int(g["iterations"]), "lm_trials": int(g["trials"]),
+            "translation_error_m": round(float(np.abs(g["pose"][9:] - tcw).max()), 6),
+            "note": "each search builds a new frame view (sivo_mframe_create: grid + ONE upload into a pooled slab, no allocation) and runs one launch + one "
+                    "read-back; PoseOptimization is one launch of one persistent workgroup reading its edges from pinned host memory, no allocation, no copy calls",
+            "parity": "tests/test_pin_matcher.py (144 cases against the reference's ORBmatcher.cc compiled untouched, device leg in -m gpu), tests/test_gpu_search.py; "
+                      "tests/test_pin_optimizer.py (22 cases against the reference's Optimizer.cc compiled untouched), tests/test_gpu_ba_solve.py (1e-7 vs the oracle)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -332,7 +401,7 @@ def main():
     ap.add_argument("--no-orb", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--configs", default="all", help="N = 1 only: which further BASELINE configs to measure after the main one and "
-                    "report under \"configs\": all | none | comma list of basic,t48,ba,host (rocprofv3 runs use one at a time)")
+                    "report under \"configs\": all | none | comma list of basic,t48,ba,host,track,shards (rocprofv3 runs use one at a time)")
     ap.add_argument("--per-layer", action="store_true", help="print the per-layer event timings to stderr")
     args = ap.parse_args()
 
@@ -383,7 +452,14 @@ def main():
                 torch.empty((H, W), dtype=torch.float64, device="cuda"))
     maps = new_maps()
     do_orb = (rank == 0) and not args.no_orb
-    stats = {"kps": 0, "matches": 0}
+    stats = {"kps": 0, "matches": 0, "gate_s": 0.0, "gate_n": 0, "selected": 0, "last": None}
+    from sivo_amd import selection
+    # KITTI-00 intrinsics / baseline; a pose covariance of the size PoseOptimization leaves (1e-4 rad^2 / m^2); config_kitti.yaml's
+    # entropy-reduction threshold is a tuning parameter — 0 bits here ("the observation tells more about the pose than the class map
+    # doubts the point")
+    KFX = KFY = 718.856; KCX, KCY, KBF = 607.1928, 185.2157, 386.1448; KBL = KBF / KFX
+    STATE_COV = np.eye(6) * 1e-4
+    GATE_TH = 0.0
     # Frame.cc:125-174 on the device (sivo_amd/frame.py): the network is enqueued FIRST, the two extractors and the matching of
     # every left key run beside it, the semantic filter + median cull wait for the class map
     from sivo_amd.frame import StereoFramePipeline
@@ -391,26 +467,43 @@ def main():
     fp = StereoFramePipeline(device=local, start_delay_s=orb_delay) if do_orb else None
     tail_probe = [] if os.environ.get("SIVO_BENCH_TAIL_PROBE") else None         # experiment: host time of the cull behind the class map
 
+    rank_events = []         # N > 1: (start, forward done, all-reduce done) of every frame on this rank's stream
+
     def frame(seed):
         if world == 1:
             # one device holds all T samples: segmentImage on device-resident data (f64 mean, no probability sum in memory)
             sn.segment_into(d_bgr, seed, maps)           # asynchronous: ~65 launches enqueued in ~0.5 ms
             pending = fp.start_orb(d_left, d_right) if do_orb else None      # ORB of this frame runs beside the network
         else:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
             if n_local:
                 sn.forward_into(d_bgr, seed, prob_sum, n_samples=n_local, sample0=sample0)
             else:
                 prob_sum.zero_()                           # more ranks than samples: contribute nothing
+            ev[1].record()
             pending = fp.start_orb(d_left, d_right) if do_orb else None
             parallel.all_reduce_prob_sum(prob_sum)
+            ev[2].record()
             sn.finalize(prob_sum, t_total=T, out=maps)
+            rank_events.append(ev)
         if do_orb:
             cls_host = maps[0].cpu().numpy()              # 360 KB D2H; waits for this frame's class map
             t0 = time.perf_counter()
             r = fp.finish(pending, cls_host)
+            if world == 1:
+                # entropy feature selection over the frame's semantic keys (Tracking.cc:934-1023): the keys are on the host, the
+                # f64 entropy map stays where the network wrote it (sivo_entropy_gate_map_dev)
+                t1 = time.perf_counter()
+                d = r["depth"]; k = r["keys"]
+                xyz = np.stack([(k["x"] - KCX) * d / KFX, (k["y"] - KCY) * d / KFY, d], 1).astype(np.float64)
+                _, _, acc = selection.entropy_gate_map_dev(k, d, xyz, maps[2], STATE_COV, KFX, KFY, KBL, fp.ex_l.GetScaleSigmaSquares(), GATE_TH)
+                stats["gate_s"] += time.perf_counter() - t1; stats["gate_n"] += 1
+                stats["selected"] = int(acc.sum())
             if tail_probe is not None:
                 tail_probe.append(time.perf_counter() - t0)
             stats["kps"], stats["matches"] = r["semantic_keys"], r["stereo_matches"]
+            stats["last"] = r
 
     def barrier():
         torch.cuda.synchronize()
@@ -431,10 +524,25 @@ def main():
     PROFILE_EVERY = 8
     events = os.environ.get("SIVO_BENCH_NO_EVENTS") != "1"
     elapsed, prof_timed, prof, n_detail = time_segnet(sn, frame, args.steps, args.warmup, barrier, PROFILE_EVERY, events)
+    multi = None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # where a frame's time goes on every rank: its own shard's forward (prefix + n_local samples), then the all-reduce, which
+        # ends when the slowest rank has arrived — so "all-reduce" on a light rank is mostly waiting, on the heaviest rank the wire time
+        torch.cuda.synchronize()
+        evs = rank_events[args.warmup:args.warmup + args.steps]
+        mine = torch.tensor([float(np.mean([e[0].elapsed_time(e[1]) for e in evs])), float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))],
+                            dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        multi = {"forward_ms_per_rank": [round(float(t[0]), 3) for t in allr], "allreduce_incl_wait_ms_per_rank": [round(float(t[1]), 3) for t in allr],
+                 "allreduce_wire_ms": round(min(float(t[1]) for t in allr), 3),
+                 "allreduce_bytes": int(prob_sum.numel() * 4),
+                 "note": "HIP events on each rank's stream, mean over the timed frames: forward = the rank's shard (sample-invariant prefix + its samples); "
+                         "all-reduce incl. wait = from the end of the rank's forward to the end of the collective (waiting for the slowest rank included); "
+                         "wire = the smallest of those (the rank that arrives last waits for nobody)"}
 
     if rank == 0 and tail_probe:
         print(f"host tail (semantic filter + median cull) mean {1e3 * float(np.mean(tail_probe)):.3f} ms over {len(tail_probe)} frames", file=sys.stderr)
@@ -470,6 +578,10 @@ def main():
                "config": {"workload": f"full per-frame path: ORB 2000x8 stereo + SegNet-{args.net} T={T} MC-dropout + entropy maps + semantic key filter + stereo match, {H}x{W}, synthetic stereo pair, seeded random weights",
                           "T": T, "samples_per_rank": [parallel.shard_samples(T, world, r)[1] for r in range(world)],
                           "orb": bool(do_orb), "semantic_keys": stats["kps"], "stereo_matches": stats["matches"],
+                          "entropy_gate": ({"in_timed_frame": True, "keys_selected": stats["selected"], "threshold_bits": GATE_TH,
+                                            "ms_per_call": round(1e3 * stats["gate_s"] / max(stats["gate_n"], 1), 4),
+                                            "parity": "tests/test_gpu_match_ba.py::test_entropy_gate_matches_oracle, tests/test_pin_helpers.py (the reference's sivo_helpers chain)"}
+                                           if do_orb and world == 1 else None),
                           "algorithmic_gflop_per_frame": round((sn.flops_shared + T * sn.flops_per_sample) / 1e9, 2),
                           "reference_equivalent_gflop_per_frame": round(T * (sn.flops_shared + sn.flops_per_sample) / 1e9, 2),
                           "gemm": dict(zip(("mode", "fp16_overflow_frames"), sn.gemm_status()[:2])),
@@ -479,9 +591,11 @@ def main():
 
         if world == 1:
             out["membound"] = membound_block(prof, fp, d_left, H, W, T, sn.classes)
+        if multi:
+            out["multi_gpu"] = multi
 
     # ------------------------------------------------------------------------------------------ further configs (N = 1)
-    want = set() if (world > 1 or args.configs == "none") else set(("basic,t48,ba,host" if args.configs == "all" else args.configs).split(","))
+    want = set() if (world > 1 or args.configs == "none") else set(("basic,t48,ba,host,track,shards" if args.configs == "all" else args.configs).split(","))
     extra = []
     if rank == 0 and want:
         if "host" in want:
@@ -515,6 +629,35 @@ def main():
         if "t48" in want:
             extra.append(segnet_config("BASELINE configs[3] on ONE GPU: SegNet Standard T=48 (the 8-GPU form shards 6 samples per rank)", "standard", 48, 6,
                                        "tests/test_gpu_segnet_fullsize.py::test_t48_and_its_shards_at_full_size (T = 48 in one handle and the 6-sample shards, oracle-checked), tests/test_distributed_cpu.py", "t48"))
+        if "shards" in want:
+            # what ONE rank computes per frame when the T samples are sharded over N ranks (prefix + its samples + finalize), measured on this
+            # GPU: the ceiling of the strong-scaling curve the driver's N = 2, 4, 8 runs can reach (all-reduce and ORB on rank 0 come on top)
+            _, _, net = build_net(args.net, T)
+            ps = torch.zeros((net.classes, H, W), dtype=torch.float32, device="cuda")
+            m = new_maps()
+            rows = []
+            for nr in (1, 2, 4, 8):
+                nl = parallel.max_shard(T, nr)
+                def one(seed, nl=nl):
+                    net.forward_into(d_bgr, seed, ps, n_samples=nl, sample0=0)
+                    net.finalize(ps, t_total=T, out=m)
+                for i in range(3):
+                    one(i)
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(10):
+                    one(10 + i)
+                barrier()
+                rows.append({"ranks": nr, "samples_on_the_heaviest_rank": nl, "ms_per_frame": round(1e2 * (time.perf_counter() - t0), 3)})
+            del net
+            torch.cuda.empty_cache()
+            for r_ in rows:
+                r_["speedup_ceiling"] = round(rows[0]["ms_per_frame"] / r_["ms_per_frame"], 2)
+            extra.append({"name": f"sample shards of the T = {T} frame on one GPU (SegNet forward of the heaviest rank's share + finalize; no ORB, no all-reduce)",
+                          "metric": "ms per frame of the heaviest rank", "value": rows[-1]["ms_per_frame"], "shards": rows,
+                          "parity": "tests/test_gpu_segnet_fullsize.py::test_t48_and_its_shards_at_full_size, tests/test_distributed_cpu.py"})
+        if "track" in want and stats["last"] is not None:
+            extra.append(tracking_config(stats["last"], fp, (KFX, KFY, KCX, KCY, KBF), local))
         if "ba" in want:
             from sivo_amd import optimizer
             poses, pts, edges, intr = ba_scene()
@@ -524,14 +667,14 @@ def main():
             X0 = pts + rng.normal(0, 0.05, pts.shape)
             optimizer.local_ba(P0, fixed, X0, edges, intr, cov_pose=19)
             ts = []
-            for _ in range(5):
+            for _ in range(10):
                 t0 = time.perf_counter(); g = optimizer.local_ba(P0, fixed, X0, edges, intr, cov_pose=19); ts.append(time.perf_counter() - t0)
-            t_call = min(ts)
+            t_call = float(np.mean(ts))                                         # the mean, like every other figure of the line
             nE, it = len(edges), max(g["iterations"], 1)
             alg_bytes = nE * (48 + 96 + 24 + (3 + 18 + 9 + 1 + 18 + 18) * 8) * it      # ~0.9 KB per edge per LM iteration
             extra.append({"name": "BASELINE configs[4]: local BA, 20 keyframes x 3000 map points (whole Optimizer::LocalBundleAdjustment solve on the GPU: "
                                   "per-edge residuals / Jacobians, Schur complement, LM, marginal covariance)",
-                          "metric": "ms per LocalBundleAdjustment call", "value": round(t_call * 1e3, 3), "edges": int(nE), "lm_iterations": g["iterations"],
+                          "metric": "ms per LocalBundleAdjustment call (mean of 10)", "value": round(t_call * 1e3, 3), "min_ms": round(min(ts) * 1e3, 3), "edges": int(nE), "lm_iterations": g["iterations"],
                           "ms_per_lm_iteration": round(t_call * 1e3 / it, 3),
                           "roofline": {"bound": "hbm", "achieved": round(alg_bytes / t_call / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(alg_bytes / t_call / 1e9 / HBM_PEAK_GBS, 5),

@@ -515,6 +515,13 @@ int sivo_entropy_gate_dev(int n, const SivoKeyPoint *d_kps, const float *d_depth
                           const double *d_entropy, int rows, int cols, const double state_cov[36], double fx,
                           double fy, double bl, const float *level_sigma2, int nlevels, double th,
                           double *d_mi, double *d_reduction, uint8_t *d_accept, void *stream);
+/* Host key arrays against the DEVICE-resident entropy map (what sivo_segnet_segment_dev left in HBM): the form the per-frame
+ * path uses — the keys come out of the semantic filter on the host, the map stays where the network wrote it.  Synchronous;
+ * the caller has synchronised with the producer of d_entropy. */
+int sivo_entropy_gate_map_dev(int n, const SivoKeyPoint *kps, const float *depth, const double *xyz,
+                              const double *d_entropy, int rows, int cols, const double state_cov[36], double fx,
+                              double fy, double bl, const float *level_sigma2, int nlevels, double th, double *mi,
+                              double *reduction, uint8_t *accept);
 int sivo_entropy_gate(int n, const SivoKeyPoint *kps, const float *depth, const double *xyz,
                       const double *entropy, int rows, int cols, const double state_cov[36], double fx,
                       double fy, double bl, const float *level_sigma2, int nlevels, double th, double *mi,

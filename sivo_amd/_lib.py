@@ -115,6 +115,7 @@ SIGNATURES = {
     "sivo_stereo_match_begin": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp],
     "sivo_stereo_match_cull": [_i, _vp, _vp, _vp, _vp],
     "sivo_entropy_gate_dev": [_i, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(_d), _d, _d, _d, _vp, _i, _d, _vp, _vp, _vp, _vp],
+    "sivo_entropy_gate_map_dev": [_i, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(_d), _d, _d, _d, _vp, _i, _d, _vp, _vp, _vp],
     "sivo_entropy_gate": [_i, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(_d), _d, _d, _d, _vp, _i, _d, _vp, _vp, _vp],
     "sivo_check_semantics_dev": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(_d), _d, _d, _d, _vp, _i, _d, _d, _vp, _vp, _vp, _vp],
     "sivo_check_semantics": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(_d), _d, _d, _d, _vp, _i, _d, _d, _vp, _vp, _vp],

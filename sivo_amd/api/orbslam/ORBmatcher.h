@@ -23,9 +23,14 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <list>
+#include <memory>
+#include <mutex>
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <typeinfo>
 #include <utility>
 #include <vector>
 
@@ -41,19 +46,25 @@ inline void check(int rc, const char *what) {
     if (rc != SIVO_OK) throw std::runtime_error(std::string("ORBmatcher::") + what + ": " + sivo_last_error());
 }
 
-// The matcher's view of a Frame / KeyFrame on the device (keys, mvRight, descriptors, 64 x 48 grid); built per call —
-// a frame is ~100 KB, the upload is a few tens of microseconds.
+// The HIP device the matcher's frame views live on: -1 (default) = the calling thread's current device.  Set once, before the
+// first Search* call, by a host that drives several GPUs (ORBmatcher::SetDevice).
+inline int &matcher_device() {
+    static int device = -1;
+    return device;
+}
+
+// The matcher's view of a Frame / KeyFrame on the device (keys, mvRight, descriptors, 64 x 48 grid).
 class DeviceFrame {
  public:
     template <class FrameT>
-    explicit DeviceFrame(const FrameT &F) {
+    DeviceFrame(const FrameT &F, int device) {
         const int n = static_cast<int>(F.mvKeysSemantic.size());
         if (n && (!F.mDescriptorsSemantic.isContinuous() || F.mDescriptorsSemantic.rows != n || F.mDescriptorsSemantic.cols != 32))
             throw std::invalid_argument("ORBmatcher: mDescriptorsSemantic must be a continuous N x 32 CV_8U matrix");
         check(sivo_mframe_create(reinterpret_cast<const SivoKeyPoint *>(F.mvKeysSemantic.data()), n,
                                  F.mvRight.empty() ? nullptr : F.mvRight.data(), F.mDescriptorsSemantic.data, (float)F.mnMinX,
                                  (float)F.mnMaxX, (float)F.mnMinY, (float)F.mnMaxY, F.mvScaleFactors.data(), F.mvLevelSigma2.data(),
-                                 F.mvInvLevelSigma2.data(), (int)F.mvScaleFactors.size(), 0, &h_),
+                                 F.mvInvLevelSigma2.data(), (int)F.mvScaleFactors.size(), device, &h_),
               "frame upload");
         n_ = n;
     }
@@ -62,10 +73,102 @@ class DeviceFrame {
     DeviceFrame &operator=(const DeviceFrame &) = delete;
     sivo_mframe_t get() const { return h_; }
     int size() const { return n_; }
+    std::mutex &mutex() { return mu_; }
 
  private:
     sivo_mframe_t h_ = nullptr;
     int n_ = 0;
+    std::mutex mu_;        // a handle serves one search at a time (its stream and scratch are its own)
+};
+
+// Views are kept per Frame / KeyFrame: Tracking searches the current frame two or three times per image (motion model, local
+// map, relocalisation candidates), LocalMapping and LoopClosing search and fuse into the same keyframes again and again.  The
+// key is what identifies the data the view was built from — the object's type and mnId, the number of semantic keys, the
+// address of the descriptor matrix's pixels (a copied Frame clones its descriptors, a recycled address has another mnId) and
+// a fingerprint of three of its entries — so that a view never outlives the data it mirrors in any way the matcher could observe.  The least recently used views
+// are dropped beyond CAPACITY (their device memory goes back to the library's pool).  Types without an mnId get a view per call.
+class FrameCache {
+ public:
+    enum : size_t { CAPACITY = 128 };
+    struct Key {
+        size_t type;
+        unsigned long long id, print;
+        int n, device;
+        const void *desc;
+        bool operator==(const Key &o) const {
+            return type == o.type && id == o.id && print == o.print && n == o.n && device == o.device && desc == o.desc;
+        }
+    };
+    // FNV-1a over the first, middle and last key / descriptor / mvRight entry: stand-in types in tests re-use ids and addresses
+    template <class FrameT>
+    static unsigned long long fingerprint(const FrameT &F) {
+        unsigned long long h = 1469598103934665603ull;
+        auto mix = [&h](const void *p, size_t bytes) {
+            const unsigned char *c = static_cast<const unsigned char *>(p);
+            for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+        };
+        const size_t n = F.mvKeysSemantic.size();
+        if (!n) return h;
+        for (size_t i : {(size_t)0, n / 2, n - 1}) {
+            mix(&F.mvKeysSemantic[i], sizeof(cv::KeyPoint));
+            mix(F.mDescriptorsSemantic.data + 32 * i, 32);
+            if (!F.mvRight.empty()) mix(&F.mvRight[i], sizeof(float));
+        }
+        return h;
+    }
+    static FrameCache &instance() {
+        static FrameCache c;
+        return c;
+    }
+    template <class FrameT>
+    std::shared_ptr<DeviceFrame> get(const FrameT &F) {
+        return get_impl(F, matcher_device(), 0);
+    }
+    void clear() {
+        std::lock_guard<std::mutex> lock(mu_);
+        lru_.clear();
+    }
+    size_t size() {
+        std::lock_guard<std::mutex> lock(mu_);
+        return lru_.size();
+    }
+
+ private:
+    // chosen when FrameT has an mnId ...
+    template <class FrameT>
+    auto get_impl(const FrameT &F, int device, int) -> decltype((void)F.mnId, std::shared_ptr<DeviceFrame>()) {
+        const Key k{typeid(FrameT).hash_code(), (unsigned long long)F.mnId, fingerprint(F), (int)F.mvKeysSemantic.size(), device,
+                    (const void *)F.mDescriptorsSemantic.data};
+        std::lock_guard<std::mutex> lock(mu_);
+        for (auto it = lru_.begin(); it != lru_.end(); ++it)
+            if (it->first == k) {
+                lru_.splice(lru_.begin(), lru_, it);
+                return lru_.front().second;
+            }
+        lru_.emplace_front(k, std::make_shared<DeviceFrame>(F, device));
+        if (lru_.size() > CAPACITY) lru_.pop_back();
+        return lru_.front().second;
+    }
+    // ... a view per call otherwise
+    template <class FrameT>
+    std::shared_ptr<DeviceFrame> get_impl(const FrameT &F, int device, long) {
+        return std::make_shared<DeviceFrame>(F, device);
+    }
+    std::mutex mu_;
+    std::list<std::pair<Key, std::shared_ptr<DeviceFrame>>> lru_;
+};
+
+// A frame's view for the duration of one matcher call.
+class FrameLease {
+ public:
+    template <class FrameT>
+    explicit FrameLease(const FrameT &F) : frame_(FrameCache::instance().get(F)), lock_(frame_->mutex()) {}
+    sivo_mframe_t get() const { return frame_->get(); }
+    int size() const { return frame_->size(); }
+
+ private:
+    std::shared_ptr<DeviceFrame> frame_;
+    std::unique_lock<std::mutex> lock_;
 };
 
 // The float arithmetic of the cv::Mat expressions the reference routines evaluate per point (OpenCV 3.x, matmul.cpp /
@@ -144,6 +247,11 @@ class ORBmatcher {
 
     // Computes the Hamming distance between two ORB descriptors (1 x 32 CV_8U rows).
     static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);
+
+    // (not in the reference) the HIP device the frames' views are kept on — default -1: the calling thread's current device — and
+    // the release of every cached view (e.g. at System::Reset).
+    static void SetDevice(int device) { matcher_detail::matcher_device() = device; matcher_detail::FrameCache::instance().clear(); }
+    static void ReleaseDeviceFrames() { matcher_detail::FrameCache::instance().clear(); }
 
     // Search matches between Frame keypoints and projected MapPoints.  Returns number of matches.
     // Used to track the local map (Tracking).                                              ORBmatcher.cc:44-127
@@ -253,7 +361,7 @@ int ORBmatcher::SearchByProjection(FrameT &F, const std::vector<MapPointT *> &vp
         obs[i] = pMP->Observations();
         descriptor_row(pMP->GetDescriptor(), desc, i);
     }
-    DeviceFrame dF(F);
+    FrameLease dF(F);
     std::vector<int32_t> occ(dF.size()), match(dF.size());
     for (int k = 0; k < dF.size(); ++k) occ[k] = F.mvpMapPoints[k] ? (int32_t)F.mvpMapPoints[k]->Observations() : -1;
     int nmatches = 0;
@@ -296,7 +404,7 @@ int ORBmatcher::SearchByProjection(FrameT &CurrentFrame, const FrameT &LastFrame
         obs[i] = pMP->Observations();
         descriptor_row(pMP->GetDescriptor(), desc, (size_t)i);
     }
-    DeviceFrame dF(CurrentFrame);
+    FrameLease dF(CurrentFrame);
     std::vector<int32_t> occ(dF.size()), match(dF.size());
     for (int k = 0; k < dF.size(); ++k) occ[k] = CurrentFrame.mvpMapPoints[k] ? (int32_t)CurrentFrame.mvpMapPoints[k]->Observations() : -1;
     int nmatches = 0;
@@ -341,7 +449,7 @@ int ORBmatcher::SearchByProjection(FrameT &CurrentFrame, KeyFrameT *pKF, const s
         angle[i] = pKF->mvKeysSemantic[i].angle;
         descriptor_row(pMP->GetDescriptor(), desc, i);
     }
-    DeviceFrame dF(CurrentFrame);
+    FrameLease dF(CurrentFrame);
     std::vector<uint8_t> occupied((size_t)dF.size());
     std::vector<int32_t> match((size_t)dF.size());
     for (int k = 0; k < dF.size(); ++k) occupied[k] = CurrentFrame.mvpMapPoints[k] != nullptr;
@@ -409,7 +517,7 @@ int ORBmatcher::SearchByProjection(KeyFrameT *pKF, cv::Mat Scw, const std::vecto
         valid[i] = 1; level[i] = lvl;
         descriptor_row(pMP->GetDescriptor(), desc, i);
     }
-    DeviceFrame dKF(*pKF);
+    FrameLease dKF(*pKF);
     std::vector<uint8_t> matched((size_t)dKF.size());
     std::vector<int32_t> match((size_t)dKF.size());
     for (int k = 0; k < dKF.size(); ++k) matched[k] = vpMatched[k] != nullptr;
@@ -442,7 +550,7 @@ int ORBmatcher::Fuse(KeyFrameT *pKF, const std::vector<MapPointT *> &vpMapPoints
         valid[i] = 1; level[i] = lvl;
         descriptor_row(pMP->GetDescriptor(), desc, i);
     }
-    DeviceFrame dKF(*pKF);
+    FrameLease dKF(*pKF);
     int nFused = 0;
     check(sivo_fuse(dKF.get(), (int)n, valid.data(), u.data(), v.data(), ur.data(), level.data(), desc.data(), th, 0, best.data(),
                     nullptr, &nFused),
@@ -491,7 +599,7 @@ int ORBmatcher::Fuse(KeyFrameT *pKF, cv::Mat Scw, const std::vector<MapPointT *>
         valid[i] = 1; level[i] = lvl;
         descriptor_row(pMP->GetDescriptor(), desc, i);
     }
-    DeviceFrame dKF(*pKF);
+    FrameLease dKF(*pKF);
     int nFused = 0;
     check(sivo_fuse(dKF.get(), (int)n, valid.data(), u.data(), v.data(), nullptr, level.data(), desc.data(), th, 1, best.data(), nullptr,
                     &nFused),
@@ -565,7 +673,7 @@ int ORBmatcher::SearchBySim3(KeyFrameT *pKF1, KeyFrameT *pKF2, std::vector<MapPo
             level[i] = pMP->PredictScale(dist3D, into);
             descriptor_row(pMP->GetDescriptor(), desc, i);
         }
-        DeviceFrame d(*into);
+        FrameLease d(*into);
         vnMatch.assign(n, -1);
         check(sivo_search_by_sim3_dir(d.get(), (int)n, valid.data(), u.data(), v.data(), level.data(), desc.data(), th, vnMatch.data()),
               "SearchBySim3");
@@ -591,7 +699,7 @@ int ORBmatcher::SearchByBoW(KeyFrameT *pKF, FrameT &F, std::vector<MapPointT *> 
     const size_t nKF = vpMapPointsKF.size();
     std::vector<uint8_t> valid(nKF, 0);
     for (size_t i = 0; i < nKF; ++i) valid[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();
-    DeviceFrame dF(F);
+    FrameLease dF(F);
     std::vector<int32_t> match((size_t)dF.size(), -1);
     int nmatches = 0;
     check(sivo_search_by_bow_kf_frame((int)off1.size() - 1, off1.data(), idx1.data(), off2.data(), idx2.data(), valid.data(),
@@ -613,7 +721,7 @@ int ORBmatcher::SearchByBoW(KeyFrameT *pKF1, KeyFrameT *pKF2, std::vector<MapPoi
     std::vector<uint8_t> valid1(vpMapPoints1.size()), valid2(vpMapPoints2.size());
     for (size_t i = 0; i < valid1.size(); ++i) valid1[i] = vpMapPoints1[i] && !vpMapPoints1[i]->isBad();
     for (size_t i = 0; i < valid2.size(); ++i) valid2[i] = vpMapPoints2[i] && !vpMapPoints2[i]->isBad();
-    DeviceFrame d2(*pKF2);
+    FrameLease d2(*pKF2);
     std::vector<int32_t> m12(vpMapPoints1.size(), -1);
     int nmatches = 0;
     check(sivo_search_by_bow_kf_kf((int)off1.size() - 1, off1.data(), idx1.data(), off2.data(), idx2.data(), valid1.data(),
@@ -644,7 +752,7 @@ int ORBmatcher::SearchForTriangulation(KeyFrameT *pKF1, KeyFrameT *pKF2, cv::Mat
     float F[9];
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) F[3 * r + c] = F12.at<float>(r, c);
-    DeviceFrame d2(*pKF2);
+    FrameLease d2(*pKF2);
     std::vector<int32_t> m12((size_t)n1, -1);
     int nmatches = 0;
     check(sivo_search_for_triangulation((int)off1.size() - 1, off1.data(), idx1.data(), off2.data(), idx2.data(),

@@ -174,57 +174,227 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double *s_red /* [NT/6
 }
 
 // ------------------------------------------------------------------------------------------------
-// PoseOptimization: one persistent workgroup
+// PoseOptimization: one persistent workgroup, no serial section
+//
+// 4 rounds x 10 Levenberg-Marquardt iterations x (system build + >= 1 trial) are ~100 dependent steps over <= ~2000 edges: a
+// latency chain, not a bandwidth problem.  The kernel is built around that:
+//   * the edges (observation, information, the map point's position, flags) are read ONCE into LDS, 57 B per edge (PO_CAP =
+//     2560 edges = 143 KB of the CU's 160 KB; edges beyond that are read from memory in every pass);
+//   * every thread carries the whole solver state (pose, H, b, lambda ...) in registers and takes every decision itself from
+//     the same reduced sums — 6x6 Cholesky, SE3 exponential, gain ratio are computed redundantly by all 512 threads instead of
+//     by thread 0 between two barriers: ONE barrier per reduction is all the synchronisation there is;
+//   * the 28 sums of a system build (21 of H, 6 of b, chi2) are reduced by a butterfly that HALVES the values a lane carries
+//     at every step (reduce-scatter: 16 + 8 + 4 + 2 + 1 + 1 exchanges instead of 28 x 6), waves in index order after that:
+//     a fixed summation order, the result does not depend on timing;
+//   * the error vectors g2o keeps inside its edges are not stored: the chi2 test after a round needs them at the pose of the
+//     LAST TRIAL (accepted or not — g2o does not recompute after a rejected step, Optimizer.cc:432-467 reads e->chi2()), which is
+//     12 doubles; the errors are recomputed from it, bit for bit what the trial pass computed;
+//   * divisions: the Jacobian multiplies by 1/z and 1/z^2 (one division per edge instead of 14), Cholesky by the reciprocal of
+//     each pivot (12 instead of 33), (2 rho - 1)^3 is two multiplications — rounding-level differences (1e-16) against the
+//     oracle's forms, far inside the 1e-9 the solver tests ask for.
 // ------------------------------------------------------------------------------------------------
-constexpr int PO_THREADS = 512;
+constexpr int PO_THREADS = 512, PO_WAVES = PO_THREADS / 64, PO_CAP = 2560;
+constexpr int PO_LDS_BYTES = PO_CAP * (7 * 8 + 1) + 2 * PO_WAVES * 32 * 8;
 
 struct PoseOptArgs {
-    const double *pose0;     // 12
-    const double *points;    // 3 per map point (fixed)
-    const SivoEdge *edges;
+    const double *in;        // [0, 12) pose0; then 8 doubles per edge: obs[3], inv_sigma2, X, Y, Z, stereo (0 / 1)
     int n;
     Intr K;
     double delta_mono, delta_stereo;
     uint8_t *outlier;        // n   (Frame::mvbOutlier)
-    double *err;             // 3n  workspace: the error vectors g2o would hold
-    double *pose_out;        // 12
-    double *cov;             // 36
-    double *chi2;            // n or null
-    int *info;               // [0] cov_ok [1] nBad [2] iterations [3] trials
+    double *out;             // [0, 12) pose  [12, 48) covariance  [48, 52) cov_ok, nBad, iterations, trials  [52, 52 + n) chi2 (want_chi2)
+    int want_chi2;
 };
 
-__global__ __launch_bounds__(PO_THREADS) void pose_optimize_kernel(PoseOptArgs a) {
-    __shared__ double sP[12], sBk[12], sH[36], sHlast[36], sb[6];
-    __shared__ double s_red[(PO_THREADS / 64) * 28], s_sum[28];
-    __shared__ double s_lambda, s_ni, s_current, s_scale;
-    __shared__ int s_ok, s_cont, s_term, s_qmax, s_iters, s_trials;
-    const int tid = threadIdx.x;
-    const Intr K = a.K;
-    if (tid == 0) { s_iters = 0; s_trials = 0; }
-    for (int e = tid; e < a.n; e += PO_THREADS) a.outlier[e] = 0;
-    for (int i = tid; i < 36; i += PO_THREADS) sHlast[i] = 0.0;
-    __syncthreads();
-    int nbad_total = 0;
-    for (int round = 0; round < 4; ++round) {
-        if (tid < 12) sP[tid] = a.pose0[tid];      // vSE3->setEstimate(pFrame->mTcw) at every round (:419)
+// x from lane (lane ^ M) for M = 1, 2, 8 on the VALU's data-parallel crossbar (no LDS traffic); 4, 16, 32 through ds_bpermute
+template <int M>
+__device__ __forceinline__ double lane_xor(double x) {
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "");
+    if constexpr (M == 1 || M == 2 || M == 8) {
+        constexpr int ctrl = M == 1 ? 0xB1 /* quad_perm [1,0,3,2] */ : M == 2 ? 0x4E /* quad_perm [2,3,0,1] */ : 0x128 /* row_ror:8 */;
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    } else {
+        return __shfl_xor(x, M, 64);
+    }
+}
+
+// One step of the halving butterfly: a lane whose bit M is clear keeps v[0, N) and hands v[N, 2N) to its partner, the other way
+// round for a set bit; N values are left.
+template <int M, int N>
+__device__ __forceinline__ void halve_step(double *v, bool bit) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const double keep = bit ? v[N + j] : v[j], send = bit ? v[j] : v[N + j];
+        v[j] = keep + lane_xor<M>(send);
+    }
+}
+
+struct PoseReducer {
+    double *s_red;           // [2][PO_WAVES][32]
+    int buf = 0;
+    // v[0, 28) summed over the workgroup -> out[0, 28) in every thread.  Slot k ends in the lanes with bits (b0 .. b4) = the
+    // binary digits of k, most significant first.
+    __device__ __forceinline__ void sum28(double (&v)[32], double (&out)[28]) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        halve_step<1, 16>(v, lane & 1);
+        halve_step<2, 8>(v, lane & 2);
+        halve_step<4, 4>(v, lane & 4);
+        halve_step<8, 2>(v, lane & 8);
+        halve_step<16, 1>(v, lane & 16);
+        const double t = v[0] + lane_xor<32>(v[0]);
+        const int slot = ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+        double *r = s_red + buf * (PO_WAVES * 32);
+        if (lane < 32) r[wave * 32 + slot] = t;
         __syncthreads();
+        double s = 0;                                        // lane k (and k + 32): slot k over the waves, in wave order
+#pragma unroll
+        for (int w = 0; w < PO_WAVES; ++w) s += r[w * 32 + (lane & 31)];
+        buf ^= 1;
+#pragma unroll
+        for (int k = 0; k < 28; ++k)
+            out[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), k), __builtin_amdgcn_readlane(__double2loint(s), k));
+    }
+    __device__ __forceinline__ double sum1(double x) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        x += lane_xor<1>(x); x += lane_xor<2>(x); x += lane_xor<4>(x); x += lane_xor<8>(x); x += lane_xor<16>(x); x += lane_xor<32>(x);
+        double *r = s_red + buf * (PO_WAVES * 32);
+        if (lane == 0) r[wave] = x;
+        __syncthreads();
+        double s = 0;
+#pragma unroll
+        for (int w = 0; w < PO_WAVES; ++w) s += r[w];
+        buf ^= 1;
+        return s;
+    }
+};
+
+// lower Cholesky factor of the 6x6 matrix A (row-major, lower triangle read), the reciprocals of its diagonal in rd
+__device__ __forceinline__ bool chol6_recip(double (&A)[36], double (&rd)[6]) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= A[j * 6 + k] * A[j * 6 + k];
+        ok = ok && (d > 0.0);
+        d = sqrt(d);
+        A[j * 6 + j] = d;
+        rd[j] = 1.0 / d;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double s = A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= A[i * 6 + k] * A[j * 6 + k];
+            A[i * 6 + j] = s * rd[j];
+        }
+    }
+    return ok;
+}
+__device__ __forceinline__ void chol6_recip_solve(const double (&L)[36], const double (&rd)[6], double (&x)[6]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = x[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * x[k];
+        x[i] = s * rd[i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = x[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k];
+        x[i] = s * rd[i];
+    }
+}
+
+struct PoEdge { double ox, oy, orr, isig, X, Y, Z; bool st; };
+
+__global__ __launch_bounds__(PO_THREADS) void pose_optimize_kernel(PoseOptArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char po_lds[];
+    double *const sE = reinterpret_cast<double *>(po_lds);                 // [7][PO_CAP]
+    double *const s_red = sE + 7 * PO_CAP;                                 // [2][PO_WAVES][32]
+    uint8_t *const sF = reinterpret_cast<uint8_t *>(s_red + 2 * PO_WAVES * 32);   // [PO_CAP]: bit 0 stereo, bit 1 outlier
+    const int tid = threadIdx.x, n = a.n;
+    const Intr K = a.K;
+    const double *const edges = a.in + 12;
+    for (int e = tid; e < n && e < PO_CAP; e += PO_THREADS) {
+        const double *q = edges + 8 * (int64_t)e;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) sE[k * PO_CAP + e] = q[k];
+        sF[e] = q[7] != 0.0 ? 1 : 0;
+    }
+    for (int e = PO_CAP + tid; e < n; e += PO_THREADS) a.outlier[e] = 0;
+    // (edge e is always handled by thread e % PO_THREADS: the LDS copy and the flags need no barrier)
+    auto edge = [&](int e) {
+        PoEdge g;
+        if (e < PO_CAP) {
+            g.ox = sE[e]; g.oy = sE[PO_CAP + e]; g.orr = sE[2 * PO_CAP + e]; g.isig = sE[3 * PO_CAP + e];
+            g.X = sE[4 * PO_CAP + e]; g.Y = sE[5 * PO_CAP + e]; g.Z = sE[6 * PO_CAP + e]; g.st = sF[e] & 1;
+        } else {
+            const double *q = edges + 8 * (int64_t)e;
+            g.ox = q[0]; g.oy = q[1]; g.orr = q[2]; g.isig = q[3]; g.X = q[4]; g.Y = q[5]; g.Z = q[6]; g.st = q[7] != 0.0;
+        }
+        return g;
+    };
+    // flag byte of an edge (LDS, or a.outlier[e] beyond PO_CAP until the kernel's last loop): bit 0 stereo (LDS only), bit 1 outlier,
+    // bit 2 outlier before the latest chi2 test
+    auto flags = [&](int e) -> int { return e < PO_CAP ? sF[e] : a.outlier[e]; };
+    auto is_outlier = [&](int e) -> bool { return (flags(e) & 2) != 0; };
+    auto set_outlier = [&](int e, bool o) {
+        const int f = flags(e), nf = (f & 1) | (o ? 2 : 0) | ((f & 2) ? 4 : 0);
+        if (e < PO_CAP) sF[e] = (uint8_t)nf; else a.outlier[e] = (uint8_t)nf;
+    };
+    // the error vector of edge g at pose T (EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose::computeError), camera-frame point out
+    auto residual = [&](const double (&T)[12], const PoEdge &g, double (&er)[3], double &x, double &y, double &invz) {
+        x = T[0] * g.X + T[1] * g.Y + T[2] * g.Z + T[9];
+        y = T[3] * g.X + T[4] * g.Y + T[5] * g.Z + T[10];
+        const double z = T[6] * g.X + T[7] * g.Y + T[8] * g.Z + T[11];
+        invz = 1.0 / z;
+        er[0] = g.ox - (x * invz * K.fx + K.cx);
+        er[1] = g.oy - (y * invz * K.fy + K.cy);
+        er[2] = g.st ? g.orr - (x * invz * K.fx + K.cx - K.bf * invz) : 0.0;
+    };
+    PoseReducer red{s_red};
+
+    double P[12], Peval[12], H[21], b[6];
+    double lambda = 0, ni = 2, current = 0;
+    int iters = 0, trials = 0, nbad_total = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { Peval[i] = a.in[i]; P[i] = a.in[i]; }
+#pragma unroll
+    for (int i = 0; i < 21; ++i) H[i] = 0.0;
+    for (int round = 0; round < 4; ++round) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) P[i] = a.in[i];          // vSE3->setEstimate(pFrame->mTcw) at every round (:419)
         for (int it = 0; it < 10; ++it) {
             // computeActiveErrors + buildSystem
-            double acc[28];
+            double acc[32];
 #pragma unroll
-            for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-            for (int e = tid; e < a.n; e += PO_THREADS) {
-                const SivoEdge ed = a.edges[e];
-                const bool st = ed.stereo != 0;
-                if (st && a.outlier[e]) continue;                 // level 1
-                double er[3], jp[18];
-                bool dok;
-                edge_eval<true>(sP, a.points + 3 * (int64_t)ed.point, ed, K, er, jp, nullptr, dok);
-                a.err[3 * e] = er[0]; a.err[3 * e + 1] = er[1]; a.err[3 * e + 2] = er[2];
-                const double c2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * ed.inv_sigma2;
+            for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+            for (int e = tid; e < n; e += PO_THREADS) {
+                const PoEdge g = edge(e);
+                if (g.st && is_outlier(e)) continue;             // level 1
+                double er[3], x, y, iz;
+                residual(P, g, er, x, y, iz);
+                const double iz2 = iz * iz;
+                double jp[18];
+                jp[0] = x * y * iz2 * K.fx;   jp[1] = -(1 + (x * x * iz2)) * K.fx;  jp[2] = y * iz * K.fx;
+                jp[3] = -iz * K.fx;           jp[4] = 0;                            jp[5] = x * iz2 * K.fx;
+                jp[6] = (1 + y * y * iz2) * K.fy;  jp[7] = -x * y * iz2 * K.fy;     jp[8] = -x * iz * K.fy;
+                jp[9] = 0;                    jp[10] = -iz * K.fy;                  jp[11] = y * iz2 * K.fy;
+                if (g.st) {
+                    jp[12] = jp[0] - K.bf * y * iz2;  jp[13] = jp[1] + K.bf * x * iz2;  jp[14] = jp[2];
+                    jp[15] = jp[3];                   jp[16] = 0;                       jp[17] = jp[5] - K.bf * iz2;
+                } else {
+#pragma unroll
+                    for (int j = 12; j < 18; ++j) jp[j] = 0.0;
+                }
+                const double c2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * g.isig;
                 double r = c2, w = 1.0;
-                if (!st || round < 3) huber(c2, st ? a.delta_stereo : a.delta_mono, r, w);   // kernel dropped after it==2 (:462)
-                const double wo = w * ed.inv_sigma2;
+                if (!g.st || round < 3) huber(c2, g.st ? a.delta_stereo : a.delta_mono, r, w);   // kernel dropped after it==2 (:462)
+                const double wo = w * g.isig;
                 int k = 0;
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
@@ -234,109 +404,113 @@ __global__ __launch_bounds__(PO_THREADS) void pose_optimize_kernel(PoseOptArgs a
                 for (int i = 0; i < 6; ++i) acc[21 + i] -= wo * (jp[i] * er[0] + jp[6 + i] * er[1] + jp[12 + i] * er[2]);
                 acc[27] += r;
             }
-            block_sum<28, PO_THREADS>(acc, s_red, s_sum);
-            if (tid == 0) {
-                int k = 0;
-                for (int i = 0; i < 6; ++i)
-                    for (int j = i; j < 6; ++j) { sH[6 * i + j] = s_sum[k]; sH[6 * j + i] = s_sum[k]; ++k; }
-                for (int i = 0; i < 6; ++i) sb[i] = s_sum[21 + i];
-                for (int i = 0; i < 36; ++i) sHlast[i] = sH[i];
-                s_current = s_sum[27];
-                if (it == 0) {
-                    double md = 0;
-                    for (int i = 0; i < 6; ++i) md = fmax(md, fabs(sH[7 * i]));
-                    s_lambda = 1e-5 * md; s_ni = 2;
-                }
-                s_qmax = 0;
+            double S[28];
+            red.sum28(acc, S);
+#pragma unroll
+            for (int i = 0; i < 21; ++i) H[i] = S[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) b[i] = S[21 + i];
+            current = S[27];
+            if (it == 0) {
+                const double md = fmax(fmax(fmax(fabs(H[0]), fabs(H[6])), fmax(fabs(H[11]), fabs(H[15]))), fmax(fabs(H[18]), fabs(H[20])));
+                lambda = 1e-5 * md; ni = 2;
             }
-            __syncthreads();
+            int qmax = 0;
+            bool cont, term;
             do {
-                if (tid == 0) {
-                    double A[36], x[6];
-                    for (int i = 0; i < 12; ++i) sBk[i] = sP[i];
-                    for (int i = 0; i < 36; ++i) A[i] = sH[i];
-                    for (int i = 0; i < 6; ++i) { A[7 * i] += s_lambda; x[i] = sb[i]; }
-                    const bool ok = chol6(A);
-                    double scale = 0;
-                    if (ok) {
-                        chol6_solve(A, x);
-                        double Tn[12];
-                        se3_oplus(sBk, x, Tn);
-                        for (int i = 0; i < 12; ++i) sP[i] = Tn[i];
-                        for (int i = 0; i < 6; ++i) scale += x[i] * (s_lambda * x[i] + sb[i]);
-                    }
-                    s_ok = ok; s_scale = scale;
+                double A[36], rd[6], x6[6], Bk[12];
+                {
+                    int k = 0;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+#pragma unroll
+                        for (int j = i; j < 6; ++j) { A[6 * j + i] = H[k]; A[6 * i + j] = H[k]; ++k; }
                 }
-                __syncthreads();
-                double chi[1] = {0.0};
-                for (int e = tid; e < a.n; e += PO_THREADS) {
-                    const SivoEdge ed = a.edges[e];
-                    const bool st = ed.stereo != 0;
-                    if (st && a.outlier[e]) continue;
-                    double er[3];
-                    bool dok;
-                    edge_eval<false>(sP, a.points + 3 * (int64_t)ed.point, ed, K, er, nullptr, nullptr, dok);
-                    a.err[3 * e] = er[0]; a.err[3 * e + 1] = er[1]; a.err[3 * e + 2] = er[2];
-                    const double c2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * ed.inv_sigma2;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { A[7 * i] += lambda; x6[i] = b[i]; }
+#pragma unroll
+                for (int i = 0; i < 12; ++i) Bk[i] = P[i];
+                const bool ok = chol6_recip(A, rd);
+                double scale = 0;
+                if (ok) {
+                    chol6_recip_solve(A, rd, x6);
+                    se3_oplus(Bk, x6, P);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) scale += x6[i] * (lambda * x6[i] + b[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 12; ++i) Peval[i] = P[i];
+                double chi = 0.0;
+                for (int e = tid; e < n; e += PO_THREADS) {
+                    const PoEdge g = edge(e);
+                    if (g.st && is_outlier(e)) continue;
+                    double er[3], x, y, iz;
+                    residual(P, g, er, x, y, iz);
+                    const double c2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * g.isig;
                     double r = c2, w;
-                    if (!st || round < 3) huber(c2, st ? a.delta_stereo : a.delta_mono, r, w);
-                    chi[0] += r;
+                    if (!g.st || round < 3) huber(c2, g.st ? a.delta_stereo : a.delta_mono, r, w);
+                    chi += r;
                 }
-                block_sum<1, PO_THREADS>(chi, s_red, s_sum);
-                if (tid == 0) {
-                    const double temp = s_ok ? s_sum[0] : DBL_MAX;
-                    const double rho = (s_current - temp) / (s_scale + 1e-3);
-                    if (rho > 0 && isfinite(temp)) {
-                        double alpha = 1. - pow(2 * rho - 1, 3);
-                        alpha = fmin(alpha, 2. / 3.);
-                        s_lambda *= fmax(1. / 3., alpha);
-                        s_ni = 2; s_current = temp;
-                    } else {
-                        s_lambda *= s_ni; s_ni *= 2;
-                        for (int i = 0; i < 12; ++i) sP[i] = sBk[i];
-                    }
-                    ++s_qmax; ++s_trials;
-                    s_cont = (rho < 0 && s_qmax < 10);
-                    s_term = (s_qmax == 10 || rho == 0);
+                const double chi_sum = red.sum1(chi);
+                const double temp = ok ? chi_sum : DBL_MAX;
+                const double rho = (current - temp) / (scale + 1e-3);
+                if (rho > 0 && isfinite(temp)) {
+                    const double t = 2 * rho - 1;
+                    double alpha = 1. - t * t * t;
+                    alpha = fmin(alpha, 2. / 3.);
+                    lambda *= fmax(1. / 3., alpha);
+                    ni = 2; current = temp;
+                } else {
+                    lambda *= ni; ni *= 2;
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) P[i] = Bk[i];
                 }
-                __syncthreads();
-            } while (s_cont);
-            if (tid == 0) ++s_iters;
-            if (s_term) break;
+                ++qmax; ++trials;
+                cont = (rho < 0 && qmax < 10);
+                term = (qmax == 10 || rho == 0);
+            } while (cont);
+            ++iters;
+            if (term) break;
         }
-        __syncthreads();
-        // chi2 test on the stereo edges (:432-467); mono edges are not re-classified by the reference
-        double bad[1] = {0.0};
-        for (int e = tid; e < a.n; e += PO_THREADS) {
-            const SivoEdge ed = a.edges[e];
-            if (!ed.stereo) continue;
-            double er[3];
-            if (a.outlier[e]) {
-                bool dok;
-                edge_eval<false>(sP, a.points + 3 * (int64_t)ed.point, ed, K, er, nullptr, nullptr, dok);
-                a.err[3 * e] = er[0]; a.err[3 * e + 1] = er[1]; a.err[3 * e + 2] = er[2];
-            } else {
-                er[0] = a.err[3 * e]; er[1] = a.err[3 * e + 1]; er[2] = a.err[3 * e + 2];
-            }
-            const float c2 = (float)((er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * ed.inv_sigma2);
+        // chi2 test on the stereo edges (:432-467); mono edges are not re-classified by the reference.  An inlier's error vector
+        // is the one of the last trial (Peval), an outlier's is computed at the estimate (computeError, :441-444)
+        double bad = 0.0;
+        for (int e = tid; e < n; e += PO_THREADS) {
+            const PoEdge g = edge(e);
+            if (!g.st) continue;
+            double er[3], x, y, iz;
+            if (is_outlier(e)) residual(P, g, er, x, y, iz);
+            else residual(Peval, g, er, x, y, iz);
+            const float c2 = (float)((er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * g.isig);
             const bool out = c2 > 7.815f;
-            a.outlier[e] = out;
-            bad[0] += out ? 1.0 : 0.0;
+            set_outlier(e, out);
+            bad += out ? 1.0 : 0.0;
         }
-        block_sum<1, PO_THREADS>(bad, s_red, s_sum);
-        nbad_total = (int)s_sum[0];
-        __syncthreads();
-        if (a.n < 10) break;                                   // optimizer.edges().size() < 10 (:469)
+        nbad_total = (int)red.sum1(bad);
+        if (n < 10) break;                                     // optimizer.edges().size() < 10 (:469)
     }
-    if (tid < 12) a.pose_out[tid] = sP[tid];
-    if (a.chi2)
-        for (int e = tid; e < a.n; e += PO_THREADS)
-            a.chi2[e] = (a.err[3 * e] * a.err[3 * e] + a.err[3 * e + 1] * a.err[3 * e + 1] + a.err[3 * e + 2] * a.err[3 * e + 2]) * a.edges[e].inv_sigma2;
+    for (int e = tid; e < n; e += PO_THREADS) {
+        const int f = flags(e);
+        a.outlier[e] = (f & 2) ? 1 : 0;
+        if (a.want_chi2) {
+            // the chi2 g2o's edge holds when the reference returns: from the error vector last computed for it — the final round's test
+            // above recomputed an outlier's at the estimate, left an inlier's (and every mono edge's) at the last trial
+            const PoEdge g = edge(e);
+            double er[3], x, y, iz;
+            if (g.st && (f & 4)) residual(P, g, er, x, y, iz);
+            else residual(Peval, g, er, x, y, iz);
+            a.out[52 + e] = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * g.isig;
+        }
+    }
+    if (tid < 12) a.out[tid] = P[tid];
     if (tid == 0) {
-        double C[36];
-        const bool ok = inv6_spd(sHlast, C);
-        for (int i = 0; i < 36; ++i) a.cov[i] = ok ? C[i] : 0.0;
-        a.info[0] = ok; a.info[1] = nbad_total; a.info[2] = s_iters; a.info[3] = s_trials;
+        double Hf[36], C[36];
+        int k = 0;
+        for (int i = 0; i < 6; ++i)
+            for (int j = i; j < 6; ++j) { Hf[6 * i + j] = H[k]; Hf[6 * j + i] = H[k]; ++k; }
+        const bool ok = inv6_spd(Hf, C);
+        for (int i = 0; i < 36; ++i) a.out[12 + i] = ok ? C[i] : 0.0;
+        a.out[48] = ok; a.out[49] = nbad_total; a.out[50] = iters; a.out[51] = trials;
     }
 }
 
@@ -1258,6 +1432,56 @@ extern "C" int sivo_local_ba(double *poses, const uint8_t *pose_fixed, int n_pos
     });
 }
 
+// Per-thread state of sivo_pose_optimize (PoseOptimization runs once or more per frame on the tracking thread): pinned host
+// buffers the kernel reads its input from and writes its results to, and a stream of its own (the null stream is also
+// PyTorch's default stream: a per-frame solve must not queue behind whatever the host application runs there).  Grow-only,
+// released when the thread exits; nothing is allocated in a call once the buffers fit.
+struct PoseCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    void *h_in = nullptr, *h_out = nullptr;
+    size_t cap_in = 0, cap_out = 0;
+    void release() {
+        if (h_in) (void)hipHostFree(h_in);
+        if (h_out) (void)hipHostFree(h_out);
+        if (stream) (void)hipStreamDestroy(stream);
+        h_in = h_out = nullptr; stream = nullptr; cap_in = cap_out = 0;
+    }
+    ~PoseCtx() { release(); }
+    void reserve(size_t in_bytes, size_t out_bytes) {
+        if (in_bytes > cap_in) {
+            if (h_in) SIVO_HIP(hipHostFree(h_in));
+            h_in = nullptr; cap_in = 0;
+            const size_t cap = std::max(in_bytes * 2, (size_t)256 << 10);
+            SIVO_HIP(hipHostMalloc(&h_in, cap, hipHostMallocDefault));
+            cap_in = cap;
+        }
+        if (out_bytes > cap_out) {
+            if (h_out) SIVO_HIP(hipHostFree(h_out));
+            h_out = nullptr; cap_out = 0;
+            const size_t cap = std::max(out_bytes * 2, (size_t)64 << 10);
+            SIVO_HIP(hipHostMalloc(&h_out, cap, hipHostMallocDefault));
+            cap_out = cap;
+        }
+    }
+};
+static PoseCtx &pose_ctx() {
+    static thread_local PoseCtx c;
+    int dev = 0;
+    SIVO_HIP(hipGetDevice(&dev));
+    if (c.device != dev) {
+        c.release();
+        int lo = 0, hi = 0;
+        SIVO_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        SIVO_HIP(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, hi));
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lock(mu);
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pose_optimize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PO_LDS_BYTES));
+        c.device = dev;
+    }
+    return c;
+}
+
 extern "C" int sivo_pose_optimize(const double pose0[12], const double *points, int n_points, const SivoEdge *edges,
                                   int64_t n_edges, const double intr[5], uint8_t *outlier, double pose_out[12],
                                   double cov[36], int *cov_ok, double *chi2, int *n_inliers, int *iterations,
@@ -1277,25 +1501,45 @@ extern "C" int sivo_pose_optimize(const double pose0[12], const double *points, 
             return SIVO_OK;
         }
         need_gpu();
-        t_arena.reset();
-        Buf dP, dX, dE, dOut, dErr, dPose, dCov, dChi, dInfo;
-        dP.upload(pose0, 96); dX.upload(points, (size_t)n_points * 24); dE.upload(edges, (size_t)n_edges * sizeof(SivoEdge));
-        dOut.zero((size_t)n_edges); dErr.zero((size_t)n_edges * 24); dPose.alloc(96); dCov.alloc(288);
-        dChi.alloc((size_t)n_edges * 8); dInfo.zero(16);
+        PoseCtx &c = pose_ctx();
+        const size_t in_doubles = 12 + 8 * (size_t)n_edges, out_doubles = 52 + (chi2 ? (size_t)n_edges : 0);
+        c.reserve(in_doubles * 8, out_doubles * 8 + (size_t)n_edges);
+        double *in = (double *)c.h_in;
+        std::memcpy(in, pose0, 96);
+        for (int64_t e = 0; e < n_edges; ++e) {
+            double *q = in + 12 + 8 * e;
+            const double *X = points + 3 * (int64_t)edges[e].point;
+            q[0] = edges[e].obs[0]; q[1] = edges[e].obs[1]; q[2] = edges[e].obs[2]; q[3] = edges[e].inv_sigma2;
+            q[4] = X[0]; q[5] = X[1]; q[6] = X[2]; q[7] = edges[e].stereo ? 1.0 : 0.0;
+        }
         PoseOptArgs a;
-        a.pose0 = dP.as<double>(); a.points = dX.as<double>(); a.edges = dE.as<SivoEdge>(); a.n = (int)n_edges;
+        a.n = (int)n_edges;
         a.K = Intr{intr[0], intr[1], intr[2], intr[3], intr[4]};
         a.delta_mono = (double)std::sqrt(5.991f); a.delta_stereo = (double)std::sqrt(7.815f);   // :307-308
-        a.outlier = dOut.as<uint8_t>(); a.err = dErr.as<double>(); a.pose_out = dPose.as<double>(); a.cov = dCov.as<double>();
-        a.chi2 = chi2 ? dChi.as<double>() : nullptr; a.info = dInfo.as<int>();
-        hipLaunchKernelGGL(pose_optimize_kernel, dim3(1), dim3(PO_THREADS), 0, 0, a);
+        a.want_chi2 = chi2 != nullptr;
+        double *h_out = (double *)c.h_out;
+        uint8_t *h_flag = (uint8_t *)(h_out + out_doubles);
+        if (n_edges <= PO_CAP) {
+            // the kernel reads the staged edges once (into LDS) and writes a few hundred bytes: both straight through the pinned
+            // host buffers — one launch and one synchronisation, no copy calls
+            a.in = in; a.out = h_out; a.outlier = h_flag;
+        } else {
+            // edges beyond the LDS copy are read in every pass: they, and their flags, live in device memory
+            t_arena.reset();
+            Buf dIn, dOut;
+            dIn.alloc(in_doubles * 8); dOut.alloc(out_doubles * 8 + (size_t)n_edges);
+            SIVO_HIP(hipMemcpyAsync(dIn.p, in, in_doubles * 8, hipMemcpyHostToDevice, c.stream));
+            a.in = dIn.as<double>(); a.out = dOut.as<double>(); a.outlier = (uint8_t *)(dOut.as<double>() + out_doubles);
+        }
+        hipLaunchKernelGGL(pose_optimize_kernel, dim3(1), dim3(PO_THREADS), (size_t)PO_LDS_BYTES, c.stream, a);
         SIVO_HIP(hipGetLastError());
-        int info[4];
-        SIVO_HIP(hipMemcpy(info, dInfo.p, sizeof info, hipMemcpyDeviceToHost));
-        SIVO_HIP(hipMemcpy(pose_out, dPose.p, 96, hipMemcpyDeviceToHost));
-        SIVO_HIP(hipMemcpy(outlier, dOut.p, (size_t)n_edges, hipMemcpyDeviceToHost));
-        if (cov) SIVO_HIP(hipMemcpy(cov, dCov.p, 288, hipMemcpyDeviceToHost));
-        if (chi2) SIVO_HIP(hipMemcpy(chi2, dChi.p, (size_t)n_edges * 8, hipMemcpyDeviceToHost));
+        if (n_edges > PO_CAP) SIVO_HIP(hipMemcpyAsync(h_out, a.out, out_doubles * 8 + (size_t)n_edges, hipMemcpyDeviceToHost, c.stream));
+        SIVO_HIP(hipStreamSynchronize(c.stream));
+        std::memcpy(pose_out, h_out, 96);
+        std::memcpy(outlier, h_flag, (size_t)n_edges);
+        if (cov) std::memcpy(cov, h_out + 12, 288);
+        if (chi2) std::memcpy(chi2, h_out + 52, (size_t)n_edges * 8);
+        const int info[4] = {(int)h_out[48], (int)h_out[49], (int)h_out[50], (int)h_out[51]};
         if (cov_ok) *cov_ok = info[0];
         if (n_inliers) *n_inliers = (int)n_edges - info[1];
         if (iterations) *iterations = info[2];

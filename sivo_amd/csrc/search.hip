@@ -22,6 +22,8 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <type_traits>
 #include <stdexcept>
 #include <vector>
 
@@ -33,6 +35,23 @@
 #define SIVO_TH_HIGH 100
 #define SIVO_TH_LOW 50
 
+// Device side of a frame: ONE device allocation (keys, descriptors, grid, scale tables, then the engine's scratch), one pinned
+// host buffer of the same layout to stage uploads and read results back through, one stream.  Slabs outlive the frames that
+// use them: sivo_mframe_destroy hands the slab to a per-process pool and the next sivo_mframe_create on that device takes it
+// back, so a tracking loop that builds a frame view per image allocates nothing after its first frames (hipMalloc +
+// hipHostMalloc + hipStreamCreate are ~0.3 ms together, more than the searches they would serve).
+struct MframeSlab {
+    int device = 0;
+    char *d = nullptr, *h = nullptr;           // device memory / pinned host mirror
+    size_t cap = 0;
+    hipStream_t stream = nullptr;
+    ~MframeSlab() {
+        if (d) (void)hipFree(d);
+        if (h) (void)hipHostFree(h);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
 struct sivo_mframe {
     int device = 0, n = 0, nlevels = 0;
     float min_x = 0, max_x = 0, min_y = 0, max_y = 0, inv_w = 0, inv_h = 0;
@@ -40,21 +59,15 @@ struct sivo_mframe {
     std::vector<SivoKeyPoint> keys;
     std::vector<float> u_right, scale, sigma2, inv_sigma2;
     std::vector<int32_t> cell_off, cell_idx;
-    // device
+    // device (offsets into the slab)
+    std::unique_ptr<MframeSlab> slab;
+    size_t frame_bytes = 0;                    // the frame's own arrays end here; the engine's scratch follows
     float *d_x = nullptr, *d_y = nullptr, *d_angle = nullptr, *d_ur = nullptr, *d_scale = nullptr, *d_sigma2 = nullptr,
           *d_inv_sigma2 = nullptr;
     int32_t *d_oct = nullptr, *d_cell_off = nullptr, *d_cell_idx = nullptr;
     uint4 *d_desc = nullptr;
     hipStream_t stream = nullptr;
-    // grow-only scratch of the engine
-    void *d_scratch = nullptr;
-    size_t scratch_bytes = 0;
-    std::vector<void *> owned;
-    ~sivo_mframe() {
-        for (void *p : owned) (void)hipFree(p);
-        if (d_scratch) (void)hipFree(d_scratch);
-        if (stream) (void)hipStreamDestroy(stream);
-    }
+    ~sivo_mframe();
 };
 
 namespace sivo {
@@ -219,6 +232,7 @@ __global__ __launch_bounds__(1024) void search_finalize_kernel(FinalArgs a) {
     __shared__ int keep[SIVO_HISTO];
     const int tid = threadIdx.x;
     if (tid < SIVO_HISTO) { hist[tid] = 0; keep[tid] = 1; }
+    if (tid < 2) a.counters[tid] = 0;
     for (int k = tid; k < a.n; k += 1024) a.match_train[k] = -1;
     __syncthreads();
     const float factor = 1.0f / SIVO_HISTO;
@@ -284,6 +298,71 @@ T *carve(char *&p, size_t count) {
     return r;
 }
 
+// ---- slab pool ------------------------------------------------------------------------------------------------------
+struct SlabPool {
+    std::mutex mu;
+    std::vector<std::unique_ptr<MframeSlab>> idle;
+    static constexpr size_t KEEP = 64;          // a local map's keyframes + the tracking frames; beyond that slabs are freed
+    std::unique_ptr<MframeSlab> take(int device, size_t bytes) {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            int best = -1;
+            for (size_t i = 0; i < idle.size(); ++i)
+                if (idle[i]->device == device && idle[i]->cap >= bytes && (best < 0 || idle[i]->cap < idle[(size_t)best]->cap)) best = (int)i;
+            if (best >= 0) {
+                std::unique_ptr<MframeSlab> r = std::move(idle[(size_t)best]);
+                idle.erase(idle.begin() + best);
+                return r;
+            }
+        }
+        std::unique_ptr<MframeSlab> r(new MframeSlab);
+        r->device = device;
+        r->cap = std::max(bytes, (size_t)1 << 20);
+        SIVO_HIP(hipMalloc((void **)&r->d, r->cap));
+        SIVO_HIP(hipHostMalloc((void **)&r->h, r->cap, hipHostMallocDefault));
+        SIVO_HIP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+        return r;
+    }
+    void give(std::unique_ptr<MframeSlab> sl) {
+        if (!sl) return;
+        (void)hipStreamSynchronize(sl->stream);      // (an upload nobody searched against may still be in flight)
+        std::lock_guard<std::mutex> lock(mu);
+        if (idle.size() < KEEP) idle.push_back(std::move(sl));
+    }
+};
+SlabPool &slab_pool() {
+    static SlabPool *p = new SlabPool;           // never destroyed: frames may be released after main() returns
+    return *p;
+}
+
+// Lays the frame's arrays out in the slab (device pointers into F, the same offsets in the pinned mirror); returns the bytes used.
+size_t bind_frame(sivo_mframe &F, char *base) {
+    char *p = base;
+    const size_t n = (size_t)F.n;
+    F.d_x = carve<float>(p, n); F.d_y = carve<float>(p, n); F.d_angle = carve<float>(p, n); F.d_oct = carve<int32_t>(p, n);
+    F.d_ur = carve<float>(p, F.u_right.size());
+    F.d_desc = carve<uint4>(p, n * 2);
+    F.d_cell_off = carve<int32_t>(p, F.cell_off.size()); F.d_cell_idx = carve<int32_t>(p, F.cell_idx.size());
+    F.d_scale = carve<float>(p, (size_t)F.nlevels); F.d_sigma2 = carve<float>(p, (size_t)F.nlevels); F.d_inv_sigma2 = carve<float>(p, (size_t)F.nlevels);
+    return (size_t)(p - base);
+}
+
+// The engine's scratch behind the frame's arrays; a call that needs more than the slab holds moves the frame to a bigger slab
+// (the pinned mirror still holds the frame's arrays: one copy host to host, one upload).
+char *scratch(sivo_mframe &F, size_t bytes) {
+    if (F.frame_bytes + bytes > F.slab->cap) {
+        std::unique_ptr<MframeSlab> big = slab_pool().take(F.device, (F.frame_bytes + bytes) * 2);
+        SIVO_HIP(hipStreamSynchronize(F.slab->stream));
+        std::memcpy(big->h, F.slab->h, F.frame_bytes);
+        SIVO_HIP(hipMemcpyAsync(big->d, big->h, F.frame_bytes, hipMemcpyHostToDevice, big->stream));
+        slab_pool().give(std::move(F.slab));
+        F.slab = std::move(big);
+        F.stream = F.slab->stream;
+        bind_frame(F, F.slab->d);
+    }
+    return F.slab->d + F.frame_bytes;
+}
+
 // The engine on host arrays: upload queries, rounds, finalize, download.
 void run_search(sivo_mframe &F, const SivoSearchQuery *queries, const uint8_t *query_desc, int nq, const int32_t *cand_begin,
                 const int32_t *cand_end, const int32_t *cand_idx, int n_cand, const SivoSearchRule &rule, const uint8_t *blocked,
@@ -301,35 +380,47 @@ void run_search(sivo_mframe &F, const SivoSearchQuery *queries, const uint8_t *q
             if ((uint32_t)cand_idx[j] >= (uint32_t)F.n) throw std::invalid_argument("sivo_search: candidate index outside the frame's keypoints");
     DeviceGuard dg(F.device);
     const int n = F.n;
-    const size_t need = 256 * 16 + (size_t)nq * (sizeof(SivoSearchQuery) + 32 + 8 + 4 * 4) + (size_t)(cand_idx ? n_cand : 0) * 4 +
+    const size_t need = 256 * 20 + (size_t)nq * (sizeof(SivoSearchQuery) + 32 + 8 + 4 * 4) + (size_t)(cand_idx ? n_cand : 0) * 4 +
                         (size_t)(n + 64) * (1 + 4 * 4) + 1024;
-    if (need > F.scratch_bytes) {
-        if (F.d_scratch) SIVO_HIP(hipFree(F.d_scratch));
-        F.d_scratch = nullptr;
-        F.scratch_bytes = need * 2;
-        SIVO_HIP(hipMalloc(&F.d_scratch, F.scratch_bytes));
-    }
-    char *p = (char *)F.d_scratch;
+    // Scratch = [ upload block | device-only | download block ], the pinned mirror has the same layout: ONE copy up (queries,
+    // their descriptors, candidate lists, blocked flags and the initial values of pick / owner / npick / flags), one copy down.
+    char *const d0 = scratch(F, need);
+    char *const h0 = F.slab->h + (d0 - F.slab->d);
+    char *p = d0;
     SivoSearchQuery *d_q = carve<SivoSearchQuery>(p, nq);
     uint4 *d_qdesc = carve<uint4>(p, (size_t)nq * 2);
     int32_t *d_cbeg = carve<int32_t>(p, nq), *d_cend = carve<int32_t>(p, nq);
     int32_t *d_cidx = carve<int32_t>(p, cand_idx ? n_cand : 0);
     uint8_t *d_blocked = carve<uint8_t>(p, n);
-    int32_t *d_owner[2] = {carve<int32_t>(p, n), carve<int32_t>(p, n)};
-    int32_t *d_npick = carve<int32_t>(p, n), *d_mtrain = carve<int32_t>(p, n);
-    int32_t *d_pick = carve<int32_t>(p, nq), *d_bd = carve<int32_t>(p, nq), *d_sd = carve<int32_t>(p, nq), *d_mq = carve<int32_t>(p, nq);
+    int32_t *d_pick = carve<int32_t>(p, nq);
+    int32_t *d_owner0 = carve<int32_t>(p, rule.dynamic ? n : 0), *d_npick = carve<int32_t>(p, rule.dynamic ? n : 0);
     int32_t *d_flags = carve<int32_t>(p, 4);     // collision, changed, accepted, culled
+    const size_t up_bytes = (size_t)(p - d0);
+    int32_t *d_owner1 = carve<int32_t>(p, rule.dynamic ? n : 0);
+    if (!rule.dynamic) d_npick = carve<int32_t>(p, n);
+    char *const down0 = p;
+    int32_t *d_counters = carve<int32_t>(p, 4);
+    int32_t *d_mq = carve<int32_t>(p, nq), *d_mtrain = carve<int32_t>(p, n), *d_bd = carve<int32_t>(p, nq), *d_sd = carve<int32_t>(p, nq);
+    const size_t down_bytes = (size_t)(p - down0);
+    int32_t *d_owner[2] = {d_owner0, d_owner1};
+    auto host = [&](auto *dev) { return reinterpret_cast<std::remove_reference_t<decltype(*dev)> *>(h0 + ((char *)dev - d0)); };
     hipStream_t st = F.stream;
-    SIVO_HIP(hipMemcpyAsync(d_q, queries, (size_t)nq * sizeof(SivoSearchQuery), hipMemcpyHostToDevice, st));
-    SIVO_HIP(hipMemcpyAsync(d_qdesc, query_desc, (size_t)nq * 32, hipMemcpyHostToDevice, st));
+    SIVO_HIP(hipStreamSynchronize(st));          // (the mirror may still feed the frame's own upload)
+    std::memcpy(host(d_q), queries, (size_t)nq * sizeof(SivoSearchQuery));
+    std::memcpy(host(d_qdesc), query_desc, (size_t)nq * 32);
     if (cand_idx) {
-        SIVO_HIP(hipMemcpyAsync(d_cbeg, cand_begin, (size_t)nq * 4, hipMemcpyHostToDevice, st));
-        SIVO_HIP(hipMemcpyAsync(d_cend, cand_end, (size_t)nq * 4, hipMemcpyHostToDevice, st));
-        if (n_cand) SIVO_HIP(hipMemcpyAsync(d_cidx, cand_idx, (size_t)n_cand * 4, hipMemcpyHostToDevice, st));
+        std::memcpy(host(d_cbeg), cand_begin, (size_t)nq * 4);
+        std::memcpy(host(d_cend), cand_end, (size_t)nq * 4);
+        if (n_cand) std::memcpy(host(d_cidx), cand_idx, (size_t)n_cand * 4);
     }
-    if (blocked && n) SIVO_HIP(hipMemcpyAsync(d_blocked, blocked, (size_t)n, hipMemcpyHostToDevice, st));
-    SIVO_HIP(hipMemsetAsync(d_pick, 0xff, (size_t)nq * 4, st));      // -1
-    SIVO_HIP(hipMemsetAsync(d_flags, 0, 16, st));
+    if (blocked && n) std::memcpy(host(d_blocked), blocked, (size_t)n);
+    std::memset(host(d_pick), 0xff, (size_t)nq * 4);        // -1
+    if (rule.dynamic && n) {
+        std::memset(host(d_owner0), 0x7f, (size_t)n * 4);    // 0x7f7f7f7f > any query index
+        std::memset(host(d_npick), 0, (size_t)n * 4);
+    }
+    std::memset(host(d_flags), 0, 16);
+    SIVO_HIP(hipMemcpyAsync(d0, h0, up_bytes, hipMemcpyHostToDevice, st));
 
     SearchArgs a{};
     a.n = n; a.x = F.d_x; a.y = F.d_y; a.angle = F.d_angle; a.ur = F.u_right.empty() ? nullptr : F.d_ur;
@@ -344,14 +435,14 @@ void run_search(sivo_mframe &F, const SivoSearchQuery *queries, const uint8_t *q
     for (;; ++rounds) {
         a.owner_prev = rounds == 0 ? nullptr : d_owner[(rounds + 1) & 1];
         a.owner_next = d_owner[rounds & 1];
-        if (rule.dynamic && n) {
-            SIVO_HIP(hipMemsetAsync(a.owner_next, 0x7f, (size_t)n * 4, st));       // 0x7f7f7f7f > any query index
+        if (rounds && rule.dynamic && n) {                                         // (round 0's values came with the upload)
+            SIVO_HIP(hipMemsetAsync(a.owner_next, 0x7f, (size_t)n * 4, st));
             SIVO_HIP(hipMemsetAsync(d_npick, 0, (size_t)n * 4, st));
         }
         if (rounds) SIVO_HIP(hipMemsetAsync(d_flags, 0, 8, st));
         hipLaunchKernelGGL(search_round_kernel, dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, st, a);
         if (!rule.dynamic) { ++rounds; break; }
-        int32_t fl[2];
+        int32_t *fl = host(d_flags);
         SIVO_HIP(hipMemcpyAsync(fl, d_flags, 8, hipMemcpyDeviceToHost, st));
         SIVO_HIP(hipStreamSynchronize(st));
         // round 0 is final when no keypoint was picked twice — unless a ratio test is on: a keypoint an earlier query took
@@ -361,16 +452,16 @@ void run_search(sivo_mframe &F, const SivoSearchQuery *queries, const uint8_t *q
     }
     FinalArgs f{};
     f.n = n; f.nq = nq; f.q = d_q; f.angle = F.d_angle; f.pick = d_pick; f.check_orientation = rule.check_orientation;
-    f.match_query = d_mq; f.match_train = d_mtrain; f.counters = d_flags + 2;
+    f.match_query = d_mq; f.match_train = d_mtrain; f.counters = d_counters;
     hipLaunchKernelGGL(search_finalize_kernel, dim3(1), dim3(1024), 0, st, f);
-    int32_t cnt[2] = {0, 0};
-    SIVO_HIP(hipMemcpyAsync(cnt, d_flags + 2, 8, hipMemcpyDeviceToHost, st));
-    if (match_query) SIVO_HIP(hipMemcpyAsync(match_query, d_mq, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    if (match_train && n) SIVO_HIP(hipMemcpyAsync(match_train, d_mtrain, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    if (best_dist) SIVO_HIP(hipMemcpyAsync(best_dist, d_bd, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    if (second_dist) SIVO_HIP(hipMemcpyAsync(second_dist, d_sd, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    SIVO_HIP(hipMemcpyAsync(h0 + (down0 - d0), down0, down_bytes, hipMemcpyDeviceToHost, st));
     SIVO_HIP(hipStreamSynchronize(st));
     SIVO_HIP(hipGetLastError());
+    const int32_t *cnt = host(d_counters);
+    if (match_query) std::memcpy(match_query, host(d_mq), (size_t)nq * 4);
+    if (match_train && n) std::memcpy(match_train, host(d_mtrain), (size_t)n * 4);
+    if (best_dist) std::memcpy(best_dist, host(d_bd), (size_t)nq * 4);
+    if (second_dist) std::memcpy(second_dist, host(d_sd), (size_t)nq * 4);
     if (n_matches) *n_matches = cnt[0] - cnt[1];
     if (rounds_out) *rounds_out = rounds;
 }
@@ -423,6 +514,8 @@ void require(bool ok, const char *what) {
 
 using namespace sivo;
 
+sivo_mframe::~sivo_mframe() { slab_pool().give(std::move(slab)); }
+
 extern "C" int sivo_mframe_create(const SivoKeyPoint *keys, int n, const float *u_right, const uint8_t *descriptors,
                                   float min_x, float max_x, float min_y, float max_y, const float *scale_factors,
                                   const float *level_sigma2, const float *inv_level_sigma2, int nlevels, int device,
@@ -433,7 +526,9 @@ extern "C" int sivo_mframe_create(const SivoKeyPoint *keys, int n, const float *
         require(n >= 0 && (n == 0 || (keys && descriptors)), "keys / descriptors are NULL");
         require(nlevels > 0 && scale_factors && level_sigma2 && inv_level_sigma2, "scale tables are NULL");
         require(max_x > min_x && max_y > min_y, "empty image bounds");
-        if (sivo_device_count() <= device || device < 0)
+        if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device: libsivo_hip has no CPU fallback");
+        if (device < 0) SIVO_HIP(hipGetDevice(&device));                    // -1: the calling thread's current device
+        if (sivo_device_count() <= device)
             return fail(SIVO_ERR_RUNTIME, "HIP device %d is not available (%d visible): libsivo_hip has no CPU fallback", device,
                         sivo_device_count());
         std::unique_ptr<sivo_mframe> F(new sivo_mframe);
@@ -464,25 +559,27 @@ extern "C" int sivo_mframe_create(const SivoKeyPoint *keys, int n, const float *
             if (cell_of[i] >= 0) F->cell_idx[fill[cell_of[i]]++] = i;
 
         DeviceGuard dg(device);
-        std::vector<float> x(n), y(n), ang(n);
-        std::vector<int32_t> oct(n);
-        for (int i = 0; i < n; ++i) { x[i] = keys[i].x; y[i] = keys[i].y; ang[i] = keys[i].angle; oct[i] = keys[i].octave; }
-        auto up = [&](auto *&dst, const void *src, size_t bytes) {
-            using T = std::remove_reference_t<decltype(*dst)>;
-            dst = reinterpret_cast<T *>(dev_alloc<char>(bytes ? bytes : 16));
-            F->owned.push_back(dst);
-            if (bytes) SIVO_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
-        };
-        up(F->d_x, x.data(), (size_t)n * 4); up(F->d_y, y.data(), (size_t)n * 4); up(F->d_angle, ang.data(), (size_t)n * 4);
-        up(F->d_oct, oct.data(), (size_t)n * 4);
-        up(F->d_ur, F->u_right.data(), F->u_right.size() * 4);
-        up(F->d_desc, descriptors, (size_t)n * 32);
-        up(F->d_cell_off, F->cell_off.data(), F->cell_off.size() * 4);
-        up(F->d_cell_idx, F->cell_idx.data(), F->cell_idx.size() * 4);
-        up(F->d_scale, F->scale.data(), (size_t)nlevels * 4);
-        up(F->d_sigma2, F->sigma2.data(), (size_t)nlevels * 4);
-        up(F->d_inv_sigma2, F->inv_sigma2.data(), (size_t)nlevels * 4);
-        SIVO_HIP(hipStreamCreateWithFlags(&F->stream, hipStreamNonBlocking));
+        // one slab: the frame's arrays + scratch for a call with as many queries as the frame has keys (a bigger call grows it)
+        const size_t frame_bytes = bind_frame(*F, reinterpret_cast<char *>((uintptr_t)4096));
+        const size_t scratch_guess = 256 * 20 + (size_t)(n + 64) * (sizeof(SivoSearchQuery) + 32 + 8 + 16 + 17) + 1024;
+        F->slab = slab_pool().take(device, frame_bytes + scratch_guess);
+        F->stream = F->slab->stream;
+        F->frame_bytes = frame_bytes;
+        bind_frame(*F, F->slab->d);
+        char *const h = F->slab->h, *const d = F->slab->d;
+        auto host = [&](auto *dev) { return reinterpret_cast<std::remove_reference_t<decltype(*dev)> *>(h + ((char *)dev - d)); };
+        float *hx = host(F->d_x), *hy = host(F->d_y), *ha = host(F->d_angle);
+        int32_t *ho = host(F->d_oct);
+        for (int i = 0; i < n; ++i) { hx[i] = keys[i].x; hy[i] = keys[i].y; ha[i] = keys[i].angle; ho[i] = keys[i].octave; }
+        if (!F->u_right.empty()) std::memcpy(host(F->d_ur), F->u_right.data(), F->u_right.size() * 4);
+        if (n) std::memcpy(host(F->d_desc), descriptors, (size_t)n * 32);
+        std::memcpy(host(F->d_cell_off), F->cell_off.data(), F->cell_off.size() * 4);
+        if (!F->cell_idx.empty()) std::memcpy(host(F->d_cell_idx), F->cell_idx.data(), F->cell_idx.size() * 4);
+        std::memcpy(host(F->d_scale), F->scale.data(), (size_t)nlevels * 4);
+        std::memcpy(host(F->d_sigma2), F->sigma2.data(), (size_t)nlevels * 4);
+        std::memcpy(host(F->d_inv_sigma2), F->inv_sigma2.data(), (size_t)nlevels * 4);
+        // (asynchronous: every search of this frame runs on the same stream, behind the upload)
+        SIVO_HIP(hipMemcpyAsync(d, h, frame_bytes, hipMemcpyHostToDevice, F->stream));
         *out = F.release();
         return SIVO_OK;
     });

@@ -14,6 +14,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <cstring>
+
 #include "common.hpp"
 
 namespace sivo {
@@ -153,6 +156,71 @@ extern "C" int sivo_entropy_gate_dev(int n, const SivoKeyPoint *d_kps, const flo
         g.mi = d_mi; g.reduction = d_reduction; g.accept = d_accept;
         hipLaunchKernelGGL(entropy_gate_kernel, dim3(cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, g);
         SIVO_HIP(hipGetLastError());
+        return SIVO_OK;
+    });
+}
+
+// Host keypoints against the entropy map the network left in HBM (the per-frame form: the keys come out of the semantic filter on
+// the host, the 2.9 MB f64 map never has to leave the device for this).  The key arrays are staged into a pinned buffer of the
+// calling thread which the kernel reads directly, and the three outputs are written straight into pinned memory: one launch, one
+// synchronisation, no allocation once the buffers fit.  The caller has synchronised with whatever produced d_entropy (the frame
+// has: it reads the class map back before it filters the keys).
+namespace {
+struct GateCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    char *h = nullptr;
+    size_t cap = 0;
+    void release() {
+        if (h) (void)hipHostFree(h);
+        if (stream) (void)hipStreamDestroy(stream);
+        h = nullptr; stream = nullptr; cap = 0;
+    }
+    ~GateCtx() { release(); }
+};
+GateCtx &gate_ctx(size_t bytes) {
+    static thread_local GateCtx c;
+    int dev = 0;
+    SIVO_HIP(hipGetDevice(&dev));
+    if (c.device != dev) {
+        c.release();
+        SIVO_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        c.device = dev;
+    }
+    if (bytes > c.cap) {
+        if (c.h) SIVO_HIP(hipHostFree(c.h));
+        c.h = nullptr; c.cap = 0;
+        const size_t cap = std::max(bytes * 2, (size_t)256 << 10);
+        SIVO_HIP(hipHostMalloc((void **)&c.h, cap, hipHostMallocDefault));
+        c.cap = cap;
+    }
+    return c;
+}
+}  // namespace
+
+extern "C" int sivo_entropy_gate_map_dev(int n, const SivoKeyPoint *kps, const float *depth, const double *xyz,
+                                         const double *d_entropy, int rows, int cols, const double state_cov[36], double fx,
+                                         double fy, double bl, const float *level_sigma2, int nlevels, double th, double *mi,
+                                         double *reduction, uint8_t *accept) {
+    return guarded([&] {
+        if (n < 0) throw std::invalid_argument("negative size");
+        if (n == 0) return SIVO_OK;
+        if (!kps || !depth || !xyz || !d_entropy) throw std::invalid_argument("null argument");
+        if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device: libsivo_hip has no CPU fallback");
+        const size_t N = (size_t)n, o_xyz = 0, o_mi = o_xyz + N * 24, o_red = o_mi + N * 8, o_kps = o_red + N * 8,
+                     o_depth = o_kps + N * sizeof(SivoKeyPoint), o_acc = o_depth + N * 4, total = o_acc + N;
+        GateCtx &c = gate_ctx(total);
+        std::memcpy(c.h + o_xyz, xyz, N * 24);
+        std::memcpy(c.h + o_kps, kps, N * sizeof(SivoKeyPoint));
+        std::memcpy(c.h + o_depth, depth, N * 4);
+        const int rc = sivo_entropy_gate_dev(n, (const SivoKeyPoint *)(c.h + o_kps), (const float *)(c.h + o_depth), (const double *)(c.h + o_xyz),
+                                             d_entropy, rows, cols, state_cov, fx, fy, bl, level_sigma2, nlevels, th,
+                                             (double *)(c.h + o_mi), (double *)(c.h + o_red), (uint8_t *)(c.h + o_acc), c.stream);
+        if (rc) return rc;
+        SIVO_HIP(hipStreamSynchronize(c.stream));
+        if (mi) std::memcpy(mi, c.h + o_mi, N * 8);
+        if (reduction) std::memcpy(reduction, c.h + o_red, N * 8);
+        if (accept) std::memcpy(accept, c.h + o_acc, N);
         return SIVO_OK;
     });
 }

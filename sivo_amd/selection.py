@@ -22,6 +22,21 @@ def entropy_gate(kps, depth, xyz, entropy, state_cov, fx, fy, bl, level_sigma2, 
     return mi, red, acc
 
 
+def entropy_gate_map_dev(kps, depth, xyz, d_entropy, state_cov, fx, fy, bl, level_sigma2, th_entropy_reduction):
+    """Host key arrays (numpy) against the entropy map the network left on the device (a cuda f64 tensor): the per-frame form
+    (sivo_entropy_gate_map_dev).  Returns (mutual_information, entropy_reduction, accept)."""
+    kps = np.ascontiguousarray(kps, KP_DTYPE); depth = np.ascontiguousarray(depth, np.float32)
+    xyz = np.ascontiguousarray(xyz, np.float64)
+    ls2 = np.ascontiguousarray(level_sigma2, np.float32)
+    cov = (C.c_double * 36)(*np.asarray(state_cov, np.float64).ravel())
+    n = len(kps)
+    mi = np.empty(n); red = np.empty(n); acc = np.empty(n, np.uint8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(lib().sivo_entropy_gate_map_dev(n, p(kps), p(depth), p(xyz), d_entropy.data_ptr(), d_entropy.shape[0], d_entropy.shape[1], cov,
+                                          fx, fy, bl, p(ls2), len(ls2), th_entropy_reduction, p(mi), p(red), p(acc)))
+    return mi, red, acc
+
+
 def entropy_gate_dev(d_kps_u8, d_depth, d_xyz, d_entropy, state_cov, fx, fy, bl, level_sigma2, th, d_mi, d_red, d_acc):
     """Device-resident form: cuda tensors (kps as a uint8 view of SivoKeyPoint records); entropy is the f64 map
     BayesianSegNet.finalize() left in HBM."""

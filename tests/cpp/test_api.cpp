@@ -130,7 +130,7 @@ struct TFrame {
         mTcw.at<float>(0, 3) = tx; mTcw.at<float>(1, 3) = ty; mTcw.at<float>(2, 3) = tz;
     }
     std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r, int minLevel = -1, int maxLevel = -1) const {
-        SIVO::matcher_detail::DeviceFrame d(*this);
+        SIVO::matcher_detail::FrameLease d(*this);
         std::vector<int32_t> out(mvKeysSemantic.size() + 1);
         int n = 0;
         sivo_mframe_features_in_area(d.get(), x, y, r, minLevel, maxLevel, out.data(), (int)out.size(), &n);

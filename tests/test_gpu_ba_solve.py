@@ -115,6 +115,31 @@ def test_pose_optimization_matches_oracle(oracle, kf, seed):
     assert np.abs(g["pose"] - poses[kf]).max() < 2e-2 < np.abs(p0 - poses[kf]).max()
 
 
+def test_pose_optimization_more_edges_than_the_lds_copy_holds(oracle):
+    """pose_optimize_kernel keeps 2560 edges in LDS and reads the rest from memory in every pass: one keyframe seeing ~5000 points
+    (with planted outliers, so that flags beyond the LDS copy change), then the same call timed at a tracking-sized problem."""
+    import time
+    poses, pts, edges, intr = make_ba_scene(seed=11, n_kf=2, n_pts=9000)
+    ek = edges[edges["pose"] == 1].copy()
+    assert len(ek) > 3000
+    rng = np.random.default_rng(5)
+    planted = rng.choice(len(ek), 150, replace=False)
+    ek["obs"][planted, 0] += rng.choice([-1, 1], 150) * rng.uniform(8, 30, 150)
+    p0 = perturb_pose(poses[1], np.random.default_rng(6))
+    g = optimizer.pose_optimize(p0, pts, ek, intr); o = oracle.pose_optimize(p0, pts, ek, intr)
+    np.testing.assert_allclose(g["pose"], o["pose"], atol=1e-7, rtol=0)
+    assert np.array_equal(g["outlier"], o["outlier"]) and g["inliers"] == o["inliers"] and g["outlier"][2560:].any()
+    np.testing.assert_allclose(g["chi2"], o["chi2"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(g["cov"], o["cov"], rtol=1e-6, atol=1e-18)
+    for n in (300, 1000, 2000, len(ek)):
+        sub = ek[:n]
+        optimizer.pose_optimize(p0, pts, sub, intr)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            r = optimizer.pose_optimize(p0, pts, sub, intr)
+        print(f"[pose_optimize {n} edges] {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per call (through ctypes), {r['iterations']} iterations, {r['trials']} trials")
+
+
 def test_pose_optimization_edge_cases(oracle):
     poses, pts, edges, intr = make_ba_scene(seed=3, n_kf=2, n_pts=60)
     ek = edges[edges["pose"] == 1].copy()

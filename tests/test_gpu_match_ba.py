@@ -98,6 +98,12 @@ def test_entropy_gate_matches_oracle(oracle):
     assert (g[2][~(depth > 0)] == 0).all()
     e = selection.entropy_gate(kps[:0], depth[:0], xyz[:0], ent, Sx, 718.856, 718.856, 0.537, ls2, 4.0)
     assert len(e[0]) == 0
+    # the per-frame form: host keys against the device-resident map (same kernel, read through pinned memory): identical
+    import torch
+    d_ent = torch.from_numpy(ent).cuda()
+    for m in (n, 700, 1):                   # (shrinking calls re-use the thread's staging buffer)
+        gm = selection.entropy_gate_map_dev(kps[:m], depth[:m], xyz[:m], d_ent, Sx, 718.856, 718.856, 0.537, ls2, 4.0)
+        assert np.array_equal(gm[0], g[0][:m]) and np.array_equal(gm[1], g[1][:m]) and np.array_equal(gm[2], g[2][:m])
 
 
 def test_check_semantics_matches_oracle(oracle):

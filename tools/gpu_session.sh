@@ -33,6 +33,17 @@ for step in "$@"; do
     lanes) timeout 300 python tools/h3_debug2.py default > $O/lanes.log 2>&1; grep "lanes ==" $O/lanes.log;;
     e2e) timeout 600 python -m pytest tests/test_gpu_frame_e2e.py -q -s > $O/e2e.log 2>&1; echo "e2e rc=$?"; grep -E "e2e|passed|failed|Error" $O/e2e.log | tail -8;;
     fullsize) timeout 1500 python -m pytest tests/test_gpu_segnet_fullsize.py -q -s > $O/fullsize.log 2>&1; echo "fullsize rc=$?"; grep -E "dlogit|passed|failed|FAILED|Error" $O/fullsize.log | tail -40;;
+    track) timeout 900 python -m pytest tests/test_gpu_ba_solve.py tests/test_gpu_search.py tests/test_gpu_match_ba.py tests/test_pin_matcher.py tests/test_pin_optimizer.py tests/test_cpp_api.py tests/test_pin_helpers.py -m gpu -q -s > $O/track.log 2>&1; echo "track rc=$?"; grep -E "pose_optimize|passed|failed|FAILED|Error|FAIL " $O/track.log | tail -30;;
+    benchtrack) timeout 600 python bench.py --configs track,ba,shards --no-cpu-baseline --steps 20 > $O/bench_track.json 2> $O/bench_track.err; echo "benchtrack rc=$?"; tail -5 $O/bench_track.err; python - <<PY
+import json
+try:
+    d=json.load(open("$O/bench_track.json"))
+    print("  ", d["value"], "fps", d["ms_per_step"], "ms; gate", d["config"].get("entropy_gate"))
+    for c in d.get("configs", []):
+        print("  ", {k: v for k, v in c.items() if k not in ("name", "note", "parity", "roofline")})
+except Exception as e: print("  no line:", e)
+PY
+;;
     alltests) timeout 1800 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; echo "alltests rc=$?"; tail -5 $O/gpu_tests.log;;
   esac
 done
