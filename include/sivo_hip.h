@@ -186,18 +186,25 @@ typedef struct {
 int sivo_segnet_profile(sivo_segnet_t h, int enable);
 int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int capacity, int *n_out);
 
-/* The GEMM the F(4x4,3x3) layers of the handle run: *mode = 2 f16x3 (fp32 operands as fp16 hi + lo planes, three
- * products: the default), 1 bf16x6 (three bf16 planes, six products: SIVO_GEMM=x6, and every handle after a frame
- * raised the fp16 overflow flag), 0 fp32 MFMA (SIVO_GEMM=f32) or no such layer.  *overflow_frames = frames in which a
- * transformed value left the fp16 range since the handle was created; sivo_segnet_segment recomputes such a frame on the
- * bf16x6 path before it returns, the asynchronous *_dev entry points cannot: after one of them check this count.
- * per_layer (optional): one row per f16x3-capable layer with the calibration frame's largest |V| and the powers of two
- * chosen for V and U; *n_layers = rows available. */
+/* The arithmetic the matrix-core layers of the handle run: *mode = 2 f16x3 (fp32 operands as fp16 hi + lo planes, three
+ * products: the default), 1 bf16x6 (three bf16 planes, six products: SIVO_GEMM=x6, and a handle whose fourth frame raised
+ * the fp16 overflow flag), 0 fp32 MFMA (SIVO_GEMM=f32) or no such layer.  *overflow_frames = frames in which a value times
+ * its layer's scale left the fp16 range since the handle was created.  Such a frame is wrong.  sivo_segnet_segment recomputes
+ * it (without f16x3) before it returns; the asynchronous *_dev entry points cannot: once the caller has synchronised with the
+ * frame it asks sivo_segnet_take_overflow, and if that says 1 it issues the same call again — that call runs without f16x3.
+ * After every such frame the handle lowers its f16x3 scales by 2^2 (two more bits of headroom) and stays on f16x3; the
+ * fourth switches it to bf16x6 / fp32 kernels for good.
+ * per_layer (optional): one row per f16x3-capable layer with the calibration's largest |V| (three synthetic frames x MC
+ * samples 0..11) and the powers of two in use for V and U; *n_layers = rows available. */
 typedef struct SivoH3Layer {
     char layer[48];
     float vmax, vscale, uscale;
 } SivoH3Layer;
 int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow_frames, SivoH3Layer *per_layer, int capacity, int *n_layers);
+/* *overflowed = 1 when a frame issued on this handle since the last call (or the last synchronous entry point) left the fp16
+ * range: the handle has backed off as described above and its NEXT forward runs without f16x3 — issue the frame again.
+ * Reads one word of pinned host memory: free to call once per frame, after the frame's results were synchronised with. */
+int sivo_segnet_take_overflow(sivo_segnet_t h, int *overflowed);
 
 /* ===========================================================================
  * ORB extractor — stands behind SIVO::ORBextractor

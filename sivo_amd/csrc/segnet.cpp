@@ -157,6 +157,8 @@ struct sivo_segnet {
     volatile uint32_t *h3_flag = nullptr;
     uint32_t *d_h3_vmax = nullptr;  // calibration: one word per op (bit pattern of the largest |V|)
     int h3_overflow_frames = 0;     // frames that raised the flag (each was recomputed on the bf16x6 path when the entry point is synchronous)
+    int h3_back_offs = 0;           // times the scales were lowered by 2^2 after such a frame (f16x3 is switched off at the fourth)
+    bool h3_pause = false;          // the next forward runs without f16x3 (the recomputation of the frame that raised the flag)
     float *d_wino4_ws = nullptr;    // V + M workspace shared by every F(4x4,3x3) layer (one region per lane)
     size_t wino4_ws_floats = 0;
     size_t wino4_slot_floats = 0;   // three rotating slots (V, M, next V) for layers that run all samples in one pass
@@ -676,23 +678,39 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
     return Sp;
 }
 
-// The transform kernels of an f16x3 layer store 1 into the pinned flag word when a value times the layer's scale leaves
-// the fp16 range.  The frame that raised it is wrong (inf / NaN in that layer); from then on the handle runs those layers
-// on the bf16x6 GEMM, which has fp32's range.  Synchronous entry points recompute the frame before they return.
-bool h3_tripped(sivo_segnet &S) {
+// The kernels of an f16x3 layer store 1 into the pinned flag word when a value times the layer's scale leaves the fp16 range.
+// The frame that raised it is wrong (inf / NaN in that layer).  What follows (h3_back_off): the NEXT forward of the handle runs
+// without f16x3 (bf16x6 / fp32 kernels: fp32's range) — that is the recomputation of the frame, which the synchronous entry points
+// do before they return and a caller of the asynchronous ones does after sivo_segnet_take_overflow told it to — and every
+// f16x3 scale of the handle is lowered by 2^2: two more bits of headroom for two bits of the lo plane (2^-20 instead of 2^-22
+// relative; still below the fp32 FMA chain's own error).  The fourth such frame switches f16x3 off for good: activations that
+// outgrow 2^14 times the calibration's are not what the scales were made for.
+bool h3_flag_take(sivo_segnet &S) {
     if (!S.h3_flag || !*S.h3_flag) return false;
     *S.h3_flag = 0;
-    S.h3_on = false;
     ++S.h3_overflow_frames;
+    return true;
+}
+void h3_back_off(sivo_segnet &S) {
+    S.h3_pause = true;
+    if (++S.h3_back_offs > 3) { S.h3_on = false; return; }
+    for (Op &op : S.ops) {
+        if (op.h3_vscale > 0.f) op.h3_vscale *= 0.25f;
+        if (op.d3_vscale > 0.f) op.d3_vscale *= 0.25f;
+    }
+}
+bool h3_tripped(sivo_segnet &S) {
+    if (!h3_flag_take(S)) return false;
+    h3_back_off(S);
     return true;
 }
 
 // Deterministic frame for the calibration pass: rectangles of random colour over a gradient plus per-pixel noise — edges,
 // flat regions and texture, i.e. high-frequency content at least as strong as a camera frame's (the F(4x4) input transform
 // amplifies exactly that), independent of anything but the network geometry.
-std::vector<uint8_t> calibration_frame(int H, int W) {
+std::vector<uint8_t> calibration_frame(int H, int W, int variant = 0) {
     std::vector<uint8_t> img((size_t)H * W * 3);
-    uint32_t st = 0x51f0u;
+    uint32_t st = 0x51f0u + 7919u * (uint32_t)variant;
     auto rnd = [&] { st = st * 1664525u + 1013904223u; return st >> 8; };
     std::vector<int> acc((size_t)H * W * 3);
     for (int y = 0; y < H; ++y)
@@ -706,8 +724,12 @@ std::vector<uint8_t> calibration_frame(int H, int W) {
             for (int x = x0; x < std::min(W, x0 + w); ++x)
                 for (int c = 0; c < 3; ++c) acc[((size_t)y * W + x) * 3 + c] = col[c];
     }
+    // variant 1: the same kind of scene at full contrast (black / white rectangles dominate); variant 2: heavy sensor noise
+    const int amp = variant == 2 ? 61 : 25;
     for (size_t i = 0; i < acc.size(); ++i) {
-        const int v = acc[i] + (int)(rnd() % 25u) - 12;
+        int v = acc[i];
+        if (variant == 1) v = v < 100 ? v / 4 : v > 156 ? 255 - (255 - v) / 4 : v;
+        v += (int)(rnd() % (uint32_t)amp) - amp / 2;
         img[i] = (uint8_t)std::min(255, std::max(0, v));
     }
     return img;
@@ -717,11 +739,13 @@ struct McTargets;
 void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t seed, float *d_prob_sum, float *d_logits,
              float *d_prob, hipStream_t st, const McTargets *mc = nullptr);
 
-// f16x3 GEMM: per-layer power-of-two scale of the transformed input, from one pass of the calibration frame (one MC
-// sample, fixed seed, bf16x6 GEMM) whose transform kernels record each layer's largest |V|.  The largest value is put at
-// [2^7, 2^8): 2^8 of headroom below fp16's 65504 for frames with larger activations, full hi + lo precision (2^-22) down
-// to 2^-10 of the maximum and an absolute error of 2^-25 below that.  The scales depend on the weights and the network
-// geometry only — not on T, the device or the frames seen — so every handle of one model computes identical bits.
+// f16x3: per-layer power-of-two scale of the (transformed) input, from calibration passes on the fp32 kernels whose transform /
+// absmax kernels record each layer's largest |V| — three synthetic frames (calibration_frame variants: a scene, the same at
+// full contrast, heavy noise) x the MC samples 0 .. 11 of each.  The largest value is put at [2^7, 2^8): 2^8 of headroom below
+// fp16's 65504 for frames with larger activations, full hi + lo precision (2^-22) down to 2^-10 of the maximum and an absolute
+// error of 2^-25 below that.  The scales depend on the weights and the network geometry only — not on T (the 36 passes are the
+// same (frame, global sample) pairs for every T), the device or the frames seen — so every handle of one model computes
+// identical bits, until a frame overflows (h3_back_off).
 // SIVO_H3_BOOST=k multiplies the scales by 2^k (tests: k = 9 forces the overflow path).
 void calibrate_h3(sivo_segnet &S) {
     bool any = false;
@@ -734,12 +758,20 @@ void calibrate_h3(sivo_segnet &S) {
     S.d_h3_vmax = dev_alloc<uint32_t>(2 * S.ops.size());         // [op]: largest |V| of an F(4x4) layer; [ops + op]: largest |input| of a direct f16x3 layer
     S.owned.push_back(S.d_h3_vmax);
     SIVO_HIP(hipMemset(S.d_h3_vmax, 0, 2 * S.ops.size() * sizeof(uint32_t)));
-    const std::vector<uint8_t> img = calibration_frame(S.H, S.W);
-    SIVO_HIP(hipMemcpy(S.d_image, img.data(), img.size(), hipMemcpyHostToDevice));
+    // THREE frames (calibration_frame variants 0, 1, 2), the MC samples 0 .. 11 of each — the dropout masks decide which activations
+    // survive, and a layer's largest value is not in every sample — in passes of as many samples as the handle holds: the same 36
+    // (frame, global sample index) pairs whatever T is, so that handles of one model that shard the samples compute identical scales.
+    constexpr int CAL_FRAMES = 3, CAL_SAMPLES = 12;
     S.calibrating = true;
     try {
-        forward(S, S.d_image, 1, 0, 0x5157ca11b8a7e5ull, S.d_prob_sum, nullptr, nullptr, S.stream, nullptr);
-        SIVO_HIP(hipStreamSynchronize(S.stream));
+        for (int f = 0; f < CAL_FRAMES; ++f) {
+            const std::vector<uint8_t> img = calibration_frame(S.H, S.W, f);
+            SIVO_HIP(hipMemcpy(S.d_image, img.data(), img.size(), hipMemcpyHostToDevice));
+            for (int s0 = 0; s0 < CAL_SAMPLES; s0 += S.T) {
+                forward(S, S.d_image, std::min(S.T, CAL_SAMPLES - s0), s0, 0x5157ca11b8a7e5ull + (uint64_t)f, S.d_prob_sum, nullptr, nullptr, S.stream, nullptr);
+                SIVO_HIP(hipStreamSynchronize(S.stream));
+            }
+        }
     } catch (...) {
         S.calibrating = false;
         throw;
@@ -979,7 +1011,13 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
              float *d_logits, float *d_prob, hipStream_t st, const McTargets *mc) {
     const int64_t hw = (int64_t)S.H * S.W;
     if (S.profile) harvest(S);
-    (void)h3_tripped(S);        // an earlier (asynchronous) frame left the fp16 range: bf16x6 from here on
+    (void)h3_tripped(S);        // an earlier (asynchronous) frame left the fp16 range and nobody asked: back off now
+    // the recomputation of a frame that raised the flag: this forward is enqueued without f16x3
+    struct Pause {
+        sivo_segnet &S; bool was;
+        explicit Pause(sivo_segnet &s) : S(s), was(s.h3_on) { if (S.h3_pause) S.h3_on = false; S.h3_pause = false; }
+        ~Pause() { S.h3_on = was; }
+    } pause(S);
     const Blob &lg = S.blobs[S.logits_blob];
     if (lg.shared) throw std::runtime_error("the network has no test-time dropout: nothing to sample");
     launch_preprocess(d_bgr, (float *)S.blobs[S.input_blob].d, hw, st);
@@ -1093,8 +1131,8 @@ void sivo::segnet_forward_chunked(sivo_segnet_t h, const uint8_t *d_bgr, int n, 
     h->sum_chunk = 0; h->d_sum64 = nullptr;
 }
 
-bool sivo::segnet_fp16_overflowed(sivo_segnet_t h) { return h3_tripped(*h); }
-void sivo::segnet_force_bf16x6(sivo_segnet_t h) { h->h3_on = false; }
+bool sivo::segnet_fp16_overflowed(sivo_segnet_t h) { return h3_flag_take(*h); }
+void sivo::segnet_fp16_back_off(sivo_segnet_t h) { h3_back_off(*h); }
 
 using namespace sivo;
 
@@ -1304,7 +1342,7 @@ extern "C" int sivo_segnet_segment(sivo_segnet_t h, const uint8_t *bgr, int rows
             if (confidence) SIVO_HIP(hipMemcpyAsync(confidence, h->d_conf, hw * sizeof(double), hipMemcpyDeviceToHost, st));
             if (entropy) SIVO_HIP(hipMemcpyAsync(entropy, h->d_ent, hw * sizeof(double), hipMemcpyDeviceToHost, st));
             SIVO_HIP(hipStreamSynchronize(st));
-            if (!h3_tripped(*h)) break;       // a value left the fp16 range in this frame: once more, on the bf16x6 GEMM
+            if (!h3_tripped(*h)) break;       // a value left the fp16 range in this frame: once more, without f16x3
         }
         return SIVO_OK;
     });
@@ -1453,8 +1491,17 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
     });
 }
 
+extern "C" int sivo_segnet_take_overflow(sivo_segnet_t h, int *overflowed) {
+    return guarded([&] {
+        if (!h || !overflowed) throw std::invalid_argument("null argument");
+        if (h->multi) throw std::invalid_argument("a multi-device handle has synchronous entry points only: they recompute such a frame themselves");
+        *overflowed = h3_tripped(*h) ? 1 : 0;
+        return SIVO_OK;
+    });
+}
+
 // Which GEMM the F(4x4,3x3) layers of this handle run (2 = f16x3, 1 = bf16x6, 0 = fp32 MFMA / none) and how many frames
-// raised the fp16 overflow flag since the handle was created (the first one switched the handle to bf16x6 for good).
+// raised the fp16 overflow flag since the handle was created (each lowered the scales by 2^2; the fourth switched f16x3 off).
 // per_layer (optional, capacity rows): layer name, largest |V| of the calibration frame and the scale chosen.
 extern "C" int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow_frames, SivoH3Layer *per_layer, int capacity, int *n_layers) {
     return guarded([&] {

@@ -265,12 +265,12 @@ void segnet_multi_segment(SegnetMulti *M, const uint8_t *bgr, int rows, int cols
     DeviceRestore restore;              // also when an RCCL or HIP error unwinds mid-frame
     for (int attempt = 0; attempt < 2; ++attempt) {
         multi_frame(M, bgr, rows, cols, seed, classes, confidence, entropy);
-        // a value left the fp16 range on some device: every device's handle switches to the bf16x6 GEMM (the devices must
-        // run the same arithmetic for the maps not to depend on the sharding) and the frame is computed once more
+        // a value left the fp16 range on some device: EVERY device's handle backs off the same way (the devices must run the
+        // same arithmetic for the maps not to depend on the sharding) and the frame is computed once more, without f16x3
         bool tripped = false;
         for (MultiDevice &D : M->dev) tripped = segnet_fp16_overflowed(D.net) || tripped;
         if (!tripped) break;
-        for (MultiDevice &D : M->dev) segnet_force_bf16x6(D.net);
+        for (MultiDevice &D : M->dev) segnet_fp16_back_off(D.net);
     }
 }
 

@@ -22,5 +22,5 @@ void segnet_forward_chunked(sivo_segnet_t h, const uint8_t *d_bgr, int n, int sa
                             int64_t chunk, hipStream_t st);
 // true once after a frame of the handle raised the fp16 overflow flag of the f16x3 GEMM (the handle is on bf16x6 from then on)
 bool segnet_fp16_overflowed(sivo_segnet_t h);
-void segnet_force_bf16x6(sivo_segnet_t h);
+void segnet_fp16_back_off(sivo_segnet_t h);
 }  // namespace sivo

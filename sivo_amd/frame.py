@@ -62,4 +62,7 @@ class StereoFramePipeline:
         segnet.segment_into(d_bgr, seed, maps)              # asynchronous: ~65 launches enqueued in ~0.5 ms
         pending = self.start_orb(d_left, d_right)
         classes_host = maps[0].cpu().numpy()                # 360 KB D2H; waits for this frame's class map
+        if segnet.take_overflow():                          # an activation left the fp16 range of an f16x3 layer: the maps are wrong —
+            segnet.segment_into(d_bgr, seed, maps)          # the same frame once more (this call runs without f16x3; the scales back off)
+            classes_host = maps[0].cpu().numpy()
         return self.finish(pending, classes_host)

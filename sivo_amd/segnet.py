@@ -159,10 +159,18 @@ class BayesianSegNet:
                      kernel_launches=a.kernel_launches)
                 for a in arr]
 
+    def take_overflow(self):
+        """True when a frame issued through forward_into / segment_into since the last call left the fp16 range of the f16x3
+        layers (sivo_segnet_take_overflow): that frame's maps are wrong — issue the same call again, it runs without f16x3.
+        Call it once the frame's results were synchronised with (it reads one pinned host word)."""
+        ov = C.c_int32()
+        check(self._L.sivo_segnet_take_overflow(self._h, C.byref(ov)))
+        return bool(ov.value)
+
     def gemm_status(self):
-        """(mode, overflow_frames, layers): mode 2 = f16x3 GEMM in the F(4x4,3x3) layers (default), 1 = bf16x6, 0 = fp32 MFMA /
-        none; overflow_frames = frames in which a transformed value left the fp16 range (the handle switched to bf16x6);
-        layers = [(name, largest |V| of the calibration frame, V scale, U scale)]."""
+        """(mode, overflow_frames, layers): mode 2 = f16x3 in the matrix-core layers (default), 1 = bf16x6, 0 = fp32 MFMA /
+        none; overflow_frames = frames in which a value left the fp16 range (each lowered the scales by 2^2, the fourth switched
+        the handle to bf16x6); layers = [(name, largest |V| of the calibration, V scale, U scale)]."""
         class _Row(C.Structure):
             _fields_ = [("layer", C.c_char * 48), ("vmax", C.c_float), ("vscale", C.c_float), ("uscale", C.c_float)]
         mode, ov, n = C.c_int32(), C.c_int32(), C.c_int32()

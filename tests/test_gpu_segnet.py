@@ -545,30 +545,54 @@ def test_f4x4_gemm_forms_agree(oracle, H, W, width):
     assert np.abs(lg["h3"] - res["logits"]).max() <= 1.1 * np.abs(lg["f32"] - res["logits"]).max()
 
 
-def test_fp16_overflow_sends_the_frame_to_the_bf16x6_gemm(oracle):
-    """A transformed value that leaves the fp16 range raises the flag of the transform kernels: sivo_segnet_segment
-    recomputes the frame on the bf16x6 GEMM before it returns and the handle stays there.  Forced with SIVO_H3_BOOST=9 (the
-    calibrated scales times 2^9: the calibration maximum itself lands at >= 65536).  The maps equal those of a handle built
-    with SIVO_GEMM=x6 bit for bit."""
+def test_fp16_overflow_recomputes_the_frame_and_backs_the_scales_off(oracle):
+    """A value that leaves the fp16 range raises the flag of the f16x3 kernels: sivo_segnet_segment recomputes the frame without
+    f16x3 (here: the bf16x6 GEMM) before it returns, the handle lowers its scales by 2^2 and stays on f16x3; the fourth such frame
+    switches it to bf16x6 for good.  Forced with SIVO_H3_BOOST (the calibrated scales times 2^k: k = 9 puts the calibration
+    maximum itself at >= 65536).  A recomputed frame equals that of a handle built with SIVO_GEMM=x6 bit for bit."""
     T, H, W, width = 3, 22, 64, 256
     text = _conv_stack_prototxt(T, H, W, width)
     img = _image(np.random.default_rng(4), H, W)
     _, _, boosted = _make_env(text, T, 5, SIVO_H3_BOOST=9)
     _, _, x6 = _make_env(text, T, 5, SIVO_GEMM="x6")
+    _, _, plain = _make_env(text, T, 5)
     assert boosted.gemm_status()[:2] == (2, 0)
+    scales0 = [r[2] for r in boosted.gemm_status()[2]]
     got = boosted.segment_image(img, seed=3)
     want = x6.segment_image(img, seed=3)
-    assert boosted.gemm_status()[:2] == (1, 1)
+    assert boosted.gemm_status()[:2] == (2, 1)                       # still f16x3, one frame recomputed ...
+    assert [r[2] for r in boosted.gemm_status()[2]] == [v / 4 for v in scales0]        # ... and two more bits of headroom
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
     assert np.isfinite(got[1]).all() and np.isfinite(got[2]).all()
-    # asynchronous entry point: the frame that overflowed is not recomputed, the handle reports it and switches
+    # the next frame runs f16x3 at 2^7 times the calibrated scales (the calibration maximum at < 2^15): no flag, and the maps are
+    # those of an unboosted handle up to the split's rounding
+    got2 = boosted.segment_image(img, seed=4)
+    ref2 = plain.segment_image(img, seed=4)
+    assert boosted.gemm_status()[:2] == (2, 1)
+    assert (got2[0] != ref2[0]).mean() < 2e-3
+    np.testing.assert_allclose(got2[1], ref2[1], atol=1e-4, rtol=0)
+    # a handle whose scales are hopeless (2^20): four recomputed frames, then bf16x6 for good
+    _, _, hopeless = _make_env(text, T, 5, SIVO_H3_BOOST=20)
+    for i in range(4):
+        g = hopeless.segment_image(img, seed=3)
+        assert hopeless.gemm_status()[:2] == ((2, i + 1) if i < 3 else (1, 4))
+        for a, b in zip(g, want):
+            assert np.array_equal(a, b)
+    g = hopeless.segment_image(img, seed=3)
+    assert hopeless.gemm_status()[:2] == (1, 4) and all(np.array_equal(a, b) for a, b in zip(g, want))
+    # asynchronous entry point: the frame that overflowed is not recomputed; the caller asks once it has synchronised and issues it again
     _, _, boosted2 = _make_env(text, T, 5, SIVO_H3_BOOST=9)
     d = torch.from_numpy(img).cuda()
     boosted2.forward(d, 3)
     torch.cuda.synchronize()
-    assert boosted2.gemm_status()[:2] == (1, 1)
-    ps, _, _ = boosted2.forward(d, 3)
+    assert boosted2.take_overflow() and not boosted2.take_overflow()
+    assert boosted2.gemm_status()[:2] == (2, 1)
+    ps, _, _ = boosted2.forward(d, 3)                                 # this one runs without f16x3
     ps_x6, _, _ = x6.forward(d, 3)
     torch.cuda.synchronize()
-    assert torch.equal(ps, ps_x6)
+    assert torch.equal(ps, ps_x6) and not boosted2.take_overflow()
+    ps2, _, _ = boosted2.forward(d, 3)                                # and this one on f16x3 again
+    torch.cuda.synchronize()
+    assert not boosted2.take_overflow() and not torch.equal(ps2, ps_x6)
+    assert (ps2 - ps_x6).abs().max() < 1e-3
