@@ -116,6 +116,20 @@ __host__ __device__ inline void se3_oplus(const double *Tin, const double *u, do
     for (int i = 0; i < 3; ++i) Tout[9 + i] = tn[i];
 }
 
+// sqrt(x) and 1 / sqrt(x) for the pivots of the dense Cholesky (x > 0, far from the ends of the exponent range): v_rsq_f64 and
+// Newton steps — ~15 dependent operations instead of the ~70 of an IEEE sqrt followed by an IEEE division, which is what the
+// 6 x 6 diagonal block's factorisation (a serial chain every step of the blocked algorithm waits for) consists of.  Both results
+// are within an ulp of the correctly rounded ones.
+__device__ __forceinline__ void sqrt_and_rsqrt(double x, double &s, double &r) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    double g = x * y;
+    g = fma(fma(-g, g, x), 0.5 * y, g);          // g += (x - g^2) y / 2
+    r = fma(fma(-g, y, 1.0), y, y);              // y += y (1 - g y)
+    s = g;
+}
+
 // in-place lower Cholesky of a 6x6 (row-major); false when not positive definite
 __host__ __device__ inline bool chol6(double *A) {
     for (int j = 0; j < 6; ++j) {
@@ -147,6 +161,74 @@ __host__ __device__ inline bool inv6_spd(const double *H, double *out) {
         for (int r = 0; r < 6; ++r) out[6 * r + c] = e[r];
     }
     return true;
+}
+
+// x from lane (lane ^ M) for M = 1, 2, 8 on the VALU's data-parallel crossbar (no LDS traffic); 4, 16, 32 through ds_bpermute
+template <int M>
+__device__ __forceinline__ double lane_xor(double x) {
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "");
+    if constexpr (M == 1 || M == 2 || M == 8) {
+        constexpr int ctrl = M == 1 ? 0xB1 /* quad_perm [1,0,3,2] */ : M == 2 ? 0x4E /* quad_perm [2,3,0,1] */ : 0x128 /* row_ror:8 */;
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    } else {
+        return __shfl_xor(x, M, 64);
+    }
+}
+
+// One step of the halving butterfly: a lane whose bit M is clear keeps v[0, N) and hands v[N, 2N) to its partner, the other way
+// round for a set bit; N values are left.
+template <int M, int N>
+__device__ __forceinline__ void halve_step(double *v, bool bit) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const double keep = bit ? v[N + j] : v[j], send = bit ? v[j] : v[N + j];
+        v[j] = keep + lane_xor<M>(send);
+    }
+}
+
+// The same sum as block_sum for K > ~8 values: the wave step is a butterfly that HALVES the values a lane carries at every
+// exchange (reduce-scatter: P/2 + P/4 + ... + 1 exchanges for P = K rounded up to a power of two, instead of 6 K), after which
+// lane l holds the wave's total of ONE slot; the rest of the butterfly adds that slot over the lanes that share it.  Waves in
+// index order after that.  A fixed order: the result does not depend on timing.  v has P entries, entries >= K are zero.
+template <int P>
+__device__ __forceinline__ int halving_slot(int lane) {       // the slot whose total lane `lane` ends up with
+    int s = 0;
+#pragma unroll
+    for (int b = 0; (1 << b) < P; ++b) s |= ((lane >> b) & 1) << ((P == 64 ? 5 : P == 32 ? 4 : 3) - b);
+    return s;
+}
+template <int K, int P, int NT>
+__device__ __forceinline__ void block_sum_h(const double (&v)[K], double *s_red /* [NT/64][P] */, double *s_out /* [K] */) {
+    static_assert((P == 16 || P == 32 || P == 64) && K <= P && 2 * K > P, "P = K rounded up to a power of two");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double w[P / 2];
+    {   // first step on the K values themselves (slots >= K are zero and are not kept in registers)
+        const bool bit = lane & 1;
+#pragma unroll
+        for (int j = 0; j < P / 2; ++j) {
+            const double hi = P / 2 + j < K ? v[P / 2 + j < K ? P / 2 + j : 0] : 0.0;
+            const double keep = bit ? hi : v[j], send = bit ? v[j] : hi;
+            w[j] = keep + lane_xor<1>(send);
+        }
+    }
+    halve_step<2, P / 4>(w, lane & 2);
+    halve_step<4, P / 8>(w, lane & 4);
+    halve_step<8, P / 16>(w, lane & 8);
+    if constexpr (P >= 32) halve_step<16, P / 32>(w, lane & 16);
+    if constexpr (P >= 64) halve_step<32, P / 64>(w, lane & 32);
+    double t = w[0];
+    if constexpr (P < 32) t += lane_xor<16>(t);
+    if constexpr (P < 64) t += lane_xor<32>(t);
+    if (lane < P) s_red[wave * P + halving_slot<P>(lane)] = t;
+    __syncthreads();
+    if (threadIdx.x < K) {
+        double s = 0;
+        for (int w_ = 0; w_ < NT / 64; ++w_) s += s_red[w_ * P + threadIdx.x];
+        s_out[threadIdx.x] = s;
+    }
+    __syncthreads();
 }
 
 // Sum K per-thread values over the workgroup in a fixed order: wave butterfly, then waves in index order.
@@ -205,31 +287,6 @@ struct PoseOptArgs {
     double *out;             // [0, 12) pose  [12, 48) covariance  [48, 52) cov_ok, nBad, iterations, trials  [52, 52 + n) chi2 (want_chi2)
     int want_chi2;
 };
-
-// x from lane (lane ^ M) for M = 1, 2, 8 on the VALU's data-parallel crossbar (no LDS traffic); 4, 16, 32 through ds_bpermute
-template <int M>
-__device__ __forceinline__ double lane_xor(double x) {
-    static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "");
-    if constexpr (M == 1 || M == 2 || M == 8) {
-        constexpr int ctrl = M == 1 ? 0xB1 /* quad_perm [1,0,3,2] */ : M == 2 ? 0x4E /* quad_perm [2,3,0,1] */ : 0x128 /* row_ror:8 */;
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, 0xf, 0xf, false);
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xf, 0xf, false);
-        return __hiloint2double(hi, lo);
-    } else {
-        return __shfl_xor(x, M, 64);
-    }
-}
-
-// One step of the halving butterfly: a lane whose bit M is clear keeps v[0, N) and hands v[N, 2N) to its partner, the other way
-// round for a set bit; N values are left.
-template <int M, int N>
-__device__ __forceinline__ void halve_step(double *v, bool bit) {
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const double keep = bit ? v[N + j] : v[j], send = bit ? v[j] : v[N + j];
-        v[j] = keep + lane_xor<M>(send);
-    }
-}
 
 struct PoseReducer {
     double *s_red;           // [2][PO_WAVES][32]
@@ -642,6 +699,7 @@ __global__ __launch_bounds__(1024) void ba_sum_kernel(const double *in, int64_t 
 // (BA_PL = 4 lanes per point, each walking every fourth edge of the point's list, partial sums combined by a butterfly over
 // the four lanes: the list is a chain of dependent loads — index, edge, Jacobian — and a point has ~12 edges)
 constexpr int BA_PL = 4;
+constexpr int BA_BUILD_T = 1024;     // ba_build_kernel: a free pose's ~2000 edges are two per thread, the chi2 sum 35 per thread
 template <int K>
 __device__ __forceinline__ void ba_lanes_sum(double (&v)[K]) {
 #pragma unroll
@@ -651,7 +709,7 @@ __device__ __forceinline__ void ba_lanes_sum(double (&v)[K]) {
     }
 }
 __device__ __forceinline__ void ba_point_body(const BaDev &d, int block) {
-    const int t = block * BA_T + threadIdx.x, sub = t & (BA_PL - 1);
+    const int t = block * BA_BUILD_T + threadIdx.x, sub = t & (BA_PL - 1);
     const int q = t / BA_PL < d.nX ? t / BA_PL : d.nX - 1;          // (surplus lanes repeat the last point and do not store: every lane takes part in the butterfly)
     const bool mine = t / BA_PL < d.nX && sub == 0;
     double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
@@ -678,11 +736,11 @@ __device__ __forceinline__ void ba_point_body(const BaDev &d, int block) {
 
 // Hpp, bp of one free pose per workgroup
 __device__ __forceinline__ void ba_pose_body(const BaDev &d, int s) {
-    __shared__ double s_red[(BA_T / 64) * 27], s_out[27];
+    __shared__ double s_red[(BA_BUILD_T / 64) * 32], s_out[27];
     double acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-    for (int64_t i = d.ps_off[s] + threadIdx.x; i < d.ps_off[s + 1]; i += BA_T) {
+    for (int64_t i = d.ps_off[s] + threadIdx.x; i < d.ps_off[s + 1]; i += BA_BUILD_T) {
         const int e = d.ps_edges[i];
         if (d.level[e]) continue;
         const double wo = d.wo[e];
@@ -695,7 +753,7 @@ __device__ __forceinline__ void ba_pose_body(const BaDev &d, int s) {
 #pragma unroll
         for (int a = 0; a < 6; ++a) acc[21 + a] -= wo * (jp[a] * er[0] + jp[6 + a] * er[1] + jp[12 + a] * er[2]);
     }
-    block_sum<27, BA_T>(acc, s_red, s_out);
+    block_sum_h<27, 32, BA_BUILD_T>(acc, s_red, s_out);
     if (threadIdx.x == 0) {
         int k = 0;
         for (int a = 0; a < 6; ++a)
@@ -707,17 +765,18 @@ __device__ __forceinline__ void ba_pose_body(const BaDev &d, int s) {
 // One launch behind the edge kernel for the three independent reductions of a linearisation: blocks [0, point_blocks) the
 // points' Hll / bl, the next nF blocks the free poses' Hpp / bp, the last block chi2 of the linearisation point (scal[6]).
 // (Three launches before: 9 + 21 + 25 us back to back on a 36 k-edge problem, each mostly latency.)
-__global__ __launch_bounds__(BA_T) void ba_build_kernel(BaDev d, int point_blocks) {
+__global__ __launch_bounds__(BA_BUILD_T) void ba_build_kernel(BaDev d, int point_blocks) {
     const int b = blockIdx.x;
     if (b < point_blocks) { ba_point_body(d, b); return; }
     if (b < point_blocks + d.nF) { ba_pose_body(d, b - point_blocks); return; }
-    __shared__ double s_red[BA_T / 64], s_out[1];
+    constexpr int T_ = BA_BUILD_T;
+    __shared__ double s_red[T_ / 64], s_out[1];
     double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
     int64_t i = threadIdx.x;
-    for (; i + 3 * BA_T < d.nE; i += 4 * BA_T) { p0 += d.rchi[i]; p1 += d.rchi[i + BA_T]; p2 += d.rchi[i + 2 * BA_T]; p3 += d.rchi[i + 3 * BA_T]; }
-    for (; i < d.nE; i += BA_T) p0 += d.rchi[i];
+    for (; i + 3 * T_ < d.nE; i += 4 * T_) { p0 += d.rchi[i]; p1 += d.rchi[i + T_]; p2 += d.rchi[i + 2 * T_]; p3 += d.rchi[i + 3 * T_]; }
+    for (; i < d.nE; i += T_) p0 += d.rchi[i];
     double v[1] = {(p0 + p1) + (p2 + p3)};
-    block_sum<1, BA_T>(v, s_red, s_out);
+    block_sum<1, T_>(v, s_red, s_out);
     if (threadIdx.x == 0) d.scal[6] = s_out[0];
 }
 
@@ -770,9 +829,9 @@ __global__ __launch_bounds__(BA_T) void ba_edge_y_kernel(BaDev d, double lambda)
 // S block (i, j), i <= j:  [i == j] (Hpp_i + lambda I)  -  sum_q Y_{e(i,q)} W_{e(j,q)}' ; rhs_i = bp_i - sum_q Y_{e(i,q)} bl_q
 // (1024 threads per block — 3 points per thread instead of 12 — was measured in round 3: the whole call went from 3.4 to 3.9 ms;
 // the 42-value block reduction over 16 waves costs more than the shorter chains of dependent loads save)
-constexpr int BA_SCHUR_T = 256;
+constexpr int BA_SCHUR_T = 512;       // a pair of keyframes shares up to nX points and every thread walks a chain of dependent loads per point: 6 points per thread (42 f64 accumulators: 1024 threads would spill)
 __global__ __launch_bounds__(BA_SCHUR_T) void ba_schur_kernel(BaDev d, double lambda) {
-    __shared__ double s_red[(BA_SCHUR_T / 64) * 42], s_out[42];
+    __shared__ double s_red[(BA_SCHUR_T / 64) * 64], s_out[42];
     // block index -> (i, j) of the upper triangle
     int i = 0, rem = blockIdx.x;
     while (rem >= d.nF - i) { rem -= d.nF - i; ++i; }
@@ -781,24 +840,43 @@ __global__ __launch_bounds__(BA_SCHUR_T) void ba_schur_kernel(BaDev d, double la
     double acc[42];
 #pragma unroll
     for (int k = 0; k < 42; ++k) acc[k] = 0.0;
-    for (int q = threadIdx.x; q < d.nX; q += BA_SCHUR_T) {
-        const int e1 = ti[q];
-        if (e1 < 0 || d.level[e1]) continue;
-        const double *Y = d.Y + 18 * (int64_t)e1;
-        if (i == j) {
-            const double *bl = d.bl + 3 * (int64_t)q;
+    // A point costs a chain of dependent loads (table entry -> level flag -> 18 + 18 doubles) and a thread has several: the table
+    // entries and flags of SCH_U points are fetched together before anything depends on them (points in increasing order, as before).
+    constexpr int SCH_U = 3;
+    for (int q0 = threadIdx.x; q0 < d.nX; q0 += SCH_U * BA_SCHUR_T) {
+        int e1[SCH_U], e2[SCH_U];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) acc[36 + a] += Y[3 * a] * bl[0] + Y[3 * a + 1] * bl[1] + Y[3 * a + 2] * bl[2];
+        for (int u = 0; u < SCH_U; ++u) {
+            const int q = q0 + u * BA_SCHUR_T;
+            e1[u] = q < d.nX ? ti[q] : -1;
+            e2[u] = q < d.nX ? tj[q] : -1;
         }
-        const int e2 = tj[q];
-        if (e2 < 0 || d.level[e2]) continue;
-        const double *W = d.W + 18 * (int64_t)e2;
+        bool on1[SCH_U], on2[SCH_U];
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
+        for (int u = 0; u < SCH_U; ++u) {
+            const uint8_t l1 = d.level[e1[u] < 0 ? 0 : e1[u]], l2 = d.level[e2[u] < 0 ? 0 : e2[u]];
+            on1[u] = e1[u] >= 0 && !l1;
+            on2[u] = on1[u] && e2[u] >= 0 && !l2;
+        }
 #pragma unroll
-            for (int b = 0; b < 6; ++b) acc[6 * a + b] += Y[3 * a] * W[3 * b] + Y[3 * a + 1] * W[3 * b + 1] + Y[3 * a + 2] * W[3 * b + 2];
+        for (int u = 0; u < SCH_U; ++u) {
+            if (!on1[u]) continue;
+            const int q = q0 + u * BA_SCHUR_T;
+            const double *Y = d.Y + 18 * (int64_t)e1[u];
+            if (i == j) {
+                const double *bl = d.bl + 3 * (int64_t)q;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) acc[36 + a] += Y[3 * a] * bl[0] + Y[3 * a + 1] * bl[1] + Y[3 * a + 2] * bl[2];
+            }
+            if (!on2[u]) continue;
+            const double *W = d.W + 18 * (int64_t)e2[u];
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) acc[6 * a + b] += Y[3 * a] * W[3 * b] + Y[3 * a + 1] * W[3 * b + 1] + Y[3 * a + 2] * W[3 * b + 2];
+        }
     }
-    block_sum<42, BA_SCHUR_T>(acc, s_red, s_out);
+    block_sum_h<42, 64, BA_SCHUR_T>(acc, s_red, s_out);
     const int n6 = 6 * d.nF;
     if (threadIdx.x < 36) {
         const int a = threadIdx.x / 6, b = threadIdx.x % 6;
@@ -815,7 +893,7 @@ __global__ __launch_bounds__(BA_SCHUR_T) void ba_schur_kernel(BaDev d, double la
 // matrix: 3 barriers per keyframe instead of 3 per column), as are the two triangular solves.  This is the form for systems
 // that do not fit in LDS (more than 21 free keyframes: a global bundle adjustment); it works in global memory.  A local BA
 // (n <= 126) takes ba_dense_solve_lds_kernel below.
-constexpr int BA_SOLVE_T = 256;
+constexpr int BA_SOLVE_T = 256;        // (1024 threads: 89 us instead of 63 — every wave repeats the diagonal block's Cholesky, four waves per SIMD take turns at it)
 __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_kernel(BaDev d) {
     __shared__ int s_ok;
     __shared__ double s_x[6];
@@ -944,7 +1022,8 @@ __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_lds_kernel(BaDev d)
 #pragma unroll
             for (int k = 0; k < j; ++k) dj -= l[j][k] * l[j][k];
             if (!(dj > 0.0)) ok = false;                 // (the same value in every thread: uniform)
-            const double sd = sqrt(dj), inv = 1.0 / sd;
+            double sd, inv;
+            sqrt_and_rsqrt(dj, sd, inv);
             l[j][j] = sd;
             li[j][j] = inv;
 #pragma unroll
@@ -1269,7 +1348,8 @@ class BaSolver {
             const double *P = poses_[cur_].as<double>(), *X = points_[cur_].as<double>();
             if (nE_) hipLaunchKernelGGL(ba_edge_kernel<true>, dim3(gE), dim3(BA_T), 0, 0, d_, P, X);
             // Hll / bl of the points, Hpp / bp of the free poses, chi2 at the current estimate (scal[6])
-            hipLaunchKernelGGL(ba_build_kernel, dim3((landmarks ? gX4 : 0u) + (unsigned)nF_ + 1u), dim3(BA_T), 0, 0, d_, landmarks ? (int)gX4 : 0);
+            const unsigned gXb = (unsigned)cdiv(std::max(nX_, 1) * BA_PL, BA_BUILD_T);
+            hipLaunchKernelGGL(ba_build_kernel, dim3((landmarks ? gXb : 0u) + (unsigned)nF_ + 1u), dim3(BA_BUILD_T), 0, 0, d_, landmarks ? (int)gXb : 0);
             linearized = true;
             // The host needs lambda before the first trial only in the first iteration (computeLambdaInit: 1e-5 max |diag H|);
             // afterwards the chi2 of the linearisation point is read together with the trial's result: ONE host read per trial
