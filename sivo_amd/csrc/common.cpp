@@ -46,6 +46,18 @@ FirstUse::~FirstUse() {
     first_use_mutex().unlock();
 }
 
+#ifdef SIVO_DIAG
+uint32_t *diag_words() {
+    static uint32_t *w = [] {
+        uint32_t *p = nullptr;
+        if (hipHostMalloc((void **)&p, 64 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) throw std::runtime_error("diag_words: hipHostMalloc");
+        for (int i = 0; i < 64; ++i) p[i] = 0;
+        return p;
+    }();
+    return w;
+}
+#endif
+
 }  // namespace sivo
 
 extern "C" const char *sivo_last_error(void) { return sivo::last_error_ref().c_str(); }

@@ -99,6 +99,19 @@ class FirstUse {
 #define SIVO_DIAG_ENV(name) (static_cast<const char *>(nullptr))
 #endif
 
+#ifdef SIVO_DIAG
+// Diagnostic build only: 64 words of pinned host memory kernels report into (tools/coresident_probe.py reads them through
+// sivo_debug_words):  [0] border cells of a bridge workgroup's LDS plane found non-zero at its end (somebody else wrote there),
+// [1] bridge workgroups checked, [2] canary words behind the f16x3 GEMM's stage buffers found changed, [3] GEMM workgroups checked.
+uint32_t *diag_words();
+// SIVO_POISON_LDS=1: fills every CU's LDS with NaNs in front of the next kernel of the stream (a kernel that reads LDS it did not
+// write then produces NaNs instead of depending on what its predecessor left there).
+void diag_poison_lds(hipStream_t s);
+#define SIVO_DIAG_POISON(s) ::sivo::diag_poison_lds(s)
+#else
+#define SIVO_DIAG_POISON(s) ((void)0)
+#endif
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

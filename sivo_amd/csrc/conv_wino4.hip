@@ -25,6 +25,7 @@
 //                                                                     ReLU, Philox dropout, 4 float4 stores
 // P = tiles of the sample group (n * ceil(H/4) * W/4), Pp / Kp padded to multiples of 128.
 #include <hip/hip_runtime.h>
+#include <map>
 #include <stdint.h>
 
 #include <cstdlib>
@@ -75,6 +76,10 @@ struct Wino4Args {
     float vscale, mscale;
     uint32_t *h3_flag;
     uint32_t *vmax;             // calibration pass: atomicMax of the bit pattern of |V| (the layer's largest transformed value), or null
+#ifdef SIVO_DIAG
+    uint32_t *diag;             // diagnostic build: diag_words()
+    int diag_coherent;          // diagnostic build: the bridge reads M with agent-scope loads (past the CU's vector L1)
+#endif
 };
 
 // end of a transform thread: report an overflow / the calibration maximum (rare / calibration only)
@@ -628,7 +633,8 @@ __global__ __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *
     const int64_t xs_m = (int64_t)a.Kp * a.Pp, xs_v = (int64_t)a.K * a.Pp;
     bool bad = false;
     float vmax = 0.f;
-    for (int t = threadIdx.x; t < ntile; t += blockDim.x) {
+    // the 4 x 4 output pixels of tile t of (sample n, cout co) after the epilogue (BN, ReLU, dropout); rows 4 ty + i >= H do not exist
+    auto tile_values = [&](int t, float (&vv)[4][4]) __attribute__((always_inline)) {
         const int tx = t % a.tw, ty = t / a.tw;
         const float *src = a.M + (int64_t)co * a.Pp + (int64_t)n * ntile + t;
         float tt[4][6];
@@ -636,7 +642,13 @@ __global__ __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *
         for (int j = 0; j < 6; ++j) {
             float m[6];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) m[i] = src[(int64_t)(i * 6 + j) * xs_m];
+            for (int i = 0; i < 6; ++i) {
+#ifdef SIVO_DIAG
+                if (a.diag_coherent) m[i] = __hip_atomic_load(src + (int64_t)(i * 6 + j) * xs_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else
+#endif
+                    m[i] = src[(int64_t)(i * 6 + j) * xs_m];
+            }
             float s4[4];
             wino4_at(m[0], m[1], m[2], m[3], m[4], m[5], s4);
 #pragma unroll
@@ -645,7 +657,6 @@ __global__ __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int y = 4 * ty + i;
-            if (y >= a.H) break;                 // rows below the image stay zero
             float v[4];
             wino4_at(tt[i][0], tt[i][1], tt[i][2], tt[i][3], tt[i][4], tt[i][5], v);
 #pragma unroll
@@ -654,17 +665,56 @@ __global__ __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *
                 if (a.relu) v[r] = v[r] > 0.f ? v[r] : 0.f;
             }
             const int x = 4 * tx;
-            if (a.drop_site >= 0) {
+            if (a.drop_site >= 0 && y < a.H) {
                 const uint32_t e = (uint32_t)((co * a.H + y) * a.W + x);
                 const uint32_t w = wino4_dropout_word(e, (uint32_t)a.drop_site, (uint32_t)(a.sample0 + n), a.seed) >> (e & 31);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = ((w >> r) & 1u) ? v[r] * 2.f : 0.f;
             }
-            float *dst = plane + (y + 1) * RS + x + 1;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dst[r] = v[r];
+            for (int r = 0; r < 4; ++r) vv[i][r] = v[r];
+        }
+    };
+    for (int t = threadIdx.x; t < ntile; t += blockDim.x) {
+        const int tx = t % a.tw, ty = t / a.tw;
+        float vv[4][4];
+        tile_values(t, vv);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int y = 4 * ty + i;
+            if (y >= a.H) break;                 // rows below the image stay zero
+            float *dst = plane + (y + 1) * RS + 4 * tx + 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[r] = vv[i][r];
         }
     }
+#ifdef SIVO_DIAG
+    // diagnostic build (SIVO_BRIDGE_CHECK): every thread computes its tiles' values again and compares them with what the plane holds
+    // now — a difference means the LDS word changed after this workgroup wrote it.  [7] words found changed; the first such word:
+    // [8] float index in the plane, [9] the bits written, [10] the bits found, [11] n << 16 | co, [12] rows << 16 | row stride
+    if (a.diag) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < ntile; t += blockDim.x) {
+            const int tx = t % a.tw, ty = t / a.tw;
+            float vv[4][4];
+            tile_values(t, vv);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int y = 4 * ty + i;
+                if (y >= a.H) break;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int at = (y + 1) * RS + 4 * tx + 1 + r;
+                    const uint32_t want = __float_as_uint(vv[i][r]), got = __float_as_uint(plane[at]);
+                    if (want != got && atomicAdd(a.diag + 7, 1u) == 0u) {
+                        a.diag[8] = (uint32_t)at; a.diag[9] = want; a.diag[10] = got; a.diag[11] = (uint32_t)(n << 16 | co);
+                        a.diag[12] = (uint32_t)(rows << 16 | RS);
+                    }
+                }
+            }
+        }
+    }
+#endif
     __syncthreads();
     for (int t = threadIdx.x; t < ntile; t += blockDim.x) {
         const int tx = t % a.tw, ty = t / a.tw;
@@ -704,6 +754,21 @@ __global__ __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *
         r.vmax = next_vmax;
         wino4_report(r, bad, vmax);
     }
+#ifdef SIVO_DIAG
+    // the zero border of the plane (row 0, the rows below the image, column 0, the columns right of the image) is written by nobody
+    // after the first loop of this kernel: a non-zero cell at the end was written by somebody else
+    if (a.diag) {
+        __syncthreads();
+        unsigned dirty = 0;
+        for (int i = threadIdx.x; i < rows * RS; i += blockDim.x) {
+            const int y = i / RS, x = i % RS;
+            const bool border = y == 0 || y > a.H || x == 0 || x > a.W;
+            if (border && __float_as_uint(plane[i]) != 0u) ++dirty;
+        }
+        if (dirty) atomicAdd(a.diag + 0, dirty);
+        if (threadIdx.x == 0) atomicAdd(a.diag + 1, 1u);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -792,6 +857,23 @@ size_t wino4_workspace_floats(int group, int cin, int cout, int H, int W) {
     return (size_t)(36 * Pp * ((int64_t)cin + wino4_cout_pad(cout)));
 }
 
+#ifdef SIVO_DIAG
+// diagnostic build, SIVO_W4_VERIFY=1: a layer's GEMM and bridge are run a second time into scratch buffers, under the same
+// concurrent conditions, and compared word for word: diag word [4] counts M words that differ, [5] V' words, [6] layers compared
+__global__ void diag_compare_kernel(const uint32_t *x, const uint32_t *y, int64_t n, uint32_t *count, int Pp, int P, uint32_t *rec) {
+    unsigned bad = 0;          // (columns P .. Pp of a row of Pp words are padding nobody writes)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if ((i % Pp) < P && x[i] != y[i]) {
+            ++bad;
+            if (rec) {                               // the first twelve differing words: index, first run, second run
+                const unsigned k = atomicAdd(rec, 1u);
+                if (k < 12) { rec[1 + 3 * k] = (uint32_t)i; rec[2 + 3 * k] = x[i]; rec[3 + 3 * k] = y[i]; }
+            }
+        }
+    if (bad) atomicAdd(count, bad);
+}
+#endif
+
 size_t wino4_bridge_lds_bytes(int H, int W) { return (size_t)(4 * ((H + 3) / 4) + 2) * (W + 4) * sizeof(float); }
 
 // One F(4x4,3x3) layer.  `group` samples per pass over the workspace.  plan (optional) chains layers without going
@@ -819,6 +901,10 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
     a.U = c.wt; a.ep_scale = c.ep_scale; a.ep_shift = c.ep_shift;
     a.relu = c.relu; a.drop_site = c.drop_site; a.seed = c.seed; a.in_sample_stride = c.in_sample_stride;
     a.pool_out = c.pool_out; a.pool_mask = c.pool_mask; a.pool_drop_site = c.pool_drop_site; a.Ho = (c.H + 1) / 2; a.Wo = (c.W + 1) / 2;
+#ifdef SIVO_DIAG
+    a.diag = std::getenv("SIVO_BRIDGE_CHECK") ? diag_words() : nullptr;
+    a.diag_coherent = std::getenv("SIVO_BRIDGE_M_COHERENT") != nullptr;
+#endif
     const bool h3 = c.wt_h3 && c.h3_vscale > 0.f;
     a.vscale = h3 ? c.h3_vscale : 0.f;
     a.mscale = h3 ? 1.f / (c.h3_vscale * c.h3_uscale) : 1.f;
@@ -845,6 +931,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         if (e && !gemm_only_events) (void)hipEventRecord(e[0], s);
         if (!(plan && plan->skip_input)) {
             const dim3 gi(pblocks, (unsigned)a.C), bi(W4_TIN);
+            SIVO_DIAG_POISON(s);
             if (a.mask && h3) hipLaunchKernelGGL((wino4_input_kernel<true, true>), gi, bi, 0, s, a);
             else if (a.mask) hipLaunchKernelGGL((wino4_input_kernel<true, false>), gi, bi, 0, s, a);
             else if (h3) hipLaunchKernelGGL((wino4_input_kernel<false, true>), gi, bi, 0, s, a);
@@ -854,6 +941,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         auto nblocks = [&](int bm, int bn) { return (int64_t)36 * ((a.P + bm - 1) / bm) * (a.Kp / bn); };
         // bf16x6 (128 x 128 items): whenever the layer has the split weights and the launch is not tiny
         static const int x6_min_blocks = SIVO_DIAG_ENV("SIVO_X6_MINBLOCKS") ? std::atoi(SIVO_DIAG_ENV("SIVO_X6_MINBLOCKS")) : 128;
+        SIVO_DIAG_POISON(s);
         if (h3) {
             launch_wino4_gemm_h3(reinterpret_cast<const uint32_t *>(a.V), c.wt_h3, a.M, a.C, a.Kp, a.P, a.Pp, s);
         } else if (c.wt_x6 && nblocks(128, 128) >= x6_min_blocks) {
@@ -878,14 +966,46 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
             const int ntile = a.th * a.tw;
             const int nthr = ntile >= 1024 ? 1024 : (ntile + 63) / 64 * 64;
             const dim3 gb((unsigned)a.n, (unsigned)a.K);
-            const size_t lb = wino4_bridge_lds_bytes(a.H, a.W);
+            // (diagnostic build: SIVO_BRIDGE_LDS_ALL=1 gives the bridge a CU's whole LDS, so that it never shares a CU with an LDS user)
+            const size_t lb = SIVO_DIAG_ENV("SIVO_BRIDGE_LDS_ALL") ? (size_t)160 * 1024 : wino4_bridge_lds_bytes(a.H, a.W);
+            SIVO_DIAG_POISON(s);
             if (plan->next_vscale > 0.f) hipLaunchKernelGGL(wino4_bridge_kernel<true>, gb, dim3(nthr), lb, s, a, plan->Vnext, plan->next_vscale, plan->next_vmax);
             else hipLaunchKernelGGL(wino4_bridge_kernel<false>, gb, dim3(nthr), lb, s, a, plan->Vnext, 0.f, plan->next_vmax);
         } else {
+            SIVO_DIAG_POISON(s);
             if (a.pool_out) hipLaunchKernelGGL(wino4_output_kernel<true>, dim3(pblocks, (unsigned)a.K), dim3(W4_TIN), 0, s, a);
             else hipLaunchKernelGGL(wino4_output_kernel<false>, dim3(pblocks, (unsigned)a.K), dim3(W4_TIN), 0, s, a);
         }
         if (e && !gemm_only_events) (void)hipEventRecord(e[3], s);
+#ifdef SIVO_DIAG
+        if (h3 && plan && plan->bridge && SIVO_DIAG_ENV("SIVO_W4_VERIFY")) {
+            struct Scratch { float *m2 = nullptr, *v2 = nullptr; size_t cap = 0; };
+            static std::map<hipStream_t, Scratch> per_stream;           // (the lanes of a handle are enqueued by one host thread)
+            Scratch &sc = per_stream[s];
+            const size_t need = (size_t)36 * std::max(a.Kp, a.C) * a.Pp;
+            if (need > sc.cap) {
+                SIVO_HIP(hipDeviceSynchronize());
+                if (sc.m2) { (void)hipFree(sc.m2); (void)hipFree(sc.v2); }
+                SIVO_HIP(hipMalloc((void **)&sc.m2, need * 4)); SIVO_HIP(hipMalloc((void **)&sc.v2, need * 4));
+                sc.cap = need;
+            }
+            float *m2 = sc.m2, *v2 = sc.v2;
+            launch_wino4_gemm_h3(reinterpret_cast<const uint32_t *>(a.V), c.wt_h3, m2, a.C, a.Kp, a.P, a.Pp, s);
+            hipLaunchKernelGGL(diag_compare_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(a.M), reinterpret_cast<const uint32_t *>(m2),
+                               (int64_t)36 * a.Kp * a.Pp, diag_words() + 4, (int)a.Pp, (int)a.Pp, (uint32_t *)nullptr);
+            const int ntile = a.th * a.tw, nthr = ntile >= 1024 ? 1024 : (ntile + 63) / 64 * 64;
+            const size_t lb = SIVO_DIAG_ENV("SIVO_BRIDGE_LDS_ALL") ? (size_t)160 * 1024 : wino4_bridge_lds_bytes(a.H, a.W);
+            if (plan->next_vscale > 0.f) hipLaunchKernelGGL(wino4_bridge_kernel<true>, dim3((unsigned)a.n, (unsigned)a.K), dim3(nthr), lb, s, a, v2, plan->next_vscale, plan->next_vmax);
+            else hipLaunchKernelGGL(wino4_bridge_kernel<false>, dim3((unsigned)a.n, (unsigned)a.K), dim3(nthr), lb, s, a, v2, 0.f, plan->next_vmax);
+            // (the padding columns P .. Pp of V' are written by nobody: compare sample by sample, the tiles that exist)
+            hipLaunchKernelGGL(diag_compare_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(plan->Vnext), reinterpret_cast<const uint32_t *>(v2),
+                               (int64_t)36 * a.K * a.Pp, diag_words() + 5, (int)a.Pp, (int)a.P, diag_words() + 20);
+            ++diag_words()[6];
+            if (diag_words()[20] && !diag_words()[19]) {        // geometry of the first layer that showed a difference (host side, after the fact: approximate)
+                diag_words()[16] = (uint32_t)a.K; diag_words()[17] = (uint32_t)a.Pp; diag_words()[18] = (uint32_t)(a.th * a.tw); diag_words()[19] = (uint32_t)a.tw;
+            }
+        }
+#endif
     }
 }
 

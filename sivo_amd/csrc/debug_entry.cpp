@@ -352,3 +352,36 @@ extern "C" int sivo_debug_conv_cls_h3_dev(int T, int Cin, int C, int H, int W, c
         return SIVO_OK;
     });
 }
+
+#ifdef SIVO_DIAG
+namespace sivo { void launch_occupy(int lds_bytes, int mode, int microseconds, const uint32_t *src, uint32_t *sink, hipStream_t s); }
+// diagnostic build: `launches` launches of the occupant kernel (diag_kernels.hip) back to back on a stream of its own, each holding
+// lds_bytes of every CU's LDS for ~microseconds; returns when they are enqueued (sivo_debug_occupy_wait joins them)
+static hipStream_t g_occ_stream = nullptr;
+static uint32_t *g_occ_src = nullptr;
+extern "C" int sivo_debug_occupy(int lds_bytes, int mode, int microseconds, int launches) {
+    return sivo::guarded([&] {
+        if (!g_occ_stream) {
+            SIVO_HIP(hipStreamCreateWithFlags(&g_occ_stream, hipStreamNonBlocking));
+            SIVO_HIP(hipMalloc((void **)&g_occ_src, (size_t)(1 << 20) + 4096));
+            SIVO_HIP(hipMemset(g_occ_src, 0x5a, (size_t)(1 << 20) + 4096));
+        }
+        for (int i = 0; i < launches; ++i) sivo::launch_occupy(lds_bytes, mode, microseconds, g_occ_src, g_occ_src, g_occ_stream);
+        return SIVO_OK;
+    });
+}
+extern "C" int sivo_debug_occupy_wait(void) {
+    return sivo::guarded([&] {
+        if (g_occ_stream) SIVO_HIP(hipStreamSynchronize(g_occ_stream));
+        return SIVO_OK;
+    });
+}
+// diagnostic build: the 64 report words of sivo::diag_words() (common.hpp); reset != 0 clears them after the read
+extern "C" int sivo_debug_words(uint32_t out[64], int reset) {
+    return sivo::guarded([&] {
+        uint32_t *w = sivo::diag_words();
+        for (int i = 0; i < 64; ++i) { if (out) out[i] = w[i]; if (reset) w[i] = 0; }
+        return SIVO_OK;
+    });
+}
+#endif

@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Diagnostic build (libsivo_hip_diag.so), GPU box: SegNet-Standard T = 12 at 352 x 1024, three lanes against one lane (must be bit
+identical) under the environment of the call, plus the report words of the diagnostic hooks (bridge border check, GEMM canary).
+    python tools/coresident_probe.py            -> runs every variant below in its own process (the switches are read once)
+    python tools/coresident_probe.py --one NAME -> the body, under the caller's environment"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+VARIANTS = [
+    ("claim-160K (as shipped)", {"SIVO_BRIDGE_CHECK": "1", "SIVO_H3_CANARY": "1"}),
+    ("exact LDS", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_CHECK": "1"}),
+    ("exact LDS again", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_CHECK": "1"}),
+    ("exact LDS, every bridged layer's GEMM and bridge run twice and compared", {"SIVO_H3_LDS_ALL": "0", "SIVO_W4_VERIFY": "1"}),
+    ("claim-160K, every bridged layer's GEMM and bridge run twice and compared", {"SIVO_W4_VERIFY": "1"}),
+    ("exact LDS, coherent: the bridge reads M past the CU's L1 (agent-scope loads)", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_M_COHERENT": "1", "SIVO_W4_VERIFY": "1"}),
+    ("exact LDS, bridge claims 160K", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_LDS_ALL": "1", "SIVO_BRIDGE_CHECK": "1"}),
+    ("exact LDS, packed chain off", {"SIVO_H3_LDS_ALL": "0", "SIVO_D3_PK": "0", "SIVO_BRIDGE_CHECK": "1"}),
+    ("exact LDS, x6 GEMM", {"SIVO_H3_LDS_ALL": "0", "SIVO_GEMM": "x6"}),
+    ("occupant idle 128K beside a ONE-lane handle (bridge workgroups at LDS bases >= 128K, nobody else using LDS)", {"DBG_LANES_A": "1", "SIVO_H3_LDS_ALL": "0", "PROBE_OCCUPY": "131072,0"}),
+    ("occupant with ds traffic 128K beside a one-lane handle", {"DBG_LANES_A": "1", "SIVO_H3_LDS_ALL": "0", "PROBE_OCCUPY": "131072,1"}),
+    ("occupant with LDS-DMA traffic 128K beside a one-lane handle", {"DBG_LANES_A": "1", "SIVO_H3_LDS_ALL": "0", "PROBE_OCCUPY": "131072,2"}),
+    ("occupant with LDS-DMA traffic 112K beside a one-lane handle", {"DBG_LANES_A": "1", "SIVO_H3_LDS_ALL": "0", "PROBE_OCCUPY": "114688,2"}),
+    ("one lane both, LDS poisoned in front of every kernel", {"SIVO_POISON_LDS": "1", "DBG_LANES_A": "1", "SIVO_H3_LDS_ALL": "0"}),
+]
+
+
+def body(name):
+    import numpy as np
+    import torch
+    from sivo_amd import _lib, netspec, weights as wts
+    from sivo_amd.segnet import BayesianSegNet
+    from bench import make_inputs
+    H, W, T = 352, 1024, 12
+    text = netspec.standard_prototxt(T, H, W)
+    layers = netspec.parse_layers(text)
+    flat = wts.pack(layers, wts.synth_weights(layers, 42))
+    img = torch.from_numpy(make_inputs(H, W)[0]).cuda()
+    with _lib.use("diag") as L:
+        L.sivo_debug_words.argtypes = [C.c_void_p, C.c_int]
+        L.sivo_debug_occupy.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+
+        def words(reset=1):
+            w = (C.c_uint32 * 64)()
+            L.sivo_debug_words(w, reset)
+            return list(w[:64])
+
+        def make(lanes):
+            os.environ["SIVO_LANES"] = str(lanes)
+            return BayesianSegNet(prototxt=text, weights=flat, T=T)
+        poison = os.environ.pop("SIVO_POISON_LDS", None)       # the reference handle is never poisoned
+        b = make(1)
+        _, lb0, _ = b.forward(img, 99, want_logits=True)
+        torch.cuda.synchronize()
+        if poison:
+            os.environ["SIVO_POISON_LDS"] = poison
+        a = make(int(os.environ.get("DBG_LANES_A", "3")))
+        words()
+        bad = 0
+        occ = os.environ.get("PROBE_OCCUPY")
+        for seed in (99, 5, 7, 11):
+            if occ:      # ~40 ms of occupant launches (150 us each) on their own stream, then the two frames beside them
+                L.sivo_debug_occupy(int(occ.split(",")[0]), int(occ.split(",")[1]), 150, 400)
+                import time
+                time.sleep(0.002)
+            _, la, _ = a.forward(img, seed, want_logits=True)
+            _, la2, _ = a.forward(img, seed, want_logits=True)
+            if occ:
+                torch.cuda.synchronize()
+                t_w = time.perf_counter()
+                L.sivo_debug_occupy_wait()
+                print(f"  (occupant launches outlasted the two frames by {1e3 * (time.perf_counter() - t_w):.1f} ms)")
+            _, lb, _ = b.forward(img, seed, want_logits=True)
+            torch.cuda.synchronize()
+            d = (la - lb).abs()
+            nz = (d > 0) | torch.isnan(la)
+            info = ""
+            if nz.any():
+                idx = nz.nonzero()
+                info = (f" differing {int(nz.sum())} (NaN {int(torch.isnan(la).sum())}) samples {sorted(set(idx[:, 0].tolist()))} y {int(idx[:, 2].min())}-{int(idx[:, 2].max())} "
+                        f"x {int(idx[:, 3].min())}-{int(idx[:, 3].max())} max {float(torch.nan_to_num(d).max()):.3e}")
+                bad += 1
+            print(f"  seed {seed}: equal to the one-lane handle {bool(torch.equal(la, lb))}; repeatable {bool(torch.equal(la, la2))}{info}", flush=True)
+        w = words()
+        if w[20]:
+            print(f"  first differing V' words ({w[20]} recorded; geometry of a layer seen after the first difference: K {w[16]} Pp {w[17]} tiles per sample {w[18]} tiles per row {w[19]}):")
+            for k in range(min(w[20], 12)):
+                idx, xa, xb = w[21 + 3 * k], w[22 + 3 * k], w[23 + 3 * k]
+                K, Pp, nt, tw = max(w[16], 1), max(w[17], 1), max(w[18], 1), max(w[19], 1)
+                xi, co, pp = idx // (K * Pp), (idx // Pp) % K, idx % Pp
+                print(f"    word {idx}: xi {xi} cout {co} sample {pp // nt} tile {pp % nt} (row {pp % nt // tw} col {pp % nt % tw}): first run {xa:08x} second run {xb:08x}")
+        print(f"[{name}] frames that differ: {bad} of 4; bridge border cells dirty {w[0]} in {w[1]} workgroups checked; GEMM canary words changed {w[2]} in {w[3]} workgroups; "
+              f"re-run compare over {w[6]} layers: M words differing {w[4]}, V' words differing {w[5]}; "
+              f"plane words changed after they were written {w[7]} (first: index {w[8]} of a {w[12] >> 16} x {w[12] & 0xffff} plane, wrote {w[9]:08x} found {w[10]:08x}, n {w[11] >> 16} cout {w[11] & 0xffff})", flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 3 and sys.argv[1] == "--one":
+        body(sys.argv[2])
+    else:
+        sel = os.environ.get("PROBE_ONLY")
+        for name, env in VARIANTS:
+            if sel and sel not in name:
+                continue
+            e = dict(os.environ); e.update(env)
+            print(f"== {name}: {env}", flush=True)
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--one", name], env=e, timeout=600)
