@@ -264,11 +264,12 @@ def membound_block(prof, fp, d_left, H, W, T, classes):
     return rows
 
 
-def time_segnet(sn, frame, steps, warmup, barrier, profile_every=8, events=True):
+def time_segnet(sn, frame, steps, warmup, barrier, profile_every=8, events=True, flush=lambda: None):
     """Warm up, time `steps` calls of frame(seed) between barriers, return (elapsed s, MFMA-kernel rows of the timed region,
     all-kernel rows of min(steps, 10) further untimed single-lane frames)."""
     for i in range(warmup):
         frame(1000 + i)
+    flush()
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -277,6 +278,7 @@ def time_segnet(sn, frame, steps, warmup, barrier, profile_every=8, events=True)
         elif events and i % profile_every == 1:
             sn.profile(False)
         frame(2000 + i)
+    flush()                      # (frames still in flight are completed inside the timed region)
     barrier()
     elapsed = time.perf_counter() - t0
     prof_timed = sn.profile_read() if events else []
@@ -284,6 +286,7 @@ def time_segnet(sn, frame, steps, warmup, barrier, profile_every=8, events=True)
     sn.profile(True, reset=True)
     for i in range(n_detail):
         frame(3000 + i)
+    flush()
     barrier()
     prof = sn.profile_read()
     sn.profile(False)
@@ -400,6 +403,7 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--no-orb", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="N = 1: one frame in flight (the host tail of a frame is not overlapped with the next frame's device work)")
     ap.add_argument("--configs", default="all", help="N = 1 only: which further BASELINE configs to measure after the main one and "
                     "report under \"configs\": all | none | comma list of basic,t48,ba,host,track,shards (rocprofv3 runs use one at a time)")
     ap.add_argument("--per-layer", action="store_true", help="print the per-layer event timings to stderr")
@@ -469,43 +473,81 @@ def main():
 
     rank_events = []         # N > 1: (start, forward done, all-reduce done) of every frame on this rank's stream
 
+    # N = 1: TWO frames in flight.  A frame's device work (network, ORB, matching) is enqueued; its host tail — semantic filter, median
+    # cull, entropy gate, ≈0.35 ms during which the GPU would otherwise idle — runs after the NEXT frame's device work has been
+    # enqueued.  Same per-frame results (the frames are independent: Frame::Frame needs the image only), one frame more latency;
+    # --serial restores the strict sequence and the line reports both rates.
+    pipelined = world == 1 and do_orb and not args.serial
+    slots = 2 if pipelined else 1
+    maps_s = [maps] + [new_maps() for _ in range(slots - 1)]
+    cls_pin = [torch.empty((H, W), dtype=torch.uint8).pin_memory() for _ in range(slots)] if world == 1 and do_orb else None
+    done_ev = [torch.cuda.Event() for _ in range(slots)]
+    inflight = []            # [(slot, seed, pending)] issued and not completed
+
+    def issue(seed):
+        slot = (inflight[-1][0] + 1) % slots if inflight else 0
+        sn.segment_into(d_bgr, seed, maps_s[slot])        # asynchronous: ~65 launches enqueued in ~0.5 ms
+        cls_pin[slot].copy_(maps_s[slot][0], non_blocking=True)      # 360 KB D2H behind the frame's last kernel
+        done_ev[slot].record()
+        pending = fp.start_orb(d_left, d_right)                      # ORB of this frame runs beside the network
+        inflight.append((slot, seed, pending))
+
+    def complete():
+        slot, seed, pending = inflight.pop(0)
+        done_ev[slot].synchronize()                       # this frame's maps are complete (a later frame may still be running)
+        if sn.take_overflow():         # (one pinned word) an activation left the fp16 range in a frame issued so far: drain, and every
+            torch.cuda.synchronize()   # frame still in flight once more (the first of them runs without f16x3, the scales back off)
+            for sl, sd, _ in [(slot, seed, None)] + inflight:
+                sn.segment_into(d_bgr, sd, maps_s[sl])
+                cls_pin[sl].copy_(maps_s[sl][0], non_blocking=True)
+                done_ev[sl].record()
+                stats["recomputed"] += 1
+            done_ev[slot].synchronize()
+        cls_host = cls_pin[slot].numpy()
+        t0 = time.perf_counter()
+        r = fp.finish(pending, cls_host)
+        # entropy feature selection over the frame's semantic keys (Tracking.cc:934-1023): the keys are on the host, the
+        # f64 entropy map stays where the network wrote it (sivo_entropy_gate_map_dev)
+        t1 = time.perf_counter()
+        d = r["depth"]; k = r["keys"]
+        xyz = np.stack([(k["x"] - KCX) * d / KFX, (k["y"] - KCY) * d / KFY, d], 1).astype(np.float64)
+        _, _, acc = selection.entropy_gate_map_dev(k, d, xyz, maps_s[slot][2], STATE_COV, KFX, KFY, KBL, fp.ex_l.GetScaleSigmaSquares(), GATE_TH)
+        stats["gate_s"] += time.perf_counter() - t1; stats["gate_n"] += 1
+        stats["selected"] = int(acc.sum())
+        if tail_probe is not None:
+            tail_probe.append(time.perf_counter() - t0)
+        stats["kps"], stats["matches"] = r["semantic_keys"], r["stereo_matches"]
+        stats["last"] = r
+
+    def flush():
+        while inflight:
+            complete()
+
     def frame(seed):
+        if world == 1 and do_orb:
+            issue(seed)
+            if len(inflight) >= slots:
+                complete()
+            return
         if world == 1:
             # one device holds all T samples: segmentImage on device-resident data (f64 mean, no probability sum in memory)
-            sn.segment_into(d_bgr, seed, maps)           # asynchronous: ~65 launches enqueued in ~0.5 ms
-            pending = fp.start_orb(d_left, d_right) if do_orb else None      # ORB of this frame runs beside the network
+            sn.segment_into(d_bgr, seed, maps)
+            return
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        if n_local:
+            sn.forward_into(d_bgr, seed, prob_sum, n_samples=n_local, sample0=sample0)
         else:
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            ev[0].record()
-            if n_local:
-                sn.forward_into(d_bgr, seed, prob_sum, n_samples=n_local, sample0=sample0)
-            else:
-                prob_sum.zero_()                           # more ranks than samples: contribute nothing
-            ev[1].record()
-            pending = fp.start_orb(d_left, d_right) if do_orb else None
-            parallel.all_reduce_prob_sum(prob_sum)
-            ev[2].record()
-            sn.finalize(prob_sum, t_total=T, out=maps)
-            rank_events.append(ev)
+            prob_sum.zero_()                           # more ranks than samples: contribute nothing
+        ev[1].record()
+        pending = fp.start_orb(d_left, d_right) if do_orb else None
+        parallel.all_reduce_prob_sum(prob_sum)
+        ev[2].record()
+        sn.finalize(prob_sum, t_total=T, out=maps)
+        rank_events.append(ev)
         if do_orb:
             cls_host = maps[0].cpu().numpy()              # 360 KB D2H; waits for this frame's class map
-            if world == 1 and sn.take_overflow():         # (one pinned word) an activation left the fp16 range: the frame once more,
-                sn.segment_into(d_bgr, seed, maps)        # without f16x3 — inside the timed region like everything else
-                cls_host = maps[0].cpu().numpy()
-                stats["recomputed"] += 1
-            t0 = time.perf_counter()
             r = fp.finish(pending, cls_host)
-            if world == 1:
-                # entropy feature selection over the frame's semantic keys (Tracking.cc:934-1023): the keys are on the host, the
-                # f64 entropy map stays where the network wrote it (sivo_entropy_gate_map_dev)
-                t1 = time.perf_counter()
-                d = r["depth"]; k = r["keys"]
-                xyz = np.stack([(k["x"] - KCX) * d / KFX, (k["y"] - KCY) * d / KFY, d], 1).astype(np.float64)
-                _, _, acc = selection.entropy_gate_map_dev(k, d, xyz, maps[2], STATE_COV, KFX, KFY, KBL, fp.ex_l.GetScaleSigmaSquares(), GATE_TH)
-                stats["gate_s"] += time.perf_counter() - t1; stats["gate_n"] += 1
-                stats["selected"] = int(acc.sum())
-            if tail_probe is not None:
-                tail_probe.append(time.perf_counter() - t0)
             stats["kps"], stats["matches"] = r["semantic_keys"], r["stereo_matches"]
             stats["last"] = r
 
@@ -527,7 +569,17 @@ def main():
     # issue the forward in one lane so that a launch has the GPU to itself); SIVO_BENCH_NO_EVENTS=1: none at all.
     PROFILE_EVERY = 8
     events = os.environ.get("SIVO_BENCH_NO_EVENTS") != "1"
-    elapsed, prof_timed, prof, n_detail = time_segnet(sn, frame, args.steps, args.warmup, barrier, PROFILE_EVERY, events)
+    elapsed, prof_timed, prof, n_detail = time_segnet(sn, frame, args.steps, args.warmup, barrier, PROFILE_EVERY, events, flush)
+    serial_fps = None
+    if pipelined:              # the same loop with one frame in flight, for the record
+        slots = 1
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            frame(4000 + i)
+        flush()
+        barrier()
+        serial_fps = args.steps / (time.perf_counter() - t0)
     multi = None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -581,6 +633,11 @@ def main():
                               "bf16x6 / fp32 MFMA kernels, SIVO_D3=0 the fp32 fused Winograd kernels); MC mean / confidence / entropy in f64"),
                "config": {"workload": f"full per-frame path: ORB 2000x8 stereo + SegNet-{args.net} T={T} MC-dropout + entropy maps + semantic key filter + stereo match, {H}x{W}, synthetic stereo pair, seeded random weights",
                           "T": T, "samples_per_rank": [parallel.shard_samples(T, world, r)[1] for r in range(world)],
+                          "frames_in_flight": 2 if pipelined else 1,
+                          "pipeline": ("a frame's host tail (semantic filter, median cull, entropy gate) runs while the NEXT frame's device work is already enqueued; "
+                                       "every frame's results are those of the serial loop (tests/test_gpu_frame_e2e.py), latency + 1 frame; serial_fps = the same loop with one frame in flight")
+                                      if pipelined else None,
+                          "serial_fps": round(serial_fps, 4) if serial_fps else None,
                           "orb": bool(do_orb), "semantic_keys": stats["kps"], "stereo_matches": stats["matches"],
                           "entropy_gate": ({"in_timed_frame": True, "keys_selected": stats["selected"], "threshold_bits": GATE_TH,
                                             "ms_per_call": round(1e3 * stats["gate_s"] / max(stats["gate_n"], 1), 4),

@@ -184,7 +184,9 @@ GateCtx &gate_ctx(size_t bytes) {
     SIVO_HIP(hipGetDevice(&dev));
     if (c.device != dev) {
         c.release();
-        SIVO_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        int lo = 0, hi = 0;          // (a dozen workgroups that a host thread waits for: ahead of whatever else the device is running)
+        SIVO_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        SIVO_HIP(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, hi));
         c.device = dev;
     }
     if (bytes > c.cap) {
