@@ -473,30 +473,53 @@ def main():
 
     rank_events = []         # N > 1: (start, forward done, all-reduce done) of every frame on this rank's stream
 
-    # N = 1: TWO frames in flight.  A frame's device work (network, ORB, matching) is enqueued; its host tail — semantic filter, median
-    # cull, entropy gate, ≈0.35 ms during which the GPU would otherwise idle — runs after the NEXT frame's device work has been
-    # enqueued.  Same per-frame results (the frames are independent: Frame::Frame needs the image only), one frame more latency;
-    # --serial restores the strict sequence and the line reports both rates.
-    pipelined = world == 1 and do_orb and not args.serial
+    # The rank that runs ORB (rank 0) keeps TWO frames in flight.  A frame's device work (network [+ all-reduce + finalize], ORB,
+    # matching) is enqueued; its host tail — semantic filter, median cull, entropy gate, ≈0.35 ms during which the GPU would otherwise
+    # idle — runs after the NEXT frame's device work has been enqueued.  Same per-frame results (the frames are independent:
+    # Frame::Frame needs the image only), one frame more latency; --serial restores the strict sequence and the N = 1 line reports
+    # both rates.  (The other ranks of an N > 1 run never wait inside the loop anyway.)
+    pipelined = do_orb and not args.serial
     slots = 2 if pipelined else 1
     maps_s = [maps] + [new_maps() for _ in range(slots - 1)]
-    cls_pin = [torch.empty((H, W), dtype=torch.uint8).pin_memory() for _ in range(slots)] if world == 1 and do_orb else None
+    cls_pin = [torch.empty((H, W), dtype=torch.uint8).pin_memory() for _ in range(slots)] if do_orb else None
     done_ev = [torch.cuda.Event() for _ in range(slots)]
     inflight = []            # [(slot, seed, pending)] issued and not completed
 
+    def network(seed, out):
+        """This rank's share of the frame's network work, enqueued on the current stream; ORB (rank 0) is started beside it."""
+        if world == 1:
+            # one device holds all T samples: segmentImage on device-resident data (f64 mean, no probability sum in memory)
+            sn.segment_into(d_bgr, seed, out)           # asynchronous: ~65 launches enqueued in ~0.5 ms
+            return fp.start_orb(d_left, d_right) if do_orb else None
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        if n_local:
+            sn.forward_into(d_bgr, seed, prob_sum, n_samples=n_local, sample0=sample0)
+        else:
+            prob_sum.zero_()                           # more ranks than samples: contribute nothing
+        ev[1].record()
+        pending = fp.start_orb(d_left, d_right) if do_orb else None
+        parallel.all_reduce_prob_sum(prob_sum)
+        ev[2].record()
+        sn.finalize(prob_sum, t_total=T, out=out)
+        rank_events.append(ev)
+        return pending
+
     def issue(seed):
         slot = (inflight[-1][0] + 1) % slots if inflight else 0
-        sn.segment_into(d_bgr, seed, maps_s[slot])        # asynchronous: ~65 launches enqueued in ~0.5 ms
+        pending = network(seed, maps_s[slot])
         cls_pin[slot].copy_(maps_s[slot][0], non_blocking=True)      # 360 KB D2H behind the frame's last kernel
         done_ev[slot].record()
-        pending = fp.start_orb(d_left, d_right)                      # ORB of this frame runs beside the network
         inflight.append((slot, seed, pending))
 
     def complete():
         slot, seed, pending = inflight.pop(0)
         done_ev[slot].synchronize()                       # this frame's maps are complete (a later frame may still be running)
-        if sn.take_overflow():         # (one pinned word) an activation left the fp16 range in a frame issued so far: drain, and every
-            torch.cuda.synchronize()   # frame still in flight once more (the first of them runs without f16x3, the scales back off)
+        if world == 1 and sn.take_overflow():
+            # (one pinned word) an activation left the fp16 range in a frame issued so far: drain, and every frame still in flight
+            # once more (the first of them runs without f16x3, the scales back off).  [N > 1: a rank cannot redo a collective on its
+            # own; sivo_segnet_create_multi is the multi-device form that recomputes, DESIGN 4]
+            torch.cuda.synchronize()
             for sl, sd, _ in [(slot, seed, None)] + inflight:
                 sn.segment_into(d_bgr, sd, maps_s[sl])
                 cls_pin[sl].copy_(maps_s[sl][0], non_blocking=True)
@@ -524,32 +547,12 @@ def main():
             complete()
 
     def frame(seed):
-        if world == 1 and do_orb:
+        if do_orb:
             issue(seed)
             if len(inflight) >= slots:
                 complete()
-            return
-        if world == 1:
-            # one device holds all T samples: segmentImage on device-resident data (f64 mean, no probability sum in memory)
-            sn.segment_into(d_bgr, seed, maps)
-            return
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        ev[0].record()
-        if n_local:
-            sn.forward_into(d_bgr, seed, prob_sum, n_samples=n_local, sample0=sample0)
         else:
-            prob_sum.zero_()                           # more ranks than samples: contribute nothing
-        ev[1].record()
-        pending = fp.start_orb(d_left, d_right) if do_orb else None
-        parallel.all_reduce_prob_sum(prob_sum)
-        ev[2].record()
-        sn.finalize(prob_sum, t_total=T, out=maps)
-        rank_events.append(ev)
-        if do_orb:
-            cls_host = maps[0].cpu().numpy()              # 360 KB D2H; waits for this frame's class map
-            r = fp.finish(pending, cls_host)
-            stats["kps"], stats["matches"] = r["semantic_keys"], r["stereo_matches"]
-            stats["last"] = r
+            network(seed, maps)                          # (no host work depends on the result: nothing to wait for inside the loop)
 
     def barrier():
         torch.cuda.synchronize()
@@ -571,7 +574,7 @@ def main():
     events = os.environ.get("SIVO_BENCH_NO_EVENTS") != "1"
     elapsed, prof_timed, prof, n_detail = time_segnet(sn, frame, args.steps, args.warmup, barrier, PROFILE_EVERY, events, flush)
     serial_fps = None
-    if pipelined:              # the same loop with one frame in flight, for the record
+    if pipelined and world == 1:              # the same loop with one frame in flight, for the record
         slots = 1
         barrier()
         t0 = time.perf_counter()
@@ -642,7 +645,7 @@ def main():
                           "entropy_gate": ({"in_timed_frame": True, "keys_selected": stats["selected"], "threshold_bits": GATE_TH,
                                             "ms_per_call": round(1e3 * stats["gate_s"] / max(stats["gate_n"], 1), 4),
                                             "parity": "tests/test_gpu_match_ba.py::test_entropy_gate_matches_oracle, tests/test_pin_helpers.py (the reference's sivo_helpers chain)"}
-                                           if do_orb and world == 1 else None),
+                                           if do_orb else None),
                           "algorithmic_gflop_per_frame": round((sn.flops_shared + T * sn.flops_per_sample) / 1e9, 2),
                           "reference_equivalent_gflop_per_frame": round(T * (sn.flops_shared + sn.flops_per_sample) / 1e9, 2),
                           "gemm": dict(zip(("mode", "fp16_overflow_frames"), sn.gemm_status()[:2]), frames_recomputed=stats["recomputed"]),

@@ -79,6 +79,7 @@ struct Wino4Args {
 #ifdef SIVO_DIAG
     uint32_t *diag;             // diagnostic build: diag_words()
     int diag_coherent;          // diagnostic build: the bridge reads M with agent-scope loads (past the CU's vector L1)
+    int diag_nt;                // diagnostic build: bit 0 the bridge reads M with non-temporal loads, bit 1 writes V' with non-temporal stores
 #endif
 };
 
@@ -645,6 +646,7 @@ __global__ __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *
             for (int i = 0; i < 6; ++i) {
 #ifdef SIVO_DIAG
                 if (a.diag_coherent) m[i] = __hip_atomic_load(src + (int64_t)(i * 6 + j) * xs_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (a.diag_nt & 1) m[i] = __builtin_nontemporal_load(src + (int64_t)(i * 6 + j) * xs_m);
                 else
 #endif
                     m[i] = src[(int64_t)(i * 6 + j) * xs_m];
@@ -744,6 +746,13 @@ __global__ __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *
                 for (int j = 0; j < 6; ++j) vmax = fmaxf(vmax, fabsf(row[j]));
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
+#ifdef SIVO_DIAG
+                if (a.diag_nt & 2) {
+                    if (PACK) __builtin_nontemporal_store(wino4_pack_h3(row[j], next_vscale, bad), reinterpret_cast<uint32_t *>(dst) + (int64_t)(i * 6 + j) * xs_v);
+                    else __builtin_nontemporal_store(row[j], dst + (int64_t)(i * 6 + j) * xs_v);
+                    continue;
+                }
+#endif
                 if (PACK) reinterpret_cast<uint32_t *>(dst)[(int64_t)(i * 6 + j) * xs_v] = wino4_pack_h3(row[j], next_vscale, bad);
                 else dst[(int64_t)(i * 6 + j) * xs_v] = row[j];
             }
@@ -904,6 +913,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
 #ifdef SIVO_DIAG
     a.diag = std::getenv("SIVO_BRIDGE_CHECK") ? diag_words() : nullptr;
     a.diag_coherent = std::getenv("SIVO_BRIDGE_M_COHERENT") != nullptr;
+    a.diag_nt = std::getenv("SIVO_BRIDGE_NT") ? std::atoi(std::getenv("SIVO_BRIDGE_NT")) : 0;
 #endif
     const bool h3 = c.wt_h3 && c.h3_vscale > 0.f;
     a.vscale = h3 ? c.h3_vscale : 0.f;

@@ -17,6 +17,9 @@ T, H, W = 12, 352, 1024
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 text = netspec.standard_prototxt(T, H, W)
 layers = netspec.parse_layers(text)
+if os.environ.get("LT_DIAG"):          # the diagnostic build (A/B switches): LT_DIAG=1 SIVO_...=x python tools/layer_times.py
+    from sivo_amd import _lib
+    _lib.use("diag").__enter__()
 sn = BayesianSegNet(prototxt=text, weights=wts.pack(layers, wts.synth_weights(layers, 42)), T=T)
 rng = np.random.default_rng(0)
 img = torch.from_numpy(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).cuda()
