@@ -541,6 +541,10 @@ def main():
             tail_probe.append(time.perf_counter() - t0)
         stats["kps"], stats["matches"] = r["semantic_keys"], r["stereo_matches"]
         stats["last"] = r
+        if keep is not None:            # (the self-check below: a frame's maps, keys, matches and selection by seed)
+            keep[seed] = (maps_s[slot][0].clone(), maps_s[slot][1].clone(), maps_s[slot][2].clone(), r["keys"].copy(), r["right"].copy(), r["depth"].copy(), acc.copy())
+
+    keep = None
 
     def flush():
         while inflight:
@@ -573,6 +577,21 @@ def main():
     PROFILE_EVERY = 8
     events = os.environ.get("SIVO_BENCH_NO_EVENTS") != "1"
     elapsed, prof_timed, prof, n_detail = time_segnet(sn, frame, args.steps, args.warmup, barrier, PROFILE_EVERY, events, flush)
+    pipeline_check = None
+    if pipelined and world == 1:
+        # self-check of the two-frames-in-flight loop: the frame with seed 777 between two others, against the same frame alone
+        keep = {}
+        for sd in (776, 777, 778):
+            frame(sd)
+        flush()
+        two = keep[777]
+        keep = {}
+        slots = 1
+        frame(777); flush()
+        one = keep[777]
+        slots = 2
+        keep = None
+        pipeline_check = bool(all(torch.equal(x, y) if torch.is_tensor(x) else np.array_equal(x, y) for x, y in zip(two, one)))
     serial_fps = None
     if pipelined and world == 1:              # the same loop with one frame in flight, for the record
         slots = 1
@@ -641,6 +660,7 @@ def main():
                                        "every frame's results are those of the serial loop (tests/test_gpu_frame_e2e.py), latency + 1 frame; serial_fps = the same loop with one frame in flight")
                                       if pipelined else None,
                           "serial_fps": round(serial_fps, 4) if serial_fps else None,
+                          "pipelined_frame_equals_serial_frame": pipeline_check,      # maps (u8 / f64 / f64), keys, mvuRight, mvDepth, selection: bit for bit
                           "orb": bool(do_orb), "semantic_keys": stats["kps"], "stereo_matches": stats["matches"],
                           "entropy_gate": ({"in_timed_frame": True, "keys_selected": stats["selected"], "threshold_bits": GATE_TH,
                                             "ms_per_call": round(1e3 * stats["gate_s"] / max(stats["gate_n"], 1), 4),

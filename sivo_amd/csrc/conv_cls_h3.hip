@@ -53,20 +53,30 @@ constexpr int C_OST = 352;                                 // pieces per (plane,
 constexpr int C_STAGE = 8 * C_OST * 16;                    // 45,056 bytes: [plane 2][octet 4][352] pieces
 constexpr int C_NDMA = 8 * C_OST / 64;                     // 44 DMA instructions per stage, 11 per wave
 constexpr int C_WKS = 9 * 2 * 4 * 16 * 16;                 // weight bytes per 32-channel k-step: [tap][plane][octet][cout 16][8 halfs] = 18,432
-constexpr int C_W0 = 2 * C_STAGE;
 static_assert(C_NDMA == 44 && C_NDMA % 4 == 0, "DMA pieces per wave");
-static_assert(C_W0 + 3 * C_WKS <= 160 * 1024 - 2048, "LDS (the last 2 KiB are the prefetch probes' scratch)");
+static_assert(C_STAGE + 2 * C_WKS <= 80 * 1024, "two workgroups per CU (64 input channels)");
 
-// NW = 4 (the default): one wave per SIMD, wave w owns rows 2 w, 2 w + 1 (four blocks of 16 pixels).  NW = 8 (diagnostic build,
-// SIVO_CLS_NW=8): two waves per SIMD, wave w owns row w (two blocks) — written to fill the gaps of the one-wave form (DMA issue,
-// stage barrier, a sample's Softmax) and measured SLOWER (0.54 against 0.46 ms, tools/cls_probe.py): the weight fragments are read
-// once per two blocks instead of once per four, and half the lanes idle through every sample's Softmax.
+// One wave per SIMD (NW = 4): wave w owns rows 2 w, 2 w + 1 of the tile (four blocks of 16 pixels).  (A form with two waves per
+// SIMD, one row each, was measured slower — 0.54 against 0.46 ms, round 4 — and removed: the weight fragments are read once per
+// two blocks instead of once per four, and half the lanes idle through every sample's Softmax.)
+// Pipeline (round 4, final form): ONE patch buffer and TWO workgroups per CU (45,056 + 36,864 bytes = exactly half of the CU's LDS
+// each).  A sample's last stage ends in ~4 us of Softmax + statistics per workgroup, the stages before it in ~0.2 us of MFMAs,
+// and the input is a 1.1 GB stream: with two buffers in one 160 KB workgroup per CU the kernel took the SUM of its stream (0.22 ms
+// alone, 4.9 TB/s) and its Softmax tail (0.37 ms alone) — 0.48–0.52 ms in three different issue orders, one wave per SIMD having
+// nothing to put beside either.  Two independent workgroups per CU do what the issue orders could not: one streams while the
+// other is in its Softmax, and the SIMDs have two waves to choose from: **0.36 ms**, outputs bit-identical (tools/cls_probe.py).
+// Within a workgroup the next stage is requested as soon as every wave has read the current one (one barrier), i.e. under the
+// Softmax when there is one.  The two workgroups of a CU both issue LDS-DMA next to each other's ds_read traffic — the
+// constellation of DESIGN 3.1e's co-residency finding; this pair was checked bit-identical against the one-workgroup form and
+// by the full-size network tests, and bench.py compares every run's pipelined frames with the serial loop.
 // ABL (diagnostic builds only, -DSIVO_DIAG; results are wrong by construction): 1 no MFMAs, 2 no Softmax / sum at the end of a sample,
 // 4 no patch DMA after the first stage, 8 no fragment reads after the first tap.
 template <int NW, int ABL = 0>
-__global__ __launch_bounds__(NW * 64) void conv_cls_h3_kernel(ClsMcArgs a) {
+__global__ __launch_bounds__(NW * 64, 2) void conv_cls_h3_kernel(ClsMcArgs a) {
+    constexpr int W0 = C_STAGE;                 // the filter bank behind the patch buffer
     constexpr int NB = 16 / NW;                 // 16-pixel blocks per wave: block b = (row b / 2 of the wave's rows, half b % 2)
-    constexpr int NDW = (C_NDMA + NW - 1) / NW; // DMA pieces per wave and stage
+    static_assert(NW == 4 && C_NDMA % NW == 0, "every wave issues the same number of DMA instructions per stage (the vmcnt accounting)");
+    constexpr int NDW = C_NDMA / NW;            // DMA pieces per wave and stage
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_c[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,7 +95,7 @@ __global__ __launch_bounds__(NW * 64) void conv_cls_h3_kernel(ClsMcArgs a) {
     // ---- the filter bank: nks x 18 pieces of 1 KiB, wave w copies pieces w, w + 4, ...
     {
         const unsigned char *wsrc = static_cast<const unsigned char *>(a.wt_h3);
-        for (int pc = wave; pc < 18 * nks; pc += NW) lds_dma16_s(wsrc, (uint32_t)(pc * 1024 + lane * 16), lds_base + C_W0 + pc * 1024);
+        for (int pc = wave; pc < 18 * nks; pc += NW) lds_dma16_s(wsrc, (uint32_t)(pc * 1024 + lane * 16), lds_base + W0 + pc * 1024);
     }
     // ---- patch DMA plan: instruction j = wave + 4 i (i = 0 .. 10) fills pieces 64 j .. 64 j + 63 of the stage image
     // [plane][octet][352]: piece q = (plane * 4 + octet) * 352 + r, r < 340: patch pixel (r / 34, r % 34); pad pieces copy a
@@ -102,41 +112,14 @@ __global__ __launch_bounds__(NW * 64) void conv_cls_h3_kernel(ClsMcArgs a) {
     }
     const int64_t ks_stride = (int64_t)8 * a.in_Hp * a.in_Wp * 16;           // 32 channels = 4 octets x 2 planes
     const unsigned char *tile_src = static_cast<const unsigned char *>(a.in_pk) + ((int64_t)y0 * a.in_Wp + x0) * 16;
-    auto issue_stage = [&](int s, int ks, int buf) __attribute__((always_inline)) {
+    auto issue_stage = [&](int s, int ks) __attribute__((always_inline)) {
         const unsigned char *sb = tile_src + (int64_t)s * a.in_pk_sample_bytes + ks * ks_stride;
 #pragma unroll
-        for (int i = 0; i < NDW; ++i)
-            if ((i + 1) * NW <= C_NDMA || wave + NW * i < C_NDMA) lds_dma16_s(sb, voff[i], lds_base + buf * C_STAGE + (wave + NW * i) * 1024);
-    };
-
-    // ---- L2 prefetch of the stage AFTER the one whose DMA is in flight.  With two patch buffers only one stage (44 KB per CU) can
-    // be on its way into LDS, and a stage's DMA is issued when its buffer becomes free: measured 0.55 ms = 2.0 TB/s with a stage
-    // waiting ~3 us for its data.  Touching every 128-byte line of the NEXT stage's source rows (80 rows of 544 bytes: 6 probes
-    // each, two dword LDS-DMAs per wave into a scratch corner of LDS: loads without a register destination, so nothing the
-    // compiler could copy or reuse while they are in flight — a first form with register destinations corrupted the frame)
-    // brings it into this XCD's L2 a stage earlier, so the DMA that follows is an L2 hit.  The probes are issued BEHIND the
-    // stage's DMA and complete in issue order, so the wait at the top of the next iteration is vmcnt(2): everything but the two
-    // probes.
-    uint32_t pf_off[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int i = NW == 4 ? tid + 256 * k : (tid & 255) + 256 * k, row = i / 6 < 80 ? i / 6 : 79, seg = i - (i / 6) * 6;
-        const int po = row / C_PR, py = row - po * C_PR;                  // po = plane * 4 + octet as in the stage image
-        const int byte = seg * 128 < 540 ? seg * 128 : 540;
-        pf_off[k] = (uint32_t)((((po & 3) * 2 + (po >> 2)) * a.in_Hp + py) * a.in_Wp * 16 + byte);
-    }
-    const uint32_t pf_lds = lds_base + (uint32_t)(160 * 1024 - 2048) + (uint32_t)(wave & 3) * 512;       // 2 x 256 bytes of scratch per probing wave
-    constexpr int NPROBE = 2;                   // probes per probing wave (waves 0 .. 3) and stage
-    auto prefetch_stage = [&](int s, int ks) __attribute__((always_inline)) {
-        const unsigned char *sb = tile_src + (int64_t)s * a.in_pk_sample_bytes + ks * ks_stride;
-        if (wave < 4) {
-            lds_dma4_s(sb, pf_off[0], pf_lds);
-            lds_dma4_s(sb, pf_off[1], pf_lds + 256);
-        }
+        for (int i = 0; i < NDW; ++i) lds_dma16_s(sb, voff[i], lds_base + (wave + NW * i) * 1024);
     };
 
     // ---- MFMA operands: A = weights [cout = lane & 15][octet = lane >> 4], B = patch [octet = lane >> 4][pixel = lane & 15]
-    const uint32_t a_off = (uint32_t)(C_W0 + lane * 16);
+    const uint32_t a_off = (uint32_t)(W0 + lane * 16);
     // block b = 2 rr + h of wave w: row (NB / 2) w + rr, columns 16 h .. 16 h + 15
     const uint32_t b_off = (uint32_t)((lg * C_OST + ((NB / 2) * wave) * C_PW + lp) * 16);
     f32x4 acc[4];
@@ -146,35 +129,22 @@ __global__ __launch_bounds__(NW * 64) void conv_cls_h3_kernel(ClsMcArgs a) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) sum[c] = 0.0;
 
-    // the pixel this lane post-processes: pixel lp of block lg of its wave (NW = 8: blocks 0, 1 exist — the lanes of rows 2, 3 idle)
+    // the pixel this lane post-processes: pixel lp of block lg of its wave
     const int prow = (NB / 2) * wave + (lg >> 1), pcol = 16 * (lg & 1) + lp;
     const int gy = y0 + prow, gx = x0 + pcol;
     const bool pix_ok = lg < NB && gy < a.H && gx < a.W;
     const int64_t pix = (int64_t)gy * a.W + gx;
     const float mscale = 1.f / (a.h3_vscale * a.h3_uscale);
 
-    issue_stage(0, 0, 0);
+    issue_stage(0, 0);
     const int total = a.T * nks;
     int s = 0, ks = 0;
-    bool probes_behind = false;         // the newest two vector-memory operations of this wave are prefetch probes
-    if (1 < total) { prefetch_stage(nks > 1 ? 0 : 1, nks > 1 ? 1 : 0); probes_behind = true; }
     for (int g = 0; g < total; ++g) {
-        // this wave's DMA of stage g (and, g = 0, of the filter bank) has landed; behind the barrier everybody's has, and nobody
-        // reads the other buffer (stage g - 1) any more.  (a.logits: the diagnostic stores of a sample's epilogue sit behind the
-        // probes in the queue — wait for everything then)
-        if (probes_behind && !a.logits && wave < 4) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(NPROBE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        probes_behind = false;
+        // this wave's DMA of stage g (and, g = 0, of the filter bank) has landed; behind the barrier everybody's has
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         int s2 = s, k2 = ks + 1;
         if (k2 == nks) { k2 = 0; ++s2; }
-        int s3 = s2, k3 = k2 + 1;
-        if (k3 == nks) { k3 = 0; ++s3; }
-        if (g + 1 < total && !(ABL & 4)) issue_stage(s2, k2, (g + 1) & 1);
-        if (g + 2 < total && !(ABL & 4)) {
-            prefetch_stage(s3, k3);
-            probes_behind = true;
-        }
-        const unsigned char *ps = lds_c + (g & 1) * C_STAGE + b_off, *ws = lds_c + a_off + ks * C_WKS;
+        const unsigned char *ps = lds_c + b_off, *ws = lds_c + a_off + ks * C_WKS;
         // fragments one tap ahead: [10 ds_read_b128 of tap t + 1][12 MFMAs of tap t].  With ONE wave per SIMD nothing else covers an
         // LDS round trip: left alone, hipcc placed every read right in front of its first use (35 lgkmcnt waits per stage in the
         // .s) and a stage took ~8 k cycles for ~1.8 k cycles of MFMAs.
@@ -209,6 +179,12 @@ __global__ __launch_bounds__(NW * 64) void conv_cls_h3_kernel(ClsMcArgs a) {
                 }
             }
         }
+        if (g + 1 < total && !(ABL & 4)) {
+            // the next stage goes into the buffer as soon as every wave has read this one — under this sample's Softmax when there
+            // is one; the other workgroup of the CU covers the rest
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            issue_stage(s2, k2);
+        }
         if (ks == nks - 1 && !(ABL & 2)) {
             // ---- end of sample s: acc[b][j] = class 4 lg + j at pixel lp of block b.  4 x 4 transpose over the four 16-lane rows
             // (register index b <-> row lg), per j: afterwards w[c] = class 4 c + j at pixel lp of block lg.
@@ -234,7 +210,6 @@ __global__ __launch_bounds__(NW * 64) void conv_cls_h3_kernel(ClsMcArgs a) {
         }
         s = s2; ks = k2;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the last probes: no LDS-DMA may be in flight when the workgroup ends)
     if (!pix_ok) return;
 #include "conv_cls_mc_maps.inc"
 }
@@ -295,26 +270,22 @@ void launch_conv_cls_h3(const ClsMcArgs &a0, hipStream_t s) {
     if (a.sum_chunk <= 0 || a.sum_chunk > (int64_t)a.H * a.W) a.sum_chunk = (int64_t)a.H * a.W;
     static int attr_set[64] = {0};
     if (FirstUse once(attr_set); once) {
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_cls_h3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_cls_h3_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_cls_h3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, C_STAGE + 3 * C_WKS));
     }
     const int P = a.tiles_x * a.tiles_y, per = (P + 7) / 8;
+    const size_t lds = (size_t)C_STAGE + (size_t)(a.Cin / 32) * C_WKS;       // 80 KB at 64 input channels: two workgroups per CU (98 KB at 96: one)
 #ifdef SIVO_DIAG
     if (const char *ab = SIVO_DIAG_ENV("SIVO_CLS_ABL")) {                                     // diagnostic build: ablations of the default form
 #define CLS_ABL_CASE(n)                                                                                                                             \
     case n:                                                                                                                                         \
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_cls_h3_kernel<4, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        hipLaunchKernelGGL((conv_cls_h3_kernel<4, n>), dim3((unsigned)(8 * per)), dim3(256), (size_t)160 * 1024, s, a);                            \
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_cls_h3_kernel<4, n>), hipFuncAttributeMaxDynamicSharedMemorySize, C_STAGE + 3 * C_WKS)); \
+        hipLaunchKernelGGL((conv_cls_h3_kernel<4, n>), dim3((unsigned)(8 * per)), dim3(256), lds, s, a);                            \
         return;
         switch (std::atoi(ab)) { CLS_ABL_CASE(1) CLS_ABL_CASE(2) CLS_ABL_CASE(3) CLS_ABL_CASE(4) CLS_ABL_CASE(6) CLS_ABL_CASE(8) CLS_ABL_CASE(9) CLS_ABL_CASE(11) CLS_ABL_CASE(15) default: break; }
 #undef CLS_ABL_CASE
     }
-    if (SIVO_DIAG_ENV("SIVO_CLS_NW") && std::atoi(SIVO_DIAG_ENV("SIVO_CLS_NW")) == 8) {        // diagnostic build: the two-waves-per-SIMD form
-        hipLaunchKernelGGL((conv_cls_h3_kernel<8>), dim3((unsigned)(8 * per)), dim3(512), (size_t)160 * 1024, s, a);
-        return;
-    }
 #endif
-    hipLaunchKernelGGL((conv_cls_h3_kernel<4>), dim3((unsigned)(8 * per)), dim3(256), (size_t)160 * 1024, s, a);
+    hipLaunchKernelGGL((conv_cls_h3_kernel<4>), dim3((unsigned)(8 * per)), dim3(256), lds, s, a);
 }
 
 }  // namespace sivo

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the time of the f16x3 classifier + MC kernel goes (conv_cls_h3.hip): the production form, the one-wave-per-SIMD form and the
+"""Where the time of the f16x3 classifier + MC kernel goes (conv_cls_h3.hip): the production form and the
 compile-time ablations of libsivo_hip_diag.so (SIVO_CLS_ABL bits: 1 no MFMAs, 2 no Softmax / sum, 4 no patch DMA after the first stage,
 8 no fragment reads after the first tap) at the network's shape (T = 12, 64 -> 15, 352 x 1024).  GPU box only."""
 import ctypes as C
@@ -23,10 +23,10 @@ logits = torch.empty((T, K, H, W), device="cuda")
 cls = torch.empty((H, W), dtype=torch.uint8, device="cuda")
 conf = torch.empty((H, W), dtype=torch.float64, device="cuda")
 ent = torch.empty((H, W), dtype=torch.float64, device="cuda")
-for name, env in [("as built (4 waves)", {}), ("8 waves", {"SIVO_CLS_NW": "8"}), ("no MFMA", {"SIVO_CLS_ABL": "1"}), ("no softmax", {"SIVO_CLS_ABL": "2"}),
+for name, env in [("as built", {}), ("no MFMA", {"SIVO_CLS_ABL": "1"}), ("no softmax", {"SIVO_CLS_ABL": "2"}),
                   ("no patch DMA", {"SIVO_CLS_ABL": "4"}), ("no fragment reads", {"SIVO_CLS_ABL": "8"}), ("no MFMA, no reads", {"SIVO_CLS_ABL": "9"}),
                   ("DMA + barriers only", {"SIVO_CLS_ABL": "11"}), ("barriers only", {"SIVO_CLS_ABL": "15"}), ("MFMA + reads only", {"SIVO_CLS_ABL": "6"})]:
-    for k in ("SIVO_CLS_NW", "SIVO_CLS_ABL"):
+    for k in ("SIVO_CLS_ABL",):
         os.environ.pop(k, None)
     os.environ.update(env)
     ms = d(0)
