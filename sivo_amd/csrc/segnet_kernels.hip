@@ -329,7 +329,53 @@ __global__ void maxpool2_kernel(PoolArgs a) {
     }
     a.out[i] = best;
 }
+// The same for FOUR adjacent windows of a row per thread (W % 8 == 0, H even: every geometry of the reference nets at KITTI size):
+// two 16-byte loads per input row, one 16-byte store, four codes in one dword, the four dropout bits from one Philox word
+// (consecutive elements e .. e + 3 with e % 4 == 0 share it).  Window scan order and the strict '>' are those of the scalar kernel.
+__global__ __launch_bounds__(256) void maxpool2x4_kernel(PoolArgs a) {
+    const int Wq = a.Wo >> 2;
+    const int64_t total = (int64_t)a.N * a.C * a.Ho * Wq;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int pq = (int)(i % Wq);
+    int64_t t = i / Wq;
+    const int ph = (int)(t % a.Ho); t /= a.Ho;
+    const int c = (int)(t % a.C);
+    const int n = (int)(t / a.C);
+    const float *ip = a.in + (int64_t)n * a.in_sample_stride + ((int64_t)c * a.H + 2 * ph) * a.W + 8 * pq;
+    const float4 r0a = *reinterpret_cast<const float4 *>(ip), r0b = *reinterpret_cast<const float4 *>(ip + 4);
+    const float4 r1a = *reinterpret_cast<const float4 *>(ip + a.W), r1b = *reinterpret_cast<const float4 *>(ip + a.W + 4);
+    const float top[8] = {r0a.x, r0a.y, r0a.z, r0a.w, r0b.x, r0b.y, r0b.z, r0b.w};
+    const float bot[8] = {r1a.x, r1a.y, r1a.z, r1a.w, r1b.x, r1b.y, r1b.z, r1b.w};
+    float best[4];
+    uint32_t codes = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float b = -3.402823466e+38f;
+        int code = 0;
+        if (top[2 * k] > b) { b = top[2 * k]; code = 0; }
+        if (top[2 * k + 1] > b) { b = top[2 * k + 1]; code = 1; }
+        if (bot[2 * k] > b) { b = bot[2 * k]; code = 2; }
+        if (bot[2 * k + 1] > b) { b = bot[2 * k + 1]; code = 3; }
+        best[k] = b;
+        codes |= (uint32_t)code << (8 * k);
+    }
+    const int64_t chw = (int64_t)a.C * a.Ho * a.Wo;
+    const int64_t e = ((int64_t)c * a.Ho + ph) * a.Wo + 4 * pq;          // element index inside the sample
+    if (n < a.mask_N) *reinterpret_cast<uint32_t *>(a.mask + (int64_t)n * chw + e) = codes;
+    if (a.drop_site >= 0) {
+        const uint32_t w = dropout_word((uint32_t)e, (uint32_t)a.drop_site, (uint32_t)(a.sample0 + n), a.seed) >> (e & 31);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) best[k] = ((w >> k) & 1u) ? best[k] * 2.f : 0.f;
+    }
+    *reinterpret_cast<float4 *>(a.out + (int64_t)n * chw + e) = make_float4(best[0], best[1], best[2], best[3]);
+}
 void launch_maxpool2(const PoolArgs &a, hipStream_t s) {
+    if (a.W % 8 == 0 && a.H % 2 == 0 && a.Wo * 2 == a.W && a.Ho * 2 == a.H && a.in_sample_stride % 4 == 0) {
+        const int64_t total = (int64_t)a.N * a.C * a.Ho * (a.Wo >> 2);
+        hipLaunchKernelGGL(maxpool2x4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+        return;
+    }
     const int64_t total = (int64_t)a.N * a.C * a.Ho * a.Wo;
     hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
 }
