@@ -26,6 +26,8 @@
 // P = tiles of the sample group (n * ceil(H/4) * W/4), Pp / Kp padded to multiples of 128.
 #include <hip/hip_runtime.h>
 #include <map>
+#include <cstdio>
+#include <unistd.h>
 #include <stdint.h>
 
 #include <cstdlib>
@@ -867,6 +869,7 @@ size_t wino4_workspace_floats(int group, int cin, int cout, int H, int W) {
 }
 
 #ifdef SIVO_DIAG
+void launch_occupy(int lds_bytes, int mode, int microseconds, const uint32_t *src, uint32_t *sink, hipStream_t s);      // diag_kernels.hip
 // diagnostic build, SIVO_W4_VERIFY=1: a layer's GEMM and bridge are run a second time into scratch buffers, under the same
 // concurrent conditions, and compared word for word: diag word [4] counts M words that differ, [5] V' words, [6] layers compared
 __global__ void diag_compare_kernel(const uint32_t *x, const uint32_t *y, int64_t n, uint32_t *count, int Pp, int P, uint32_t *rec) {
@@ -1005,12 +1008,29 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
                                (int64_t)36 * a.Kp * a.Pp, diag_words() + 4, (int)a.Pp, (int)a.Pp, (uint32_t *)nullptr);
             const int ntile = a.th * a.tw, nthr = ntile >= 1024 ? 1024 : (ntile + 63) / 64 * 64;
             const size_t lb = SIVO_DIAG_ENV("SIVO_BRIDGE_LDS_ALL") ? (size_t)160 * 1024 : wino4_bridge_lds_bytes(a.H, a.W);
+            if (const char *occ = SIVO_DIAG_ENV("SIVO_W4_VERIFY_OCC")) {
+                // "mode,bytes": the second run of the bridge happens BESIDE a synthetic neighbour — the occupant kernel of diag_kernels.hip,
+                // one workgroup on every CU for 3 ms holding `bytes` of LDS (mode 0 idle, 1 ds traffic, 2 LDS-DMA traffic) — and nothing else
+                static hipStream_t occ_stream = nullptr;
+                static uint32_t *occ_src = nullptr;
+                if (!occ_stream) {
+                    SIVO_HIP(hipStreamCreateWithFlags(&occ_stream, hipStreamNonBlocking));
+                    SIVO_HIP(hipMalloc((void **)&occ_src, (size_t)(1 << 20) + 4096));
+                    SIVO_HIP(hipMemset(occ_src, 0x5a, (size_t)(1 << 20) + 4096));
+                }
+                int mode = 0, bytes = 131072;
+                std::sscanf(occ, "%d,%d", &mode, &bytes);
+                SIVO_HIP(hipDeviceSynchronize());
+                launch_occupy(bytes, mode, 3000, occ_src, occ_src, occ_stream);
+                usleep(400);                                   // the occupant is resident on every CU by now, and stays for 3 ms
+            }
             if (plan->next_vscale > 0.f) hipLaunchKernelGGL(wino4_bridge_kernel<true>, dim3((unsigned)a.n, (unsigned)a.K), dim3(nthr), lb, s, a, v2, plan->next_vscale, plan->next_vmax);
             else hipLaunchKernelGGL(wino4_bridge_kernel<false>, dim3((unsigned)a.n, (unsigned)a.K), dim3(nthr), lb, s, a, v2, 0.f, plan->next_vmax);
             // (the padding columns P .. Pp of V' are written by nobody: compare sample by sample, the tiles that exist)
             hipLaunchKernelGGL(diag_compare_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(plan->Vnext), reinterpret_cast<const uint32_t *>(v2),
                                (int64_t)36 * a.K * a.Pp, diag_words() + 5, (int)a.Pp, (int)a.P, diag_words() + 20);
             ++diag_words()[6];
+            if (SIVO_DIAG_ENV("SIVO_W4_VERIFY_OCC")) SIVO_HIP(hipDeviceSynchronize());
             if (diag_words()[20] && !diag_words()[19]) {        // geometry of the first layer that showed a difference (host side, after the fact: approximate)
                 diag_words()[16] = (uint32_t)a.K; diag_words()[17] = (uint32_t)a.Pp; diag_words()[18] = (uint32_t)(a.th * a.tw); diag_words()[19] = (uint32_t)a.tw;
             }

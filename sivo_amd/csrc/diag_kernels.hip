@@ -1,5 +1,5 @@
 // diag_kernels.hip — diagnostic build only (libsivo_hip_diag.so; empty in the product): a kernel that does nothing but hold a chosen
-// amount of the LDS of half the CUs (128 workgroups: the kernels under test must still find room) for a chosen time, optionally with LDS traffic of its own, so that other kernels' workgroups are placed
+// amount of every CU's LDS for a chosen time, optionally with LDS traffic of its own, so that other kernels' workgroups are placed
 // BESIDE it — at LDS bases they never see when the CU is theirs (tools/coresident_probe.py occupant).
 #ifdef SIVO_DIAG
 #include <hip/hip_runtime.h>
@@ -46,7 +46,7 @@ void launch_occupy(int lds_bytes, int mode, int microseconds, const uint32_t *sr
     static int attr_set[64] = {0};
     if (FirstUse once(attr_set); once)
         SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(occupy_kernel, dim3(128), dim3(512), (size_t)lds_bytes, s, lds_bytes, mode, (long long)microseconds * 100, src, sink);   // s_memrealtime: 100 MHz
+    hipLaunchKernelGGL(occupy_kernel, dim3(256), dim3(512), (size_t)lds_bytes, s, lds_bytes, mode, (long long)microseconds * 100, src, sink);   // s_memrealtime: 100 MHz
     SIVO_HIP(hipGetLastError());
 }
 

@@ -21,6 +21,9 @@ VARIANTS = [
     ("exact LDS, bridge claims 160K", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_LDS_ALL": "1", "SIVO_BRIDGE_CHECK": "1"}),
     ("exact LDS, packed chain off", {"SIVO_H3_LDS_ALL": "0", "SIVO_D3_PK": "0", "SIVO_BRIDGE_CHECK": "1"}),
     ("exact LDS, x6 GEMM", {"SIVO_H3_LDS_ALL": "0", "SIVO_GEMM": "x6"}),
+    ("one lane, claim-160K GEMM; the bridge's second run beside an IDLE occupant holding 128K of every CU", {"DBG_LANES_A": "1", "SIVO_W4_VERIFY": "1", "SIVO_W4_VERIFY_OCC": "0,131072"}),
+    ("one lane, claim-160K GEMM; the bridge's second run beside an occupant with ds traffic", {"DBG_LANES_A": "1", "SIVO_W4_VERIFY": "1", "SIVO_W4_VERIFY_OCC": "1,131072"}),
+    ("one lane, claim-160K GEMM; the bridge's second run beside an occupant with LDS-DMA traffic", {"DBG_LANES_A": "1", "SIVO_W4_VERIFY": "1", "SIVO_W4_VERIFY_OCC": "2,131072"}),
     ("occupant idle 128K beside a ONE-lane handle (bridge workgroups at LDS bases >= 128K, nobody else using LDS)", {"DBG_LANES_A": "1", "SIVO_H3_LDS_ALL": "0", "PROBE_OCCUPY": "131072,0"}),
     ("occupant with ds traffic 128K beside a one-lane handle", {"DBG_LANES_A": "1", "SIVO_H3_LDS_ALL": "0", "PROBE_OCCUPY": "131072,1"}),
     ("occupant with LDS-DMA traffic 128K beside a one-lane handle", {"DBG_LANES_A": "1", "SIVO_H3_LDS_ALL": "0", "PROBE_OCCUPY": "131072,2"}),

@@ -2,7 +2,9 @@
 # Round profile on the GPU box: bench line, rocprofv3 kernel statistics of every configuration of the line (main run plain and
 # SIVO_LANES=1 — the one whose average launch duration must agree with the HIP events of `roofline` —, SegNet-Basic T = 6,
 # Standard T = 48, local BA), PMC passes (HBM traffic / matrix-core busy; one counter group per pass, no trace domains) for the
-# main run, Basic and T = 48, optionally the GPU test suite.   Usage: bash tools/profile_round.sh <tag> [tests|onlytests]
+# main run, Basic and T = 48, optionally the GPU test suite.  Every profiler pass runs under `timeout` and with --serial: round 4's
+# last session lost 36 GPU-minutes to the one-lane `--kernel-trace` pass hanging with two frames in flight (the three-lane pass of
+# the same build completed; without rocprofv3 the one-lane bench runs, tools/gpu_session.sh).   Usage: bash tools/profile_round.sh <tag> [tests|onlytests]
 #   -> gpurun_out/<tag>_*  (copy what is to be judged into profiles/)
 set -u
 TAG=${1:-r03_x}
@@ -18,7 +20,7 @@ pmc() {   # name, bench args
   for pass in "f FETCH_SIZE" "w WRITE_SIZE" "m SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     set -- $pass; p=$1; shift
     rm -rf /tmp/pmc_${name}_$p
-    (cd /tmp && SIVO_LANES=1 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_${name}_$p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-orb --configs none $args > /dev/null 2>&1)
+    (cd /tmp && SIVO_LANES=1 timeout 240 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_${name}_$p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-orb --configs none $args > /dev/null 2>&1)
   done
   python tools/pmc_summary.py $O/${TAG}_pmc_traffic_$name.json /tmp/pmc_${name}_f /tmp/pmc_${name}_w /tmp/pmc_${name}_m > /dev/null && python - <<PY
 import json
@@ -42,7 +44,7 @@ PY
 stats() {   # name, bench args (quoted string), env...
   local name=$1 args=$2; shift 2
   rm -rf /tmp/prof_$name
-  (cd /tmp && env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o $name -- python $R/bench.py --no-cpu-baseline --configs none $args > $O/${TAG}_bench_line_under_rocprof_$name.json 2>/dev/null)
+  (cd /tmp && env "$@" timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o $name -- python $R/bench.py --serial --no-cpu-baseline --configs none $args > $O/${TAG}_bench_line_under_rocprof_$name.json 2>/dev/null)
   local f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $O/${TAG}_kernel_stats_$name.csv && head -5 $O/${TAG}_kernel_stats_$name.csv | cut -c1-150
 }
@@ -52,7 +54,7 @@ stats basic "--net basic --T 6 --steps 20 --no-orb" SIVO_LANES=1
 stats t48 "--T 48 --steps 4 --warmup 1 --no-orb" SIVO_LANES=1
 timeout 200 python tools/layer_times.py 10 > $O/${TAG}_layer_times.txt 2>&1; tail -3 $O/${TAG}_layer_times.txt
 rm -rf /tmp/prof_ba
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ba -o ba -- python $R/tests/tools/ba_bench.py > $O/${TAG}_ba_bench_under_rocprof.json 2>/dev/null)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ba -o ba -- python $R/tests/tools/ba_bench.py > $O/${TAG}_ba_bench_under_rocprof.json 2>/dev/null)
 f=$(find /tmp/prof_ba -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_kernel_stats_ba.csv && head -6 $O/${TAG}_kernel_stats_ba.csv | cut -c1-150
 timeout 300 python tests/tools/ba_bench.py > $O/${TAG}_ba_bench.json 2>/dev/null; cut -c1-400 $O/${TAG}_ba_bench.json
 if [ "$WITH_TESTS" = tests ]; then
