@@ -67,9 +67,14 @@ extern "C" {
 
 const char *sivo_last_error(void) { return "abi_on_oracle: error"; }
 
+// (test hook: how many frame views were built / are alive — tests/cpp/test_frame_cache.cpp counts what ORBmatcher.h's cache saves)
+static int g_mframes_created = 0, g_mframes_alive = 0;
+int abi_on_oracle_mframes_created(void) { return g_mframes_created; }
+int abi_on_oracle_mframes_alive(void) { return g_mframes_alive; }
 int sivo_mframe_create(const SivoKeyPoint *keys, int n, const float *u_right, const uint8_t *descriptors, float min_x, float max_x,
                        float min_y, float max_y, const float *scale_factors, const float *level_sigma2, const float *inv_level_sigma2,
                        int nlevels, int, sivo_mframe_t *out) {
+    ++g_mframes_created; ++g_mframes_alive;
     sivo_mframe *h = new sivo_mframe;
     h->keys.assign(keys, keys + n);
     if (u_right) h->right.assign(u_right, u_right + n);
@@ -84,7 +89,7 @@ int sivo_mframe_create(const SivoKeyPoint *keys, int n, const float *u_right, co
     return SIVO_OK;
 }
 int sivo_mframe_destroy(sivo_mframe_t h) {
-    if (h) { orc_frame_destroy(h->F); delete h; }
+    if (h) { orc_frame_destroy(h->F); delete h; --g_mframes_alive; }
     return SIVO_OK;
 }
 int sivo_mframe_features_in_area(sivo_mframe_t h, float x, float y, float r, int min_level, int max_level, int32_t *out, int capacity,

@@ -55,3 +55,14 @@ def test_device_path_equals_the_reference_matcher():
     """GPU: the same comparison with libsivo_hip.so behind the C ABI (prebuilt oracle/_ref/pin_matcher_gpu carries the
     reference's object code to the box; without it the golden file stands in)."""
     _run("gpu")
+
+
+def test_frame_view_cache_builds_one_view_per_frame():
+    """CPU: ORBmatcher.h keeps a frame's matcher view per Frame / KeyFrame (FrameCache): tests/cpp/test_frame_cache.cpp counts the
+    views built through the oracle-backed C ABI — one per frame however often it is searched, a new one for another id / cloned
+    descriptors / changed keys, LRU eviction beyond the capacity, views in use survive a release."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_frame_cache")
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "test_frame_cache"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "frame cache: ok" in r.stdout, r.stdout + r.stderr
