@@ -189,7 +189,26 @@ def mfma_roofline(prof_timed, prof_detail, n_timed_frames, n_detail, ms_per_fram
         if c and v["flops"] > 0:
             t_peak_ms += v["flops"] / n_detail * c[0] / (c[1] * 1e12) * 1e3
     traffic, tsrc = traffic_from_profiles(dom_name, tag)
+    # The dominant kernel is ONE of the (up to) four kernels of an F(4x4) layer and is credited with the layer's whole convolution:
+    # chain = the same FLOPs over the GEMM AND its transform kernels (input / bridge / output), conv_stack = every
+    # convolution FLOP of the frame over every convolution kernel — both against the same fp16 dense peak, from the untimed
+    # single-lane frames in which every kernel carries events (the transforms are not bracketed in the timed frames)
+    chain_ms = sum(v["ms"] for k, v in by_kernel.items() if k.startswith("wino4_"))
+    chain_fl = sum(v["flops"] for k, v in by_kernel.items() if k.startswith("wino4_gemm"))
+    stack_ms = sum(v["ms"] for k, v in by_kernel.items() if kernel_class(k) or k.startswith("wino4_"))
+    stack_fl = sum(v["flops"] for k, v in by_kernel.items() if kernel_class(k))
+    chain = chain_fl / (chain_ms * 1e-3) / 1e12 if chain_ms > 0 else None
+    stack = stack_fl / (stack_ms * 1e-3) / 1e12 if stack_ms > 0 else None
     return {"bound": "mfma", "kernel": "sivo::" + dom_name, "instruction": what,
+            "chain_tflops": round(chain, 2) if chain else None, "chain_frac": round(chain / BF16_MFMA_PEAK_TFLOPS, 4) if chain else None,
+            "chain_ms_per_frame": round(chain_ms / n_detail, 3),
+            "conv_stack_tflops": round(stack, 2) if stack else None, "conv_stack_frac": round(stack / BF16_MFMA_PEAK_TFLOPS, 4) if stack else None,
+            "conv_stack_ms_per_frame": round(stack_ms / n_detail, 3),
+            "measured_on": {"timed_frames (inside the driver-timed region)": ["achieved", "frac", "executed_tflops", "executed_frac", "avg_launch_ms", "launches_per_frame", "flops_per_launch"]
+                            if timed and frames == n_timed_frames and mfma is not None and prof_timed else [],
+                            "untimed_single_lane_frames (after the timed region, every kernel bracketed by events)":
+                                ["chain_*", "conv_stack_*", "mfma_kernels", "kernels_ms_per_frame", "segnet_kernel_ms_per_frame", "whole_frame_mfma_util (numerator)"],
+                            "committed rocprofv3 --pmc passes of the same command": ["traffic"]},
             "achieved": round(alg, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(alg / peak, 4),
             "executed_tflops": round(executed, 2), "executed_frac": round(executed / peak, 4), "executed_per_algorithmic": round(ratio, 4),
             "traffic": traffic, "traffic_source": f"{tsrc} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, mean bytes per launch)" if traffic else None,
@@ -458,12 +477,11 @@ def main():
     do_orb = (rank == 0) and not args.no_orb
     stats = {"kps": 0, "matches": 0, "recomputed": 0, "gate_s": 0.0, "gate_n": 0, "selected": 0, "last": None}
     from sivo_amd import selection
-    # KITTI-00 intrinsics / baseline; a pose covariance of the size PoseOptimization leaves (1e-4 rad^2 / m^2); config_kitti.yaml's
-    # entropy-reduction threshold is a tuning parameter — 0 bits here ("the observation tells more about the pose than the class map
-    # doubts the point")
-    KFX = KFY = 718.856; KCX, KCY, KBF = 607.1928, 185.2157, 386.1448; KBL = KBF / KFX
+    # the reference's own configuration of this sequence (config/kitti/KITTI00-02.yaml:8-11,25,38): Camera.fx / fy / cx / cy / bf and
+    # ThEntropyReduction = 4 bits; a pose covariance of the size PoseOptimization leaves (1e-4 rad^2 / m^2)
+    KFX = KFY = 718.856; KCX, KCY, KBF = 498.692, 173.215, 386.1448; KBL = KBF / KFX
     STATE_COV = np.eye(6) * 1e-4
-    GATE_TH = 0.0
+    GATE_TH = 4.0
     # Frame.cc:125-174 on the device (sivo_amd/frame.py): the network is enqueued FIRST, the two extractors and the matching of
     # every left key run beside it, the semantic filter + median cull wait for the class map
     from sivo_amd.frame import StereoFramePipeline
@@ -520,6 +538,7 @@ def main():
             # once more (the first of them runs without f16x3, the scales back off).  [N > 1: a rank cannot redo a collective on its
             # own; sivo_segnet_create_multi is the multi-device form that recomputes, DESIGN 4]
             torch.cuda.synchronize()
+            sn.take_overflow()                            # what the frames still in flight raised meanwhile belongs to the same event
             for sl, sd, _ in [(slot, seed, None)] + inflight:
                 sn.segment_into(d_bgr, sd, maps_s[sl])
                 cls_pin[sl].copy_(maps_s[sl][0], non_blocking=True)
@@ -607,6 +626,14 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # fp16 range guard of the f16x3 layers: a rank cannot redo a collective on its own, so this loop does not
+        # recompute an overflowed frame the way the N = 1 loop does (sivo_segnet_create_multi, the in-handle multi-device form, does).
+        # It must not report a rate made of wrong frames either: any rank's flag fails the run loudly.
+        ov = torch.tensor([1.0 if sn.take_overflow() else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ov, op=dist.ReduceOp.MAX)
+        if float(ov.item()) > 0:
+            raise SystemExit("an activation left the fp16 range of an f16x3 layer on some rank during the timed frames: their maps are wrong and "
+                             "this N > 1 loop does not recompute them — no line is reported (SIVO_GEMM=x6 runs the fp32-range kernels)")
         # where a frame's time goes on every rank: its own shard's forward (prefix + n_local samples), then the all-reduce, which
         # ends when the slowest rank has arrived — so "all-reduce" on a light rank is mostly waiting, on the heaviest rank the wire time
         torch.cuda.synchronize()
@@ -647,7 +674,7 @@ def main():
         out = {"metric": "frames/sec, SIVO per-frame path (ORB+SegNet T=%d+entropy) %dx%d" % (T, H, W),
                "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_frame, 3), "higher_is_better": True, "scaling": "strong",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "vs_baseline": None, "dtype": "f32 (f16x3)", "data": "synthetic",
                "arithmetic": ("activations, weights, transforms, accumulators and outputs fp32; the batched GEMM of the Winograd F(4x4,3x3) layers and the direct "
                               "3x3 kernel of the layers with <= 128 channels (<= 256 in the sample-invariant prefix) multiply fp32 operands as fp16 hi + lo pairs "
                               "(power-of-two layer scales, 2^-22 relative) / 3 fp16 MFMA products with fp32 accumulation (error at the level of the fp32 FMA chain "

@@ -201,8 +201,12 @@ typedef struct SivoH3Layer {
     float vmax, vscale, uscale;
 } SivoH3Layer;
 int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow_frames, SivoH3Layer *per_layer, int capacity, int *n_layers);
-/* *overflowed = 1 when a frame issued on this handle since the last call (or the last synchronous entry point) left the fp16
- * range: the handle has backed off as described above and its NEXT forward runs without f16x3 — issue the frame again.
+/* *overflowed = 1 when a frame issued through an asynchronous entry point of this handle since the last call left the fp16
+ * range: the handle has backed off as described above (once per event, however many frames in flight raised the flag) and its
+ * NEXT forward runs without f16x3.  The answer is sticky: a later forward or status query that finds the flag first reacts
+ * to it but leaves the report to this call, so with k frames in flight the caller that asks about frame i after frame i+1 was
+ * issued still gets its 1.  The flag does not say WHICH frame: on 1, wait for every frame in flight, call this once more
+ * (whatever they raised meanwhile belongs to the same event) and issue ALL of them again.
  * Reads one word of pinned host memory: free to call once per frame, after the frame's results were synchronised with. */
 int sivo_segnet_take_overflow(sivo_segnet_t h, int *overflowed);
 

@@ -159,6 +159,8 @@ struct sivo_segnet {
     int h3_overflow_frames = 0;     // frames that raised the flag (each was recomputed on the bf16x6 path when the entry point is synchronous)
     int h3_back_offs = 0;           // times the scales were lowered by 2^2 after such a frame (f16x3 is switched off at the fourth)
     bool h3_pause = false;          // the next forward runs without f16x3 (the recomputation of the frame that raised the flag)
+    bool h3_unreported = false;     // a forward() / status query consumed the flag of an asynchronous frame nobody has asked about yet:
+                                    // sivo_segnet_take_overflow still owes its caller a 1 (sticky until that call)
     float *d_wino4_ws = nullptr;    // V + M workspace shared by every F(4x4,3x3) layer (one region per lane)
     size_t wino4_ws_floats = 0;
     size_t wino4_slot_floats = 0;   // three rotating slots (V, M, next V) for layers that run all samples in one pass
@@ -699,10 +701,20 @@ void h3_back_off(sivo_segnet &S) {
         if (op.d3_vscale > 0.f) op.d3_vscale *= 0.25f;
     }
 }
+// One overflow EVENT = every frame that was issued with the scales that overflowed.  With several frames in flight the flag can
+// go up more than once per event (the frames still running when the first one was noticed carry the same scales): the scales are
+// lowered once per event — a flag that shows up while the back-off's pause has not been consumed by a forward yet belongs to the
+// event that caused the back-off.
 bool h3_tripped(sivo_segnet &S) {
     if (!h3_flag_take(S)) return false;
-    h3_back_off(S);
+    if (!S.h3_pause) h3_back_off(S);
     return true;
+}
+// A place that is not the caller's question (the start of a forward, a status query) found the flag up: react, and remember that
+// sivo_segnet_take_overflow has not told anybody yet — with two frames in flight forward(k) runs before the caller asks about
+// frame k-1, and consuming the flag silently would let k-1's wrong maps through.
+void h3_absorb(sivo_segnet &S) {
+    if (h3_tripped(S)) S.h3_unreported = true;
 }
 
 // Deterministic frame for the calibration pass: rectangles of random colour over a gradient plus per-pixel noise — edges,
@@ -1012,7 +1024,7 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
              float *d_logits, float *d_prob, hipStream_t st, const McTargets *mc) {
     const int64_t hw = (int64_t)S.H * S.W;
     if (S.profile) harvest(S);
-    (void)h3_tripped(S);        // an earlier (asynchronous) frame left the fp16 range and nobody asked: back off now
+    h3_absorb(S);               // an earlier (asynchronous) frame left the fp16 range and nobody asked yet: back off now, report later
     // the recomputation of a frame that raised the flag: this forward is enqueued without f16x3
     struct Pause {
         sivo_segnet &S; bool was;
@@ -1496,7 +1508,9 @@ extern "C" int sivo_segnet_take_overflow(sivo_segnet_t h, int *overflowed) {
     return guarded([&] {
         if (!h || !overflowed) throw std::invalid_argument("null argument");
         if (h->multi) throw std::invalid_argument("a multi-device handle has synchronous entry points only: they recompute such a frame themselves");
-        *overflowed = h3_tripped(*h) ? 1 : 0;
+        const bool now = h3_tripped(*h);
+        *overflowed = (now || h->h3_unreported) ? 1 : 0;
+        h->h3_unreported = false;
         return SIVO_OK;
     });
 }
@@ -1509,7 +1523,7 @@ extern "C" int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow
         if (!h) throw std::invalid_argument("null handle");
         if (h->multi) throw std::invalid_argument("per-device state: query the handles of a multi-device handle one by one");
         DeviceGuard dg(h->device);
-        (void)h3_tripped(*h);
+        h3_absorb(*h);
         bool any_h3 = false, any_x6 = false;
         int rows = 0;
         for (const Op &op : h->ops) {

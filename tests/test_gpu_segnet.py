@@ -596,3 +596,42 @@ def test_fp16_overflow_recomputes_the_frame_and_backs_the_scales_off(oracle):
     torch.cuda.synchronize()
     assert not boosted2.take_overflow() and not torch.equal(ps2, ps_x6)
     assert (ps2 - ps_x6).abs().max() < 1e-3
+
+
+def test_fp16_overflow_is_reported_with_two_frames_in_flight(oracle):
+    """Two frames in flight (bench.py's loop: issue(k) runs before complete(k - 1)): frame k - 1 raises the flag, forward(k) finds it
+    first.  forward(k) reacts (one back-off, frame k itself runs without f16x3) but must not swallow the report:
+    sivo_segnet_take_overflow still says 1 when the caller asks about frame k - 1, exactly once, and a flag that goes up again
+    before the back-off's pause is consumed does not lower the scales a second time."""
+    T, H, W, width = 3, 22, 64, 256
+    text = _conv_stack_prototxt(T, H, W, width)
+    d = torch.from_numpy(_image(np.random.default_rng(4), H, W)).cuda()
+    _, _, boosted = _make_env(text, T, 5, SIVO_H3_BOOST=9)
+    _, _, x6 = _make_env(text, T, 5, SIVO_GEMM="x6")
+    boosted.forward(d, 3)                                  # frame k - 1: overflows
+    torch.cuda.synchronize()                               # (the deterministic form of the race: the flag is up before forward(k) is enqueued)
+    ps_k, _, _ = boosted.forward(d, 4)                     # forward(k) consumes the flag and the pause ...
+    ps_k_x6, _, _ = x6.forward(d, 4)
+    torch.cuda.synchronize()
+    assert torch.equal(ps_k, ps_k_x6)                      # ... so frame k ran without f16x3 and is right as it is
+    assert boosted.take_overflow()                         # the report about frame k - 1 is still owed
+    assert not boosted.take_overflow()                     # once
+    mode, frames, layers = boosted.gemm_status()
+    assert (mode, frames) == (2, 1)
+    # the flag going up twice in ONE event: frame B, issued with the old scales, is still running when frame A's overflow is noticed
+    _, _, b2 = _make_env(text, T, 5, SIVO_H3_BOOST=9)
+    s0 = [r[2] for r in b2.gemm_status()[2]]
+    ev_a = torch.cuda.Event()
+    torch.cuda._sleep(200_000_000)                         # (spin kernels: both forwards are enqueued before A starts, and B starts
+    b2.forward(d, 3); ev_a.record()                        #  long after the host has asked about A)
+    torch.cuda._sleep(400_000_000)
+    b2.forward(d, 5)
+    ev_a.synchronize()
+    assert b2.take_overflow()                              # A noticed: back-off, pause pending
+    torch.cuda.synchronize()                               # B (old scales) raises the flag again
+    assert b2.take_overflow()                              # the same event: reported, no second back-off
+    b2.forward(d, 3); b2.forward(d, 5)                     # both again: the first without f16x3, the second on the lowered scales
+    torch.cuda.synchronize()
+    assert not b2.take_overflow()
+    assert [r[2] for r in b2.gemm_status()[2]] == [v / 4 for v in s0]       # lowered once
+    assert b2.gemm_status()[:2] == (2, 2)                  # (two frames raised the flag)
