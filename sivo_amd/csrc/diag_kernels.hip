@@ -50,5 +50,96 @@ void launch_occupy(int lds_bytes, int mode, int microseconds, const uint32_t *sr
     SIVO_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The LDS access pattern of wino4_bridge_kernel (conv_wino4.hip) on SYNTHETIC, self-checking data (tools/coresident_repro.py):
+// zero-fill of the plane by all threads -> barrier -> every thread writes the 4 x 4 pixels of its tiles at [y + 1][4 tx + 1 ..]
+// (odd dword alignment: ds_write2_b32 pairs, as the bridge compiles) -> barrier -> every thread reads its 6 x 6 window back as
+// ds_read_b128 + ds_read_b64 per row and compares all 36 words with what they MUST be (a function of round, workgroup and pixel;
+// zero on the border).  `jitter`: dwords each thread loads from `src` in front of its writes (the bridge's M loads: the waves
+// reach the LDS phase at different times).  Report words (rep): [0] workgroups run, [1] workgroups whose LDS allocation does not
+// start at 0 (s_getreg LDS_ALLOC: they ran BESIDE another LDS user on their CU), [2] window words that differed, [3] rounds run by
+// co-resident workgroups; first difference: [4] round, [5] window word (row * 6 + col), [6] expected bits, [7] bits read,
+// [8] LDS_ALLOC register, [9] workgroup, [10] tile, [11] what the same word reads a second time (after another barrier);
+// [12 .. 47] per window word (36): differences at that word; [48] / [49] LDS_ALLOC of a co-resident / a lone workgroup.
+__global__ __launch_bounds__(1024) void lds_victim_kernel(int H, int W, int rounds, int jitter, const uint32_t *src, uint32_t *rep) {
+    extern __shared__ float vplane[];
+    const int th = (H + 3) / 4, tw = W / 4, ntile = th * tw, RS = W + 4, rows = 4 * th + 2;
+    const uint32_t alloc = __builtin_amdgcn_s_getreg((31 << 11) | 6);          // HW_REG_LDS_ALLOC: [7:0] base, [20:12] size
+    const bool beside = (alloc & 0xfffu) != 0u;                                  // (the base field, whatever its width on gfx950)
+    uint32_t bad = 0;
+    auto pix = [&](int r, int y, int x) -> float {        // the value of image pixel (y, x) in round r: never 0, never a NaN pattern
+        return __uint_as_float(0x3f000000u | ((uint32_t)(r & 0x3f) << 17) | ((uint32_t)(blockIdx.x & 0xf) << 13) | (uint32_t)(y * W + x + 1) % 8191u + 1u);
+    };
+    for (int r = 0; r < rounds; ++r) {
+        for (int i = threadIdx.x; i < rows * RS; i += blockDim.x) vplane[i] = 0.f;
+        __syncthreads();
+        uint32_t acc = 0;
+        for (int k = 0; k < jitter; ++k) acc ^= src[((blockIdx.x * 131 + r * 17 + k) * 1024 + threadIdx.x) & ((1 << 18) - 1)];
+        for (int t = threadIdx.x; t < ntile; t += blockDim.x) {
+            const int tx = t % tw, ty = t / tw;
+            float vv[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vv[i][q] = pix(r, 4 * ty + i, 4 * tx + q);
+            if (acc == 0x9e3779b9u) vv[0][0] = 1.f;      // (keeps the loads alive)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int y = 4 * ty + i;
+                if (y >= H) break;
+                float *dst = vplane + (y + 1) * RS + 4 * tx + 1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[q] = vv[i][q];
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < ntile; t += blockDim.x) {
+            const int tx = t % tw, ty = t / tw;
+            const float *win = vplane + (4 * ty) * RS + 4 * tx;
+            float d[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float4 q = *reinterpret_cast<const float4 *>(win + i * RS);
+                const float2 r2 = *reinterpret_cast<const float2 *>(win + i * RS + 4);
+                d[i][0] = q.x; d[i][1] = q.y; d[i][2] = q.z; d[i][3] = q.w; d[i][4] = r2.x; d[i][5] = r2.y;
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int y = 4 * ty + i - 1, x = 4 * tx + j - 1;
+                    const float want = (y >= 0 && y < H && x >= 0 && x < W) ? pix(r, y, x) : 0.f;
+                    if (__float_as_uint(want) != __float_as_uint(d[i][j])) {
+                        atomicAdd(rep + 12 + i * 6 + j, 1u);
+                        if (atomicAdd(rep + 2, 1u) == 0u) {
+                            rep[4] = (uint32_t)r; rep[5] = (uint32_t)(i * 6 + j); rep[6] = __float_as_uint(want); rep[7] = __float_as_uint(d[i][j]);
+                            rep[8] = alloc; rep[9] = blockIdx.x; rep[10] = (uint32_t)t;
+                            bad = 1u + (uint32_t)(i * 6 + j);
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+        if (bad) {          // the thread that recorded the first difference reads the same word once more
+            const int t = (int)rep[10], tx = t % tw, ty = t / tw, w = (int)bad - 1;
+            rep[11] = __float_as_uint(vplane[(4 * ty + w / 6) * RS + 4 * tx + w % 6]);
+            bad = 0;
+        }
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(rep + 0, 1u);
+        if (beside) { atomicAdd(rep + 1, 1u); atomicAdd(rep + 3, (uint32_t)rounds); rep[48] = alloc; }
+        else rep[49] = alloc;
+    }
+}
+
+void launch_lds_victim(int grid, int H, int W, int rounds, int jitter, const uint32_t *src, uint32_t *rep, hipStream_t s) {
+    const int th = (H + 3) / 4, tw = W / 4, ntile = th * tw;
+    const int nthr = ntile >= 1024 ? 1024 : (ntile + 63) / 64 * 64;             // as launch_conv_wino4 launches the bridge
+    const size_t lds = (size_t)(4 * th + 2) * (W + 4) * sizeof(float);
+    hipLaunchKernelGGL(lds_victim_kernel, dim3(grid), dim3(nthr), lds, s, H, W, rounds, jitter, src, rep);
+    SIVO_HIP(hipGetLastError());
+}
+
 }  // namespace sivo
 #endif
