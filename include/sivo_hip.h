@@ -201,6 +201,21 @@ typedef struct SivoH3Layer {
     float vmax, vscale, uscale;
 } SivoH3Layer;
 int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow_frames, SivoH3Layer *per_layer, int capacity, int *n_layers);
+/* The load-time accuracy guard of the matrix-core layers.  At construction every 3x3 layer the plan runs on Winograd
+ * F(4x4,3x3) or on the fp16 hi + lo split is evaluated on two built-in calibration frames x MC samples 0, 1 beside the direct fp32
+ * kernel, on the same input: rel_err = max |layer - direct fp32| / max |direct fp32| (rel_rms the same in rms).  A layer above
+ * *budget = 1e-3 / (*logit_max * sqrt(guarded layers)) was moved one level down and the handle planned again (*builds plans in
+ * all): level 0 as planned, 1 off F(4x4) (direct f16x3), 2 off f16x3 as well (F(2x2) / direct fp32), 3 direct fp32 only.  Rows
+ * describe the FINAL plan (kernel = what the layer runs now); first_rel_err = what the layer measured in the first plan.
+ * *guard_ms = wall time the guard added to construction; nothing runs per frame. */
+typedef struct SivoGuardLayer {
+    char layer[48];
+    char kernel[24];
+    float rel_err, rel_rms, ref_max, first_rel_err;
+    int32_t level;
+} SivoGuardLayer;
+int sivo_segnet_guard_report(sivo_segnet_t h, SivoGuardLayer *rows, int capacity, int *n_rows, float *budget, float *logit_max,
+                             double *guard_ms, int *builds);
 /* *overflowed = 1 when a frame issued through an asynchronous entry point of this handle since the last call left the fp16
  * range: the handle has backed off as described above (once per event, however many frames in flight raised the flag) and its
  * NEXT forward runs without f16x3.  The answer is sticky: a later forward or status query that finds the flag first reacts

@@ -920,6 +920,35 @@ void launch_conv3_h3(const ConvArgs &a0, hipStream_t s) {
     }
 }
 
+// the load-time accuracy guard (segnet.cpp accuracy_guard): largest |a - b| and |b| of two tensors (bit patterns, atomicMax) and
+// the sums of (a - b)^2 and b^2 in f64
+__global__ __launch_bounds__(256) void absdiff_max_kernel(const float *a, const float *b, int64_t n, uint32_t *out_bits, double *out_sums) {
+    float md = 0.f, mb = 0.f;
+    double sd = 0.0, sb = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = a[i], y = b[i], d = x - y;
+        md = fmaxf(md, fabsf(d)); mb = fmaxf(mb, fabsf(y));
+        if (!(fabsf(d) <= 3.0e38f)) md = 3.0e38f;              // NaN / inf in the layer under test: an error of any size
+        sd += (double)d * d; sb += (double)y * y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        md = fmaxf(md, __shfl_xor(md, off)); mb = fmaxf(mb, __shfl_xor(mb, off));
+        sd += __shfl_xor(sd, off); sb += __shfl_xor(sb, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(out_bits + 0, __float_as_uint(md));
+        atomicMax(out_bits + 1, __float_as_uint(mb));
+        atomicAdd(out_sums + 0, sd);
+        atomicAdd(out_sums + 1, sb);
+    }
+}
+
+void launch_absdiff_max(const float *a, const float *b, int64_t n, uint32_t *out_bits, double *out_sums, hipStream_t s) {
+    const int blocks = (int)std::min<int64_t>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(absdiff_max_kernel, dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3(256), 0, s, a, b, n, out_bits, out_sums);
+}
+
 void launch_absmax(const float *x, int64_t n, uint32_t *out_bits, hipStream_t s) {
     const int blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3(256), 0, s, x, n, out_bits);

@@ -28,6 +28,8 @@
 #include "prototxt.hpp"
 #include "segnet_kernels.hpp"
 #include "segnet_multi.hpp"
+#include <chrono>
+#include <algorithm>
 
 namespace sivo {
 bool looks_like_caffemodel(const std::string &bytes);
@@ -107,6 +109,7 @@ struct Op {
     int pool_op = -1;              // F(4x4) conv: index of the MAX 2x2 pooling fused into its output transform
     int unpool_in = -1, unpool_mask = -1;   // that convolution: pooled blob and mask blob it reads through
     int drop_site = -1;
+    int guard_level = 0;           // accuracy guard (accuracy_guard): 0 as planned, 1 no F(4x4) (direct f16x3 at any width), 2 no f16x3 either (F(2x2) / direct fp32), 3 direct fp32 only
     // lrn
     int local_size = 5;
     float alpha = 0.f, beta = 0.f;
@@ -161,6 +164,12 @@ struct sivo_segnet {
     bool h3_pause = false;          // the next forward runs without f16x3 (the recomputation of the frame that raised the flag)
     bool h3_unreported = false;     // a forward() / status query consumed the flag of an asynchronous frame nobody has asked about yet:
                                     // sivo_segnet_take_overflow still owes its caller a 1 (sticky until that call)
+    // load-time accuracy guard (accuracy_guard below): one row per guarded layer, the budget it was held against, what it cost
+    struct GuardRow { std::string layer, kernel; float rel_err = 0.f, rel_rms = 0.f, ref_max = 0.f, first_rel_err = 0.f; int level = 0; };
+    std::vector<GuardRow> guard_rows;
+    float guard_budget = 0.f, guard_logit_max = 0.f;
+    double guard_ms = 0.0;
+    int guard_builds = 0;
     float *d_wino4_ws = nullptr;    // V + M workspace shared by every F(4x4,3x3) layer (one region per lane)
     size_t wino4_ws_floats = 0;
     size_t wino4_slot_floats = 0;   // three rotating slots (V, M, next V) for layers that run all samples in one pass
@@ -213,7 +222,8 @@ int new_blob(sivo_segnet &S, const std::string &name, int C, int H, int W, bool 
 
 // Re-layout Caffe (Cout,Cin,k,k) weights to [ceil(Cin/KC)][k*k][KC][CoutPad] and fold
 // bias (+ BN scale/shift) into the epilogue's per-channel affine.
-void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int H, int Wd, bool keep_ties) {
+void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int H, int Wd, bool keep_ties, int guard_level = 0) {
+    op.guard_level = guard_level;
     const int ks = op.ks, cin = op.cin, cout = op.cout;
     std::vector<float> wt;
     static const bool force_v1 = SIVO_DIAG_ENV("SIVO_CONV_V1") != nullptr;
@@ -229,7 +239,7 @@ void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int 
     // pixel after unpooling.  Measured on the KITTI test frame with F(4x4) in the prefix: 5672 instead of 27 differing
     // switches at pool1, 0.46 % instead of 0.04 % of the final class map differing from the oracle.  The prefix runs once
     // per frame, so keeping it on F(2x2) costs 0.13 ms.
-    const bool f4_ok = !no_wino && !keep_ties;
+    const bool f4_ok = !no_wino && !keep_ties && guard_level < 1;      // (a layer the accuracy guard took off F(4x4): level >= 1)
     // Narrow layers (<= SIVO_D3_MAXC = 128 channels in and out): the direct f16x3 kernel (conv3_h3.hip), whenever the handle
     // runs its F(4x4) GEMMs on f16x3 as well (SIVO_GEMM unset) — SIVO_D3=0 disables.  A direct kernel treats every output
     // position alike, so it also keeps the exact pooling ties of the prefix.
@@ -238,10 +248,11 @@ void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int 
     const bool no_d3 = std::getenv("SIVO_D3") && std::atoi(std::getenv("SIVO_D3")) == 0;
     // (the sample-invariant prefix runs once per frame with N = 1: there the alternative is the fused F(2x2) kernel on the fp32
     // pipe, not the F(4x4) GEMM, and the direct kernel wins up to 256 channels — SIVO_D3_MAXC_SHARED)
-    const int d3_maxc = keep_ties ? (SIVO_DIAG_ENV("SIVO_D3_MAXC_SHARED") ? std::atoi(SIVO_DIAG_ENV("SIVO_D3_MAXC_SHARED")) : 256)
+    // (guard level 1: the layer left the F(4x4) GEMM for accuracy, not for speed — the direct f16x3 kernel takes it at any width)
+    const int d3_maxc = guard_level == 1 ? (1 << 30) : keep_ties ? (SIVO_DIAG_ENV("SIVO_D3_MAXC_SHARED") ? std::atoi(SIVO_DIAG_ENV("SIVO_D3_MAXC_SHARED")) : 256)
                                   : (SIVO_DIAG_ENV("SIVO_D3_MAXC") ? std::atoi(SIVO_DIAG_ENV("SIVO_D3_MAXC")) : 128);
     const bool d3_prefix = !(SIVO_DIAG_ENV("SIVO_D3_PREFIX") && std::atoi(SIVO_DIAG_ENV("SIVO_D3_PREFIX")) == 0);
-    op.d3 = !no_d3 && !no_wino && gemm_default && (d3_prefix || !keep_ties) && cin <= d3_maxc && cout <= d3_maxc && conv3_h3_supported(ks, cin, cout, H, Wd, false);
+    op.d3 = !no_d3 && !no_wino && gemm_default && guard_level < 2 && (d3_prefix || !keep_ties) && cin <= d3_maxc && cout <= d3_maxc && conv3_h3_supported(ks, cin, cout, H, Wd, false);
     if (op.d3) {
         std::vector<uint16_t> planes;
         op.d3_uscale = conv3_h3_pack_weights(W, cin, cout, planes);
@@ -253,7 +264,7 @@ void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int 
     // narrow layers (below the F(4x4) GEMM threshold): the fused F(4x4) kernel — SIVO_NO_WINO4F falls back to fused F(2x2)
     static const bool no_wino4f = SIVO_DIAG_ENV("SIVO_NO_WINO4F") != nullptr;
     op.wino4f = !op.wino4 && f4_ok && !no_wino4f && wino4f_supported(ks, cin, cout, H, Wd);
-    op.wino = !op.wino4 && !op.wino4f && !no_wino && wino_supported(ks, cin, cout, H, Wd);
+    op.wino = !op.wino4 && !op.wino4f && !no_wino && guard_level < 3 && wino_supported(ks, cin, cout, H, Wd);
     op.v2 = !op.wino4 && !op.wino4f && !op.wino && conv2_supported(ks) && !force_v1;
     // SegNet-Basic's 64 -> 64 7x7 layers: bf16x6 on the bf16 matrix cores (SIVO_CONV7=f32 keeps the fp32-MFMA direct kernel)
     const bool conv7_f32 = std::getenv("SIVO_CONV7") && std::string(std::getenv("SIVO_CONV7")) == "f32";      // (read per handle: tests build both)
@@ -345,7 +356,7 @@ void fold_bn(Op &op, const float *scale, const float *shift) {
 void calibrate_h3(sivo_segnet &S);
 
 std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const float *weights, size_t n_weights,
-                                   int device) {
+                                   int device, const std::map<std::string, int> &guard_levels = {}) {
     std::unique_ptr<sivo_segnet> Sp(new sivo_segnet);
     sivo_segnet &S = *Sp;
     S.device = device;
@@ -388,7 +399,8 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             if (const char *extra = SIVO_DIAG_ENV("SIVO_KEEP_TIES_LAYERS"))        // comma-separated layer names (experiments)
                 keep_ties = keep_ties || ("," + std::string(extra) + ",").find("," + L.name + ",") != std::string::npos;
             op.w_off = woff;
-            upload_conv(S, op, weights + woff, weights + woff + nw, b.H, b.W, keep_ties);
+            const auto gl = guard_levels.find(L.name);
+            upload_conv(S, op, weights + woff, weights + woff + nw, b.H, b.W, keep_ties, gl == guard_levels.end() ? 0 : gl->second);
             woff += nw + op.cout;
             op.flops = 2.0 * op.ks * op.ks * op.cin * op.cout * (double)b.H * b.W;
             op.name = L.name;
@@ -808,6 +820,210 @@ void calibrate_h3(sivo_segnet &S) {
     S.h3_on = true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Load-time accuracy guard.  The fp16 RANGE of the f16x3 layers is guarded by calibrate_h3 + the overflow flag; this guards their
+// ACCURACY for the weights at hand: how much of the 1e-3 logit budget Winograd F(4x4,3x3) (4 d0 - 5 d2 + d4 cancels the common mode
+// of a tile) and the fp16 hi + lo split use depends on the weights' and activations' dynamic range, and trained weights are not the
+// synthetic ones the tests sweep.  On two calibration frames x MC samples 0, 1 the network is evaluated once more, UNFUSED, along a
+// reference chain — every 3x3 layer that production runs on F(4x4) or f16x3 is computed by the direct fp32 matrix-core kernel
+// (conv_v2.hip: v_mfma_f32, the fp32 FMA chain) from the reference chain's own input — and beside it the layer's production kernel
+// (input transform + f16x3 / bf16x6 GEMM + output transform, or the direct f16x3 kernel) runs on the SAME input: err_l = max |fast -
+// ref| / max |ref| is that layer's own error, free of propagated differences and of pooling-switch flips.
+// Budget: errors of independent layers add in quadrature and a relative error of the activations carries to the logits, so with n
+// guarded layers and logits up to L the frame stays within tol = 1e-3 when every layer holds err_l <= tol / (L sqrt(n)).  A layer
+// above its budget moves one level down — F(4x4) -> direct f16x3 (no transform) -> F(2x2) / direct fp32 -> direct fp32 — the
+// handle is planned again (fusions depend on the kernels) and guarded again.  Two samples, two frames: ~1 s at load, nothing per
+// frame.  The decisions depend on the weights and the geometry only (never on T: always samples 0 and 1), so shard handles of one
+// model plan identically.  Diagnostic build: SIVO_GUARD=0 skips it, SIVO_GUARD_TOL sets tol.
+struct GuardVerdict { bool any_over = false; std::map<std::string, int> levels; };
+
+GuardVerdict accuracy_guard(sivo_segnet &S, const float *weights, const std::map<std::string, int> &levels_in, float tol) {
+    GuardVerdict verdict;
+    verdict.levels = levels_in;
+    const int n = std::min(S.T, 2);
+    std::vector<size_t> guarded;
+    auto d3_runs = [&](const Op &op) { return op.d3 && S.h3_on && op.d3_vscale > 0.f && op.drop_site < 0; };
+    for (size_t i = 0; i < S.ops.size(); ++i) {
+        const Op &op = S.ops[i];
+        // (F(2x2) fp32 layers only when the guard itself put them there: they can still go one level down, to the direct kernel)
+        if (op.kind == OP_CONV && op.ks == 3 && (int)i != S.cls_op && (op.wino4 || op.wino4f || d3_runs(op) || (op.wino && op.guard_level >= 2))) guarded.push_back(i);
+    }
+    if (guarded.empty()) return verdict;
+    const auto t_begin = std::chrono::steady_clock::now();
+    hipStream_t st = S.stream;
+    // every blob of the net, materialised for n samples (shared ones once); freed when the guard returns
+    std::vector<void *> buf(S.blobs.size(), nullptr);
+    std::vector<void *> scratch;
+    auto release = [&] { for (void *p : buf) if (p) (void)hipFree(p); for (void *p : scratch) if (p) (void)hipFree(p); };
+    try {
+        int64_t max_out = 0;
+        for (size_t b = 0; b < S.blobs.size(); ++b) {
+            const Blob &B = S.blobs[b];
+            const size_t cnt = (size_t)(B.shared ? 1 : n) * B.chw();
+            SIVO_HIP(hipMalloc(&buf[b], cnt * (B.is_mask ? 1 : sizeof(float))));
+            if (!B.is_mask) max_out = std::max<int64_t>(max_out, (int64_t)cnt);
+        }
+        float *d_fast = nullptr;
+        uint32_t *d_bits = nullptr;
+        double *d_sums = nullptr;
+        std::vector<float *> d_wref(S.ops.size(), nullptr);      // per guarded layer: its Caffe weights packed for the direct fp32 kernel
+        std::vector<int> wref_pad(S.ops.size(), 0);
+        SIVO_HIP(hipMalloc((void **)&d_fast, (size_t)max_out * sizeof(float))); scratch.push_back(d_fast);
+        SIVO_HIP(hipMalloc((void **)&d_bits, (2 * S.ops.size() + 2) * sizeof(uint32_t))); scratch.push_back(d_bits);
+        SIVO_HIP(hipMalloc((void **)&d_sums, 2 * S.ops.size() * sizeof(double))); scratch.push_back(d_sums);
+        SIVO_HIP(hipMemset(d_bits, 0, (2 * S.ops.size() + 2) * sizeof(uint32_t)));
+        SIVO_HIP(hipMemset(d_sums, 0, 2 * S.ops.size() * sizeof(double)));
+        auto fp = [&](int b) { return (float *)buf[b]; };
+        const uint64_t seed = 0x6a09e667f3bcc908ull;
+        for (int frame = 0; frame < 2; ++frame) {
+            const std::vector<uint8_t> img = calibration_frame(S.H, S.W, frame);
+            SIVO_HIP(hipMemcpyAsync(S.d_image, img.data(), img.size(), hipMemcpyHostToDevice, st));
+            launch_preprocess(S.d_image, fp(S.input_blob), (int64_t)S.H * S.W, st);
+            for (size_t oi = 0; oi < S.ops.size(); ++oi) {
+                const Op &op = S.ops[oi];
+                const Blob &bi = S.blobs[op.in], &bo = S.blobs[op.out];
+                const int N = bo.shared ? 1 : n;
+                switch (op.kind) {
+                    case OP_CONV: {
+                        ConvArgs a{};
+                        a.in = fp(op.in); a.in_sample_stride = bi.shared ? 0 : bi.chw();
+                        a.wt = op.d_w; a.ep_scale = op.d_scale; a.ep_shift = op.d_shift;
+                        a.out = fp(op.out);
+                        a.N = N; a.Cin = op.cin; a.H = bi.H; a.W = bi.W; a.Cout = op.cout; a.CoutPad = op.cout_pad;
+                        a.relu = op.relu; a.drop_site = op.drop_site; a.sample0 = 0; a.seed = seed + (uint64_t)frame;
+                        a.wt_x6 = op.d_wx6;
+                        const bool is_guarded = std::find(guarded.begin(), guarded.end(), oi) != guarded.end();
+                        if (!is_guarded) {
+                            // the layer's own fp32 kernel (no F(4x4), no f16x3 in it): part of the reference chain as it is
+                            if (op.c7x6) launch_conv7_x6(a, st);
+                            else if (op.wino) launch_conv_wino(a, op.wino_cfg, st);
+                            else if (op.v2) launch_conv2(a, op.ks, st);
+                            else launch_conv(a, op.ks, st);
+                            break;
+                        }
+                        // reference: the direct fp32 matrix-core kernel on weights packed for it from the Caffe array
+                        if (!d_wref[oi]) {
+                            std::vector<float> wt;
+                            conv2_pack_weights(weights + op.w_off, op.ks, op.cin, op.cout, wt, &wref_pad[oi]);
+                            SIVO_HIP(hipMalloc((void **)&d_wref[oi], wt.size() * sizeof(float))); scratch.push_back(d_wref[oi]);
+                            SIVO_HIP(hipMemcpy(d_wref[oi], wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+                        }
+                        ConvArgs r = a;
+                        r.wt = d_wref[oi]; r.CoutPad = wref_pad[oi]; r.wt_x6 = nullptr;
+                        launch_conv2(r, op.ks, st);
+                        // the production kernel of this layer on the same input, standalone (no bridge, no fused pooling / Upsample)
+                        ConvArgs f = a;
+                        f.out = d_fast;
+                        if (op.wino4) {
+                            if (S.h3_on && op.d_wh3 && op.h3_vscale > 0.f) { f.wt_h3 = op.d_wh3; f.h3_vscale = op.h3_vscale; f.h3_uscale = op.h3_uscale; }
+                            f.h3_flag = const_cast<uint32_t *>(S.h3_flag);
+                            launch_conv_wino4(f, S.d_wino4_ws, op.wino4_group, st, nullptr, false, nullptr);
+                        } else if (op.wino4f) {
+                            f.variant |= 4096;
+                            launch_conv_wino4f(f, st);
+                        } else if (!d3_runs(op)) {
+                            launch_conv_wino(f, op.wino_cfg, st);
+                        } else {
+                            f.wt_h3 = op.d_wd3; f.h3_vscale = op.d3_vscale; f.h3_uscale = op.d3_uscale; f.h3_flag = const_cast<uint32_t *>(S.h3_flag);
+                            f.CoutPad = op.cout;
+                            launch_conv3_h3(f, st);
+                        }
+                        launch_absdiff_max(d_fast, fp(op.out), (int64_t)N * bo.chw(), d_bits + 2 * oi, d_sums + 2 * oi, st);
+                        break;
+                    }
+                    case OP_POOL: {
+                        PoolArgs a{};
+                        a.in = fp(op.in); a.in_sample_stride = bi.shared ? 0 : bi.chw();
+                        a.out = fp(op.out); a.mask = (uint8_t *)buf[op.out2];
+                        a.mask_N = S.blobs[op.out2].shared ? 1 : n;
+                        a.N = N; a.C = bi.C; a.H = bi.H; a.W = bi.W; a.Ho = bo.H; a.Wo = bo.W;
+                        a.drop_site = op.drop_site; a.sample0 = 0; a.seed = seed + (uint64_t)frame;
+                        launch_maxpool2(a, st);
+                        break;
+                    }
+                    case OP_UNPOOL: {
+                        UnpoolArgs a{};
+                        const Blob &bm = S.blobs[op.in2];
+                        a.in = fp(op.in); a.mask = (const uint8_t *)buf[op.in2];
+                        a.mask_sample_stride = bm.shared ? 0 : bm.chw();
+                        a.out = fp(op.out); a.N = N; a.C = bi.C; a.H = bi.H; a.W = bi.W;
+                        launch_unpool2(a, st);
+                        break;
+                    }
+                    case OP_DROPOUT:
+                        launch_dropout(fp(op.in), bi.shared ? 0 : bi.chw(), fp(op.out), n, bi.chw(), op.drop_site, 0, seed + (uint64_t)frame, st);
+                        break;
+                    case OP_LRN:
+                        launch_lrn(fp(op.in), fp(op.out), N, bi.C, (int64_t)bi.H * bi.W, op.local_size, op.alpha, op.beta, st);
+                        break;
+                }
+            }
+            launch_absmax(fp(S.logits_blob), (int64_t)n * S.blobs[S.logits_blob].chw(), d_bits + 2 * S.ops.size(), st);
+        }
+        SIVO_HIP(hipStreamSynchronize(st));
+        SIVO_HIP(hipGetLastError());
+        std::vector<uint32_t> bits(2 * S.ops.size() + 2);
+        std::vector<double> sums(2 * S.ops.size());
+        SIVO_HIP(hipMemcpy(bits.data(), d_bits, bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        SIVO_HIP(hipMemcpy(sums.data(), d_sums, sums.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (S.h3_flag) *S.h3_flag = 0;            // (the guard's frames are the calibration's: nothing to report to a caller)
+        auto as_float = [](uint32_t b) { float v; std::memcpy(&v, &b, 4); return v; };
+        const float L = std::max(1.f, as_float(bits[2 * S.ops.size()]));
+        const float budget = tol / (L * std::sqrt((float)guarded.size()));
+        std::vector<sivo_segnet::GuardRow> rows;
+        for (size_t oi : guarded) {
+            const Op &op = S.ops[oi];
+            sivo_segnet::GuardRow r;
+            r.layer = op.name;
+            r.kernel = op.wino4 ? (S.h3_on && op.d_wh3 && op.h3_vscale > 0.f ? "F(4x4) f16x3 GEMM" : op.d_wx6 ? "F(4x4) bf16x6 GEMM" : "F(4x4) fp32 GEMM") : op.wino4f ? "F(4x4) fp32 fused" : d3_runs(op) ? "direct f16x3" : "F(2x2) fp32 fused";
+            r.ref_max = as_float(bits[2 * oi + 1]);
+            r.rel_err = as_float(bits[2 * oi]) / std::max(r.ref_max, 1e-30f);
+            r.rel_rms = (float)std::sqrt(sums[2 * oi] / std::max(sums[2 * oi + 1], 1e-300));
+            r.level = op.guard_level;
+            r.first_rel_err = r.rel_err;
+            for (const auto &prev : S.guard_rows) if (prev.layer == r.layer) r.first_rel_err = prev.first_rel_err;
+            if (!(r.rel_err <= budget) && op.guard_level < 3) {
+                // one level down from the kernel that was measured
+                const int next = (op.wino4 || op.wino4f) ? std::max(1, op.guard_level + 1) : d3_runs(op) ? std::max(2, op.guard_level + 1) : 3;
+                verdict.levels[op.name] = next;
+                verdict.any_over = true;
+            }
+            rows.push_back(r);
+        }
+        S.guard_rows = rows;
+        S.guard_budget = budget; S.guard_logit_max = L;
+    } catch (...) {
+        release();
+        throw;
+    }
+    release();
+    S.guard_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return verdict;
+}
+
+// build + guard + (when a layer is over its budget) plan again with that layer one level down, until nothing moves
+std::unique_ptr<sivo_segnet> build_guarded(const ProtoNet &net, int t_override, const float *weights, size_t n_weights, int device) {
+    const bool off = SIVO_DIAG_ENV("SIVO_GUARD") && std::atoi(SIVO_DIAG_ENV("SIVO_GUARD")) == 0;
+    const float tol = SIVO_DIAG_ENV("SIVO_GUARD_TOL") ? (float)std::atof(SIVO_DIAG_ENV("SIVO_GUARD_TOL")) : 1e-3f;
+    std::map<std::string, int> levels;
+    std::unique_ptr<sivo_segnet> S;
+    std::vector<sivo_segnet::GuardRow> carried;
+    double ms = 0.0;
+    for (int round = 0; round < 5; ++round) {
+        S.reset();                                   // (the previous plan's 16 GB go back before the next one allocates)
+        S = build(net, t_override, weights, n_weights, device, levels);
+        S->guard_builds = round + 1;
+        if (off) break;
+        DeviceGuard dg(device);
+        S->guard_rows = carried; S->guard_ms = ms;
+        const GuardVerdict v = accuracy_guard(*S, weights, levels, tol);
+        carried = S->guard_rows; ms = S->guard_ms;
+        if (!v.any_over) break;
+        levels = v.levels;
+    }
+    return S;
+}
+
 void harvest(sivo_segnet &S) {
     if (!S.pending) return;
     for (Op &op : S.ops) {
@@ -1198,7 +1414,7 @@ extern "C" int sivo_segnet_create(const char *text, size_t len, int t_override, 
             return fail(SIVO_ERR_RUNTIME, "HIP device %d is not available (%d visible): libsivo_hip has no CPU fallback",
                         device, sivo_device_count());
         ProtoNet net = parse_prototxt(std::string(text, len));
-        *out = build(net, t_override, weights, n_weights, device).release();
+        *out = build_guarded(net, t_override, weights, n_weights, device).release();
         return SIVO_OK;
     });
 }
@@ -1511,6 +1727,30 @@ extern "C" int sivo_segnet_take_overflow(sivo_segnet_t h, int *overflowed) {
         const bool now = h3_tripped(*h);
         *overflowed = (now || h->h3_unreported) ? 1 : 0;
         h->h3_unreported = false;
+        return SIVO_OK;
+    });
+}
+
+// The load-time accuracy guard's report (accuracy_guard): one row per guarded layer of the final plan.
+extern "C" int sivo_segnet_guard_report(sivo_segnet_t h, SivoGuardLayer *rows, int capacity, int *n_rows, float *budget, float *logit_max,
+                                        double *guard_ms, int *builds) {
+    return guarded([&] {
+        if (!h) throw std::invalid_argument("null handle");
+        if (h->multi) throw std::invalid_argument("per-device state: query the handles of a multi-device handle one by one");
+        if (n_rows) *n_rows = (int)h->guard_rows.size();
+        if (budget) *budget = h->guard_budget;
+        if (logit_max) *logit_max = h->guard_logit_max;
+        if (guard_ms) *guard_ms = h->guard_ms;
+        if (builds) *builds = h->guard_builds;
+        if (rows)
+            for (int i = 0; i < capacity && i < (int)h->guard_rows.size(); ++i) {
+                const sivo_segnet::GuardRow &g = h->guard_rows[(size_t)i];
+                SivoGuardLayer &r = rows[i];
+                std::memset(&r, 0, sizeof r);
+                std::snprintf(r.layer, sizeof r.layer, "%s", g.layer.c_str());
+                std::snprintf(r.kernel, sizeof r.kernel, "%s", g.kernel.c_str());
+                r.rel_err = g.rel_err; r.rel_rms = g.rel_rms; r.ref_max = g.ref_max; r.first_rel_err = g.first_rel_err; r.level = g.level;
+            }
         return SIVO_OK;
     });
 }

@@ -89,6 +89,8 @@ bool conv3_h3_supported(int ks, int cin, int cout, int H, int W, bool unpool);
 float conv3_h3_pack_weights(const float *W, int cin, int cout, std::vector<uint16_t> &out);      // returns the scale applied
 void launch_conv3_h3(const ConvArgs &a, hipStream_t s);
 void launch_absmax(const float *x, int64_t n, uint32_t *out_bits, hipStream_t s);                 // atomicMax of the bit pattern of |x|
+// accuracy guard: out_bits[0] = max |a - b|, out_bits[1] = max |b| (bit patterns, atomicMax); out_sums[0] += sum (a - b)^2, [1] += sum b^2
+void launch_absdiff_max(const float *a, const float *b, int64_t n, uint32_t *out_bits, double *out_sums, hipStream_t s);
 // packed activation format of conv3_h3.hip (pk_format.hip).  Planes are (Hp, Wp) with the image at [1 .. H][1 .. W]; the
 // border is never written (allocate zeroed).
 size_t pk_bytes(int N, int C, int Hp, int Wp);

@@ -179,6 +179,21 @@ class BayesianSegNet:
         check(self._L.sivo_segnet_gemm_status(self._h, C.byref(mode), C.byref(ov), rows, n.value, C.byref(n)))
         return mode.value, ov.value, [(r.layer.decode(), r.vmax, r.vscale, r.uscale) for r in rows[:n.value]]
 
+    def guard_report(self):
+        """The load-time accuracy guard (sivo_segnet_guard_report): dict(budget, logit_max, ms, builds, layers=[dict(layer, kernel,
+        rel_err, rel_rms, ref_max, first_rel_err, level)]) — see include/sivo_hip.h."""
+        class _Row(C.Structure):
+            _fields_ = [("layer", C.c_char * 48), ("kernel", C.c_char * 24), ("rel_err", C.c_float), ("rel_rms", C.c_float),
+                        ("ref_max", C.c_float), ("first_rel_err", C.c_float), ("level", C.c_int32)]
+        n, builds = C.c_int32(), C.c_int32()
+        budget, lmax, ms = C.c_float(), C.c_float(), C.c_double()
+        check(self._L.sivo_segnet_guard_report(self._h, None, 0, C.byref(n), C.byref(budget), C.byref(lmax), C.byref(ms), C.byref(builds)))
+        rows = (_Row * max(n.value, 1))()
+        check(self._L.sivo_segnet_guard_report(self._h, rows, n.value, C.byref(n), None, None, None, None))
+        return dict(budget=budget.value, logit_max=lmax.value, ms=ms.value, builds=builds.value,
+                    layers=[dict(layer=r.layer.decode(), kernel=r.kernel.decode(), rel_err=r.rel_err, rel_rms=r.rel_rms, ref_max=r.ref_max,
+                                 first_rel_err=r.first_rel_err, level=r.level) for r in rows[:n.value]])
+
     def blob(self, name):
         shape = (C.c_int32 * 4)()
         check(self._L.sivo_segnet_blob(self._h, name.encode(), None, 0, shape))

@@ -26,6 +26,8 @@ VARIANTS = [
     ("beside an occupant with ds traffic, 128K", {}, (131072, 1)),
     ("beside an occupant with LDS-DMA traffic, 128K", {}, (131072, 2)),
     ("beside an occupant with LDS-DMA traffic, 112K", {}, (114688, 2)),
+    ("beside a GEMM-like occupant (LDS-DMA + ds_read_b128 / ds_write_b128 + barriers), 128K", {}, (131072, 3)),
+    ("beside a GEMM-like occupant with MFMAs, 128K", {}, (131072, 4)),
     ("beside the f16x3 GEMM, exact LDS", {"SIVO_H3_LDS_ALL": "0"}, "gemm"),
     ("beside the f16x3 GEMM, exact LDS, again", {"SIVO_H3_LDS_ALL": "0"}, "gemm"),
     ("beside the f16x3 GEMM claiming 160K (as shipped)", {}, "gemm"),
@@ -72,12 +74,12 @@ def body(name):
                     L.sivo_debug_occupy_wait()
                 first = tot[2] == 0 and rep[2] != 0
                 for i in range(64):
-                    if i in (0, 1, 2, 3) or 12 <= i < 48:
+                    if i in (0, 1, 2, 3, 50) or 12 <= i < 48:
                         tot[i] += rep[i]
-                    elif first or (i >= 48 and rep[i]):
+                    elif first or (i in (48, 49) and rep[i]):
                         tot[i] = rep[i]
             words = {k: tot[12 + k] for k in range(36) if tot[12 + k]}
-            print(f"[{name}] plane {H}x{W}: workgroups {tot[0]}, of which beside another LDS user {tot[1]} ({tot[3]} rounds); window words that differed {tot[2]}"
+            print(f"[{name}] plane {H}x{W}: workgroups {tot[0]}, of which above >= 112 KB of other LDS {tot[1]} ({tot[3]} rounds; base exactly 112 / 128 KB: {tot[50]}); window words that differed {tot[2]}"
                   + (f"; first: round {tot[4]} window word (row {tot[5] // 6}, col {tot[5] % 6}) expected {tot[6]:08x} read {tot[7]:08x} re-read {tot[11]:08x} "
                      f"LDS_ALLOC {tot[8]:08x} workgroup {tot[9]} tile {tot[10]}; by window word {words}" if tot[2] else "")
                   + f"; LDS_ALLOC of a co-resident / a lone workgroup {tot[48]:08x} / {tot[49]:08x}  [{time.perf_counter() - t0:.1f} s]", flush=True)
