@@ -489,7 +489,15 @@ def main():
     fp = StereoFramePipeline(device=local, start_delay_s=orb_delay) if do_orb else None
     tail_probe = [] if os.environ.get("SIVO_BENCH_TAIL_PROBE") else None         # experiment: host time of the cull behind the class map
 
-    rank_events = []         # N > 1: (start, forward done, all-reduce done) of every frame on this rank's stream
+    rank_events = []         # N > 1: (start, band done, gather done, forward done, all-reduce done) of every frame on this rank's stream
+    # N > 1: the sample-invariant prefix in row bands over the ranks + one all-gather of the slots instead of N recomputations
+    # (SIVO_BENCH_BANDS=0 keeps the recomputation)
+    banded = world > 1 and os.environ.get("SIVO_BENCH_BANDS", "1") != "0"
+    if banded:
+        band_plan = sn.prefix_bands(world)
+        my_slot = torch.zeros(band_plan["slot_bytes"], dtype=torch.uint8, device="cuda")
+        all_slots = torch.zeros((world, band_plan["slot_bytes"]), dtype=torch.uint8, device="cuda")
+        slot_views = [all_slots[r] for r in range(world)]
 
     # The rank that runs ORB (rank 0) keeps TWO frames in flight.  A frame's device work (network [+ all-reduce + finalize], ORB,
     # matching) is enqueued; its host tail — semantic filter, median cull, entropy gate, ≈0.35 ms during which the GPU would otherwise
@@ -509,16 +517,27 @@ def main():
             # one device holds all T samples: segmentImage on device-resident data (f64 mean, no probability sum in memory)
             sn.segment_into(d_bgr, seed, out)           # asynchronous: ~65 launches enqueued in ~0.5 ms
             return fp.start_orb(d_left, d_right) if do_orb else None
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record()
-        if n_local:
-            sn.forward_into(d_bgr, seed, prob_sum, n_samples=n_local, sample0=sample0)
+        if banded:
+            sn.prefix_band_into(d_bgr, rank, world, my_slot)
+            ev[1].record()
+            dist.all_gather(slot_views, my_slot)
+            ev[2].record()
+            if n_local:
+                sn.forward_banded_into(all_slots, world, seed, prob_sum, n_samples=n_local, sample0=sample0)
+            else:
+                prob_sum.zero_()                       # more ranks than samples: contribute nothing
         else:
-            prob_sum.zero_()                           # more ranks than samples: contribute nothing
-        ev[1].record()
+            ev[1].record(); ev[2].record()
+            if n_local:
+                sn.forward_into(d_bgr, seed, prob_sum, n_samples=n_local, sample0=sample0)
+            else:
+                prob_sum.zero_()
+        ev[3].record()
         pending = fp.start_orb(d_left, d_right) if do_orb else None
         parallel.all_reduce_prob_sum(prob_sum)
-        ev[2].record()
+        ev[4].record()
         sn.finalize(prob_sum, t_total=T, out=out)
         rank_events.append(ev)
         return pending
@@ -638,14 +657,18 @@ def main():
         # ends when the slowest rank has arrived — so "all-reduce" on a light rank is mostly waiting, on the heaviest rank the wire time
         torch.cuda.synchronize()
         evs = rank_events[args.warmup:args.warmup + args.steps]
-        mine = torch.tensor([float(np.mean([e[0].elapsed_time(e[1]) for e in evs])), float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))],
-                            dtype=torch.float64, device="cuda")
+        mine = torch.tensor([float(np.mean([e[a].elapsed_time(e[b]) for e in evs])) for a, b in ((0, 1), (1, 2), (2, 3), (3, 4))], dtype=torch.float64, device="cuda")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        multi = {"forward_ms_per_rank": [round(float(t[0]), 3) for t in allr], "allreduce_incl_wait_ms_per_rank": [round(float(t[1]), 3) for t in allr],
-                 "allreduce_wire_ms": round(min(float(t[1]) for t in allr), 3),
+        multi = {"prefix": "row bands over the ranks + one all-gather of the slots (DESIGN 4)" if banded else "recomputed on every rank",
+                 "prefix_band_ms_per_rank": [round(float(t[0]), 3) for t in allr] if banded else None,
+                 "band_allgather_incl_wait_ms_per_rank": [round(float(t[1]), 3) for t in allr] if banded else None,
+                 "band_allgather_bytes_per_rank": int(band_plan["slot_bytes"]) if banded else None,
+                 "forward_ms_per_rank": [round(float(t[2]), 3) for t in allr], "allreduce_incl_wait_ms_per_rank": [round(float(t[3]), 3) for t in allr],
+                 "allreduce_wire_ms": round(min(float(t[3]) for t in allr), 3),
                  "allreduce_bytes": int(prob_sum.numel() * 4),
-                 "note": "HIP events on each rank's stream, mean over the timed frames: forward = the rank's shard (sample-invariant prefix + its samples); "
+                 "note": "HIP events on each rank's stream, mean over the timed frames: prefix band = the rank's rows of the sample-invariant prefix; band all-gather "
+                         "incl. wait = until every rank's slot has arrived; forward = unpacking + the rank's samples (with the prefix recomputed: prefix + samples); "
                          "all-reduce incl. wait = from the end of the rank's forward to the end of the collective (waiting for the slowest rank included); "
                          "wire = the smallest of those (the rank that arrives last waits for nobody)"}
 
@@ -752,21 +775,42 @@ def main():
                 def one(seed, nl=nl):
                     net.forward_into(d_bgr, seed, ps, n_samples=nl, sample0=0)
                     net.finalize(ps, t_total=T, out=m)
-                for i in range(3):
-                    one(i)
-                barrier()
-                t0 = time.perf_counter()
-                for i in range(10):
-                    one(10 + i)
-                barrier()
-                rows.append({"ranks": nr, "samples_on_the_heaviest_rank": nl, "ms_per_frame": round(1e2 * (time.perf_counter() - t0), 3)})
+                def timed_ms(fn):
+                    for i in range(3):
+                        fn(i)
+                    barrier()
+                    t0 = time.perf_counter()
+                    for i in range(10):
+                        fn(10 + i)
+                    barrier()
+                    return round(1e2 * (time.perf_counter() - t0), 3)
+                row = {"ranks": nr, "samples_on_the_heaviest_rank": nl, "ms_per_frame_prefix_recomputed": timed_ms(one)}
+                if nr > 1:
+                    # the same rank with the prefix in row bands: ITS band (the last rank's: the largest) + unpacking the gathered
+                    # slots + its samples + finalize; the other ranks' slots are computed once, outside the timing (they arrive by all-gather)
+                    plan = net.prefix_bands(nr)
+                    slots = torch.zeros((nr, plan["slot_bytes"]), dtype=torch.uint8, device="cuda")
+                    for r in range(nr):
+                        net.prefix_band_into(d_bgr, r, nr, slots[r])
+                    def one_b(seed, nl=nl, nr=nr, slots=slots):
+                        net.prefix_band_into(d_bgr, nr - 1, nr, slots[nr - 1])
+                        net.forward_banded_into(slots, nr, seed, ps, n_samples=nl, sample0=0)
+                        net.finalize(ps, t_total=T, out=m)
+                    row["ms_per_frame"] = timed_ms(one_b)
+                    row["band_rows_of_the_image"] = plan["input_rows"][nr - 1][1] - plan["input_rows"][nr - 1][0]
+                    row["allgather_bytes_per_rank"] = plan["slot_bytes"]
+                else:
+                    row["ms_per_frame"] = row["ms_per_frame_prefix_recomputed"]
+                rows.append(row)
             del net
             torch.cuda.empty_cache()
             for r_ in rows:
                 r_["speedup_ceiling"] = round(rows[0]["ms_per_frame"] / r_["ms_per_frame"], 2)
-            extra.append({"name": f"sample shards of the T = {T} frame on one GPU (SegNet forward of the heaviest rank's share + finalize; no ORB, no all-reduce)",
+                r_["speedup_ceiling_prefix_recomputed"] = round(rows[0]["ms_per_frame"] / r_["ms_per_frame_prefix_recomputed"], 2)
+            extra.append({"name": f"sample shards of the T = {T} frame on one GPU (the heaviest rank's share: its band of the prefix + unpacking + its samples + finalize; "
+                                  "no ORB, no all-gather / all-reduce wire time; *_prefix_recomputed = every rank computing the whole prefix, as before round 5)",
                           "metric": "ms per frame of the heaviest rank", "value": rows[-1]["ms_per_frame"], "shards": rows,
-                          "parity": "tests/test_gpu_segnet_fullsize.py::test_t48_and_its_shards_at_full_size, tests/test_distributed_cpu.py"})
+                          "parity": "tests/test_gpu_prefix_bands.py (banded prefix == whole-image forward, bit for bit, world 2 / 4 / 8), tests/test_gpu_segnet_fullsize.py::test_t48_and_its_shards_at_full_size, tests/test_distributed_cpu.py"})
         if "track" in want and stats["last"] is not None:
             extra.append(tracking_config(stats["last"], fp, (KFX, KFY, KCX, KCY, KBF), local))
         if "ba" in want:

@@ -114,6 +114,23 @@ int sivo_segnet_forward_dev(sivo_segnet_t h, const uint8_t *d_bgr, int n_samples
 int sivo_mc_finalize_dev(const float *d_prob_sum, int classes, int64_t hw, int t_total,
                          uint8_t *d_classes, double *d_confidence, double *d_entropy, void *stream);
 
+/* ---- The sample-invariant prefix split into row bands over the ranks that share a frame's samples (the reference has one
+ * device and no such split: bayesian_segnet.cpp:174-177 copies the image T times and Caffe computes the encoder T times).
+ * With the T samples sharded over `world` ranks (sivo_segnet_forward_dev with n_samples / sample0) every rank would recompute the
+ * whole prefix (everything in front of the first test-time Dropout: conv1_1 .. pool3 in SegNet-Standard).  Instead rank r computes
+ * the rows rows[r] .. rows[r + 1] of the prefix output from a band of the image (input_rows[2 r] .. input_rows[2 r + 1]: its rows
+ * plus the receptive-field halo) and packs what the per-sample part reads of the prefix — the pooled values in front of the dropout
+ * and the pooling masks — into a slot of *slot_bytes; ONE all-gather of the slots (rank order) replaces the recomputation:
+ *     sivo_segnet_prefix_bands(h, world, &slot_bytes, rows, input_rows);            // once
+ *     sivo_segnet_prefix_band_dev(h, d_bgr, rank, world, d_my_slot, stream);        // per frame: my band
+ *     ... all-gather: d_slots = world slots in rank order (RCCL / torch.distributed) ...
+ *     sivo_segnet_forward_banded_dev(h, d_slots, world, n_samples, sample0, seed, d_prob_sum, NULL, stream);
+ * The results are bit-identical to sivo_segnet_forward_dev on the whole image (tests/test_gpu_prefix_bands.py): a band's valid
+ * rows do not depend on the band.  The last H_out % world ranks take one row more (rank 0 the lighter share). */
+int sivo_segnet_prefix_bands(sivo_segnet_t h, int world, size_t *slot_bytes, int32_t *rows, int32_t *input_rows);
+int sivo_segnet_prefix_band_dev(sivo_segnet_t h, const uint8_t *d_bgr, int rank, int world, void *d_slot, void *stream);
+int sivo_segnet_forward_banded_dev(sivo_segnet_t h, const void *d_slots, int world, int n_samples, int sample0, uint64_t seed,
+                                   float *d_prob_sum, float *d_logits, void *stream);
 /* Softmax over the class axis of (n, classes, hw) logits and sum over n
  * (Softmax layer + the sum half of extractMeanConfidence).  accumulate != 0
  * adds to d_prob_sum instead of overwriting it. */
@@ -203,19 +220,22 @@ typedef struct SivoH3Layer {
 int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow_frames, SivoH3Layer *per_layer, int capacity, int *n_layers);
 /* The load-time accuracy guard of the matrix-core layers.  At construction every 3x3 layer the plan runs on Winograd
  * F(4x4,3x3) or on the fp16 hi + lo split is evaluated on two built-in calibration frames x MC samples 0, 1 beside the direct fp32
- * kernel, on the same input: rel_err = max |layer - direct fp32| / max |direct fp32| (rel_rms the same in rms).  A layer above
- * *budget = 1e-3 / (*logit_max * sqrt(guarded layers)) was moved one level down and the handle planned again (*builds plans in
- * all): level 0 as planned, 1 off F(4x4) (direct f16x3), 2 off f16x3 as well (F(2x2) / direct fp32), 3 direct fp32 only.  Rows
- * describe the FINAL plan (kernel = what the layer runs now); first_rel_err = what the layer measured in the first plan.
- * *guard_ms = wall time the guard added to construction; nothing runs per frame. */
+ * kernel, on the same input: rel_err = max |layer - direct fp32| / max |direct fp32| (rel_rms the same in rms).  *predicted =
+ * 0.5 sqrt(sum rel_err^2) estimates the error of the logits relative to their scale; *budget = 1e-3 / 30 (the tolerance at the
+ * logit range of the reference configuration).  While the prediction was above the budget the largest contributors were moved
+ * one level down and the handle planned again (*builds plans in all): level 0 as planned, 1 off F(4x4) (direct f16x3), 2 off
+ * f16x3 as well (F(2x2) / direct fp32), 3 direct fp32 only.  Rows describe the FINAL plan (kernel = what the layer runs now);
+ * first_rel_err = what the layer measured in the first plan.  *logit_max = largest |logit| of the guard's frames.
+ * *guard_ms = wall time the guard added to construction; nothing runs per frame.  No rows: nothing to guard, or the guard
+ * was skipped (diagnostic build SIVO_GUARD=0; scales forced out of the fp16 range). */
 typedef struct SivoGuardLayer {
     char layer[48];
     char kernel[24];
     float rel_err, rel_rms, ref_max, first_rel_err;
     int32_t level;
 } SivoGuardLayer;
-int sivo_segnet_guard_report(sivo_segnet_t h, SivoGuardLayer *rows, int capacity, int *n_rows, float *budget, float *logit_max,
-                             double *guard_ms, int *builds);
+int sivo_segnet_guard_report(sivo_segnet_t h, SivoGuardLayer *rows, int capacity, int *n_rows, float *budget, float *predicted,
+                             float *logit_max, double *guard_ms, int *builds);
 /* *overflowed = 1 when a frame issued through an asynchronous entry point of this handle since the last call left the fp16
  * range: the handle has backed off as described above (once per event, however many frames in flight raised the flag) and its
  * NEXT forward runs without f16x3.  The answer is sticky: a later forward or status query that finds the flag first reacts

@@ -83,7 +83,10 @@ SIGNATURES = {
     "sivo_segnet_profile": [_vp, _i],
     "sivo_segnet_profile_read": [_vp, _vp, _i, _pi32],
     "sivo_segnet_gemm_status": [_vp, _pi32, _pi32, _vp, _i, _pi32],
-    "sivo_segnet_guard_report": [_vp, _vp, _i, _pi32, _vp, _vp, _vp, _pi32],
+    "sivo_segnet_prefix_bands": [_vp, _i, _vp, _vp, _vp],
+    "sivo_segnet_prefix_band_dev": [_vp, _vp, _i, _i, _vp, _vp],
+    "sivo_segnet_forward_banded_dev": [_vp, _vp, _i, _i, _i, C.c_uint64, _vp, _vp, _vp],
+    "sivo_segnet_guard_report": [_vp, _vp, _i, _pi32, _vp, _vp, _vp, _vp, _pi32],
     "sivo_segnet_take_overflow": [_vp, _pi32],
     "sivo_orb_create": [_i, _f, _i, _i, _i, _i, C.POINTER(_vp)],
     "sivo_orb_destroy": [_vp],

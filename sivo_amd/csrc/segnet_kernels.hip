@@ -668,6 +668,30 @@ void launch_mask_to_index(const uint8_t *mask, float *out, int64_t total, int Ho
                        Ho, Wo, Win);
 }
 
+// Row bands of the sample-invariant prefix (segnet.cpp PrefixBands): the slots of all ranks -> one full (C, H, W) blob.  A slot holds,
+// at item_off, this blob's band as [C][rows_max][W] elements of `elt` bytes (rows past the band's own count are padding); rank r owns
+// the rows [tab.y0[r], tab.y0[r + 1]).  One thread per 16 bytes of a row (W * elt % 16 == 0).
+__global__ __launch_bounds__(256) void unpack_bands_kernel(unsigned char *dst, const unsigned char *slots, size_t slot_bytes, size_t item_off,
+                                                           int elt, int C, int H, int W, int rows_max, BandTable tab) {
+    const int row_vec = W * elt / 16;
+    const int64_t total = (int64_t)C * H * row_vec;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int v = (int)(i % row_vec);
+    const int y = (int)((i / row_vec) % H);
+    const int c = (int)(i / ((int64_t)row_vec * H));
+    int r = 0;
+    while (r + 1 < tab.world && y >= tab.y0[r + 1]) ++r;
+    const unsigned char *src = slots + (size_t)r * slot_bytes + item_off + ((size_t)((int64_t)c * rows_max + (y - tab.y0[r])) * row_vec + v) * 16;
+    *reinterpret_cast<uint4 *>(dst + (size_t)i * 16) = *reinterpret_cast<const uint4 *>(src);
+}
+void launch_unpack_bands(void *dst, const void *slots, size_t slot_bytes, size_t item_off, int elt, int C, int H, int W, int rows_max,
+                         const BandTable &tab, hipStream_t s) {
+    const int64_t total = (int64_t)C * H * (W * elt / 16);
+    hipLaunchKernelGGL(unpack_bands_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (unsigned char *)dst, (const unsigned char *)slots,
+                       slot_bytes, item_off, elt, C, H, W, rows_max, tab);
+}
+
 #ifdef SIVO_DIAG
 __global__ __launch_bounds__(1024) void lds_poison_kernel() {
     extern __shared__ uint32_t poison_lds[];

@@ -200,6 +200,10 @@ void launch_mc_finalize64(const double *prob_sum, int C, int64_t hw, int T, uint
 void launch_add_f64(double *dst, const double *src, int64_t n, bool init, hipStream_t s);      // dst = src (init) or dst += src
 void launch_mc_variance(const float *prob, int T, int C, int64_t hw, const uint8_t *classes, double *variance,
                         hipStream_t s);
+// row bands of the sample-invariant prefix: gathered slots -> a full blob (segnet_kernels.hip unpack_bands_kernel)
+struct BandTable { int world; int y0[17]; };      // y0[r] .. y0[r + 1]: the rows of this blob rank r owns (world <= 16)
+void launch_unpack_bands(void *dst, const void *slots, size_t slot_bytes, size_t item_off, int elt, int C, int H, int W, int rows_max,
+                         const BandTable &tab, hipStream_t s);
 void launch_mask_to_index(const uint8_t *mask, float *out, int64_t total, int Ho, int Wo, int Win, hipStream_t s);
 
 }  // namespace sivo

@@ -91,6 +91,7 @@ struct MultiDevice {
     uint8_t *d_image = nullptr;
     double *d_sum = nullptr;            // [ndev][classes][chunk]: this device's f64 sums for every pixel chunk
     double *d_rs = nullptr;             // [classes][chunk]: all devices' sums for this device's pixel chunk
+    unsigned char *d_slots = nullptr;   // [ndev][slot]: the prefix bands of all devices (own slot written here, the others gathered)
     uint8_t *d_cls_chunk = nullptr, *d_cls = nullptr;
     double *d_conf_chunk = nullptr, *d_conf = nullptr, *d_ent_chunk = nullptr, *d_ent = nullptr;
 };
@@ -102,12 +103,13 @@ struct SegnetMulti {
     bool emulate = false;
     int T = 0, H = 0, W = 0, classes = 0;
     int64_t hw = 0, chunk = 0;
+    size_t slot_bytes = 0;              // > 0: the sample-invariant prefix is split into row bands over the devices (segnet.cpp PrefixBands)
     std::vector<MultiDevice> dev;
     ~SegnetMulti() {
         for (MultiDevice &d : dev) {
             (void)hipSetDevice(d.device);
             if (d.comm) (void)rccl().CommDestroy(d.comm);
-            for (void *p : {(void *)d.d_image, (void *)d.d_sum, (void *)d.d_rs, (void *)d.d_cls_chunk, (void *)d.d_cls, (void *)d.d_conf_chunk,
+            for (void *p : {(void *)d.d_slots, (void *)d.d_image, (void *)d.d_sum, (void *)d.d_rs, (void *)d.d_cls_chunk, (void *)d.d_cls, (void *)d.d_conf_chunk,
                             (void *)d.d_conf, (void *)d.d_ent_chunk, (void *)d.d_ent})
                 if (p) (void)hipFree(p);
             if (d.stream) (void)hipStreamDestroy(d.stream);
@@ -169,6 +171,18 @@ SegnetMulti *segnet_multi_create(const char *text, size_t len, int t_total, cons
         D.d_conf_chunk = dev_alloc<double>((size_t)M->chunk); D.d_conf = dev_alloc<double>((size_t)M->hw);
         D.d_ent_chunk = dev_alloc<double>((size_t)M->chunk); D.d_ent = dev_alloc<double>((size_t)M->hw);
     }
+    // the prefix in row bands (one all-gather of ~2 MB per device) instead of ndev recomputations; SIVO_MULTI_BANDS=0 (diagnostic
+    // build) keeps the recomputation, for the tests that compare the two
+    const bool bands_off = SIVO_DIAG_ENV("SIVO_MULTI_BANDS") && std::atoi(SIVO_DIAG_ENV("SIVO_MULTI_BANDS")) == 0;
+    if (ndev > 1 && !bands_off) {
+        M->slot_bytes = segnet_prefix_slot_bytes(M->dev[0].net, ndev);
+        for (int d = 0; d < ndev && M->slot_bytes; ++d) {
+            MultiDevice &D = M->dev[d];
+            if (segnet_prefix_slot_bytes(D.net, ndev) != M->slot_bytes) throw std::runtime_error("prefix bands: the devices plan differently");
+            SIVO_HIP(hipSetDevice(D.device));
+            D.d_slots = dev_alloc<unsigned char>((size_t)ndev * M->slot_bytes);
+        }
+    }
     if (!M->emulate) {
         std::vector<ncclComm_t> comms((size_t)ndev);
         nccl_check(rccl().CommInitAll(comms.data(), ndev, device_ids), "ncclCommInitAll");
@@ -198,7 +212,35 @@ static void multi_frame(SegnetMulti *M, const uint8_t *bgr, int rows, int cols, 
         SIVO_HIP(hipSetDevice(D.device));
         SIVO_HIP(hipMemcpy2DAsync(D.d_image, (size_t)W * 3, bgr + ((size_t)y_tl * cols + x_tl) * 3, (size_t)cols * 3, (size_t)W * 3, (size_t)H,
                                   hipMemcpyHostToDevice, D.stream));
-        segnet_forward_chunked(D.net, D.d_image, D.n_samples, D.sample0, seed, D.d_sum, M->chunk, D.stream);
+        if (M->slot_bytes) segnet_prefix_band(D.net, D.d_image, (int)(&D - M->dev.data()), ndev, D.d_slots + (size_t)(&D - M->dev.data()) * M->slot_bytes, D.stream);
+        else segnet_forward_chunked(D.net, D.d_image, D.n_samples, D.sample0, seed, D.d_sum, M->chunk, D.stream);
+    }
+    if (M->slot_bytes) {
+        // 1b. all-gather of the prefix bands (in place: every device's own slot sits at its rank's position), then the per-sample part
+        if (!M->emulate) {
+            Rccl &R = rccl();
+            nccl_check(R.GroupStart(), "ncclGroupStart");
+            for (int d = 0; d < ndev; ++d) {
+                MultiDevice &D = M->dev[d];
+                nccl_check(R.AllGather(D.d_slots + (size_t)d * M->slot_bytes, D.d_slots, M->slot_bytes, ncclUint8, D.comm, D.stream), "ncclAllGather");
+            }
+            nccl_check(R.GroupEnd(), "ncclGroupEnd");
+        } else {
+            for (MultiDevice &D : M->dev) {
+                SIVO_HIP(hipSetDevice(D.device));
+                SIVO_HIP(hipStreamSynchronize(D.stream));
+            }
+            for (int d = 0; d < ndev; ++d) {
+                MultiDevice &D = M->dev[d];
+                SIVO_HIP(hipSetDevice(D.device));
+                for (int e = 0; e < ndev; ++e)
+                    if (e != d) SIVO_HIP(hipMemcpyAsync(D.d_slots + (size_t)e * M->slot_bytes, M->dev[e].d_slots + (size_t)e * M->slot_bytes, M->slot_bytes, hipMemcpyDeviceToDevice, D.stream));
+            }
+        }
+        for (MultiDevice &D : M->dev) {
+            SIVO_HIP(hipSetDevice(D.device));
+            segnet_forward_chunked(D.net, D.d_image, D.n_samples, D.sample0, seed, D.d_sum, M->chunk, D.stream, D.d_slots, ndev);
+        }
     }
     if (M->emulate)
         for (MultiDevice &D : M->dev) {

@@ -19,8 +19,12 @@ void segnet_multi_segment(SegnetMulti *M, const uint8_t *bgr, int rows, int cols
 // The sums are the f64 accumulators themselves (not rounded to fp32): added over the devices in f64 they give the
 // reference's f64 mean (bayesian_segnet.cpp:291-294) up to an f64 rounding, whatever the number of devices.
 void segnet_forward_chunked(sivo_segnet_t h, const uint8_t *d_bgr, int n, int sample0, uint64_t seed, double *d_sum_chunked,
-                            int64_t chunk, hipStream_t st);
+                            int64_t chunk, hipStream_t st, const void *d_slots = nullptr, int world = 0);
 // true once after a frame of the handle raised the fp16 overflow flag of the f16x3 GEMM (the handle is on bf16x6 from then on)
+// row bands of the sample-invariant prefix (segnet.cpp PrefixBands): slot size for `world` ranks (0: this net cannot be split, every
+// device recomputes the prefix), one rank's band -> its slot, and the forward above on the gathered slots (slots != null)
+size_t segnet_prefix_slot_bytes(sivo_segnet_t h, int world);
+void segnet_prefix_band(sivo_segnet_t h, const uint8_t *d_bgr, int rank, int world, void *d_slot, hipStream_t st);
 bool segnet_fp16_overflowed(sivo_segnet_t h);
 void segnet_fp16_back_off(sivo_segnet_t h);
 }  // namespace sivo

@@ -29,3 +29,35 @@ def all_reduce_prob_sum(prob_sum):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(prob_sum, op=dist.ReduceOp.SUM)
     return prob_sum
+
+
+# ---- the sample-invariant prefix in row bands over the ranks (the product's plan is sivo_segnet_prefix_bands in
+# sivo_amd/csrc/segnet.cpp — these two functions restate it for the host-side tests and for documentation)
+def band_rows(h_out, world):
+    """Rows of the prefix output (the pooling in front of the first test-time Dropout) per rank: [world + 1] boundaries.  The LAST
+    h_out % world ranks take one row more — rank 0, which also runs ORB and the host side of the frame, never the larger share."""
+    base, extra = divmod(h_out, world)
+    return [r * base + max(0, r - (world - extra)) for r in range(world + 1)]
+
+
+def band_input_rows(prefix_layers, H, y0, y1):
+    """Image rows [lo, hi) a rank needs for the rows [y0, y1) of the prefix output.  prefix_layers: the parsed layers of the prefix in
+    order (dicts with "type" and, for Convolution / Pooling, "kernel_size").  A 2x2 pooling doubles the range, a k x k convolution
+    widens it by k // 2 on both sides (clipped to the layer's height); the result is aligned to 2^poolings rows so that every pooling
+    window of the band is a pooling window of the frame."""
+    pools = sum(1 for L in prefix_layers if L["type"] == "Pooling")
+    heights = []
+    h = H
+    for L in prefix_layers:
+        heights.append(h)
+        if L["type"] == "Pooling":
+            h //= 2
+    lo, hi = y0, y1
+    for L, h_in in zip(reversed(prefix_layers), reversed(heights)):
+        if L["type"] == "Pooling":
+            lo, hi = 2 * lo, 2 * hi
+        elif L["type"] == "Convolution":
+            lo, hi = lo - L["kernel_size"] // 2, hi + L["kernel_size"] // 2
+        lo, hi = max(lo, 0), min(hi, h_in)
+    a = 1 << pools
+    return lo // a * a, min(H, (hi + a - 1) // a * a)

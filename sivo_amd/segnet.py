@@ -116,6 +116,28 @@ class BayesianSegNet:
                                          out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), _stream()))
         return out
 
+    # -- the sample-invariant prefix as row bands over ranks (include/sivo_hip.h) ---------------
+    def prefix_bands(self, world):
+        """Plan the split for `world` ranks: dict(slot_bytes, rows=[world + 1] rows of the prefix output per rank,
+        input_rows=[(first, end)] image rows each rank's band reads)."""
+        sb = C.c_size_t()
+        rows = (C.c_int32 * (world + 1))()
+        inp = (C.c_int32 * (2 * world))()
+        check(self._L.sivo_segnet_prefix_bands(self._h, world, C.byref(sb), rows, inp))
+        return dict(slot_bytes=sb.value, rows=list(rows), input_rows=[(inp[2 * r], inp[2 * r + 1]) for r in range(world)])
+
+    def prefix_band_into(self, d_bgr, rank, world, slot):
+        """This rank's band of the prefix -> slot (cuda uint8 tensor of slot_bytes), on the current stream."""
+        assert slot.is_cuda and slot.dtype == torch.uint8 and slot.is_contiguous()
+        check(self._L.sivo_segnet_prefix_band_dev(self._h, d_bgr.data_ptr(), rank, world, slot.data_ptr(), _stream()))
+
+    def forward_banded_into(self, slots, world, seed, prob_sum, n_samples=None, sample0=0, logits=None):
+        """The per-sample part of the forward on the gathered prefix (slots: cuda uint8 (world, slot_bytes), rank order)."""
+        n = self.T if n_samples is None else n_samples
+        assert slots.is_cuda and slots.dtype == torch.uint8 and slots.is_contiguous()
+        check(self._L.sivo_segnet_forward_banded_dev(self._h, slots.data_ptr(), world, n, sample0, C.c_uint64(seed), prob_sum.data_ptr(),
+                                                     logits.data_ptr() if logits is not None else None, _stream()))
+
     def segment_into(self, d_bgr, seed, out, logits=None):
         """segmentImage on device-resident data: out = (classes u8, confidence f64, entropy f64) cuda tensors (H, W).
         logits: optional cuda f32 tensor (T, classes, H, W) that receives the logits the maps were computed from."""
@@ -180,17 +202,17 @@ class BayesianSegNet:
         return mode.value, ov.value, [(r.layer.decode(), r.vmax, r.vscale, r.uscale) for r in rows[:n.value]]
 
     def guard_report(self):
-        """The load-time accuracy guard (sivo_segnet_guard_report): dict(budget, logit_max, ms, builds, layers=[dict(layer, kernel,
+        """The load-time accuracy guard (sivo_segnet_guard_report): dict(budget, predicted, logit_max, ms, builds, layers=[dict(layer, kernel,
         rel_err, rel_rms, ref_max, first_rel_err, level)]) — see include/sivo_hip.h."""
         class _Row(C.Structure):
             _fields_ = [("layer", C.c_char * 48), ("kernel", C.c_char * 24), ("rel_err", C.c_float), ("rel_rms", C.c_float),
                         ("ref_max", C.c_float), ("first_rel_err", C.c_float), ("level", C.c_int32)]
         n, builds = C.c_int32(), C.c_int32()
-        budget, lmax, ms = C.c_float(), C.c_float(), C.c_double()
-        check(self._L.sivo_segnet_guard_report(self._h, None, 0, C.byref(n), C.byref(budget), C.byref(lmax), C.byref(ms), C.byref(builds)))
+        budget, pred, lmax, ms = C.c_float(), C.c_float(), C.c_float(), C.c_double()
+        check(self._L.sivo_segnet_guard_report(self._h, None, 0, C.byref(n), C.byref(budget), C.byref(pred), C.byref(lmax), C.byref(ms), C.byref(builds)))
         rows = (_Row * max(n.value, 1))()
-        check(self._L.sivo_segnet_guard_report(self._h, rows, n.value, C.byref(n), None, None, None, None))
-        return dict(budget=budget.value, logit_max=lmax.value, ms=ms.value, builds=builds.value,
+        check(self._L.sivo_segnet_guard_report(self._h, rows, n.value, C.byref(n), None, None, None, None, None))
+        return dict(budget=budget.value, predicted=pred.value, logit_max=lmax.value, ms=ms.value, builds=builds.value,
                     layers=[dict(layer=r.layer.decode(), kernel=r.kernel.decode(), rel_err=r.rel_err, rel_rms=r.rel_rms, ref_max=r.ref_max,
                                  first_rel_err=r.first_rel_err, level=r.level) for r in rows[:n.value]])
 

@@ -65,3 +65,87 @@ def test_two_rank_sharded_frame_equals_single_process(tmp_path, T):
     np.testing.assert_allclose(r0["conf"], res["confidence"], atol=1e-6)
     np.testing.assert_allclose(r0["ent"], res["entropy"], atol=1e-5)
     assert (r0["cls"] == res["classes"]).mean() > 0.999
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The sample-invariant prefix in row bands over the ranks: rank r computes ITS rows of the prefix output from a band of
+# the image, one all-gather reassembles the prefix.  The compute leg is the oracle (plain C convolutions); the partition is
+# sivo_amd.parallel.band_rows / band_input_rows, which restate the product's plan (the GPU test checks that they agree).
+def _prefix_net(T, H, W):
+    net = oproto.parse(netspec.standard_prototxt(T, H, W))
+    cut = next(i for i, L in enumerate(net["layers"]) if L["type"] == "Dropout" and L["sample_weights_test"])
+    layers = net["layers"][:cut]
+    return dict(net, layers=layers), layers
+
+
+def _codes(mask, w_in):
+    m = mask.astype(np.int64)
+    return ((m // w_in) % 2) * 2 + (m % w_in) % 2
+
+
+def test_band_partition_properties():
+    _, layers = _prefix_net(2, 352, 1024)
+    chain = [L for L in layers if L["type"] in ("Convolution", "Pooling")]
+    for world in (1, 2, 3, 4, 8, 11):
+        rows = parallel.band_rows(44, world)
+        assert rows[0] == 0 and rows[-1] == 44 and len(rows) == world + 1
+        sizes = [b - a for a, b in zip(rows, rows[1:])]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes)
+        for r in range(world):
+            lo, hi = parallel.band_input_rows(chain, 352, rows[r], rows[r + 1])
+            assert lo % 8 == 0 and hi % 8 == 0
+            assert lo == max(0, (8 * rows[r] - 18) // 8 * 8) and hi == min(352, -((-8 * rows[r + 1] - 18) // 8) * 8)      # halo 18, aligned to 8
+    assert parallel.band_rows(44, 8) == [0, 5, 10, 15, 20, 26, 32, 38, 44]
+
+
+def _band_worker(rank, world, port, H, W, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net, layers = _prefix_net(2, H, W)
+    w = wts.synth_weights(oproto.parse(netspec.standard_prototxt(2, H, W))["layers"], 42)
+    img = np.random.default_rng(0).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    chain = [L for L in layers if L["type"] in ("Convolution", "Pooling")]
+    rows = parallel.band_rows(H // 8, world)
+    lo, hi = parallel.band_input_rows(chain, H, rows[rank], rows[rank + 1])
+    band = O.run_net(dict(net, shape=[1, 3, hi - lo, W]), w, O.preprocess(img[lo:hi], 1, hi - lo, W), 0,
+                     keep=["pool3", "pool1_mask", "pool2_mask", "pool3_mask"])
+    # the valid rows of every exchanged blob, as the product packs them: values as they are, masks as window codes
+    rmax = max(b - a for a, b in zip(rows, rows[1:]))
+    parts = {}
+    for name, level, w_in in (("pool3", 3, None), ("pool3_mask", 3, W // 4), ("pool2_mask", 2, W // 2), ("pool1_mask", 1, W)):
+        sh = 3 - level
+        x = band[name][0]
+        x = _codes(x, w_in).astype(np.float32) if w_in else x
+        first = (rows[rank] << sh) - (lo >> level)
+        n = (rows[rank + 1] - rows[rank]) << sh
+        slot = np.zeros((x.shape[0], rmax << sh, x.shape[2]), np.float32)
+        slot[:, :n] = x[:, first:first + n]
+        parts[name] = torch.from_numpy(slot)
+    gathered = {}
+    for name, t in parts.items():
+        outs = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        gathered[name] = outs
+    if rank == 0:
+        full = {}
+        for name, level in (("pool3", 3), ("pool3_mask", 3), ("pool2_mask", 2), ("pool1_mask", 1)):
+            sh = 3 - level
+            full[name] = np.concatenate([gathered[name][r].numpy()[:, :(rows[r + 1] - rows[r]) << sh] for r in range(world)], axis=1)
+        np.savez(os.path.join(out_dir, "bands.npz"), **full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_banded_prefix_equals_the_whole_image(tmp_path):
+    """world_size 2 over gloo: each rank runs the prefix (conv1_1 .. pool3 of SegNet-Standard) on its band of the image, the valid
+    rows are all-gathered, and the reassembled pooled values and pooling switches equal the whole-image prefix BIT FOR BIT."""
+    H, W = 48, 64
+    mp.spawn(_band_worker, args=(2, _free_port(), H, W, str(tmp_path)), nprocs=2, join=True)
+    net, _ = _prefix_net(2, H, W)
+    w = wts.synth_weights(oproto.parse(netspec.standard_prototxt(2, H, W))["layers"], 42)
+    img = np.random.default_rng(0).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    ref = O.run_net(dict(net, shape=[1, 3, H, W]), w, O.preprocess(img, 1, H, W), 0, keep=["pool3", "pool1_mask", "pool2_mask", "pool3_mask"])
+    got = np.load(tmp_path / "bands.npz")
+    assert np.array_equal(got["pool3"], ref["pool3"][0])
+    for name, w_in in (("pool3_mask", W // 4), ("pool2_mask", W // 2), ("pool1_mask", W)):
+        assert np.array_equal(got[name], _codes(ref[name][0], w_in).astype(np.float32)), name

@@ -1,0 +1,93 @@
+"""The sample-invariant prefix split into row bands over the ranks that share a frame's samples (include/sivo_hip.h
+sivo_segnet_prefix_bands / _prefix_band_dev / _forward_banded_dev; segnet.cpp PrefixBands).  On ONE GPU: every rank's band is
+computed by the same handle, the slots are laid side by side the way an all-gather would leave them, and the banded forward must
+equal the forward on the whole image BIT FOR BIT — logits, probability sums and every pooling mask — for every world size, at the
+full geometry of BASELINE configs[2] / configs[1]; and through the in-handle multi-device form with emulated collectives."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import prototxt as oproto
+from sivo_amd import netspec, weights as wts
+from sivo_amd.segnet import BayesianSegNet
+
+from test_gpu_segnet import _diag
+
+pytestmark = pytest.mark.gpu
+
+
+def _handle(kind, T, H, W):
+    text = (netspec.standard_prototxt if kind == "standard" else netspec.basic_prototxt)(T, H, W)
+    net = oproto.parse(text)
+    w = wts.synth_weights(net["layers"], 42)
+    return text, net, w, BayesianSegNet(prototxt=text, weights=wts.pack(net["layers"], w), T=T)
+
+
+@pytest.mark.parametrize("kind,worlds", [("standard", (2, 4, 8)), ("basic", (2, 8))])
+def test_banded_prefix_is_bit_identical_at_full_size(kind, worlds, kitti_like_bgr):
+    T, H, W = 3, 352, 1024
+    _, net, _, sn = _handle(kind, T, H, W)
+    from bench import make_inputs
+    img_y = torch.from_numpy(np.ascontiguousarray(kitti_like_bgr[:H, :W])).cuda()
+    img_x = torch.from_numpy(make_inputs(H, W)[0]).cuda()
+    masks = [L["top"][1] for L in net["layers"] if L["type"] == "Pooling"][:3]           # the prefix's poolings
+    ps_y, lg_y, _ = sn.forward(img_y, 77, n_samples=2, sample0=1, want_logits=True)
+    torch.cuda.synchronize()
+    mk_y = {m: sn.blob(m) for m in masks}
+    for world in worlds:
+        plan = sn.prefix_bands(world)
+        rows = plan["rows"]
+        assert rows[0] == 0 and rows[-1] == H // 8 and all(b > a for a, b in zip(rows, rows[1:]))
+        sizes = [b - a for a, b in zip(rows, rows[1:])]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes)                    # rank 0 never has the larger share
+        # the product's plan is the one sivo_amd.parallel restates (the CPU gloo test partitions with that)
+        from sivo_amd import parallel
+        cut = next(i for i, L in enumerate(net["layers"]) if L["type"] == "Dropout" and L["sample_weights_test"])
+        chain = [L for L in net["layers"][:cut] if L["type"] in ("Convolution", "Pooling")]
+        assert rows == parallel.band_rows(H // 8, world)
+        assert plan["input_rows"] == [parallel.band_input_rows(chain, H, rows[r], rows[r + 1]) for r in range(world)]
+        for r, (a, b) in enumerate(plan["input_rows"]):
+            assert a % 8 == 0 and b % 8 == 0 and 0 <= a <= 8 * rows[r] and 8 * rows[r + 1] <= b <= H
+            halo = 24 if kind == "standard" else 24
+            assert (a == 0 or 8 * rows[r] - a <= halo) and (b == H or b - 8 * rows[r + 1] <= halo)
+        # another frame through the whole-image forward first: the shared blobs now hold ITS prefix
+        sn.forward(img_x, 3, n_samples=2, sample0=0)
+        slots = torch.zeros((world, plan["slot_bytes"]), dtype=torch.uint8, device="cuda")
+        for r in range(world):
+            sn.prefix_band_into(img_y, r, world, slots[r])
+        ps_b = torch.empty_like(ps_y); lg_b = torch.empty_like(lg_y)
+        sn.forward_banded_into(slots, world, 77, ps_b, n_samples=2, sample0=1, logits=lg_b)
+        torch.cuda.synchronize()
+        assert torch.equal(lg_b, lg_y) and torch.equal(ps_b, ps_y), (kind, world)
+        for m in masks:
+            assert np.array_equal(sn.blob(m), mk_y[m]), (kind, world, m)
+        frac = sum(b - a for a, b in plan["input_rows"]) / world / H
+        print(f"[bands {kind} world {world}] slot {plan['slot_bytes'] / 1e6:.2f} MB per rank; a rank's band is {frac:.2f} of the image on average "
+              f"(rows of the prefix output per rank {sizes})")
+    assert not sn.take_overflow()
+
+
+@pytest.mark.parametrize("ndev,T", [(2, 4), (4, 6), (8, 12)])
+def test_multi_device_handle_splits_its_prefix(ndev, T, kitti_like_bgr):
+    """sivo_segnet_create_multi (emulated collectives on one GPU): the handle computes the prefix in ndev row bands + one all-gather
+    of the slots.  Same maps as the same handle recomputing the prefix on every device (SIVO_MULTI_BANDS=0), bit for bit, and as
+    the single-device handle up to the order of the f64 sums."""
+    H, W = 64, 128
+    text = netspec.standard_prototxt(T, H, W)
+    net = oproto.parse(text)
+    w = wts.synth_weights(net["layers"], 42)
+    flat = wts.pack(net["layers"], w)
+    sn = BayesianSegNet(prototxt=text, weights=flat, T=T)
+    with _diag(SIVO_MULTI_EMULATE="1"):
+        banded = BayesianSegNet(prototxt=text, weights=flat, T=T, devices=[0] * ndev)
+    with _diag(SIVO_MULTI_EMULATE="1", SIVO_MULTI_BANDS="0"):
+        recomputed = BayesianSegNet(prototxt=text, weights=flat, T=T, devices=[0] * ndev)
+    img = np.ascontiguousarray(kitti_like_bgr[:H, :W])
+    for seed in (5, 6):
+        a = banded.segment_image(img, seed=seed)
+        b = recomputed.segment_image(img, seed=seed)
+        c = sn.segment_image(img, seed=seed)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        np.testing.assert_allclose(a[1], c[1], atol=1e-12, rtol=0)
+        np.testing.assert_allclose(a[2], c[2], atol=1e-11, rtol=0)
+        assert (a[0] != c[0]).sum() <= 2

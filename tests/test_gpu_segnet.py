@@ -635,3 +635,48 @@ def test_fp16_overflow_is_reported_with_two_frames_in_flight(oracle):
     assert not b2.take_overflow()
     assert [r[2] for r in b2.gemm_status()[2]] == [v / 4 for v in s0]       # lowered once
     assert b2.gemm_status()[:2] == (2, 2)                  # (two frames raised the flag)
+
+
+def test_accuracy_guard_measures_every_layer_and_reroutes_an_inaccurate_plan(oracle):
+    """The load-time accuracy guard (segnet.cpp accuracy_guard, include/sivo_hip.h sivo_segnet_guard_report).
+    (i) A default handle: one row per F(4x4) / f16x3 layer with its own error against the direct fp32 kernel on the same input,
+    the predicted logit error within the budget, nothing rerouted, one plan, the cost reported.
+    (ii) A plan that really is inaccurate — the f16x3 scales forced 2^16 too SMALL (diagnostic build, SIVO_H3_BOOST=-16: the
+    operands sit in fp16's subnormal range and lose most of their lo plane; no weight family of the full-size sweep pushes the
+    F(4x4) / f16x3 arithmetic itself over the budget): UNGUARDED (SIVO_GUARD=0) its logits miss the 1e-3 tolerance
+    against the oracle; GUARDED the same configuration measures the damage layer by layer, takes those layers off F(4x4) and
+    then off f16x3, plans again, and meets the tolerance."""
+    T, H, W = 2, 96, 192
+    text = netspec.standard_prototxt(T, H, W)
+    img = _image(np.random.default_rng(8), H, W)
+    d = torch.from_numpy(img).cuda()
+
+    def logit_error(net, w, sn):
+        _, lg, _ = sn.forward(d, 31, want_logits=True)
+        torch.cuda.synchronize()
+        masks = {L["top"][1]: sn.blob(L["top"][1]) for L in net["layers"] if L["type"] == "Pooling"}
+        res = oracle.segment(net, w, img, 31, logits_name="conv1_1_D", force_masks=masks, flips={})
+        return float(np.abs(lg.cpu().numpy() - res["logits"]).max()), float(np.abs(res["logits"]).max())
+
+    net, w, sn = _make(text, T)
+    g = sn.guard_report()
+    assert g["builds"] == 1 and g["layers"] and all(r["level"] == 0 for r in g["layers"])
+    assert 0 < g["predicted"] <= g["budget"] == pytest.approx(1e-3 / 30)
+    assert {r["kernel"] for r in g["layers"]} <= {"F(4x4) f16x3 GEMM", "direct f16x3", "F(4x4) fp32 fused"}
+    assert all(0 < r["rel_err"] < 3e-5 and r["rel_rms"] < r["rel_err"] for r in g["layers"])
+    err, mag = logit_error(net, w, sn)
+    print(f"[guard] default plan: {len(g['layers'])} layers guarded in {g['ms']:.0f} ms, predicted {g['predicted']:.2e} of the logit scale "
+          f"(budget {g['budget']:.2e}), largest layer error {max(r['rel_err'] for r in g['layers']):.2e}; max|dlogit| vs oracle {err:.2e} at max|logit| {mag:.1f}")
+    assert err < LOGIT_TOL
+
+    net_u, w_u, bad = _make_env(text, T, 42, SIVO_H3_BOOST=-16, SIVO_GUARD=0)
+    assert bad.guard_report()["layers"] == []
+    err_u, _ = logit_error(net_u, w_u, bad)
+    net_g, w_g, good = _make_env(text, T, 42, SIVO_H3_BOOST=-16)
+    gg = good.guard_report()
+    err_g, _ = logit_error(net_g, w_g, good)
+    moved = [(r["layer"], r["level"], r["kernel"], r["first_rel_err"]) for r in gg["layers"] if r["level"]]
+    print(f"[guard] scales 2^-16: unguarded max|dlogit| {err_u:.2e}; guarded {err_g:.2e} after {gg['builds']} plans ({gg['ms']:.0f} ms), "
+          f"predicted {gg['predicted']:.2e}; moved {len(moved)} layers, largest first-plan layer error {max(m[3] for m in moved):.2e}")
+    assert err_u > LOGIT_TOL                      # the hazard is real ...
+    assert gg["builds"] >= 2 and moved and err_g < LOGIT_TOL and gg["predicted"] <= gg["budget"]       # ... and the guard removes it

@@ -58,7 +58,7 @@ def main():
             err = float(np.abs(lg - res["logits"]).max())
             mag = float(np.abs(res["logits"]).max())
             print(f"[bn_offset {off:g}] {'guarded' if guarded else 'UNGUARDED'}: construction {t_build:.2f} s (guard {g['ms']:.0f} ms, plans {g['builds']}), "
-                  f"budget {g['budget']:.2e} at max|logit| {g['logit_max']:.1f} (oracle {mag:.1f}); max|dlogit| vs oracle {err:.3e}; "
+                  f"predicted {g['predicted']:.2e} / budget {g['budget']:.2e} of the logit scale, max|logit| {g['logit_max']:.1f} (oracle {mag:.1f}); max|dlogit| vs oracle {err:.3e}; "
                   f"rerouted {[(r['layer'], r['level'], r['kernel']) for r in g['layers'] if r['level']]}", flush=True)
             if guarded:
                 for r in g["layers"]:
