@@ -222,8 +222,8 @@ int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow_frames, Si
  * F(4x4,3x3) or on the fp16 hi + lo split is evaluated on two built-in calibration frames x MC samples 0, 1 beside the direct fp32
  * kernel, on the same input: rel_err = max |layer - direct fp32| / max |direct fp32| (rel_rms the same in rms).  *predicted =
  * 0.5 sqrt(sum rel_err^2) estimates the error of the logits relative to their scale; *budget = 1e-3 / 30 (the tolerance at the
- * logit range of the reference configuration).  While the prediction was above the budget the largest contributors were moved
- * one level down and the handle planned again (*builds plans in all): level 0 as planned, 1 off F(4x4) (direct f16x3), 2 off
+ * logit range of the reference configuration).  While the prediction was above the budget (a third of it, once a plan has needed
+ * correction) the largest contributors were moved one level down and the handle planned again (*builds plans in all): level 0 as planned, 1 off F(4x4) (direct f16x3), 2 off
  * f16x3 as well (F(2x2) / direct fp32), 3 direct fp32 only.  Rows describe the FINAL plan (kernel = what the layer runs now);
  * first_rel_err = what the layer measured in the first plan.  *logit_max = largest |logit| of the guard's frames.
  * *guard_ms = wall time the guard added to construction; nothing runs per frame.  No rows: nothing to guard, or the guard

@@ -5,6 +5,7 @@ visible when a compute entry point is called, the call fails loudly.
 """
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsivo_hip.so")
@@ -137,6 +138,7 @@ DEBUG_SIGNATURES = {
     "sivo_debug_h3_gemm": [_i, _i, _i, _vp, _vp, _f, _vp, _i, C.POINTER(_d)],
     "sivo_debug_conv3_h3_dev": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _i, C.POINTER(_d), C.POINTER(_i)],
     "sivo_debug_conv3_h3_pk_dev": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _i, _vp, _i, C.POINTER(_d), C.POINTER(_i)],
+    "sivo_debug_lds_claims": [_vp, _i],
     "sivo_debug_conv_cls_h3_dev": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, C.POINTER(_d)],
 }
 DBG_PATH = os.path.join(_HERE, "libsivo_hip_dbg.so")
@@ -144,6 +146,7 @@ DBG_PATH = os.path.join(_HERE, "libsivo_hip_dbg.so")
 DIAG_PATH = os.path.join(_HERE, "libsivo_hip_diag.so")
 
 _libs = {}            # "product" / "diag" -> CDLL
+_tls = threading.local()
 _current = "product"
 _dbg = None
 
@@ -188,10 +191,15 @@ def _load(path):
         pass
     L = C.CDLL(path)
     L.sivo_last_error.restype = C.c_char_p
+
+    def note(result, func, args, L=L):      # every call remembers the library it went into: check() reads THAT library's error text
+        _tls.last = L
+        return result
     for name, args in SIGNATURES.items():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = C.c_int
+        fn.errcheck = note
     return L
 
 
@@ -199,7 +207,9 @@ def lib():
     """The library the calling code should use: libsivo_hip.so (build it with `python -c 'import __graft_entry__ as g; g.build()'`),
     or — inside a `with use("diag")` block — libsivo_hip_diag.so, the same sources compiled with -DSIVO_DIAG: the only build that
     reads the A/B / fault-injection switches (SIVO_NO_FUSE_*, SIVO_D3_FORM, SIVO_H3_BOOST, SIVO_MULTI_EMULATE, ...; the product
-    reads eight documented ones).  Objects (BayesianSegNet, ORBextractor, ...) keep the library they were created with."""
+    reads eight documented ones).  Every handle-owning object (BayesianSegNet, ORBextractor, MatchFrame) keeps the library it was created
+    in (`._L`): its methods, the functions that take it as an argument, its error text and its destructor go there, whatever the current
+    context is — a handle never crosses into a library with other statics or a -DSIVO_DIAG struct layout."""
     if _current not in _libs:
         _libs[_current] = _load(LIB_PATH if _current == "product" else DIAG_PATH)
     return _libs[_current]
@@ -225,10 +235,13 @@ class use:
 
 
 def check(rc):
+    """The error text comes from the library the failing call went into (this thread's last call: product or diagnostic build)."""
+    if rc == OK:
+        return
+    L = getattr(_tls, "last", None) or lib()
     if rc == ERR_INVALID_ARGUMENT:      # the reference throws std::invalid_argument there
-        raise SivoInvalidArgument(rc, lib().sivo_last_error().decode(errors="replace"))
-    if rc != OK:
-        raise SivoError(rc, lib().sivo_last_error().decode(errors="replace"))
+        raise SivoInvalidArgument(rc, L.sivo_last_error().decode(errors="replace"))
+    raise SivoError(rc, L.sivo_last_error().decode(errors="replace"))
 
 
 def require_gpu():

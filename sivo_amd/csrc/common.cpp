@@ -46,6 +46,16 @@ FirstUse::~FirstUse() {
     first_use_mutex().unlock();
 }
 
+static uint32_t g_lds_claim[LDS_CLAIM_KERNELS] = {0, 0, 0, 0};
+void lds_claim_note(int kernel, size_t bytes_per_cu) {
+    const uint32_t b = (uint32_t)bytes_per_cu;
+    uint32_t cur = __atomic_load_n(&g_lds_claim[kernel], __ATOMIC_RELAXED);
+    while ((cur == 0 || b < cur) && !__atomic_compare_exchange_n(&g_lds_claim[kernel], &cur, b, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+void lds_claims(uint32_t out[LDS_CLAIM_KERNELS], bool reset) {
+    for (int k = 0; k < LDS_CLAIM_KERNELS; ++k) out[k] = reset ? __atomic_exchange_n(&g_lds_claim[k], 0u, __ATOMIC_RELAXED) : __atomic_load_n(&g_lds_claim[k], __ATOMIC_RELAXED);
+}
+
 #ifdef SIVO_DIAG
 uint32_t *diag_words() {
     static uint32_t *w = [] {

@@ -112,6 +112,14 @@ void diag_poison_lds(hipStream_t s);
 #define SIVO_DIAG_POISON(s) ((void)0)
 #endif
 
+// The co-residency mitigation: a kernel that issues LDS-DMA in inline assembly leaves no LDS on its CU for a foreign
+// workgroup (one workgroup claiming the CU's 160 KB, or — the classifier at 64 input channels — two of its own claiming 80 KB each).
+// Its launcher notes the LDS it asked for PER CU; tests/test_gpu_coresidency.py reads the smallest note per kernel through
+// sivo_debug_lds_claims and fails when a launch leaves room beside it.
+enum { LDS_CLAIM_GEMM_H3 = 0, LDS_CLAIM_CONV3_H3, LDS_CLAIM_CLS_H3, LDS_CLAIM_CONV7_H3, LDS_CLAIM_KERNELS };
+void lds_claim_note(int kernel, size_t bytes_per_cu);
+void lds_claims(uint32_t out[LDS_CLAIM_KERNELS], bool reset);        // 0 = no launch since the last reset
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

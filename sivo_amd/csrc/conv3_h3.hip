@@ -875,6 +875,7 @@ void launch_conv3_h3(const ConvArgs &a0, hipStream_t s) {
         throw std::invalid_argument("launch_conv3_h3: packed output plane too small / no scale");
     // the whole LDS of the CU, as conv_wino4_h3.hip (no other workgroup beside a persistent one)
     const size_t lds = (size_t)160 * 1024;
+    lds_claim_note(LDS_CLAIM_CONV3_H3, lds);
     // SIVO_D3_FORM=0: the phased stage loop of the fp32-input forms (read at every launch: tests compare the two forms bit for bit)
     const int form = SIVO_DIAG_ENV("SIVO_D3_FORM") && std::atoi(SIVO_DIAG_ENV("SIVO_D3_FORM")) == 0 ? 0 : 1;
 #ifdef SIVO_DIAG

@@ -284,15 +284,20 @@ void launch_conv7_h3(const ConvArgs &a0, hipStream_t s) {
     if (!a0.wt_h3 || !(a0.h3_vscale > 0.f) || !a0.h3_flag) throw std::invalid_argument("launch_conv7_h3: weights / scale / flag missing");
     static int attr_set[64] = {0};
     if (FirstUse once(attr_set); once) {
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv7_h3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, H7_LDS));
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv7_h3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, H7_LDS));
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv7_h3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv7_h3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     ConvArgs a = a0;
     a.tiles_x = (a.W + H7_TW - 1) / H7_TW;
     a.tiles_y = (a.H + H7_TH - 1) / H7_TH;
     const int P = a.tiles_x * a.tiles_y * a.N, band = (P + 7) / 8;
-    if (a.unpool_mask) hipLaunchKernelGGL(conv7_h3_kernel<true>, dim3((unsigned)(8 * band)), dim3(H7_NTHR), H7_LDS, s, a, reinterpret_cast<const uint4 *>(a.wt_h3));
-    else hipLaunchKernelGGL(conv7_h3_kernel<false>, dim3((unsigned)(8 * band)), dim3(H7_NTHR), H7_LDS, s, a, reinterpret_cast<const uint4 *>(a.wt_h3));
+    // the kernel uses H7_LDS (116 KB); it claims the CU's whole LDS like every kernel that issues LDS-DMA in inline assembly (DESIGN 3.1e:
+    // no foreign workgroup beside it — it is a one-workgroup-per-CU kernel either way)
+    const size_t lds = (size_t)160 * 1024;
+    static_assert(H7_LDS <= 160 * 1024, "LDS");
+    lds_claim_note(LDS_CLAIM_CONV7_H3, lds);
+    if (a.unpool_mask) hipLaunchKernelGGL(conv7_h3_kernel<true>, dim3((unsigned)(8 * band)), dim3(H7_NTHR), lds, s, a, reinterpret_cast<const uint4 *>(a.wt_h3));
+    else hipLaunchKernelGGL(conv7_h3_kernel<false>, dim3((unsigned)(8 * band)), dim3(H7_NTHR), lds, s, a, reinterpret_cast<const uint4 *>(a.wt_h3));
 }
 
 }  // namespace sivo

@@ -270,10 +270,16 @@ void launch_conv_cls_h3(const ClsMcArgs &a0, hipStream_t s) {
     if (a.sum_chunk <= 0 || a.sum_chunk > (int64_t)a.H * a.W) a.sum_chunk = (int64_t)a.H * a.W;
     static int attr_set[64] = {0};
     if (FirstUse once(attr_set); once) {
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_cls_h3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, C_STAGE + 3 * C_WKS));
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_cls_h3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const int P = a.tiles_x * a.tiles_y, per = (P + 7) / 8;
-    const size_t lds = (size_t)C_STAGE + (size_t)(a.Cin / 32) * C_WKS;       // 80 KB at 64 input channels: two workgroups per CU (98 KB at 96: one)
+    // 64 input channels: 80 KB, TWO workgroups of this kernel per CU (the two halves of a CU's LDS: what turned the sum of the kernel's
+    // two phases into their maximum) — a full CU has no LDS left for anybody else, and what a half-filled CU (head / tail of
+    // the launch) may host beside one of them is covered by tests/test_gpu_coresidency.py.  Any other width would leave a gap (98 KB at 96
+    // channels): there the single workgroup claims the CU's whole LDS, like the other kernels that issue LDS-DMA in inline assembly.
+    const size_t need = (size_t)C_STAGE + (size_t)(a.Cin / 32) * C_WKS;
+    const size_t lds = 2 * need == (size_t)160 * 1024 ? need : (size_t)160 * 1024;
+    lds_claim_note(LDS_CLAIM_CLS_H3, 2 * need == (size_t)160 * 1024 ? 2 * need : lds);
 #ifdef SIVO_DIAG
     if (const char *ab = SIVO_DIAG_ENV("SIVO_CLS_ABL")) {                                     // diagnostic build: ablations of the default form
 #define CLS_ABL_CASE(n)                                                                                                                             \

@@ -433,6 +433,7 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
 #undef H3_ABL_CASE
     }
 #endif
+    lds_claim_note(LDS_CLAIM_GEMM_H3, lds);
     if (t.bm == 256 && t.bn == 256) hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256>), grid, dim3(512), lds, s, a);
     else if (t.bm == 128 && t.bn == 256) hipLaunchKernelGGL((wino4_gemm_h3_kernel<128, 256>), grid, dim3(512), lds, s, a);
     else hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 128>), grid, dim3(512), lds, s, a);

@@ -353,6 +353,17 @@ extern "C" int sivo_debug_conv_cls_h3_dev(int T, int Cin, int C, int H, int W, c
     });
 }
 
+// What the launchers of the inline-asm LDS-DMA kernels asked for per CU since the last reset (common.hpp lds_claim_note): out[0] the
+// f16x3 GEMM, [1] the direct f16x3 3x3 kernel, [2] the f16x3 classifier (per CU: both of its workgroups), [3] the f16x3 7x7 kernel;
+// the smallest request of each, 0 = not launched.
+extern "C" int sivo_debug_lds_claims(uint32_t out[4], int reset) {
+    return sivo::guarded([&] {
+        if (!out) throw std::invalid_argument("null argument");
+        sivo::lds_claims(out, reset != 0);
+        return SIVO_OK;
+    });
+}
+
 #ifdef SIVO_DIAG
 namespace sivo { void launch_occupy(int lds_bytes, int mode, int microseconds, const uint32_t *src, uint32_t *sink, hipStream_t s); }
 // diagnostic build: `launches` launches of the occupant kernel (diag_kernels.hip) back to back on a stream of its own, each holding

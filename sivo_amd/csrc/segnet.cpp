@@ -1019,13 +1019,18 @@ GuardVerdict accuracy_guard(sivo_segnet &S, const float *weights, const std::map
         // of a layer's LARGEST error reaches the logits: measured 0.3 - 0.5 over the weight families of the full-size sweep)
         constexpr double GUARD_CARRY = 0.5, REROUTED_ERR = 2e-6;
         double predicted = GUARD_CARRY * std::sqrt(sum2);
-        if (!(predicted <= budget)) {
+        // The prediction is an estimate: found / predicted was 0.6 - 0.9 for the weight families of the sweep and 2.4 for a plan whose
+        // scales were forced wrong (tests/test_gpu_segnet.py).  A plan that never needed correction is held to the budget itself; once a
+        // plan HAS needed correction the weights (or scales) are not of the kind the estimate was fitted on, and the corrected plan is
+        // held to a third of it.
+        const double target = levels_in.empty() ? budget : budget / 3.0;
+        if (!(predicted <= target)) {
             // take the largest contributors one level down until the prediction (a rerouted layer counted at the direct kernels' ~2e-6) fits
             std::sort(by_err.begin(), by_err.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
             double s2 = sum2;
             for (const auto &[err, oi] : by_err) {
                 const Op &op = S.ops[oi];
-                if (GUARD_CARRY * std::sqrt(std::max(s2, 0.0)) <= budget || !(err > REROUTED_ERR)) break;
+                if (GUARD_CARRY * std::sqrt(std::max(s2, 0.0)) <= budget / 3.0 || !(err > REROUTED_ERR)) break;
                 if (op.guard_level >= 3) continue;
                 const int next = (op.wino4 || op.wino4f) ? std::max(1, op.guard_level + 1) : d3_runs(op) ? std::max(2, op.guard_level + 1) : 3;
                 verdict.levels[op.name] = next;

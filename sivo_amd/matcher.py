@@ -78,7 +78,8 @@ class MatchFrame:
         self.desc = _a(desc, np.uint8).reshape(self.n, 32)
         self.scale, self.sigma2, self.inv_sigma2 = _a(scale, np.float32), _a(sigma2, np.float32), _a(inv_sigma2, np.float32)
         h = C.c_void_p()
-        check(lib().sivo_mframe_create(_p(self.keys), self.n, _p(self.u_right), _p(self.desc), *[float(b) for b in bounds],
+        self._L = lib()          # the library this object lives in
+        check(self._L.sivo_mframe_create(_p(self.keys), self.n, _p(self.u_right), _p(self.desc), *[float(b) for b in bounds],
                                        _p(self.scale), _p(self.sigma2), _p(self.inv_sigma2), len(self.scale), device, C.byref(h)))
         self._h = h
 
@@ -86,7 +87,7 @@ class MatchFrame:
         h = getattr(self, "_h", None)
         if h:
             try:
-                lib().sivo_mframe_destroy(h)
+                self._L.sivo_mframe_destroy(h)
             except Exception:
                 pass
             self._h = None
@@ -94,7 +95,7 @@ class MatchFrame:
     def features_in_area(self, x, y, r, min_level=-1, max_level=-1):
         """Frame::GetFeaturesInArea (Frame.cc:326-390)."""
         out = np.empty(self.n + 1, np.int32); n = C.c_int32(0)
-        check(lib().sivo_mframe_features_in_area(self._h, x, y, r, min_level, max_level, _p(out), out.size, C.byref(n)))
+        check(self._L.sivo_mframe_features_in_area(self._h, x, y, r, min_level, max_level, _p(out), out.size, C.byref(n)))
         return out[:n.value].copy()
 
 
@@ -116,7 +117,7 @@ def search(train, queries, query_desc, rule, cand_begin=None, cand_end=None, can
     bl = None if blocked is None else _a(blocked, np.uint8)
     mq = np.empty(nq, np.int32); mt = np.empty(train.n, np.int32); bd = np.empty(nq, np.int32); sd = np.empty(nq, np.int32)
     nm, rounds = C.c_int32(0), C.c_int32(0)
-    check(lib().sivo_search(train._h, _p(q), _p(qd), nq, _p(cb), _p(ce), _p(ci), nc, C.byref(r), _p(bl), _p(mq), _p(mt), _p(bd), _p(sd),
+    check(train._L.sivo_search(train._h, _p(q), _p(qd), nq, _p(cb), _p(ce), _p(ci), nc, C.byref(r), _p(bl), _p(mq), _p(mt), _p(bd), _p(sd),
                             C.byref(nm), C.byref(rounds)))
     return {"match_query": mq, "match_train": mt, "best_dist": bd, "second_dist": sd, "n_matches": nm.value, "rounds": rounds.value}
 
@@ -124,7 +125,7 @@ def search(train, queries, query_desc, rule, cand_begin=None, cand_end=None, can
 def search_by_projection_mappoints(F, track_in_view, px, py, pxr, level, view_cos, mp_desc, mp_obs, th, nn_ratio, occ_obs):
     """ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (ORBmatcher.cc:44-127)."""
     occ = _a(occ_obs, np.int32).copy(); match = np.empty(F.n, np.int32); nm = C.c_int32(0)
-    check(lib().sivo_search_by_projection_mappoints(F._h, len(px), _p(_a(track_in_view, np.uint8)), _p(_a(px, np.float32)),
+    check(F._L.sivo_search_by_projection_mappoints(F._h, len(px), _p(_a(track_in_view, np.uint8)), _p(_a(px, np.float32)),
                                                     _p(_a(py, np.float32)), _p(_a(pxr, np.float32)), _p(_a(level, np.int32)),
                                                     _p(_a(view_cos, np.float32)), _p(_a(mp_desc, np.uint8)), _p(_a(mp_obs, np.int32)),
                                                     th, nn_ratio, _p(occ), _p(match), C.byref(nm)))
@@ -135,7 +136,7 @@ def search_by_projection_frame(Cur, valid, u, v, inv_z, last_octave, last_angle,
                                check_ori, occ_obs):
     """ORBmatcher::SearchByProjection(Frame &Current, const Frame &Last, th, bMono) (ORBmatcher.cc:1278-1418)."""
     occ = _a(occ_obs, np.int32).copy(); match = np.empty(Cur.n, np.int32); nm = C.c_int32(0)
-    check(lib().sivo_search_by_projection_frame(Cur._h, len(u), _p(_a(valid, np.uint8)), _p(_a(u, np.float32)), _p(_a(v, np.float32)),
+    check(Cur._L.sivo_search_by_projection_frame(Cur._h, len(u), _p(_a(valid, np.uint8)), _p(_a(u, np.float32)), _p(_a(v, np.float32)),
                                                 _p(_a(inv_z, np.float32)), _p(_a(last_octave, np.int32)), _p(_a(last_angle, np.float32)),
                                                 _p(_a(mp_desc, np.uint8)), _p(_a(mp_obs, np.int32)), th, int(forward), int(backward), bf,
                                                 int(check_ori), _p(occ), _p(match), C.byref(nm)))
@@ -145,7 +146,7 @@ def search_by_projection_frame(Cur, valid, u, v, inv_z, last_octave, last_angle,
 def search_by_projection_reloc(Cur, valid, u, v, pred_level, kf_angle, mp_desc, th, orb_dist, check_ori, occupied):
     """ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1420-1543)."""
     occ = _a(occupied, np.uint8).copy(); match = np.empty(Cur.n, np.int32); nm = C.c_int32(0)
-    check(lib().sivo_search_by_projection_reloc(Cur._h, len(u), _p(_a(valid, np.uint8)), _p(_a(u, np.float32)), _p(_a(v, np.float32)),
+    check(Cur._L.sivo_search_by_projection_reloc(Cur._h, len(u), _p(_a(valid, np.uint8)), _p(_a(u, np.float32)), _p(_a(v, np.float32)),
                                                 _p(_a(pred_level, np.int32)), _p(_a(kf_angle, np.float32)), _p(_a(mp_desc, np.uint8)), th,
                                                 int(orb_dist), int(check_ori), _p(occ), _p(match), C.byref(nm)))
     return nm.value, match, occ
@@ -154,7 +155,7 @@ def search_by_projection_reloc(Cur, valid, u, v, pred_level, kf_angle, mp_desc, 
 def search_by_projection_kf(KF, valid, u, v, pred_level, mp_desc, th, matched):
     """ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:286-399)."""
     m = _a(matched, np.uint8).copy(); match = np.empty(KF.n, np.int32); nm = C.c_int32(0)
-    check(lib().sivo_search_by_projection_kf(KF._h, len(u), _p(_a(valid, np.uint8)), _p(_a(u, np.float32)), _p(_a(v, np.float32)),
+    check(KF._L.sivo_search_by_projection_kf(KF._h, len(u), _p(_a(valid, np.uint8)), _p(_a(u, np.float32)), _p(_a(v, np.float32)),
                                              _p(_a(pred_level, np.int32)), _p(_a(mp_desc, np.uint8)), int(th), _p(m), _p(match),
                                              C.byref(nm)))
     return nm.value, match, m
@@ -164,7 +165,7 @@ def fuse(KF, valid, u, v, ur, pred_level, mp_desc, th, scw_variant):
     """ORBmatcher::Fuse (ORBmatcher.cc:787-929 / :931-1053) up to the choice of the keypoint."""
     n = len(u)
     bi = np.empty(n, np.int32); bd = np.empty(n, np.int32); nf = C.c_int32(0)
-    check(lib().sivo_fuse(KF._h, n, _p(_a(valid, np.uint8)), _p(_a(u, np.float32)), _p(_a(v, np.float32)),
+    check(KF._L.sivo_fuse(KF._h, n, _p(_a(valid, np.uint8)), _p(_a(u, np.float32)), _p(_a(v, np.float32)),
                           _p(_a(ur, np.float32)) if ur is not None else None, _p(_a(pred_level, np.int32)), _p(_a(mp_desc, np.uint8)),
                           th, int(scw_variant), _p(bi), _p(bd), C.byref(nf)))
     return nf.value, bi, bd
@@ -173,7 +174,7 @@ def fuse(KF, valid, u, v, ur, pred_level, mp_desc, th, scw_variant):
 def search_by_sim3_dir(KF, valid, u, v, pred_level, mp_desc, th):
     """One direction of ORBmatcher::SearchBySim3 (ORBmatcher.cc:1102-1176)."""
     out = np.empty(len(u), np.int32)
-    check(lib().sivo_search_by_sim3_dir(KF._h, len(u), _p(_a(valid, np.uint8)), _p(_a(u, np.float32)), _p(_a(v, np.float32)),
+    check(KF._L.sivo_search_by_sim3_dir(KF._h, len(u), _p(_a(valid, np.uint8)), _p(_a(u, np.float32)), _p(_a(v, np.float32)),
                                         _p(_a(pred_level, np.int32)), _p(_a(mp_desc, np.uint8)), th, _p(out)))
     return out
 
@@ -193,7 +194,7 @@ def search_by_bow_kf_frame(off1, idx1, off2, idx2, kf_valid, keys_kf, desc_kf, F
     keys_kf = _a(keys_kf, KP_DTYPE)
     match_f = np.empty(F.n, np.int32); nm = C.c_int32(0)
     off1 = _a(off1, np.int32)
-    check(lib().sivo_search_by_bow_kf_frame(len(off1) - 1, _p(off1), _p(_a(idx1, np.int32)), _p(_a(off2, np.int32)), _p(_a(idx2, np.int32)),
+    check(F._L.sivo_search_by_bow_kf_frame(len(off1) - 1, _p(off1), _p(_a(idx1, np.int32)), _p(_a(off2, np.int32)), _p(_a(idx2, np.int32)),
                                             _p(_a(kf_valid, np.uint8)), _p(keys_kf), _p(_a(desc_kf, np.uint8)), len(keys_kf), F._h,
                                             nn_ratio, int(check_ori), _p(match_f), C.byref(nm)))
     return nm.value, match_f
@@ -204,7 +205,7 @@ def search_by_bow_kf_kf(off1, idx1, off2, idx2, valid1, keys1, desc1, valid2, KF
     keys1 = _a(keys1, KP_DTYPE)
     m12 = np.empty(len(keys1), np.int32); nm = C.c_int32(0)
     off1 = _a(off1, np.int32)
-    check(lib().sivo_search_by_bow_kf_kf(len(off1) - 1, _p(off1), _p(_a(idx1, np.int32)), _p(_a(off2, np.int32)), _p(_a(idx2, np.int32)),
+    check(KF2._L.sivo_search_by_bow_kf_kf(len(off1) - 1, _p(off1), _p(_a(idx1, np.int32)), _p(_a(off2, np.int32)), _p(_a(idx2, np.int32)),
                                          _p(_a(valid1, np.uint8)), _p(keys1), _p(_a(desc1, np.uint8)), len(keys1), _p(_a(valid2, np.uint8)),
                                          KF2._h, nn_ratio, int(check_ori), _p(m12), C.byref(nm)))
     return nm.value, m12
@@ -215,7 +216,7 @@ def search_for_triangulation(off1, idx1, off2, idx2, keys1, ur1, has_mp1, desc1,
     keys1 = _a(keys1, KP_DTYPE)
     m12 = np.empty(len(keys1), np.int32); nm = C.c_int32(0)
     off1 = _a(off1, np.int32)
-    check(lib().sivo_search_for_triangulation(len(off1) - 1, _p(off1), _p(_a(idx1, np.int32)), _p(_a(off2, np.int32)), _p(_a(idx2, np.int32)),
+    check(KF2._L.sivo_search_for_triangulation(len(off1) - 1, _p(off1), _p(_a(idx1, np.int32)), _p(_a(off2, np.int32)), _p(_a(idx2, np.int32)),
                                               _p(keys1), _p(_a(ur1, np.float32)) if ur1 is not None else None, _p(_a(has_mp1, np.uint8)),
                                               _p(_a(desc1, np.uint8)), len(keys1), KF2._h, _p(_a(has_mp2, np.uint8)),
                                               _p(_a(F12, np.float32)), ex, ey, int(only_stereo), int(check_ori), _p(m12), C.byref(nm)))

@@ -21,18 +21,19 @@ class ORBextractor:
 
     def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th_fast=20, min_th_fast=7, device=0):
         h = C.c_void_p()
-        check(lib().sivo_orb_create(nfeatures, C.c_float(scale_factor), nlevels, ini_th_fast, min_th_fast, device, C.byref(h)))
+        self._L = lib()          # the library this object lives in (product, or the diagnostic build inside `with _lib.use("diag")`)
+        check(self._L.sivo_orb_create(nfeatures, C.c_float(scale_factor), nlevels, ini_th_fast, min_th_fast, device, C.byref(h)))
         self._h = h
         self.nfeatures, self.nlevels, self._scale_factor = nfeatures, nlevels, scale_factor
         arrs = [np.empty(nlevels, np.float32) for _ in range(4)] + [np.empty(nlevels, np.int32)]
-        check(lib().sivo_orb_tables(h, *[_p(a) for a in arrs]))
+        check(self._L.sivo_orb_tables(h, *[_p(a) for a in arrs]))
         self._scale, self._inv_scale, self._sigma2, self._inv_sigma2, self.features_per_level = arrs
 
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
             try:
-                lib().sivo_orb_destroy(h)
+                self._L.sivo_orb_destroy(h)
             except Exception:      # interpreter shutdown: the module globals may already be gone
                 pass
             self._h = None
@@ -56,39 +57,39 @@ class ORBextractor:
                 return kps[:0], desc[:0]
             assert image.dtype == np.uint8 and image.ndim == 2, "image must be CV_8UC1"
             img = image if image.strides[1] == 1 else np.ascontiguousarray(image)
-            check(lib().sivo_orb_extract(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0], _p(kps), _p(desc), cap, C.byref(n)))
+            check(self._L.sivo_orb_extract(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0], _p(kps), _p(desc), cap, C.byref(n)))
         else:
             import torch
             assert image.is_cuda and image.dtype == torch.uint8 and image.dim() == 2 and image.stride(1) == 1
-            check(lib().sivo_orb_extract_dev(self._h, image.data_ptr(), image.shape[0], image.shape[1], image.stride(0),
+            check(self._L.sivo_orb_extract_dev(self._h, image.data_ptr(), image.shape[0], image.shape[1], image.stride(0),
                                              _p(kps), _p(desc), cap, C.byref(n),
                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return kps[:n.value].copy(), desc[:n.value].copy()
 
     def profile(self, enable=True):
         """Bracket the extractor's kernel groups with HIP events from now on (and clear the accumulators)."""
-        check(lib().sivo_orb_profile(self._h, int(bool(enable))))
+        check(self._L.sivo_orb_profile(self._h, int(bool(enable))))
 
     def profile_read(self):
         """{group: mean ms per extraction}, extractions, mean keypoints — groups: pyramid, blur, fast, angle, descriptor."""
         ms = (C.c_double * 5)(); n = C.c_int32(0); k = C.c_double(0)
-        check(lib().sivo_orb_profile_read(self._h, ms, C.byref(n), C.byref(k)))
+        check(self._L.sivo_orb_profile_read(self._h, ms, C.byref(n), C.byref(k)))
         return dict(zip(("pyramid", "blur", "fast", "angle", "descriptor"), list(ms))), n.value, k.value
 
     def image_pyramid(self, level, with_border=False):
         """mvImagePyramid[level] of the last extraction (interior view unless with_border)."""
         r, c = C.c_int32(), C.c_int32()
-        check(lib().sivo_orb_level(self._h, level, None, 0, C.byref(r), C.byref(c)))
+        check(self._L.sivo_orb_level(self._h, level, None, 0, C.byref(r), C.byref(c)))
         b = EDGE_THRESHOLD
         buf = np.empty((r.value + 2 * b, c.value + 2 * b), np.uint8)
-        check(lib().sivo_orb_level(self._h, level, _p(buf), buf.size, C.byref(r), C.byref(c)))
+        check(self._L.sivo_orb_level(self._h, level, _p(buf), buf.size, C.byref(r), C.byref(c)))
         return buf if with_border else buf[b:b + r.value, b:b + c.value]
 
     def candidates(self, level):
         n = C.c_int32(0)
-        check(lib().sivo_orb_candidates(self._h, level, None, 0, C.byref(n)))
+        check(self._L.sivo_orb_candidates(self._h, level, None, 0, C.byref(n)))
         out = np.zeros(max(n.value, 1), KP_DTYPE)
-        check(lib().sivo_orb_candidates(self._h, level, _p(out), n.value, C.byref(n)))
+        check(self._L.sivo_orb_candidates(self._h, level, _p(out), n.value, C.byref(n)))
         return out[:n.value]
 
 
@@ -107,7 +108,7 @@ def stereo_match(left, right, kpL, descL, kpR, descR, bf, b):
     descL = np.ascontiguousarray(descL, np.uint8); descR = np.ascontiguousarray(descR, np.uint8)
     nL = len(kpL)
     uR = np.empty(nL, np.float32); depth = np.empty(nL, np.float32); best = np.empty(nL, np.int32)
-    check(lib().sivo_stereo_match(left._h, right._h, _p(kpL), _p(descL), nL, _p(kpR), _p(descR), len(kpR),
+    check(left._L.sivo_stereo_match(left._h, right._h, _p(kpL), _p(descL), nL, _p(kpR), _p(descR), len(kpR),
                                   C.c_float(bf), C.c_float(b), _p(uR), _p(depth), _p(best)))
     return uR, depth, best
 
@@ -118,7 +119,7 @@ def stereo_match_begin(left, right, kpL, descL, kpR, descR, bf, b):
     descL = np.ascontiguousarray(descL, np.uint8); descR = np.ascontiguousarray(descR, np.uint8)
     nL = len(kpL)
     uR = np.empty(nL, np.float32); depth = np.empty(nL, np.float32); best = np.empty(nL, np.int32); sad = np.empty(nL, np.int32)
-    check(lib().sivo_stereo_match_begin(left._h, right._h, _p(kpL), _p(descL), nL, _p(kpR), _p(descR), len(kpR),
+    check(left._L.sivo_stereo_match_begin(left._h, right._h, _p(kpL), _p(descL), nL, _p(kpR), _p(descR), len(kpR),
                                         C.c_float(bf), C.c_float(b), _p(uR), _p(depth), _p(best), _p(sad)))
     return uR, depth, best, sad
 

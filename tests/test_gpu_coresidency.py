@@ -1,0 +1,114 @@
+"""The co-residency mitigation of DESIGN 3.1e, guarded deterministically, and the frame's kernels beside each other.
+
+Round 3 found frames that were not reproducible when a wino4_bridge_kernel workgroup shared a CU with the f16x3 GEMM's LDS-DMA
+stream (the bridge lost one LDS dword).  The mechanism is still open (tools/coresident_repro.py, DESIGN 3.1e: neither the bridge
+beside synthetic LDS / LDS-DMA occupants nor a self-checking copy of its access pattern beside the real GEMM reproduces it); the
+product avoids the constellation: every kernel that issues LDS-DMA in inline assembly leaves no LDS on its CU for a foreign
+workgroup.
+  * test_lds_dma_kernels_leave_no_lds_beside_them — the launchers note the dynamic LDS they ask for per CU; one frame of each
+    reference net later every note must be the CU's whole 160 KB.  Fails the moment somebody removes the claim from a launcher.
+  * test_frame_kernels_beside_each_other — the one pairing that is NOT excluded by construction: the f16x3 classifier runs two
+    80 KB workgroups per CU, and at the head / tail of its launch a CU may hold one of them plus foreign workgroups (ORB, stereo
+    matching, the entropy gate on its high-priority stream).  The whole frame is run with the ORB / gate work started at a sweep of
+    delays so that it lands on every phase of the network, the classifier included: class / confidence / entropy maps, keys,
+    descriptors, stereo matches and the gate's outputs must equal the solo results bit for bit, every time."""
+import ctypes as C
+import threading
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from sivo_amd import _lib, netspec, selection, weights as wts
+from sivo_amd.frame import StereoFramePipeline
+from sivo_amd.segnet import BayesianSegNet
+
+pytestmark = pytest.mark.gpu
+H, W = 352, 1024
+WHOLE_LDS = 160 * 1024
+
+
+def _net(kind, T):
+    text = (netspec.standard_prototxt if kind == "standard" else netspec.basic_prototxt)(T, H, W)
+    layers = netspec.parse_layers(text)
+    return BayesianSegNet(prototxt=text, weights=wts.pack(layers, wts.synth_weights(layers, 42)), T=T)
+
+
+def _maps():
+    return (torch.empty((H, W), dtype=torch.uint8, device="cuda"), torch.empty((H, W), dtype=torch.float64, device="cuda"),
+            torch.empty((H, W), dtype=torch.float64, device="cuda"))
+
+
+def test_lds_dma_kernels_leave_no_lds_beside_them():
+    from bench import make_inputs
+    d_bgr = torch.from_numpy(make_inputs(H, W)[0]).cuda()
+    out = (C.c_uint32 * 4)()
+    _lib.check(_lib.dbg().sivo_debug_lds_claims(out, 1))
+    m = _maps()
+    std = _net("standard", 4)
+    std.segment_into(d_bgr, 1, m)
+    torch.cuda.synchronize()
+    _lib.check(_lib.dbg().sivo_debug_lds_claims(out, 1))
+    gemm, conv3, cls, conv7 = list(out)
+    assert (gemm, conv3, cls) == (WHOLE_LDS, WHOLE_LDS, WHOLE_LDS) and conv7 == 0, list(out)       # (no 7x7 layer in SegNet-Standard)
+    del std
+    basic = _net("basic", 2)
+    basic.segment_into(d_bgr, 1, m)
+    torch.cuda.synchronize()
+    _lib.check(_lib.dbg().sivo_debug_lds_claims(out, 1))
+    assert out[3] == WHOLE_LDS and all(v in (0, WHOLE_LDS) for v in out), list(out)
+
+
+def test_frame_kernels_beside_each_other():
+    from bench import make_inputs
+    bgr, left, right = make_inputs(H, W)
+    d_bgr, d_left, d_right = (torch.from_numpy(a).cuda() for a in (bgr, left, right))
+    sn = _net("standard", 12)
+    solo = _maps()
+    sn.segment_into(d_bgr, 2000, solo)
+    torch.cuda.synchronize()
+    fp0 = StereoFramePipeline()
+    ref = fp0.finish(fp0.start_orb(d_left, d_right), solo[0].cpu().numpy())       # ORB + matching with nothing beside them
+    k, d = ref["keys"], ref["depth"]
+    xyz = np.stack([(k["x"] - 498.692) * d / 718.856, (k["y"] - 173.215) * d / 718.856, d], 1).astype(np.float64)
+    gate_args = (np.eye(6) * 1e-4, 718.856, 718.856, 386.1448 / 718.856, fp0.ex_l.GetScaleSigmaSquares(), 4.0)
+    gate_ref = selection.entropy_gate_map_dev(k, d, xyz, solo[2], *gate_args)
+    assert not sn.take_overflow()
+
+    # the network alone: how long a frame is, so that the sweep below covers it end to end
+    t0 = time.perf_counter()
+    for _ in range(3):
+        sn.segment_into(d_bgr, 2000, _maps())
+    torch.cuda.synchronize()
+    frame_s = (time.perf_counter() - t0) / 3
+    delays = [f * frame_s for f in (0.0, 0.3, 0.6, 0.8, 0.88, 0.94, 1.0)]
+    checked = 0
+    for delay in delays:
+        for _ in range(3):
+            fp = StereoFramePipeline(start_delay_s=delay)
+            m = _maps()
+            stop = threading.Event()
+            gate_bad = []
+
+            def gate_loop():
+                # the entropy gate (its own high-priority stream) over and over while the frame runs, on the solo frame's map
+                while not stop.is_set():
+                    g = selection.entropy_gate_map_dev(k, d, xyz, solo[2], *gate_args)
+                    if not all(np.array_equal(a, b) for a, b in zip(g, gate_ref)):
+                        gate_bad.append(1)
+            th = threading.Thread(target=gate_loop)
+            th.start()
+            sn.segment_into(d_bgr, 2000, m)
+            pending = fp.start_orb(d_left, d_right)
+            torch.cuda.synchronize()
+            got = fp.finish(pending, m[0].cpu().numpy())
+            stop.set(); th.join()
+            assert all(torch.equal(a, b) for a, b in zip(m, solo)), f"maps differ from the solo frame (ORB started {1e3 * delay:.1f} ms into the frame)"
+            for key in ("keys", "desc", "right", "depth"):
+                assert got[key].tobytes() == ref[key].tobytes(), (key, delay)
+            assert not gate_bad
+            checked += 1
+    assert not sn.take_overflow()
+    print(f"[coresident] {checked} frames with ORB / stereo matching / the entropy gate started 0 .. {1e3 * delays[-1]:.1f} ms into a {1e3 * frame_s:.2f} ms frame: "
+          "maps, keys, descriptors, matches and gate outputs equal the solo results bit for bit")

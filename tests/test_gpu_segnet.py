@@ -679,4 +679,4 @@ def test_accuracy_guard_measures_every_layer_and_reroutes_an_inaccurate_plan(ora
     print(f"[guard] scales 2^-16: unguarded max|dlogit| {err_u:.2e}; guarded {err_g:.2e} after {gg['builds']} plans ({gg['ms']:.0f} ms), "
           f"predicted {gg['predicted']:.2e}; moved {len(moved)} layers, largest first-plan layer error {max(m[3] for m in moved):.2e}")
     assert err_u > LOGIT_TOL                      # the hazard is real ...
-    assert gg["builds"] >= 2 and moved and err_g < LOGIT_TOL and gg["predicted"] <= gg["budget"]       # ... and the guard removes it
+    assert gg["builds"] >= 2 and moved and err_g < LOGIT_TOL and gg["predicted"] <= gg["budget"] / 3   # ... and the guard removes it

@@ -22,11 +22,16 @@ def main():
     from sivo_amd.segnet import BayesianSegNet
     from bench import make_inputs
     H, W, T = 352, 1024, 2
-    offsets = [float(x) for x in sys.argv[1:]] or [0.0, 3.0, 30.0, 100.0]
+    args = sys.argv[1:] or ["0", "3", "30", "100"]
+    boosts = [int(a.split(":")[1]) for a in args if a.startswith("boost:")]         # boost:-16 = the f16x3 scales forced 2^-16 (diagnostic build)
+    offsets = [float(x) for x in args if not x.startswith("boost:")]
     text = netspec.standard_prototxt(T, H, W)
     img = make_inputs(H, W)[0]
     d = torch.from_numpy(img).cuda()
-    for off in offsets:
+    for off in offsets + [("boost", b) for b in boosts]:
+        boost = None
+        if isinstance(off, tuple):
+            boost, off = off[1], 0.0
         net = oproto.parse(text)
         w = wts.synth_weights(net["layers"], 42)
         if off:
@@ -40,13 +45,17 @@ def main():
         res = None
         for guarded in (True, False):
             t0 = time.perf_counter()
-            if guarded:
+            if boost is not None:
+                os.environ["SIVO_H3_BOOST"] = str(boost)
+            if guarded and boost is None:
                 sn = BayesianSegNet(prototxt=text, weights=flat, T=T)
             else:
-                os.environ["SIVO_GUARD"] = "0"
+                if not guarded:
+                    os.environ["SIVO_GUARD"] = "0"
                 with _lib.use("diag"):
                     sn = BayesianSegNet(prototxt=text, weights=flat, T=T)
-                os.environ.pop("SIVO_GUARD")
+                os.environ.pop("SIVO_GUARD", None)
+            os.environ.pop("SIVO_H3_BOOST", None)
             t_build = time.perf_counter() - t0
             g = sn.guard_report()
             _, lg, _ = sn.forward(d, 11, want_logits=True)
@@ -57,7 +66,7 @@ def main():
             res = O.segment(net, w, img, 11, logits_name="conv1_1_D", force_masks=masks, flips=flips, shared_prefix=True)
             err = float(np.abs(lg - res["logits"]).max())
             mag = float(np.abs(res["logits"]).max())
-            print(f"[bn_offset {off:g}] {'guarded' if guarded else 'UNGUARDED'}: construction {t_build:.2f} s (guard {g['ms']:.0f} ms, plans {g['builds']}), "
+            print(f"[{'bn_offset %g' % off if boost is None else 'scales 2^%d' % boost}] {'guarded' if guarded else 'UNGUARDED'}: construction {t_build:.2f} s (guard {g['ms']:.0f} ms, plans {g['builds']}), "
                   f"predicted {g['predicted']:.2e} / budget {g['budget']:.2e} of the logit scale, max|logit| {g['logit_max']:.1f} (oracle {mag:.1f}); max|dlogit| vs oracle {err:.3e}; "
                   f"rerouted {[(r['layer'], r['level'], r['kernel']) for r in g['layers'] if r['level']]}", flush=True)
             if guarded:
