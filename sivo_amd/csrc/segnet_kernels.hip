@@ -668,28 +668,66 @@ void launch_mask_to_index(const uint8_t *mask, float *out, int64_t total, int Ho
                        Ho, Wo, Win);
 }
 
-// Row bands of the sample-invariant prefix (segnet.cpp PrefixBands): the slots of all ranks -> one full (C, H, W) blob.  A slot holds,
-// at item_off, this blob's band as [C][rows_max][W] elements of `elt` bytes (rows past the band's own count are padding); rank r owns
-// the rows [tab.y0[r], tab.y0[r + 1]).  One thread per 16 bytes of a row (W * elt % 16 == 0).
-__global__ __launch_bounds__(256) void unpack_bands_kernel(unsigned char *dst, const unsigned char *slots, size_t slot_bytes, size_t item_off,
-                                                           int elt, int C, int H, int W, int rows_max, BandTable tab) {
-    const int row_vec = W * elt / 16;
-    const int64_t total = (int64_t)C * H * row_vec;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+// Row bands of the sample-invariant prefix (segnet.cpp PrefixBands).
+// pack: the valid rows of a rank's band blobs -> its slot ([C][rows_max][W] per item, rows past the band's own count are padding);
+// unpack: the slots of all ranks -> the full (C, H, W) blobs; rank r owns the rows [y0[r], y0[r + 1]) of an item.  The item flagged
+// `drop` (the fork pooling's values) is not stored as it is: its per-sample dropout (the pooling kernel's own: same counter-based
+// word per element and global sample) is applied on the way and the n per-sample copies are written.
+// One launch each, one thread per 16 bytes of a row (W * elt % 16 == 0).
+__global__ __launch_bounds__(256) void pack_bands_kernel(BandPack p, unsigned char *slot) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int k = 0;
+    while (k < p.n_items && i >= p.item[k].vecs) { i -= p.item[k].vecs; ++k; }
+    if (k >= p.n_items) return;
+    const BandPackItem &it = p.item[k];
+    const int row_vec = it.W * it.elt / 16;
     const int v = (int)(i % row_vec);
-    const int y = (int)((i / row_vec) % H);
-    const int c = (int)(i / ((int64_t)row_vec * H));
-    int r = 0;
-    while (r + 1 < tab.world && y >= tab.y0[r + 1]) ++r;
-    const unsigned char *src = slots + (size_t)r * slot_bytes + item_off + ((size_t)((int64_t)c * rows_max + (y - tab.y0[r])) * row_vec + v) * 16;
-    *reinterpret_cast<uint4 *>(dst + (size_t)i * 16) = *reinterpret_cast<const uint4 *>(src);
+    const int y = (int)((i / row_vec) % it.n_rows);
+    const int c = (int)(i / ((int64_t)row_vec * it.n_rows));
+    const unsigned char *src = it.src + ((size_t)((int64_t)c * it.src_H + it.row0 + y) * row_vec + v) * 16;
+    *reinterpret_cast<uint4 *>(slot + it.off + ((size_t)((int64_t)c * it.rows_max + y) * row_vec + v) * 16) = *reinterpret_cast<const uint4 *>(src);
 }
-void launch_unpack_bands(void *dst, const void *slots, size_t slot_bytes, size_t item_off, int elt, int C, int H, int W, int rows_max,
-                         const BandTable &tab, hipStream_t s) {
-    const int64_t total = (int64_t)C * H * (W * elt / 16);
-    hipLaunchKernelGGL(unpack_bands_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (unsigned char *)dst, (const unsigned char *)slots,
-                       slot_bytes, item_off, elt, C, H, W, rows_max, tab);
+void launch_pack_bands(const BandPack &p, void *slot, hipStream_t s) {
+    int64_t total = 0;
+    for (int k = 0; k < p.n_items; ++k) total += p.item[k].vecs;
+    if (total) hipLaunchKernelGGL(pack_bands_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, (unsigned char *)slot);
+}
+
+__global__ __launch_bounds__(256) void unpack_bands_kernel(BandUnpack u, const unsigned char *slots) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int k = 0;
+    while (k < u.n_items && i >= u.item[k].vecs) { i -= u.item[k].vecs; ++k; }
+    if (k >= u.n_items) return;
+    const BandUnpackItem &it = u.item[k];
+    const int row_vec = it.W * it.elt / 16;
+    const int v = (int)(i % row_vec);
+    const int y = (int)((i / row_vec) % it.H);
+    const int c = (int)(i / ((int64_t)row_vec * it.H));
+    int r = 0;
+    while (r + 1 < u.world && y >= it.y0[r + 1]) ++r;
+    const uint4 q = *reinterpret_cast<const uint4 *>(slots + (size_t)r * u.slot_bytes + it.off + ((size_t)((int64_t)c * it.rows_max + (y - it.y0[r])) * row_vec + v) * 16);
+    if (!it.drop) {
+        *reinterpret_cast<uint4 *>(it.dst + (size_t)i * 16) = q;
+        return;
+    }
+    // four consecutive fp32 elements e .. e + 3 of the (C, H, W) sample; out[n] = dropout of the SAME values with sample n's bits
+    const int64_t chw = (int64_t)it.C * it.H * it.W;
+    const uint32_t e = (uint32_t)(i * 4);
+    const float x[4] = {__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)};
+    for (int n = 0; n < u.n; ++n) {
+        float o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t w = dropout_word(e + t, (uint32_t)u.site, (uint32_t)(u.sample0 + n), u.seed);
+            o[t] = ((w >> ((e + t) & 31)) & 1u) ? x[t] * 2.f : 0.f;
+        }
+        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(it.dst) + (int64_t)n * chw + e) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+void launch_unpack_bands(const BandUnpack &u, const void *slots, hipStream_t s) {
+    int64_t total = 0;
+    for (int k = 0; k < u.n_items; ++k) total += u.item[k].vecs;
+    if (total) hipLaunchKernelGGL(unpack_bands_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, u, (const unsigned char *)slots);
 }
 
 #ifdef SIVO_DIAG

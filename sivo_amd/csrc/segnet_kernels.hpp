@@ -200,10 +200,14 @@ void launch_mc_finalize64(const double *prob_sum, int C, int64_t hw, int T, uint
 void launch_add_f64(double *dst, const double *src, int64_t n, bool init, hipStream_t s);      // dst = src (init) or dst += src
 void launch_mc_variance(const float *prob, int T, int C, int64_t hw, const uint8_t *classes, double *variance,
                         hipStream_t s);
-// row bands of the sample-invariant prefix: gathered slots -> a full blob (segnet_kernels.hip unpack_bands_kernel)
-struct BandTable { int world; int y0[17]; };      // y0[r] .. y0[r + 1]: the rows of this blob rank r owns (world <= 16)
-void launch_unpack_bands(void *dst, const void *slots, size_t slot_bytes, size_t item_off, int elt, int C, int H, int W, int rows_max,
-                         const BandTable &tab, hipStream_t s);
+// row bands of the sample-invariant prefix (segnet_kernels.hip pack_bands_kernel / unpack_bands_kernel; segnet.cpp PrefixBands)
+constexpr int BAND_ITEMS = 6, BAND_RANKS = 16;
+struct BandPackItem { const unsigned char *src; int src_H, row0, n_rows, C, W, elt, rows_max; size_t off; int64_t vecs; };   // vecs = C * n_rows * W * elt / 16
+struct BandPack { int n_items; BandPackItem item[BAND_ITEMS]; };
+struct BandUnpackItem { unsigned char *dst; int C, H, W, elt, rows_max, drop; size_t off; int64_t vecs; int y0[BAND_RANKS + 1]; };      // vecs = C * H * W * elt / 16
+struct BandUnpack { int n_items, world, n, site, sample0; uint64_t seed; size_t slot_bytes; BandUnpackItem item[BAND_ITEMS]; };
+void launch_pack_bands(const BandPack &p, void *slot, hipStream_t s);
+void launch_unpack_bands(const BandUnpack &u, const void *slots, hipStream_t s);
 void launch_mask_to_index(const uint8_t *mask, float *out, int64_t total, int Ho, int Wo, int Win, hipStream_t s);
 
 }  // namespace sivo

@@ -662,7 +662,8 @@ def test_accuracy_guard_measures_every_layer_and_reroutes_an_inaccurate_plan(ora
     g = sn.guard_report()
     assert g["builds"] == 1 and g["layers"] and all(r["level"] == 0 for r in g["layers"])
     assert 0 < g["predicted"] <= g["budget"] == pytest.approx(1e-3 / 30)
-    assert {r["kernel"] for r in g["layers"]} <= {"F(4x4) f16x3 GEMM", "direct f16x3", "F(4x4) fp32 fused"}
+    assert {r["kernel"] for r in g["layers"]} <= {"F(4x4) f16x3 GEMM", "direct f16x3", "F(4x4) fp32 fused", "classifier f16x3"}
+    assert "classifier f16x3" in {r["kernel"] for r in g["layers"]}
     assert all(0 < r["rel_err"] < 3e-5 and r["rel_rms"] < r["rel_err"] for r in g["layers"])
     err, mag = logit_error(net, w, sn)
     print(f"[guard] default plan: {len(g['layers'])} layers guarded in {g['ms']:.0f} ms, predicted {g['predicted']:.2e} of the logit scale "

@@ -22,7 +22,12 @@ def main():
     nl = parallel.max_shard(T, world)
     text = netspec.standard_prototxt(max(2, nl), H, W)
     layers = netspec.parse_layers(text)
-    sn = BayesianSegNet(prototxt=text, weights=wts.pack(layers, wts.synth_weights(layers, 42)), T=max(2, nl))
+    if os.environ.get("PROBE_DIAG"):         # the diagnostic build (reads SIVO_BAND_GRAPH=0: the band as eager launches)
+        from sivo_amd import _lib
+        with _lib.use("diag"):
+            sn = BayesianSegNet(prototxt=text, weights=wts.pack(layers, wts.synth_weights(layers, 42)), T=max(2, nl))
+    else:
+        sn = BayesianSegNet(prototxt=text, weights=wts.pack(layers, wts.synth_weights(layers, 42)), T=max(2, nl))
     d = torch.from_numpy(make_inputs(H, W)[0]).cuda()
     ps = torch.zeros((sn.classes, H, W), dtype=torch.float32, device="cuda")
     maps = (torch.empty((H, W), dtype=torch.uint8, device="cuda"), torch.empty((H, W), dtype=torch.float64, device="cuda"),
