@@ -493,11 +493,32 @@ def main():
     # N > 1: the sample-invariant prefix in row bands over the ranks + one all-gather of the slots instead of N recomputations
     # (SIVO_BENCH_BANDS=0 keeps the recomputation)
     banded = world > 1 and os.environ.get("SIVO_BENCH_BANDS", "1") != "0"
+    # The band of frame k + 1 (and its all-gather) is issued on a side stream while frame k's samples run: a band's kernels leave most
+    # of the chip idle (one work item per CU at a fifth of the rows), the per-sample kernels of one or two samples do too, and the frames
+    # are independent (the next image is needed one frame early — the same extra frame of latency the N = 1 loop takes for its host
+    # tail).  SIVO_BENCH_BAND_OVERLAP=0: band -> all-gather -> samples in sequence on one stream.
+    band_overlap = banded and os.environ.get("SIVO_BENCH_BAND_OVERLAP", "1") != "0"
     if banded:
         band_plan = sn.prefix_bands(world)
-        my_slot = torch.zeros(band_plan["slot_bytes"], dtype=torch.uint8, device="cuda")
-        all_slots = torch.zeros((world, band_plan["slot_bytes"]), dtype=torch.uint8, device="cuda")
-        slot_views = [all_slots[r] for r in range(world)]
+        nbuf = 2 if band_overlap else 1
+        my_slot = [torch.zeros(band_plan["slot_bytes"], dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+        all_slots = [torch.zeros((world, band_plan["slot_bytes"]), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+        slot_views = [[a[r] for r in range(world)] for a in all_slots]
+        side = torch.cuda.Stream() if band_overlap else None
+        band_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(nbuf)]      # band start / band done / gathered
+        consumed = [torch.cuda.Event() for _ in range(nbuf)]                                             # the samples that read this buffer are enqueued
+        band_state = {"cur": 0, "primed": False}
+
+        def issue_band(b):
+            """This rank's band of the prefix + the all-gather of every rank's slot into buffer b, on the side stream."""
+            with torch.cuda.stream(side):
+                side.wait_event(consumed[b])             # (the frame that last read buffer b)
+                band_ev[b] = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                band_ev[b][0].record()
+                sn.prefix_band_into(d_bgr, rank, world, my_slot[b])
+                band_ev[b][1].record()
+                dist.all_gather(slot_views[b], my_slot[b])
+                band_ev[b][2].record()
 
     # The rank that runs ORB (rank 0) keeps TWO frames in flight.  A frame's device work (network [+ all-reduce + finalize], ORB,
     # matching) is enqueued; its host tail — semantic filter, median cull, entropy gate, ≈0.35 ms during which the GPU would otherwise
@@ -519,13 +540,30 @@ def main():
             return fp.start_orb(d_left, d_right) if do_orb else None
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record()
-        if banded:
-            sn.prefix_band_into(d_bgr, rank, world, my_slot)
+        if band_overlap:
+            if not band_state["primed"]:
+                consumed[0].record(); consumed[1].record()
+                issue_band(0)
+                band_state["primed"] = True
+            b = band_state["cur"]
+            ev[1], ev[2] = band_ev[b][1], band_ev[b][2]          # (this frame's band ran during the previous frame; ev[0] -> ev[3] is what the main stream spent)
+            ev_band0 = band_ev[b][0]
+            torch.cuda.current_stream().wait_event(band_ev[b][2])
+            issue_band(1 - b)                                    # the NEXT frame's band, beside this frame's samples
+            if n_local:
+                sn.forward_banded_into(all_slots[b], world, seed, prob_sum, n_samples=n_local, sample0=sample0)
+            else:
+                prob_sum.zero_()                       # more ranks than samples: contribute nothing
+            consumed[b].record()
+            band_state["cur"] = 1 - b
+            ev.append(ev_band0)
+        elif banded:
+            sn.prefix_band_into(d_bgr, rank, world, my_slot[0])
             ev[1].record()
-            dist.all_gather(slot_views, my_slot)
+            dist.all_gather(slot_views[0], my_slot[0])
             ev[2].record()
             if n_local:
-                sn.forward_banded_into(all_slots, world, seed, prob_sum, n_samples=n_local, sample0=sample0)
+                sn.forward_banded_into(all_slots[0], world, seed, prob_sum, n_samples=n_local, sample0=sample0)
             else:
                 prob_sum.zero_()                       # more ranks than samples: contribute nothing
         else:
@@ -657,10 +695,14 @@ def main():
         # ends when the slowest rank has arrived — so "all-reduce" on a light rank is mostly waiting, on the heaviest rank the wire time
         torch.cuda.synchronize()
         evs = rank_events[args.warmup:args.warmup + args.steps]
-        mine = torch.tensor([float(np.mean([e[a].elapsed_time(e[b]) for e in evs])) for a, b in ((0, 1), (1, 2), (2, 3), (3, 4))], dtype=torch.float64, device="cuda")
+        # overlapped bands: a frame's band / gather events come from the side stream (issued one frame earlier): band = e[5] -> e[1],
+        # gather = e[1] -> e[2], and "forward" = what the main stream spent between the frame's start and the end of its samples
+        spans = ((5, 1), (1, 2), (0, 3), (3, 4)) if band_overlap else ((0, 1), (1, 2), (2, 3), (3, 4))
+        mine = torch.tensor([float(np.mean([e[a].elapsed_time(e[b]) for e in evs])) for a, b in spans], dtype=torch.float64, device="cuda")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        multi = {"prefix": "row bands over the ranks + one all-gather of the slots (DESIGN 4)" if banded else "recomputed on every rank",
+        multi = {"prefix": ("row bands over the ranks + one all-gather of the slots (DESIGN 4)" + (", issued one frame ahead on a side stream beside the previous frame's samples" if band_overlap else ""))
+                           if banded else "recomputed on every rank",
                  "prefix_band_ms_per_rank": [round(float(t[0]), 3) for t in allr] if banded else None,
                  "band_allgather_incl_wait_ms_per_rank": [round(float(t[1]), 3) for t in allr] if banded else None,
                  "band_allgather_bytes_per_rank": int(band_plan["slot_bytes"]) if banded else None,
@@ -796,7 +838,18 @@ def main():
                         net.prefix_band_into(d_bgr, nr - 1, nr, slots[nr - 1])
                         net.forward_banded_into(slots, nr, seed, ps, n_samples=nl, sample0=0)
                         net.finalize(ps, t_total=T, out=m)
-                    row["ms_per_frame"] = timed_ms(one_b)
+                    row["ms_per_frame_band_in_sequence"] = timed_ms(one_b)
+                    # ... and as the N > 1 loop runs it: the NEXT frame's band on a side stream beside this frame's samples
+                    side_s = torch.cuda.Stream()
+                    slots_next = slots.clone()
+                    def one_o(seed, nl=nl, nr=nr, slots=slots, slots_next=slots_next, side_s=side_s):
+                        side_s.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(side_s):
+                            net.prefix_band_into(d_bgr, nr - 1, nr, slots_next[nr - 1])
+                        net.forward_banded_into(slots, nr, seed, ps, n_samples=nl, sample0=0)
+                        net.finalize(ps, t_total=T, out=m)
+                        torch.cuda.current_stream().wait_stream(side_s)
+                    row["ms_per_frame"] = timed_ms(one_o)
                     row["band_rows_of_the_image"] = plan["input_rows"][nr - 1][1] - plan["input_rows"][nr - 1][0]
                     row["allgather_bytes_per_rank"] = plan["slot_bytes"]
                 else:
@@ -808,7 +861,8 @@ def main():
                 r_["speedup_ceiling"] = round(rows[0]["ms_per_frame"] / r_["ms_per_frame"], 2)
                 r_["speedup_ceiling_prefix_recomputed"] = round(rows[0]["ms_per_frame"] / r_["ms_per_frame_prefix_recomputed"], 2)
             extra.append({"name": f"sample shards of the T = {T} frame on one GPU (the heaviest rank's share: its band of the prefix + unpacking + its samples + finalize; "
-                                  "no ORB, no all-gather / all-reduce wire time; *_prefix_recomputed = every rank computing the whole prefix, as before round 5)",
+                                  "the band of the NEXT frame on a side stream beside the samples, as the N > 1 loop issues it; no ORB, no all-gather / all-reduce wire time; "
+                                  "*_band_in_sequence = band, then samples, on one stream; *_prefix_recomputed = every rank computing the whole prefix, as before round 5)",
                           "metric": "ms per frame of the heaviest rank", "value": rows[-1]["ms_per_frame"], "shards": rows,
                           "parity": "tests/test_gpu_prefix_bands.py (banded prefix == whole-image forward, bit for bit, world 2 / 4 / 8), tests/test_gpu_segnet_fullsize.py::test_t48_and_its_shards_at_full_size, tests/test_distributed_cpu.py"})
         if "track" in want and stats["last"] is not None:

@@ -260,6 +260,11 @@ typedef struct sivo_orb *sivo_orb_t;
 int sivo_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast,
                     int device, sivo_orb_t *out);
 int sivo_orb_destroy(sivo_orb_t h);
+/* The GaussianBlur(7x7, sigma 2) in front of the descriptors (ORBextractor.cc:1060-1062) is OpenCV's, and its 8-bit taps differ
+ * between the OpenCV versions README.md:57 admits ("> 3.2"): variant 0 (default) 18 34 49 55 49 34 18 — OpenCV 3.2 - 3.4.12 and
+ * 4.0 - 4.5.0; variant 1 18 34 48 56 48 34 18 — OpenCV >= 3.4.13 / >= 4.5.1 (error-diffused taps, sum 256).  Pick the one the
+ * reference build you compare against was linked with; descriptors are bit-exact per variant (INTEGRATION.md "OpenCV contract"). */
+int sivo_orb_set_gaussian(sivo_orb_t h, int variant);
 /* GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
  * GetInverseScaleSigmaSquares + mnFeaturesPerLevel; arrays of nlevels. */
 int sivo_orb_tables(sivo_orb_t h, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,

@@ -373,10 +373,13 @@ KP_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32),
 class OrbExtractor:
     """ORBextractor (ORBextractor.cc:412-475, 1019-1083) on the oracle."""
 
-    def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+    def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, gaussian="rounded"):
+        """gaussian: which OpenCV GaussianBlur 8U kernel the descriptor image is blurred with (orb_oracle.c orc_gaussian7_taps):
+        "rounded" 18 34 49 55 ... (OpenCV 3.2 - 3.4.12, 4.0 - 4.5.0) or "ed" 18 34 48 56 ... (OpenCV >= 3.4.13 / >= 4.5.1)."""
         self.nlevels = nlevels
         self.nfeatures = nfeatures
         self._h = C.c_void_p(lib().orc_orb_create(nfeatures, C.c_float(scale_factor), nlevels, ini_th, min_th))
+        lib().orc_orb_set_gaussian(self._h, {"rounded": 0, "ed": 1}[gaussian])
         s = np.empty(nlevels, np.float32); i = np.empty(nlevels, np.float32)
         s2 = np.empty(nlevels, np.float32); i2 = np.empty(nlevels, np.float32)
         fpl = np.empty(nlevels, np.int32); um = np.empty(16, np.int32)
@@ -420,11 +423,17 @@ def resize_linear_u8(src, dh, dw):
     return dst
 
 
-def gaussian7_u8(src):
+def gaussian7_u8(src, variant="rounded"):
     src = np.ascontiguousarray(src, np.uint8)
     dst = np.empty_like(src)
-    lib().orc_gaussian7_u8(_p(src, c_u8p), src.shape[0], src.shape[1], src.strides[0], _p(dst, c_u8p), dst.strides[0])
+    lib().orc_gaussian7_u8_v(_p(src, c_u8p), src.shape[0], src.shape[1], src.strides[0], _p(dst, c_u8p), dst.strides[0], {"rounded": 0, "ed": 1}[variant])
     return dst
+
+
+def gaussian7_taps(variant="rounded"):
+    k = (C.c_int * 7)()
+    lib().orc_gaussian7_taps({"rounded": 0, "ed": 1}[variant], k)
+    return list(k)
 
 
 def fast9_16(img, threshold, nonmax=True):

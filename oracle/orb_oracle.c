@@ -137,14 +137,43 @@ void orc_border101(uint8_t *img, int rows, int cols, int step, int b) {
     }
 }
 
-/* GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on an isolated 8UC1 image. */
-void orc_gaussian7_u8(const uint8_t *src, int rows, int cols, int sstep, uint8_t *dst, int dstep) {
+/* GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on an isolated 8UC1 image: a separable 8.8 fixed-point kernel, row pass
+ * sum k p (16 bits), column pass (sum k row + 2^15) >> 16, saturated.  What differs between OpenCV versions is the KERNEL
+ * (restated from the published sources; OpenCV is not in the tree, so neither variant is pinned):
+ *   variant 0 "rounded"  every tap round(g * 256): 18 34 49 55 49 34 18, sum 257.  The 8-bit separable filter of
+ *                        OpenCV 3.2 - 3.4.0 (createSeparableLinearFilter, bits = 8; its SSE column path rounds ties to even
+ *                        instead: +-1 LSB on ~1e-5 of the pixels, build dependent) and the bit-exact fixed-point path
+ *                        (ufixedpoint16) of OpenCV 3.4.1 - 3.4.12 / 4.0 - 4.5.0, whose scalar and SIMD forms agree.
+ *   variant 1 "ed"       getGaussianKernelFixedPoint_ED (OpenCV >= 3.4.13 / >= 4.5.1): the rounding error of each tap is
+ *                        carried into the next one from the outside in and the centre takes what is left of 256:
+ *                        18 34 48 56 48 34 18, sum 256 (no brightness gain).
+ * Same arithmetic for both, so every u8 result is exact for the variant's kernel. */
+void orc_gaussian7_taps(int variant, int kq[7]) {
+    if (variant == 1) {
+        /* getGaussianKernelBitExact (exp in double here; softdouble there: the taps are far from any rounding tie) + _ED at 8 fraction bits */
+        double g[7], sum = 0, err = 0;
+        int acc = 0;
+        for (int i = 0; i < 7; ++i) { const double x = i - 3.0; g[i] = exp(-0.5 / 4.0 * x * x); sum += g[i]; }
+        for (int i = 0; i < 3; ++i) {
+            const double adj = g[i] / sum * 256.0 + err;
+            const int v = orc_cvround(adj);
+            err = adj - v;
+            kq[i] = kq[6 - i] = v;
+            acc += 2 * v;
+        }
+        kq[3] = 256 - acc;
+        return;
+    }
     /* getGaussianKernel(7, 2, CV_32F) then convertTo(CV_32S, 256) */
     float cf[7]; double sum = 0;
     for (int i = 0; i < 7; ++i) { const double x = i - 3.0; cf[i] = (float)exp(-0.5 / 4.0 * x * x); sum += cf[i]; }
     sum = 1. / sum;
-    int kq[7];
     for (int i = 0; i < 7; ++i) { cf[i] = (float)(cf[i] * sum); kq[i] = orc_cvround((double)cf[i] * 256.0); }
+}
+
+void orc_gaussian7_u8_v(const uint8_t *src, int rows, int cols, int sstep, uint8_t *dst, int dstep, int variant) {
+    int kq[7];
+    orc_gaussian7_taps(variant, kq);
     int *tmp = (int *)malloc(sizeof(int) * (size_t)rows * cols);
     for (int y = 0; y < rows; ++y)
         for (int x = 0; x < cols; ++x) {
@@ -160,6 +189,10 @@ void orc_gaussian7_u8(const uint8_t *src, int rows, int cols, int sstep, uint8_t
             dst[(size_t)y * dstep + x] = (uint8_t)(v > 255 ? 255 : v);
         }
     free(tmp);
+}
+
+void orc_gaussian7_u8(const uint8_t *src, int rows, int cols, int sstep, uint8_t *dst, int dstep) {
+    orc_gaussian7_u8_v(src, rows, cols, sstep, dst, dstep, 0);
 }
 
 /* ---- cv::FAST TYPE_9_16 --------------------------------------------------- */
@@ -259,7 +292,10 @@ typedef struct OrcOrb {
     uint8_t *buf[MAX_LEVELS]; int rows[MAX_LEVELS], cols[MAX_LEVELS], step[MAX_LEVELS];
     /* per-level candidate dump (vToDistributeKeys) for stage parity */
     OrcKeyPoint *cand[MAX_LEVELS]; int ncand[MAX_LEVELS];
+    int gaussian_variant;            /* orc_gaussian7_u8_v: 0 "rounded" (default), 1 "ed" */
 } OrcOrb;
+
+void orc_orb_set_gaussian(OrcOrb *o, int variant) { o->gaussian_variant = variant; }
 
 /* ORBextractor::ORBextractor (ORBextractor.cc:412-475) */
 OrcOrb *orc_orb_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST) {
@@ -635,7 +671,7 @@ int orc_orb_extract(OrcOrb *o, const uint8_t *gray, int rows, int cols, int step
             const int h = o->rows[level], w = o->cols[level];
             const uint8_t *img = o->buf[level] + (size_t)EDGE_THRESHOLD * o->step[level] + EDGE_THRESHOLD;
             uint8_t *work = (uint8_t *)malloc((size_t)h * w);
-            orc_gaussian7_u8(img, h, w, o->step[level], work, w);
+            orc_gaussian7_u8_v(img, h, w, o->step[level], work, w, o->gaussian_variant);
             for (int k = 0; k < nk; ++k) {
                 if (total + k < max_out && desc_out) orb_descriptor(&kps[k], work, w, desc_out + 32 * (size_t)(total + k));
             }

@@ -11,9 +11,25 @@ namespace SIVO {
 
 static const int EDGE_THRESHOLD = 19;
 
+// The reference blurs the descriptor image with cv::GaussianBlur (ORBextractor.cc:1060-1062), whose 8-bit taps depend on the OpenCV it is
+// linked with (sivo_orb_set_gaussian): built against a real OpenCV this class picks the taps of THAT version, so that its descriptors
+// are the ones the reference's own ORBextractor produces in the same build; against the compat shim (no OpenCV) the default (0).
+#if defined(CV_VERSION_MAJOR) && defined(CV_VERSION_MINOR) && defined(CV_VERSION_REVISION)
+#if (CV_VERSION_MAJOR > 4) || (CV_VERSION_MAJOR == 4 && (CV_VERSION_MINOR > 5 || (CV_VERSION_MINOR == 5 && CV_VERSION_REVISION >= 1))) || \
+    (CV_VERSION_MAJOR == 3 && CV_VERSION_MINOR == 4 && CV_VERSION_REVISION >= 13)
+int ORBextractor::sGaussianVariant = 1;      // getGaussianKernelFixedPoint_ED: 18 34 48 56 48 34 18
+#else
+int ORBextractor::sGaussianVariant = 0;      // round(g * 256): 18 34 49 55 49 34 18
+#endif
+#else
+int ORBextractor::sGaussianVariant = 0;
+#endif
+
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST) {
     if (sivo_orb_create(_nfeatures, _scaleFactor, _nlevels, _iniThFAST, _minThFAST, 0, &mpHandle) != SIVO_OK)
+        throw std::runtime_error(std::string("ORBextractor: ") + sivo_last_error());
+    if (sivo_orb_set_gaussian(mpHandle, sGaussianVariant) != SIVO_OK)
         throw std::runtime_error(std::string("ORBextractor: ") + sivo_last_error());
     mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels);
     mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);

@@ -45,6 +45,10 @@ class ORBextractor {
 
     sivo_orb *handle() { return mpHandle; }   // for the device-side stereo matcher
 
+    // Which OpenCV's GaussianBlur 8U taps new extractors blur the descriptor image with (sivo_orb_set_gaussian: 0 = OpenCV 3.2 - 3.4.12 /
+    // 4.0 - 4.5.0, 1 = OpenCV >= 3.4.13 / >= 4.5.1).  Initialised from the OpenCV version this file is compiled against.
+    static int sGaussianVariant;
+
  protected:
     int nfeatures;
     double scaleFactor;

@@ -743,6 +743,38 @@ int extract(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, Siv
 
 }  // namespace
 
+// Which OpenCV's GaussianBlur(7x7, sigma 2) on 8U the descriptor image is blurred like (ORBextractor.cc:1060-1062; README.md:57 asks
+// for "OpenCV > 3.2", and the 8.8 fixed-point taps changed inside that range): 0 = every tap round(g * 256): 18 34 49 55 49 34 18
+// (OpenCV 3.2 - 3.4.12 and 4.0 - 4.5.0; the default), 1 = getGaussianKernelFixedPoint_ED of OpenCV >= 3.4.13 / >= 4.5.1: the
+// rounding error carried from tap to tap, the centre takes the rest of 256: 18 34 48 56 48 34 18.  Same arithmetic either way
+// (blur_kernel); oracle: orb_oracle.c orc_gaussian7_taps.
+extern "C" int sivo_orb_set_gaussian(sivo_orb_t h, int variant) {
+    return guarded([&] {
+        if (!h) throw std::invalid_argument("null handle");
+        if (variant != 0 && variant != 1) throw std::invalid_argument("GaussianBlur variant: 0 (rounded taps) or 1 (error-diffused taps)");
+        double g[7], sum = 0;
+        float cf[7];
+        for (int i = 0; i < 7; ++i) { const double x = i - 3.0; g[i] = std::exp(-0.5 / 4.0 * x * x); cf[i] = (float)g[i]; }
+        if (variant == 0) {
+            for (int i = 0; i < 7; ++i) sum += cf[i];
+            sum = 1. / sum;
+            for (int i = 0; i < 4; ++i) h->gk[i] = cv_round((double)(float)(cf[i] * sum) * 256.0);
+        } else {
+            for (int i = 0; i < 7; ++i) sum += g[i];
+            double err = 0;
+            int acc = 0;
+            for (int i = 0; i < 3; ++i) {
+                const double adj = g[i] / sum * 256.0 + err;
+                h->gk[i] = cv_round(adj);
+                err = adj - h->gk[i];
+                acc += 2 * h->gk[i];
+            }
+            h->gk[3] = 256 - acc;
+        }
+        return SIVO_OK;
+    });
+}
+
 extern "C" int sivo_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast,
                                int device, sivo_orb_t *out) {
     return guarded([&] {

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 def _compare(oracle, gray, **kw):
     ex_o = oracle.OrbExtractor(**{k: v for k, v in kw.items()})
-    names = {"nfeatures": "nfeatures", "scale_factor": "scale_factor", "nlevels": "nlevels", "ini_th": "ini_th_fast", "min_th": "min_th_fast"}
+    names = {"nfeatures": "nfeatures", "scale_factor": "scale_factor", "nlevels": "nlevels", "ini_th": "ini_th_fast", "min_th": "min_th_fast", "gaussian": "gaussian"}
     ex_g = orb.ORBextractor(**{names[k]: v for k, v in kw.items()})
     kp_o, d_o = ex_o(gray)
     kp_g, d_g = ex_g(gray)
@@ -37,6 +37,16 @@ def test_orb_kitti_frame_bit_exact(oracle, kitti_like_bgr):
 
 def test_orb_synthetic_bit_exact(oracle):
     _compare(oracle, synthetic_frame(1234))
+
+
+def test_orb_gaussian_taps_of_newer_opencv_bit_exact(oracle, kitti_like_bgr):
+    """sivo_orb_set_gaussian(1): the descriptor image blurred with the error-diffused taps of OpenCV >= 3.4.13 / >= 4.5.1 (18 34 48 56 ...):
+    bit-exact against the oracle's restatement of that variant, same keypoints as the default variant, other descriptors."""
+    gray = oracle.bgr2gray(kitti_like_bgr)
+    _, _, kp_e, d_e = _compare(oracle, gray, gaussian="ed")
+    _, _, kp_r, d_r = _compare(oracle, gray, gaussian="rounded")
+    assert kp_e.tobytes() == kp_r.tobytes() and not np.array_equal(d_e, d_r)
+    _compare(oracle, synthetic_frame(5, 97, 131), nfeatures=50, nlevels=3, scale_factor=1.5, gaussian="ed")
 
 
 def test_orb_device_resident_input(oracle):

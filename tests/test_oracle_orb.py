@@ -63,6 +63,29 @@ def test_gaussian_is_the_8bit_fixed_point_kernel(oracle):
     assert (flat == (100 * 257 * 257 + 32768) // 65536).all()              # the 257/256 gain of that OpenCV path
 
 
+def test_gaussian_variant_of_newer_opencv(oracle):
+    """OpenCV >= 3.4.13 / >= 4.5.1 (getGaussianKernelFixedPoint_ED): the rounding error of each tap is carried into the next from the
+    outside in and the centre takes the rest of 256 — taps 18 34 48 56 48 34 18, no brightness gain; the arithmetic is the same 8.8
+    fixed point.  (The default "rounded" variant is OpenCV 3.2 - 3.4.12 / 4.0 - 4.5.0.)"""
+    assert oracle.gaussian7_taps("rounded") == [18, 34, 49, 55, 49, 34, 18]
+    assert oracle.gaussian7_taps("ed") == [18, 34, 48, 56, 48, 34, 18] and sum(oracle.gaussian7_taps("ed")) == 256
+    src = synthetic_frame(4, 64, 80)
+    k = np.array([18, 34, 48, 56, 48, 34, 18], np.int64)
+    pad = np.pad(src.astype(np.int64), 3, mode="reflect")
+    rows = sum(k[i] * pad[3:-3, i:i + 80] for i in range(7))
+    rows = np.pad(rows, ((3, 3), (0, 0)), mode="reflect")
+    ref = (sum(k[i] * rows[i:i + 64] for i in range(7)) + (1 << 15)) >> 16
+    dst = oracle.gaussian7_u8(src, "ed")
+    assert np.array_equal(dst, np.clip(ref, 0, 255).astype(np.uint8))
+    assert (oracle.gaussian7_u8(np.full((20, 20), 100, np.uint8), "ed") == 100).all()
+    d = dst.astype(int) - oracle.gaussian7_u8(src, "rounded").astype(int)
+    assert np.abs(d).max() <= 2 and (d != 0).mean() > 0.2                  # the two OpenCV generations differ by an LSB or two on many pixels
+    kp_r, de_r = oracle.OrbExtractor(nfeatures=300, nlevels=4)(synthetic_frame(5, 120, 160))
+    kp_e, de_e = oracle.OrbExtractor(nfeatures=300, nlevels=4, gaussian="ed")(synthetic_frame(5, 120, 160))
+    assert kp_r.tobytes() == kp_e.tobytes()                                # keypoints come from the unblurred pyramid ...
+    assert not np.array_equal(de_r, de_e)                                  # ... descriptors from the blurred one
+
+
 def test_fast_against_bruteforce_definition(oracle):
     img = synthetic_frame(5, 60, 70)
     xy, sc = oracle.fast9_16(img, 20, nonmax=False)
