@@ -165,7 +165,16 @@ def test_timed_configuration_against_the_oracle(oracle, kind, T, image, seed, ki
     assert ferr.max() < LOGIT_TOL
     np.testing.assert_allclose(maps[1].cpu().numpy(), res["confidence"], atol=LOGIT_TOL / 2, rtol=0)
     np.testing.assert_allclose(maps[2].cpu().numpy(), res["entropy"], atol=5e-3, rtol=0)
-    del res, err, ferr, fl, maps, plain, post
+    # class flips against the oracle (same switches): bounded, and only where the oracle's own two best mean probabilities are closer
+    # than the probability error the logit tolerance allows (|dp| <= |dlogit| / 2) — so that a later change of the device Softmax
+    # (v_exp_f32 + one reciprocal per pixel, softmax.hpp) cannot widen the gap unnoticed
+    flip = maps[0].cpu().numpy() != res["classes"]
+    srt = np.sort(res["mean"], axis=0)
+    print(f"[{kind} T={T} {image} seed={seed}] class map vs the oracle at the same switches: {int(flip.sum())} of {flip.size} pixels differ"
+          + (f", largest top-2 gap of the oracle's mean among them {float((srt[-1] - srt[-2])[flip].max()):.2e}" if flip.any() else ""))
+    assert flip.mean() <= 1e-4
+    assert not flip.any() or float((srt[-1] - srt[-2])[flip].max()) <= LOGIT_TOL / 2
+    del res, err, ferr, fl, maps, plain, post, srt, flip
 
     # ---- free-running: the oracle's own switches
     pre = [L["bottom"][0] for L in pools]
