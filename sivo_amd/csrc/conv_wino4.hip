@@ -67,6 +67,7 @@ struct Wino4Args {
     float *out;                                  // (n, K, H, W)
     int n, C, K, Kp, H, W, th, tw, P, Pp;
     int relu, drop_site, sample0;
+    int in_drop, in_drop_site;                   // in_drop != 0: dropout of site in_drop_site applied to the input as it is read (ConvArgs::in_drop_site)
     uint64_t seed;
     // output transform fused with the MAX 2x2 pooling that consumes this layer (the 4x4 tile holds four whole windows):
     float *pool_out;            // (n, K, Ho, Wo) or null
@@ -168,12 +169,27 @@ __global__ __launch_bounds__(W4_TIN) void wino4_input_kernel(Wino4Args a) {
             const bool row_ok = y >= 0 && y < a.H;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (row_ok) v = *reinterpret_cast<const f32x4 *>(src + (int64_t)y * a.W + x0);     // W % 4 == 0: aligned, in bounds
+            // in_drop: the four elements e .. e + 3 of the (C, H, W) sample share one dropout word (e % 4 == 0); dropped BEFORE the
+            // shuffles, so a neighbour receives the dropped value
+            const uint32_t e = (uint32_t)((c * a.H + y) * a.W + x0);
+            if (a.in_drop && row_ok) {
+                const uint32_t w = wino4_dropout_word(e, (uint32_t)a.in_drop_site, (uint32_t)(a.sample0 + n), a.seed) >> (e & 31);
+                v.x = (w & 1u) ? v.x * 2.f : 0.f; v.y = (w & 2u) ? v.y * 2.f : 0.f; v.z = (w & 4u) ? v.z * 2.f : 0.f; v.w = (w & 8u) ? v.w * 2.f : 0.f;
+            }
             // every lane takes part in the shuffles (rows outside the image contribute zeros)
             const float from_left = __shfl_up(v.w, 1, 64), from_right = __shfl_down(v.x, 1, 64);
             float l = 0.f, rr = 0.f;
             if (row_ok) {
-                if (left_lane) l = from_left; else if (x0 > 0) l = src[(int64_t)y * a.W + x0 - 1];
-                if (right_lane) rr = from_right; else if (x0 + 4 < a.W) rr = src[(int64_t)y * a.W + x0 + 4];
+                if (left_lane) l = from_left;
+                else if (x0 > 0) {
+                    l = src[(int64_t)y * a.W + x0 - 1];
+                    if (a.in_drop) l = ((wino4_dropout_word(e - 1u, (uint32_t)a.in_drop_site, (uint32_t)(a.sample0 + n), a.seed) >> ((e - 1u) & 31)) & 1u) ? l * 2.f : 0.f;
+                }
+                if (right_lane) rr = from_right;
+                else if (x0 + 4 < a.W) {
+                    rr = src[(int64_t)y * a.W + x0 + 4];
+                    if (a.in_drop) rr = ((wino4_dropout_word(e + 4u, (uint32_t)a.in_drop_site, (uint32_t)(a.sample0 + n), a.seed) >> ((e + 4u) & 31)) & 1u) ? rr * 2.f : 0.f;
+                }
             }
             d[r][0] = l; d[r][1] = v.x; d[r][2] = v.y; d[r][3] = v.z; d[r][4] = v.w; d[r][5] = rr;
         }
@@ -912,6 +928,8 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
     a.th = (c.H + 3) / 4; a.tw = c.W / 4;
     a.U = c.wt; a.ep_scale = c.ep_scale; a.ep_shift = c.ep_shift;
     a.relu = c.relu; a.drop_site = c.drop_site; a.seed = c.seed; a.in_sample_stride = c.in_sample_stride;
+    a.in_drop = c.in_drop_site >= 0 ? 1 : 0; a.in_drop_site = c.in_drop_site;
+    if (a.in_drop && (c.unpool_mask || c.in_sample_stride != 0)) throw std::invalid_argument("launch_conv_wino4: in_drop_site needs a plain sample-invariant input");
     a.pool_out = c.pool_out; a.pool_mask = c.pool_mask; a.pool_drop_site = c.pool_drop_site; a.Ho = (c.H + 1) / 2; a.Wo = (c.W + 1) / 2;
 #ifdef SIVO_DIAG
     a.diag = std::getenv("SIVO_BRIDGE_CHECK") ? diag_words() : nullptr;

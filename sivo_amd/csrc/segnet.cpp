@@ -44,6 +44,8 @@ struct Blob {
     int src_W = 0;         // masks: width of the pooled input plane (for index reconstruction)
     void *d = nullptr;
     bool fused_away = false;   // an Upsample output read straight through its pooled input by the next convolution
+    int drop_pending = -1;     // >= 0: the blob holds the values IN FRONT of this dropout site (sample-invariant); the per-sample dropped tensor
+                               // Caffe holds under this name only exists inside the consumer's input transform (sivo_segnet_blob re-creates it)
     // Packed form (conv3_h3.hip / pk_format.hip): the blob between two direct f16x3 layers as fp16 hi / lo pieces in zero-bordered
     // (pk_Hp, pk_Wp) planes, times the consumer's power of two.  pk_fresh: the last forward wrote ONLY this form (the fp32 array
     // is stale; sivo_segnet_blob unpacks).  Masks: d_bits = the window codes re-laid per channel octet for a consumer that
@@ -109,6 +111,10 @@ struct Op {
     int pool_op = -1;              // F(4x4) conv: index of the MAX 2x2 pooling fused into its output transform
     int unpool_in = -1, unpool_mask = -1;   // that convolution: pooled blob and mask blob it reads through
     int drop_site = -1;
+    // the fork pooling's Dropout moved into the F(4x4) input transform of its consumer (plan pass below): the pooling writes its values
+    // once (sample-invariant), the consumer drops them out per sample as it reads (ConvArgs::in_drop_site)
+    bool drop_moved = false;       // pooling: its dropout is applied by its consumer
+    int in_drop_site = -1;         // convolution: dropout site applied to its (shared) input
     int guard_level = 0;           // accuracy guard (accuracy_guard): 0 as planned, 1 no F(4x4) (direct f16x3 at any width), 2 no f16x3 either (F(2x2) / direct fp32), 3 direct fp32 only
     // lrn
     int local_size = 5;
@@ -134,6 +140,8 @@ struct sivo_segnet {
     std::map<std::string, int> guard_levels_used;
     std::map<int, sivo::PrefixBands *> bands;
     bool owns_flag = true;                // (a band handle raises its owner's overflow flag)
+    uint64_t last_seed = 0;               // of the last forward (sivo_segnet_blob re-creates a blob whose dropout moved downstream)
+    int last_sample0 = 0;
     int device = 0;
     int T = 0, C = 3, H = 0, W = 0, classes = 0;
     std::vector<sivo::Blob> blobs;
@@ -600,6 +608,25 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
             A.pool_op = pi;
             S.ops[pi].skip = true;
             S.blobs[A.out].fused_away = true;
+        }
+    // Fork pooling (sample-invariant input, test-time Dropout in place on its output) -> F(4x4) convolution: the pooling kernel would
+    // write T dropped copies of the same tensor (SegNet-Standard pool3: 12 x 5.8 MB) for the input transform to read back; instead the
+    // pooling writes its values once and the input transform applies the dropout as it reads — the same counter-based word per
+    // (element, site, global sample), so V is bit-identical.  SIVO_NO_FUSE_INDROP disables (diagnostic build: the A/B of the test).
+    if (!SIVO_DIAG_ENV("SIVO_NO_FUSE_INDROP"))
+        for (size_t i = 0; i < S.ops.size(); ++i) {
+            Op &P = S.ops[i];
+            if (P.kind != OP_POOL || P.skip || P.drop_site < 0 || !S.blobs[P.in].shared || S.blobs[P.out].shared || P.out == S.logits_blob) continue;
+            int uses = 0, ci = -1;
+            for (size_t k = 0; k < S.ops.size(); ++k)
+                if (S.ops[k].in == P.out || S.ops[k].in2 == P.out || S.ops[k].unpool_in == P.out) { ++uses; ci = (int)k; }
+            if (uses != 1) continue;
+            Op &Cv = S.ops[(size_t)ci];
+            if (Cv.kind != OP_CONV || !Cv.wino4 || Cv.in != P.out || Cv.unpool_in >= 0 || Cv.w4_bridged_in || S.blobs[P.out].W % 4) continue;
+            Cv.in_drop_site = P.drop_site;
+            P.drop_moved = true;
+            S.blobs[P.out].shared = true;
+            S.blobs[P.out].drop_pending = P.drop_site;
         }
     // classifier convolution -> Softmax -> mean over the samples -> argmax / max / entropy in one kernel (conv_cls_mc.hip):
     // the logits stay on chip whenever the caller asks for the maps or the probability sums only.  SIVO_NO_FUSE_MC disables.
@@ -1162,6 +1189,7 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                 a.out = fptr(bo);
                 a.N = N; a.Cin = op.cin; a.H = bi.H; a.W = bi.W; a.Cout = op.cout; a.CoutPad = op.cout_pad;
                 a.relu = op.relu; a.drop_site = op.drop_site; a.sample0 = sample0; a.seed = seed;
+                a.in_drop_site = op.in_drop_site;
                 a.wt_x6 = op.d_wx6;
                 const auto h3_active = [&](const Op &o) { return S.h3_on && !S.calibrating && o.d_wh3 && o.h3_vscale > 0.f; };
                 if (op.wino4) {
@@ -1276,7 +1304,7 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                 a.out = fptr(bo); a.mask = mptr(S.blobs[op.out2]);
                 a.mask_N = S.blobs[op.out2].shared ? 1 : n;
                 a.N = N; a.C = bi.C; a.H = bi.H; a.W = bi.W; a.Ho = bo.H; a.Wo = bo.W;
-                a.drop_site = op.drop_site; a.sample0 = sample0; a.seed = seed;
+                a.drop_site = op.drop_moved ? -1 : op.drop_site; a.sample0 = sample0; a.seed = seed;
                 launch_maxpool2(a, st);
                 if (op.make_bits && S.pk_on && S.h3_on && !S.calibrating) {
                     const Blob &bm = S.blobs[op.out2];
@@ -1324,6 +1352,7 @@ struct McTargets {
 void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t seed, float *d_prob_sum,
              float *d_logits, float *d_prob, hipStream_t st, const McTargets *mc, const BandInput *pre) {
     const int64_t hw = (int64_t)S.H * S.W;
+    S.last_seed = seed; S.last_sample0 = sample0;
     if (S.profile) harvest(S);
     h3_absorb(S);               // an earlier (asynchronous) frame left the fp16 range and nobody asked yet: back off now, report later
     // the recomputation of a frame that raised the flag: this forward is enqueued without f16x3
@@ -1465,7 +1494,12 @@ PrefixBands &plan_bands(sivo_segnet &S, int world) {
     B->world = world; B->device = S.device;
     size_t fork = 0;
     while (fork < S.ops.size() && (S.ops[fork].skip || S.blobs[S.ops[fork].out].shared)) ++fork;
-    if (fork >= S.ops.size() || S.ops[fork].kind != OP_POOL || S.ops[fork].drop_site < 0 || !S.blobs[S.ops[fork].in].shared)
+    // the prefix ends in the pooling whose in-place Dropout makes the blobs per-sample: either that pooling is the first per-sample op
+    // itself, or its dropout moved into the input transform of the convolution behind it (drop_moved) and that convolution is
+    if (fork < S.ops.size() && S.ops[fork].kind == OP_CONV && S.ops[fork].in_drop_site >= 0 && fork > 0 && S.ops[fork - 1].out == S.ops[fork].in &&
+        S.ops[fork - 1].kind == OP_POOL && S.ops[fork - 1].drop_moved)
+        --fork;
+    else if (fork >= S.ops.size() || S.ops[fork].kind != OP_POOL || S.ops[fork].drop_site < 0 || !S.blobs[S.ops[fork].in].shared)
         throw std::invalid_argument("prefix bands: the sample-invariant prefix must end in a pooling with test-time dropout");
     B->fork = (int)fork;
     for (size_t i = 0; i <= fork; ++i) {
@@ -1574,7 +1608,9 @@ void bands_unpack(sivo_segnet &S, const BandInput &pre, int n, int sample0, uint
     u.world = B.world; u.n = n; u.site = P.drop_site; u.sample0 = sample0; u.seed = seed; u.slot_bytes = B.slot_bytes;
     for (const PrefixBands::Item &it : B.items) {
         BandUnpackItem &q = u.item[u.n_items++];
-        q.drop = &it == &B.items[0] ? 1 : 0;           // the fork pooling's values: straight into the per-sample blob, through its dropout
+        // the fork pooling's values: straight into the per-sample blob, through its dropout — unless that dropout moved into the
+        // consumer's input transform (drop_moved): then the blob is the sample-invariant one and the values go in as they are
+        q.drop = (&it == &B.items[0] && !P.drop_moved) ? 1 : 0;
         q.dst = static_cast<unsigned char *>(S.blobs[it.blob].d);
         q.C = it.C; q.H = it.H; q.W = it.W; q.elt = it.elt; q.rows_max = B.rows_max << it.shift; q.off = it.off;
         q.vecs = (int64_t)q.C * q.H * (q.W * q.elt / 16);
@@ -1933,14 +1969,21 @@ extern "C" int sivo_segnet_blob(sivo_segnet_t h, const char *name, float *host_o
         const Blob &b = h->blobs[it->second];
         if (b.fused_away)
             throw std::invalid_argument(std::string("blob '") + name + "' is not materialised: it only exists on chip, fused into the next convolution (the diagnostic library libsivo_hip_diag.so has switches that keep Upsample outputs / conv-to-conv activations / pooled convolutions in HBM: DESIGN.md appendix)");
-        const int N = b.shared ? 1 : h->T;
+        const int N = (b.shared && b.drop_pending < 0) ? 1 : h->T;
         if (shape) { shape[0] = N; shape[1] = b.C; shape[2] = b.H; shape[3] = b.W; }
         const size_t n = (size_t)N * b.chw();
         if (!host_out) return SIVO_OK;
         if (capacity < n) return fail(SIVO_ERR_CAPACITY, "blob '%s' holds %zu values, capacity %zu", name, n, capacity);
         DeviceGuard dg(h->device);
         SIVO_HIP(hipDeviceSynchronize());
-        if (b.is_mask) {
+        if (b.drop_pending >= 0) {
+            // Caffe's blob of this name is the per-sample DROPPED tensor; here its dropout is applied inside the consumer's input
+            // transform and only the values in front of it are stored: re-create the T samples of the last forward
+            float *tmp = dev_alloc<float>(n);
+            launch_dropout((const float *)b.d, 0, tmp, N, b.chw(), b.drop_pending, h->last_sample0, h->last_seed, nullptr);
+            SIVO_HIP(hipMemcpy(host_out, tmp, n * sizeof(float), hipMemcpyDeviceToHost));
+            SIVO_HIP(hipFree(tmp));
+        } else if (b.is_mask) {
             float *tmp = dev_alloc<float>(n);
             launch_mask_to_index((const uint8_t *)b.d, tmp, (int64_t)n, b.H, b.W, b.src_W, nullptr);
             SIVO_HIP(hipMemcpy(host_out, tmp, n * sizeof(float), hipMemcpyDeviceToHost));

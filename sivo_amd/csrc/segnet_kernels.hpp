@@ -18,6 +18,10 @@ struct ConvArgs {
     int tiles_x, tiles_y;      // filled by the launcher
     int relu;
     int drop_site;             // < 0: no dropout in the epilogue
+    // F(4x4,3x3) three-kernel path only: >= 0: the INPUT is a sample-invariant tensor (in_sample_stride 0) that the network drops out
+    // per sample in front of this layer (the fork pooling's Dropout): the input transform applies that dropout as it reads — the
+    // counter-based word of (element, site, global sample) the pooling kernel would have used — and the T dropped copies never exist
+    int in_drop_site = -1;
     int sample0;
     uint64_t seed;
     // F(4x4,3x3) path only: when set, `in` is the POOLED tensor (N or 1, Cin, H/2, W/2) and the kernel reads the

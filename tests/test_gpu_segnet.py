@@ -681,3 +681,23 @@ def test_accuracy_guard_measures_every_layer_and_reroutes_an_inaccurate_plan(ora
           f"predicted {gg['predicted']:.2e}; moved {len(moved)} layers, largest first-plan layer error {max(m[3] for m in moved):.2e}")
     assert err_u > LOGIT_TOL                      # the hazard is real ...
     assert gg["builds"] >= 2 and moved and err_g < LOGIT_TOL and gg["predicted"] <= gg["budget"] / 3   # ... and the guard removes it
+
+
+def test_fork_dropout_in_the_input_transform_is_bit_identical():
+    """pool3's in-place Dropout (the fork: everything behind it is per-sample) moved into conv4_1's F(4x4) input transform: the pooling
+    writes its values once instead of T dropped copies, the transform applies the same counter-based dropout word as it reads.  Against
+    the same build with the fusion off (diagnostic build, SIVO_NO_FUSE_INDROP): logits bit for bit; and sivo_segnet_blob still hands
+    out Caffe's per-sample dropped blob (re-created from the stored values and the last forward's seed)."""
+    T, H, W = 3, 96, 192
+    text = netspec.standard_prototxt(T, H, W)
+    _, _, fused = _make(text, T)
+    _, _, plain = _make_env(text, T, 42, SIVO_NO_FUSE_INDROP=1)
+    img = torch.from_numpy(_image(np.random.default_rng(12), H, W)).cuda()
+    for seed, n, s0 in ((5, 3, 0), (6, 2, 1)):
+        pa, la, _ = fused.forward(img, seed, n_samples=n, sample0=s0, want_logits=True)
+        pb, lb, _ = plain.forward(img, seed, n_samples=n, sample0=s0, want_logits=True)
+        torch.cuda.synchronize()
+        assert torch.equal(la, lb) and torch.equal(pa, pb)
+        a, b = fused.blob("pool3"), plain.blob("pool3")
+        assert a.shape == b.shape == (T, 256, H // 8, W // 8)
+        assert np.array_equal(a[:n], b[:n]) and (a[:n] == 0).mean() > 0.3
