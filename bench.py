@@ -464,6 +464,12 @@ def main():
         return text, w, BayesianSegNet(prototxt=text, weights=wts.pack(layers, w), T=t, device=local)
 
     text, w, sn = build_net(args.net, t_alloc)
+    _g = sn.guard_report()       # the load-time accuracy guard of the matrix-core layers: what THESE weights cost
+    guard_summary = {"layers_guarded": len(_g["layers"]), "largest_layer_rel_err": max([r["rel_err"] for r in _g["layers"]], default=None),
+                     "predicted_logit_rel_err": _g["predicted"], "budget": _g["budget"], "plans": _g["builds"], "layers_rerouted": sum(1 for r in _g["layers"] if r["level"]),
+                     "ms_at_construction": round(_g["ms"], 1),
+                     "note": "per layer: max |production kernel - direct fp32 kernel| / max |direct fp32| on the same input (two built-in frames x 2 MC samples); predicted = 0.5 sqrt(sum err^2) "
+                             "of the logit scale against 1e-3 / 30; tests/test_gpu_segnet.py::test_accuracy_guard_measures_every_layer_and_reroutes_an_inaccurate_plan"}
     bgr, left, right = make_inputs(H, W)
     d_bgr = torch.from_numpy(bgr).cuda()
     d_left = torch.from_numpy(left).cuda()
@@ -761,6 +767,7 @@ def main():
                           "algorithmic_gflop_per_frame": round((sn.flops_shared + T * sn.flops_per_sample) / 1e9, 2),
                           "reference_equivalent_gflop_per_frame": round(T * (sn.flops_shared + sn.flops_per_sample) / 1e9, 2),
                           "gemm": dict(zip(("mode", "fp16_overflow_frames"), sn.gemm_status()[:2]), frames_recomputed=stats["recomputed"]),
+                          "accuracy_guard": guard_summary,
                           "parity": "tests/test_gpu_frame_e2e.py (this frame end to end against the oracle pipeline), tests/test_gpu_segnet_fullsize.py (this network "
                                     "configuration, every logit, oracle-checked), tests/test_gpu_orb.py, tests/test_gpu_match_ba.py"},
                "roofline": roofline}
