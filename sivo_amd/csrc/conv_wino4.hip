@@ -83,6 +83,9 @@ struct Wino4Args {
     uint32_t *diag;             // diagnostic build: diag_words()
     int diag_coherent;          // diagnostic build: the bridge reads M with agent-scope loads (past the CU's vector L1)
     int diag_nt;                // diagnostic build: bit 0 the bridge reads M with non-temporal loads, bit 1 writes V' with non-temporal stores
+    int diag_hz;                // diagnostic build (SIVO_BRIDGE_HAZARD, the co-residency investigation): bit 0 a second barrier behind the one
+                                // that separates the plane's writes from its reads, bit 1 s_sleep behind it, bit 2 the window's 8-byte reads as
+                                // two 4-byte reads, bit 3 lgkmcnt(0) + s_sleep IN FRONT of the barrier
 #endif
 };
 
@@ -734,8 +737,13 @@ __global__ __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *
             }
         }
     }
+    if (a.diag_hz & 8) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_sleep(8); }
 #endif
     __syncthreads();
+#ifdef SIVO_DIAG
+    if (a.diag_hz & 1) __syncthreads();
+    if (a.diag_hz & 2) __builtin_amdgcn_s_sleep(8);
+#endif
     for (int t = threadIdx.x; t < ntile; t += blockDim.x) {
         const int tx = t % a.tw, ty = t / a.tw;
         const float *win = plane + (4 * ty) * RS + 4 * tx;       // 16-byte aligned: RS % 4 == 0
@@ -743,7 +751,10 @@ __global__ __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const f32x4 q = *reinterpret_cast<const f32x4 *>(win + i * RS);
-            const float2 r2 = *reinterpret_cast<const float2 *>(win + i * RS + 4);
+            float2 r2 = *reinterpret_cast<const float2 *>(win + i * RS + 4);
+#ifdef SIVO_DIAG
+            if (a.diag_hz & 4) { r2.x = *reinterpret_cast<const volatile float *>(win + i * RS + 4); r2.y = *reinterpret_cast<const volatile float *>(win + i * RS + 5); }
+#endif
             d[i][0] = q.x; d[i][1] = q.y; d[i][2] = q.z; d[i][3] = q.w; d[i][4] = r2.x; d[i][5] = r2.y;
         }
         float tb[6][6];
@@ -935,6 +946,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
     a.diag = std::getenv("SIVO_BRIDGE_CHECK") ? diag_words() : nullptr;
     a.diag_coherent = std::getenv("SIVO_BRIDGE_M_COHERENT") != nullptr;
     a.diag_nt = std::getenv("SIVO_BRIDGE_NT") ? std::atoi(std::getenv("SIVO_BRIDGE_NT")) : 0;
+    a.diag_hz = std::getenv("SIVO_BRIDGE_HAZARD") ? std::atoi(std::getenv("SIVO_BRIDGE_HAZARD")) : 0;
 #endif
     const bool h3 = c.wt_h3 && c.h3_vscale > 0.f;
     a.vscale = h3 ? c.h3_vscale : 0.f;

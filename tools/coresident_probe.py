@@ -28,6 +28,13 @@ VARIANTS = [
     ("occupant with ds traffic 128K beside a one-lane handle", {"DBG_LANES_A": "1", "SIVO_H3_LDS_ALL": "0", "PROBE_OCCUPY": "131072,1"}),
     ("occupant with LDS-DMA traffic 128K beside a one-lane handle", {"DBG_LANES_A": "1", "SIVO_H3_LDS_ALL": "0", "PROBE_OCCUPY": "131072,2"}),
     ("occupant with LDS-DMA traffic 112K beside a one-lane handle", {"DBG_LANES_A": "1", "SIVO_H3_LDS_ALL": "0", "PROBE_OCCUPY": "114688,2"}),
+    ("HZ exact LDS, baseline (does the round-3 corruption still reproduce on this build?)", {"SIVO_H3_LDS_ALL": "0"}),
+    ("HZ exact LDS, baseline again", {"SIVO_H3_LDS_ALL": "0"}),
+    ("HZ exact LDS, a second barrier between the plane's writes and its reads", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "1"}),
+    ("HZ exact LDS, s_sleep behind the barrier", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "2"}),
+    ("HZ exact LDS, the window's 8-byte reads as two 4-byte reads", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "4"}),
+    ("HZ exact LDS, lgkmcnt(0) + s_sleep in front of the barrier", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "8"}),
+    ("HZ exact LDS, second barrier + sleep + split reads", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "7"}),
     ("one lane both, LDS poisoned in front of every kernel", {"SIVO_POISON_LDS": "1", "DBG_LANES_A": "1", "SIVO_H3_LDS_ALL": "0"}),
 ]
 
@@ -65,7 +72,7 @@ def body(name):
         words()
         bad = 0
         occ = os.environ.get("PROBE_OCCUPY")
-        for seed in (99, 5, 7, 11):
+        for seed in ((99, 5, 7, 11, 13, 17, 19, 23) if os.environ.get('PROBE_SEEDS8') else (99, 5, 7, 11)):
             if occ:      # ~40 ms of occupant launches (150 us each) on their own stream, then the two frames beside them
                 L.sivo_debug_occupy(int(occ.split(",")[0]), int(occ.split(",")[1]), 150, 400)
                 import time
@@ -96,7 +103,7 @@ def body(name):
                 K, Pp, nt, tw = max(w[16], 1), max(w[17], 1), max(w[18], 1), max(w[19], 1)
                 xi, co, pp = idx // (K * Pp), (idx // Pp) % K, idx % Pp
                 print(f"    word {idx}: xi {xi} cout {co} sample {pp // nt} tile {pp % nt} (row {pp % nt // tw} col {pp % nt % tw}): first run {xa:08x} second run {xb:08x}")
-        print(f"[{name}] frames that differ: {bad} of 4; bridge border cells dirty {w[0]} in {w[1]} workgroups checked; GEMM canary words changed {w[2]} in {w[3]} workgroups; "
+        print(f"[{name}] frames that differ: {bad} of {8 if os.environ.get('PROBE_SEEDS8') else 4}; bridge border cells dirty {w[0]} in {w[1]} workgroups checked; GEMM canary words changed {w[2]} in {w[3]} workgroups; "
               f"re-run compare over {w[6]} layers: M words differing {w[4]}, V' words differing {w[5]}; "
               f"plane words changed after they were written {w[7]} (first: index {w[8]} of a {w[12] >> 16} x {w[12] & 0xffff} plane, wrote {w[9]:08x} found {w[10]:08x}, n {w[11] >> 16} cout {w[11] & 0xffff})", flush=True)
 
