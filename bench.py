@@ -515,6 +515,13 @@ def main():
         consumed = [torch.cuda.Event() for _ in range(nbuf)]                                             # the samples that read this buffer are enqueued
         band_state = {"cur": 0, "primed": False}
 
+        def gather_slots(b):
+            # RCCL: straight into the (world, slot) tensor; gloo (the one-GPU rehearsal) has no all_gather_into_tensor for device tensors
+            if backend == "nccl":
+                dist.all_gather_into_tensor(all_slots[b].view(-1), my_slot[b])
+            else:
+                dist.all_gather(slot_views[b], my_slot[b])
+
         def issue_band(b):
             """This rank's band of the prefix + the all-gather of every rank's slot into buffer b, on the side stream."""
             with torch.cuda.stream(side):
@@ -523,7 +530,7 @@ def main():
                 band_ev[b][0].record()
                 sn.prefix_band_into(d_bgr, rank, world, my_slot[b])
                 band_ev[b][1].record()
-                dist.all_gather(slot_views[b], my_slot[b])
+                gather_slots(b)
                 band_ev[b][2].record()
 
     # The rank that runs ORB (rank 0) keeps TWO frames in flight.  A frame's device work (network [+ all-reduce + finalize], ORB,
@@ -566,7 +573,7 @@ def main():
         elif banded:
             sn.prefix_band_into(d_bgr, rank, world, my_slot[0])
             ev[1].record()
-            dist.all_gather(slot_views[0], my_slot[0])
+            gather_slots(0)
             ev[2].record()
             if n_local:
                 sn.forward_banded_into(all_slots[0], world, seed, prob_sum, n_samples=n_local, sample0=sample0)
@@ -658,27 +665,7 @@ def main():
     # issue the forward in one lane so that a launch has the GPU to itself); SIVO_BENCH_NO_EVENTS=1: none at all.
     PROFILE_EVERY = 8
     events = os.environ.get("SIVO_BENCH_NO_EVENTS") != "1"
-    # Under `rocprofv3 --selected-regions` (tools/profile_round.sh sets SIVO_BENCH_ROCTX=1) only the frames are collected: the kernels a
-    # handle launches while it is constructed (calibration passes, the accuracy guard's two frames — partly the SAME kernels at two
-    # samples per launch) would otherwise sit in the per-kernel averages the roofline figures are cross-checked against.
-    roctx = None
-    if os.environ.get("SIVO_BENCH_ROCTX") == "1":
-        import ctypes
-        for name in ("librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so"):
-            try:
-                roctx = ctypes.CDLL(name)
-                roctx.roctxProfilerResume.argtypes = [ctypes.c_uint64]; roctx.roctxProfilerPause.argtypes = [ctypes.c_uint64]
-                break
-            except (OSError, AttributeError):
-                roctx = None
-        if roctx is None:
-            raise SystemExit("SIVO_BENCH_ROCTX=1 but no roctx library with roctxProfilerResume is loadable")
-        torch.cuda.synchronize()
-        roctx.roctxProfilerResume(0)
     elapsed, prof_timed, prof, n_detail = time_segnet(sn, frame, args.steps, args.warmup, barrier, PROFILE_EVERY, events, flush)
-    if roctx is not None:
-        torch.cuda.synchronize()
-        roctx.roctxProfilerPause(0)
     pipeline_check = None
     if pipelined and world == 1:
         # self-check of the two-frames-in-flight loop: the frame with seed 777 between two others, against the same frame alone

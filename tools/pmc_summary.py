@@ -22,12 +22,21 @@ def short(name):
 def main():
     out_path, dirs = sys.argv[1], sys.argv[2:]
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    dropped = 0
     for d in dirs:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-            for r in csv.DictReader(open(f)):
+            rows = list(csv.DictReader(open(f)))
+            # frames only: a handle's construction (calibration passes, the accuracy guard) launches kernels too, partly the same ones at
+            # two samples per launch; the guard's comparison kernel is the last thing construction launches
+            key = "Dispatch_Id" if rows and "Dispatch_Id" in rows[0] else None
+            last = max((int(r[key]) for r in rows if "absdiff_max_kernel" in r["Kernel_Name"]), default=-1) if key else -1
+            for r in rows:
+                if key and int(r[key]) <= last:
+                    dropped += 1
+                    continue
                 a = acc[short(r["Kernel_Name"])][r["Counter_Name"]]
                 a[0] += float(r["Counter_Value"]); a[1] += 1
-    res = {"_how": "rocprofv3 --pmc passes (one counter group per pass, no trace domains) over `python bench.py --steps 2 --warmup 1 "
+    res = {"_construction_rows_dropped": dropped, "_how": "FRAMES ONLY (every dispatch up to the accuracy guard's last absdiff_max_kernel dropped: construction); rocprofv3 --pmc passes (one counter group per pass, no trace domains) over `python bench.py --steps 2 --warmup 1 "
                    "--no-cpu-baseline --no-orb`; per-dispatch means; bytes = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024 with the gfx950 "
                    "FETCH_SIZE correction of MI355X_MICROARCH.md; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs / 8 XCD-summed)"}
     for k, cs in sorted(acc.items()):
@@ -42,7 +51,7 @@ def main():
         res[k] = e
     json.dump(res, open(out_path, "w"), indent=1)
     for k, e in res.items():
-        if k != "_how":
+        if not k.startswith("_"):
             print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in e.items()})
 
 

@@ -1,6 +1,8 @@
 #!/bin/bash
-# (Round 5: every rocprofv3 pass of bench.py runs with --selected-regions; bench.py opens the region behind the handle's construction,
-# so that calibration and accuracy-guard launches are not in the per-kernel figures.)
+# (Round 5: a handle launches kernels while it is constructed — calibration passes, the accuracy guard's two frames, partly the SAME
+# kernels at two samples per launch.  The per-kernel figures below count the FRAMES only: tools/frame_kernel_stats.py and
+# tools/pmc_summary.py drop every dispatch up to the guard's last absdiff_max_kernel; rocprofv3's own --stats file, which counts
+# everything, is kept beside it as *_incl_construction.csv.  `rocprofv3 --selected-regions` produced no output here.)
 # Round profile on the GPU box: bench line, rocprofv3 kernel statistics of every configuration of the line (main run plain and
 # SIVO_LANES=1 — the one whose average launch duration must agree with the HIP events of `roofline` —, SegNet-Basic T = 6,
 # Standard T = 48, local BA), PMC passes (HBM traffic / matrix-core busy; one counter group per pass, no trace domains) for the
@@ -22,7 +24,7 @@ pmc() {   # name, bench args
   for pass in "f FETCH_SIZE" "w WRITE_SIZE" "m SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     set -- $pass; p=$1; shift
     rm -rf /tmp/pmc_${name}_$p
-    (cd /tmp && SIVO_BENCH_ROCTX=1 SIVO_LANES=1 timeout 240 rocprofv3 --selected-regions --pmc "$@" --output-format csv -d /tmp/pmc_${name}_$p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-orb --configs none $args > /dev/null 2>&1)
+    (cd /tmp && SIVO_LANES=1 timeout 240 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_${name}_$p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-orb --configs none $args > /dev/null 2>&1)
   done
   python tools/pmc_summary.py $O/${TAG}_pmc_traffic_$name.json /tmp/pmc_${name}_f /tmp/pmc_${name}_w /tmp/pmc_${name}_m > /dev/null && python - <<PY
 import json
@@ -46,9 +48,11 @@ PY
 stats() {   # name, bench args (quoted string), env...
   local name=$1 args=$2; shift 2
   rm -rf /tmp/prof_$name
-  (cd /tmp && env SIVO_BENCH_ROCTX=1 "$@" timeout 300 rocprofv3 --selected-regions --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o $name -- python $R/bench.py --serial --no-cpu-baseline --configs none $args > $O/${TAG}_bench_line_under_rocprof_$name.json 2>/dev/null)
+  (cd /tmp && env "$@" timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o $name -- python $R/bench.py --serial --no-cpu-baseline --configs none $args > $O/${TAG}_bench_line_under_rocprof_$name.json 2>/dev/null)
   local f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
-  [ -n "$f" ] && cp $f $O/${TAG}_kernel_stats_$name.csv && head -5 $O/${TAG}_kernel_stats_$name.csv | cut -c1-150
+  [ -n "$f" ] && cp $f $O/${TAG}_kernel_stats_${name}_incl_construction.csv
+  local t=$(find /tmp/prof_$name -name "*kernel_trace.csv" | head -1)
+  [ -n "$t" ] && python tools/frame_kernel_stats.py $t $O/${TAG}_kernel_stats_$name.csv && head -5 $O/${TAG}_kernel_stats_$name.csv | cut -c1-150
 }
 stats main "--steps 20" SIVO_DUMMY=1
 stats onelane "--steps 20" SIVO_LANES=1
