@@ -890,14 +890,15 @@ def main():
             X0 = pts + rng.normal(0, 0.05, pts.shape)
             optimizer.local_ba(P0, fixed, X0, edges, intr, cov_pose=19)
             ts = []
-            for _ in range(10):
+            for _ in range(30):
                 t0 = time.perf_counter(); g = optimizer.local_ba(P0, fixed, X0, edges, intr, cov_pose=19); ts.append(time.perf_counter() - t0)
             t_call = float(np.mean(ts))                                         # the mean, like every other figure of the line
             nE, it = len(edges), max(g["iterations"], 1)
             alg_bytes = nE * (48 + 96 + 24 + (3 + 18 + 9 + 1 + 18 + 18) * 8) * it      # ~0.9 KB per edge per LM iteration
             extra.append({"name": "BASELINE configs[4]: local BA, 20 keyframes x 3000 map points (whole Optimizer::LocalBundleAdjustment solve on the GPU: "
                                   "per-edge residuals / Jacobians, Schur complement, LM, marginal covariance)",
-                          "metric": "ms per LocalBundleAdjustment call (mean of 10)", "value": round(t_call * 1e3, 3), "min_ms": round(min(ts) * 1e3, 3), "edges": int(nE), "lm_iterations": g["iterations"],
+                          "metric": "ms per LocalBundleAdjustment call (mean of 30)", "value": round(t_call * 1e3, 3), "min_ms": round(min(ts) * 1e3, 3),
+                          "median_ms": round(float(np.median(ts)) * 1e3, 3), "std_ms": round(float(np.std(ts)) * 1e3, 3), "calls": len(ts), "edges": int(nE), "lm_iterations": g["iterations"],
                           "ms_per_lm_iteration": round(t_call * 1e3 / it, 3),
                           "roofline": {"bound": "hbm", "achieved": round(alg_bytes / t_call / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(alg_bytes / t_call / 1e9 / HBM_PEAK_GBS, 5),

@@ -646,7 +646,12 @@ __global__ __launch_bounds__(W4_TIN) void wino4_output_kernel(Wino4Args a) {
 // PACK: the next layer runs the f16x3 GEMM: its V is written as packed fp16 pairs scaled by next_vscale.
 template <bool PACK>
 __global__ __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *Vnext, float next_vscale, uint32_t *next_vmax) {
-    extern __shared__ float plane[];            // (4*th + 2) rows x (W + 4) floats; image pixel (y, x) at [y + 1][x + 1]
+    extern __shared__ float plane_raw[];        // (4*th + 2) rows x (W + 4) floats; image pixel (y, x) at [y + 1][x + 1]
+#ifdef SIVO_DIAG
+    float *plane = plane_raw + ((a.diag_hz & 16) ? 4096 : 0);      // (co-residency investigation: the plane 16 KB into its allocation)
+#else
+    float *plane = plane_raw;
+#endif
     const int n = blockIdx.x, co = blockIdx.y;
     const int RS = a.W + 4, rows = 4 * a.th + 2, ntile = a.th * a.tw;
     for (int i = threadIdx.x; i < rows * RS; i += blockDim.x) plane[i] = 0.f;
@@ -913,6 +918,9 @@ __global__ void diag_compare_kernel(const uint32_t *x, const uint32_t *y, int64_
 }
 #endif
 
+static size_t wino4_bridge_diag_pad() {      // diagnostic build, SIVO_BRIDGE_HAZARD bit 4: 16 KB of unused LDS in front of the bridge's plane
+    return (SIVO_DIAG_ENV("SIVO_BRIDGE_HAZARD") && (std::atoi(SIVO_DIAG_ENV("SIVO_BRIDGE_HAZARD")) & 16)) ? (size_t)16384 : 0;
+}
 size_t wino4_bridge_lds_bytes(int H, int W) { return (size_t)(4 * ((H + 3) / 4) + 2) * (W + 4) * sizeof(float); }
 
 // One F(4x4,3x3) layer.  `group` samples per pass over the workspace.  plan (optional) chains layers without going
@@ -1010,7 +1018,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
             const int nthr = ntile >= 1024 ? 1024 : (ntile + 63) / 64 * 64;
             const dim3 gb((unsigned)a.n, (unsigned)a.K);
             // (diagnostic build: SIVO_BRIDGE_LDS_ALL=1 gives the bridge a CU's whole LDS, so that it never shares a CU with an LDS user)
-            const size_t lb = SIVO_DIAG_ENV("SIVO_BRIDGE_LDS_ALL") ? (size_t)160 * 1024 : wino4_bridge_lds_bytes(a.H, a.W);
+            const size_t lb = SIVO_DIAG_ENV("SIVO_BRIDGE_LDS_ALL") ? (size_t)160 * 1024 : wino4_bridge_lds_bytes(a.H, a.W) + wino4_bridge_diag_pad();
             SIVO_DIAG_POISON(s);
             if (plan->next_vscale > 0.f) hipLaunchKernelGGL(wino4_bridge_kernel<true>, gb, dim3(nthr), lb, s, a, plan->Vnext, plan->next_vscale, plan->next_vmax);
             else hipLaunchKernelGGL(wino4_bridge_kernel<false>, gb, dim3(nthr), lb, s, a, plan->Vnext, 0.f, plan->next_vmax);
@@ -1037,7 +1045,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
             hipLaunchKernelGGL(diag_compare_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(a.M), reinterpret_cast<const uint32_t *>(m2),
                                (int64_t)36 * a.Kp * a.Pp, diag_words() + 4, (int)a.Pp, (int)a.Pp, (uint32_t *)nullptr);
             const int ntile = a.th * a.tw, nthr = ntile >= 1024 ? 1024 : (ntile + 63) / 64 * 64;
-            const size_t lb = SIVO_DIAG_ENV("SIVO_BRIDGE_LDS_ALL") ? (size_t)160 * 1024 : wino4_bridge_lds_bytes(a.H, a.W);
+            const size_t lb = SIVO_DIAG_ENV("SIVO_BRIDGE_LDS_ALL") ? (size_t)160 * 1024 : wino4_bridge_lds_bytes(a.H, a.W) + wino4_bridge_diag_pad();
             if (const char *occ = SIVO_DIAG_ENV("SIVO_W4_VERIFY_OCC")) {
                 // "mode,bytes": the second run of the bridge happens BESIDE a synthetic neighbour — the occupant kernel of diag_kernels.hip,
                 // one workgroup on every CU for 3 ms holding `bytes` of LDS (mode 0 idle, 1 ds traffic, 2 LDS-DMA traffic) — and nothing else
