@@ -742,7 +742,7 @@ def main():
                       f'{p["bytes_per_sample"] * p["samples"] / ms / 1e6 if ms else 0:8.1f} GB/s(alg)', file=sys.stderr)
         n_timed = len(range(0, args.steps, PROFILE_EVERY))
         note = (f"dominant kernel: HIP events on its launch stream in every {PROFILE_EVERY}th of the {args.steps} timed frames (those frames run the forward in one "
-                f"lane, one launch per layer; the others split the samples over three lanes); kernels_ms_per_frame: {n_detail} further untimed single-lane "
+                f"lane, one launch per layer; the others split the samples over SIVO_LANES sample groups on separate streams, default two); kernels_ms_per_frame: {n_detail} further untimed single-lane "
                 "frames with every kernel bracketed.  achieved / frac = direct-convolution FLOPs (SURVEY 8d) / kernel time against the dense fp16 / bf16 peak; "
                 "executed_* = the matrix-core products issued (the Winograd-domain GEMM of F(4x4,3x3) multiplies 1/4 of the direct convolution's products, the direct "
                 "f16x3 kernel all of them; each fp32 product is three fp16 MFMA products — so executed = 3/4 of algorithmic for the GEMM and 3x for the direct "
@@ -815,7 +815,7 @@ def main():
                     "algorithmic_gflop_per_frame": round(alg, 2), "roofline": r, "parity": parity}
         if "basic" in want:
             extra.append(segnet_config("BASELINE configs[1]: Bayesian SegNet Basic, T=6, 352x1024, 1 MI355X (SegNet + MC maps)", "basic", 6, 20,
-                                       "tests/test_gpu_segnet_fullsize.py [basic-6-*] (every logit within 1e-3 of the oracle, three lanes)", "basic"))
+                                       "tests/test_gpu_segnet_fullsize.py [basic-6-*] (every logit within 1e-3 of the oracle, default lanes)", "basic"))
         if "t48" in want:
             extra.append(segnet_config("BASELINE configs[3] on ONE GPU: SegNet Standard T=48 (the 8-GPU form shards 6 samples per rank)", "standard", 48, 6,
                                        "tests/test_gpu_segnet_fullsize.py::test_t48_and_its_shards_at_full_size (T = 48 in one handle and the 6-sample shards, oracle-checked), tests/test_distributed_cpu.py", "t48"))

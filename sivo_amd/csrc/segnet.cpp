@@ -721,7 +721,7 @@ std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const fl
         }
     }
     if (S.wino4_ws_floats) {
-        const int env_lanes = std::getenv("SIVO_LANES") ? std::atoi(std::getenv("SIVO_LANES")) : 3;
+        const int env_lanes = std::getenv("SIVO_LANES") ? std::atoi(std::getenv("SIVO_LANES")) : 2;
         S.ws_lanes = std::max(1, std::min(env_lanes, (int)sivo_segnet::MAX_LANES));
         S.d_wino4_ws = dev_alloc<float>((size_t)S.ws_lanes * S.wino4_ws_floats);      // one region per lane
         S.owned.push_back(S.d_wino4_ws);
@@ -1372,9 +1372,10 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
     // the sample-invariant ops form a prefix of the plan
     size_t fork = 0;
     while (fork < last && (S.ops[fork].skip || S.blobs[S.ops[fork].out].shared)) ++fork;
-    // SIVO_LANES = 1..4 (default 3: measured 68.5 / 70.0 / 70.7 / 66.6 frames/s for 1 / 2 / 3 / 4 lanes at T = 12): how many
+    // SIVO_LANES = 1..4 (default 2 since round 5: 137.8 / 141.3 - 143.2 / 139.1 - 140.3 / 129.5 frames/s for 1 / 2 / 3 / 4 lanes at T = 12
+    // with the f16x3 kernels, profiles/r05_lanes_sweep.log; T = 48: 40.9 / 40.5 / 40.1 for 2 / 3 / 4; round 1's fp32 kernels preferred 3): how many
     // sample groups run side by side; profiling keeps one launch per op, and lanes of fewer than 2 samples gain nothing
-    int lanes = S.d_wino4_ws ? S.ws_lanes : 3;
+    int lanes = S.d_wino4_ws ? S.ws_lanes : 2;
     if (S.profile) lanes = 1;
     while (lanes > 1 && n < 2 * lanes) --lanes;
     // The op at the fork (pool3 with its fused dropout in SegNet-Standard) produces per-sample values but also writes a

@@ -1,9 +1,9 @@
 """Parity of the configurations bench.py TIMES, at BASELINE.json's full geometry (352 x 1024, full widths):
-SegNet-Standard T = 12 and SegNet-Basic T = 6, default build (the per-sample part of the forward in three lanes
-on three streams, bridge / pooling / upsample fusions on), through the C ABI, against the CPU oracle.
+SegNet-Standard T = 12 and SegNet-Basic T = 6, default build (the per-sample part of the forward in sample groups on
+separate streams — two lanes since round 5, three before —, bridge / pooling / upsample fusions on), through the C ABI, against the CPU oracle.
 
 Three statements per (net, image, dropout seed):
-  1. lanes: the three-lane forward is bit-identical to a one-lane forward of the same handle configuration;
+  1. lanes: the two-lane (default) and the three-lane forward are bit-identical to a one-lane forward of the same handle configuration;
   2. teacher-forced: with the device's pooling switches imposed on the oracle, EVERY logit of EVERY sample agrees
      within 1e-3 (north star), and every imposed switch that differs from the oracle's own choice is a near-tie;
   3. free-running: the oracle decides its own switches.  Max pooling is discontinuous, so where the two sides
@@ -79,17 +79,21 @@ def _device_run(sn, net, img, seed):
 
 @pytest.mark.parametrize("kind,T", [("standard", 12), ("basic", 6)])
 def test_three_lanes_equal_one_lane_at_full_size(kind, T, kitti_like_bgr):
-    net, _, sn3 = _handle(kind, T)
+    """(and the default, two lanes: SIVO_LANES unset)"""
+    net, _, sn2 = _handle(kind, T)
     _, _, sn1 = _handle(kind, T, lanes=1)
+    _, _, sn3 = _handle(kind, T, lanes=3)
     img = torch.from_numpy(_images(kitti_like_bgr)["kitti"]).cuda()
     for seed in (2024, 5):
-        ps3, lg3, _ = sn3.forward(img, seed, want_logits=True)
         ps1, lg1, _ = sn1.forward(img, seed, want_logits=True)
-        torch.cuda.synchronize()
-        assert torch.equal(lg3, lg1) and torch.equal(ps3, ps1)
-        for L in _pool_layers(net):
-            assert np.array_equal(sn3.blob(L["top"][1]), sn1.blob(L["top"][1])), L["name"]
-    _cache.pop((kind, T, 1, ""))            # free the one-lane handle
+        for snx in (sn2, sn3):
+            psx, lgx, _ = snx.forward(img, seed, want_logits=True)
+            torch.cuda.synchronize()
+            assert torch.equal(lgx, lg1) and torch.equal(psx, ps1)
+            for L in _pool_layers(net):
+                assert np.array_equal(snx.blob(L["top"][1]), sn1.blob(L["top"][1])), L["name"]
+    _cache.pop((kind, T, 1, ""))            # free the one-lane and the three-lane handle
+    _cache.pop((kind, T, 3, ""))
 
 
 def _decoder_influence(net, mask_name, dirty_pooled, logits_name):
