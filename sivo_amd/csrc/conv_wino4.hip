@@ -753,6 +753,18 @@ __global__ __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *
         const int tx = t % a.tw, ty = t / a.tw;
         const float *win = plane + (4 * ty) * RS + 4 * tx;       // 16-byte aligned: RS % 4 == 0
         float d[6][6];
+#ifdef SIVO_DIAG
+        if (a.diag_hz & 32) {
+            // the window's rows read BOTTOM-UP (row 5 first): does the wrong word follow the read order or stay at element (0, 5)?
+#pragma unroll
+            for (int i = 5; i >= 0; --i) {
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(win + i * RS);
+                const float2 r2 = *reinterpret_cast<const float2 *>(win + i * RS + 4);
+                d[i][0] = q.x; d[i][1] = q.y; d[i][2] = q.z; d[i][3] = q.w; d[i][4] = r2.x; d[i][5] = r2.y;
+                asm volatile("" ::: "memory");          // (keeps the reads in this order)
+            }
+        } else
+#endif
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const f32x4 q = *reinterpret_cast<const f32x4 *>(win + i * RS);

@@ -38,6 +38,8 @@ VARIANTS = [
     ("HZ2 exact LDS, 256-tile GEMM items wherever the layer has 256 couts (160 KB: only the 112 KB 256 x 128 GEMM can share a CU)", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_TILE": "0"}),
     ("HZ2 exact LDS, 128-tile GEMM items everywhere (128 KB)", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_TILE": "1"}),
     ("HZ2 exact LDS, one lane (no other lane's bridge beside a GEMM; its own stream is ordered)", {"SIVO_H3_LDS_ALL": "0", "DBG_LANES_A": "1"}),
+    ("HZ3 exact LDS, GEMM + bridge run twice and compared (which V' element differs)", {"SIVO_H3_LDS_ALL": "0", "SIVO_W4_VERIFY": "1"}),
+    ("HZ3 exact LDS, run twice and compared, the bridge reads its window bottom-up", {"SIVO_H3_LDS_ALL": "0", "SIVO_W4_VERIFY": "1", "SIVO_BRIDGE_HAZARD": "32"}),
     ("HZ exact LDS, second barrier + sleep + split reads", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "7"}),
     ("one lane both, LDS poisoned in front of every kernel", {"SIVO_POISON_LDS": "1", "DBG_LANES_A": "1", "SIVO_H3_LDS_ALL": "0"}),
 ]
