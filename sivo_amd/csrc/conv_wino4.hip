@@ -712,6 +712,16 @@ __global__ __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *
             const int y = 4 * ty + i;
             if (y >= a.H) break;                 // rows below the image stay zero
             float *dst = plane + (y + 1) * RS + 4 * tx + 1;
+#ifdef SIVO_DIAG
+            if (a.diag_hz & 64) {          // every word by a ds_write_b32 of its own instead of ds_write2_b32 pairs
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)(dst + r);
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(la), "v"(vv[i][r]) : "memory");
+                }
+                continue;
+            }
+#endif
 #pragma unroll
             for (int r = 0; r < 4; ++r) dst[r] = vv[i][r];
         }

@@ -40,6 +40,8 @@ VARIANTS = [
     ("HZ2 exact LDS, one lane (no other lane's bridge beside a GEMM; its own stream is ordered)", {"SIVO_H3_LDS_ALL": "0", "DBG_LANES_A": "1"}),
     ("HZ3 exact LDS, GEMM + bridge run twice and compared (which V' element differs)", {"SIVO_H3_LDS_ALL": "0", "SIVO_W4_VERIFY": "1"}),
     ("HZ3 exact LDS, run twice and compared, the bridge reads its window bottom-up", {"SIVO_H3_LDS_ALL": "0", "SIVO_W4_VERIFY": "1", "SIVO_BRIDGE_HAZARD": "32"}),
+    ("HZ4 exact LDS, the plane written with one ds_write_b32 per word instead of ds_write2_b32 pairs", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "64"}),
+    ("HZ4 exact LDS, baseline once more", {"SIVO_H3_LDS_ALL": "0"}),
     ("HZ exact LDS, second barrier + sleep + split reads", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "7"}),
     ("one lane both, LDS poisoned in front of every kernel", {"SIVO_POISON_LDS": "1", "DBG_LANES_A": "1", "SIVO_H3_LDS_ALL": "0"}),
 ]
