@@ -820,6 +820,31 @@ __global__ __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *
         wino4_report(r, bad, vmax);
     }
 #ifdef SIVO_DIAG
+    // SIVO_BRIDGE_HAZARD bit 7 (co-residency investigation): at the very END of the workgroup — after the window reads, the transforms and
+    // the 36 V' stores — every thread loads the M values of its tiles AGAIN and compares what they give with what its plane words have
+    // held since the start.  A difference means the FIRST load of M saw other bytes than this one: M was not (yet) what the GEMM wrote
+    // when this workgroup started.  diag words: [13] plane words whose late recomputation differs, [14] bits held, [15] bits recomputed,
+    // [40] n << 16 | cout, [41] tile << 8 | (row << 2 | column) of the first such word
+    if ((a.diag_hz & 128) && a.diag) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < ntile; t += blockDim.x) {
+            const int tx = t % a.tw, ty = t / a.tw;
+            float vv[4][4];
+            tile_values(t, vv);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int y = 4 * ty + i;
+                if (y >= a.H) break;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t want = __float_as_uint(vv[i][r]), got = __float_as_uint(plane[(y + 1) * RS + 4 * tx + 1 + r]);
+                    if (want != got && atomicAdd(a.diag + 13, 1u) == 0u) {
+                        a.diag[14] = got; a.diag[15] = want; a.diag[40] = (uint32_t)(n << 16 | co); a.diag[41] = (uint32_t)(t << 8 | i << 2 | r);
+                    }
+                }
+            }
+        }
+    }
     // the zero border of the plane (row 0, the rows below the image, column 0, the columns right of the image) is written by nobody
     // after the first loop of this kernel: a non-zero cell at the end was written by somebody else
     if (a.diag) {
@@ -973,7 +998,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
     if (a.in_drop && (c.unpool_mask || c.in_sample_stride != 0)) throw std::invalid_argument("launch_conv_wino4: in_drop_site needs a plain sample-invariant input");
     a.pool_out = c.pool_out; a.pool_mask = c.pool_mask; a.pool_drop_site = c.pool_drop_site; a.Ho = (c.H + 1) / 2; a.Wo = (c.W + 1) / 2;
 #ifdef SIVO_DIAG
-    a.diag = std::getenv("SIVO_BRIDGE_CHECK") ? diag_words() : nullptr;
+    a.diag = (std::getenv("SIVO_BRIDGE_CHECK") || (std::getenv("SIVO_BRIDGE_HAZARD") && (std::atoi(std::getenv("SIVO_BRIDGE_HAZARD")) & 128))) ? diag_words() : nullptr;
     a.diag_coherent = std::getenv("SIVO_BRIDGE_M_COHERENT") != nullptr;
     a.diag_nt = std::getenv("SIVO_BRIDGE_NT") ? std::atoi(std::getenv("SIVO_BRIDGE_NT")) : 0;
     a.diag_hz = std::getenv("SIVO_BRIDGE_HAZARD") ? std::atoi(std::getenv("SIVO_BRIDGE_HAZARD")) : 0;

@@ -42,6 +42,8 @@ VARIANTS = [
     ("HZ3 exact LDS, run twice and compared, the bridge reads its window bottom-up", {"SIVO_H3_LDS_ALL": "0", "SIVO_W4_VERIFY": "1", "SIVO_BRIDGE_HAZARD": "32"}),
     ("HZ4 exact LDS, the plane written with one ds_write_b32 per word instead of ds_write2_b32 pairs", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "64"}),
     ("HZ4 exact LDS, baseline once more", {"SIVO_H3_LDS_ALL": "0"}),
+    ("HZ5 exact LDS, every bridge workgroup recomputes its plane from M once more at its END", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "128"}),
+    ("HZ5 claim-160K, the same late recomputation (control)", {"SIVO_BRIDGE_HAZARD": "128"}),
     ("HZ exact LDS, second barrier + sleep + split reads", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "7"}),
     ("one lane both, LDS poisoned in front of every kernel", {"SIVO_POISON_LDS": "1", "DBG_LANES_A": "1", "SIVO_H3_LDS_ALL": "0"}),
 ]
@@ -111,6 +113,11 @@ def body(name):
                 K, Pp, nt, tw = max(w[16], 1), max(w[17], 1), max(w[18], 1), max(w[19], 1)
                 xi, co, pp = idx // (K * Pp), (idx // Pp) % K, idx % Pp
                 print(f"    word {idx}: xi {xi} cout {co} sample {pp // nt} tile {pp % nt} (row {pp % nt // tw} col {pp % nt % tw}): first run {xa:08x} second run {xb:08x}")
+        if w[13]:
+            print(f"  plane words whose recomputation from M at the END of the workgroup differs from what the plane held: {w[13]}; first: held {w[14]:08x} recomputed {w[15]:08x} "
+                  f"sample {w[40] >> 16} cout {w[40] & 0xffff} tile {w[41] >> 8} output row {(w[41] >> 2) & 3} column {w[41] & 3}")
+        elif os.environ.get("SIVO_BRIDGE_HAZARD") and int(os.environ["SIVO_BRIDGE_HAZARD"]) & 128:
+            print("  plane words whose recomputation from M at the END of the workgroup differs: 0")
         print(f"[{name}] frames that differ: {bad} of {8 if os.environ.get('PROBE_SEEDS8') else 4}; bridge border cells dirty {w[0]} in {w[1]} workgroups checked; GEMM canary words changed {w[2]} in {w[3]} workgroups; "
               f"re-run compare over {w[6]} layers: M words differing {w[4]}, V' words differing {w[5]}; "
               f"plane words changed after they were written {w[7]} (first: index {w[8]} of a {w[12] >> 16} x {w[12] & 0xffff} plane, wrote {w[9]:08x} found {w[10]:08x}, n {w[11] >> 16} cout {w[11] & 0xffff})", flush=True)
