@@ -1041,6 +1041,9 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         static const int x6_min_blocks = SIVO_DIAG_ENV("SIVO_X6_MINBLOCKS") ? std::atoi(SIVO_DIAG_ENV("SIVO_X6_MINBLOCKS")) : 128;
         SIVO_DIAG_POISON(s);
         if (h3) {
+#ifdef SIVO_DIAG
+            if (a.diag_hz & 512) launch_occupy(0, 0, 50, nullptr, nullptr, s);
+#endif
             launch_wino4_gemm_h3(reinterpret_cast<const uint32_t *>(a.V), c.wt_h3, a.M, a.C, a.Kp, a.P, a.Pp, s);
         } else if (c.wt_x6 && nblocks(128, 128) >= x6_min_blocks) {
             const int pt6 = (a.P + 127) / 128, kt6 = a.Kp / 128;
@@ -1067,6 +1070,11 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
             // (diagnostic build: SIVO_BRIDGE_LDS_ALL=1 gives the bridge a CU's whole LDS, so that it never shares a CU with an LDS user)
             const size_t lb = SIVO_DIAG_ENV("SIVO_BRIDGE_LDS_ALL") ? (size_t)160 * 1024 : wino4_bridge_lds_bytes(a.H, a.W) + wino4_bridge_diag_pad();
             SIVO_DIAG_POISON(s);
+#ifdef SIVO_DIAG
+            // SIVO_BRIDGE_HAZARD bit 8: a kernel that does nothing for 50 us between the GEMM and its bridge on their stream (does the
+            // bridge see M too early?); bit 9: the same in FRONT of the GEMM (control: the same extra launch, another place)
+            if (a.diag_hz & 256) launch_occupy(0, 0, 50, nullptr, nullptr, s);
+#endif
             if (plan->next_vscale > 0.f) hipLaunchKernelGGL(wino4_bridge_kernel<true>, gb, dim3(nthr), lb, s, a, plan->Vnext, plan->next_vscale, plan->next_vmax);
             else hipLaunchKernelGGL(wino4_bridge_kernel<false>, gb, dim3(nthr), lb, s, a, plan->Vnext, 0.f, plan->next_vmax);
         } else {
