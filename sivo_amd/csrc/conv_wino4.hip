@@ -759,6 +759,9 @@ __global__ __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *
     if (a.diag_hz & 1) __syncthreads();
     if (a.diag_hz & 2) __builtin_amdgcn_s_sleep(8);
 #endif
+#ifdef SIVO_DIAG
+    uint32_t hz_chk = 0, hz_d05 = 0;
+#endif
     for (int t = threadIdx.x; t < ntile; t += blockDim.x) {
         const int tx = t % a.tw, ty = t / a.tw;
         const float *win = plane + (4 * ty) * RS + 4 * tx;       // 16-byte aligned: RS % 4 == 0
@@ -784,6 +787,15 @@ __global__ __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *
 #endif
             d[i][0] = q.x; d[i][1] = q.y; d[i][2] = q.z; d[i][3] = q.w; d[i][4] = r2.x; d[i][5] = r2.y;
         }
+#ifdef SIVO_DIAG
+        if (a.diag_hz & 1024) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) hz_chk = hz_chk * 0x9E3779B1u + __float_as_uint(d[i][j]);
+            hz_d05 = hz_d05 * 31u + __float_as_uint(d[0][5]);
+        }
+#endif
         float tb[6][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -843,6 +855,28 @@ __global__ __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *
                     }
                 }
             }
+        }
+    }
+    // SIVO_BRIDGE_HAZARD bit 10: every thread reads its tiles' 6 x 6 windows from the plane ONCE MORE at the end of the workgroup and
+    // compares a hash of the 36 words with the hash of what its first reads returned (no arithmetic between).  A difference means the
+    // first read saw other LDS contents than the last one; none, while frames still differ, means the fault is behind the transforms
+    // (the V' stores / memory).  [58] threads whose hashes differ, [59] of them with another word (0, 5), [60] n << 16 | cout, [61] thread
+    if ((a.diag_hz & 1024) && a.diag) {
+        __syncthreads();
+        asm volatile("" ::: "memory");
+        uint32_t chk2 = 0, d052 = 0;
+        for (int t = threadIdx.x; t < ntile; t += blockDim.x) {
+            const int tx = t % a.tw, ty = t / a.tw;
+            const volatile float *win = plane + (4 * ty) * RS + 4 * tx;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) chk2 = chk2 * 0x9E3779B1u + __float_as_uint(win[i * RS + j]);
+            d052 = d052 * 31u + __float_as_uint(win[5]);
+        }
+        if (chk2 != hz_chk) {
+            if (atomicAdd(a.diag + 58, 1u) == 0u) { a.diag[60] = (uint32_t)(n << 16 | co); a.diag[61] = threadIdx.x; }
+            if (d052 != hz_d05) atomicAdd(a.diag + 59, 1u);
         }
     }
     // the zero border of the plane (row 0, the rows below the image, column 0, the columns right of the image) is written by nobody
@@ -998,7 +1032,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
     if (a.in_drop && (c.unpool_mask || c.in_sample_stride != 0)) throw std::invalid_argument("launch_conv_wino4: in_drop_site needs a plain sample-invariant input");
     a.pool_out = c.pool_out; a.pool_mask = c.pool_mask; a.pool_drop_site = c.pool_drop_site; a.Ho = (c.H + 1) / 2; a.Wo = (c.W + 1) / 2;
 #ifdef SIVO_DIAG
-    a.diag = (std::getenv("SIVO_BRIDGE_CHECK") || (std::getenv("SIVO_BRIDGE_HAZARD") && (std::atoi(std::getenv("SIVO_BRIDGE_HAZARD")) & 128))) ? diag_words() : nullptr;
+    a.diag = (std::getenv("SIVO_BRIDGE_CHECK") || (std::getenv("SIVO_BRIDGE_HAZARD") && (std::atoi(std::getenv("SIVO_BRIDGE_HAZARD")) & (128 | 1024)))) ? diag_words() : nullptr;
     a.diag_coherent = std::getenv("SIVO_BRIDGE_M_COHERENT") != nullptr;
     a.diag_nt = std::getenv("SIVO_BRIDGE_NT") ? std::atoi(std::getenv("SIVO_BRIDGE_NT")) : 0;
     a.diag_hz = std::getenv("SIVO_BRIDGE_HAZARD") ? std::atoi(std::getenv("SIVO_BRIDGE_HAZARD")) : 0;

@@ -44,6 +44,8 @@ VARIANTS = [
     ("HZ4 exact LDS, baseline once more", {"SIVO_H3_LDS_ALL": "0"}),
     ("HZ5 exact LDS, every bridge workgroup recomputes its plane from M once more at its END", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "128"}),
     ("HZ5 claim-160K, the same late recomputation (control)", {"SIVO_BRIDGE_HAZARD": "128"}),
+    ("HZ7 exact LDS, every thread reads its window once more at the END of the workgroup and compares hashes", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "1024"}),
+    ("HZ7 claim-160K, the same (control)", {"SIVO_BRIDGE_HAZARD": "1024"}),
     ("HZ6 exact LDS, a 50 us do-nothing kernel between every GEMM and its bridge (same stream)", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "256"}),
     ("HZ6 exact LDS, the same kernel in front of every GEMM instead (control)", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "512"}),
     ("HZ exact LDS, second barrier + sleep + split reads", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "7"}),
@@ -120,6 +122,9 @@ def body(name):
                   f"sample {w[40] >> 16} cout {w[40] & 0xffff} tile {w[41] >> 8} output row {(w[41] >> 2) & 3} column {w[41] & 3}")
         elif os.environ.get("SIVO_BRIDGE_HAZARD") and int(os.environ["SIVO_BRIDGE_HAZARD"]) & 128:
             print("  plane words whose recomputation from M at the END of the workgroup differs: 0")
+        if os.environ.get("SIVO_BRIDGE_HAZARD") and int(os.environ["SIVO_BRIDGE_HAZARD"]) & 1024:
+            print(f"  threads whose 6 x 6 window read at the END of the workgroup differs from their first read: {w[58]} (of them with another word (0, 5): {w[59]}; "
+                  f"first: sample {w[60] >> 16} cout {w[60] & 0xffff} thread {w[61]})")
         print(f"[{name}] frames that differ: {bad} of {8 if os.environ.get('PROBE_SEEDS8') else 4}; bridge border cells dirty {w[0]} in {w[1]} workgroups checked; GEMM canary words changed {w[2]} in {w[3]} workgroups; "
               f"re-run compare over {w[6]} layers: M words differing {w[4]}, V' words differing {w[5]}; "
               f"plane words changed after they were written {w[7]} (first: index {w[8]} of a {w[12] >> 16} x {w[12] & 0xffff} plane, wrote {w[9]:08x} found {w[10]:08x}, n {w[11] >> 16} cout {w[11] & 0xffff})", flush=True)
