@@ -44,6 +44,8 @@ VARIANTS = [
     ("HZ4 exact LDS, baseline once more", {"SIVO_H3_LDS_ALL": "0"}),
     ("HZ5 exact LDS, every bridge workgroup recomputes its plane from M once more at its END", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "128"}),
     ("HZ5 claim-160K, the same late recomputation (control)", {"SIVO_BRIDGE_HAZARD": "128"}),
+    ("HZ8 exact LDS, conv_wino4.hip (transforms + bridge) compiled WITHOUT packed-FP32 VALU instructions", {"SIVO_H3_LDS_ALL": "0", "PROBE_DIAG_LIB": "libsivo_hip_diag_nopk.so"}),
+    ("HZ8 exact LDS, the usual diagnostic build (control)", {"SIVO_H3_LDS_ALL": "0"}),
     ("HZ7 exact LDS, every thread reads its window once more at the END of the workgroup and compares hashes", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "1024"}),
     ("HZ7 claim-160K, the same (control)", {"SIVO_BRIDGE_HAZARD": "1024"}),
     ("HZ6 exact LDS, a 50 us do-nothing kernel between every GEMM and its bridge (same stream)", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "256"}),
@@ -64,6 +66,8 @@ def body(name):
     layers = netspec.parse_layers(text)
     flat = wts.pack(layers, wts.synth_weights(layers, 42))
     img = torch.from_numpy(make_inputs(H, W)[0]).cuda()
+    if os.environ.get("PROBE_DIAG_LIB"):          # another build of the diagnostic library (sivo_amd/csrc/Makefile: diag_nopk)
+        _lib.DIAG_PATH = os.path.join(os.path.dirname(_lib.DIAG_PATH), os.environ["PROBE_DIAG_LIB"])
     with _lib.use("diag") as L:
         L.sivo_debug_words.argtypes = [C.c_void_p, C.c_int]
         L.sivo_debug_occupy.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
