@@ -390,7 +390,7 @@ extern "C" int sivo_debug_occupy_wait(void) {
 // diagnostic build: `launches` launches of the self-checking bridge-pattern kernel (diag_kernels.hip lds_victim_kernel) on a stream of
 // its own, `grid` workgroups of the (H, W) plane geometry each, `rounds` rounds per workgroup; synchronises, then copies the 64 report
 // words (accumulated over the launches) to rep_out.  occupant_src is shared with sivo_debug_occupy.
-namespace sivo { void launch_lds_victim(int grid, int H, int W, int rounds, int jitter, const uint32_t *src, uint32_t *rep, hipStream_t s); }
+namespace sivo { void launch_lds_victim(int grid, int H, int W, int rounds, int jitter, const uint32_t *src, uint32_t *rep, hipStream_t s, bool pk); }
 extern "C" int sivo_debug_lds_victim(int grid, int H, int W, int rounds, int jitter, int launches, uint32_t rep_out[64]) {
     return sivo::guarded([&] {
         static hipStream_t st = nullptr;
@@ -402,7 +402,8 @@ extern "C" int sivo_debug_lds_victim(int grid, int H, int W, int rounds, int jit
             SIVO_HIP(hipMemset(d_src, 0x33, (size_t)(1 << 20) + 4096));
         }
         SIVO_HIP(hipMemsetAsync(d_rep, 0, 64 * sizeof(uint32_t), st));
-        for (int i = 0; i < launches; ++i) sivo::launch_lds_victim(grid, H, W, rounds, jitter, d_src, d_rep, st);
+        // (launches < 0: |launches| launches of the variant that also runs the bridge's arithmetic twice and compares, diag_kernels.hip PK)
+        for (int i = 0; i < std::abs(launches); ++i) sivo::launch_lds_victim(grid, H, W, rounds, jitter, d_src, d_rep, st, launches < 0);
         SIVO_HIP(hipStreamSynchronize(st));
         if (rep_out) SIVO_HIP(hipMemcpy(rep_out, d_rep, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost));
         return SIVO_OK;

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "common.hpp"
+#include "h3_split.hpp"
 #include "lds_dma.hpp"
 
 namespace sivo {
@@ -92,7 +93,37 @@ void launch_occupy(int lds_bytes, int mode, int microseconds, const uint32_t *sr
 // co-resident workgroups; first difference: [4] round, [5] window word (row * 6 + col), [6] expected bits, [7] bits read,
 // [8] LDS_ALLOC register, [9] workgroup, [10] tile, [11] what the same word reads a second time (after another barrier);
 // [12 .. 47] per window word (36): differences at that word; [48] / [49] LDS_ALLOC of a co-resident / a lone workgroup.
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7, 8))) void lds_victim_kernel(int H, int W, int rounds, int jitter, const uint32_t *src, uint32_t *rep) {
+// PK (tools/coresident_repro.py "pk"): every thread also runs the bridge's ARITHMETIC on its (verified) window — the two 1-D input
+// transforms (as wino4_bt, conv_wino4.hip; the compiler turns them into v_pk_mul_f32 / v_pk_add_f32) and the fp16 split of the 36 results —
+// TWICE from the same registers, and compares the packed words row by row: [51] rows of six words whose two computations differ,
+// first such row: [52] row, [53] / [54] hash of the first / second computation, [55] thread, [56] LDS_ALLOC, [57] rows computed / 2^20
+__device__ __forceinline__ void victim_bt(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5, float *t) {
+    const float a = d4 - 4.f * d2, b = d3 - 4.f * d1, c = d4 - d2, e = 2.f * (d3 - d1);
+    t[0] = 4.f * d0 - 5.f * d2 + d4; t[1] = a + b; t[2] = a - b; t[3] = c + e; t[4] = c - e; t[5] = 4.f * d1 - 5.f * d3 + d5;
+}
+__device__ __forceinline__ void victim_rows(const float (&d)[6][6], float scale, uint32_t (&h)[6]) {
+    float tb[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float col[6];
+        victim_bt(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], col);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tb[i][j] = col[i];
+    }
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float row[6];
+        victim_bt(tb[i][0], tb[i][1], tb[i][2], tb[i][3], tb[i][4], tb[i][5], row);
+        uint32_t x = 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) x = x * 0x9E3779B1u + wino4_pack_h3(row[j], scale, bad);
+        h[i] = x;
+    }
+}
+
+template <bool PK>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PK ? 4 : 7, 8))) void lds_victim_kernel(int H, int W, int rounds, int jitter, const uint32_t *src, uint32_t *rep) {
     extern __shared__ float vplane[];
     const int th = (H + 3) / 4, tw = W / 4, ntile = th * tw, RS = W + 4, rows = 4 * th + 2;
     const uint32_t alloc = __builtin_amdgcn_s_getreg((31 << 11) | 6);          // HW_REG_LDS_ALLOC: [7:0] base, [20:12] size
@@ -137,6 +168,24 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7, 8))) vo
                 const float2 r2 = *reinterpret_cast<const float2 *>(win + i * RS + 4);
                 d[i][0] = q.x; d[i][1] = q.y; d[i][2] = q.z; d[i][3] = q.w; d[i][4] = r2.x; d[i][5] = r2.y;
             }
+            if (PK) {
+                uint32_t h1[6], h2[6];
+                victim_rows(d, 16.f, h1);
+                asm volatile("" ::: "memory");          // the window is read from LDS once more (it was verified by the plain variant): each
+#pragma unroll                                          // computation is the bridge's own sequence, reads -> transforms -> split
+                for (int i = 0; i < 6; ++i) {
+                    const float4 q = *reinterpret_cast<const float4 *>(win + i * RS);
+                    const float2 r2 = *reinterpret_cast<const float2 *>(win + i * RS + 4);
+                    d[i][0] = q.x; d[i][1] = q.y; d[i][2] = q.z; d[i][3] = q.w; d[i][4] = r2.x; d[i][5] = r2.y;
+                }
+                victim_rows(d, 16.f, h2);
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    if (h1[i] != h2[i] && atomicAdd(rep + 51, 1u) == 0u) {
+                        rep[52] = (uint32_t)i; rep[53] = h1[i]; rep[54] = h2[i]; rep[55] = threadIdx.x; rep[56] = alloc;
+                    }
+            }
+            if (!PK)          // (the PK variant leaves the window check to the plain one: the registers are needed for the arithmetic)
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -168,11 +217,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7, 8))) vo
     }
 }
 
-void launch_lds_victim(int grid, int H, int W, int rounds, int jitter, const uint32_t *src, uint32_t *rep, hipStream_t s) {
+void launch_lds_victim(int grid, int H, int W, int rounds, int jitter, const uint32_t *src, uint32_t *rep, hipStream_t s, bool pk) {
     const int th = (H + 3) / 4, tw = W / 4, ntile = th * tw;
     const int nthr = ntile >= 1024 ? 1024 : (ntile + 63) / 64 * 64;             // as launch_conv_wino4 launches the bridge
     const size_t lds = (size_t)(4 * th + 2) * (W + 4) * sizeof(float);
-    hipLaunchKernelGGL(lds_victim_kernel, dim3(grid), dim3(nthr), lds, s, H, W, rounds, jitter, src, rep);
+    if (pk) hipLaunchKernelGGL(lds_victim_kernel<true>, dim3(grid), dim3(nthr), lds, s, H, W, rounds, jitter, src, rep);
+    else hipLaunchKernelGGL(lds_victim_kernel<false>, dim3(grid), dim3(nthr), lds, s, H, W, rounds, jitter, src, rep);
     SIVO_HIP(hipGetLastError());
 }
 

@@ -31,6 +31,14 @@ VARIANTS = [
     ("beside the f16x3 GEMM, exact LDS", {"SIVO_H3_LDS_ALL": "0"}, "gemm"),
     ("beside the f16x3 GEMM, exact LDS, again", {"SIVO_H3_LDS_ALL": "0"}, "gemm"),
     ("beside the f16x3 GEMM claiming 160K (as shipped)", {}, "gemm"),
+    # PK: the victim also runs the bridge's arithmetic (packed-FP32 VALU instructions) twice on every window and compares
+    ("PK alone", {"REPRO_PK": "1"}, None),
+    ("PK beside a GEMM-like occupant with MFMAs, 128K", {"REPRO_PK": "1"}, (131072, 4)),
+    ("PK beside a GEMM-like occupant without MFMAs, 128K", {"REPRO_PK": "1"}, (131072, 3)),
+    ("PK beside the f16x3 GEMM, exact LDS", {"REPRO_PK": "1", "SIVO_H3_LDS_ALL": "0"}, "gemm"),
+    ("PK beside the f16x3 GEMM claiming 160K", {"REPRO_PK": "1"}, "gemm"),
+    ("PK, compiled without packed-FP32 instructions, beside the f16x3 GEMM, exact LDS", {"REPRO_PK": "1", "SIVO_H3_LDS_ALL": "0", "PROBE_DIAG_LIB": "libsivo_hip_diag_nopk.so"}, "gemm"),
+    ("PK, compiled without packed-FP32 instructions, beside a GEMM-like occupant with MFMAs, 128K", {"REPRO_PK": "1", "PROBE_DIAG_LIB": "libsivo_hip_diag_nopk.so"}, (131072, 4)),
 ]
 
 
@@ -40,6 +48,9 @@ def body(name):
     from sivo_amd import _lib
     from sivo_amd.segnet import h3_gemm
     spec = dict((n, o) for n, _, o in VARIANTS)[name]
+    if os.environ.get("PROBE_DIAG_LIB"):          # another build of the diagnostic library (sivo_amd/csrc/Makefile: diag_nopk)
+        _lib.DIAG_PATH = os.path.join(os.path.dirname(_lib.DIAG_PATH), os.environ["PROBE_DIAG_LIB"])
+    pk = bool(os.environ.get("REPRO_PK"))
     with _lib.use("diag") as L:
         L.sivo_debug_lds_victim.argtypes = [C.c_int] * 6 + [C.c_void_p]
         L.sivo_debug_occupy.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
@@ -68,20 +79,21 @@ def body(name):
                     L.sivo_debug_occupy(spec[0], spec[1], 3000, 4)       # 4 x 3 ms on the occupant's stream
                     time.sleep(0.0005)
                 rep = (C.c_uint32 * 64)()
-                rc = L.sivo_debug_lds_victim(2048, H, W, 24, 6, 6, rep)
+                rc = L.sivo_debug_lds_victim(2048, H, W, 24, 6, -6 if pk else 6, rep)
                 assert rc == 0, L.sivo_last_error()
                 if isinstance(spec, tuple):
                     L.sivo_debug_occupy_wait()
                 first = tot[2] == 0 and rep[2] != 0
                 for i in range(64):
-                    if i in (0, 1, 2, 3, 50) or 12 <= i < 48:
+                    if i in (0, 1, 2, 3, 50, 51) or 12 <= i < 48:
                         tot[i] += rep[i]
-                    elif first or (i in (48, 49) and rep[i]):
+                    elif first or (i in (48, 49) and rep[i]) or (52 <= i <= 56 and rep[51] and not tot[53] and not tot[54]):
                         tot[i] = rep[i]
             words = {k: tot[12 + k] for k in range(36) if tot[12 + k]}
             print(f"[{name}] plane {H}x{W}: workgroups {tot[0]}, of which above >= 112 KB of other LDS {tot[1]} ({tot[3]} rounds; base exactly 112 / 128 KB: {tot[50]}); window words that differed {tot[2]}"
                   + (f"; first: round {tot[4]} window word (row {tot[5] // 6}, col {tot[5] % 6}) expected {tot[6]:08x} read {tot[7]:08x} re-read {tot[11]:08x} "
                      f"LDS_ALLOC {tot[8]:08x} workgroup {tot[9]} tile {tot[10]}; by window word {words}" if tot[2] else "")
+                  + (f"; PK: rows of six packed words whose two computations differ {tot[51]}" + (f" (first: row {tot[52]} hashes {tot[53]:08x} / {tot[54]:08x} thread {tot[55]} LDS_ALLOC {tot[56]:08x})" if tot[51] else "") if pk else "")
                   + f"; LDS_ALLOC of a co-resident / a lone workgroup {tot[48]:08x} / {tot[49]:08x}  [{time.perf_counter() - t0:.1f} s]", flush=True)
         stop.set()
         if th:
