@@ -44,6 +44,9 @@ VARIANTS = [
     ("HZ4 exact LDS, baseline once more", {"SIVO_H3_LDS_ALL": "0"}),
     ("HZ5 exact LDS, every bridge workgroup recomputes its plane from M once more at its END", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "128"}),
     ("HZ5 claim-160K, the same late recomputation (control)", {"SIVO_BRIDGE_HAZARD": "128"}),
+    ("HZ9 exact LDS, ONLY the bridge kernel compiled without packed-FP32 instructions", {"SIVO_H3_LDS_ALL": "0", "PROBE_DIAG_LIB": "libsivo_hip_diag_nopk_bridge.so"}),
+    ("HZ9 exact LDS, only the bridge kernel without packed-FP32 instructions, GEMM + bridge run twice and compared", {"SIVO_H3_LDS_ALL": "0", "SIVO_W4_VERIFY": "1", "PROBE_DIAG_LIB": "libsivo_hip_diag_nopk_bridge.so"}),
+    ("HZ9 exact LDS, the OTHER kernels of conv_wino4.hip compiled without them, the bridge as shipped", {"SIVO_H3_LDS_ALL": "0", "PROBE_DIAG_LIB": "libsivo_hip_diag_nopk_others.so"}),
     ("HZ8 exact LDS, conv_wino4.hip (transforms + bridge) compiled WITHOUT packed-FP32 VALU instructions", {"SIVO_H3_LDS_ALL": "0", "PROBE_DIAG_LIB": "libsivo_hip_diag_nopk.so"}),
     ("HZ8 exact LDS, the usual diagnostic build (control)", {"SIVO_H3_LDS_ALL": "0"}),
     ("HZ7 exact LDS, every thread reads its window once more at the END of the workgroup and compares hashes", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "1024"}),
