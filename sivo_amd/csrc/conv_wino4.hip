@@ -37,16 +37,16 @@
 #include <type_traits>
 #include <vector>
 
-// co-residency investigation (Makefile diag_nopk_split): kernels of this file compiled without packed-FP32 VALU instructions
-#ifdef SIVO_NOPK_BRIDGE
-#define W4_NOPK_BRIDGE __attribute__((target("no-packed-fp32-ops")))
+// wino4_bridge_kernel is compiled WITHOUT packed-FP32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32), DESIGN 3.3: with
+// them, a bridge workgroup that shares a CU with a workgroup of the f16x3 GEMM (wino4_gemm_h3_kernel<128, 256>: fp16 MFMAs + LDS-DMA) now
+// and then stores a V' word computed from other values than its registers held — LDS, M and the window reads verified clean, the same
+// arithmetic in scalar instructions never differs (tools/coresident_probe.py HZ5 / HZ7 / HZ8 / HZ9, profiles/r05_coresident_hazard_*).
+// tests/test_codeobj.py checks the product's code object for it.  The diagnostic build can put the packed form back
+// (-DSIVO_BRIDGE_PACKED_FP32, Makefile diag_pkbridge): the reproducer.
+#if defined(SIVO_DIAG) && defined(SIVO_BRIDGE_PACKED_FP32)
+#define W4_BRIDGE_NO_PK
 #else
-#define W4_NOPK_BRIDGE
-#endif
-#ifdef SIVO_NOPK_OTHERS
-#define W4_NOPK_OTHERS __attribute__((target("no-packed-fp32-ops")))
-#else
-#define W4_NOPK_OTHERS
+#define W4_BRIDGE_NO_PK __attribute__((target("no-packed-fp32-ops")))
 #endif
 
 #include "common.hpp"
@@ -128,7 +128,7 @@ constexpr int W4_TIN = 256;
 // UNPOOL: the input is read through a max-unpool (Upsample scale 2): 4 x 4 pooled values + window codes per tile
 // instead of 6 x 6 unpooled values, and the unpooled tensor never exists in HBM.
 template <bool UNPOOL, bool PACK>
-__global__ W4_NOPK_OTHERS __launch_bounds__(W4_TIN) void wino4_input_kernel(Wino4Args a) {
+__global__ __launch_bounds__(W4_TIN) void wino4_input_kernel(Wino4Args a) {
     const int p = blockIdx.x * W4_TIN + threadIdx.x, c = blockIdx.y;
     if (p >= a.P) return;       // whole waves leave together except in the last block; shuffles below only pair live lanes
     const int tx = p % a.tw, ty = (p / a.tw) % a.th, n = p / (a.tw * a.th);
@@ -250,7 +250,7 @@ constexpr int G_STAGE = G_KC * (G_BM + G_BN);             // floats per LDS stag
 // row c stores its 16-float groups XOR-swizzled by (c & 1): even rows as they are, odd rows with neighbouring
 // groups exchanged.  LDS-DMA fixes the destination (wave base + lane * 16 B), so the swizzle is applied to the SOURCE.
 template <int BM, int BN>
-__global__ W4_NOPK_OTHERS __launch_bounds__(256, 2) void wino4_gemm_kernel(Wino4Args a, int ptiles, int ktiles) {
+__global__ __launch_bounds__(256, 2) void wino4_gemm_kernel(Wino4Args a, int ptiles, int ktiles) {
     extern __shared__ float lds[];
     constexpr int TM = BM / 2, TN = BN / 2, MTF = TM / 16, NTF = TN / 16;     // fragments per lane: 4 or 2
     constexpr int STAGE = G_KC * (BM + BN);
@@ -392,7 +392,7 @@ __device__ __forceinline__ void x6p_barrier() { asm volatile("s_waitcnt lgkmcnt(
 constexpr int X6P_VRAW = 128 * X6_KC * 4;        // one fp32 V stage as the LDS-DMA leaves it (16 KB)
 constexpr int X6P_LDS = (2 + 3) * 3 * X6_PLANE + 2 * X6P_VRAW;       // V planes x 2, U planes x 3, raw V x 2 = 152 KB
 
-__global__ W4_NOPK_OTHERS __launch_bounds__(512, 1) void wino4_gemm_x6p_kernel(Wino4Args a, const uint4 *__restrict__ Ux, int ptiles, int ktiles) {
+__global__ __launch_bounds__(512, 1) void wino4_gemm_x6p_kernel(Wino4Args a, const uint4 *__restrict__ Ux, int ptiles, int ktiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds6[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nchunks = a.C / X6_KC;
@@ -568,7 +568,7 @@ __device__ __forceinline__ void wino4_at(const float m0, const float m1, const f
 // POOL: instead of the 4x4 outputs the kernel writes the 2x2 pooled values (first strict maximum in scan order, as
 // maxpool2_kernel / Caffe), their window codes and the pooling layer's dropout — the convolution output is not stored.
 template <bool POOL>
-__global__ W4_NOPK_OTHERS __launch_bounds__(W4_TIN) void wino4_output_kernel(Wino4Args a) {
+__global__ __launch_bounds__(W4_TIN) void wino4_output_kernel(Wino4Args a) {
     const int p = blockIdx.x * W4_TIN + threadIdx.x, co = blockIdx.y;
     if (p >= a.P) return;
     const int tx = p % a.tw, ty = (p / a.tw) % a.th, n = p / (a.tw * a.th);
@@ -657,7 +657,7 @@ __global__ W4_NOPK_OTHERS __launch_bounds__(W4_TIN) void wino4_output_kernel(Win
 // Reads 2.25 y + writes 2.25 y instead of (2.25 y + y) + (y + 2.25 y).   grid: (n, K_A), dynamic LDS = plane.
 // PACK: the next layer runs the f16x3 GEMM: its V is written as packed fp16 pairs scaled by next_vscale.
 template <bool PACK>
-__global__ W4_NOPK_BRIDGE __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *Vnext, float next_vscale, uint32_t *next_vmax) {
+__global__ W4_BRIDGE_NO_PK __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *Vnext, float next_vscale, uint32_t *next_vmax) {
     extern __shared__ float plane_raw[];        // (4*th + 2) rows x (W + 4) floats; image pixel (y, x) at [y + 1][x + 1]
 #ifdef SIVO_DIAG
     float *plane = plane_raw + ((a.diag_hz & 16) ? 4096 : 0);      // (co-residency investigation: the plane 16 KB into its allocation)

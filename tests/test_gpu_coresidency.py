@@ -1,10 +1,15 @@
-"""The co-residency mitigation of DESIGN 3.1e, guarded deterministically, and the frame's kernels beside each other.
+"""The co-residency fault of DESIGN 3.3, its two mitigations guarded deterministically, and the frame's kernels beside each other.
 
-Round 3 found frames that were not reproducible when a wino4_bridge_kernel workgroup shared a CU with the f16x3 GEMM's LDS-DMA
-stream (the bridge lost one LDS dword).  The mechanism is still open (tools/coresident_repro.py, DESIGN 3.1e: neither the bridge
-beside synthetic LDS / LDS-DMA occupants nor a self-checking copy of its access pattern beside the real GEMM reproduces it); the
-product avoids the constellation: every kernel that issues LDS-DMA in inline assembly leaves no LDS on its CU for a foreign
-workgroup.
+Round 3 found frames that were not reproducible when a wino4_bridge_kernel workgroup shared a CU with a workgroup of the f16x3 GEMM.
+Round 5 narrowed it down (tools/coresident_probe.py HZ5 / HZ7 / HZ8 / HZ9): LDS, M and the bridge's window reads are clean; the wrong
+V' words come out of the bridge's arithmetic when — and only when — the kernel is compiled with packed-FP32 VALU instructions
+(v_pk_mul_f32 / v_pk_add_f32).  The product (a) compiles the bridge without them (tests/test_codeobj.py checks the code object on the
+CPU) and (b) still keeps the constellation from arising: every kernel that issues LDS-DMA in inline assembly leaves no LDS on its CU
+for a foreign workgroup.
+  * test_bridge_as_shipped_is_reproducible_beside_the_exact_lds_gemm — (b) switched off in the diagnostic build (the GEMM asks for
+    its exact LDS, so bridge workgroups DO share CUs with it): eight full-size frames on three lanes must equal the one-lane
+    handle bit for bit.  With the packed form of the bridge (libsivo_hip_diag_pkbridge.so, the reproducer) 6 - 8 of 8 differ; that run
+    is reported, not asserted.
   * test_lds_dma_kernels_leave_no_lds_beside_them — the launchers note the dynamic LDS they ask for per CU; one frame of each
     reference net later every note must be the CU's whole 160 KB.  Fails the moment somebody removes the claim from a launcher.
   * test_frame_kernels_beside_each_other — the one pairing that is NOT excluded by construction: the f16x3 classifier runs two
@@ -38,6 +43,32 @@ def _net(kind, T):
 def _maps():
     return (torch.empty((H, W), dtype=torch.uint8, device="cuda"), torch.empty((H, W), dtype=torch.float64, device="cuda"),
             torch.empty((H, W), dtype=torch.float64, device="cuda"))
+
+
+def _probe(name):
+    """One variant of tools/coresident_probe.py in its own process (the diagnostic switches are read once per process)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import coresident_probe as cp
+    env = dict(os.environ)
+    env.update(dict((n, e) for n, e in cp.VARIANTS)[name])
+    env["PROBE_SEEDS8"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "coresident_probe.py"), "--one", name], env=env, capture_output=True, text=True, timeout=600)
+    m = re.search(r"frames that differ: (\d+) of (\d+)", out.stdout)
+    assert out.returncode == 0 and m, out.stdout[-2000:] + out.stderr[-2000:]
+    return int(m.group(1)), int(m.group(2)), out.stdout
+
+
+def test_bridge_as_shipped_is_reproducible_beside_the_exact_lds_gemm():
+    bad, n, _ = _probe("HZ8 exact LDS, the bridge as shipped (no packed-FP32 instructions)")
+    assert (bad, n) == (0, 8)
+    bad_pk, n_pk, _ = _probe("HZ8 exact LDS, the bridge with packed-FP32 instructions (the reproducer)")
+    print(f"[coresident] GEMM with its exact LDS (bridge workgroups share CUs with it), 3 lanes against 1 lane, full size: the bridge as shipped {bad} of {n} "
+          f"frames differ; the bridge compiled with packed-FP32 instructions {bad_pk} of {n_pk} frames differ")
 
 
 def test_lds_dma_kernels_leave_no_lds_beside_them():

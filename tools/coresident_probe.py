@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic build (libsivo_hip_diag.so), GPU box: SegNet-Standard T = 12 at 352 x 1024, three lanes against one lane (must be bit
+"""Diagnostic build (libsivo_hip_diag_pkbridge.so: the bridge WITH packed-FP32 instructions, the form that fails — DESIGN 3.3), GPU box: SegNet-Standard T = 12 at 352 x 1024, three lanes against one lane (must be bit
 identical) under the environment of the call, plus the report words of the diagnostic hooks (bridge border check, GEMM canary).
     python tools/coresident_probe.py            -> runs every variant below in its own process (the switches are read once)
     python tools/coresident_probe.py --one NAME -> the body, under the caller's environment"""
@@ -44,11 +44,9 @@ VARIANTS = [
     ("HZ4 exact LDS, baseline once more", {"SIVO_H3_LDS_ALL": "0"}),
     ("HZ5 exact LDS, every bridge workgroup recomputes its plane from M once more at its END", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "128"}),
     ("HZ5 claim-160K, the same late recomputation (control)", {"SIVO_BRIDGE_HAZARD": "128"}),
-    ("HZ9 exact LDS, ONLY the bridge kernel compiled without packed-FP32 instructions", {"SIVO_H3_LDS_ALL": "0", "PROBE_DIAG_LIB": "libsivo_hip_diag_nopk_bridge.so"}),
-    ("HZ9 exact LDS, only the bridge kernel without packed-FP32 instructions, GEMM + bridge run twice and compared", {"SIVO_H3_LDS_ALL": "0", "SIVO_W4_VERIFY": "1", "PROBE_DIAG_LIB": "libsivo_hip_diag_nopk_bridge.so"}),
-    ("HZ9 exact LDS, the OTHER kernels of conv_wino4.hip compiled without them, the bridge as shipped", {"SIVO_H3_LDS_ALL": "0", "PROBE_DIAG_LIB": "libsivo_hip_diag_nopk_others.so"}),
-    ("HZ8 exact LDS, conv_wino4.hip (transforms + bridge) compiled WITHOUT packed-FP32 VALU instructions", {"SIVO_H3_LDS_ALL": "0", "PROBE_DIAG_LIB": "libsivo_hip_diag_nopk.so"}),
-    ("HZ8 exact LDS, the usual diagnostic build (control)", {"SIVO_H3_LDS_ALL": "0"}),
+    ("HZ8 exact LDS, the bridge as shipped (no packed-FP32 instructions)", {"SIVO_H3_LDS_ALL": "0", "PROBE_DIAG_LIB": "libsivo_hip_diag.so"}),
+    ("HZ8 exact LDS, the bridge as shipped, GEMM + bridge run twice and compared", {"SIVO_H3_LDS_ALL": "0", "SIVO_W4_VERIFY": "1", "PROBE_DIAG_LIB": "libsivo_hip_diag.so"}),
+    ("HZ8 exact LDS, the bridge with packed-FP32 instructions (the reproducer)", {"SIVO_H3_LDS_ALL": "0"}),
     ("HZ7 exact LDS, every thread reads its window once more at the END of the workgroup and compares hashes", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "1024"}),
     ("HZ7 claim-160K, the same (control)", {"SIVO_BRIDGE_HAZARD": "1024"}),
     ("HZ6 exact LDS, a 50 us do-nothing kernel between every GEMM and its bridge (same stream)", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "256"}),
@@ -69,8 +67,9 @@ def body(name):
     layers = netspec.parse_layers(text)
     flat = wts.pack(layers, wts.synth_weights(layers, 42))
     img = torch.from_numpy(make_inputs(H, W)[0]).cuda()
-    if os.environ.get("PROBE_DIAG_LIB"):          # another build of the diagnostic library (sivo_amd/csrc/Makefile: diag_nopk)
-        _lib.DIAG_PATH = os.path.join(os.path.dirname(_lib.DIAG_PATH), os.environ["PROBE_DIAG_LIB"])
+    # the probe is about the fault: by default it loads the diagnostic build whose bridge still has its packed-FP32 instructions
+    # (sivo_amd/csrc/Makefile diag_pkbridge); PROBE_DIAG_LIB=libsivo_hip_diag.so is the diagnostic build of the bridge as shipped
+    _lib.DIAG_PATH = os.path.join(os.path.dirname(_lib.DIAG_PATH), os.environ.get("PROBE_DIAG_LIB", "libsivo_hip_diag_pkbridge.so"))
     with _lib.use("diag") as L:
         L.sivo_debug_words.argtypes = [C.c_void_p, C.c_int]
         L.sivo_debug_occupy.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]

@@ -37,8 +37,6 @@ VARIANTS = [
     ("PK beside a GEMM-like occupant without MFMAs, 128K", {"REPRO_PK": "1"}, (131072, 3)),
     ("PK beside the f16x3 GEMM, exact LDS", {"REPRO_PK": "1", "SIVO_H3_LDS_ALL": "0"}, "gemm"),
     ("PK beside the f16x3 GEMM claiming 160K", {"REPRO_PK": "1"}, "gemm"),
-    ("PK, compiled without packed-FP32 instructions, beside the f16x3 GEMM, exact LDS", {"REPRO_PK": "1", "SIVO_H3_LDS_ALL": "0", "PROBE_DIAG_LIB": "libsivo_hip_diag_nopk.so"}, "gemm"),
-    ("PK, compiled without packed-FP32 instructions, beside a GEMM-like occupant with MFMAs, 128K", {"REPRO_PK": "1", "PROBE_DIAG_LIB": "libsivo_hip_diag_nopk.so"}, (131072, 4)),
 ]
 
 
@@ -48,8 +46,6 @@ def body(name):
     from sivo_amd import _lib
     from sivo_amd.segnet import h3_gemm
     spec = dict((n, o) for n, _, o in VARIANTS)[name]
-    if os.environ.get("PROBE_DIAG_LIB"):          # another build of the diagnostic library (sivo_amd/csrc/Makefile: diag_nopk)
-        _lib.DIAG_PATH = os.path.join(os.path.dirname(_lib.DIAG_PATH), os.environ["PROBE_DIAG_LIB"])
     pk = bool(os.environ.get("REPRO_PK"))
     with _lib.use("diag") as L:
         L.sivo_debug_lds_victim.argtypes = [C.c_int] * 6 + [C.c_void_p]
