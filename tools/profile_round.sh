@@ -33,11 +33,15 @@ for k,v in d.items():
     if isinstance(v,dict) and v.get("bytes",0)>5e7: print("$name", k[:60], v.get("dispatches"), "MB", round(v["bytes"]/1e6,1), "mfma_busy", round(v.get("mfma_busy_frac",0),3))
 PY
 }
+# PROFILE_LIGHT=1: the bench line and the kernel statistics of the main configuration only (the PMC summaries in profiles/ stay)
+LIGHT=${PROFILE_LIGHT:-}
+if [ -z "$LIGHT" ]; then
 pmc main ""
 pmc basic "--net basic --T 6"
 pmc t48 "--T 48"
+fi
 # the line reads its `traffic` from profiles/: the PMC passes of THIS build first
-cp $O/${TAG}_pmc_traffic_*.json $R/profiles/ 2>/dev/null
+[ -z "$LIGHT" ] && cp $O/${TAG}_pmc_traffic_*.json $R/profiles/ 2>/dev/null
 timeout 600 python bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"
 python - <<PY
 import json
@@ -56,6 +60,7 @@ stats() {   # name, bench args (quoted string), env...
 }
 stats main "--steps 20" SIVO_DUMMY=1
 stats onelane "--steps 20" SIVO_LANES=1
+[ -n "$LIGHT" ] && exit 0
 stats basic "--net basic --T 6 --steps 20 --no-orb" SIVO_LANES=1
 stats t48 "--T 48 --steps 4 --warmup 1 --no-orb" SIVO_LANES=1
 timeout 200 python tools/layer_times.py 10 > $O/${TAG}_layer_times.txt 2>&1; tail -3 $O/${TAG}_layer_times.txt
