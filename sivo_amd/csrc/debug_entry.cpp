@@ -409,6 +409,65 @@ extern "C" int sivo_debug_lds_victim(int grid, int H, int W, int rounds, int jit
         return SIVO_OK;
     });
 }
+// diagnostic build: the two-kernel reproducer of DESIGN 3.3 — no network, no transforms but the bridge.  `lanes` streams, each with buffers
+// of its own, run ONE bridged F(4x4) layer of n samples, C -> C channels at H x W over and over: f16x3 GEMM (V -> M), bridge (M -> V'),
+// enqueued round-robin from this thread as the engine enqueues its lanes, so that one lane's bridge workgroups share CUs with another
+// lane's GEMM.  With SIVO_W4_VERIFY=1 in the environment launch_conv_wino4 runs GEMM and bridge a second time into scratch buffers and
+// compares word for word (diag words [4] M words, [5] V' words that differ, [6] layers compared).  V and the weights are random;
+// SIVO_H3_LDS_ALL=0 gives the GEMM its exact LDS.  out: [0] layers run per lane, [1] 1 if an overflow flag was raised.
+extern "C" int sivo_debug_bridge_pair(int lanes, int n, int C, int H, int W, int rounds, uint32_t out[2]) {
+    return sivo::guarded([&] {
+        if (sivo_device_count() < 1) return fail(SIVO_ERR_RUNTIME, "no HIP device");
+        if (lanes < 1 || lanes > 4 || n < 1 || !wino4_h3_supported(C, C) || H < 4 || W % 4 || rounds < 1) throw std::invalid_argument("bad argument");
+        const int th = (H + 3) / 4, tw = W / 4;
+        const int64_t P = (int64_t)n * th * tw, Pp = (P + 127) / 128 * 128;
+        const size_t nv = (size_t)36 * C * Pp;
+        std::vector<uint32_t> vp(nv);
+        uint64_t st = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&] { st = st * 6364136223846793005ull + 1442695040888963407ull; return (float)((int64_t)(st >> 40) - (1 << 23)) * (1.f / (1 << 23)); };   // [-1, 1)
+        for (size_t i = 0; i < nv; ++i) vp[i] = wino4_h3_pack_value(8.f * rnd(), 16.f);
+        std::vector<float> U((size_t)36 * C * C);
+        for (auto &u : U) u = 0.05f * rnd();
+        std::vector<uint16_t> planes;
+        const float uscale = wino4_h3_pack_weights(U, C, C, planes);
+        std::vector<float> eps((size_t)C, 0.05f), sh((size_t)C, 0.01f);
+        struct Lane { hipStream_t s; uint32_t *v; uint16_t *u; float *m, *vn, *sc, *sh; uint32_t *flag; };
+        std::vector<Lane> L((size_t)lanes);
+        for (auto &l : L) {
+            SIVO_HIP(hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking));
+            l.v = dev_alloc<uint32_t>(nv); l.u = dev_alloc<uint16_t>(planes.size()); l.m = dev_alloc<float>(nv); l.vn = dev_alloc<float>(nv);
+            l.sc = dev_alloc<float>((size_t)C); l.sh = dev_alloc<float>((size_t)C); l.flag = dev_alloc<uint32_t>(1);
+            SIVO_HIP(hipMemcpy(l.v, vp.data(), nv * 4, hipMemcpyHostToDevice));
+            SIVO_HIP(hipMemcpy(l.u, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+            SIVO_HIP(hipMemcpy(l.sc, eps.data(), (size_t)C * 4, hipMemcpyHostToDevice));
+            SIVO_HIP(hipMemcpy(l.sh, sh.data(), (size_t)C * 4, hipMemcpyHostToDevice));
+            SIVO_HIP(hipMemset(l.flag, 0, 4));
+            SIVO_HIP(hipMemset(l.m, 0, nv * 4)); SIVO_HIP(hipMemset(l.vn, 0, nv * 4));
+        }
+        SIVO_HIP(hipDeviceSynchronize());
+        for (int r = 0; r < rounds; ++r)
+            for (auto &l : L) {
+                ConvArgs c{};
+                c.in = nullptr; c.in_sample_stride = 0; c.wt = nullptr; c.ep_scale = l.sc; c.ep_shift = l.sh; c.out = nullptr;
+                c.N = n; c.Cin = C; c.H = H; c.W = W; c.Cout = C; c.CoutPad = C; c.relu = 1; c.drop_site = -1; c.sample0 = 0; c.seed = 1;
+                c.wt_h3 = l.u; c.h3_vscale = 16.f; c.h3_uscale = uscale; c.h3_flag = l.flag;
+                Wino4Plan plan{};
+                plan.V = reinterpret_cast<float *>(l.v); plan.M = l.m; plan.Vnext = l.vn; plan.skip_input = true; plan.bridge = true; plan.next_vscale = 16.f;
+                launch_conv_wino4(c, nullptr, n, l.s, nullptr, false, &plan);
+            }
+        SIVO_HIP(hipDeviceSynchronize());
+        uint32_t any = 0;
+        for (auto &l : L) {
+            uint32_t f = 0;
+            SIVO_HIP(hipMemcpy(&f, l.flag, 4, hipMemcpyDeviceToHost));
+            any |= f;
+            (void)hipFree(l.v); (void)hipFree(l.u); (void)hipFree(l.m); (void)hipFree(l.vn); (void)hipFree(l.sc); (void)hipFree(l.sh); (void)hipFree(l.flag);
+            (void)hipStreamDestroy(l.s);
+        }
+        if (out) { out[0] = (uint32_t)rounds; out[1] = any; }
+        return SIVO_OK;
+    });
+}
 // diagnostic build: the 64 report words of sivo::diag_words() (common.hpp); reset != 0 clears them after the read
 extern "C" int sivo_debug_words(uint32_t out[64], int reset) {
     return sivo::guarded([&] {
