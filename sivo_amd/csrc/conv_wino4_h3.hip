@@ -433,6 +433,22 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
 #undef H3_ABL_CASE
     }
 #endif
+#ifdef SIVO_DIAG
+    // co-residency investigation (tools/bridge_pair_repro.py): the 128 x 256 form — the bridge's partner — with parts of its
+    // work removed, at the LDS size of the call: which of its activities does the neighbour's fault need?
+    if (const char *ab = SIVO_DIAG_ENV("SIVO_H3_ABL128"); ab && t.bm == 128 && t.bn == 256) {
+#define H3_ABL128_CASE(n)                                                                                                           \
+    case n:                                                                                                                         \
+        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<128, 256, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((wino4_gemm_h3_kernel<128, 256, n>), grid, dim3(512), lds, s, a);                                        \
+        return;
+        switch (std::atoi(ab)) {
+            H3_ABL128_CASE(1) H3_ABL128_CASE(2) H3_ABL128_CASE(3) H3_ABL128_CASE(4) H3_ABL128_CASE(8) H3_ABL128_CASE(11) H3_ABL128_CASE(15)
+            default: break;
+        }
+#undef H3_ABL128_CASE
+    }
+#endif
     lds_claim_note(LDS_CLAIM_GEMM_H3, lds);
     if (t.bm == 256 && t.bn == 256) hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256>), grid, dim3(512), lds, s, a);
     else if (t.bm == 128 && t.bn == 256) hipLaunchKernelGGL((wino4_gemm_h3_kernel<128, 256>), grid, dim3(512), lds, s, a);

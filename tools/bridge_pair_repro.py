@@ -21,6 +21,14 @@ VARIANTS = [
     ("packed bridge, GEMM claiming 160 KB, 2 lanes", "libsivo_hip_diag_pkbridge.so", {}, 2),
     ("packed bridge, GEMM with its exact LDS, 1 lane", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0"}, 1),
     ("packed bridge, GEMM with its exact LDS, 3 lanes", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0"}, 3),
+    # the partner with parts of its work removed (its M is wrong by construction, but the same in both runs of the bridge)
+    ("ABL packed bridge, exact LDS, 2 lanes, GEMM without its MFMAs", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_ABL128": "8"}, 2),
+    ("ABL packed bridge, exact LDS, 2 lanes, GEMM without its U' LDS-DMA (after the prologue)", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_ABL128": "2"}, 2),
+    ("ABL packed bridge, exact LDS, 2 lanes, GEMM without its V' loads (after the prologue)", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_ABL128": "1"}, 2),
+    ("ABL packed bridge, exact LDS, 2 lanes, GEMM without loads and LDS-DMA", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_ABL128": "3"}, 2),
+    ("ABL packed bridge, exact LDS, 2 lanes, GEMM without its M stores", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_ABL128": "4"}, 2),
+    ("ABL packed bridge, exact LDS, 2 lanes, GEMM without loads, LDS-DMA and MFMAs (LDS reads + M stores left)", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_ABL128": "11"}, 2),
+    ("ABL packed bridge, exact LDS, 2 lanes, GEMM without loads, LDS-DMA, stores and MFMAs (LDS reads and barriers left)", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_ABL128": "15"}, 2),
 ]
 
 
@@ -46,6 +54,9 @@ if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "--one":
         body(sys.argv[2])
     else:
+        sel = os.environ.get("PROBE_ONLY")
         for name, _, env, _ in VARIANTS:
+            if sel and sel not in name:
+                continue
             e = dict(os.environ); e.update(env); e["SIVO_W4_VERIFY"] = "1"
             subprocess.run([sys.executable, os.path.abspath(__file__), "--one", name], env=e, timeout=200)
