@@ -800,6 +800,8 @@ __global__ W4_BRIDGE_NO_PK __launch_bounds__(1024) void wino4_bridge_kernel(Wino
             d[i][0] = q.x; d[i][1] = q.y; d[i][2] = q.z; d[i][3] = q.w; d[i][4] = r2.x; d[i][5] = r2.y;
         }
 #ifdef SIVO_DIAG
+        // bit 11: every LDS read has returned before the first arithmetic instruction (no packed instruction beside an LDS return)
+        if (a.diag_hz & 2048) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (a.diag_hz & 1024) {
 #pragma unroll
             for (int i = 0; i < 6; ++i)
@@ -836,6 +838,10 @@ __global__ W4_BRIDGE_NO_PK __launch_bounds__(1024) void wino4_bridge_kernel(Wino
                 if (PACK) reinterpret_cast<uint32_t *>(dst)[(int64_t)(i * 6 + j) * xs_v] = wino4_pack_h3(row[j], next_vscale, bad);
                 else dst[(int64_t)(i * 6 + j) * xs_v] = row[j];
             }
+#ifdef SIVO_DIAG
+            // bit 12: the six stores of a row have left the wave before the next row's arithmetic (no packed instruction beside a store in flight)
+            if (a.diag_hz & 4096) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         }
     }
     if (PACK || next_vmax) {

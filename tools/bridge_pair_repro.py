@@ -21,6 +21,11 @@ VARIANTS = [
     ("packed bridge, GEMM claiming 160 KB, 2 lanes", "libsivo_hip_diag_pkbridge.so", {}, 2),
     ("packed bridge, GEMM with its exact LDS, 1 lane", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0"}, 1),
     ("packed bridge, GEMM with its exact LDS, 3 lanes", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0"}, 3),
+    # the victim with one ingredient removed (SIVO_BRIDGE_HAZARD bits of conv_wino4.hip)
+    ("VIC packed bridge, exact LDS, 2 lanes, lgkmcnt(0) behind the window reads (no packed instruction beside an LDS return)", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "2048"}, 2),
+    ("VIC packed bridge, exact LDS, 2 lanes, vmcnt(0) behind every row's six stores (no packed instruction beside a store in flight)", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "4096"}, 2),
+    ("VIC packed bridge, exact LDS, 2 lanes, both", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "6144"}, 2),
+    ("VIC packed bridge, exact LDS, 2 lanes, unchanged (control)", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0"}, 2),
     # the partner with parts of its work removed (its M is wrong by construction, but the same in both runs of the bridge)
     ("ABL packed bridge, exact LDS, 2 lanes, GEMM without its MFMAs", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_ABL128": "8"}, 2),
     ("ABL packed bridge, exact LDS, 2 lanes, GEMM without its U' LDS-DMA (after the prologue)", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_ABL128": "2"}, 2),
