@@ -10,6 +10,8 @@ for a foreign workgroup.
     its exact LDS, so bridge workgroups DO share CUs with it): eight full-size frames on three lanes must equal the one-lane
     handle bit for bit.  With the packed form of the bridge (libsivo_hip_diag_pkbridge.so, the reproducer) 6 - 8 of 8 differ; that run
     is reported, not asserted.
+  * test_two_kernel_reproducer_bridge_beside_gemm — the same pair without the network (tools/bridge_pair_repro.py): one bridged layer
+    on two streams, every GEMM + bridge run twice and compared; 0 differing V' words as shipped, ~10^4 with the packed form (reported).
   * test_lds_dma_kernels_leave_no_lds_beside_them — the launchers note the dynamic LDS they ask for per CU; one frame of each
     reference net later every note must be the CU's whole 160 KB.  Fails the moment somebody removes the claim from a launcher.
   * test_frame_kernels_beside_each_other — the one pairing that is NOT excluded by construction: the f16x3 classifier runs two
@@ -69,6 +71,34 @@ def test_bridge_as_shipped_is_reproducible_beside_the_exact_lds_gemm():
     bad_pk, n_pk, _ = _probe("HZ8 exact LDS, the bridge with packed-FP32 instructions (the reproducer)")
     print(f"[coresident] GEMM with its exact LDS (bridge workgroups share CUs with it), 3 lanes against 1 lane, full size: the bridge as shipped {bad} of {n} "
           f"frames differ; the bridge compiled with packed-FP32 instructions {bad_pk} of {n_pk} frames differ")
+
+
+def test_two_kernel_reproducer_bridge_beside_gemm():
+    """tools/bridge_pair_repro.py: no network — two streams each run one bridged F(4x4) layer (f16x3 GEMM, then the bridge) over and over
+    on random data, the GEMM with its exact LDS so that one lane's bridge workgroups share CUs with the other lane's GEMM; every GEMM +
+    bridge is run twice and compared word for word.  The bridge as shipped: no V' word may differ in 1200 layer runs.  The same with the
+    bridge in its packed-FP32 form (the reproducer build) is reported beside it: ~10^4 words differ per second of run time."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import bridge_pair_repro as bp
+    found = {}
+    for name in ("bridge as shipped, GEMM with its exact LDS, 2 lanes", "packed bridge, GEMM with its exact LDS, 2 lanes"):
+        env = dict(os.environ)
+        env.update(next(v for v in bp.VARIANTS if v[0] == name)[2])
+        env["SIVO_W4_VERIFY"] = "1"
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "bridge_pair_repro.py"), "--one", name], env=env, capture_output=True, text=True, timeout=300)
+        m = re.search(r"(\d+) layer runs compared .*M words that differ (\d+), V' words that differ (\d+)", out.stdout)
+        assert out.returncode == 0 and m, out.stdout[-2000:] + out.stderr[-2000:]
+        found[name] = tuple(int(g) for g in m.groups())
+    shipped, packed = found["bridge as shipped, GEMM with its exact LDS, 2 lanes"], found["packed bridge, GEMM with its exact LDS, 2 lanes"]
+    assert shipped[0] >= 1200 and shipped[1:] == (0, 0), shipped
+    assert packed[1] == 0, packed                      # the GEMM itself is deterministic in either build
+    print(f"[coresident] two-kernel reproducer, {shipped[0]} layer runs each: V' words that differ between two runs of the same GEMM + bridge: "
+          f"bridge as shipped {shipped[2]}, bridge with packed-FP32 instructions {packed[2]}")
 
 
 def test_lds_dma_kernels_leave_no_lds_beside_them():
