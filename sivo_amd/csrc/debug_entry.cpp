@@ -409,6 +409,24 @@ extern "C" int sivo_debug_lds_victim(int grid, int H, int W, int rounds, int jit
         return SIVO_OK;
     });
 }
+// diagnostic build: `launches` launches of pkform_victim_kernel (diag_kernels.hip) on a stream of its own, grid workgroups of 384 threads
+// with 24 KB of LDS (the bridge's shape at 44 x 128), `rounds` instructions per thread; the report words accumulate over the launches
+namespace sivo { void launch_pkform_victim(int grid, int threads, int lds_bytes, int form, int rounds, uint32_t *rep, hipStream_t s); }
+extern "C" int sivo_debug_pkform(int grid, int form, int rounds, int launches, uint32_t rep_out[16]) {
+    return sivo::guarded([&] {
+        static hipStream_t st = nullptr;
+        static uint32_t *d_rep = nullptr;
+        if (!st) {
+            SIVO_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            SIVO_HIP(hipMalloc((void **)&d_rep, 16 * sizeof(uint32_t)));
+        }
+        SIVO_HIP(hipMemsetAsync(d_rep, 0, 16 * sizeof(uint32_t), st));
+        for (int i = 0; i < launches; ++i) sivo::launch_pkform_victim(grid, 384, 24 * 1024, form, rounds, d_rep, st);
+        SIVO_HIP(hipStreamSynchronize(st));
+        if (rep_out) SIVO_HIP(hipMemcpy(rep_out, d_rep, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        return SIVO_OK;
+    });
+}
 // diagnostic build: the two-kernel reproducer of DESIGN 3.3 — no network, no transforms but the bridge.  `lanes` streams, each with buffers
 // of its own, run ONE bridged F(4x4) layer of n samples, C -> C channels at H x W over and over: f16x3 GEMM (V -> M), bridge (M -> V'),
 // enqueued round-robin from this thread as the engine enqueues its lanes, so that one lane's bridge workgroups share CUs with another

@@ -217,6 +217,54 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PK ? 4 : 7
     }
 }
 
+// One packed-FP32 instruction form in a loop on known operands (tools/pkform_repro.py).  The forms are the ones that occur
+// in wino4_bridge_kernel's packed build and in no kernel that is known to be safe; the first computes, IN PLACE, {a - a, a - b} from the
+// register pair {a, b}: its high half reads the LOW source element, which the same instruction overwrites with its low result.
+//   form 0: v_pk_add_f32 p, p, p op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]      (in place)            expected {0, a - b}
+//   form 1: the same into another register pair                                                       expected {0, a - b}
+//   form 2: v_pk_add_f32 p, p, q (plain, in place)                                                    expected {a + c, b + d}
+// rep: [0] workgroups, [1] instructions checked / 2^20, [2] wrong high halves, [3] wrong low halves, [4] of the wrong high halves those that
+// equal -b (= low RESULT - b: the high half read the overwritten register), first wrong: [5] a, [6] b, [7] high found, [8] lane, [9] form
+__global__ __launch_bounds__(1024) void pkform_victim_kernel(int form, int rounds, uint32_t *rep) {
+    extern __shared__ float pkf_lds[];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    pkf_lds[threadIdx.x] = 0.f;           // (a dynamic LDS allocation like the bridge's, so that the workgroup is placed like one)
+    uint32_t st = (blockIdx.x * 1024u + threadIdx.x) * 2654435761u + 12345u;
+    unsigned bad_hi = 0, bad_lo = 0, bad_hi_is_minus_b = 0;
+    for (int r = 0; r < rounds; ++r) {
+        st = st * 1664525u + 1013904223u;
+        const float a = __uint_as_float(0x3f800000u | (st >> 9));                 // [1, 2)
+        st = st * 1664525u + 1013904223u;
+        const float b = __uint_as_float(0x40000000u | (st >> 9));                 // [2, 4)
+        f2 p = {a, b}, q = {b, a};
+        float want_lo, want_hi;
+        if (form == 0) {
+            asm volatile("v_pk_add_f32 %0, %0, %0 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "+v"(p));
+            want_lo = 0.f; want_hi = a - b;
+        } else if (form == 1) {
+            f2 d;
+            asm volatile("v_pk_add_f32 %0, %1, %1 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=&v"(d) : "v"(p));
+            p = d; want_lo = 0.f; want_hi = a - b;
+        } else {
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p) : "v"(q));
+            want_lo = a + b; want_hi = b + a;
+        }
+        if (__float_as_uint(p.y) != __float_as_uint(want_hi)) {
+            if (bad_hi++ == 0 && atomicAdd(rep + 2, 0u) == 0u) { rep[5] = __float_as_uint(a); rep[6] = __float_as_uint(b); rep[7] = __float_as_uint(p.y); rep[8] = threadIdx.x & 63; rep[9] = (uint32_t)form; }
+            if (__float_as_uint(p.y) == __float_as_uint(0.f - b)) ++bad_hi_is_minus_b;
+        }
+        if (__float_as_uint(p.x) != __float_as_uint(want_lo)) ++bad_lo;
+    }
+    if (bad_hi) atomicAdd(rep + 2, bad_hi);
+    if (bad_lo) atomicAdd(rep + 3, bad_lo);
+    if (bad_hi_is_minus_b) atomicAdd(rep + 4, bad_hi_is_minus_b);
+    if (threadIdx.x == 0) { atomicAdd(rep + 0, 1u); if (pkf_lds[0] == 1.f) rep[10] = 1; }
+}
+void launch_pkform_victim(int grid, int threads, int lds_bytes, int form, int rounds, uint32_t *rep, hipStream_t s) {
+    hipLaunchKernelGGL(pkform_victim_kernel, dim3(grid), dim3(threads), (size_t)lds_bytes, s, form, rounds, rep);
+    SIVO_HIP(hipGetLastError());
+}
+
 void launch_lds_victim(int grid, int H, int W, int rounds, int jitter, const uint32_t *src, uint32_t *rep, hipStream_t s, bool pk) {
     const int th = (H + 3) / 4, tw = W / 4, ntile = th * tw;
     const int nthr = ntile >= 1024 ? 1024 : (ntile + 63) / 64 * 64;             // as launch_conv_wino4 launches the bridge
