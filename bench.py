@@ -696,7 +696,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        # fp16 range guard of the f16x3 layers (DESIGN 3.1e): a rank cannot redo a collective on its own, so this loop does not
+        # fp16 range guard of the f16x3 layers (DESIGN 3.2): a rank cannot redo a collective on its own, so this loop does not
         # recompute an overflowed frame the way the N = 1 loop does (sivo_segnet_create_multi, the in-handle multi-device form, does).
         # It must not report a rate made of wrong frames either: any rank's flag fails the run loudly.
         ov = torch.tensor([1.0 if sn.take_overflow() else 0.0], dtype=torch.float64, device="cuda")

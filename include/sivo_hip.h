@@ -218,7 +218,7 @@ typedef struct SivoH3Layer {
     float vmax, vscale, uscale;
 } SivoH3Layer;
 int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow_frames, SivoH3Layer *per_layer, int capacity, int *n_layers);
-/* The load-time accuracy guard of the matrix-core layers (DESIGN 3.1h).  At construction every 3x3 layer the plan runs on Winograd
+/* The load-time accuracy guard of the matrix-core layers (DESIGN 3.4).  At construction every 3x3 layer the plan runs on Winograd
  * F(4x4,3x3) or on the fp16 hi + lo split is evaluated on two built-in calibration frames x MC samples 0, 1 beside the direct fp32
  * kernel, on the same input: rel_err = max |layer - direct fp32| / max |direct fp32| (rel_rms the same in rms).  *predicted =
  * 0.5 sqrt(sum rel_err^2) estimates the error of the logits relative to their scale; *budget = 1e-3 / 30 (the tolerance at the

@@ -48,7 +48,7 @@ int sivo_debug_conv_cls_h3_dev(int T, int Cin, int C, int H, int W, const float 
                                const float *shift, int relu, float vscale, float *d_logits, uint8_t *d_classes,
                                double *d_confidence, double *d_entropy, int iters, double *ms_out);
 
-/* The co-residency mitigation (DESIGN 3.1e): dynamic LDS per CU the launchers of the kernels that issue LDS-DMA in inline assembly asked
+/* The co-residency mitigation (DESIGN 3.3): dynamic LDS per CU the launchers of the kernels that issue LDS-DMA in inline assembly asked
  * for since the last reset — out[0] wino4_gemm_h3_kernel, [1] conv3_h3_kernel, [2] conv_cls_h3_kernel (both of its workgroups on a CU),
  * [3] conv7_h3_kernel; the smallest request of each, 0 = not launched.  163840 = nobody else's LDS fits on that CU. */
 int sivo_debug_lds_claims(uint32_t out[4], int reset);

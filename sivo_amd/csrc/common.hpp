@@ -112,7 +112,7 @@ void diag_poison_lds(hipStream_t s);
 #define SIVO_DIAG_POISON(s) ((void)0)
 #endif
 
-// The co-residency mitigation (DESIGN 3.1e): a kernel that issues LDS-DMA in inline assembly leaves no LDS on its CU for a foreign
+// The co-residency mitigation (DESIGN 3.3): a kernel that issues LDS-DMA in inline assembly leaves no LDS on its CU for a foreign
 // workgroup (one workgroup claiming the CU's 160 KB, or — the classifier at 64 input channels — two of its own claiming 80 KB each).
 // Its launcher notes the LDS it asked for PER CU; tests/test_gpu_coresidency.py reads the smallest note per kernel through
 // sivo_debug_lds_claims and fails when a launch leaves room beside it.

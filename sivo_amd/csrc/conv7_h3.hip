@@ -291,7 +291,7 @@ void launch_conv7_h3(const ConvArgs &a0, hipStream_t s) {
     a.tiles_x = (a.W + H7_TW - 1) / H7_TW;
     a.tiles_y = (a.H + H7_TH - 1) / H7_TH;
     const int P = a.tiles_x * a.tiles_y * a.N, band = (P + 7) / 8;
-    // the kernel uses H7_LDS (116 KB); it claims the CU's whole LDS like every kernel that issues LDS-DMA in inline assembly (DESIGN 3.1e:
+    // the kernel uses H7_LDS (116 KB); it claims the CU's whole LDS like every kernel that issues LDS-DMA in inline assembly (DESIGN 3.3:
     // no foreign workgroup beside it — it is a one-workgroup-per-CU kernel either way)
     const size_t lds = (size_t)160 * 1024;
     static_assert(H7_LDS <= 160 * 1024, "LDS");

@@ -67,7 +67,7 @@ static_assert(C_STAGE + 2 * C_WKS <= 80 * 1024, "two workgroups per CU (64 input
 // other is in its Softmax, and the SIMDs have two waves to choose from: **0.36 ms**, outputs bit-identical (tools/cls_probe.py).
 // Within a workgroup the next stage is requested as soon as every wave has read the current one (one barrier), i.e. under the
 // Softmax when there is one.  The two workgroups of a CU both issue LDS-DMA next to each other's ds_read traffic — the
-// constellation of DESIGN 3.1e's co-residency finding; this pair was checked bit-identical against the one-workgroup form and
+// constellation of DESIGN 3.3's co-residency finding; this pair was checked bit-identical against the one-workgroup form and
 // by the full-size network tests, and bench.py compares every run's pipelined frames with the serial loop.
 // ABL (diagnostic builds only, -DSIVO_DIAG; results are wrong by construction): 1 no MFMAs, 2 no Softmax / sum at the end of a sample,
 // 4 no patch DMA after the first stage, 8 no fragment reads after the first tap.
@@ -274,7 +274,7 @@ void launch_conv_cls_h3(const ClsMcArgs &a0, hipStream_t s) {
     }
     const int P = a.tiles_x * a.tiles_y, per = (P + 7) / 8;
     // 64 input channels: 80 KB, TWO workgroups of this kernel per CU (the two halves of a CU's LDS: what turned the sum of the kernel's
-    // two phases into their maximum) — a full CU has no LDS left for anybody else, and what a half-filled CU (head / tail of
+    // two phases into their maximum, NOTEBOOK 3.1g) — a full CU has no LDS left for anybody else, and what a half-filled CU (head / tail of
     // the launch) may host beside one of them is covered by tests/test_gpu_coresidency.py.  Any other width would leave a gap (98 KB at 96
     // channels): there the single workgroup claims the CU's whole LDS, like the other kernels that issue LDS-DMA in inline assembly.
     const size_t need = (size_t)C_STAGE + (size_t)(a.Cin / 32) * C_WKS;

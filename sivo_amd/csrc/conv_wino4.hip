@@ -380,7 +380,7 @@ __host__ __device__ __forceinline__ int x6_slot(int r, int kg) {
 // across item boundaries and a consumer's epilogue stores overlap the next item's first stages.  Items are dealt so
 // that the cout blocks of one (position, tile block) pair run at the same time on CUs of ONE XCD (V tile fetched into
 // that L2 once), and an XCD stays on one position for many items (U_xi resident in its L2).
-// Measured in round 2 (the variants tried there — flat two-workgroup form, 8 consumer / 8 producer waves, U
+// Measured in round 2 (NOTEBOOK 3.1b; the variants tried there — flat two-workgroup form, 8 consumer / 8 producer waves, U
 // fragments from global memory, two stages per barrier, wave priorities, per-role cycle stamps — are in the git history of
 // this file, their numbers in DESIGN): a stage costs 3250 cycles against 1536 of its MFMAs and the producers' chain
 // (ten DMA pieces + the V split per wave and stage) is the critical one.

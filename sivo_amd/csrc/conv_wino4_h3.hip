@@ -383,7 +383,7 @@ float wino4_h3_pack_weights(const std::vector<float> &U, int cin, int Kp, std::v
 // items each (the 22 x 64 layers, short shards); 256 x 128 when the layer has 128 couts.  (Items holding all 512 couts of a
 // layer — 128 x 512 tiles, the V' tile read from HBM once instead of twice — were built, verified and measured in round 3:
 // 3.19 against 3.00 ms of GEMM per frame; twice the U' bytes per stage through a CU's load path cost more than the
-// halved V' traffic saves.  Removed; numbers in DESIGN 3.1e.)
+// halved V' traffic saves.  Removed; numbers in NOTEBOOK 3.1e.)
 struct H3Tile { int bm, bn; };
 static H3Tile h3_tile(int64_t P, int Kp) {
     if (Kp % 256) return {256, 128};
@@ -396,8 +396,9 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
     // the exact size (96 - 128 KB in the first form of the kernel) another lane's small-LDS workgroups (wino4_bridge_kernel:
     // 7 - 24 KB) were placed beside it and the frame was no longer reproducible run to run (measured, round 3: three lanes !=
     // one lane, the same handle twice != itself; with every workgroup alone on its CU, or with no LDS user beside it,
-    // bit-identical; the GEMM alone beside such workgroups stays bit-exact, so the victim is presumably the neighbour — the
-    // mechanism was not isolated).  SIVO_H3_LDS_ALL=0 requests the exact size (debugging).
+    // bit-identical; the GEMM alone beside such workgroups stays bit-exact: the victim is the neighbour.  Round 5, DESIGN 3.3: the
+    // bridge's packed-FP32 instructions go wrong beside this kernel's MFMAs; the bridge is compiled without them now, the claim stays
+    // because the trigger is only known for that kernel).  SIVO_H3_LDS_ALL=0 requests the exact size (diagnostic build).
     static const bool lds_all = !(SIVO_DIAG_ENV("SIVO_H3_LDS_ALL") && std::atoi(SIVO_DIAG_ENV("SIVO_H3_LDS_ALL")) == 0);
     // SIVO_H3_TILE=0/1 forces the larger / smaller tile count per item (tests)
     static const int force_tile = SIVO_DIAG_ENV("SIVO_H3_TILE") ? std::atoi(SIVO_DIAG_ENV("SIVO_H3_TILE")) : -1;

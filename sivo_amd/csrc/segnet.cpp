@@ -881,7 +881,7 @@ void calibrate_h3(sivo_segnet &S) {
 // Budget: the tolerance is 1e-3 at the logit range of the reference configuration (|logit| <= 30), i.e. 3.3e-5 of the logits' scale.
 // Errors of independent layers add in quadrature and a relative error of the activations carries to the logits with a factor <= 0.5
 // (measured: predicted 0.5 sqrt(sum err_l^2) = 1.7 - 1.9e-5 against 0.95 - 1.9e-5 found against the oracle for the synthetic weights,
-// BN offsets 3 / 30 / 100, DESIGN 3.1h).  While the prediction is above the budget the largest contributors move one level down —
+// BN offsets 3 / 30 / 100, DESIGN 3.4).  While the prediction is above the budget the largest contributors move one level down —
 // F(4x4) -> direct f16x3 (no transform) -> F(2x2) / direct fp32 -> direct fp32 — the handle is planned again (fusions depend on
 // the kernels) and guarded again.  Two samples, two frames: ~1 s at load, nothing per
 // frame.  The decisions depend on the weights and the geometry only (never on T: always samples 0 and 1), so shard handles of one
@@ -1079,7 +1079,7 @@ GuardVerdict accuracy_guard(sivo_segnet &S, const float *weights, const std::map
             rows.push_back(r);
         }
         // predicted error of the logits relative to their scale: the layers' own errors in quadrature, times GUARD_CARRY (how much
-        // of a layer's LARGEST error reaches the logits: measured 0.3 - 0.5 over the weight families of the full-size sweep, DESIGN 3.1h)
+        // of a layer's LARGEST error reaches the logits: measured 0.3 - 0.5 over the weight families of the full-size sweep, DESIGN 3.4)
         constexpr double GUARD_CARRY = 0.5, REROUTED_ERR = 2e-6;
         double predicted = GUARD_CARRY * std::sqrt(sum2);
         // The prediction is an estimate: found / predicted was 0.6 - 0.9 for the weight families of the sweep and 2.4 for a plan whose

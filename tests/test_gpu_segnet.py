@@ -643,7 +643,7 @@ def test_accuracy_guard_measures_every_layer_and_reroutes_an_inaccurate_plan(ora
     the predicted logit error within the budget, nothing rerouted, one plan, the cost reported.
     (ii) A plan that really is inaccurate — the f16x3 scales forced 2^16 too SMALL (diagnostic build, SIVO_H3_BOOST=-16: the
     operands sit in fp16's subnormal range and lose most of their lo plane; no weight family of the full-size sweep pushes the
-    F(4x4) / f16x3 arithmetic itself over the budget, DESIGN 3.1h): UNGUARDED (SIVO_GUARD=0) its logits miss the 1e-3 tolerance
+    F(4x4) / f16x3 arithmetic itself over the budget, DESIGN 3.4): UNGUARDED (SIVO_GUARD=0) its logits miss the 1e-3 tolerance
     against the oracle; GUARDED the same configuration measures the damage layer by layer, takes those layers off F(4x4) and
     then off f16x3, plans again, and meets the tolerance."""
     T, H, W = 2, 96, 192

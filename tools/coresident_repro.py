@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic build, GPU box: the LDS access pattern of wino4_bridge_kernel on synthetic SELF-CHECKING data (lds_victim_kernel,
 diag_kernels.hip) beside (a) nothing, (b) the synthetic occupant (idle / ds traffic / LDS-DMA traffic) and (c) the REAL f16x3
-GEMM of the F(4x4) path with its exact LDS size (the pair that corrupted frames, DESIGN 3.1e) or claiming the whole LDS (the
+GEMM of the F(4x4) path with its exact LDS size (the pair that corrupted frames, DESIGN 3.3) or claiming the whole LDS (the
 mitigation).  The victim reports from the device how many of its workgroups ran BESIDE another LDS user on their CU (their LDS
 allocation does not start at 0), so "it did not fail" can be told from "it never shared a CU".
     python tools/coresident_repro.py            -> every variant in its own process (the switches are read once per process)
