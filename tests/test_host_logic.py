@@ -365,3 +365,29 @@ def test_kitti_sequence_listing_and_trajectory_format(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "cpp.txt").read_text() == out.read_text()
     assert r.stdout.split() == ["3", f"{seq}/image_2/000002.png", f"{seq}/image_3/000002.png", "0.207635"]
+
+
+def test_tools_the_gpu_tests_run_are_loadable():
+    """tests/test_gpu_coresidency.py runs tools/coresident_probe.py and tools/bridge_pair_repro.py in processes of their own and looks
+    their variants up by name: the tools must parse, import without a GPU, and still carry those variants and the libraries they name."""
+    import importlib
+    import py_compile
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in sorted(os.listdir(os.path.join(root, "tools"))):
+        if f.endswith(".py"):
+            py_compile.compile(os.path.join(root, "tools", f), doraise=True)
+    sys.path.insert(0, os.path.join(root, "tools"))
+    cp = importlib.import_module("coresident_probe")
+    bp = importlib.import_module("bridge_pair_repro")
+    probe = dict(cp.VARIANTS)
+    for name in ("HZ8 exact LDS, the bridge as shipped (no packed-FP32 instructions)", "HZ8 exact LDS, the bridge with packed-FP32 instructions (the reproducer)"):
+        assert probe[name].get("SIVO_H3_LDS_ALL") == "0", name
+    assert probe["HZ8 exact LDS, the bridge as shipped (no packed-FP32 instructions)"]["PROBE_DIAG_LIB"] == "libsivo_hip_diag.so"
+    pair = {v[0]: v for v in bp.VARIANTS}
+    assert pair["bridge as shipped, GEMM with its exact LDS, 2 lanes"][1:] == ("libsivo_hip_diag.so", {"SIVO_H3_LDS_ALL": "0"}, 2)
+    assert pair["packed bridge, GEMM with its exact LDS, 2 lanes"][1:] == ("libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0"}, 2)
+    assert pair["packed bridge, GEMM claiming 160 KB, 2 lanes"][1:] == ("libsivo_hip_diag_pkbridge.so", {}, 2)
+    # both diagnostic libraries are part of the build (the packed form of the bridge is the reproducer)
+    mk = open(os.path.join(root, "sivo_amd", "csrc", "Makefile")).read()
+    assert "all: $(OUT) dbg diag diag_pkbridge" in mk
