@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box: what compiling the WHOLE product library without packed-FP32 VALU instructions would cost (the blanket form
-of the mitigation).  sivo_amd/libsivo_hip_nopk.so is built by hand (every source with -Xclang -target-feature -Xclang
+of the mitigation).  sivo_amd/libsivo_hip_nopk.so: `make -C sivo_amd/csrc nopk` (every source with -Xclang -target-feature -Xclang
 -packed-fp32-ops; not part of `make all`); bench.py's main line runs once with the product library and once with that one.
     python tools/nopk_cost_probe.py"""
 import json
