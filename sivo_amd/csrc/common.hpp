@@ -100,16 +100,11 @@ class FirstUse {
 #endif
 
 #ifdef SIVO_DIAG
-// Diagnostic build only: 64 words of pinned host memory kernels report into (tools/coresident_probe.py reads them through
-// sivo_debug_words):  [0] border cells of a bridge workgroup's LDS plane found non-zero at its end (somebody else wrote there),
-// [1] bridge workgroups checked, [2] canary words behind the f16x3 GEMM's stage buffers found changed, [3] GEMM workgroups checked.
+// Diagnostic build only: 64 words of pinned host memory the SIVO_W4_VERIFY comparison reports into (conv_wino4.hip; read through
+// sivo_debug_words by tools/coresident_probe.py and tools/bridge_pair_repro.py): [4] M words that differ between two runs of a GEMM,
+// [5] V' words that differ between two runs of its bridge, [6] layers compared, [16..19] geometry of the first differing layer,
+// [20..] the first twelve differing V' words.
 uint32_t *diag_words();
-// SIVO_POISON_LDS=1: fills every CU's LDS with NaNs in front of the next kernel of the stream (a kernel that reads LDS it did not
-// write then produces NaNs instead of depending on what its predecessor left there).
-void diag_poison_lds(hipStream_t s);
-#define SIVO_DIAG_POISON(s) ::sivo::diag_poison_lds(s)
-#else
-#define SIVO_DIAG_POISON(s) ((void)0)
 #endif
 
 // The co-residency mitigation: a kernel that issues LDS-DMA in inline assembly leaves no LDS on its CU for a foreign

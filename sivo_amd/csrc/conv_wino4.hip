@@ -27,7 +27,6 @@
 #include <hip/hip_runtime.h>
 #include <map>
 #include <cstdio>
-#include <unistd.h>
 #include <stdint.h>
 
 #include <cstdlib>
@@ -91,14 +90,6 @@ struct Wino4Args {
     float vscale, mscale;
     uint32_t *h3_flag;
     uint32_t *vmax;             // calibration pass: atomicMax of the bit pattern of |V| (the layer's largest transformed value), or null
-#ifdef SIVO_DIAG
-    uint32_t *diag;             // diagnostic build: diag_words()
-    int diag_coherent;          // diagnostic build: the bridge reads M with agent-scope loads (past the CU's vector L1)
-    int diag_nt;                // diagnostic build: bit 0 the bridge reads M with non-temporal loads, bit 1 writes V' with non-temporal stores
-    int diag_hz;                // diagnostic build (SIVO_BRIDGE_HAZARD, the co-residency investigation): bit 0 a second barrier behind the one
-                                // that separates the plane's writes from its reads, bit 1 s_sleep behind it, bit 2 the window's 8-byte reads as
-                                // two 4-byte reads, bit 3 lgkmcnt(0) + s_sleep IN FRONT of the barrier
-#endif
 };
 
 // end of a transform thread: report an overflow / the calibration maximum (rare / calibration only)
@@ -659,11 +650,7 @@ __global__ __launch_bounds__(W4_TIN) void wino4_output_kernel(Wino4Args a) {
 template <bool PACK>
 __global__ W4_BRIDGE_NO_PK __launch_bounds__(1024) void wino4_bridge_kernel(Wino4Args a, float *Vnext, float next_vscale, uint32_t *next_vmax) {
     extern __shared__ float plane_raw[];        // (4*th + 2) rows x (W + 4) floats; image pixel (y, x) at [y + 1][x + 1]
-#ifdef SIVO_DIAG
-    float *plane = plane_raw + ((a.diag_hz & 16) ? 4096 : 0);      // (co-residency investigation: the plane 16 KB into its allocation)
-#else
     float *plane = plane_raw;
-#endif
     const int n = blockIdx.x, co = blockIdx.y;
     const int RS = a.W + 4, rows = 4 * a.th + 2, ntile = a.th * a.tw;
     for (int i = threadIdx.x; i < rows * RS; i += blockDim.x) plane[i] = 0.f;
@@ -682,12 +669,7 @@ __global__ W4_BRIDGE_NO_PK __launch_bounds__(1024) void wino4_bridge_kernel(Wino
             float m[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-#ifdef SIVO_DIAG
-                if (a.diag_coherent) m[i] = __hip_atomic_load(src + (int64_t)(i * 6 + j) * xs_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else if (a.diag_nt & 1) m[i] = __builtin_nontemporal_load(src + (int64_t)(i * 6 + j) * xs_m);
-                else
-#endif
-                    m[i] = src[(int64_t)(i * 6 + j) * xs_m];
+                m[i] = src[(int64_t)(i * 6 + j) * xs_m];
             }
             float s4[4];
             wino4_at(m[0], m[1], m[2], m[3], m[4], m[5], s4);
@@ -724,92 +706,21 @@ __global__ W4_BRIDGE_NO_PK __launch_bounds__(1024) void wino4_bridge_kernel(Wino
             const int y = 4 * ty + i;
             if (y >= a.H) break;                 // rows below the image stay zero
             float *dst = plane + (y + 1) * RS + 4 * tx + 1;
-#ifdef SIVO_DIAG
-            if (a.diag_hz & 64) {          // every word by a ds_write_b32 of its own instead of ds_write2_b32 pairs
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)(dst + r);
-                    asm volatile("ds_write_b32 %0, %1" ::"v"(la), "v"(vv[i][r]) : "memory");
-                }
-                continue;
-            }
-#endif
 #pragma unroll
             for (int r = 0; r < 4; ++r) dst[r] = vv[i][r];
         }
     }
-#ifdef SIVO_DIAG
-    // diagnostic build (SIVO_BRIDGE_CHECK): every thread computes its tiles' values again and compares them with what the plane holds
-    // now — a difference means the LDS word changed after this workgroup wrote it.  [7] words found changed; the first such word:
-    // [8] float index in the plane, [9] the bits written, [10] the bits found, [11] n << 16 | co, [12] rows << 16 | row stride
-    if (a.diag) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < ntile; t += blockDim.x) {
-            const int tx = t % a.tw, ty = t / a.tw;
-            float vv[4][4];
-            tile_values(t, vv);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int y = 4 * ty + i;
-                if (y >= a.H) break;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int at = (y + 1) * RS + 4 * tx + 1 + r;
-                    const uint32_t want = __float_as_uint(vv[i][r]), got = __float_as_uint(plane[at]);
-                    if (want != got && atomicAdd(a.diag + 7, 1u) == 0u) {
-                        a.diag[8] = (uint32_t)at; a.diag[9] = want; a.diag[10] = got; a.diag[11] = (uint32_t)(n << 16 | co);
-                        a.diag[12] = (uint32_t)(rows << 16 | RS);
-                    }
-                }
-            }
-        }
-    }
-    if (a.diag_hz & 8) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_sleep(8); }
-#endif
     __syncthreads();
-#ifdef SIVO_DIAG
-    if (a.diag_hz & 1) __syncthreads();
-    if (a.diag_hz & 2) __builtin_amdgcn_s_sleep(8);
-#endif
-#ifdef SIVO_DIAG
-    uint32_t hz_chk = 0, hz_d05 = 0;
-#endif
     for (int t = threadIdx.x; t < ntile; t += blockDim.x) {
         const int tx = t % a.tw, ty = t / a.tw;
         const float *win = plane + (4 * ty) * RS + 4 * tx;       // 16-byte aligned: RS % 4 == 0
         float d[6][6];
-#ifdef SIVO_DIAG
-        if (a.diag_hz & 32) {
-            // the window's rows read BOTTOM-UP (row 5 first): does the wrong word follow the read order or stay at element (0, 5)?
-#pragma unroll
-            for (int i = 5; i >= 0; --i) {
-                const f32x4 q = *reinterpret_cast<const f32x4 *>(win + i * RS);
-                const float2 r2 = *reinterpret_cast<const float2 *>(win + i * RS + 4);
-                d[i][0] = q.x; d[i][1] = q.y; d[i][2] = q.z; d[i][3] = q.w; d[i][4] = r2.x; d[i][5] = r2.y;
-                asm volatile("" ::: "memory");          // (keeps the reads in this order)
-            }
-        } else
-#endif
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const f32x4 q = *reinterpret_cast<const f32x4 *>(win + i * RS);
-            float2 r2 = *reinterpret_cast<const float2 *>(win + i * RS + 4);
-#ifdef SIVO_DIAG
-            if (a.diag_hz & 4) { r2.x = *reinterpret_cast<const volatile float *>(win + i * RS + 4); r2.y = *reinterpret_cast<const volatile float *>(win + i * RS + 5); }
-#endif
+            const float2 r2 = *reinterpret_cast<const float2 *>(win + i * RS + 4);
             d[i][0] = q.x; d[i][1] = q.y; d[i][2] = q.z; d[i][3] = q.w; d[i][4] = r2.x; d[i][5] = r2.y;
         }
-#ifdef SIVO_DIAG
-        // bit 11: every LDS read has returned before the first arithmetic instruction (no packed instruction beside an LDS return)
-        if (a.diag_hz & 2048) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (a.diag_hz & 1024) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) hz_chk = hz_chk * 0x9E3779B1u + __float_as_uint(d[i][j]);
-            hz_d05 = hz_d05 * 31u + __float_as_uint(d[0][5]);
-        }
-#endif
         float tb[6][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -828,20 +739,9 @@ __global__ W4_BRIDGE_NO_PK __launch_bounds__(1024) void wino4_bridge_kernel(Wino
                 for (int j = 0; j < 6; ++j) vmax = fmaxf(vmax, fabsf(row[j]));
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-#ifdef SIVO_DIAG
-                if (a.diag_nt & 2) {
-                    if (PACK) __builtin_nontemporal_store(wino4_pack_h3(row[j], next_vscale, bad), reinterpret_cast<uint32_t *>(dst) + (int64_t)(i * 6 + j) * xs_v);
-                    else __builtin_nontemporal_store(row[j], dst + (int64_t)(i * 6 + j) * xs_v);
-                    continue;
-                }
-#endif
                 if (PACK) reinterpret_cast<uint32_t *>(dst)[(int64_t)(i * 6 + j) * xs_v] = wino4_pack_h3(row[j], next_vscale, bad);
                 else dst[(int64_t)(i * 6 + j) * xs_v] = row[j];
             }
-#ifdef SIVO_DIAG
-            // bit 12: the six stores of a row have left the wave before the next row's arithmetic (no packed instruction beside a store in flight)
-            if (a.diag_hz & 4096) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         }
     }
     if (PACK || next_vmax) {
@@ -849,68 +749,6 @@ __global__ W4_BRIDGE_NO_PK __launch_bounds__(1024) void wino4_bridge_kernel(Wino
         r.vmax = next_vmax;
         wino4_report(r, bad, vmax);
     }
-#ifdef SIVO_DIAG
-    // SIVO_BRIDGE_HAZARD bit 7 (co-residency investigation): at the very END of the workgroup — after the window reads, the transforms and
-    // the 36 V' stores — every thread loads the M values of its tiles AGAIN and compares what they give with what its plane words have
-    // held since the start.  A difference means the FIRST load of M saw other bytes than this one: M was not (yet) what the GEMM wrote
-    // when this workgroup started.  diag words: [13] plane words whose late recomputation differs, [14] bits held, [15] bits recomputed,
-    // [40] n << 16 | cout, [41] tile << 8 | (row << 2 | column) of the first such word
-    if ((a.diag_hz & 128) && a.diag) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < ntile; t += blockDim.x) {
-            const int tx = t % a.tw, ty = t / a.tw;
-            float vv[4][4];
-            tile_values(t, vv);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int y = 4 * ty + i;
-                if (y >= a.H) break;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const uint32_t want = __float_as_uint(vv[i][r]), got = __float_as_uint(plane[(y + 1) * RS + 4 * tx + 1 + r]);
-                    if (want != got && atomicAdd(a.diag + 13, 1u) == 0u) {
-                        a.diag[14] = got; a.diag[15] = want; a.diag[40] = (uint32_t)(n << 16 | co); a.diag[41] = (uint32_t)(t << 8 | i << 2 | r);
-                    }
-                }
-            }
-        }
-    }
-    // SIVO_BRIDGE_HAZARD bit 10: every thread reads its tiles' 6 x 6 windows from the plane ONCE MORE at the end of the workgroup and
-    // compares a hash of the 36 words with the hash of what its first reads returned (no arithmetic between).  A difference means the
-    // first read saw other LDS contents than the last one; none, while frames still differ, means the fault is behind the transforms
-    // (the V' stores / memory).  [58] threads whose hashes differ, [59] of them with another word (0, 5), [60] n << 16 | cout, [61] thread
-    if ((a.diag_hz & 1024) && a.diag) {
-        __syncthreads();
-        asm volatile("" ::: "memory");
-        uint32_t chk2 = 0, d052 = 0;
-        for (int t = threadIdx.x; t < ntile; t += blockDim.x) {
-            const int tx = t % a.tw, ty = t / a.tw;
-            const volatile float *win = plane + (4 * ty) * RS + 4 * tx;
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) chk2 = chk2 * 0x9E3779B1u + __float_as_uint(win[i * RS + j]);
-            d052 = d052 * 31u + __float_as_uint(win[5]);
-        }
-        if (chk2 != hz_chk) {
-            if (atomicAdd(a.diag + 58, 1u) == 0u) { a.diag[60] = (uint32_t)(n << 16 | co); a.diag[61] = threadIdx.x; }
-            if (d052 != hz_d05) atomicAdd(a.diag + 59, 1u);
-        }
-    }
-    // the zero border of the plane (row 0, the rows below the image, column 0, the columns right of the image) is written by nobody
-    // after the first loop of this kernel: a non-zero cell at the end was written by somebody else
-    if (a.diag) {
-        __syncthreads();
-        unsigned dirty = 0;
-        for (int i = threadIdx.x; i < rows * RS; i += blockDim.x) {
-            const int y = i / RS, x = i % RS;
-            const bool border = y == 0 || y > a.H || x == 0 || x > a.W;
-            if (border && __float_as_uint(plane[i]) != 0u) ++dirty;
-        }
-        if (dirty) atomicAdd(a.diag + 0, dirty);
-        if (threadIdx.x == 0) atomicAdd(a.diag + 1, 1u);
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -919,8 +757,8 @@ __global__ W4_BRIDGE_NO_PK __launch_bounds__(1024) void wino4_bridge_kernel(Wino
 bool wino4_supported(int ks, int cin, int cout, int H, int W) {
     // below 128 channels a transform-position GEMM is HBM-bound on V and M (C*K / (2 (C + K)) < 32 flop/byte; couts are
     // padded to 128 as well) and the fused F(2x2) kernel wins — measured on the Standard shapes: 256->128 0.69 vs 0.92 ms,
-    // 128->128 1.52 vs 1.74 ms, but 128->64 1.37 vs 0.95 ms and 64->64 3.2 vs 1.9 ms.  SIVO_WINO4_MINC moves the threshold.
-    static const int minc = SIVO_DIAG_ENV("SIVO_WINO4_MINC") ? std::atoi(SIVO_DIAG_ENV("SIVO_WINO4_MINC")) : 128;
+    // 128->128 1.52 vs 1.74 ms, but 128->64 1.37 vs 0.95 ms and 64->64 3.2 vs 1.9 ms.
+    const int minc = 128;
     return ks == 3 && cin % G_KC == 0 && cin >= minc && cout >= minc && W % 4 == 0 && H >= 4 && W >= 4;
 }
 
@@ -1000,7 +838,6 @@ size_t wino4_workspace_floats(int group, int cin, int cout, int H, int W) {
 }
 
 #ifdef SIVO_DIAG
-void launch_occupy(int lds_bytes, int mode, int microseconds, const uint32_t *src, uint32_t *sink, hipStream_t s);      // diag_kernels.hip
 // diagnostic build, SIVO_W4_VERIFY=1: a layer's GEMM and bridge are run a second time into scratch buffers, under the same
 // concurrent conditions, and compared word for word: diag word [4] counts M words that differ, [5] V' words, [6] layers compared
 __global__ void diag_compare_kernel(const uint32_t *x, const uint32_t *y, int64_t n, uint32_t *count, int Pp, int P, uint32_t *rec) {
@@ -1017,9 +854,6 @@ __global__ void diag_compare_kernel(const uint32_t *x, const uint32_t *y, int64_
 }
 #endif
 
-static size_t wino4_bridge_diag_pad() {      // diagnostic build, SIVO_BRIDGE_HAZARD bit 4: 16 KB of unused LDS in front of the bridge's plane
-    return (SIVO_DIAG_ENV("SIVO_BRIDGE_HAZARD") && (std::atoi(SIVO_DIAG_ENV("SIVO_BRIDGE_HAZARD")) & 16)) ? (size_t)16384 : 0;
-}
 size_t wino4_bridge_lds_bytes(int H, int W) { return (size_t)(4 * ((H + 3) / 4) + 2) * (W + 4) * sizeof(float); }
 
 // One F(4x4,3x3) layer.  `group` samples per pass over the workspace.  plan (optional) chains layers without going
@@ -1049,12 +883,6 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
     a.in_drop = c.in_drop_site >= 0 ? 1 : 0; a.in_drop_site = c.in_drop_site;
     if (a.in_drop && (c.unpool_mask || c.in_sample_stride != 0)) throw std::invalid_argument("launch_conv_wino4: in_drop_site needs a plain sample-invariant input");
     a.pool_out = c.pool_out; a.pool_mask = c.pool_mask; a.pool_drop_site = c.pool_drop_site; a.Ho = (c.H + 1) / 2; a.Wo = (c.W + 1) / 2;
-#ifdef SIVO_DIAG
-    a.diag = (std::getenv("SIVO_BRIDGE_CHECK") || (std::getenv("SIVO_BRIDGE_HAZARD") && (std::atoi(std::getenv("SIVO_BRIDGE_HAZARD")) & (128 | 1024)))) ? diag_words() : nullptr;
-    a.diag_coherent = std::getenv("SIVO_BRIDGE_M_COHERENT") != nullptr;
-    a.diag_nt = std::getenv("SIVO_BRIDGE_NT") ? std::atoi(std::getenv("SIVO_BRIDGE_NT")) : 0;
-    a.diag_hz = std::getenv("SIVO_BRIDGE_HAZARD") ? std::atoi(std::getenv("SIVO_BRIDGE_HAZARD")) : 0;
-#endif
     const bool h3 = c.wt_h3 && c.h3_vscale > 0.f;
     a.vscale = h3 ? c.h3_vscale : 0.f;
     a.mscale = h3 ? 1.f / (c.h3_vscale * c.h3_uscale) : 1.f;
@@ -1081,7 +909,6 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         if (e && !gemm_only_events) (void)hipEventRecord(e[0], s);
         if (!(plan && plan->skip_input)) {
             const dim3 gi(pblocks, (unsigned)a.C), bi(W4_TIN);
-            SIVO_DIAG_POISON(s);
             if (a.mask && h3) hipLaunchKernelGGL((wino4_input_kernel<true, true>), gi, bi, 0, s, a);
             else if (a.mask) hipLaunchKernelGGL((wino4_input_kernel<true, false>), gi, bi, 0, s, a);
             else if (h3) hipLaunchKernelGGL((wino4_input_kernel<false, true>), gi, bi, 0, s, a);
@@ -1090,12 +917,8 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
         if (e) (void)hipEventRecord(e[1], s);
         auto nblocks = [&](int bm, int bn) { return (int64_t)36 * ((a.P + bm - 1) / bm) * (a.Kp / bn); };
         // bf16x6 (128 x 128 items): whenever the layer has the split weights and the launch is not tiny
-        static const int x6_min_blocks = SIVO_DIAG_ENV("SIVO_X6_MINBLOCKS") ? std::atoi(SIVO_DIAG_ENV("SIVO_X6_MINBLOCKS")) : 128;
-        SIVO_DIAG_POISON(s);
+        const int x6_min_blocks = 128;
         if (h3) {
-#ifdef SIVO_DIAG
-            if (a.diag_hz & 512) launch_occupy(0, 0, 50, nullptr, nullptr, s);
-#endif
             launch_wino4_gemm_h3(reinterpret_cast<const uint32_t *>(a.V), c.wt_h3, a.M, a.C, a.Kp, a.P, a.Pp, s);
         } else if (c.wt_x6 && nblocks(128, 128) >= x6_min_blocks) {
             const int pt6 = (a.P + 127) / 128, kt6 = a.Kp / 128;
@@ -1104,7 +927,7 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
             hipLaunchKernelGGL(wino4_gemm_x6p_kernel, gp, dim3(512), X6P_LDS, s, a, reinterpret_cast<const uint4 *>(c.wt_x6), pt6, kt6);
         } else {
             // fp32 MFMA: the largest tile that still gives every CU ~4 workgroups (256 CUs)
-            static const int min_blocks = SIVO_DIAG_ENV("SIVO_WINO4_MINBLOCKS") ? std::atoi(SIVO_DIAG_ENV("SIVO_WINO4_MINBLOCKS")) : 1024;
+            const int min_blocks = 1024;
             const int tile = nblocks(128, 128) >= min_blocks ? 0 : nblocks(64, 128) >= min_blocks ? 1 : 2;
             const int bm = tile == 0 ? 128 : 64, bn = tile == 2 ? 64 : 128;
             const int pt_n = (a.P + bm - 1) / bm, kt_n = a.Kp / bn, pairs8 = (36 * pt_n + 7) / 8;
@@ -1119,18 +942,10 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
             const int ntile = a.th * a.tw;
             const int nthr = ntile >= 1024 ? 1024 : (ntile + 63) / 64 * 64;
             const dim3 gb((unsigned)a.n, (unsigned)a.K);
-            // (diagnostic build: SIVO_BRIDGE_LDS_ALL=1 gives the bridge a CU's whole LDS, so that it never shares a CU with an LDS user)
-            const size_t lb = SIVO_DIAG_ENV("SIVO_BRIDGE_LDS_ALL") ? (size_t)160 * 1024 : wino4_bridge_lds_bytes(a.H, a.W) + wino4_bridge_diag_pad();
-            SIVO_DIAG_POISON(s);
-#ifdef SIVO_DIAG
-            // SIVO_BRIDGE_HAZARD bit 8: a kernel that does nothing for 50 us between the GEMM and its bridge on their stream (does the
-            // bridge see M too early?); bit 9: the same in FRONT of the GEMM (control: the same extra launch, another place)
-            if (a.diag_hz & 256) launch_occupy(0, 0, 50, nullptr, nullptr, s);
-#endif
+            const size_t lb = wino4_bridge_lds_bytes(a.H, a.W);
             if (plan->next_vscale > 0.f) hipLaunchKernelGGL(wino4_bridge_kernel<true>, gb, dim3(nthr), lb, s, a, plan->Vnext, plan->next_vscale, plan->next_vmax);
             else hipLaunchKernelGGL(wino4_bridge_kernel<false>, gb, dim3(nthr), lb, s, a, plan->Vnext, 0.f, plan->next_vmax);
         } else {
-            SIVO_DIAG_POISON(s);
             if (a.pool_out) hipLaunchKernelGGL(wino4_output_kernel<true>, dim3(pblocks, (unsigned)a.K), dim3(W4_TIN), 0, s, a);
             else hipLaunchKernelGGL(wino4_output_kernel<false>, dim3(pblocks, (unsigned)a.K), dim3(W4_TIN), 0, s, a);
         }
@@ -1152,30 +967,13 @@ void launch_conv_wino4(const ConvArgs &c, float *workspace, int group, hipStream
             hipLaunchKernelGGL(diag_compare_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(a.M), reinterpret_cast<const uint32_t *>(m2),
                                (int64_t)36 * a.Kp * a.Pp, diag_words() + 4, (int)a.Pp, (int)a.Pp, (uint32_t *)nullptr);
             const int ntile = a.th * a.tw, nthr = ntile >= 1024 ? 1024 : (ntile + 63) / 64 * 64;
-            const size_t lb = SIVO_DIAG_ENV("SIVO_BRIDGE_LDS_ALL") ? (size_t)160 * 1024 : wino4_bridge_lds_bytes(a.H, a.W) + wino4_bridge_diag_pad();
-            if (const char *occ = SIVO_DIAG_ENV("SIVO_W4_VERIFY_OCC")) {
-                // "mode,bytes": the second run of the bridge happens BESIDE a synthetic neighbour — the occupant kernel of diag_kernels.hip,
-                // one workgroup on every CU for 3 ms holding `bytes` of LDS (mode 0 idle, 1 ds traffic, 2 LDS-DMA traffic) — and nothing else
-                static hipStream_t occ_stream = nullptr;
-                static uint32_t *occ_src = nullptr;
-                if (!occ_stream) {
-                    SIVO_HIP(hipStreamCreateWithFlags(&occ_stream, hipStreamNonBlocking));
-                    SIVO_HIP(hipMalloc((void **)&occ_src, (size_t)(1 << 20) + 4096));
-                    SIVO_HIP(hipMemset(occ_src, 0x5a, (size_t)(1 << 20) + 4096));
-                }
-                int mode = 0, bytes = 131072;
-                std::sscanf(occ, "%d,%d", &mode, &bytes);
-                SIVO_HIP(hipDeviceSynchronize());
-                launch_occupy(bytes, mode, 3000, occ_src, occ_src, occ_stream);
-                usleep(400);                                   // the occupant is resident on every CU by now, and stays for 3 ms
-            }
+            const size_t lb = wino4_bridge_lds_bytes(a.H, a.W);
             if (plan->next_vscale > 0.f) hipLaunchKernelGGL(wino4_bridge_kernel<true>, dim3((unsigned)a.n, (unsigned)a.K), dim3(nthr), lb, s, a, v2, plan->next_vscale, plan->next_vmax);
             else hipLaunchKernelGGL(wino4_bridge_kernel<false>, dim3((unsigned)a.n, (unsigned)a.K), dim3(nthr), lb, s, a, v2, 0.f, plan->next_vmax);
             // (the padding columns P .. Pp of V' are written by nobody: compare sample by sample, the tiles that exist)
             hipLaunchKernelGGL(diag_compare_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(plan->Vnext), reinterpret_cast<const uint32_t *>(v2),
                                (int64_t)36 * a.K * a.Pp, diag_words() + 5, (int)a.Pp, (int)a.P, diag_words() + 20);
             ++diag_words()[6];
-            if (SIVO_DIAG_ENV("SIVO_W4_VERIFY_OCC")) SIVO_HIP(hipDeviceSynchronize());
             if (diag_words()[20] && !diag_words()[19]) {        // geometry of the first layer that showed a difference (host side, after the fact: approximate)
                 diag_words()[16] = (uint32_t)a.K; diag_words()[17] = (uint32_t)a.Pp; diag_words()[18] = (uint32_t)(a.th * a.tw); diag_words()[19] = (uint32_t)a.tw;
             }

@@ -59,10 +59,6 @@ struct H3Args {
     float *M;                // [36][Kp][Pp]
     int C, Kp, P, Pp;
     int ptiles, ktiles;      // tile groups (BM) and cout groups (BN) of the launch
-#ifdef SIVO_DIAG
-    uint32_t *diag;          // diagnostic build: diag_words(), or null
-    int lds_bytes;           // dynamic LDS of the launch (canary: the words behind the stage buffers)
-#endif
 };
 
 // LDS-DMA with a scalar base: lane l copies the 16 bytes at sbase + voff to LDS address lds_byte_addr + 16 l.
@@ -102,15 +98,6 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef SIVO_DIAG
-    // canary: the kernel never touches the LDS behind its five stage buffers; whatever changes there was written by a DMA (its own,
-    // at a wrong address) or by somebody else
-    constexpr int USED = 2 * VBYTES + 3 * UBYTES;
-    if (a.diag) {
-        for (int i = USED / 4 + tid; i < a.lds_bytes / 4; i += 512) reinterpret_cast<uint32_t *>(lds_h3)[i] = 0xC0FFEE00u + (uint32_t)i;
-        __syncthreads();
-    }
-#endif
     const int ln = lane & 31, lh = lane >> 5;
     const int nst = a.C / H3_KC;
 
@@ -314,17 +301,6 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         if (s + 1 < total) iteration(s + 1, vA);
     }
     if (pend) store_item(pxi, ppt, pkt);
-#ifdef SIVO_DIAG
-    if (a.diag) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        unsigned changed = 0;
-        for (int i = USED / 4 + tid; i < a.lds_bytes / 4; i += 512)
-            if (reinterpret_cast<const volatile uint32_t *>(lds_h3)[i] != 0xC0FFEE00u + (uint32_t)i) ++changed;
-        if (changed) atomicAdd(a.diag + 2, changed);
-        if (tid == 0) atomicAdd(a.diag + 3, 1u);
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -416,10 +392,6 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
     a.ptiles = (int)((P + t.bm - 1) / t.bm); a.ktiles = Kp / t.bn;
     const size_t lds = lds_all ? (size_t)160 * 1024 : (size_t)(2 * t.bm + 3 * t.bn) * 128;
 #ifdef SIVO_DIAG
-    a.diag = std::getenv("SIVO_H3_CANARY") ? diag_words() : nullptr;
-    a.lds_bytes = (int)lds;
-#endif
-#ifdef SIVO_DIAG
     if (const char *ab = SIVO_DIAG_ENV("SIVO_H3_ABL")) {          // diagnostic build: ablations of the 256 x 256 kernel
         a.ptiles = (P + 255) / 256; a.ktiles = Kp / 256;
 #define H3_ABL_CASE(n)                                                                                                              \
@@ -432,22 +404,6 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
             default: break;
         }
 #undef H3_ABL_CASE
-    }
-#endif
-#ifdef SIVO_DIAG
-    // co-residency investigation (tools/bridge_pair_repro.py): the 128 x 256 form — the bridge's partner — with parts of its
-    // work removed, at the LDS size of the call: which of its activities does the neighbour's fault need?
-    if (const char *ab = SIVO_DIAG_ENV("SIVO_H3_ABL128"); ab && t.bm == 128 && t.bn == 256) {
-#define H3_ABL128_CASE(n)                                                                                                           \
-    case n:                                                                                                                         \
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<128, 256, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        hipLaunchKernelGGL((wino4_gemm_h3_kernel<128, 256, n>), grid, dim3(512), lds, s, a);                                        \
-        return;
-        switch (std::atoi(ab)) {
-            H3_ABL128_CASE(1) H3_ABL128_CASE(2) H3_ABL128_CASE(3) H3_ABL128_CASE(4) H3_ABL128_CASE(8) H3_ABL128_CASE(11) H3_ABL128_CASE(15)
-            default: break;
-        }
-#undef H3_ABL128_CASE
     }
 #endif
     lds_claim_note(LDS_CLAIM_GEMM_H3, lds);

@@ -365,68 +365,6 @@ extern "C" int sivo_debug_lds_claims(uint32_t out[4], int reset) {
 }
 
 #ifdef SIVO_DIAG
-namespace sivo { void launch_occupy(int lds_bytes, int mode, int microseconds, const uint32_t *src, uint32_t *sink, hipStream_t s); }
-// diagnostic build: `launches` launches of the occupant kernel (diag_kernels.hip) back to back on a stream of its own, each holding
-// lds_bytes of every CU's LDS for ~microseconds; returns when they are enqueued (sivo_debug_occupy_wait joins them)
-static hipStream_t g_occ_stream = nullptr;
-static uint32_t *g_occ_src = nullptr;
-extern "C" int sivo_debug_occupy(int lds_bytes, int mode, int microseconds, int launches) {
-    return sivo::guarded([&] {
-        if (!g_occ_stream) {
-            SIVO_HIP(hipStreamCreateWithFlags(&g_occ_stream, hipStreamNonBlocking));
-            SIVO_HIP(hipMalloc((void **)&g_occ_src, (size_t)(1 << 20) + 4096));
-            SIVO_HIP(hipMemset(g_occ_src, 0x5a, (size_t)(1 << 20) + 4096));
-        }
-        for (int i = 0; i < launches; ++i) sivo::launch_occupy(lds_bytes, mode, microseconds, g_occ_src, g_occ_src, g_occ_stream);
-        return SIVO_OK;
-    });
-}
-extern "C" int sivo_debug_occupy_wait(void) {
-    return sivo::guarded([&] {
-        if (g_occ_stream) SIVO_HIP(hipStreamSynchronize(g_occ_stream));
-        return SIVO_OK;
-    });
-}
-// diagnostic build: `launches` launches of the self-checking bridge-pattern kernel (diag_kernels.hip lds_victim_kernel) on a stream of
-// its own, `grid` workgroups of the (H, W) plane geometry each, `rounds` rounds per workgroup; synchronises, then copies the 64 report
-// words (accumulated over the launches) to rep_out.  occupant_src is shared with sivo_debug_occupy.
-namespace sivo { void launch_lds_victim(int grid, int H, int W, int rounds, int jitter, const uint32_t *src, uint32_t *rep, hipStream_t s, bool pk); }
-extern "C" int sivo_debug_lds_victim(int grid, int H, int W, int rounds, int jitter, int launches, uint32_t rep_out[64]) {
-    return sivo::guarded([&] {
-        static hipStream_t st = nullptr;
-        static uint32_t *d_rep = nullptr, *d_src = nullptr;
-        if (!st) {
-            SIVO_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            SIVO_HIP(hipMalloc((void **)&d_rep, 64 * sizeof(uint32_t)));
-            SIVO_HIP(hipMalloc((void **)&d_src, (size_t)(1 << 20) + 4096));
-            SIVO_HIP(hipMemset(d_src, 0x33, (size_t)(1 << 20) + 4096));
-        }
-        SIVO_HIP(hipMemsetAsync(d_rep, 0, 64 * sizeof(uint32_t), st));
-        // (launches < 0: |launches| launches of the variant that also runs the bridge's arithmetic twice and compares, diag_kernels.hip PK)
-        for (int i = 0; i < std::abs(launches); ++i) sivo::launch_lds_victim(grid, H, W, rounds, jitter, d_src, d_rep, st, launches < 0);
-        SIVO_HIP(hipStreamSynchronize(st));
-        if (rep_out) SIVO_HIP(hipMemcpy(rep_out, d_rep, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        return SIVO_OK;
-    });
-}
-// diagnostic build: `launches` launches of pkform_victim_kernel (diag_kernels.hip) on a stream of its own, grid workgroups of 384 threads
-// with 24 KB of LDS (the bridge's shape at 44 x 128), `rounds` instructions per thread; the report words accumulate over the launches
-namespace sivo { void launch_pkform_victim(int grid, int threads, int lds_bytes, int form, int rounds, uint32_t *rep, hipStream_t s); }
-extern "C" int sivo_debug_pkform(int grid, int form, int rounds, int launches, uint32_t rep_out[16]) {
-    return sivo::guarded([&] {
-        static hipStream_t st = nullptr;
-        static uint32_t *d_rep = nullptr;
-        if (!st) {
-            SIVO_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            SIVO_HIP(hipMalloc((void **)&d_rep, 16 * sizeof(uint32_t)));
-        }
-        SIVO_HIP(hipMemsetAsync(d_rep, 0, 16 * sizeof(uint32_t), st));
-        for (int i = 0; i < launches; ++i) sivo::launch_pkform_victim(grid, 384, 24 * 1024, form, rounds, d_rep, st);
-        SIVO_HIP(hipStreamSynchronize(st));
-        if (rep_out) SIVO_HIP(hipMemcpy(rep_out, d_rep, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        return SIVO_OK;
-    });
-}
 // diagnostic build: the two-kernel reproducer of DESIGN 3.3 — no network, no transforms but the bridge.  `lanes` streams, each with buffers
 // of its own, run ONE bridged F(4x4) layer of n samples, C -> C channels at H x W over and over: f16x3 GEMM (V -> M), bridge (M -> V'),
 // enqueued round-robin from this thread as the engine enqueues its lanes, so that one lane's bridge workgroups share CUs with another

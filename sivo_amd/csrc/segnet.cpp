@@ -1180,7 +1180,6 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
             if (!op.ev0) { SIVO_HIP(hipEventCreate(&op.ev0)); SIVO_HIP(hipEventCreate(&op.ev1)); }
             SIVO_HIP(hipEventRecord(op.ev0, st));
         }
-        SIVO_DIAG_POISON(st);
         switch (op.kind) {
             case OP_CONV: {
                 ConvArgs a{};

@@ -730,22 +730,6 @@ void launch_unpack_bands(const BandUnpack &u, const void *slots, hipStream_t s) 
     if (total) hipLaunchKernelGGL(unpack_bands_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, u, (const unsigned char *)slots);
 }
 
-#ifdef SIVO_DIAG
-__global__ __launch_bounds__(1024) void lds_poison_kernel() {
-    extern __shared__ uint32_t poison_lds[];
-    for (int i = threadIdx.x; i < 160 * 256; i += 1024) poison_lds[i] = 0x7fc00000u;       // quiet NaN
-    __syncthreads();
-    if (poison_lds[(threadIdx.x * 37) % (160 * 256)] == 0u) __builtin_trap();             // (keeps the stores)
-}
-void diag_poison_lds(hipStream_t s) {
-    static const bool on = std::getenv("SIVO_POISON_LDS") && std::atoi(std::getenv("SIVO_POISON_LDS")) != 0;
-    if (!on) return;
-    static int attr_set[64] = {0};
-    if (FirstUse once(attr_set); once)
-        SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lds_poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(lds_poison_kernel, dim3(1024), dim3(1024), (size_t)160 * 1024, s);     // 4 rounds over 256 CUs: every CU gets some
-}
-#endif
 
 }  // namespace sivo
 

@@ -1,10 +1,12 @@
 """The product's gfx950 code object, disassembled (no GPU): properties of the COMPILED kernels that the design relies on.
 
-  * wino4_bridge_kernel carries no packed-FP32 VALU instruction.  With v_pk_mul_f32 / v_pk_add_f32 in it, a bridge
-    workgroup sharing a CU with a workgroup of the f16x3 GEMM stored wrong V' words now and then (tools/coresident_probe.py HZ8 / HZ9:
-    8 of 8 frames differ with them, 0 of 8 without, everything else equal).  The kernel is compiled with
-    __attribute__((target("no-packed-fp32-ops"))); this test fails the moment the attribute is dropped or stops working.
-  * the check can see such instructions at all: the transform kernels beside it still have them."""
+  * NO kernel of the product carries a packed-FP32 VALU instruction (docs/HW_NOTE_packed_fp32.md).  With v_pk_mul_f32 /
+    v_pk_add_f32 in it, a wino4_bridge_kernel workgroup sharing a CU with a workgroup of the f16x3 GEMM stored wrong V' words now and then
+    (tools/coresident_probe.py HZ8: 8 of 8 frames differ with them, 0 of 8 without, everything else equal).  What else the bridge had that
+    the other packed kernels lacked was never found, so since round 6 the whole library is compiled with -target-feature
+    -packed-fp32-ops (csrc/Makefile NOPK); the bridge keeps its function attribute as well.  The test fails the moment either is dropped
+    or stops working, for any kernel.
+  * the check can see such instructions at all: the reproducer build (conv_wino4.hip compiled with them) has them."""
 import os
 import re
 import shutil
@@ -44,10 +46,10 @@ def _code_objects(lib, tmp):
     return out
 
 
-def _kernels(tmp_path):
-    """{mangled kernel name: [instruction lines]} over the whole product library."""
+def _kernels(tmp_path, lib):
+    """{mangled kernel name: [instruction lines]} over a whole library."""
     kernels = {}
-    for co in _code_objects(LIB, str(tmp_path)):
+    for co in _code_objects(lib, str(tmp_path)):
         txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", co], check=True, capture_output=True, text=True).stdout
         name = None
         for line in txt.splitlines():
@@ -60,15 +62,31 @@ def _kernels(tmp_path):
     return kernels
 
 
-@pytest.mark.skipif(not (os.path.exists(LIB) and shutil.which(os.path.join(LLVM, "llvm-objdump"))), reason="needs the built library and the ROCm LLVM tools")
-def test_bridge_kernel_has_no_packed_fp32_instructions(tmp_path):
-    kernels = _kernels(tmp_path)
-    bridge = {k: v for k, v in kernels.items() if "wino4_bridge_kernel" in k}
-    assert len(bridge) == 2, sorted(bridge)                                   # <PACK = false>, <PACK = true>
-    for name, ins in bridge.items():
-        assert len(ins) > 500, (name, len(ins))                               # (a real body, not a stub)
-        hits = [l.strip() for l in ins if PK.search(l)]
-        assert not hits, f"{name}: {len(hits)} packed-FP32 instructions, e.g. {hits[:3]} — see DESIGN 3.3 before allowing them back"
-    # the detector sees them where they are allowed: the plain input / output transforms of the same file
-    others = [k for k, v in kernels.items() if ("wino4_input_kernel" in k or "wino4_output_kernel" in k) and any(PK.search(l) for l in v)]
-    assert others, "no packed-FP32 instruction found in any Winograd transform kernel: the check does not see them"
+needs_tools = pytest.mark.skipif(not (os.path.exists(LIB) and shutil.which(os.path.join(LLVM, "llvm-objdump"))), reason="needs the built library and the ROCm LLVM tools")
+PKLIB = os.path.join(os.path.dirname(LIB), "libsivo_hip_diag_pkbridge.so")
+
+
+@needs_tools
+def test_no_kernel_of_the_product_has_packed_fp32_instructions(tmp_path):
+    kernels = _kernels(tmp_path, LIB)
+    bodies = {k: v for k, v in kernels.items() if len(v) > 8}
+    assert len(bodies) >= 100, len(bodies)                                    # (the whole library was disassembled, not one translation unit)
+    for must in ("wino4_bridge_kernel", "wino4_input_kernel", "wino4_output_kernel", "wino4_gemm_h3_kernel", "conv3_h3_kernel", "conv_cls_h3_kernel",
+                 "conv7_h3_kernel", "fast_cells_kernel", "descriptor_kernel", "entropy_gate_kernel", "maxpool2"):
+        assert any(must in k for k in bodies), f"{must}: not found in the code object"
+    bridge = {k: v for k, v in bodies.items() if "wino4_bridge_kernel" in k}
+    assert len(bridge) == 2 and all(len(v) > 500 for v in bridge.values()), {k: len(v) for k, v in bridge.items()}      # <PACK = false>, <PACK = true>: real bodies
+    hits = {k: [l.strip() for l in v if PK.search(l)] for k, v in bodies.items()}
+    hits = {k: v for k, v in hits.items() if v}
+    assert not hits, (f"{len(hits)} kernels carry packed-FP32 instructions, e.g. " + "; ".join(f"{k}: {len(v)} ({v[0]})" for k, v in list(hits.items())[:4])
+                      + " - see DESIGN 3.3 before allowing them back")
+
+
+@needs_tools
+@pytest.mark.skipif(not os.path.exists(PKLIB), reason="needs the reproducer build (make -C sivo_amd/csrc diag_pkbridge)")
+def test_the_detector_sees_packed_fp32_instructions_in_the_reproducer_build(tmp_path):
+    kernels = _kernels(tmp_path, PKLIB)
+    packed = [k for k, v in kernels.items() if "wino4_bridge_kernel" in k and any(PK.search(l) for l in v)]
+    assert len(packed) == 2, packed                                           # both forms of the bridge, as they were until round 5
+    others = [k for k, v in kernels.items() if "wino4" not in k and any(PK.search(l) for l in v)]
+    assert not others, others[:4]                                             # ... and only the one translation unit

@@ -2,7 +2,7 @@
 """The two-kernel reproducer of DESIGN 3.3 (diagnostic builds, GPU box): no network — `lanes` streams each run one bridged F(4x4) layer
 (f16x3 GEMM, then wino4_bridge_kernel; 4 samples, 512 -> 512 channels, 44 x 128: conv4_x of SegNet-Standard) over and over on random
 data, every GEMM + bridge run twice and compared word for word (sivo_debug_bridge_pair, SIVO_W4_VERIFY).  Each variant in its own
-process: the bridge in its packed-FP32 form (libsivo_hip_diag_pkbridge.so) or as shipped (libsivo_hip_diag.so); the GEMM with its exact
+process: the bridge in its packed-FP32 form (libsivo_hip_diag_pkbridge.so) or as shipped (libsivo_hip_diag.so: no packed-FP32 instruction in any kernel); the GEMM with its exact
 LDS (bridge workgroups of the other lane share CUs with it) or claiming 160 KB; two lanes or one.
     python tools/bridge_pair_repro.py"""
 import ctypes as C
@@ -21,19 +21,6 @@ VARIANTS = [
     ("packed bridge, GEMM claiming 160 KB, 2 lanes", "libsivo_hip_diag_pkbridge.so", {}, 2),
     ("packed bridge, GEMM with its exact LDS, 1 lane", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0"}, 1),
     ("packed bridge, GEMM with its exact LDS, 3 lanes", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0"}, 3),
-    # the victim with one ingredient removed (SIVO_BRIDGE_HAZARD bits of conv_wino4.hip)
-    ("VIC packed bridge, exact LDS, 2 lanes, lgkmcnt(0) behind the window reads (no packed instruction beside an LDS return)", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "2048"}, 2),
-    ("VIC packed bridge, exact LDS, 2 lanes, vmcnt(0) behind every row's six stores (no packed instruction beside a store in flight)", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "4096"}, 2),
-    ("VIC packed bridge, exact LDS, 2 lanes, both", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_BRIDGE_HAZARD": "6144"}, 2),
-    ("VIC packed bridge, exact LDS, 2 lanes, unchanged (control)", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0"}, 2),
-    # the partner with parts of its work removed (its M is wrong by construction, but the same in both runs of the bridge)
-    ("ABL packed bridge, exact LDS, 2 lanes, GEMM without its MFMAs", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_ABL128": "8"}, 2),
-    ("ABL packed bridge, exact LDS, 2 lanes, GEMM without its U' LDS-DMA (after the prologue)", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_ABL128": "2"}, 2),
-    ("ABL packed bridge, exact LDS, 2 lanes, GEMM without its V' loads (after the prologue)", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_ABL128": "1"}, 2),
-    ("ABL packed bridge, exact LDS, 2 lanes, GEMM without loads and LDS-DMA", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_ABL128": "3"}, 2),
-    ("ABL packed bridge, exact LDS, 2 lanes, GEMM without its M stores", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_ABL128": "4"}, 2),
-    ("ABL packed bridge, exact LDS, 2 lanes, GEMM without loads, LDS-DMA and MFMAs (LDS reads + M stores left)", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_ABL128": "11"}, 2),
-    ("ABL packed bridge, exact LDS, 2 lanes, GEMM without loads, LDS-DMA, stores and MFMAs (LDS reads and barriers left)", "libsivo_hip_diag_pkbridge.so", {"SIVO_H3_LDS_ALL": "0", "SIVO_H3_ABL128": "15"}, 2),
 ]
 
 
