@@ -411,6 +411,18 @@ def tracking_config(last, fp, intr, device, reps=20):
                       "tests/test_pin_optimizer.py (22 cases against the reference's Optimizer.cc compiled untouched), tests/test_gpu_ba_solve.py (1e-7 vs the oracle)"}
 
 
+def launch_command(argv, n, port=None):
+    """The command `python bench.py --gpus N ...` re-executes itself as when it was started plainly (no torch.distributed.run around it):
+    one rank per GPU of this node, rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
+    if port is None:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+            os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -427,6 +439,13 @@ def main():
                     "report under \"configs\": all | none | comma list of basic,t48,ba,host,track,shards (rocprofv3 runs use one at a time)")
     ap.add_argument("--per-layer", action="store_true", help="print the per-layer event timings to stderr")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # started plainly (`python bench.py --gpus N`): become the launcher of N ranks; rank 0 prints the one JSON line to this stdout
+        cmd = launch_command(sys.argv[1:], args.gpus)
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # (dmabuf IPC: what RCCL needs on this driver)
+        env.setdefault("OMP_NUM_THREADS", "8")
+        os.execvpe(cmd[0], cmd, env)
 
     import torch
     import torch.distributed as dist
@@ -438,7 +457,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or plainly: bench.py launches its own ranks)")
+    if not torch.cuda.is_available():
+        raise SystemExit(f"bench.py rank {rank} of {world}: no HIP device visible (there is no CPU path)")
     require_gpu()
     # SIVO_BENCH_SHARE_GPU=1 + SIVO_BENCH_BACKEND=gloo: rehearse the N>1 path on a single-GPU box (every rank on
     # cuda:0, reduction through gloo).  The driver's multi-GPU runs use neither: one rank per GPU over RCCL.
@@ -820,65 +841,94 @@ def main():
             extra.append(segnet_config("BASELINE configs[3] on ONE GPU: SegNet Standard T=48 (the 8-GPU form shards 6 samples per rank)", "standard", 48, 6,
                                        "tests/test_gpu_segnet_fullsize.py::test_t48_and_its_shards_at_full_size (T = 48 in one handle and the 6-sample shards, oracle-checked), tests/test_distributed_cpu.py", "t48"))
         if "shards" in want:
-            # what ONE rank computes per frame when the T samples are sharded over N ranks (prefix + its samples + finalize), measured on this
-            # GPU: the ceiling of the strong-scaling curve the driver's N = 2, 4, 8 runs can reach (all-reduce and ORB on rank 0 come on top)
+            # what ONE rank computes per frame when the T samples are sharded over N ranks (its band of the prefix + its samples + finalize), measured
+            # on this GPU: the ceiling of the strong-scaling curve the driver's N = 2, 4, 8 runs can reach (all-gather / all-reduce wire time on top)
+            def timed_ms(fn):
+                for i in range(3):
+                    fn(i)
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(10):
+                    fn(10 + i)
+                barrier()
+                return round(1e2 * (time.perf_counter() - t0), 3)
+
+            def shard_rows(net, t_frame, with_orb):
+                ps = torch.zeros((net.classes, H, W), dtype=torch.float32, device="cuda")
+                m = new_maps()
+                rows = []
+                for nr in (1, 2, 4, 8):
+                    shares = [parallel.shard_samples(t_frame, nr, r)[1] for r in range(nr)]
+                    nl = max(shares)
+                    heavy = max(r for r in range(nr) if shares[r] == nl)      # (the last rank: the largest band of the prefix as well)
+                    def one(seed, nl=nl):
+                        net.forward_into(d_bgr, seed, ps, n_samples=nl, sample0=0)
+                        net.finalize(ps, t_total=t_frame, out=m)
+                    row = {"ranks": nr, "samples_per_rank": shares, "samples_on_the_heaviest_rank": nl, "ms_per_frame_prefix_recomputed": timed_ms(one)}
+                    if nr > 1:
+                        # the same rank with the prefix in row bands: ITS band + unpacking the gathered slots + its samples + finalize; the
+                        # other ranks' slots are computed once, outside the timing (they arrive by all-gather)
+                        plan = net.prefix_bands(nr)
+                        slots = torch.zeros((nr, plan["slot_bytes"]), dtype=torch.uint8, device="cuda")
+                        for r in range(nr):
+                            net.prefix_band_into(d_bgr, r, nr, slots[r])
+                        def one_b(seed, nl=nl, nr=nr, slots=slots, br=heavy):
+                            net.prefix_band_into(d_bgr, br, nr, slots[br])
+                            net.forward_banded_into(slots, nr, seed, ps, n_samples=nl, sample0=0)
+                            net.finalize(ps, t_total=t_frame, out=m)
+                        row["ms_per_frame_band_in_sequence"] = timed_ms(one_b)
+                        # ... and as the N > 1 loop runs it: the NEXT frame's band on a side stream beside this frame's samples
+                        side_s = torch.cuda.Stream()
+                        slots_next = slots.clone()
+                        def one_o(seed, nl=nl, nr=nr, slots=slots, slots_next=slots_next, side_s=side_s, br=heavy, orb_too=False):
+                            side_s.wait_stream(torch.cuda.current_stream())
+                            with torch.cuda.stream(side_s):
+                                net.prefix_band_into(d_bgr, br, nr, slots_next[br])
+                            if nl:
+                                net.forward_banded_into(slots, nr, seed, ps, n_samples=nl, sample0=0)
+                            else:
+                                ps.zero_()
+                            pend = fp.start_orb(d_left, d_right) if orb_too else None
+                            net.finalize(ps, t_total=t_frame, out=m)
+                            torch.cuda.current_stream().wait_stream(side_s)
+                            if orb_too:           # rank 0's host side of the frame: class map to the host, semantic filter + cull + matching results
+                                fp.finish(pend, m[0].cpu().numpy())
+                        row["ms_per_frame"] = timed_ms(one_o)
+                        row["band_rows_of_the_image"] = plan["input_rows"][heavy][1] - plan["input_rows"][heavy][0]
+                        row["allgather_bytes_per_rank"] = plan["slot_bytes"]
+                        if with_orb and fp is not None:
+                            # rank 0 (serial, one frame in flight): band 0 + ITS samples + finalize + both ORB extractors + matching + the host tail
+                            import functools
+                            row["rank0_samples"] = shares[0]
+                            row["rank0_ms_per_frame_with_orb"] = timed_ms(functools.partial(one_o, nl=shares[0], br=0, orb_too=True))
+                            if parallel.orb_rank_is_free(t_frame, nr):       # ... and what it would take with the even split's one-or-more samples
+                                even = t_frame // nr
+                                row["rank0_ms_per_frame_with_orb_if_it_kept_%d_sample%s" % (even, "" if even == 1 else "s")] = timed_ms(functools.partial(one_o, nl=even, br=0, orb_too=True))
+                    else:
+                        row["ms_per_frame"] = row["ms_per_frame_prefix_recomputed"]
+                    rows.append(row)
+                for r_ in rows:
+                    r_["speedup_ceiling"] = round(rows[0]["ms_per_frame"] / r_["ms_per_frame"], 2)
+                    r_["speedup_ceiling_prefix_recomputed"] = round(rows[0]["ms_per_frame"] / r_["ms_per_frame_prefix_recomputed"], 2)
+                return rows
+            legend = ("the heaviest rank's share: its band of the prefix + unpacking + its samples + finalize; the band of the NEXT frame on a side stream beside the samples, "
+                      "as the N > 1 loop issues it; no all-gather / all-reduce wire time; *_band_in_sequence = band, then samples, on one stream; *_prefix_recomputed = every rank "
+                      "computing the whole prefix, as before round 5; rank0_* = rank 0's frame with ORB + matching + host tail, one frame in flight")
+            shard_parity = "tests/test_gpu_prefix_bands.py (banded prefix == whole-image forward, bit for bit, world 2 / 4 / 8), tests/test_gpu_segnet_fullsize.py::test_t48_and_its_shards_at_full_size, tests/test_distributed_cpu.py"
             _, _, net = build_net(args.net, T)
-            ps = torch.zeros((net.classes, H, W), dtype=torch.float32, device="cuda")
-            m = new_maps()
-            rows = []
-            for nr in (1, 2, 4, 8):
-                nl = parallel.max_shard(T, nr)
-                def one(seed, nl=nl):
-                    net.forward_into(d_bgr, seed, ps, n_samples=nl, sample0=0)
-                    net.finalize(ps, t_total=T, out=m)
-                def timed_ms(fn):
-                    for i in range(3):
-                        fn(i)
-                    barrier()
-                    t0 = time.perf_counter()
-                    for i in range(10):
-                        fn(10 + i)
-                    barrier()
-                    return round(1e2 * (time.perf_counter() - t0), 3)
-                row = {"ranks": nr, "samples_on_the_heaviest_rank": nl, "ms_per_frame_prefix_recomputed": timed_ms(one)}
-                if nr > 1:
-                    # the same rank with the prefix in row bands: ITS band (the last rank's: the largest) + unpacking the gathered
-                    # slots + its samples + finalize; the other ranks' slots are computed once, outside the timing (they arrive by all-gather)
-                    plan = net.prefix_bands(nr)
-                    slots = torch.zeros((nr, plan["slot_bytes"]), dtype=torch.uint8, device="cuda")
-                    for r in range(nr):
-                        net.prefix_band_into(d_bgr, r, nr, slots[r])
-                    def one_b(seed, nl=nl, nr=nr, slots=slots):
-                        net.prefix_band_into(d_bgr, nr - 1, nr, slots[nr - 1])
-                        net.forward_banded_into(slots, nr, seed, ps, n_samples=nl, sample0=0)
-                        net.finalize(ps, t_total=T, out=m)
-                    row["ms_per_frame_band_in_sequence"] = timed_ms(one_b)
-                    # ... and as the N > 1 loop runs it: the NEXT frame's band on a side stream beside this frame's samples
-                    side_s = torch.cuda.Stream()
-                    slots_next = slots.clone()
-                    def one_o(seed, nl=nl, nr=nr, slots=slots, slots_next=slots_next, side_s=side_s):
-                        side_s.wait_stream(torch.cuda.current_stream())
-                        with torch.cuda.stream(side_s):
-                            net.prefix_band_into(d_bgr, nr - 1, nr, slots_next[nr - 1])
-                        net.forward_banded_into(slots, nr, seed, ps, n_samples=nl, sample0=0)
-                        net.finalize(ps, t_total=T, out=m)
-                        torch.cuda.current_stream().wait_stream(side_s)
-                    row["ms_per_frame"] = timed_ms(one_o)
-                    row["band_rows_of_the_image"] = plan["input_rows"][nr - 1][1] - plan["input_rows"][nr - 1][0]
-                    row["allgather_bytes_per_rank"] = plan["slot_bytes"]
-                else:
-                    row["ms_per_frame"] = row["ms_per_frame_prefix_recomputed"]
-                rows.append(row)
+            rows = shard_rows(net, T, True)
             del net
             torch.cuda.empty_cache()
-            for r_ in rows:
-                r_["speedup_ceiling"] = round(rows[0]["ms_per_frame"] / r_["ms_per_frame"], 2)
-                r_["speedup_ceiling_prefix_recomputed"] = round(rows[0]["ms_per_frame"] / r_["ms_per_frame_prefix_recomputed"], 2)
-            extra.append({"name": f"sample shards of the T = {T} frame on one GPU (the heaviest rank's share: its band of the prefix + unpacking + its samples + finalize; "
-                                  "the band of the NEXT frame on a side stream beside the samples, as the N > 1 loop issues it; no ORB, no all-gather / all-reduce wire time; "
-                                  "*_band_in_sequence = band, then samples, on one stream; *_prefix_recomputed = every rank computing the whole prefix, as before round 5)",
-                          "metric": "ms per frame of the heaviest rank", "value": rows[-1]["ms_per_frame"], "shards": rows,
-                          "parity": "tests/test_gpu_prefix_bands.py (banded prefix == whole-image forward, bit for bit, world 2 / 4 / 8), tests/test_gpu_segnet_fullsize.py::test_t48_and_its_shards_at_full_size, tests/test_distributed_cpu.py"})
+            extra.append({"name": f"sample shards of the T = {T} frame on one GPU ({legend})",
+                          "metric": "ms per frame of the heaviest rank", "value": rows[-1]["ms_per_frame"], "shards": rows, "parity": shard_parity})
+            if T != 48 and args.net == "standard":
+                # BASELINE configs[3]: T = 48 over 8 GPUs, 6 samples per rank — the balanced configuration, and its own ceiling
+                _, _, net = build_net("standard", 48)
+                rows48 = shard_rows(net, 48, False)
+                del net
+                torch.cuda.empty_cache()
+                extra.append({"name": f"BASELINE configs[3] per rank: sample shards of the T = 48 frame on one GPU, 6 samples per rank at 8 ranks ({legend})",
+                              "metric": "ms per frame of the heaviest rank", "value": rows48[-1]["ms_per_frame"], "shards": rows48, "parity": shard_parity})
         if "track" in want and stats["last"] is not None:
             extra.append(tracking_config(stats["last"], fp, (KFX, KFY, KCX, KCY, KBF), local))
         if "ba" in want:

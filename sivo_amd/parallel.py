@@ -6,11 +6,21 @@ classes x H x W fp32 probability sums per frame.  Dropout masks are keyed by the
 so the result does not depend on the number of ranks."""
 
 
+def orb_rank_is_free(T, world):
+    """Rank 0 also runs the two ORB extractors, the stereo matching and the host side of the frame.  It takes NO samples when the other
+    world - 1 ranks can take all T without the heaviest of them getting more than it would have anyway (T = 12 on 8 GPUs: 0,1,1,2,2,2,2,2
+    instead of 1,1,1,1,2,2,2,2 — the frame ends with the ranks that hold 2 samples either way, and rank 0's ORB work no longer competes with a
+    sample for its GPU).  Never when that would lengthen the heaviest shard (T = 48 on 8: 6 each stays; T = 12 on 4: 3 each stays)."""
+    return world >= 4 and -(-T // (world - 1)) == -(-T // world)
+
+
 def shard_samples(T, world, rank):
-    """Contiguous shard of the T samples: returns (sample0, n_local).  When T is not a multiple of the
-    world size the LAST T % world ranks take one extra sample: rank 0 also runs the ORB extractors, the
-    stereo matching and the host side of the frame, so it gets the lighter share (T = 12 on 8 GPUs:
-    1,1,1,1,2,2,2,2).  n_local may be 0 when world > T."""
+    """Contiguous shard of the T samples: returns (sample0, n_local).  When the samples do not divide evenly the LAST ranks take one
+    extra sample, so rank 0 (ORB + host side of the frame) gets the lighter share or — orb_rank_is_free — none.  n_local may be 0."""
+    if world > 1 and orb_rank_is_free(T, world):
+        if rank == 0:
+            return 0, 0
+        world, rank = world - 1, rank - 1
     base, extra = divmod(T, world)
     first_heavy = world - extra
     n_local = base + (1 if rank >= first_heavy else 0)
@@ -19,8 +29,7 @@ def shard_samples(T, world, rank):
 
 
 def max_shard(T, world):
-    base, extra = divmod(T, world)
-    return base + (1 if extra else 0)
+    return max(shard_samples(T, world, r)[1] for r in range(world))
 
 
 def all_reduce_prob_sum(prob_sum):

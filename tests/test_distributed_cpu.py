@@ -22,8 +22,32 @@ def test_shard_samples_partition():
             covered = [s for s0, n in parts for s in range(s0, s0 + n)]
             assert covered == list(range(T))
             assert max(n for _, n in parts) == parallel.max_shard(T, world)
-            assert max(n for _, n in parts) - min(n for _, n in parts) <= 1
+            assert parallel.max_shard(T, world) == -(-T // world)            # giving rank 0 nothing never lengthens the heaviest shard
+            rest = [n for _, n in parts[1:]] if world > 1 and parallel.orb_rank_is_free(T, world) else [n for _, n in parts]
+            assert max(rest) - min(rest) <= 1
+            assert parts[0][1] == min(n for _, n in parts)                   # rank 0 (ORB + host side of the frame) never has the larger share
     assert parallel.shard_samples(48, 8, 3) == (18, 6)             # BASELINE configs[3]: 6 samples per GPU
+    assert [parallel.shard_samples(12, 8, r)[1] for r in range(8)] == [0, 1, 1, 2, 2, 2, 2, 2]        # the T = 12 frame on 8 GPUs: rank 0 only runs ORB
+    assert [parallel.shard_samples(12, 4, r)[1] for r in range(4)] == [3, 3, 3, 3]
+
+
+def test_bench_launches_its_own_ranks_when_started_plainly():
+    """`python bench.py --gpus 2` without torch.distributed.run around it (how the driver starts it) must become a 2-rank job.  There is no
+    GPU here and bench.py has no CPU path: both ranks must come up, see their RANK / WORLD_SIZE and stop at the device check."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    cmd = bench.launch_command(["--gpus", "2", "--steps", "3"], 2, port=29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    if torch.cuda.is_available():
+        pytest.skip("the device check does not stop the ranks on a GPU box (tests/test_gpu_frame_e2e.py runs the real thing)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "rank 0 of 2: no HIP device visible" in out.stderr and "rank 1 of 2: no HIP device visible" in out.stderr, out.stderr[-3000:]
 
 
 def _free_port():

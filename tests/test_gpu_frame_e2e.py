@@ -51,3 +51,25 @@ def test_bench_frame_equals_the_oracle_pipeline(oracle):
         assert got["semantic_keys"] == int(keep.sum()) and got["stereo_matches"] == int((uR >= 0).sum())
         assert got["semantic_keys"] > 300 and got["stereo_matches"] > 100
         print(f"[e2e seed {seed}] left {len(kl)} right {len(kr)} semantic {got['semantic_keys']} stereo {got['stereo_matches']}")
+
+
+def test_bench_started_plainly_with_two_gpus_launches_two_ranks():
+    """The driver starts the scaling runs as `python bench.py --gpus N`: started plainly, bench.py launches its own N ranks and rank 0 prints
+    ONE JSON line.  One GPU here: both ranks share it and the reduction goes through gloo (SIVO_BENCH_SHARE_GPU / SIVO_BENCH_BACKEND, the
+    rehearsal switches of bench.py); a small image keeps it short.  The N > 1 loop — banded prefix, all-gather, sample shards, all-reduce,
+    finalize, ORB on rank 0 — is the one the 8-GPU runs execute."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SIVO_BENCH_SHARE_GPU="1", SIVO_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--T", "4", "--height", "96", "--width", "256"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and line["config"]["samples_per_rank"] == [2, 2]
+    assert line["multi_gpu"]["allreduce_bytes"] == 15 * 96 * 256 * 4
