@@ -126,7 +126,14 @@ int sivo_mc_finalize_dev(const float *d_prob_sum, int classes, int64_t hw, int t
  *     ... all-gather: d_slots = world slots in rank order (RCCL / torch.distributed) ...
  *     sivo_segnet_forward_banded_dev(h, d_slots, world, n_samples, sample0, seed, d_prob_sum, NULL, stream);
  * The results are bit-identical to sivo_segnet_forward_dev on the whole image (tests/test_gpu_prefix_bands.py): a band's valid
- * rows do not depend on the band.  The last H_out % world ranks take one row more (rank 0 the lighter share). */
+ * rows do not depend on the band.  The last H_out % world ranks take one row more (rank 0 the lighter share).
+ * fp16 range guard across ranks: a band that leaves the fp16 range raises the flag of ITS rank's handle only
+ * (sivo_segnet_take_overflow == 1 there), but every rank has consumed its rows.  The caller must OR-reduce the answers of
+ * sivo_segnet_take_overflow over the ranks once per frame; when any rank says 1, EVERY rank reissues the frame (band, all-gather,
+ * forward) — handles that said 0 have not backed off and keep their scales, which is the one situation in which the ranks'
+ * arithmetic differs (each within tolerance, no longer bit-identical to the whole-image forward) until those handles are rebuilt;
+ * bench.py --gpus N reduces the flag and refuses to report a rate containing such a frame.  The in-handle multi-device form
+ * (sivo_segnet_create_multi) does all of this itself: every device backs off once per event and the frame is recomputed. */
 int sivo_segnet_prefix_bands(sivo_segnet_t h, int world, size_t *slot_bytes, int32_t *rows, int32_t *input_rows);
 int sivo_segnet_prefix_band_dev(sivo_segnet_t h, const uint8_t *d_bgr, int rank, int world, void *d_slot, void *stream);
 int sivo_segnet_forward_banded_dev(sivo_segnet_t h, const void *d_slots, int world, int n_samples, int sample0, uint64_t seed,
@@ -226,7 +233,8 @@ int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow_frames, Si
  * correction) the largest contributors were moved one level down and the handle planned again (*builds plans in all): level 0 as planned, 1 off F(4x4) (direct f16x3), 2 off
  * f16x3 as well (F(2x2) / direct fp32), 3 direct fp32 only.  Rows describe the FINAL plan (kernel = what the layer runs now);
  * first_rel_err = what the layer measured in the first plan.  *logit_max = largest |logit| of the guard's frames.
- * *guard_ms = wall time the guard added to construction; nothing runs per frame.  No rows: nothing to guard, or the guard
+ * *guard_ms = wall time the guard added to construction; nothing runs per frame.  *predicted > *budget with *builds == 5: the guard
+ * ran out of plans with the last one still over its budget (also written to stderr at construction).  No rows: nothing to guard, or the guard
  * was skipped (diagnostic build SIVO_GUARD=0; scales forced out of the fp16 range). */
 typedef struct SivoGuardLayer {
     char layer[48];

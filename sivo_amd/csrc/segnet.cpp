@@ -178,6 +178,7 @@ struct sivo_segnet {
     int h3_overflow_frames = 0;     // frames that raised the flag (each was recomputed on the bf16x6 path when the entry point is synchronous)
     int h3_back_offs = 0;           // times the scales were lowered by 2^2 after such a frame (f16x3 is switched off at the fourth)
     bool h3_pause = false;          // the next forward runs without f16x3 (the recomputation of the frame that raised the flag)
+    bool guard_over_budget = false; // build_guarded ran out of plans with the last verdict still over budget
     bool h3_unreported = false;     // a forward() / status query consumed the flag of an asynchronous frame nobody has asked about yet:
                                     // sivo_segnet_take_overflow still owes its caller a 1 (sticky until that call)
     // load-time accuracy guard (accuracy_guard below): one row per guarded layer, the budget it was held against, what it cost
@@ -948,6 +949,15 @@ GuardVerdict accuracy_guard(sivo_segnet &S, const float *weights, const std::map
                         a.N = N; a.Cin = op.cin; a.H = bi.H; a.W = bi.W; a.Cout = op.cout; a.CoutPad = op.cout_pad;
                         a.relu = op.relu; a.drop_site = op.drop_site; a.sample0 = 0; a.seed = seed + (uint64_t)frame;
                         a.wt_x6 = op.d_wx6;
+                        if (op.in_drop_site >= 0) {
+                            // the fork pooling's dropout lives in this layer's input transform (drop_moved): the pooling above wrote the
+                            // sample-invariant values once; here every guard sample gets its own dropped copy, so that the reference chain and
+                            // the production kernel both see per-sample masks (x 2 or 0: exact) through their plain input path
+                            float *dropped = nullptr;
+                            SIVO_HIP(hipMalloc((void **)&dropped, (size_t)n * bi.chw() * sizeof(float))); scratch.push_back(dropped);
+                            launch_dropout(fp(op.in), 0, dropped, n, bi.chw(), op.in_drop_site, 0, seed + (uint64_t)frame, st);
+                            a.in = dropped; a.in_sample_stride = bi.chw();
+                        }
                         const bool is_guarded = std::find(guarded.begin(), guarded.end(), oi) != guarded.end();
                         if (!is_guarded) {
                             // the layer's own fp32 kernel (no F(4x4), no f16x3 in it): part of the reference chain as it is
@@ -1022,7 +1032,7 @@ GuardVerdict accuracy_guard(sivo_segnet &S, const float *weights, const std::map
                         a.out = fp(op.out); a.mask = (uint8_t *)buf[op.out2];
                         a.mask_N = S.blobs[op.out2].shared ? 1 : n;
                         a.N = N; a.C = bi.C; a.H = bi.H; a.W = bi.W; a.Ho = bo.H; a.Wo = bo.W;
-                        a.drop_site = op.drop_site; a.sample0 = 0; a.seed = seed + (uint64_t)frame;
+                        a.drop_site = op.drop_moved ? -1 : op.drop_site; a.sample0 = 0; a.seed = seed + (uint64_t)frame;
                         launch_maxpool2(a, st);
                         break;
                     }
@@ -1130,9 +1140,15 @@ std::unique_ptr<sivo_segnet> build_guarded(const ProtoNet &net, int t_override, 
         S->guard_rows = carried; S->guard_ms = ms;
         const GuardVerdict v = accuracy_guard(*S, weights, levels, tol);
         carried = S->guard_rows; ms = S->guard_ms;
+        S->guard_over_budget = v.any_over;
         if (!v.any_over) break;
         levels = v.levels;
     }
+    // five plans and the last one still over its budget (never seen: three plans settle a handle whose scales are 2^16 off): the handle is
+    // returned — its layers are one to three levels down already — and says so in sivo_segnet_guard_report (predicted > budget, builds = 5)
+    if (S->guard_over_budget)
+        std::fprintf(stderr, "sivo_segnet: the accuracy guard could not bring the predicted logit error (%.3g of the logit scale) under its budget (%.3g) in %d plans\n",
+                     (double)S->guard_predicted, (double)S->guard_budget, S->guard_builds);
     return S;
 }
 
@@ -1588,6 +1604,8 @@ void bands_enqueue(sivo_segnet &S, PrefixBands &B, sivo_segnet &N, const uint8_t
 }
 
 void bands_run(sivo_segnet &S, const uint8_t *d_bgr, int rank, int world, void *d_slot, hipStream_t st) {
+    h3_absorb(S);               // (as forward(): a flag from an earlier asynchronous frame is acted on before this band reads the scales; the
+                                //  pause it sets covers this band AND the forward that consumes it — one frame, one arithmetic)
     PrefixBands &B = plan_bands(S, world);
     sivo_segnet &N = band_net(S, B, rank);
     // the owner's arithmetic: its calibrated (and possibly backed-off) scales; a frame that is being recomputed runs without f16x3
@@ -1668,8 +1686,21 @@ void sivo::segnet_forward_chunked(sivo_segnet_t h, const uint8_t *d_bgr, int n, 
     h->sum_chunk = 0; h->d_sum64 = nullptr;
 }
 
-bool sivo::segnet_fp16_overflowed(sivo_segnet_t h) { return h3_flag_take(*h); }
-void sivo::segnet_fp16_back_off(sivo_segnet_t h) { h3_back_off(*h); }
+// The multi-device form's view of the fp16 range guard (segnet_multi.cpp).  overflowed: did a kernel of this handle raise the flag since
+// the last question — seen now, or absorbed by a forward() of the same frame (the banded prefix runs BEFORE the frame's forward, whose
+// h3_absorb consumes the band's flag and backs this one handle off: *backed_off then says that the scales of this handle are lowered
+// already).  back_off: lower the scales once per event on every device — a handle that backed off by itself only gets the pause back
+// that its forward consumed, so that all devices run the recomputation with the same arithmetic.
+bool sivo::segnet_fp16_overflowed(sivo_segnet_t h, bool *backed_off) {
+    const bool now = h3_flag_take(*h), earlier = h->h3_unreported;
+    h->h3_unreported = false;
+    *backed_off = earlier;
+    return now || earlier;
+}
+void sivo::segnet_fp16_back_off(sivo_segnet_t h, bool already_backed_off) {
+    if (already_backed_off) h->h3_pause = true;
+    else h3_back_off(*h);
+}
 
 using namespace sivo;
 

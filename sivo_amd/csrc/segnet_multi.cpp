@@ -310,9 +310,14 @@ void segnet_multi_segment(SegnetMulti *M, const uint8_t *bgr, int rows, int cols
         // a value left the fp16 range on some device: EVERY device's handle backs off the same way (the devices must run the
         // same arithmetic for the maps not to depend on the sharding) and the frame is computed once more, without f16x3
         bool tripped = false;
-        for (MultiDevice &D : M->dev) tripped = segnet_fp16_overflowed(D.net) || tripped;
+        std::vector<char> backed(M->dev.size(), 0);
+        for (size_t d = 0; d < M->dev.size(); ++d) {
+            bool b = false;
+            tripped = segnet_fp16_overflowed(M->dev[d].net, &b) || tripped;
+            backed[d] = b ? 1 : 0;
+        }
         if (!tripped) break;
-        for (MultiDevice &D : M->dev) segnet_fp16_back_off(D.net);
+        for (size_t d = 0; d < M->dev.size(); ++d) segnet_fp16_back_off(M->dev[d].net, backed[d] != 0);
     }
 }
 

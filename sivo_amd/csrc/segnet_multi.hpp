@@ -25,6 +25,6 @@ void segnet_forward_chunked(sivo_segnet_t h, const uint8_t *d_bgr, int n, int sa
 // device recomputes the prefix), one rank's band -> its slot, and the forward above on the gathered slots (slots != null)
 size_t segnet_prefix_slot_bytes(sivo_segnet_t h, int world);
 void segnet_prefix_band(sivo_segnet_t h, const uint8_t *d_bgr, int rank, int world, void *d_slot, hipStream_t st);
-bool segnet_fp16_overflowed(sivo_segnet_t h);
-void segnet_fp16_back_off(sivo_segnet_t h);
+bool segnet_fp16_overflowed(sivo_segnet_t h, bool *backed_off);
+void segnet_fp16_back_off(sivo_segnet_t h, bool already_backed_off);
 }  // namespace sivo

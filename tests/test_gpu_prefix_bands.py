@@ -91,3 +91,35 @@ def test_multi_device_handle_splits_its_prefix(ndev, T, kitti_like_bgr):
         np.testing.assert_allclose(a[1], c[1], atol=1e-12, rtol=0)
         np.testing.assert_allclose(a[2], c[2], atol=1e-11, rtol=0)
         assert (a[0] != c[0]).sum() <= 2
+
+
+def test_multi_device_handle_recomputes_a_frame_whose_band_left_the_fp16_range(kitti_like_bgr):
+    """The in-handle multi-device form with banded prefix and f16x3 scales forced out of range (SIVO_H3_BOOST=9): the band kernels of
+    a frame raise the flag BEFORE that frame's forward() is enqueued, so forward()'s own h3_absorb consumes it (and backs that one device
+    off).  The report must still reach segnet_multi_segment — the frame is recomputed without f16x3 — and every device's scales end
+    exactly one back-off (2^2) lower, not two for the device that absorbed."""
+    ndev, T, H, W = 4, 6, 64, 128
+    text = netspec.standard_prototxt(T, H, W)
+    net = oproto.parse(text)
+    flat = wts.pack(net["layers"], wts.synth_weights(net["layers"], 42))
+    img = np.ascontiguousarray(kitti_like_bgr[:H, :W])
+    with _diag(SIVO_MULTI_EMULATE="1", SIVO_H3_BOOST="9"):
+        boosted = BayesianSegNet(prototxt=text, weights=flat, T=T, devices=[0] * ndev)
+    with _diag(SIVO_MULTI_EMULATE="1", SIVO_GEMM="x6"):
+        x6 = BayesianSegNet(prototxt=text, weights=flat, T=T, devices=[0] * ndev)
+    with _diag(SIVO_MULTI_EMULATE="1"):
+        plain = BayesianSegNet(prototxt=text, weights=flat, T=T, devices=[0] * ndev)
+    got = boosted.segment_image(img, seed=3)                 # overflows in the band already; recomputed before the call returns
+    want = x6.segment_image(img, seed=3)
+    assert all(np.isfinite(g).all() for g in got[1:])
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))          # = the frame of a handle that never uses f16x3
+    # the next frame runs f16x3 again, on scales lowered ONCE on every device (2^7 times the calibrated ones: in range): no recomputation,
+    # and the maps are those of an unboosted handle up to the split's rounding
+    got2 = boosted.segment_image(img, seed=4)
+    ref2 = plain.segment_image(img, seed=4)
+    assert not all(np.array_equal(a, b) for a, b in zip(got2, x6.segment_image(img, seed=4)))
+    assert (got2[0] != ref2[0]).mean() < 2e-3
+    np.testing.assert_allclose(got2[1], ref2[1], atol=1e-4, rtol=0)
+    # a third frame of the same seed is reproducible: no device is still backing off
+    got3 = boosted.segment_image(img, seed=4)
+    assert all(np.array_equal(a, b) for a, b in zip(got2, got3))
