@@ -76,6 +76,28 @@ def conv2d(x, w, b, pad, acc64=False):
     return out
 
 
+_caffe_ws = [None]
+
+
+def caffe_conv2d(x, w, b, pad):
+    """Caffe's CPU convolution (im2col + SGEMM per image, caffe_cpu.c): the reference-equivalent TIMING baseline of bench.py — sums in
+    another order than conv2d's chain, with FMAs; held to conv2d within float round-off by tests/test_oracle_segnet.py."""
+    x = np.ascontiguousarray(x, np.float32); w = np.ascontiguousarray(w, np.float32)
+    N, Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    assert 2 * pad == k - 1, "'same' convolutions only"
+    out = np.empty((N, Cout, H, W), np.float32)
+    L = lib()
+    L.cfc_conv_workspace.restype = C.c_int64
+    need = L.cfc_conv_workspace(Cin, H, W, Cout, k)
+    if _caffe_ws[0] is None or _caffe_ws[0].size < need:          # (as Caffe keeps its col_buffer_: allocated once, reused by every call)
+        _caffe_ws[0] = np.empty(need, np.float32)
+    ws = _caffe_ws[0]
+    bp = _p(np.ascontiguousarray(b, np.float32), c_f32p) if b is not None else None
+    L.cfc_conv2d(_p(x, c_f32p), N, Cin, H, W, _p(w, c_f32p), bp, Cout, k, pad, _p(out, c_f32p), _p(ws, c_f32p))
+    return out
+
+
 def bn_inference(x, scale, shift):
     x = np.ascontiguousarray(x, np.float32).copy()
     N, Cc, H, W = x.shape
@@ -155,7 +177,7 @@ def preprocess(bgr, T, H, W):
 
 
 def run_net(net, weights, blob, seed, sample0=0, keep=None, acc64=False, dropout_on=True, force_masks=None, flips=None,
-            expand_to=None):
+            expand_to=None, conv=None):
     """Execute a parsed prototxt (oracle.prototxt.parse) layer by layer, as
     caffe::Net::Forward does (bayesian_segnet.cpp:310).  `weights[name]` is the
     list of parameter blobs of layer `name` (conv: [W, b]; BN: [scale, shift]).
@@ -174,7 +196,10 @@ def run_net(net, weights, blob, seed, sample0=0, keep=None, acc64=False, dropout
     (bayesian_segnet.cpp:174-177), so every layer upstream of the first test-time Dropout computes T identical
     results.  With expand_to the caller passes ONE slot (blob of shape (1,3,H,W)); the layers run on it and the
     bottom of the first active Dropout is repeated T times there (blobs upstream keep N = 1, pooling masks are
-    broadcast where the decoder consumes them).  Same values as the T-slot run, T-1 redundant prefixes less."""
+    broadcast where the decoder consumes them).  Same values as the T-slot run, T-1 redundant prefixes less.
+
+    conv: another convolution routine with conv2d's (x, w, b, pad) signature — bench.py's reference-equivalent CPU baseline passes
+    caffe_conv2d (im2col + SGEMM, what Caffe's CPU layer does); None = the oracle's own chain."""
     blobs = {net["input"]: blob}
     site = 0
     last = net["input"]
@@ -182,7 +207,7 @@ def run_net(net, weights, blob, seed, sample0=0, keep=None, acc64=False, dropout
         t = L["type"]; bot = [blobs[b] for b in L["bottom"]]
         if t == "Convolution":
             w, b = weights[L["name"]]
-            out = conv2d(bot[0], w, b, L["pad"], acc64)
+            out = conv(bot[0], w, b, L["pad"]) if conv is not None else conv2d(bot[0], w, b, L["pad"], acc64)
         elif t == "BN":
             s, sh = weights[L["name"]]
             out = bn_inference(bot[0], s, sh)

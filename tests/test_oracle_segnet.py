@@ -147,3 +147,18 @@ def test_tiny_net_end_to_end_against_torch(oracle):
     x = F.conv2d(x, t(w["cls"][0]), t(w["cls"][1]))
     np.testing.assert_allclose(x.numpy(), ob["cls"], atol=2e-4)
     np.testing.assert_allclose(F.softmax(x, 1).numpy(), ob["__last__"], atol=1e-5)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k", [(2, 3, 64, 13, 21, 3), (1, 64, 15, 9, 12, 3), (2, 5, 7, 10, 33, 7), (1, 128, 130, 16, 32, 3), (1, 8, 8, 8, 64, 3)])
+def test_caffe_style_convolution_of_the_cpu_baseline_agrees_with_the_oracle(oracle, N, Cin, Cout, H, W, k):
+    """oracle/caffe_cpu.c (im2col + blocked SGEMM per image: bench.py's reference-equivalent CPU timing baseline) against the oracle's
+    chain and against the f64-accumulated convolution: the same numbers up to float round-off of another summation order (ragged
+    strips, row-crossing strips, cout not a multiple of the register tile, 7x7 taps)."""
+    rng = np.random.default_rng(N * 1000 + Cin)
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = oracle.conv2d(x, w, b, k // 2, acc64=True)
+    got = oracle.caffe_conv2d(x, w, b, k // 2)
+    assert np.abs(got - ref).max() < 2e-5 and np.abs(got - ref).max() <= 4 * max(np.abs(oracle.conv2d(x, w, b, k // 2) - ref).max(), 1e-6)
+    assert np.array_equal(oracle.caffe_conv2d(x, w, None, k // 2) + b[None, :, None, None], got) or np.abs(oracle.caffe_conv2d(x, w, None, k // 2) + b[None, :, None, None] - got).max() < 1e-6
