@@ -57,6 +57,23 @@ typedef struct sivo_segnet *sivo_segnet_t;
  * SIVO_ERR_INVALID_ARGUMENT, as the reference constructor throws. */
 int sivo_segnet_create(const char *prototxt_text, size_t prototxt_len, int t_override,
                        const float *weights, size_t n_weights, int device, sivo_segnet_t *out);
+/* How a handle runs, chosen by the caller at construction (the fields BayesianSegNetParams gains in sivo_amd/api/bayesian_segnet:
+ * the reference's params struct, include/bayesian_segnet/bayesian_segnet.hpp:23-40, holds the two file names only).  The library reads
+ * NO environment variable: every sivo_segnet_create* has an `_opts` twin taking this struct (NULL = the defaults below, which is also
+ * what the plain functions use).  Zero-initialise, set struct_size = sizeof(SivoSegnetOptions), fill what differs from the default. */
+typedef struct SivoSegnetOptions {
+    uint32_t struct_size;        /* sizeof(SivoSegnetOptions) of the caller's header: fields beyond it take their defaults */
+    int32_t lanes;               /* sample groups of the per-sample part on separate HIP streams: 1..4; 0 = default (2) */
+    int32_t gemm;                /* arithmetic of the matrix-core layers: 0 = default f16x3 (fp32 operands as fp16 hi + lo, 3 products);
+                                    1 = bf16x6; 2 = fp32 MFMA.  1 and 2 also turn the direct f16x3 kernels and the f16x3 classifier off */
+    int32_t no_direct_f16x3;     /* != 0: the direct f16x3 3x3 / 7x7 kernels and the f16x3 classifier off (the fp32 fused kernels instead) */
+    int32_t no_packed_activations; /* != 0: fp32 blobs between the direct f16x3 layers instead of packed fp16 hi | lo pieces */
+    int32_t conv7_fp32;          /* != 0: SegNet-Basic's 7x7 layers on the fp32 matrix cores */
+    int32_t wino4_workspace_mb;  /* workspace budget of the three-kernel F(4x4) path in MiB; 0 = default (16384) */
+    int32_t debug_sync;          /* != 0: a device synchronisation behind every op of every lane (debugging) */
+} SivoSegnetOptions;
+int sivo_segnet_create_opts(const char *prototxt_text, size_t prototxt_len, int t_override, const float *weights, size_t n_weights,
+                            int device, const SivoSegnetOptions *opts, sivo_segnet_t *out);
 /* Caffe's Net::CopyTrainedLayersFrom (called at bayesian_segnet.cpp:61): read a
  * trained `.caffemodel` (binary protobuf NetParameter; both the `layer` and the
  * legacy `layers` encodings), match its layers to the prototxt BY NAME and write
@@ -71,6 +88,8 @@ int sivo_caffemodel_weights(const char *prototxt_text, size_t prototxt_len, cons
  * (bayesian_segnet.cpp:80-89, pinned by tests/test_bayesian_segnet.cpp:138-150). */
 int sivo_segnet_create_from_files(const char *model_file, const char *weights_file, int t_override,
                                   int device, sivo_segnet_t *out);
+int sivo_segnet_create_from_files_opts(const char *model_file, const char *weights_file, int t_override, int device,
+                                       const SivoSegnetOptions *opts, sivo_segnet_t *out);
 /* The same network with the T Monte-Carlo samples of a frame spread over several GPUs INSIDE the handle (the reference
  * constructs one BayesianSegNet, src/orbslam/System.cc:94-95, so a multi-GPU drop-in has to live behind that object).
  * One process; every device holds the full weights and takes a contiguous share of the samples (dropout keyed by the
@@ -83,6 +102,10 @@ int sivo_segnet_create_multi(const char *prototxt_text, size_t prototxt_len, int
 /* The same from the two files of BayesianSegNetParams (bayesian_segnet.hpp:23-40), like sivo_segnet_create_from_files. */
 int sivo_segnet_create_multi_from_files(const char *model_file, const char *weights_file, int t_override,
                                         const int *device_ids, int ndev, sivo_segnet_t *out);
+int sivo_segnet_create_multi_opts(const char *prototxt_text, size_t prototxt_len, int t_override, const float *weights, size_t n_weights,
+                                  const int *device_ids, int ndev, const SivoSegnetOptions *opts, sivo_segnet_t *out);
+int sivo_segnet_create_multi_from_files_opts(const char *model_file, const char *weights_file, int t_override, const int *device_ids,
+                                             int ndev, const SivoSegnetOptions *opts, sivo_segnet_t *out);
 int sivo_segnet_num_devices(sivo_segnet_t h, int *ndev);
 int sivo_segnet_destroy(sivo_segnet_t h);
 /* getInputGeometry (bayesian_segnet.hpp) and the blob shapes: T, C(=3), H, W, classes. */

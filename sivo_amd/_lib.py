@@ -39,6 +39,11 @@ class OpProfile(C.Structure):  # == SivoOpProfile
                 ("kernel_launches", C.c_int32), ("pad_", C.c_int32)]
 
 
+class SegnetOptions(C.Structure):   # == SivoSegnetOptions
+    _fields_ = [("struct_size", C.c_uint32), ("lanes", C.c_int32), ("gemm", C.c_int32), ("no_direct_f16x3", C.c_int32),
+                ("no_packed_activations", C.c_int32), ("conv7_fp32", C.c_int32), ("wino4_workspace_mb", C.c_int32), ("debug_sync", C.c_int32)]
+
+
 class SearchQuery(C.Structure):   # == SivoSearchQuery (36 bytes)
     _fields_ = [("u", C.c_float), ("v", C.c_float), ("radius", C.c_float), ("lvl_lo", C.c_int32), ("lvl_hi", C.c_int32),
                 ("ur", C.c_float), ("gate", C.c_float), ("angle", C.c_float), ("flags", C.c_int32)]
@@ -63,6 +68,10 @@ SIGNATURES = {
     "sivo_version": [],
     "sivo_device_count": [],
     "sivo_segnet_create": [C.c_char_p, _sz, _i, _vp, _sz, _i, C.POINTER(_vp)],
+    "sivo_segnet_create_opts": [C.c_char_p, _sz, _i, _vp, _sz, _i, _vp, C.POINTER(_vp)],
+    "sivo_segnet_create_from_files_opts": [C.c_char_p, C.c_char_p, _i, _i, _vp, C.POINTER(_vp)],
+    "sivo_segnet_create_multi_opts": [C.c_char_p, _sz, _i, _vp, _sz, _pi32, _i, _vp, C.POINTER(_vp)],
+    "sivo_segnet_create_multi_from_files_opts": [C.c_char_p, C.c_char_p, _i, _pi32, _i, _vp, C.POINTER(_vp)],
     "sivo_caffemodel_weights": [C.c_char_p, _sz, _vp, _sz, _vp, _sz, C.POINTER(_sz)],
     "sivo_segnet_create_from_files": [C.c_char_p, C.c_char_p, _i, _i, C.POINTER(_vp)],
     "sivo_segnet_create_multi": [C.c_char_p, _sz, _i, _vp, _sz, _pi32, _i, C.POINTER(_vp)],

@@ -25,13 +25,13 @@ BayesianSegNet::BayesianSegNet(const BayesianSegNetParams &params) : params(para
     if (!this->params.use_gpu) throw std::runtime_error("use_gpu = false: libsivo_hip has no CPU path");
     const int rc =
         this->params.devices.size() > 1
-            ? sivo_segnet_create_multi_from_files(this->params.model_file.c_str(), this->params.weights_file.c_str(),
-                                                  this->params.monte_carlo_samples, this->params.devices.data(),
-                                                  (int)this->params.devices.size(), &this->handle)
-            : sivo_segnet_create_from_files(this->params.model_file.c_str(), this->params.weights_file.c_str(),
-                                            this->params.monte_carlo_samples,
-                                            this->params.devices.empty() ? this->params.device : this->params.devices[0],
-                                            &this->handle);
+            ? sivo_segnet_create_multi_from_files_opts(this->params.model_file.c_str(), this->params.weights_file.c_str(),
+                                                       this->params.monte_carlo_samples, this->params.devices.data(),
+                                                       (int)this->params.devices.size(), &this->params.options, &this->handle)
+            : sivo_segnet_create_from_files_opts(this->params.model_file.c_str(), this->params.weights_file.c_str(),
+                                                 this->params.monte_carlo_samples,
+                                                 this->params.devices.empty() ? this->params.device : this->params.devices[0],
+                                                 &this->params.options, &this->handle);
     if (rc != SIVO_OK) throw_status(rc);    // C != 3 / T <= 1 -> std::invalid_argument, as bayesian_segnet.cpp:64-70
     int32_t T, C, H, W, K;
     sivo_segnet_shape(this->handle, &T, &C, &H, &W, &K);

@@ -19,6 +19,8 @@
 #include <string>
 #include <vector>
 
+#include "../../../include/sivo_hip.h"      // SivoSegnetOptions (plain C: no other dependency)
+
 struct sivo_segnet;
 
 namespace SIVO {
@@ -56,6 +58,10 @@ struct BayesianSegNetParams {
     /// object (sivo_segnet_create_multi: per-device stream + RCCL communicator, reduce-scatter / all-gather over xGMI).
     /// Empty: the single `device` above.
     std::vector<int> devices;
+    /// How the handle runs (SivoSegnetOptions of include/sivo_hip.h; zero = the library's defaults: two lanes, f16x3 arithmetic on the
+    /// matrix-core layers, packed activations, 16 GiB F(4x4) workspace).  The library reads no environment variable: what used to be
+    /// SIVO_LANES / SIVO_GEMM / ... is set here, next to the file names.
+    SivoSegnetOptions options = {sizeof(SivoSegnetOptions), 0, 0, 0, 0, 0, 0, 0};
 };
 
 class BayesianSegNet {

@@ -131,7 +131,7 @@ extern "C" int sivo_debug_conv(int N, int Cin, int Cout, int H, int W, int ks, i
         const int KC = v2 ? 4 : conv_k_chunk(ks, Cin), BN = conv_cout_tile(ks, Cout);
         const int cout_pad = cdiv(Cout, BN) * BN, nchunks = cdiv(Cin, KC);
         const size_t nin = (size_t)N * Cin * H * W, nout = (size_t)N * Cout * H * W;
-        const int w4group = wino4 ? wino4_group(N, Cin, Cout, H, W, (size_t)(std::getenv("SIVO_WINO4_MB") ? std::atoi(std::getenv("SIVO_WINO4_MB")) : 16384) << 20) : 0;
+        const int w4group = wino4 ? wino4_group(N, Cin, Cout, H, W, (size_t)16384 << 20) : 0;
         const size_t nw = wino4f ? (size_t)((Cin + 3) / 4) * (Cout / 64) * wino4f_slab_floats() : wino4 ? (size_t)36 * Cin * wino4_cout_pad(Cout) : wino ? (size_t)wino_chunks(wcfg, Cin) * (Cout / wino_cout_tile(wcfg)) * wino_slab_floats(wcfg) : v2 ? (size_t)nchunks * (cout_pad / BN) * conv2_slab_floats(ks, Cout) : (size_t)nchunks * ks * ks * KC * cout_pad;
         std::vector<float> hin(nin), hw(nw), hs(Cout, 1.f);
         uint32_t st = 12345;

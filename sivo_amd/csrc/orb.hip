@@ -796,7 +796,7 @@ extern "C" int sivo_orb_create(int nfeatures, float scale_factor, int nlevels, i
         // each of its launches queues behind a chip-filling convolution and the frame waits for ORB, not the network.
         int prio_lo = 0, prio_hi = 0;
         SIVO_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        if (const char *e = std::getenv("SIVO_ORB_PRIO"))       // experiments: 0 = default priority, 1 = lowest
+        if (const char *e = SIVO_DIAG_ENV("SIVO_ORB_PRIO"))       // experiments: 0 = default priority, 1 = lowest
             prio_hi = std::atoi(e) == 0 ? 0 : std::atoi(e) == 1 ? prio_lo : prio_hi;
         SIVO_HIP(hipStreamCreateWithPriority(&o->stream, hipStreamNonBlocking, prio_hi));
         SIVO_HIP(hipStreamCreateWithPriority(&o->stream2, hipStreamNonBlocking, prio_hi));

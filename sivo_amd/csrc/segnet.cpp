@@ -2,1155 +2,11 @@
 // plan -> per-frame forward.  Stands behind SIVO::BayesianSegNet
 // (reference src/bayesian_segnet/bayesian_segnet.cpp:46-78 constructor,
 // :299-318 segmentImage).
-//
-// Plan construction ("what Caffe runs layer by layer, regrouped for the GPU"):
-//   * BN(INFERENCE), ReLU and Dropout that follow a Convolution in place are folded
-//     into the convolution's epilogue; Dropout that follows a Pooling in place is
-//     folded into the pooling kernel.
-//   * Everything upstream of the first Dropout does not depend on the Monte-Carlo
-//     sample: those blobs are "shared" (N = 1, computed once per frame instead of
-//     T times — 134.1 of 446.0 GFLOP per sample for SegNet-Standard) and are
-//     broadcast with a zero sample stride into the first sample-dependent op.
-//   * Softmax is not a kernel of its own: the plan ends at the logits and
-//     sivo_mc_reduce fuses softmax with the sum over samples.
-#include <cmath>
-#include <cstdlib>
-#include <cstring>
-#include <fstream>
-#include <map>
-#include <memory>
-#include <sstream>
-#include <stdexcept>
-#include <string>
-#include <vector>
-
-#include "common.hpp"
-#include "prototxt.hpp"
-#include "segnet_kernels.hpp"
-#include "segnet_multi.hpp"
-#include <chrono>
-#include <algorithm>
+// The plan is built in segnet_plan.cpp, guarded in segnet_guard.cpp, split into row bands in segnet_bands.cpp; this file runs it per
+// frame and holds the C ABI.
+#include "segnet_impl.hpp"
 
 namespace sivo {
-bool looks_like_caffemodel(const std::string &bytes);
-std::vector<float> weights_from_caffemodel(const std::string &bytes, const ProtoNet &net);
-namespace {
-
-struct Blob {
-    std::string name;
-    int C = 0, H = 0, W = 0;
-    bool shared = true;    // independent of the MC sample (stored once)
-    bool is_mask = false;  // pooling argmax codes (u8)
-    int src_W = 0;         // masks: width of the pooled input plane (for index reconstruction)
-    void *d = nullptr;
-    bool fused_away = false;   // an Upsample output read straight through its pooled input by the next convolution
-    int drop_pending = -1;     // >= 0: the blob holds the values IN FRONT of this dropout site (sample-invariant); the per-sample dropped tensor
-                               // Caffe holds under this name only exists inside the consumer's input transform (sivo_segnet_blob re-creates it)
-    // Packed form (conv3_h3.hip / pk_format.hip): the blob between two direct f16x3 layers as fp16 hi / lo pieces in zero-bordered
-    // (pk_Hp, pk_Wp) planes, times the consumer's power of two.  pk_fresh: the last forward wrote ONLY this form (the fp32 array
-    // is stale; sivo_segnet_blob unpacks).  Masks: d_bits = the window codes re-laid per channel octet for a consumer that
-    // reads a packed pooled tensor through its Upsample (planes padded like that tensor's).
-    void *d_pk = nullptr;
-    int pk_Hp = 0, pk_Wp = 0;
-    bool pk_fresh = false;
-    float pk_scale = 0.f;
-    uint32_t *d_bits = nullptr;
-    int bits_Hp = 0, bits_Wp = 0;
-    int64_t pk_sample_bytes() const { return (int64_t)(C / 8) * 2 * pk_Hp * pk_Wp * 16; }
-    int64_t bits_sample_dwords() const { return (int64_t)(C / 8) * bits_Hp * bits_Wp; }
-    int64_t chw() const { return (int64_t)C * H * W; }
-};
-
-enum OpKind { OP_CONV, OP_POOL, OP_UNPOOL, OP_DROPOUT, OP_LRN };
-
-struct Op {
-    OpKind kind;
-    int in = -1, in2 = -1, out = -1, out2 = -1;
-    // conv
-    int ks = 0, cin = 0, cout = 0, cout_pad = 0;
-    float *d_w = nullptr, *d_scale = nullptr, *d_shift = nullptr;
-    size_t w_off = 0;          // offset of the layer's Caffe weights in the flat parameter array
-    void *d_wx6 = nullptr;     // wino4: the transformed weights as three bf16 planes (bf16x6 GEMM); null = fp32 MFMA GEMM
-    void *d_wh3 = nullptr;     // wino4: the transformed weights as fp16 hi / lo planes times h3_uscale (f16x3 GEMM, the default)
-    float h3_uscale = 1.f;     // power of two
-    float h3_vscale = 0.f;     // power of two the layer's transformed input is multiplied with (set by the calibration pass; 0 = not calibrated)
-    float h3_vmax = 0.f;       // largest |V| of the calibration frame
-    // conv3_h3.hip: the narrow 3x3 layers as a DIRECT convolution on the fp16 matrix cores (f16x3).  The flags below (wino4f /
-    // wino / v2) then describe the layer's fp32 kernel, which runs the calibration frame and every frame after an fp16 overflow
-    bool d3 = false;
-    void *d_wd3 = nullptr;     // Caffe weights as fp16 hi / lo planes times d3_uscale, in the kernel's stage order
-    float d3_uscale = 1.f, d3_vscale = 0.f, d3_vmax = 0.f;   // d3_vscale: power of two for the INPUT ACTIVATION (calibrated; 0 = not yet)
-    // packed activations between direct f16x3 layers (decided at plan time, used while the handle runs f16x3):
-    bool pk_in = false;        // this d3 layer reads its input (through its Upsample, if any) in the packed form
-    int pk_to = -1;            // producer side: the d3 op that reads this layer's output in the packed form (its d3_vscale is the scale)
-    bool make_bits = false;    // pooling: a packed consumer reads through this pooling's switches -> also write them per channel octet
-    int bridge_to = -1;        // w4_bridge: the op whose transformed input this layer's bridge kernel writes
-    float *d_w_mc = nullptr;   // classifier: second copy of the weights in the layout of conv_cls_mc.hip (fused with the MC post-processing)
-    // classifier on the fp16 matrix cores (conv_cls_h3.hip), fed by its producer's packed output: weights in d_wd3 (cls_h3_pack_weights),
-    // d3_uscale / d3_vscale / d3_vmax as for a direct f16x3 layer (input scale calibrated)
-    bool c3 = false;
-    bool cls_h3_last = false;  // profiling: the last fused launch was conv_cls_h3_kernel
-    bool mc_fused_last = false;   // profiling: the last timed launch of this op was the fused kernel
-    bool relu = false;
-    bool v2 = false;           // conv_v2.hip kernel + weight layout
-    bool wino = false;         // conv_wino.hip kernel + pre-transformed weights
-    int wino_cfg = 0;
-    bool wino4f = false;       // conv_wino4f.hip: fused F(4x4,3x3), 64 couts per workgroup (narrow layers)
-    bool c7x6 = false;         // conv7_x6.hip: direct 7x7 on the bf16 matrix cores (bf16x6); weights in d_wx6
-    bool c7h3 = false;         // conv7_h3.hip: the same layer on the fp16 matrix cores (f16x3: the default while the handle runs f16x3); weights
-                               // in d_wd3, d3_uscale / d3_vscale / d3_vmax as for a direct f16x3 layer.  The bf16x6 form stays resident (fallback)
-    bool wino4 = false;        // conv_wino4.hip: F(4x4,3x3) as input transform + batched GEMM + output transform
-    int wino4_group = 1;       // samples per V/M workspace pass
-    std::vector<hipEvent_t> w4_ev;                 // profiling: 4 events per group of the last launch
-    double w4_ms[3] = {0.0, 0.0, 0.0};             // input transform, GEMM, output transform
-    int w4_groups_last = 0, w4_launches = 0;
-    bool timed_last = false, w4_gemm_only_last = false;
-    bool skip = false;             // Upsample fused into the following F(4x4,3x3) convolution
-    bool w4_bridge = false;        // output transform fused with the next F(4x4) layer's input transform (no HBM round trip)
-    bool w4_bridged_in = false;    // this layer's transformed input is written by its predecessor's bridge
-    int pool_op = -1;              // F(4x4) conv: index of the MAX 2x2 pooling fused into its output transform
-    int unpool_in = -1, unpool_mask = -1;   // that convolution: pooled blob and mask blob it reads through
-    int drop_site = -1;
-    // the fork pooling's Dropout moved into the F(4x4) input transform of its consumer (plan pass below): the pooling writes its values
-    // once (sample-invariant), the consumer drops them out per sample as it reads (ConvArgs::in_drop_site)
-    bool drop_moved = false;       // pooling: its dropout is applied by its consumer
-    int in_drop_site = -1;         // convolution: dropout site applied to its (shared) input
-    int guard_level = 0;           // accuracy guard (accuracy_guard): 0 as planned, 1 no F(4x4) (direct f16x3 at any width), 2 no f16x3 either (F(2x2) / direct fp32), 3 direct fp32 only
-    // lrn
-    int local_size = 5;
-    float alpha = 0.f, beta = 0.f;
-    double flops = 0.0;
-    // profiling (sivo_segnet_profile): HIP events bracket the launch on the launch stream
-    std::string name, kernel;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double ms_total = 0.0, bytes = 0.0;
-    int launches = 0, last_n = 0;
-};
-
-}  // namespace
-}  // namespace sivo
-
-namespace sivo { struct PrefixBands; void free_bands(PrefixBands *); }
-
-struct sivo_segnet {
-    sivo::SegnetMulti *multi = nullptr;   // set by sivo_segnet_create_multi: this handle only fronts the per-device ones
-    // row bands of the sample-invariant prefix (PrefixBands below): what a band handle is built from, and the plan per world size
-    sivo::ProtoNet proto;
-    std::vector<float> prefix_weights;    // the Caffe parameters in front of the first test-time Dropout
-    std::map<std::string, int> guard_levels_used;
-    std::map<int, sivo::PrefixBands *> bands;
-    bool owns_flag = true;                // (a band handle raises its owner's overflow flag)
-    uint64_t last_seed = 0;               // of the last forward (sivo_segnet_blob re-creates a blob whose dropout moved downstream)
-    int last_sample0 = 0;
-    int device = 0;
-    int T = 0, C = 3, H = 0, W = 0, classes = 0;
-    std::vector<sivo::Blob> blobs;
-    std::vector<sivo::Op> ops;
-    std::map<std::string, int> blob_id;
-    int input_blob = -1, logits_blob = -1;
-    int cls_op = -1;               // the last op, when it is a classifier convolution conv_cls_mc.hip can fuse with the MC post-processing
-    bool has_softmax = false;
-    uint8_t *d_image = nullptr;     // H*W*3 staging for the host entry point
-    float *d_prob_sum = nullptr;    // classes*H*W
-    uint8_t *d_classes = nullptr;
-    double *d_conf = nullptr, *d_ent = nullptr;
-    hipStream_t stream = nullptr;   // for the host-level entry point
-    int64_t sum_chunk = 0;          // layout of the probability sum the next forward writes (0 = [class][pixel])
-    double *d_sum64 = nullptr;      // when set (segnet_forward_chunked): the next forward writes its f64 probability sums here
-    double flops_shared = 0.0, flops_sample = 0.0;
-    bool profile = false, pending = false;
-    bool profile_mfma_only = false;   // bracket only the MFMA kernels (convolutions / the F(4x4) GEMM): fewer events in a timed run
-    std::vector<void *> owned;
-    // two-lane execution of the per-sample part: the MC samples are split in two halves that run on two streams, so the
-    // tail of one lane's kernel (CUs running out of workgroups) and its launch bubbles are filled by the other lane
-    static constexpr int MAX_LANES = 4;
-    int ws_lanes = 1;               // workspace regions allocated
-    hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};      // [0] unused: lane 0 is the caller's stream
-    hipEvent_t lane_fork = nullptr, lane_join[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
-    // f16x3 GEMM state (conv_wino4_h3.hip).  h3_on: the F(4x4) layers with fp16 weight planes and a calibrated V scale run
-    // the f16x3 GEMM; cleared for good when a frame raised the overflow flag (a transformed value left the fp16 range: the
-    // bf16x6 GEMM has fp32's range).  h3_flag: one word of pinned host memory the transform kernels store 1 into.
-    bool h3_on = false, calibrating = false;
-    bool pk_on = true;              // packed activations between direct f16x3 layers (SIVO_D3_PK=0 at construction: fp32 blobs everywhere)
-    bool cls_pk_now = false;        // this forward hands the classifier its input packed (fused classifier + MC kernel on f16x3)
-    volatile uint32_t *h3_flag = nullptr;
-    uint32_t *d_h3_vmax = nullptr;  // calibration: one word per op (bit pattern of the largest |V|)
-    int h3_overflow_frames = 0;     // frames that raised the flag (each was recomputed on the bf16x6 path when the entry point is synchronous)
-    int h3_back_offs = 0;           // times the scales were lowered by 2^2 after such a frame (f16x3 is switched off at the fourth)
-    bool h3_pause = false;          // the next forward runs without f16x3 (the recomputation of the frame that raised the flag)
-    bool guard_over_budget = false; // build_guarded ran out of plans with the last verdict still over budget
-    bool h3_unreported = false;     // a forward() / status query consumed the flag of an asynchronous frame nobody has asked about yet:
-                                    // sivo_segnet_take_overflow still owes its caller a 1 (sticky until that call)
-    // load-time accuracy guard (accuracy_guard below): one row per guarded layer, the budget it was held against, what it cost
-    struct GuardRow { std::string layer, kernel; float rel_err = 0.f, rel_rms = 0.f, ref_max = 0.f, first_rel_err = 0.f; int level = 0; };
-    std::vector<GuardRow> guard_rows;
-    float guard_budget = 0.f, guard_logit_max = 0.f, guard_predicted = 0.f;
-    double guard_ms = 0.0;
-    int guard_builds = 0;
-    float *d_wino4_ws = nullptr;    // V + M workspace shared by every F(4x4,3x3) layer (one region per lane)
-    size_t wino4_ws_floats = 0;
-    size_t wino4_slot_floats = 0;   // three rotating slots (V, M, next V) for layers that run all samples in one pass
-    ~sivo_segnet() {
-        if (multi) sivo::segnet_multi_destroy(multi);
-        for (auto &kv : bands) sivo::free_bands(kv.second);
-        for (sivo::Op &op : ops) {
-            if (op.ev0) (void)hipEventDestroy(op.ev0);
-            if (op.ev1) (void)hipEventDestroy(op.ev1);
-        }
-        for (void *p : owned) (void)hipFree(p);
-        if (h3_flag && owns_flag) (void)hipHostFree(const_cast<uint32_t *>(h3_flag));
-        if (stream) (void)hipStreamDestroy(stream);
-        for (int l = 0; l < MAX_LANES; ++l) {
-            if (lane_stream[l]) (void)hipStreamDestroy(lane_stream[l]);
-            if (lane_join[l]) (void)hipEventDestroy(lane_join[l]);
-        }
-        if (lane_fork) (void)hipEventDestroy(lane_fork);
-    }
-};
-
-namespace sivo {
-namespace {
-
-size_t count_params(const ProtoNet &net) {
-    std::map<std::string, int> ch;
-    ch[net.input] = net.shape[1];
-    size_t n = 0;
-    for (const ProtoLayer &L : net.layers) {
-        const int cin = L.bottom.empty() ? net.shape[1] : ch[L.bottom[0]];
-        if (L.type == "Convolution") {
-            n += (size_t)L.num_output * cin * L.kernel_size * L.kernel_size + (size_t)L.num_output;
-            ch[L.top[0]] = L.num_output;
-        } else if (L.type == "BN") {
-            n += 2 * (size_t)cin;
-            ch[L.top[0]] = cin;
-        } else {
-            for (auto &t : L.top) ch[t] = cin;
-        }
-    }
-    return n;
-}
-
-int new_blob(sivo_segnet &S, const std::string &name, int C, int H, int W, bool shared, bool is_mask = false) {
-    Blob b;
-    b.name = name; b.C = C; b.H = H; b.W = W; b.shared = shared; b.is_mask = is_mask;
-    S.blobs.push_back(b);
-    S.blob_id[name] = (int)S.blobs.size() - 1;
-    return (int)S.blobs.size() - 1;
-}
-
-// Re-layout Caffe (Cout,Cin,k,k) weights to [ceil(Cin/KC)][k*k][KC][CoutPad] and fold
-// bias (+ BN scale/shift) into the epilogue's per-channel affine.
-void upload_conv(sivo_segnet &S, Op &op, const float *W, const float *bias, int H, int Wd, bool keep_ties, int guard_level = 0) {
-    op.guard_level = guard_level;
-    const int ks = op.ks, cin = op.cin, cout = op.cout;
-    std::vector<float> wt;
-    static const bool force_v1 = SIVO_DIAG_ENV("SIVO_CONV_V1") != nullptr;
-    static const bool no_wino = SIVO_DIAG_ENV("SIVO_NO_WINOGRAD") != nullptr;
-    // F(4x4,3x3) for the wide layers (4x fewer MFMA flops; costs ~2e-4 of the 1e-3 logit budget) — SIVO_NO_WINO4 disables
-    static const bool no_wino4 = SIVO_DIAG_ENV("SIVO_NO_WINO4") != nullptr;
-    static const size_t wino4_budget = (size_t)(std::getenv("SIVO_WINO4_MB") ? std::atoi(std::getenv("SIVO_WINO4_MB")) : 16384) << 20;
-    // keep_ties: the layer belongs to the sample-invariant encoder prefix (conv1_1 .. conv3_3), whose outputs decide the
-    // switches of pool1..pool3.  Over a flat image region (sky, saturated pixels) the four elements of a pooling window
-    // are EXACTLY equal in the reference, which then takes the first; the direct and the F(2x2) kernels reproduce that (a
-    // constant patch gives bit-identical outputs at every position of a tile), F(4x4) does not (4d - 5d + d is not
-    // exactly 0 in fp32), its noise survives the following layers, and the switch picked instead moves the value by a
-    // pixel after unpooling.  Measured on the KITTI test frame with F(4x4) in the prefix: 5672 instead of 27 differing
-    // switches at pool1, 0.46 % instead of 0.04 % of the final class map differing from the oracle.  The prefix runs once
-    // per frame, so keeping it on F(2x2) costs 0.13 ms.
-    const bool f4_ok = !no_wino && !keep_ties && guard_level < 1;      // (a layer the accuracy guard took off F(4x4): level >= 1)
-    // Narrow layers (<= SIVO_D3_MAXC = 128 channels in and out): the direct f16x3 kernel (conv3_h3.hip), whenever the handle
-    // runs its F(4x4) GEMMs on f16x3 as well (SIVO_GEMM unset) — SIVO_D3=0 disables.  A direct kernel treats every output
-    // position alike, so it also keeps the exact pooling ties of the prefix.
-    const char *gemm_env = std::getenv("SIVO_GEMM");
-    const bool gemm_default = !(gemm_env && (std::string(gemm_env) == "x6" || std::string(gemm_env) == "f32"));      // (read per handle: tests build several)
-    const bool no_d3 = std::getenv("SIVO_D3") && std::atoi(std::getenv("SIVO_D3")) == 0;
-    // (the sample-invariant prefix runs once per frame with N = 1: there the alternative is the fused F(2x2) kernel on the fp32
-    // pipe, not the F(4x4) GEMM, and the direct kernel wins up to 256 channels — SIVO_D3_MAXC_SHARED)
-    // (guard level 1: the layer left the F(4x4) GEMM for accuracy, not for speed — the direct f16x3 kernel takes it at any width)
-    const int d3_maxc = guard_level == 1 ? (1 << 30) : keep_ties ? (SIVO_DIAG_ENV("SIVO_D3_MAXC_SHARED") ? std::atoi(SIVO_DIAG_ENV("SIVO_D3_MAXC_SHARED")) : 256)
-                                  : (SIVO_DIAG_ENV("SIVO_D3_MAXC") ? std::atoi(SIVO_DIAG_ENV("SIVO_D3_MAXC")) : 128);
-    const bool d3_prefix = !(SIVO_DIAG_ENV("SIVO_D3_PREFIX") && std::atoi(SIVO_DIAG_ENV("SIVO_D3_PREFIX")) == 0);
-    op.d3 = !no_d3 && !no_wino && gemm_default && guard_level < 2 && (d3_prefix || !keep_ties) && cin <= d3_maxc && cout <= d3_maxc && conv3_h3_supported(ks, cin, cout, H, Wd, false);
-    if (op.d3) {
-        std::vector<uint16_t> planes;
-        op.d3_uscale = conv3_h3_pack_weights(W, cin, cout, planes);
-        op.d_wd3 = dev_alloc<uint16_t>(planes.size());
-        S.owned.push_back(op.d_wd3);
-        SIVO_HIP(hipMemcpy(op.d_wd3, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    }
-    op.wino4 = !op.d3 && f4_ok && !no_wino4 && wino4_supported(ks, cin, cout, H, Wd);
-    // narrow layers (below the F(4x4) GEMM threshold): the fused F(4x4) kernel — SIVO_NO_WINO4F falls back to fused F(2x2)
-    static const bool no_wino4f = SIVO_DIAG_ENV("SIVO_NO_WINO4F") != nullptr;
-    op.wino4f = !op.wino4 && f4_ok && !no_wino4f && wino4f_supported(ks, cin, cout, H, Wd);
-    op.wino = !op.wino4 && !op.wino4f && !no_wino && guard_level < 3 && wino_supported(ks, cin, cout, H, Wd);
-    op.v2 = !op.wino4 && !op.wino4f && !op.wino && conv2_supported(ks) && !force_v1;
-    // SegNet-Basic's 64 -> 64 7x7 layers: bf16x6 on the bf16 matrix cores (SIVO_CONV7=f32 keeps the fp32-MFMA direct kernel)
-    const bool conv7_f32 = std::getenv("SIVO_CONV7") && std::string(std::getenv("SIVO_CONV7")) == "f32";      // (read per handle: tests build both)
-    op.c7x6 = !conv7_f32 && conv7_x6_supported(ks, cin, cout, H, Wd);
-    if (op.c7x6) {
-        std::vector<uint16_t> planes;
-        conv7_x6_pack_weights(W, cin, cout, planes);
-        op.d_wx6 = dev_alloc<uint16_t>(planes.size());
-        S.owned.push_back(op.d_wx6);
-        SIVO_HIP(hipMemcpy(op.d_wx6, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        if (!no_d3 && gemm_default && guard_level < 1 && conv7_h3_supported(ks, cin, cout, H, Wd)) {
-            std::vector<uint16_t> hp;
-            op.d3_uscale = conv7_h3_pack_weights(W, cin, cout, hp);
-            op.d_wd3 = dev_alloc<uint16_t>(hp.size());
-            S.owned.push_back(op.d_wd3);
-            SIVO_HIP(hipMemcpy(op.d_wd3, hp.data(), hp.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-            op.c7h3 = true;
-        }
-    }
-    if (op.wino4f) {
-        wino4f_pack_weights(W, cin, cout, wt, &op.cout_pad);
-    } else if (op.wino4) {
-        wino4_pack_weights(W, cin, cout, wt, &op.cout_pad);
-        // SIVO_GEMM=f32 keeps the batched GEMM on the fp32 matrix-core instructions; default: bf16x6 (conv_wino4.hip)
-        const bool gemm_f32 = std::getenv("SIVO_GEMM") && std::string(std::getenv("SIVO_GEMM")) == "f32";
-        if (!gemm_f32 && wino4_x6_supported(cin, op.cout_pad)) {
-            std::vector<uint16_t> planes;
-            wino4_x6_pack_weights(wt, cin, op.cout_pad, planes);
-            op.d_wx6 = dev_alloc<uint16_t>(planes.size());
-            S.owned.push_back(op.d_wx6);
-            SIVO_HIP(hipMemcpy(op.d_wx6, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        }
-        // SIVO_GEMM=x6 / f32 keep the bf16x6 / fp32 GEMM; default: f16x3 (conv_wino4_h3.hip), with the bf16 planes resident
-        // as well: they run the calibration pass and any frame whose values leave the fp16 range
-        const bool gemm_x6 = std::getenv("SIVO_GEMM") && std::string(std::getenv("SIVO_GEMM")) == "x6";      // (read per handle: tests build both)
-        const bool gemm_f32_now = std::getenv("SIVO_GEMM") && std::string(std::getenv("SIVO_GEMM")) == "f32";
-        if (!gemm_x6 && !gemm_f32_now && wino4_h3_supported(cin, op.cout_pad)) {
-            std::vector<uint16_t> planes;
-            op.h3_uscale = wino4_h3_pack_weights(wt, cin, op.cout_pad, planes);
-            op.d_wh3 = dev_alloc<uint16_t>(planes.size());
-            S.owned.push_back(op.d_wh3);
-            SIVO_HIP(hipMemcpy(op.d_wh3, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        }
-        op.wino4_group = wino4_group(S.T, cin, cout, H, Wd, wino4_budget);
-        S.wino4_ws_floats = std::max(S.wino4_ws_floats, wino4_workspace_floats(op.wino4_group, cin, cout, H, Wd));
-    } else if (op.wino) {
-        static const int env_cfg = SIVO_DIAG_ENV("SIVO_WINO_CFG") ? std::atoi(SIVO_DIAG_ENV("SIVO_WINO_CFG")) : 0;
-        op.wino_cfg = env_cfg;
-        wino_pack_weights(W, cin, cout, op.wino_cfg, wt, &op.cout_pad);
-    } else if (op.v2) {
-        conv2_pack_weights(W, ks, cin, cout, wt, &op.cout_pad);
-    } else {
-        const int KC = conv_k_chunk(ks, cin), BN = conv_cout_tile(ks, cout);
-        op.cout_pad = cdiv(cout, BN) * BN;
-        const int nchunks = cdiv(cin, KC), taps = ks * ks;
-        wt.assign((size_t)nchunks * taps * KC * op.cout_pad, 0.f);
-        for (int co = 0; co < cout; ++co)
-            for (int ci = 0; ci < cin; ++ci)
-                for (int t = 0; t < taps; ++t) {
-                    const size_t dst = (((size_t)(ci / KC) * taps + t) * KC + (ci % KC)) * op.cout_pad + co;
-                    wt[dst] = W[((size_t)co * cin + ci) * taps + t];
-                }
-    }
-    op.d_w = dev_alloc<float>(wt.size());
-    S.owned.push_back(op.d_w);
-    SIVO_HIP(hipMemcpy(op.d_w, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
-    std::vector<float> sc(cout, 1.f), sh(bias, bias + cout);
-    op.d_scale = dev_alloc<float>(cout);
-    op.d_shift = dev_alloc<float>(cout);
-    S.owned.push_back(op.d_scale);
-    S.owned.push_back(op.d_shift);
-    SIVO_HIP(hipMemcpy(op.d_scale, sc.data(), cout * sizeof(float), hipMemcpyHostToDevice));
-    SIVO_HIP(hipMemcpy(op.d_shift, sh.data(), cout * sizeof(float), hipMemcpyHostToDevice));
-}
-
-void fold_bn(Op &op, const float *scale, const float *shift) {
-    // y = scale*(acc*s0 + b0) + shift = (scale*s0)*acc + (scale*b0 + shift)
-    std::vector<float> s0(op.cout), b0(op.cout);
-    SIVO_HIP(hipMemcpy(s0.data(), op.d_scale, op.cout * sizeof(float), hipMemcpyDeviceToHost));
-    SIVO_HIP(hipMemcpy(b0.data(), op.d_shift, op.cout * sizeof(float), hipMemcpyDeviceToHost));
-    for (int c = 0; c < op.cout; ++c) {
-        b0[c] = scale[c] * b0[c] + shift[c];
-        s0[c] = scale[c] * s0[c];
-    }
-    SIVO_HIP(hipMemcpy(op.d_scale, s0.data(), op.cout * sizeof(float), hipMemcpyHostToDevice));
-    SIVO_HIP(hipMemcpy(op.d_shift, b0.data(), op.cout * sizeof(float), hipMemcpyHostToDevice));
-}
-
-void calibrate_h3(sivo_segnet &S);
-
-// prefix_rows > 0: build only the SAMPLE-INVARIANT PREFIX of the net (the layers in front of the first test-time Dropout) at a
-// geometry of prefix_rows x W — the row band one rank computes when the prefix is split over ranks (PrefixBands below).  Such a
-// handle has shared blobs only, no Softmax / classifier / workspace, and is not calibrated: its owner copies its own scales in.
-std::unique_ptr<sivo_segnet> build(const ProtoNet &net, int t_override, const float *weights, size_t n_weights,
-                                   int device, const std::map<std::string, int> &guard_levels = {}, int prefix_rows = 0) {
-    std::unique_ptr<sivo_segnet> Sp(new sivo_segnet);
-    sivo_segnet &S = *Sp;
-    S.device = device;
-    S.T = t_override > 0 ? t_override : net.shape[0];
-    S.C = net.shape[1]; S.H = prefix_rows > 0 ? prefix_rows : net.shape[2]; S.W = net.shape[3];
-    // reference constructor checks (bayesian_segnet.cpp:64-70)
-    if (S.C != 3) throw std::invalid_argument("Input layer must have 3 channels!");
-    if (S.T <= 1) throw std::invalid_argument("Input layer must have a batch size greater than 1!");
-    if (S.H <= 0 || S.W <= 0) throw std::invalid_argument("Input layer must have a positive geometry!");
-    if (prefix_rows <= 0 && count_params(net) != n_weights) {
-        std::ostringstream m;
-        m << "weights hold " << n_weights << " values but the prototxt implies " << count_params(net);
-        throw std::invalid_argument(m.str());
-    }
-
-    DeviceGuard dg(device);
-    S.proto = net;
-    S.guard_levels_used = guard_levels;
-    S.input_blob = new_blob(S, net.input, S.C, S.H, S.W, true);
-    size_t woff = 0;
-    int site = 0;
-    // producer[blob] = index of the op that can still absorb in-place BN/ReLU/Dropout
-    std::map<int, int> absorber;
-    for (const ProtoLayer &L : net.layers) {
-        auto bottom = [&](size_t i) -> int {
-            auto it = S.blob_id.find(L.bottom.at(i));
-            if (it == S.blob_id.end()) throw std::invalid_argument("layer '" + L.name + "': unknown bottom '" + L.bottom[i] + "'");
-            return it->second;
-        };
-        const bool inplace = !L.top.empty() && !L.bottom.empty() && L.top[0] == L.bottom[0];
-        if (L.type == "Convolution") {
-            if (L.stride != 1 || (L.kernel_size != 1 && L.kernel_size != 3 && L.kernel_size != 7) ||
-                L.pad != L.kernel_size / 2)
-                throw std::runtime_error("Convolution '" + L.name + "': only stride-1 'same' 1x1/3x3/7x7 kernels are supported");
-            const int bi = bottom(0);
-            const Blob b = S.blobs[bi];
-            Op op;
-            op.kind = OP_CONV; op.in = bi; op.ks = L.kernel_size; op.cin = b.C; op.cout = L.num_output;
-            op.out = new_blob(S, L.top[0], L.num_output, b.H, b.W, b.shared);
-            const size_t nw = (size_t)op.cout * op.cin * op.ks * op.ks;
-            bool keep_ties = b.shared;
-            if (const char *extra = SIVO_DIAG_ENV("SIVO_KEEP_TIES_LAYERS"))        // comma-separated layer names (experiments)
-                keep_ties = keep_ties || ("," + std::string(extra) + ",").find("," + L.name + ",") != std::string::npos;
-            op.w_off = woff;
-            const auto gl = guard_levels.find(L.name);
-            upload_conv(S, op, weights + woff, weights + woff + nw, b.H, b.W, keep_ties, gl == guard_levels.end() ? 0 : gl->second);
-            woff += nw + op.cout;
-            op.flops = 2.0 * op.ks * op.ks * op.cin * op.cout * (double)b.H * b.W;
-            op.name = L.name;
-            {
-                char kn[96];
-                const int bn = conv_cout_tile(op.ks, op.cout), kc = conv_k_chunk(op.ks, op.cin);
-                if (op.c7h3)
-                    snprintf(kn, sizeof kn, "conv7_h3_kernel");
-                else if (op.c7x6)
-                    snprintf(kn, sizeof kn, "conv7_x6_kernel");
-                else if (op.wino4f)
-                    snprintf(kn, sizeof kn, "conv_wino4f_kernel");
-                else if (op.wino4)
-                    snprintf(kn, sizeof kn, "conv_wino4 (input + gemm + output kernels)");
-                else if (op.wino)
-                    snprintf(kn, sizeof kn, op.wino_cfg == 2 ? "conv_wino_kernel<6,2,2,4>" : op.wino_cfg == 1 ? "conv_wino_kernel<4,1,2,8>" : "conv_wino_kernel<2,2,2,4>");
-                else if (op.v2)
-                    snprintf(kn, sizeof kn, "conv_mfma2_kernel<%d,%d,32,%d,%d,%d>", op.ks, bn == 128 ? 4 : 8, bn, bn == 128 ? 2 : 4,
-                             bn == 128 ? 2 : 1);
-                else
-                    snprintf(kn, sizeof kn, "conv_mfma_kernel<%d,%d,32,%d,%d,%d,%d>", op.ks, bn == 128 ? 4 : 8, bn, kc,
-                             bn == 128 ? 2 : 4, bn == 128 ? 2 : 1);
-                op.kernel = kn;
-            }
-            // algorithmic HBM bytes: input + output activations once, weights once
-            op.bytes = 4.0 * ((double)b.C * b.H * b.W + (double)op.cout * b.H * b.W + (double)nw);
-            S.ops.push_back(op);
-            absorber[op.out] = (int)S.ops.size() - 1;
-        } else if (L.type == "BN") {
-            if (L.bn_mode != "INFERENCE") throw std::runtime_error("BN '" + L.name + "': only bn_mode INFERENCE is supported");
-            const int bi = bottom(0);
-            auto it = absorber.find(bi);
-            if (!inplace || it == absorber.end() || S.ops[it->second].kind != OP_CONV || S.ops[it->second].relu ||
-                S.ops[it->second].drop_site >= 0)
-                throw std::runtime_error("BN '" + L.name + "' must follow a Convolution in place");
-            const int C = S.blobs[bi].C;
-            fold_bn(S.ops[it->second], weights + woff, weights + woff + C);
-            woff += 2 * (size_t)C;
-        } else if (L.type == "ReLU") {
-            const int bi = bottom(0);
-            auto it = absorber.find(bi);
-            if (!inplace || it == absorber.end() || S.ops[it->second].kind != OP_CONV || S.ops[it->second].drop_site >= 0)
-                throw std::runtime_error("ReLU '" + L.name + "' must follow a Convolution in place");
-            S.ops[it->second].relu = true;
-        } else if (L.type == "Pooling") {
-            if (L.pool != "MAX" || L.kernel_size != 2 || L.stride != 2 || L.top.size() != 2)
-                throw std::runtime_error("Pooling '" + L.name + "': only MAX 2x2 stride 2 with a mask top is supported");
-            const int bi = bottom(0);
-            const Blob b = S.blobs[bi];
-            Op op;
-            op.kind = OP_POOL; op.in = bi;
-            const int Ho = (b.H - 2 + 1) / 2 + 1, Wo = (b.W - 2 + 1) / 2 + 1;   // ceil((H-k)/s)+1
-            op.out = new_blob(S, L.top[0], b.C, Ho, Wo, b.shared);
-            op.out2 = new_blob(S, L.top[1], b.C, Ho, Wo, b.shared, true);
-            S.blobs[op.out2].src_W = b.W;
-            op.name = L.name; op.kernel = "maxpool2_kernel";
-            op.bytes = 4.0 * b.C * b.H * b.W + 5.0 * b.C * Ho * Wo;
-            S.ops.push_back(op);
-            absorber.erase(bi);
-            absorber[op.out] = (int)S.ops.size() - 1;
-        } else if (L.type == "Dropout") {
-            const int my_site = site++;
-            if (!L.sample_weights_test) continue;  // plain Caffe dropout is the identity at test time
-            if (prefix_rows > 0) break;            // the prefix ends in front of the first test-time dropout
-            if (S.prefix_weights.empty() && weights) S.prefix_weights.assign(weights, weights + woff);
-            if (std::fabs(L.dropout_ratio - 0.5f) > 1e-6f)
-                throw std::runtime_error("Dropout '" + L.name + "': only dropout_ratio 0.5 is supported");
-            const int bi = bottom(0);
-            auto it = absorber.find(bi);
-            if (inplace && it != absorber.end() && S.ops[it->second].drop_site < 0 && !S.blobs[bi].shared) {
-                S.ops[it->second].drop_site = my_site;       // conv / pool epilogue
-            } else if (inplace && it != absorber.end() && S.ops[it->second].kind == OP_POOL && S.blobs[bi].shared) {
-                // pooled output of a shared blob becomes per-sample: pool kernel broadcasts + drops
-                S.ops[it->second].drop_site = my_site;
-                S.blobs[bi].shared = false;
-            } else {
-                // general case: separate kernel, out of place into a per-sample blob that takes over the name
-                Op op;
-                op.kind = OP_DROPOUT; op.in = bi; op.drop_site = my_site;
-                const Blob b = S.blobs[bi];
-                op.out = new_blob(S, L.top[0], b.C, b.H, b.W, false);
-                op.name = L.name; op.kernel = "dropout_kernel"; op.bytes = 8.0 * b.chw();
-                S.ops.push_back(op);
-            }
-            absorber.erase(bi);
-        } else if (L.type == "Upsample") {
-            if (L.scale != 2 || L.bottom.size() != 2) throw std::runtime_error("Upsample '" + L.name + "': only scale 2 with a mask bottom");
-            const int bi = bottom(0), mi = bottom(1);
-            const Blob b = S.blobs[bi], m = S.blobs[mi];
-            if (!m.is_mask || m.C != b.C || m.H != b.H || m.W != b.W)
-                throw std::runtime_error("Upsample '" + L.name + "': mask does not match the bottom");
-            Op op;
-            op.kind = OP_UNPOOL; op.in = bi; op.in2 = mi;
-            op.out = new_blob(S, L.top[0], b.C, b.H * 2, b.W * 2, b.shared && m.shared);
-            op.name = L.name; op.kernel = "unpool2_kernel"; op.bytes = 5.0 * b.chw() + 16.0 * b.chw();
-            S.ops.push_back(op);
-            absorber.erase(bi);
-        } else if (L.type == "LRN") {
-            const int bi = bottom(0);
-            const Blob b = S.blobs[bi];
-            Op op;
-            op.kind = OP_LRN; op.in = bi; op.local_size = L.local_size; op.alpha = L.alpha; op.beta = L.beta;
-            op.out = new_blob(S, L.top[0], b.C, b.H, b.W, b.shared);
-            op.name = L.name; op.kernel = "lrn_kernel"; op.bytes = 8.0 * b.chw();
-            S.ops.push_back(op);
-        } else if (L.type == "Softmax") {
-            S.has_softmax = true;
-            S.logits_blob = bottom(0);
-        } else {
-            throw std::runtime_error("layer '" + L.name + "': unsupported type '" + L.type + "'");
-        }
-    }
-    if (prefix_rows <= 0) {
-        if (!S.has_softmax) throw std::runtime_error("the network must end in a Softmax layer");
-        S.classes = S.blobs[S.logits_blob].C;
-        if (S.classes > 16) throw std::runtime_error("at most 16 classes are supported");
-    }
-
-    // sharedness must propagate forward through ops built before a later flip (pool+dropout flips its output)
-    for (Op &op : S.ops) {
-        bool sh = S.blobs[op.in].shared && (op.in2 < 0 || S.blobs[op.in2].shared) && op.drop_site < 0;
-        if (op.kind == OP_DROPOUT) sh = false;
-        S.blobs[op.out].shared = sh;
-        if (op.out2 >= 0) S.blobs[op.out2].shared = S.blobs[op.in].shared;   // the argmax only depends on the input
-        (sh ? S.flops_shared : S.flops_sample) += op.flops;
-    }
-    // Upsample -> Winograd convolution: the F(4x4) input transform / the F(2x2) patch loader reads the pooled tensor and
-    // the window codes directly (4x fewer input bytes, no unpool kernel, the unpooled tensor is never written).
-    // SIVO_NO_FUSE_UNPOOL disables.
-    if (!SIVO_DIAG_ENV("SIVO_NO_FUSE_UNPOOL"))
-        for (Op &u : S.ops) {
-            if (u.kind != OP_UNPOOL) continue;
-            Op *consumer = nullptr;
-            int uses = u.out == S.logits_blob ? 2 : 0;
-            for (Op &c : S.ops)
-                if (c.in == u.out || c.in2 == u.out) { ++uses; consumer = &c; }
-            if (uses != 1 || consumer->kind != OP_CONV || consumer->in != u.out) continue;
-            if (!consumer->wino4 && !consumer->wino4f && !consumer->c7x6 && !(consumer->wino && consumer->wino_cfg == 0)) continue;   // every Winograd path and the 7x7 bf16x6 kernel read through the pooling
-            const Blob &pooled = S.blobs[u.in], &mask = S.blobs[u.in2], &up = S.blobs[u.out];
-            if (pooled.shared && !up.shared) continue;            // (not produced by the reference nets)
-            if (up.H != 2 * pooled.H || up.W != 2 * pooled.W || (pooled.W & 1)) continue;
-            (void)mask;
-            consumer->unpool_in = u.in; consumer->unpool_mask = u.in2;
-            u.skip = true;
-            S.blobs[u.out].fused_away = true;
-        }
-    // F(4x4) conv -> F(4x4) conv at the same resolution: the activation in between stays on chip (wino4_bridge_kernel).
-    // SIVO_NO_FUSE_BRIDGE disables (the intermediate blob is then materialised and can be inspected).
-    for (size_t i = 0; i < S.ops.size(); ++i) {
-        Op &A = S.ops[i];
-        if (A.kind != OP_CONV || !A.wino4) continue;
-        const Blob &bo = S.blobs[A.out];
-        const int N = bo.shared ? 1 : S.T;
-        if (A.wino4_group < N) continue;                           // several passes over the workspace: plain path
-        const int64_t P = (int64_t)N * ((bo.H + 3) / 4) * (bo.W / 4), Pp = (P + 127) / 128 * 128;
-        S.wino4_slot_floats = std::max(S.wino4_slot_floats, (size_t)(36 * Pp * std::max<int64_t>(A.cin, A.cout_pad)));
-        if (SIVO_DIAG_ENV("SIVO_NO_FUSE_BRIDGE") || A.out == S.logits_blob) continue;
-        Op *B = nullptr;
-        int uses = 0;
-        for (Op &c : S.ops)
-            if (c.in == A.out || c.in2 == A.out) { ++uses; B = &c; }
-        if (uses != 1 || B->kind != OP_CONV || !B->wino4 || B->in != A.out || B->unpool_in >= 0) continue;
-        const Blob &bn = S.blobs[B->out];
-        if (bn.shared != bo.shared || bn.H != bo.H || bn.W != bo.W || B->wino4_group < N) continue;
-        if (wino4_bridge_lds_bytes(bo.H, bo.W) > 150 * 1024) continue;
-        A.w4_bridge = true; B->w4_bridged_in = true;
-        A.bridge_to = (int)(B - S.ops.data());
-        S.blobs[A.out].fused_away = true;
-    }
-    if (S.wino4_slot_floats) S.wino4_ws_floats = std::max(S.wino4_ws_floats, 3 * S.wino4_slot_floats);
-    // F(4x4) conv -> MAX 2x2 pooling (per-sample part: conv4_3 -> pool4, conv5_3 -> pool5): the output transform holds
-    // whole pooling windows, so it writes the pooled tensor + window codes (+ the pooling layer's dropout) directly.
-    // SIVO_NO_FUSE_POOL disables.
-    if (!SIVO_DIAG_ENV("SIVO_NO_FUSE_POOL"))
-        for (size_t i = 0; i < S.ops.size(); ++i) {
-            Op &A = S.ops[i];
-            if (A.kind != OP_CONV || !A.wino4 || A.w4_bridge || A.out == S.logits_blob || S.blobs[A.out].shared) continue;
-            int uses = 0, pi = -1;
-            for (size_t k = 0; k < S.ops.size(); ++k)
-                if (S.ops[k].in == A.out || S.ops[k].in2 == A.out) { ++uses; pi = (int)k; }
-            if (uses != 1 || S.ops[pi].kind != OP_POOL || S.ops[pi].in != A.out || S.blobs[S.ops[pi].out2].shared) continue;
-            if (S.blobs[A.out].W % 4) continue;
-            A.pool_op = pi;
-            S.ops[pi].skip = true;
-            S.blobs[A.out].fused_away = true;
-        }
-    // Fork pooling (sample-invariant input, test-time Dropout in place on its output) -> F(4x4) convolution: the pooling kernel would
-    // write T dropped copies of the same tensor (SegNet-Standard pool3: 12 x 5.8 MB) for the input transform to read back; instead the
-    // pooling writes its values once and the input transform applies the dropout as it reads — the same counter-based word per
-    // (element, site, global sample), so V is bit-identical.  SIVO_NO_FUSE_INDROP disables (diagnostic build: the A/B of the test).
-    if (!SIVO_DIAG_ENV("SIVO_NO_FUSE_INDROP"))
-        for (size_t i = 0; i < S.ops.size(); ++i) {
-            Op &P = S.ops[i];
-            if (P.kind != OP_POOL || P.skip || P.drop_site < 0 || !S.blobs[P.in].shared || S.blobs[P.out].shared || P.out == S.logits_blob) continue;
-            int uses = 0, ci = -1;
-            for (size_t k = 0; k < S.ops.size(); ++k)
-                if (S.ops[k].in == P.out || S.ops[k].in2 == P.out || S.ops[k].unpool_in == P.out) { ++uses; ci = (int)k; }
-            if (uses != 1) continue;
-            Op &Cv = S.ops[(size_t)ci];
-            if (Cv.kind != OP_CONV || !Cv.wino4 || Cv.in != P.out || Cv.unpool_in >= 0 || Cv.w4_bridged_in || S.blobs[P.out].W % 4) continue;
-            Cv.in_drop_site = P.drop_site;
-            P.drop_moved = true;
-            S.blobs[P.out].shared = true;
-            S.blobs[P.out].drop_pending = P.drop_site;
-        }
-    // classifier convolution -> Softmax -> mean over the samples -> argmax / max / entropy in one kernel (conv_cls_mc.hip):
-    // the logits stay on chip whenever the caller asks for the maps or the probability sums only.  SIVO_NO_FUSE_MC disables.
-    if (!SIVO_DIAG_ENV("SIVO_NO_FUSE_MC") && !S.ops.empty()) {
-        Op &L = S.ops.back();
-        const Blob &bi = S.blobs[L.in], &bo = S.blobs[L.out];
-        if (L.kind == OP_CONV && L.out == S.logits_blob && !bo.shared && !bi.shared && !bi.fused_away && L.pool_op < 0 &&
-            L.unpool_in < 0 && !L.w4_bridged_in && L.drop_site < 0 && cls_mc_supported(L.ks, L.cin, L.cout, bi.H, bi.W)) {
-            std::vector<float> wt;
-            cls_mc_pack_weights(weights + L.w_off, L.cin, L.cout, wt);
-            L.d_w_mc = dev_alloc<float>(wt.size());
-            S.owned.push_back(L.d_w_mc);
-            SIVO_HIP(hipMemcpy(L.d_w_mc, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
-            S.cls_op = (int)S.ops.size() - 1;
-            // the f16x3 form (conv_cls_h3.hip), when the handle runs f16x3 at all (SIVO_GEMM unset, SIVO_D3 not 0)
-            const char *ge = std::getenv("SIVO_GEMM");
-            const bool f16x3_handle = !(ge && (std::string(ge) == "x6" || std::string(ge) == "f32")) && !(std::getenv("SIVO_D3") && std::atoi(std::getenv("SIVO_D3")) == 0);
-            const auto cgl = guard_levels.find(L.name);
-            if (cgl != guard_levels.end()) L.guard_level = cgl->second;
-            if (f16x3_handle && L.guard_level < 1 && cls_h3_supported(L.ks, L.cin, L.cout, bi.H, bi.W)) {       // (level >= 1: the accuracy guard took it off f16x3)
-                std::vector<uint16_t> planes;
-                L.d3_uscale = cls_h3_pack_weights(weights + L.w_off, L.cin, L.cout, planes);
-                L.d_wd3 = dev_alloc<uint16_t>(planes.size());
-                S.owned.push_back(L.d_wd3);
-                SIVO_HIP(hipMemcpy(L.d_wd3, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-                L.c3 = true;
-            }
-        }
-    }
-    // Direct f16x3 layer <- direct f16x3 layer (or an F(4x4) layer's output transform): the activation in between goes in the
-    // consumer's packed form (conv3_h3.hip header).  The fp32 blob stays allocated: the calibration pass and every frame after
-    // an fp16 overflow run the fp32 kernels.  SIVO_D3_PK=0 disables (read per handle: the tests build both).
-    S.pk_on = !(std::getenv("SIVO_D3_PK") && std::atoi(std::getenv("SIVO_D3_PK")) == 0);
-    if (S.pk_on)
-        for (size_t bi_ = 0; bi_ < S.ops.size(); ++bi_) {
-            Op &B = S.ops[bi_];
-            const bool b_cls = B.c3 && (int)bi_ == S.cls_op;          // the fused classifier + MC kernel on f16x3 (conv_cls_h3.hip)
-            if (B.kind != OP_CONV || !(B.d3 || b_cls) || B.skip || B.drop_site >= 0 || B.pool_op >= 0) continue;
-            const bool unpool = B.unpool_in >= 0;
-            if (b_cls && unpool) continue;
-            const int X = unpool ? B.unpool_in : B.in;
-            if (X == S.input_blob || X == S.logits_blob || S.blobs[X].fused_away || S.blobs[X].C % 16) continue;
-            int uses = 0, ai = -1, pi = -1;
-            for (size_t k = 0; k < S.ops.size(); ++k) {
-                const Op &c = S.ops[k];
-                if (c.out == X && !c.skip) ai = (int)k;
-                if (c.skip) continue;
-                if ((c.in == X && c.unpool_in < 0) || c.in2 == X || c.unpool_in == X) ++uses;
-                if (unpool && c.kind == OP_POOL && c.out2 == B.unpool_mask) pi = (int)k;
-            }
-            if (uses != 1 || ai < 0 || (unpool && pi < 0)) continue;
-            Op &A = S.ops[ai];
-            if (A.kind != OP_CONV || A.pool_op >= 0 || A.w4_bridge) continue;
-            // (a direct producer must itself run whenever the handle runs f16x3 — the conditions of d3_now in run_ops —, and fp32
-            // through an Upsample + packed output is not built)
-            const bool a_direct = A.d3 && A.drop_site < 0 && !(A.unpool_in >= 0 && !A.pk_in) &&
-                                  conv3_h3_supported(A.ks, A.cin, A.cout, S.blobs[A.in].H, S.blobs[A.in].W, A.unpool_in >= 0);
-            if (!a_direct && !A.wino4) continue;
-            const Blob &bin = S.blobs[B.in];                       // the layer's input geometry (the Upsample's output when it reads through one)
-            if (!b_cls && !conv3_h3_supported(B.ks, B.cin, B.cout, bin.H, bin.W, unpool)) continue;
-            int tile_h = 8, tile_w = 64;
-            if (b_cls) cls_h3_tile(&tile_h, &tile_w);
-            const int tx = (bin.W + tile_w - 1) / tile_w, ty = (bin.H + tile_h - 1) / tile_h;
-            Blob &bx = S.blobs[X];
-            bx.pk_Hp = (unpool ? ty * 4 : ty * tile_h) + 2; bx.pk_Wp = (unpool ? tx * 32 : tx * tile_w) + 2;
-            if (bx.pk_Hp < bx.H + 2 || bx.pk_Wp < bx.W + 2 || (int64_t)bx.C * bx.pk_Hp * bx.pk_Wp * 4 >= (1ll << 31)) { bx.pk_Hp = bx.pk_Wp = 0; continue; }
-            if (unpool) {
-                Blob &bm = S.blobs[B.unpool_mask];
-                bm.bits_Hp = bx.pk_Hp; bm.bits_Wp = bx.pk_Wp;
-                S.ops[pi].make_bits = true;
-            }
-            B.pk_in = true;
-            A.pk_to = (int)bi_;
-        }
-    // allocate
-    for (Blob &b : S.blobs) {
-        if (b.fused_away) continue;
-        const size_t n = (size_t)(b.shared ? 1 : S.T) * b.chw();
-        b.d = b.is_mask ? (void *)dev_alloc<uint8_t>(n) : (void *)dev_alloc<float>(n);
-        S.owned.push_back(b.d);
-        if (b.pk_Hp) {          // zeroed once: producers write the interior only, the border stays zero for good
-            const size_t nb = pk_bytes(b.shared ? 1 : S.T, b.C, b.pk_Hp, b.pk_Wp);
-            SIVO_HIP(hipMalloc(&b.d_pk, nb));
-            S.owned.push_back(b.d_pk);
-            SIVO_HIP(hipMemset(b.d_pk, 0, nb));
-        }
-        if (b.bits_Hp) {
-            const size_t nd = (size_t)(b.shared ? 1 : S.T) * b.bits_sample_dwords();
-            b.d_bits = dev_alloc<uint32_t>(nd);
-            S.owned.push_back(b.d_bits);
-            SIVO_HIP(hipMemset(b.d_bits, 0, nd * sizeof(uint32_t)));
-        }
-    }
-    if (S.wino4_ws_floats) {
-        const int env_lanes = std::getenv("SIVO_LANES") ? std::atoi(std::getenv("SIVO_LANES")) : 2;
-        S.ws_lanes = std::max(1, std::min(env_lanes, (int)sivo_segnet::MAX_LANES));
-        S.d_wino4_ws = dev_alloc<float>((size_t)S.ws_lanes * S.wino4_ws_floats);      // one region per lane
-        S.owned.push_back(S.d_wino4_ws);
-    }
-    const int64_t hw = (int64_t)S.H * S.W;
-    S.d_image = dev_alloc<uint8_t>(hw * 3);
-    S.d_prob_sum = dev_alloc<float>(std::max(S.classes, 1) * hw);
-    S.d_classes = dev_alloc<uint8_t>(hw);
-    S.d_conf = dev_alloc<double>(hw);
-    S.d_ent = dev_alloc<double>(hw);
-    for (void *p : {(void *)S.d_image, (void *)S.d_prob_sum, (void *)S.d_classes, (void *)S.d_conf, (void *)S.d_ent})
-        S.owned.push_back(p);
-    SIVO_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
-    if (prefix_rows <= 0) calibrate_h3(S);
-    return Sp;
-}
-
-// The kernels of an f16x3 layer store 1 into the pinned flag word when a value times the layer's scale leaves the fp16 range.
-// The frame that raised it is wrong (inf / NaN in that layer).  What follows (h3_back_off): the NEXT forward of the handle runs
-// without f16x3 (bf16x6 / fp32 kernels: fp32's range) — that is the recomputation of the frame, which the synchronous entry points
-// do before they return and a caller of the asynchronous ones does after sivo_segnet_take_overflow told it to — and every
-// f16x3 scale of the handle is lowered by 2^2: two more bits of headroom for two bits of the lo plane (2^-20 instead of 2^-22
-// relative; still below the fp32 FMA chain's own error).  The fourth such frame switches f16x3 off for good: activations that
-// outgrow 2^14 times the calibration's are not what the scales were made for.
-bool h3_flag_take(sivo_segnet &S) {
-    if (!S.h3_flag || !*S.h3_flag) return false;
-    *S.h3_flag = 0;
-    ++S.h3_overflow_frames;
-    return true;
-}
-void h3_back_off(sivo_segnet &S) {
-    S.h3_pause = true;
-    if (++S.h3_back_offs > 3) { S.h3_on = false; return; }
-    for (Op &op : S.ops) {
-        if (op.h3_vscale > 0.f) op.h3_vscale *= 0.25f;
-        if (op.d3_vscale > 0.f) op.d3_vscale *= 0.25f;
-    }
-}
-// One overflow EVENT = every frame that was issued with the scales that overflowed.  With several frames in flight the flag can
-// go up more than once per event (the frames still running when the first one was noticed carry the same scales): the scales are
-// lowered once per event — a flag that shows up while the back-off's pause has not been consumed by a forward yet belongs to the
-// event that caused the back-off.
-bool h3_tripped(sivo_segnet &S) {
-    if (!h3_flag_take(S)) return false;
-    if (!S.h3_pause) h3_back_off(S);
-    return true;
-}
-// A place that is not the caller's question (the start of a forward, a status query) found the flag up: react, and remember that
-// sivo_segnet_take_overflow has not told anybody yet — with two frames in flight forward(k) runs before the caller asks about
-// frame k-1, and consuming the flag silently would let k-1's wrong maps through.
-void h3_absorb(sivo_segnet &S) {
-    if (h3_tripped(S)) S.h3_unreported = true;
-}
-
-// Deterministic frame for the calibration pass: rectangles of random colour over a gradient plus per-pixel noise — edges,
-// flat regions and texture, i.e. high-frequency content at least as strong as a camera frame's (the F(4x4) input transform
-// amplifies exactly that), independent of anything but the network geometry.
-std::vector<uint8_t> calibration_frame(int H, int W, int variant = 0) {
-    std::vector<uint8_t> img((size_t)H * W * 3);
-    uint32_t st = 0x51f0u + 7919u * (uint32_t)variant;
-    auto rnd = [&] { st = st * 1664525u + 1013904223u; return st >> 8; };
-    std::vector<int> acc((size_t)H * W * 3);
-    for (int y = 0; y < H; ++y)
-        for (int x = 0; x < W; ++x)
-            for (int c = 0; c < 3; ++c) acc[((size_t)y * W + x) * 3 + c] = 40 + (c == 0 ? 120 * y / H : c == 1 ? 120 * x / W : 60);
-    for (int r = 0; r < 40; ++r) {
-        const int x0 = (int)(rnd() % (uint32_t)W), y0 = (int)(rnd() % (uint32_t)H);
-        const int w = 8 + (int)(rnd() % (uint32_t)(W / 3 + 1)), h = 8 + (int)(rnd() % (uint32_t)(H / 2 + 1));
-        const int col[3] = {(int)(rnd() % 256u), (int)(rnd() % 256u), (int)(rnd() % 256u)};
-        for (int y = y0; y < std::min(H, y0 + h); ++y)
-            for (int x = x0; x < std::min(W, x0 + w); ++x)
-                for (int c = 0; c < 3; ++c) acc[((size_t)y * W + x) * 3 + c] = col[c];
-    }
-    // variant 1: the same kind of scene at full contrast (black / white rectangles dominate); variant 2: heavy sensor noise
-    const int amp = variant == 2 ? 61 : 25;
-    for (size_t i = 0; i < acc.size(); ++i) {
-        int v = acc[i];
-        if (variant == 1) v = v < 100 ? v / 4 : v > 156 ? 255 - (255 - v) / 4 : v;
-        v += (int)(rnd() % (uint32_t)amp) - amp / 2;
-        img[i] = (uint8_t)std::min(255, std::max(0, v));
-    }
-    return img;
-}
-
-struct McTargets;
-struct BandInput { const void *slots; int world; };      // the gathered prefix slots of all ranks (PrefixBands)
-void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t seed, float *d_prob_sum, float *d_logits,
-             float *d_prob, hipStream_t st, const McTargets *mc = nullptr, const BandInput *pre = nullptr);
-void bands_unpack(sivo_segnet &S, const BandInput &pre, int n, int sample0, uint64_t seed, hipStream_t st, size_t *suffix_begin);
-
-// f16x3: per-layer power-of-two scale of the (transformed) input, from calibration passes on the fp32 kernels whose transform /
-// absmax kernels record each layer's largest |V| — three synthetic frames (calibration_frame variants: a scene, the same at
-// full contrast, heavy noise) x the MC samples 0 .. 11 of each.  The largest value is put at [2^7, 2^8): 2^8 of headroom below
-// fp16's 65504 for frames with larger activations, full hi + lo precision (2^-22) down to 2^-10 of the maximum and an absolute
-// error of 2^-25 below that.  The scales depend on the weights and the network geometry only — not on T (the 36 passes are the
-// same (frame, global sample) pairs for every T), the device or the frames seen — so every handle of one model computes
-// identical bits, until a frame overflows (h3_back_off).
-// SIVO_H3_BOOST=k multiplies the scales by 2^k (tests: k = 9 forces the overflow path).
-void calibrate_h3(sivo_segnet &S) {
-    bool any = false;
-    for (const Op &op : S.ops) any = any || op.d_wh3 || op.d3 || op.c3 || op.c7h3;
-    if (!any) return;
-    uint32_t *flag = nullptr;
-    SIVO_HIP(hipHostMalloc((void **)&flag, 64, hipHostMallocDefault));
-    *flag = 0;
-    S.h3_flag = flag;
-    S.d_h3_vmax = dev_alloc<uint32_t>(2 * S.ops.size());         // [op]: largest |V| of an F(4x4) layer; [ops + op]: largest |input| of a direct f16x3 layer
-    S.owned.push_back(S.d_h3_vmax);
-    SIVO_HIP(hipMemset(S.d_h3_vmax, 0, 2 * S.ops.size() * sizeof(uint32_t)));
-    // THREE frames (calibration_frame variants 0, 1, 2), the MC samples 0 .. 11 of each — the dropout masks decide which activations
-    // survive, and a layer's largest value is not in every sample — in passes of as many samples as the handle holds: the same 36
-    // (frame, global sample index) pairs whatever T is, so that handles of one model that shard the samples compute identical scales.
-    constexpr int CAL_FRAMES = 3, CAL_SAMPLES = 12;
-    S.calibrating = true;
-    try {
-        for (int f = 0; f < CAL_FRAMES; ++f) {
-            const std::vector<uint8_t> img = calibration_frame(S.H, S.W, f);
-            SIVO_HIP(hipMemcpy(S.d_image, img.data(), img.size(), hipMemcpyHostToDevice));
-            for (int s0 = 0; s0 < CAL_SAMPLES; s0 += S.T) {
-                forward(S, S.d_image, std::min(S.T, CAL_SAMPLES - s0), s0, 0x5157ca11b8a7e5ull + (uint64_t)f, S.d_prob_sum, nullptr, nullptr, S.stream, nullptr);
-                SIVO_HIP(hipStreamSynchronize(S.stream));
-            }
-        }
-    } catch (...) {
-        S.calibrating = false;
-        throw;
-    }
-    S.calibrating = false;
-    std::vector<uint32_t> bits(2 * S.ops.size());
-    SIVO_HIP(hipMemcpy(bits.data(), S.d_h3_vmax, bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    const int boost = SIVO_DIAG_ENV("SIVO_H3_BOOST") ? std::atoi(SIVO_DIAG_ENV("SIVO_H3_BOOST")) : 0;
-    auto scale_for = [&](uint32_t b, float *vmax) {
-        float v;
-        std::memcpy(&v, &b, 4);
-        *vmax = v;
-        int e = 0;
-        if (v > 0.f && std::isfinite(v)) (void)std::frexp(v, &e);        // v = m 2^e, m in [0.5, 1)
-        return std::ldexp(1.f, (v > 0.f && std::isfinite(v) ? 8 - e : 0) + boost);
-    };
-    for (size_t i = 0; i < S.ops.size(); ++i) {
-        Op &op = S.ops[i];
-        if (op.d_wh3) op.h3_vscale = scale_for(bits[i], &op.h3_vmax);
-        if (op.d3 || op.c3 || op.c7h3) op.d3_vscale = scale_for(bits[S.ops.size() + i], &op.d3_vmax);
-    }
-    S.h3_on = true;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// Load-time accuracy guard.  The fp16 RANGE of the f16x3 layers is guarded by calibrate_h3 + the overflow flag; this guards their
-// ACCURACY for the weights at hand: how much of the 1e-3 logit budget Winograd F(4x4,3x3) (4 d0 - 5 d2 + d4 cancels the common mode
-// of a tile) and the fp16 hi + lo split use depends on the weights' and activations' dynamic range, and trained weights are not the
-// synthetic ones the tests sweep.  On two calibration frames x MC samples 0, 1 the network is evaluated once more, UNFUSED, along a
-// reference chain — every 3x3 layer that production runs on F(4x4) or f16x3 is computed by the direct fp32 matrix-core kernel
-// (conv_v2.hip: v_mfma_f32, the fp32 FMA chain) from the reference chain's own input — and beside it the layer's production kernel
-// (input transform + f16x3 / bf16x6 GEMM + output transform, or the direct f16x3 kernel) runs on the SAME input: err_l = max |fast -
-// ref| / max |ref| is that layer's own error, free of propagated differences and of pooling-switch flips.
-// Budget: the tolerance is 1e-3 at the logit range of the reference configuration (|logit| <= 30), i.e. 3.3e-5 of the logits' scale.
-// Errors of independent layers add in quadrature and a relative error of the activations carries to the logits with a factor <= 0.5
-// (measured: predicted 0.5 sqrt(sum err_l^2) = 1.7 - 1.9e-5 against 0.95 - 1.9e-5 found against the oracle for the synthetic weights,
-// BN offsets 3 / 30 / 100).  While the prediction is above the budget the largest contributors move one level down —
-// F(4x4) -> direct f16x3 (no transform) -> F(2x2) / direct fp32 -> direct fp32 — the handle is planned again (fusions depend on
-// the kernels) and guarded again.  Two samples, two frames: ~1 s at load, nothing per
-// frame.  The decisions depend on the weights and the geometry only (never on T: always samples 0 and 1), so shard handles of one
-// model plan identically.  Diagnostic build: SIVO_GUARD=0 skips it, SIVO_GUARD_TOL sets tol.
-struct GuardVerdict { bool any_over = false; std::map<std::string, int> levels; };
-
-GuardVerdict accuracy_guard(sivo_segnet &S, const float *weights, const std::map<std::string, int> &levels_in, float tol) {
-    GuardVerdict verdict;
-    verdict.levels = levels_in;
-    const int n = std::min(S.T, 2);
-    std::vector<size_t> guarded;
-    auto d3_runs = [&](const Op &op) { return op.d3 && S.h3_on && op.d3_vscale > 0.f && op.drop_site < 0; };
-    auto c7_runs = [&](const Op &op) { return op.c7h3 && S.h3_on && op.d3_vscale > 0.f; };
-    auto cls_runs = [&](size_t i) { const Op &op = S.ops[i]; return (int)i == S.cls_op && op.c3 && op.pk_in && S.pk_on && S.h3_on && op.d3_vscale > 0.f; };
-    for (size_t i = 0; i < S.ops.size(); ++i) {
-        const Op &op = S.ops[i];
-        // (F(2x2) fp32 layers only when the guard itself put them there: they can still go one level down, to the direct kernel)
-        if (op.kind != OP_CONV) continue;
-        if (op.ks == 3 && (int)i != S.cls_op && (op.wino4 || op.wino4f || d3_runs(op) || (op.wino && op.guard_level >= 2))) guarded.push_back(i);
-        else if (cls_runs(i) || c7_runs(op)) guarded.push_back(i);        // the f16x3 classifier (fused with the MC statistics) / 7x7 layer
-    }
-    if (guarded.empty()) return verdict;
-    const auto t_begin = std::chrono::steady_clock::now();
-    hipStream_t st = S.stream;
-    // every blob of the net, materialised for n samples (shared ones once); freed when the guard returns
-    std::vector<void *> buf(S.blobs.size(), nullptr);
-    std::vector<void *> scratch;
-    auto release = [&] { for (void *p : buf) if (p) (void)hipFree(p); for (void *p : scratch) if (p) (void)hipFree(p); };
-    try {
-        int64_t max_out = 0;
-        for (size_t b = 0; b < S.blobs.size(); ++b) {
-            const Blob &B = S.blobs[b];
-            const size_t cnt = (size_t)(B.shared ? 1 : n) * B.chw();
-            SIVO_HIP(hipMalloc(&buf[b], cnt * (B.is_mask ? 1 : sizeof(float))));
-            if (!B.is_mask) max_out = std::max<int64_t>(max_out, (int64_t)cnt);
-        }
-        float *d_fast = nullptr;
-        void *d_cls_pk = nullptr;
-        uint32_t *d_bits = nullptr;
-        double *d_sums = nullptr;
-        std::vector<float *> d_wref(S.ops.size(), nullptr);      // per guarded layer: its Caffe weights packed for the direct fp32 kernel
-        std::vector<int> wref_pad(S.ops.size(), 0);
-        SIVO_HIP(hipMalloc((void **)&d_fast, (size_t)max_out * sizeof(float))); scratch.push_back(d_fast);
-        SIVO_HIP(hipMalloc((void **)&d_bits, (2 * S.ops.size() + 2) * sizeof(uint32_t))); scratch.push_back(d_bits);
-        SIVO_HIP(hipMalloc((void **)&d_sums, 2 * S.ops.size() * sizeof(double))); scratch.push_back(d_sums);
-        SIVO_HIP(hipMemset(d_bits, 0, (2 * S.ops.size() + 2) * sizeof(uint32_t)));
-        SIVO_HIP(hipMemset(d_sums, 0, 2 * S.ops.size() * sizeof(double)));
-        auto fp = [&](int b) { return (float *)buf[b]; };
-        const uint64_t seed = 0x6a09e667f3bcc908ull;
-        for (int frame = 0; frame < 2; ++frame) {
-            const std::vector<uint8_t> img = calibration_frame(S.H, S.W, frame);
-            SIVO_HIP(hipMemcpyAsync(S.d_image, img.data(), img.size(), hipMemcpyHostToDevice, st));
-            launch_preprocess(S.d_image, fp(S.input_blob), (int64_t)S.H * S.W, st);
-            for (size_t oi = 0; oi < S.ops.size(); ++oi) {
-                const Op &op = S.ops[oi];
-                const Blob &bi = S.blobs[op.in], &bo = S.blobs[op.out];
-                const int N = bo.shared ? 1 : n;
-                switch (op.kind) {
-                    case OP_CONV: {
-                        ConvArgs a{};
-                        a.in = fp(op.in); a.in_sample_stride = bi.shared ? 0 : bi.chw();
-                        a.wt = op.d_w; a.ep_scale = op.d_scale; a.ep_shift = op.d_shift;
-                        a.out = fp(op.out);
-                        a.N = N; a.Cin = op.cin; a.H = bi.H; a.W = bi.W; a.Cout = op.cout; a.CoutPad = op.cout_pad;
-                        a.relu = op.relu; a.drop_site = op.drop_site; a.sample0 = 0; a.seed = seed + (uint64_t)frame;
-                        a.wt_x6 = op.d_wx6;
-                        if (op.in_drop_site >= 0) {
-                            // the fork pooling's dropout lives in this layer's input transform (drop_moved): the pooling above wrote the
-                            // sample-invariant values once; here every guard sample gets its own dropped copy, so that the reference chain and
-                            // the production kernel both see per-sample masks (x 2 or 0: exact) through their plain input path
-                            float *dropped = nullptr;
-                            SIVO_HIP(hipMalloc((void **)&dropped, (size_t)n * bi.chw() * sizeof(float))); scratch.push_back(dropped);
-                            launch_dropout(fp(op.in), 0, dropped, n, bi.chw(), op.in_drop_site, 0, seed + (uint64_t)frame, st);
-                            a.in = dropped; a.in_sample_stride = bi.chw();
-                        }
-                        const bool is_guarded = std::find(guarded.begin(), guarded.end(), oi) != guarded.end();
-                        if (!is_guarded) {
-                            // the layer's own fp32 kernel (no F(4x4), no f16x3 in it): part of the reference chain as it is
-                            if (op.c7x6) launch_conv7_x6(a, st);
-                            else if (op.wino) launch_conv_wino(a, op.wino_cfg, st);
-                            else if (op.v2) launch_conv2(a, op.ks, st);
-                            else launch_conv(a, op.ks, st);
-                            break;
-                        }
-                        if (c7_runs(op)) {
-                            // 7x7: the layer's own weights are the direct fp32 kernel's (conv_mfma_kernel<7>); beside it the f16x3 form
-                            launch_conv(a, op.ks, st);
-                            ConvArgs f = a;
-                            f.out = d_fast;
-                            f.wt_h3 = op.d_wd3; f.h3_vscale = op.d3_vscale; f.h3_uscale = op.d3_uscale; f.h3_flag = const_cast<uint32_t *>(S.h3_flag);
-                            launch_conv7_h3(f, st);
-                            launch_absdiff_max(d_fast, fp(op.out), (int64_t)N * bo.chw(), d_bits + 2 * oi, d_sums + 2 * oi, st);
-                            break;
-                        }
-                        if (cls_runs(oi)) {
-                            // classifier: logits of its plain fp32 kernel against those of conv_cls_h3_kernel on the packed form of the same input
-                            if (op.v2) launch_conv2(a, op.ks, st); else launch_conv(a, op.ks, st);
-                            if (!d_cls_pk) {
-                                SIVO_HIP(hipMalloc(&d_cls_pk, pk_bytes(N, bi.C, bi.pk_Hp, bi.pk_Wp))); scratch.push_back(d_cls_pk);
-                                SIVO_HIP(hipMemsetAsync(d_cls_pk, 0, pk_bytes(N, bi.C, bi.pk_Hp, bi.pk_Wp), st));
-                            }
-                            launch_pk_pack(a.in, bi.chw(), d_cls_pk, N, bi.C, bi.H, bi.W, bi.pk_Hp, bi.pk_Wp, op.d3_vscale, const_cast<uint32_t *>(S.h3_flag), st);
-                            ClsMcArgs c{};
-                            c.in = a.in; c.in_sample_stride = bi.chw(); c.wt = op.d_w_mc; c.ep_scale = op.d_scale; c.ep_shift = op.d_shift;
-                            c.T = N; c.Cin = op.cin; c.H = bi.H; c.W = bi.W; c.C = op.cout; c.relu = op.relu;
-                            c.logits = d_fast; c.prob_sum = S.d_prob_sum; c.sum_chunk = 0;
-                            c.in_pk = d_cls_pk; c.in_pk_sample_bytes = bi.pk_sample_bytes(); c.in_Hp = bi.pk_Hp; c.in_Wp = bi.pk_Wp;
-                            c.wt_h3 = op.d_wd3; c.h3_vscale = op.d3_vscale; c.h3_uscale = op.d3_uscale;
-                            launch_conv_cls_h3(c, st);
-                            launch_absdiff_max(d_fast, fp(op.out), (int64_t)N * bo.chw(), d_bits + 2 * oi, d_sums + 2 * oi, st);
-                            break;
-                        }
-                        // reference: the direct fp32 matrix-core kernel on weights packed for it from the Caffe array
-                        if (!d_wref[oi]) {
-                            std::vector<float> wt;
-                            conv2_pack_weights(weights + op.w_off, op.ks, op.cin, op.cout, wt, &wref_pad[oi]);
-                            SIVO_HIP(hipMalloc((void **)&d_wref[oi], wt.size() * sizeof(float))); scratch.push_back(d_wref[oi]);
-                            SIVO_HIP(hipMemcpy(d_wref[oi], wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
-                        }
-                        ConvArgs r = a;
-                        r.wt = d_wref[oi]; r.CoutPad = wref_pad[oi]; r.wt_x6 = nullptr;
-                        launch_conv2(r, op.ks, st);
-                        // the production kernel of this layer on the same input, standalone (no bridge, no fused pooling / Upsample)
-                        ConvArgs f = a;
-                        f.out = d_fast;
-                        // (the order of run_ops: a direct f16x3 layer also carries the flags of the fp32 kernel it falls back to)
-                        if (d3_runs(op)) {
-                            f.wt_h3 = op.d_wd3; f.h3_vscale = op.d3_vscale; f.h3_uscale = op.d3_uscale; f.h3_flag = const_cast<uint32_t *>(S.h3_flag);
-                            f.CoutPad = op.cout;
-                            launch_conv3_h3(f, st);
-                        } else if (op.wino4) {
-                            if (S.h3_on && op.d_wh3 && op.h3_vscale > 0.f) { f.wt_h3 = op.d_wh3; f.h3_vscale = op.h3_vscale; f.h3_uscale = op.h3_uscale; }
-                            f.h3_flag = const_cast<uint32_t *>(S.h3_flag);
-                            launch_conv_wino4(f, S.d_wino4_ws, op.wino4_group, st, nullptr, false, nullptr);
-                        } else if (op.wino4f) {
-                            f.variant |= 4096;
-                            launch_conv_wino4f(f, st);
-                        } else {
-                            launch_conv_wino(f, op.wino_cfg, st);
-                        }
-                        launch_absdiff_max(d_fast, fp(op.out), (int64_t)N * bo.chw(), d_bits + 2 * oi, d_sums + 2 * oi, st);
-                        break;
-                    }
-                    case OP_POOL: {
-                        PoolArgs a{};
-                        a.in = fp(op.in); a.in_sample_stride = bi.shared ? 0 : bi.chw();
-                        a.out = fp(op.out); a.mask = (uint8_t *)buf[op.out2];
-                        a.mask_N = S.blobs[op.out2].shared ? 1 : n;
-                        a.N = N; a.C = bi.C; a.H = bi.H; a.W = bi.W; a.Ho = bo.H; a.Wo = bo.W;
-                        a.drop_site = op.drop_moved ? -1 : op.drop_site; a.sample0 = 0; a.seed = seed + (uint64_t)frame;
-                        launch_maxpool2(a, st);
-                        break;
-                    }
-                    case OP_UNPOOL: {
-                        UnpoolArgs a{};
-                        const Blob &bm = S.blobs[op.in2];
-                        a.in = fp(op.in); a.mask = (const uint8_t *)buf[op.in2];
-                        a.mask_sample_stride = bm.shared ? 0 : bm.chw();
-                        a.out = fp(op.out); a.N = N; a.C = bi.C; a.H = bi.H; a.W = bi.W;
-                        launch_unpool2(a, st);
-                        break;
-                    }
-                    case OP_DROPOUT:
-                        launch_dropout(fp(op.in), bi.shared ? 0 : bi.chw(), fp(op.out), n, bi.chw(), op.drop_site, 0, seed + (uint64_t)frame, st);
-                        break;
-                    case OP_LRN:
-                        launch_lrn(fp(op.in), fp(op.out), N, bi.C, (int64_t)bi.H * bi.W, op.local_size, op.alpha, op.beta, st);
-                        break;
-                }
-            }
-            launch_absmax(fp(S.logits_blob), (int64_t)n * S.blobs[S.logits_blob].chw(), d_bits + 2 * S.ops.size(), st);
-        }
-        SIVO_HIP(hipStreamSynchronize(st));
-        SIVO_HIP(hipGetLastError());
-        std::vector<uint32_t> bits(2 * S.ops.size() + 2);
-        std::vector<double> sums(2 * S.ops.size());
-        SIVO_HIP(hipMemcpy(bits.data(), d_bits, bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        SIVO_HIP(hipMemcpy(sums.data(), d_sums, sums.size() * sizeof(double), hipMemcpyDeviceToHost));
-        const bool overflowed = S.h3_flag && *S.h3_flag;
-        if (S.h3_flag) *S.h3_flag = 0;            // (the guard's frames are the calibration's: nothing to report to a caller)
-        auto as_float = [](uint32_t b) { float v; std::memcpy(&v, &b, 4); return v; };
-        // a value left the fp16 range DURING the guard's own frames: they are the calibration's frames, so this is a handle whose scales
-        // were forced (SIVO_H3_BOOST) — the range guard's business (overflow flag, back-off), not an accuracy verdict
-        if (overflowed) { S.guard_rows.clear(); S.guard_budget = 0.f; S.guard_predicted = 0.f; release(); return verdict; }
-        const float L = std::max(1.f, as_float(bits[2 * S.ops.size()]));
-        // the tolerance is stated at the logit range of the reference configuration (|logit| <= 30): relative to the logits' scale
-        const float budget = tol / 30.f;
-        std::vector<sivo_segnet::GuardRow> rows;
-        std::vector<std::pair<float, size_t>> by_err;
-        double sum2 = 0.0;
-        for (size_t oi : guarded) {
-            const Op &op = S.ops[oi];
-            sivo_segnet::GuardRow r;
-            r.layer = op.name;
-            r.kernel = cls_runs(oi) ? "classifier f16x3" : c7_runs(op) ? "direct 7x7 f16x3" : d3_runs(op) ? "direct f16x3" : op.wino4 ? (S.h3_on && op.d_wh3 && op.h3_vscale > 0.f ? "F(4x4) f16x3 GEMM" : op.d_wx6 ? "F(4x4) bf16x6 GEMM" : "F(4x4) fp32 GEMM") : op.wino4f ? "F(4x4) fp32 fused" : "F(2x2) fp32 fused";
-            r.ref_max = as_float(bits[2 * oi + 1]);
-            r.rel_err = as_float(bits[2 * oi]) / std::max(r.ref_max, 1e-30f);
-            r.rel_rms = (float)std::sqrt(sums[2 * oi] / std::max(sums[2 * oi + 1], 1e-300));
-            r.level = op.guard_level;
-            r.first_rel_err = r.rel_err;
-            for (const auto &prev : S.guard_rows) if (prev.layer == r.layer) r.first_rel_err = prev.first_rel_err;
-            sum2 += (double)r.rel_err * r.rel_err;
-            by_err.push_back({r.rel_err, oi});
-            rows.push_back(r);
-        }
-        // predicted error of the logits relative to their scale: the layers' own errors in quadrature, times GUARD_CARRY (how much
-        // of a layer's LARGEST error reaches the logits: measured 0.3 - 0.5 over the weight families of the full-size sweep)
-        constexpr double GUARD_CARRY = 0.5, REROUTED_ERR = 2e-6;
-        double predicted = GUARD_CARRY * std::sqrt(sum2);
-        // The prediction is an estimate: found / predicted was 0.6 - 0.9 for the weight families of the sweep and 2.4 for a plan whose
-        // scales were forced wrong (tests/test_gpu_segnet.py).  A plan that never needed correction is held to the budget itself; once a
-        // plan HAS needed correction the weights (or scales) are not of the kind the estimate was fitted on, and the corrected plan is
-        // held to a third of it.
-        const double target = levels_in.empty() ? budget : budget / 3.0;
-        if (!(predicted <= target)) {
-            // take the largest contributors one level down until the prediction (a rerouted layer counted at the direct kernels' ~2e-6) fits
-            std::sort(by_err.begin(), by_err.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
-            double s2 = sum2;
-            for (const auto &[err, oi] : by_err) {
-                const Op &op = S.ops[oi];
-                if (GUARD_CARRY * std::sqrt(std::max(s2, 0.0)) <= budget / 3.0 || !(err > REROUTED_ERR)) break;
-                if (op.guard_level >= 3) continue;
-                const int next = (cls_runs(oi) || c7_runs(op)) ? 1 : d3_runs(op) ? std::max(2, op.guard_level + 1) : (op.wino4 || op.wino4f) ? std::max(1, op.guard_level + 1) : 3;
-                verdict.levels[op.name] = next;
-                verdict.any_over = true;
-                s2 += REROUTED_ERR * REROUTED_ERR - (double)err * err;
-            }
-        }
-        S.guard_predicted = (float)predicted;
-        S.guard_rows = rows;
-        S.guard_budget = budget; S.guard_logit_max = L;
-    } catch (...) {
-        release();
-        throw;
-    }
-    release();
-    S.guard_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    return verdict;
-}
-
-// build + guard + (when a layer is over its budget) plan again with that layer one level down, until nothing moves
-std::unique_ptr<sivo_segnet> build_guarded(const ProtoNet &net, int t_override, const float *weights, size_t n_weights, int device) {
-    const bool off = SIVO_DIAG_ENV("SIVO_GUARD") && std::atoi(SIVO_DIAG_ENV("SIVO_GUARD")) == 0;
-    const float tol = SIVO_DIAG_ENV("SIVO_GUARD_TOL") ? (float)std::atof(SIVO_DIAG_ENV("SIVO_GUARD_TOL")) : 1e-3f;
-    std::map<std::string, int> levels;
-    std::unique_ptr<sivo_segnet> S;
-    std::vector<sivo_segnet::GuardRow> carried;
-    double ms = 0.0;
-    for (int round = 0; round < 5; ++round) {
-        S.reset();                                   // (the previous plan's 16 GB go back before the next one allocates)
-        S = build(net, t_override, weights, n_weights, device, levels);
-        S->guard_builds = round + 1;
-        if (off) break;
-        DeviceGuard dg(device);
-        S->guard_rows = carried; S->guard_ms = ms;
-        const GuardVerdict v = accuracy_guard(*S, weights, levels, tol);
-        carried = S->guard_rows; ms = S->guard_ms;
-        S->guard_over_budget = v.any_over;
-        if (!v.any_over) break;
-        levels = v.levels;
-    }
-    // five plans and the last one still over its budget (never seen: three plans settle a handle whose scales are 2^16 off): the handle is
-    // returned — its layers are one to three levels down already — and says so in sivo_segnet_guard_report (predicted > budget, builds = 5)
-    if (S->guard_over_budget)
-        std::fprintf(stderr, "sivo_segnet: the accuracy guard could not bring the predicted logit error (%.3g of the logit scale) under its budget (%.3g) in %d plans\n",
-                     (double)S->guard_predicted, (double)S->guard_budget, S->guard_builds);
-    return S;
-}
 
 void harvest(sivo_segnet &S) {
     if (!S.pending) return;
@@ -1347,18 +203,10 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                 break;
         }
         if (bracket) SIVO_HIP(hipEventRecord(op.ev1, st));
-        static const bool debug_sync = std::getenv("SIVO_DEBUG_SYNC") != nullptr;      // debugging aid: serialise every op of every lane
+        const bool debug_sync = S.opt.debug_sync != 0;      // debugging aid: serialise every op of every lane
         if (debug_sync) SIVO_HIP(hipDeviceSynchronize());
     }
 }
-
-// Where the Monte-Carlo post-processing of a whole frame goes (segmentImage): maps on the device, optionally the logits
-// they were computed from.
-struct McTargets {
-    uint8_t *classes;
-    double *conf, *ent;
-    float *logits;     // optional (n, classes, H, W)
-};
 
 // d_prob_sum: fp32 sums of the softmax probabilities over the n samples (layout S.sum_chunk), or null.  mc: the f64 mean
 // and its maps (exact: no probability sum goes through memory).  When the plan ends in a classifier convolution that
@@ -1468,185 +316,7 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
     SIVO_HIP(hipGetLastError());
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Row bands of the sample-invariant prefix.  With the T samples sharded over N ranks every rank used to
-// recompute the whole prefix (SegNet-Standard: conv1_1 .. pool3, 134 of 446 GFLOP per sample — 0.66 of the 1.82 ms the heaviest of 8
-// ranks needs), which caps strong scaling at 3.8x.  The prefix is a chain of 3x3 / 7x7 convolutions and 2x2 poolings: the rows
-// [y0, y1) of its output depend on the input rows [2^p y0 - halo, 2^p y1 + halo) only (halo = 18 rows for Standard, 21 for Basic), so
-// rank r computes ITS band of output rows from a band of the image on a prefix-only handle of that height (build(prefix_rows));
-// band edges inside the image see zero padding where the frame has pixels, which corrupts only halo rows that are discarded; true
-// image edges coincide with band edges.  Every kernel of the prefix treats all output positions alike (direct convolutions: one fixed
-// summation order per pixel), so a band's valid rows are BIT-identical to the full frame's (tests/test_gpu_prefix_bands.py).
-// A rank packs the valid rows of what the per-sample part reads — the fork pooling's values before its dropout and every pooling
-// mask of the prefix — into a fixed-size slot; one all-gather of the slots (SegNet-Standard, 8 ranks: 2.2 MB per rank) gives every
-// rank the whole prefix; unpacking + the dropout of the fork pooling per sample (the same counter-based stream, keyed by element and
-// global sample) replaces the prefix ops of the forward.
-}  // namespace
-struct PrefixBands {
-    int world = 0, fork = -1, pools = 0, rows_max = 0;
-    struct Item { int blob; int shift; int elt; int C, H, W; size_t off; };     // rows of rank r at this blob: (y0[r] .. y0[r + 1]) << shift
-    std::vector<Item> items;                // [0] = the fork pooling's output before dropout, then the pooling masks of the prefix
-    size_t slot_bytes = 0;
-    std::vector<int> y0;                    // [world + 1]: rows of the fork pooling's output per rank
-    std::vector<int> in0, in1;              // [world]: input rows of each rank's band handle
-    std::vector<sivo_segnet *> net;         // [world]: built on first use
-    std::vector<std::vector<std::pair<int, int>>> op_map;      // [world]: (band op, owner op) pairs by layer name
-    int device = 0;
-};
-void free_bands(PrefixBands *B) {
-    if (!B) return;
-    (void)hipSetDevice(B->device);
-    for (sivo_segnet *n : B->net) delete n;
-    delete B;
-}
 namespace {
-
-PrefixBands &plan_bands(sivo_segnet &S, int world) {
-    auto it = S.bands.find(world);
-    if (it != S.bands.end()) return *it->second;
-    if (world < 1 || world > BAND_RANKS) throw std::invalid_argument("prefix bands: 1 .. 16 ranks");
-    if (S.prefix_weights.empty()) throw std::invalid_argument("prefix bands: the network has no sample-invariant prefix (no test-time dropout)");
-    std::unique_ptr<PrefixBands, void (*)(PrefixBands *)> B(new PrefixBands, free_bands);
-    B->world = world; B->device = S.device;
-    size_t fork = 0;
-    while (fork < S.ops.size() && (S.ops[fork].skip || S.blobs[S.ops[fork].out].shared)) ++fork;
-    // the prefix ends in the pooling whose in-place Dropout makes the blobs per-sample: either that pooling is the first per-sample op
-    // itself, or its dropout moved into the input transform of the convolution behind it (drop_moved) and that convolution is
-    if (fork < S.ops.size() && S.ops[fork].kind == OP_CONV && S.ops[fork].in_drop_site >= 0 && fork > 0 && S.ops[fork - 1].out == S.ops[fork].in &&
-        S.ops[fork - 1].kind == OP_POOL && S.ops[fork - 1].drop_moved)
-        --fork;
-    else if (fork >= S.ops.size() || S.ops[fork].kind != OP_POOL || S.ops[fork].drop_site < 0 || !S.blobs[S.ops[fork].in].shared)
-        throw std::invalid_argument("prefix bands: the sample-invariant prefix must end in a pooling with test-time dropout");
-    B->fork = (int)fork;
-    for (size_t i = 0; i <= fork; ++i) {
-        const Op &op = S.ops[i];
-        if (op.skip || op.kind == OP_UNPOOL || op.kind == OP_DROPOUT || (i > 0 && op.in != S.ops[i - 1].out))
-            throw std::invalid_argument("prefix bands: the prefix must be a plain chain of convolutions, LRN and poolings");
-        if (op.kind == OP_POOL) ++B->pools;
-    }
-    const int align = 1 << B->pools;
-    const Blob &bo = S.blobs[S.ops[fork].out];
-    if (S.H % align || bo.H != S.H >> B->pools) throw std::invalid_argument("prefix bands: the image height must be a multiple of 2^poolings");
-    if (bo.H < world) throw std::invalid_argument("prefix bands: more ranks than rows of the prefix output");
-    // rows of the prefix output per rank: the LAST H % world ranks take one more (rank 0, which also runs ORB and the host side, the light share)
-    B->y0.resize((size_t)world + 1);
-    const int base = bo.H / world, extra = bo.H % world;
-    for (int r = 0; r <= world; ++r) B->y0[(size_t)r] = r * base + std::max(0, r - (world - extra));
-    B->rows_max = base + (extra ? 1 : 0);
-    // input rows each band needs: walk the chain backwards (pooling: x2; k x k convolution: +- k / 2), align to 2^poolings
-    B->in0.resize((size_t)world); B->in1.resize((size_t)world);
-    for (int r = 0; r < world; ++r) {
-        int lo = B->y0[(size_t)r], hi = B->y0[(size_t)r + 1];
-        for (int i = (int)fork; i >= 0; --i) {
-            const Op &op = S.ops[(size_t)i];
-            if (op.kind == OP_POOL) { lo *= 2; hi *= 2; }
-            else if (op.kind == OP_CONV) { lo -= op.ks / 2; hi += op.ks / 2; }
-            lo = std::max(lo, 0); hi = std::min(hi, S.blobs[op.in].H);
-        }
-        B->in0[(size_t)r] = lo / align * align;
-        B->in1[(size_t)r] = std::min(S.H, (hi + align - 1) / align * align);
-    }
-    // what the per-sample part reads of the prefix: the fork pooling's values and every pooling mask
-    auto add = [&](int blob, int level, int elt) {
-        const Blob &b = S.blobs[blob];
-        PrefixBands::Item it2{blob, B->pools - level, elt, b.C, b.H, b.W, B->slot_bytes};
-        if ((b.W * elt) % 16) throw std::invalid_argument("prefix bands: rows of the exchanged blobs must be multiples of 16 bytes");
-        if ((int)B->items.size() >= BAND_ITEMS) throw std::invalid_argument("prefix bands: more poolings in the prefix than the exchange holds");
-        B->slot_bytes += ((size_t)b.C * ((size_t)B->rows_max << it2.shift) * b.W * elt + 255) / 256 * 256;
-        B->items.push_back(it2);
-    };
-    add(S.ops[fork].out, B->pools, 4);
-    int level = 0;
-    for (size_t i = 0; i <= fork; ++i)
-        if (S.ops[i].kind == OP_POOL) add(S.ops[i].out2, ++level, 1);
-    B->net.assign((size_t)world, nullptr);
-    B->op_map.resize((size_t)world);
-    PrefixBands *raw = B.release();
-    S.bands[world] = raw;
-    return *raw;
-}
-
-sivo_segnet &band_net(sivo_segnet &S, PrefixBands &B, int rank) {
-    if (rank < 0 || rank >= B.world) throw std::invalid_argument("prefix bands: rank out of range");
-    if (!B.net[(size_t)rank]) {
-        std::unique_ptr<sivo_segnet> N = build(S.proto, 2, S.prefix_weights.data(), S.prefix_weights.size(), S.device, S.guard_levels_used,
-                                               B.in1[(size_t)rank] - B.in0[(size_t)rank]);
-        if ((int)N->ops.size() != B.fork + 1) throw std::runtime_error("prefix bands: the band handle's plan does not match the prefix");
-        N->h3_flag = S.h3_flag; N->owns_flag = false;
-        for (size_t i = 0; i < N->ops.size(); ++i)
-            for (size_t k = 0; k < S.ops.size(); ++k)
-                if (S.ops[k].name == N->ops[i].name && S.ops[k].kind == N->ops[i].kind) { B.op_map[(size_t)rank].push_back({(int)i, (int)k}); break; }
-        B.net[(size_t)rank] = N.release();
-    }
-    return *B.net[(size_t)rank];
-}
-
-// rank's band of the prefix on stream st -> its slot
-void bands_enqueue(sivo_segnet &S, PrefixBands &B, sivo_segnet &N, const uint8_t *d_bgr, int rank, void *d_slot, hipStream_t st) {
-    const int in0 = B.in0[(size_t)rank], rows = B.in1[(size_t)rank] - in0;
-    launch_preprocess(d_bgr + (size_t)in0 * S.W * 3, (float *)N.blobs[N.input_blob].d, (int64_t)rows * S.W, st);
-    run_ops(N, 0, N.ops.size(), 0, 1, 0, 0, st, 0);
-    BandPack pk{};
-    for (const PrefixBands::Item &it : B.items) {
-        const Blob &full = S.blobs[it.blob];
-        const auto bid = N.blob_id.find(full.name);
-        if (bid == N.blob_id.end()) throw std::runtime_error("prefix bands: blob '" + full.name + "' is missing in the band handle");
-        const Blob &bb = N.blobs[bid->second];
-        const int level = B.pools - it.shift;
-        BandPackItem &q = pk.item[pk.n_items++];
-        q.src = static_cast<const unsigned char *>(bb.d); q.src_H = bb.H;
-        q.row0 = (B.y0[(size_t)rank] << it.shift) - (in0 >> level);
-        q.n_rows = (B.y0[(size_t)rank + 1] - B.y0[(size_t)rank]) << it.shift;
-        q.C = it.C; q.W = it.W; q.elt = it.elt; q.rows_max = B.rows_max << it.shift; q.off = it.off;
-        q.vecs = (int64_t)q.C * q.n_rows * (q.W * q.elt / 16);
-    }
-    launch_pack_bands(pk, d_slot, st);
-}
-
-void bands_run(sivo_segnet &S, const uint8_t *d_bgr, int rank, int world, void *d_slot, hipStream_t st) {
-    h3_absorb(S);               // (as forward(): a flag from an earlier asynchronous frame is acted on before this band reads the scales; the
-                                //  pause it sets covers this band AND the forward that consumes it — one frame, one arithmetic)
-    PrefixBands &B = plan_bands(S, world);
-    sivo_segnet &N = band_net(S, B, rank);
-    // the owner's arithmetic: its calibrated (and possibly backed-off) scales; a frame that is being recomputed runs without f16x3
-    for (const auto &[bi, oi] : B.op_map[(size_t)rank]) {
-        N.ops[(size_t)bi].d3_vscale = S.ops[(size_t)oi].d3_vscale; N.ops[(size_t)bi].h3_vscale = S.ops[(size_t)oi].h3_vscale;
-    }
-    N.h3_on = S.h3_on && !S.h3_pause;
-    // (Replaying the band's ~16 launches from a HIP graph was measured: 0.274 ms either way on one MI355X — the band is bound by its
-    // kernels' own floor, one work item per CU, not by launch overhead — and removed.)
-    bands_enqueue(S, B, N, d_bgr, rank, d_slot, st);
-    SIVO_HIP(hipGetLastError());
-}
-
-void bands_unpack(sivo_segnet &S, const BandInput &pre, int n, int sample0, uint64_t seed, hipStream_t st, size_t *suffix_begin) {
-    PrefixBands &B = plan_bands(S, pre.world);
-    const Op &P = S.ops[(size_t)B.fork];
-    BandUnpack u{};
-    u.world = B.world; u.n = n; u.site = P.drop_site; u.sample0 = sample0; u.seed = seed; u.slot_bytes = B.slot_bytes;
-    for (const PrefixBands::Item &it : B.items) {
-        BandUnpackItem &q = u.item[u.n_items++];
-        // the fork pooling's values: straight into the per-sample blob, through its dropout — unless that dropout moved into the
-        // consumer's input transform (drop_moved): then the blob is the sample-invariant one and the values go in as they are
-        q.drop = (&it == &B.items[0] && !P.drop_moved) ? 1 : 0;
-        q.dst = static_cast<unsigned char *>(S.blobs[it.blob].d);
-        q.C = it.C; q.H = it.H; q.W = it.W; q.elt = it.elt; q.rows_max = B.rows_max << it.shift; q.off = it.off;
-        q.vecs = (int64_t)q.C * q.H * (q.W * q.elt / 16);
-        for (int r = 0; r <= B.world; ++r) q.y0[r] = B.y0[(size_t)r] << it.shift;
-    }
-    launch_unpack_bands(u, pre.slots, st);
-    // the switches re-laid per channel octet for the decoder layers that read packed tensors through an Upsample (run_ops does this
-    // behind the pooling kernel)
-    if (S.pk_on && S.h3_on && !S.calibrating)
-        for (int i = 0; i <= B.fork; ++i) {
-            const Op &op = S.ops[(size_t)i];
-            if (op.kind != OP_POOL || !op.make_bits) continue;
-            const Blob &bm = S.blobs[op.out2], &bi = S.blobs[op.in], &bp = S.blobs[op.out];
-            launch_pool_bits((const uint8_t *)bm.d, bm.d_bits, 1, bi.C, bp.H, bp.W, bm.bits_Hp, bm.bits_Wp, st);
-        }
-    *suffix_begin = (size_t)B.fork + 1;
-}
-
 std::string read_file(const char *path) {
     std::ifstream f(path, std::ios::binary);
     if (!f) throw std::invalid_argument(std::string("cannot open '") + path + "'");
@@ -1654,7 +324,6 @@ std::string read_file(const char *path) {
     ss << f.rdbuf();
     return ss.str();
 }
-
 }  // namespace
 }  // namespace sivo
 
@@ -1704,8 +373,8 @@ void sivo::segnet_fp16_back_off(sivo_segnet_t h, bool already_backed_off) {
 
 using namespace sivo;
 
-extern "C" int sivo_segnet_create_multi(const char *text, size_t len, int t_override, const float *weights, size_t n_weights,
-                                        const int *device_ids, int ndev, sivo_segnet_t *out) {
+extern "C" int sivo_segnet_create_multi_opts(const char *text, size_t len, int t_override, const float *weights, size_t n_weights,
+                                             const int *device_ids, int ndev, const SivoSegnetOptions *opts, sivo_segnet_t *out) {
     return guarded([&] {
         if (!out) throw std::invalid_argument("out is NULL");
         *out = nullptr;
@@ -1717,13 +386,18 @@ extern "C" int sivo_segnet_create_multi(const char *text, size_t len, int t_over
                 return fail(SIVO_ERR_RUNTIME, "HIP device %d is not available (%d visible): libsivo_hip has no CPU fallback", device_ids[d],
                             sivo_device_count());
         std::unique_ptr<sivo_segnet> S(new sivo_segnet);
-        S->multi = segnet_multi_create(text, len, t_override, weights, n_weights, device_ids, ndev);
+        const SivoSegnetOptions opt = segnet_options(opts);
+        S->multi = segnet_multi_create(text, len, t_override, weights, n_weights, device_ids, ndev, &opt);
         int32_t T, H, W, K;
         segnet_multi_shape(S->multi, &T, &H, &W, &K, nullptr);
         S->device = device_ids[0]; S->T = T; S->H = H; S->W = W; S->classes = K;
         *out = S.release();
         return SIVO_OK;
     });
+}
+extern "C" int sivo_segnet_create_multi(const char *text, size_t len, int t_override, const float *weights, size_t n_weights,
+                                        const int *device_ids, int ndev, sivo_segnet_t *out) {
+    return sivo_segnet_create_multi_opts(text, len, t_override, weights, n_weights, device_ids, ndev, nullptr, out);
 }
 
 extern "C" int sivo_segnet_num_devices(sivo_segnet_t h, int *ndev) {
@@ -1742,20 +416,25 @@ extern "C" int sivo_segnet_num_params(const char *text, size_t len, size_t *n_pa
     });
 }
 
-extern "C" int sivo_segnet_create(const char *text, size_t len, int t_override, const float *weights,
-                                  size_t n_weights, int device, sivo_segnet_t *out) {
+extern "C" int sivo_segnet_create_opts(const char *text, size_t len, int t_override, const float *weights, size_t n_weights, int device,
+                                       const SivoSegnetOptions *opts, sivo_segnet_t *out) {
     return guarded([&] {
         if (!out) throw std::invalid_argument("out is NULL");
         *out = nullptr;
         if (!text || !len) throw std::invalid_argument("model_file (.prototxt file) is empty!");
         if (!weights || !n_weights) throw std::invalid_argument("weights_file (.caffemodel file) is empty!");
+        const SivoSegnetOptions opt = segnet_options(opts);
         if (sivo_device_count() <= device || device < 0)
             return fail(SIVO_ERR_RUNTIME, "HIP device %d is not available (%d visible): libsivo_hip has no CPU fallback",
                         device, sivo_device_count());
         ProtoNet net = parse_prototxt(std::string(text, len));
-        *out = build_guarded(net, t_override, weights, n_weights, device).release();
+        *out = build_guarded(net, t_override, weights, n_weights, device, opt).release();
         return SIVO_OK;
     });
+}
+extern "C" int sivo_segnet_create(const char *text, size_t len, int t_override, const float *weights,
+                                  size_t n_weights, int device, sivo_segnet_t *out) {
+    return sivo_segnet_create_opts(text, len, t_override, weights, n_weights, device, nullptr, out);
 }
 
 extern "C" int sivo_caffemodel_weights(const char *prototxt_text, size_t prototxt_len, const void *model_bytes,
@@ -1796,22 +475,30 @@ static std::vector<float> weights_from_file(const char *model_file, const char *
     return w;
 }
 
-extern "C" int sivo_segnet_create_from_files(const char *model_file, const char *weights_file, int t_override,
-                                             int device, sivo_segnet_t *out) {
+extern "C" int sivo_segnet_create_from_files_opts(const char *model_file, const char *weights_file, int t_override, int device,
+                                                  const SivoSegnetOptions *opts, sivo_segnet_t *out) {
     return guarded([&] {
         std::string text;
         const std::vector<float> w = weights_from_file(model_file, weights_file, text);
-        return sivo_segnet_create(text.data(), text.size(), t_override, w.data(), w.size(), device, out);
+        return sivo_segnet_create_opts(text.data(), text.size(), t_override, w.data(), w.size(), device, opts, out);
     });
 }
+extern "C" int sivo_segnet_create_from_files(const char *model_file, const char *weights_file, int t_override,
+                                             int device, sivo_segnet_t *out) {
+    return sivo_segnet_create_from_files_opts(model_file, weights_file, t_override, device, nullptr, out);
+}
 
-extern "C" int sivo_segnet_create_multi_from_files(const char *model_file, const char *weights_file, int t_override,
-                                                   const int *device_ids, int ndev, sivo_segnet_t *out) {
+extern "C" int sivo_segnet_create_multi_from_files_opts(const char *model_file, const char *weights_file, int t_override, const int *device_ids,
+                                                        int ndev, const SivoSegnetOptions *opts, sivo_segnet_t *out) {
     return guarded([&] {
         std::string text;
         const std::vector<float> w = weights_from_file(model_file, weights_file, text);
-        return sivo_segnet_create_multi(text.data(), text.size(), t_override, w.data(), w.size(), device_ids, ndev, out);
+        return sivo_segnet_create_multi_opts(text.data(), text.size(), t_override, w.data(), w.size(), device_ids, ndev, opts, out);
     });
+}
+extern "C" int sivo_segnet_create_multi_from_files(const char *model_file, const char *weights_file, int t_override,
+                                                   const int *device_ids, int ndev, sivo_segnet_t *out) {
+    return sivo_segnet_create_multi_from_files_opts(model_file, weights_file, t_override, device_ids, ndev, nullptr, out);
 }
 
 extern "C" int sivo_segnet_destroy(sivo_segnet_t h) {
@@ -2182,3 +869,4 @@ extern "C" int sivo_segnet_gemm_status(sivo_segnet_t h, int *mode, int *overflow
         return SIVO_OK;
     });
 }
+

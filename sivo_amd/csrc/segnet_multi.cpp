@@ -127,7 +127,7 @@ static void shard(int T, int ndev, int d, int &sample0, int &n) {
 }
 
 SegnetMulti *segnet_multi_create(const char *text, size_t len, int t_total, const float *weights, size_t n_weights,
-                                 const int *device_ids, int ndev) {
+                                 const int *device_ids, int ndev, const SivoSegnetOptions *opts) {
     if (!device_ids || ndev < 1) throw std::invalid_argument("device_ids is empty");
     std::unique_ptr<SegnetMulti> M(new SegnetMulti);
     M->dev.resize((size_t)ndev);
@@ -143,7 +143,7 @@ SegnetMulti *segnet_multi_create(const char *text, size_t len, int t_total, cons
     {
         // the reference's constructor checks apply to the TOTAL sample count (bayesian_segnet.cpp:67-70)
         sivo_segnet_t probe = nullptr;
-        const int rc = sivo_segnet_create(text, len, t_total, weights, n_weights, device_ids[0], &probe);
+        const int rc = sivo_segnet_create_opts(text, len, t_total, weights, n_weights, device_ids[0], opts, &probe);
         if (rc != SIVO_OK) throw std::invalid_argument(sivo_last_error());
         int32_t T, C, H, W, K;
         sivo_segnet_shape(probe, &T, &C, &H, &W, &K);
@@ -159,7 +159,7 @@ SegnetMulti *segnet_multi_create(const char *text, size_t len, int t_total, cons
         MultiDevice &D = M->dev[d];
         shard(M->T, ndev, d, D.sample0, D.n_samples);
         if (!D.net) {
-            const int rc = sivo_segnet_create(text, len, t_alloc, weights, n_weights, D.device, &D.net);
+            const int rc = sivo_segnet_create_opts(text, len, t_alloc, weights, n_weights, D.device, opts, &D.net);
             if (rc != SIVO_OK) throw std::runtime_error(sivo_last_error());
         }
         SIVO_HIP(hipSetDevice(D.device));

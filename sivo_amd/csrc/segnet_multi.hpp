@@ -9,7 +9,7 @@
 namespace sivo {
 struct SegnetMulti;
 SegnetMulti *segnet_multi_create(const char *text, size_t len, int t_total, const float *weights, size_t n_weights,
-                                 const int *device_ids, int ndev);
+                                 const int *device_ids, int ndev, const SivoSegnetOptions *opts);
 void segnet_multi_destroy(SegnetMulti *M);
 void segnet_multi_shape(const SegnetMulti *M, int32_t *T, int32_t *H, int32_t *W, int32_t *classes, int32_t *ndev);
 void segnet_multi_segment(SegnetMulti *M, const uint8_t *bgr, int rows, int cols, uint64_t seed, uint8_t *classes, double *confidence,

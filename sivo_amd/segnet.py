@@ -16,10 +16,33 @@ VOID = 255
 
 
 class BayesianSegNetParams:
-    """bayesian_segnet.hpp:85-105."""
+    """bayesian_segnet.hpp:85-105, plus how the handle runs (SivoSegnetOptions of include/sivo_hip.h; None = the library's default)."""
 
-    def __init__(self, model_file="", weights_file="", use_gpu=True):
+    def __init__(self, model_file="", weights_file="", use_gpu=True, **options):
         self.model_file, self.weights_file, self.use_gpu = model_file, weights_file, use_gpu
+        self.options = dict(options)
+
+
+_GEMM = {"f16x3": 0, "": 0, "x6": 1, "bf16x6": 1, "f32": 2, "fp32": 2}
+
+
+def segnet_options(lanes=None, gemm=None, direct_f16x3=None, packed_activations=None, conv7=None, wino4_workspace_mb=None, debug_sync=None):
+    """SivoSegnetOptions from keyword arguments.  The LIBRARY reads no environment variable; for the tests, tools and bench.py this
+    Python wrapper takes an argument left at None from the environment of the process, under the names the library used to read until
+    round 5: SIVO_LANES=1..4, SIVO_GEMM=x6|f32, SIVO_D3=0, SIVO_D3_PK=0, SIVO_CONV7=f32, SIVO_WINO4_MB, SIVO_DEBUG_SYNC=1."""
+    import os
+    env = os.environ.get
+    o = _lib.SegnetOptions()
+    o.struct_size = C.sizeof(_lib.SegnetOptions)
+    o.lanes = int(lanes if lanes is not None else env("SIVO_LANES", "0"))
+    g = gemm if gemm is not None else env("SIVO_GEMM", "")
+    o.gemm = _GEMM[g] if isinstance(g, str) else int(g)
+    o.no_direct_f16x3 = int(not direct_f16x3) if direct_f16x3 is not None else int(env("SIVO_D3", "1") == "0")
+    o.no_packed_activations = int(not packed_activations) if packed_activations is not None else int(env("SIVO_D3_PK", "1") == "0")
+    o.conv7_fp32 = int(conv7 in ("f32", "fp32")) if conv7 is not None else int(env("SIVO_CONV7", "") == "f32")
+    o.wino4_workspace_mb = int(wino4_workspace_mb if wino4_workspace_mb is not None else env("SIVO_WINO4_MB", "0"))
+    o.debug_sync = int(bool(debug_sync)) if debug_sync is not None else int(env("SIVO_DEBUG_SYNC") is not None)
+    return o
 
 
 def _stream():
@@ -29,10 +52,14 @@ def _stream():
 class BayesianSegNet:
     """Constructor from a params object (files) like the reference, or from prototxt text + flat weights."""
 
-    def __init__(self, params=None, prototxt=None, weights=None, T=0, device=0, devices=None):
+    def __init__(self, params=None, prototxt=None, weights=None, T=0, device=0, devices=None, **options):
         """devices: list of HIP device ids -> the T samples of a frame are spread over them inside the handle
-        (sivo_segnet_create_multi: RCCL reduce-scatter / all-gather); only segment_image works on such a handle."""
+        (sivo_segnet_create_multi: RCCL reduce-scatter / all-gather); only segment_image works on such a handle.
+        options: segnet_options() keywords (lanes, gemm, direct_f16x3, packed_activations, conv7, wino4_workspace_mb, debug_sync)."""
         h = C.c_void_p()
+        opt = segnet_options(**dict(getattr(params, "options", {}) or {}, **options))
+        self.options = opt
+        po = C.byref(opt)
         self._L = lib()          # the library this object lives in (product, or the diagnostic build inside `with _lib.use("diag")`)
         self.devices = list(devices) if devices is not None else None
         if params is not None:
@@ -44,22 +71,22 @@ class BayesianSegNet:
                 raise _lib.SivoError(_lib.ERR_UNSUPPORTED, "use_gpu=false: this library has no CPU path")
             if self.devices is not None:
                 ids = (C.c_int32 * len(self.devices))(*self.devices)
-                rc = self._L.sivo_segnet_create_multi_from_files(params.model_file.encode(), params.weights_file.encode(), T,
-                                                               ids, len(self.devices), C.byref(h))
+                rc = self._L.sivo_segnet_create_multi_from_files_opts(params.model_file.encode(), params.weights_file.encode(), T,
+                                                                    ids, len(self.devices), po, C.byref(h))
                 device = self.devices[0] if self.devices else 0
             else:
-                rc = self._L.sivo_segnet_create_from_files(params.model_file.encode(), params.weights_file.encode(), T,
-                                                         device, C.byref(h))
+                rc = self._L.sivo_segnet_create_from_files_opts(params.model_file.encode(), params.weights_file.encode(), T,
+                                                              device, po, C.byref(h))
         elif self.devices is not None:
             text = prototxt.encode() if isinstance(prototxt, str) else (prototxt or b"")
             w = np.ascontiguousarray(weights if weights is not None else np.zeros(0), np.float32)
             ids = (C.c_int32 * len(self.devices))(*self.devices)
-            rc = self._L.sivo_segnet_create_multi(text, len(text), T, w.ctypes.data_as(C.c_void_p), w.size, ids, len(self.devices), C.byref(h))
+            rc = self._L.sivo_segnet_create_multi_opts(text, len(text), T, w.ctypes.data_as(C.c_void_p), w.size, ids, len(self.devices), po, C.byref(h))
             device = self.devices[0] if self.devices else 0
         else:
             text = prototxt.encode() if isinstance(prototxt, str) else (prototxt or b"")
             w = np.ascontiguousarray(weights if weights is not None else np.zeros(0), np.float32)
-            rc = self._L.sivo_segnet_create(text, len(text), T, w.ctypes.data_as(C.c_void_p), w.size, device, C.byref(h))
+            rc = self._L.sivo_segnet_create_opts(text, len(text), T, w.ctypes.data_as(C.c_void_p), w.size, device, po, C.byref(h))
         if rc == _lib.ERR_INVALID_ARGUMENT:
             raise ValueError(self._L.sivo_last_error().decode())                     # std::invalid_argument
         check(rc)

@@ -9,8 +9,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_addoption(parser):
+    parser.addoption("--runslow", action="store_true", default=False, help="also run the tests marked slow (or SIVO_RUN_SLOW=1)")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: further cases of a test family whose first cases run by default (full-size seeds, margin sweep, "
+                                       "8-device emulation): deselected unless --runslow / SIVO_RUN_SLOW=1, so that `-m gpu` stays well inside the driver's limit")
+
+
+def pytest_collection_modifyitems(config, items):
+    if config.getoption("--runslow") or os.environ.get("SIVO_RUN_SLOW") == "1":
+        return
+    slow = [it for it in items if it.get_closest_marker("slow")]
+    if slow:
+        items[:] = [it for it in items if not it.get_closest_marker("slow")]
+        config.hook.pytest_deselected(items=slow)
 
 
 @pytest.fixture(scope="session")

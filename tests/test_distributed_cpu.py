@@ -33,7 +33,7 @@ def test_shard_samples_partition():
 
 def test_bench_launches_its_own_ranks_when_started_plainly():
     """`python bench.py --gpus 2` without torch.distributed.run around it (how the driver starts it) must become a 2-rank job.  There is no
-    GPU here and bench.py has no CPU path: both ranks must come up, see their RANK / WORLD_SIZE and stop at the device check."""
+    GPU here and bench.py has no CPU path: the ranks must come up, see their RANK and a WORLD_SIZE of 2 and stop at the device check."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -47,7 +47,9 @@ def test_bench_launches_its_own_ranks_when_started_plainly():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0
-    assert "rank 0 of 2: no HIP device visible" in out.stderr and "rank 1 of 2: no HIP device visible" in out.stderr, out.stderr[-3000:]
+    import re
+    # (the launcher ends the job when the first rank fails: the other one may not get to its own message)
+    assert re.search(r"bench\.py rank [01] of 2: no HIP device visible", out.stderr), out.stderr[-3000:]
 
 
 def _free_port():

@@ -65,11 +65,11 @@ def test_bench_started_plainly_with_two_gpus_launches_two_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(SIVO_BENCH_SHARE_GPU="1", SIVO_BENCH_BACKEND="gloo")
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--T", "4", "--height", "176", "--width", "512"],
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--T", "4", "--height", "160", "--width", "512"],
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and line["config"]["samples_per_rank"] == [2, 2]
-    assert line["multi_gpu"]["allreduce_bytes"] == 15 * 176 * 512 * 4
+    assert line["multi_gpu"]["allreduce_bytes"] == 15 * 160 * 512 * 4

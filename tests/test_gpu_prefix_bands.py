@@ -67,7 +67,7 @@ def test_banded_prefix_is_bit_identical_at_full_size(kind, worlds, kitti_like_bg
     assert not sn.take_overflow()
 
 
-@pytest.mark.parametrize("ndev,T", [(2, 4), (4, 6), (8, 12)])
+@pytest.mark.parametrize("ndev,T", [(2, 4), (4, 6), pytest.param(8, 12, marks=pytest.mark.slow)])
 def test_multi_device_handle_splits_its_prefix(ndev, T, kitti_like_bgr):
     """sivo_segnet_create_multi (emulated collectives on one GPU): the handle computes the prefix in ndev row bands + one all-gather
     of the slots.  Same maps as the same handle recomputing the prefix on every device (SIVO_MULTI_BANDS=0), bit for bit, and as
@@ -111,8 +111,16 @@ def test_multi_device_handle_recomputes_a_frame_whose_band_left_the_fp16_range(k
         plain = BayesianSegNet(prototxt=text, weights=flat, T=T, devices=[0] * ndev)
     got = boosted.segment_image(img, seed=3)                 # overflows in the band already; recomputed before the call returns
     want = x6.segment_image(img, seed=3)
+    ref = plain.segment_image(img, seed=3)
     assert all(np.isfinite(g).all() for g in got[1:])
-    assert all(np.array_equal(a, b) for a, b in zip(got, want))          # = the frame of a handle that never uses f16x3
+    # the recomputed frame ran without f16x3 on every device (band and samples): the maps of a handle that never uses f16x3, up to the
+    # fp32 kernels' own rounding (the paused handle and the x6 handle need not pick the same fp32 kernel for every narrow layer) ...
+    assert (got[0] != want[0]).mean() < 2e-3
+    np.testing.assert_allclose(got[1], want[1], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(got[2], want[2], atol=2e-3, rtol=0)
+    # ... and those of the unboosted f16x3 handle up to the split's rounding
+    assert (got[0] != ref[0]).mean() < 2e-3
+    np.testing.assert_allclose(got[1], ref[1], atol=1e-4, rtol=0)
     # the next frame runs f16x3 again, on scales lowered ONCE on every device (2^7 times the calibrated ones: in range): no recomputation,
     # and the maps are those of an unboosted handle up to the split's rounding
     got2 = boosted.segment_image(img, seed=4)

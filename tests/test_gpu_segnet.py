@@ -22,7 +22,8 @@ LOGIT_TOL = 1e-3
 
 # The product library reads eight environment switches; every A/B or fault-injection switch exists in the
 # diagnostic build only (libsivo_hip_diag.so: the same sources compiled with -DSIVO_DIAG).  Objects created inside the block live there.
-_PRODUCT_SWITCHES = {"SIVO_LANES", "SIVO_GEMM", "SIVO_D3", "SIVO_D3_PK", "SIVO_CONV7", "SIVO_WINO4_MB", "SIVO_ORB_PRIO", "SIVO_DEBUG_SYNC"}
+# (handle options the Python wrapper takes from the environment: sivo_amd/segnet.py segnet_options; anything else is a diagnostic-build switch)
+_PRODUCT_SWITCHES = {"SIVO_LANES", "SIVO_GEMM", "SIVO_D3", "SIVO_D3_PK", "SIVO_CONV7", "SIVO_WINO4_MB", "SIVO_DEBUG_SYNC"}
 
 
 @contextlib.contextmanager

@@ -283,18 +283,31 @@ def test_abi_exports_every_declared_symbol():
     assert "sivo_debug_" not in exported
 
 
-def test_product_library_reads_eight_documented_switches():
-    """Every A/B, ablation and fault-injection switch lives behind SIVO_DIAG_ENV (sivo_amd/csrc/common.hpp) and exists in
-    libsivo_hip_diag.so only; the product binary does not even contain their names."""
+def test_product_library_reads_no_environment_switch():
+    """The library is configured through SivoSegnetOptions at construction (include/sivo_hip.h); every A/B, ablation and fault-injection
+    switch lives behind SIVO_DIAG_ENV (sivo_amd/csrc/common.hpp) and exists in libsivo_hip_diag.so only.  The product binary does not
+    contain the name of a single SIVO_ variable; the Python wrapper (sivo_amd/segnet.py segnet_options) maps the old names onto options."""
     import subprocess
-    names = sorted(set(l.strip() for l in subprocess.run(["strings", _lib.LIB_PATH], capture_output=True, text=True).stdout.splitlines() if "SIVO_" in l))
-    assert names == ["SIVO_CONV7", "SIVO_D3", "SIVO_D3_PK", "SIVO_DEBUG_SYNC", "SIVO_GEMM", "SIVO_LANES", "SIVO_ORB_PRIO", "SIVO_WINO4_MB"], names
+    names = sorted(set(l.strip() for l in subprocess.run(["strings", _lib.LIB_PATH], capture_output=True, text=True).stdout.splitlines() if re.fullmatch(r"SIVO_[A-Z0-9_]+", l.strip())))
+    assert names == [], names
     diag = subprocess.run(["strings", _lib.DIAG_PATH], capture_output=True, text=True).stdout
-    for name in ("SIVO_H3_BOOST", "SIVO_MULTI_EMULATE", "SIVO_NO_FUSE_BRIDGE", "SIVO_D3_FORM", "SIVO_D3_ABL"):
+    for name in ("SIVO_H3_BOOST", "SIVO_MULTI_EMULATE", "SIVO_NO_FUSE_BRIDGE", "SIVO_D3_FORM", "SIVO_D3_ABL", "SIVO_ORB_PRIO"):
         assert name in diag, name
-    design = open(os.path.join(ROOT, "DESIGN.md")).read()
-    for name in names:
-        assert name in design, name
+    from sivo_amd.segnet import segnet_options
+    old = {k: os.environ.pop(k, None) for k in ("SIVO_LANES", "SIVO_GEMM", "SIVO_D3", "SIVO_D3_PK", "SIVO_CONV7", "SIVO_WINO4_MB", "SIVO_DEBUG_SYNC")}
+    try:
+        d = segnet_options()
+        assert (d.struct_size, d.lanes, d.gemm, d.no_direct_f16x3, d.no_packed_activations, d.conv7_fp32, d.wino4_workspace_mb, d.debug_sync) == (32, 0, 0, 0, 0, 0, 0, 0)
+        os.environ.update(SIVO_LANES="3", SIVO_GEMM="x6", SIVO_D3="0", SIVO_D3_PK="0", SIVO_CONV7="f32", SIVO_WINO4_MB="512", SIVO_DEBUG_SYNC="1")
+        e = segnet_options()
+        assert (e.lanes, e.gemm, e.no_direct_f16x3, e.no_packed_activations, e.conv7_fp32, e.wino4_workspace_mb, e.debug_sync) == (3, 1, 1, 1, 1, 512, 1)
+        k = segnet_options(lanes=1, gemm="f32", direct_f16x3=True, packed_activations=True, conv7="h3", wino4_workspace_mb=64, debug_sync=False)
+        assert (k.lanes, k.gemm, k.no_direct_f16x3, k.no_packed_activations, k.conv7_fp32, k.wino4_workspace_mb, k.debug_sync) == (1, 2, 0, 0, 0, 64, 0)
+    finally:
+        for name, v in old.items():
+            os.environ.pop(name, None)
+            if v is not None:
+                os.environ[name] = v
 
 
 def test_struct_layouts_match_reference_types():

@@ -86,7 +86,7 @@ def test_reference_constructor_exceptions_match_this_library():
     for args, msg in expect:
         assert lib.ref_segnet_construct(*args, what, 200) == 1 and what.value == msg
     assert lib.ref_segnet_construct(b"m", b"w", 2, 3, what, 200) == 0
-    src = open(os.path.join(ROOT, "sivo_amd", "csrc", "segnet.cpp")).read()
+    src = "".join(open(os.path.join(ROOT, "sivo_amd", "csrc", f)).read() for f in ("segnet.cpp", "segnet_plan.cpp"))      # (C ABI checks / plan construction)
     for _, msg in expect:
         assert msg.decode() in src, msg
 
