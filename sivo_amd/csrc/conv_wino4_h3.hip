@@ -81,7 +81,14 @@ __device__ __forceinline__ void h3_dma16(const void *sbase, uint32_t voff, uint3
 // ahead of its loads, so that they have a whole stage to drain and never stand between a wait and the loads it leaves in flight.
 // ABL (diagnostic builds only, -DSIVO_DIAG -> libsivo_hip_diag.so, tools/h3_probe.py; results are wrong by construction):
 // 1 no V' loads after the prologue, 2 no U' DMA after the prologue, 4 no M stores, 8 no MFMAs.
-template <int BM, int BN, int ABL = 0>
+// FORM 1 (round 6, the product's): the memory side of a stage is issued INSIDE its multiply phase.  In the phased form (FORM 0, kept for
+// A/B in the diagnostic build) every wave did, behind the barrier, registers -> LDS (16 v_perm, 4 ds_write_b128), 16 buffer loads, 4 LDS-DMA
+// (each with its M0 save / restore) and only then its first fragment reads — all eight waves at once, so the matrix cores of the CU stood
+// idle for that head of every stage (the ablations' "stage = MFMA time + ingest time").  Now: barrier -> fragment reads of k-step 0 ->
+// registers -> LDS under the reads' latency -> MFMA, two loads, MFMA, two loads ... MFMA, DMA ...; the loads and DMA are issued
+// unconditionally (the cursors clamp at the last item: the last three stages fetch bytes nobody consumes) so that the hot path has no
+// branch around a filler and the wait at the top is always vmcnt(NV + NU).  Same MFMAs in the same order per accumulator: M bit-identical.
+template <int BM, int BN, int ABL = 0, int FORM = 1>
 __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_h3[];
     constexpr int WC = BN / 64, WT = 8 / WC;                     // wave grid: couts (64 per wave) x tiles
@@ -222,6 +229,19 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         clear_acc();
     };
 
+    // one load / one DMA piece at a time (FORM 1 spreads them over the MFMAs of k-step 0)
+    auto load_v_one = [&](const Cursor &c, VSet &r, const int q, const int e) __attribute__((always_inline)) {
+        const uint64_t base = (uint64_t)(uintptr_t)(a.V + (int64_t)c.xi * a.C * a.Pp);
+        const i32x4 rs = {(int)(uint32_t)base, (int)(uint32_t)((base >> 32) & 0xffffu), (int)v_slab_bytes, 0x00020000};
+        const uint32_t vo = v_lane_off + (uint32_t)c.pt * (BM * 4);
+        const uint32_t so = (uint32_t)((int64_t)(c.chunk * H3_KC + 16 * q + e) * a.Pp * 4);
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=&v"(r[q][e]) : "v"(vo), "s"(rs), "s"(so) : "memory");
+    };
+    auto dma_u_one = [&](const Cursor &c, int ubuf, const int j) __attribute__((always_inline)) {
+        const unsigned char *sb = a.U + ((int64_t)(c.xi * (a.Kp / 32) + c.kt * (BN / 32)) * nst + c.chunk) * 4096;
+        h3_dma16(sb, u_voff[j], lds_base + U0 + ubuf * UBYTES + (wave * NU + j) * 1024);
+    };
+
     Cursor cc, cu, cv;          // compute; U' DMA (two stages ahead); V' loads (three stages ahead)
     locate(cc);
     cu = cc; cv = cc;
@@ -296,9 +316,90 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
             if (++cc.k < my_items) locate(cc);
         }
     };
-    for (int s = 0; s < total; s += 2) {
-        iteration(s, vB);
-        if (s + 1 < total) iteration(s + 1, vA);
+    // FORM 1: see the comment above the kernel
+    auto iteration1 = [&](const int s, VSet &r) __attribute__((always_inline)) {
+        // all but the NV + NU operations of the previous iteration have landed: U'(s), and V'(s + 1) in r; this wave's V'(s) pieces are written
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NV + NU) : "memory");
+        landed(r);
+        if (pend) { store_item(pxi, ppt, pkt); pend = false; }
+        const unsigned char *vs = lds_h3 + (s & 1) * VBYTES, *us = lds_h3 + U0 + ub_cur * UBYTES;
+        const int ub_fill = ub_next2;
+        ub_cur = ub_cur == 2 ? 0 : ub_cur + 1;
+        ub_next2 = ub_next2 == 2 ? 0 : ub_next2 + 1;
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};            // smallest terms first: (lo, hi) (hi, lo) (hi, hi)
+        {
+            half8 A[2][2], B[TB][2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) A[c][pl] = *reinterpret_cast<const half8 *>(us + a_off + c * 4096 + pl * 2048);
+#pragma unroll
+            for (int t = 0; t < TB; ++t)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) B[t][pl] = *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048);
+            write_v((s + 1) & 1, r);                 // V'(s + 1): registers -> LDS, under the latency of the fragment reads
+            __builtin_amdgcn_sched_barrier(0);
+            int slot = 0;
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int t = 0; t < TB; ++t) {
+                        if (ABL & 8) acc[c][t][term] += (float)A[c][PA[term]][0] + (float)B[t][PB[term]][1];
+                        else acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][PA[term]], B[t][PB[term]], acc[c][t], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        // fillers behind MFMA number `slot` of the k-step: first the NV loads of V'(s + 3), two per slot, then the NU DMA pieces of U'(s + 2)
+                        if (slot < NV / 2) {
+                            if (!(ABL & 1)) { load_v_one(cv, r, (2 * slot) / 8, (2 * slot) % 8); load_v_one(cv, r, (2 * slot + 1) / 8, (2 * slot + 1) % 8); }
+                        } else if (slot < NV / 2 + NU) {
+                            if (!(ABL & 2)) dma_u_one(cu, ub_fill, slot - NV / 2);
+                        }
+                        if (slot < NV / 2 + NU) __builtin_amdgcn_sched_barrier(0);
+                        ++slot;
+                    }
+            static_assert(NV / 2 + NU <= 6 * TB, "more fillers than MFMAs in a k-step");
+        }
+        advance(cv);
+        advance(cu);
+        {
+            half8 A[2][2], B[TB][2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) A[c][pl] = *reinterpret_cast<const half8 *>(us + a_off + c * 4096 + pl * 2048 + 1024);
+#pragma unroll
+            for (int t = 0; t < TB; ++t)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) B[t][pl] = *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048 + 1024);
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int t = 0; t < TB; ++t) {
+                        if (ABL & 8) acc[c][t][term] += (float)A[c][PA[term]][0] + (float)B[t][PB[term]][1];
+                        else acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][PA[term]], B[t][PB[term]], acc[c][t], 0, 0, 0);
+                    }
+        }
+        if (++cc.chunk == nst) {
+            pend = true; pxi = cc.xi; ppt = cc.pt; pkt = cc.kt;
+            cc.chunk = 0;
+            if (++cc.k < my_items) locate(cc);
+        }
+    };
+    if (FORM == 1) {
+        for (int s = 0; s < total; s += 2) {
+            iteration1(s, vB);
+            if (s + 1 < total) iteration1(s + 1, vA);
+        }
+        // the last stages issued loads and DMA nobody consumes: they must have landed before the LDS goes to the next workgroup
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        for (int s = 0; s < total; s += 2) {
+            iteration(s, vB);
+            if (s + 1 < total) iteration(s + 1, vA);
+        }
     }
     if (pend) store_item(pxi, ppt, pkt);
 }
@@ -407,6 +508,18 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
     }
 #endif
     lds_claim_note(LDS_CLAIM_GEMM_H3, lds);
+#ifdef SIVO_DIAG
+    if (const char *f = SIVO_DIAG_ENV("SIVO_H3_FORM"); f && std::atoi(f) == 0) {          // diagnostic build: the phased form of round 3 - 5, for A/B
+        static int attr0[64] = {0};
+        if (FirstUse once(attr0); once)
+            for (const void *fn : {(const void *)wino4_gemm_h3_kernel<256, 256, 0, 0>, (const void *)wino4_gemm_h3_kernel<128, 256, 0, 0>, (const void *)wino4_gemm_h3_kernel<256, 128, 0, 0>})
+                SIVO_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (t.bm == 256 && t.bn == 256) hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, 0, 0>), grid, dim3(512), lds, s, a);
+        else if (t.bm == 128 && t.bn == 256) hipLaunchKernelGGL((wino4_gemm_h3_kernel<128, 256, 0, 0>), grid, dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 128, 0, 0>), grid, dim3(512), lds, s, a);
+        return;
+    }
+#endif
     if (t.bm == 256 && t.bn == 256) hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256>), grid, dim3(512), lds, s, a);
     else if (t.bm == 128 && t.bn == 256) hipLaunchKernelGGL((wino4_gemm_h3_kernel<128, 256>), grid, dim3(512), lds, s, a);
     else hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 128>), grid, dim3(512), lds, s, a);

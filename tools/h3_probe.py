@@ -15,7 +15,7 @@ lib.sivo_last_error.restype = C.c_char_p
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 SHAPES = [("conv4_2  512->512 44x128", 512, 512, 4224), ("conv5_2  512->512 22x64", 512, 512, 1152),
           ("conv3_3D 256->256 88x256", 256, 256, 16896), ("conv4_1D 512->256 44x128", 512, 256, 4224)]
-VARIANTS = [("as built", {}), ("no V loads", {"SIVO_H3_ABL": "1"}), ("no U DMA", {"SIVO_H3_ABL": "2"}),
+VARIANTS = [("as built", {}), ("phased form (round 5)", {"SIVO_H3_FORM": "0"}), ("no V loads", {"SIVO_H3_ABL": "1"}), ("no U DMA", {"SIVO_H3_ABL": "2"}),
             ("no loads at all", {"SIVO_H3_ABL": "3"}), ("no M stores", {"SIVO_H3_ABL": "4"}), ("MFMA + LDS only", {"SIVO_H3_ABL": "7"}),
             ("no MFMA", {"SIVO_H3_ABL": "8"}), ("no MFMA, no stores", {"SIVO_H3_ABL": "12"})]
 rng = np.random.default_rng(0)
@@ -28,7 +28,7 @@ for name, Cc, Kp, P in SHAPES:
     for vname, env in VARIANTS:
         if "SIVO_H3_TILE" in env:
             continue                              # (static in the launcher: run the script again with SIVO_H3_TILE=2 for that column)
-        for k in ("SIVO_H3_ABL",):
+        for k in ("SIVO_H3_ABL", "SIVO_H3_FORM"):
             os.environ.pop(k, None)
         os.environ.update(env)
         ms = C.c_double(0)
