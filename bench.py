@@ -59,11 +59,27 @@ def make_inputs(H, W):
     return np.ascontiguousarray(bgr), left, right
 
 
+def host_cpus():
+    """(CPUs this process may use, OpenMP threads for the CPU baseline).  os.cpu_count() is the machine's (256 hardware threads on the GPU
+    box); the container's cgroup grants a CPU-time quota (cpu.max: 16 CPUs there) — with 256 runnable threads on 16 CPUs' worth of time
+    the OpenMP loops ran at 57 GFLOP/s where 32 threads reach 1671 (tools/cpu_threads_probe.py, profiles/r06_cpu_threads.log)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n, min(len(os.sched_getaffinity(0)), 2 * n if n < len(os.sched_getaffinity(0)) else n)
+
+
 def cpu_baseline(kind, T, H, W, text, w, bgr, left, right, budget_note):
     """Two CPU figures on the host cores, about 30 s of CPU work at the full geometry.  value_dedup: the oracle — prefix once + up to FOUR
     of the T MC samples of the suffix (their mean, x T) + ORB pair + MC reduction of 2 samples (x T / 2).  value: the reference-equivalent
     figure — T full forwards with im2col + SGEMM convolutions (below)."""
     from oracle import oracle as O, prototxt as oproto
+    cores, threads = host_cpus()
+    O.lib().omp_set_num_threads(threads)          # (libgomp, through liboracle.so)
     net = oproto.parse(text)
     net["shape"][0] = 1
     first_drop = next(i for i, L in enumerate(net["layers"]) if L["type"] == "Dropout")
@@ -122,12 +138,11 @@ def cpu_baseline(kind, T, H, W, text, w, bgr, left, right, budget_note):
         ts.append(time.perf_counter() - t0)
     t_fwd = float(np.mean(ts))
     frame_ref = T * t_fwd + t_mc + t_orb
-    cores = os.cpu_count()
-    return {"value": 1.0 / frame_ref, "value_dedup": 1.0 / frame_dedup, "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": 1.0 / frame_ref, "value_dedup": 1.0 / frame_dedup, "unit": "frames/s", "cores": cores, "threads": threads, "machine_hardware_threads": os.cpu_count(), "kind": "port",
             "samples_measured": len(ts), "samples_extrapolated": T - len(ts), "samples_measured_dedup": K, "samples_extrapolated_dedup": T - K,
             "sample": (f"value = reference-equivalent: {T} full forwards (no prefix de-duplication, as the reference runs its T batch slots), convolutions as im2col + blocked FMA SGEMM "
-                       f"per image (what Caffe-CPU does; C, OpenMP over {cores} cores): {len(ts)} of {T} forwards measured, {t_fwd:.2f}s each (x{T}) + MC reduction {t_mc:.2f}s + ORB stereo pair "
-                       f"and matching {t_orb:.2f}s on {kind} {H}x{W}.  value_dedup = the CPU oracle itself (plain C loop nests, OpenMP over {cores} cores, fp32 chain order; a restatement "
+                       f"per image (what Caffe-CPU does; C, {threads} OpenMP threads on the {cores} CPUs the container's cgroup grants this process): {len(ts)} of {T} forwards measured, {t_fwd:.2f}s each (x{T}) + MC reduction {t_mc:.2f}s + ORB stereo pair "
+                       f"and matching {t_orb:.2f}s on {kind} {H}x{W}.  value_dedup = the CPU oracle itself (plain C loop nests, the same {threads} threads, fp32 chain order; a restatement "
                        f"of the reference path, not Caffe/OpenCV) WITH the prefix computed once: prefix {t_prefix:.2f}s + {K} of {T} MC samples of the suffix measured, {t_suffix:.2f}s each (x{T}) "
                        "+ the same MC reduction and ORB times")}
 

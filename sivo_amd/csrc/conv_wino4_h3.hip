@@ -59,6 +59,7 @@ struct H3Args {
     float *M;                // [36][Kp][Pp]
     int C, Kp, P, Pp;
     int ptiles, ktiles;      // tile groups (BM) and cout groups (BN) of the launch
+    uint32_t *stamps;        // diagnostic build, ABL & 64: per-wave cycle sums (see the kernel); null otherwise
 };
 
 // LDS-DMA with a scalar base: lane l copies the 16 bytes at sbase + voff to LDS address lds_byte_addr + 16 l.
@@ -317,9 +318,19 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         }
     };
     // FORM 1: see the comment above the kernel
+    auto stamp = [&]() __attribute__((always_inline)) -> uint32_t {
+        uint64_t t = 0;
+        if (ABL & 64) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return (uint32_t)t;
+    };
+    uint32_t st_wait = 0, st_k0 = 0, st_k1 = 0;
+    half8 FA[2][2][2], FB[2][TB][2];            // fragments [k-step][block][plane] (kernel scope for ABL & 16; per-iteration temporaries otherwise)
     auto iteration1 = [&](const int s, VSet &r) __attribute__((always_inline)) {
         // all but the NV + NU operations of the previous iteration have landed: U'(s), and V'(s + 1) in r; this wave's V'(s) pieces are written
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NV + NU) : "memory");
+        const uint32_t t0 = stamp();
+        if (ABL & 32) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NV + NU) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NV + NU) : "memory");
+        const uint32_t t1 = stamp();
         landed(r);
         if (pend) { store_item(pxi, ppt, pkt); pend = false; }
         const unsigned char *vs = lds_h3 + (s & 1) * VBYTES, *us = lds_h3 + U0 + ub_cur * UBYTES;
@@ -328,15 +339,17 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         ub_next2 = ub_next2 == 2 ? 0 : ub_next2 + 1;
         constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};            // smallest terms first: (lo, hi) (hi, lo) (hi, hi)
         {
-            half8 A[2][2], B[TB][2];
+            auto &A = FA[0]; auto &B = FB[0];
+            if (!(ABL & 16) || s == 0) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) A[c][pl] = *reinterpret_cast<const half8 *>(us + a_off + c * 4096 + pl * 2048);
+                    for (int pl = 0; pl < 2; ++pl) A[c][pl] = *reinterpret_cast<const half8 *>(us + a_off + c * 4096 + pl * 2048);
 #pragma unroll
-            for (int t = 0; t < TB; ++t)
+                for (int t = 0; t < TB; ++t)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) B[t][pl] = *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048);
+                    for (int pl = 0; pl < 2; ++pl) B[t][pl] = *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048);
+            }
             write_v((s + 1) & 1, r);                 // V'(s + 1): registers -> LDS, under the latency of the fragment reads
             __builtin_amdgcn_sched_barrier(0);
             int slot = 0;
@@ -362,16 +375,19 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         }
         advance(cv);
         advance(cu);
+        const uint32_t t2 = stamp();
         {
-            half8 A[2][2], B[TB][2];
+            auto &A = FA[1]; auto &B = FB[1];
+            if (!(ABL & 16) || s == 0) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) A[c][pl] = *reinterpret_cast<const half8 *>(us + a_off + c * 4096 + pl * 2048 + 1024);
+                    for (int pl = 0; pl < 2; ++pl) A[c][pl] = *reinterpret_cast<const half8 *>(us + a_off + c * 4096 + pl * 2048 + 1024);
 #pragma unroll
-            for (int t = 0; t < TB; ++t)
+                for (int t = 0; t < TB; ++t)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) B[t][pl] = *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048 + 1024);
+                    for (int pl = 0; pl < 2; ++pl) B[t][pl] = *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048 + 1024);
+            }
 #pragma unroll
             for (int term = 0; term < 3; ++term)
 #pragma unroll
@@ -382,6 +398,10 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
                         else acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][PA[term]], B[t][PB[term]], acc[c][t], 0, 0, 0);
                     }
         }
+        if (ABL & 64) {
+            const uint32_t t3 = stamp();
+            st_wait += (t1 - t0) & 0xfffffu; st_k0 += (t2 - t1) & 0xfffffu; st_k1 += (t3 - t2) & 0xfffffu;
+        }
         if (++cc.chunk == nst) {
             pend = true; pxi = cc.xi; ppt = cc.pt; pkt = cc.kt;
             cc.chunk = 0;
@@ -389,9 +409,19 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         }
     };
     if (FORM == 1) {
+        uint64_t rt0 = 0, rt1 = 0;
+        if (ABL & 64) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
+        const uint32_t tb = stamp();
         for (int s = 0; s < total; s += 2) {
             iteration1(s, vB);
             if (s + 1 < total) iteration1(s + 1, vA);
+        }
+        if ((ABL & 64) && a.stamps && lane == 0) {
+            const uint32_t te = stamp();
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
+            atomicAdd(a.stamps + 0, st_wait >> 4); atomicAdd(a.stamps + 1, st_k0 >> 4); atomicAdd(a.stamps + 2, st_k1 >> 4);
+            atomicAdd(a.stamps + 3, ((te - tb) & 0xfffffffu) >> 4); atomicAdd(a.stamps + 4, (uint32_t)(rt1 - rt0));
+            atomicAdd(a.stamps + 5, 1u); atomicAdd(a.stamps + 6, (uint32_t)total);
         }
         // the last stages issued loads and DMA nobody consumes: they must have landed before the LDS goes to the next workgroup
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -468,6 +498,15 @@ static H3Tile h3_tile(int64_t P, int Kp) {
     return {items_big >= 3 * 256 ? 256 : 128, 256};
 }
 
+#ifdef SIVO_DIAG
+// diagnostic build: 8 words of device memory the stamped ablations (ABL & 64) sum into; read and cleared by sivo_debug_h3_stamps
+uint32_t *h3_stamps() {
+    static uint32_t *d = nullptr;
+    if (!d) { SIVO_HIP(hipMalloc((void **)&d, 8 * sizeof(uint32_t))); SIVO_HIP(hipMemset(d, 0, 8 * sizeof(uint32_t))); }
+    return d;
+}
+#endif
+
 void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int Kp, int P, int Pp, hipStream_t s) {
     // The persistent workgroup claims the CU's whole LDS (160 KB) whatever its five stage buffers need (112 - 160 KB): with
     // the exact size (96 - 128 KB in the first form of the kernel) another lane's small-LDS workgroups (wino4_bridge_kernel:
@@ -500,8 +539,10 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
         SIVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_gemm_h3_kernel<256, 256, n>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, n>), grid, dim3(512), (size_t)160 * 1024, s, a);                         \
         return;
+        a.stamps = h3_stamps();
         switch (std::atoi(ab)) {
             H3_ABL_CASE(1) H3_ABL_CASE(2) H3_ABL_CASE(3) H3_ABL_CASE(4) H3_ABL_CASE(7) H3_ABL_CASE(8) H3_ABL_CASE(12)
+            H3_ABL_CASE(23) H3_ABL_CASE(39) H3_ABL_CASE(55) H3_ABL_CASE(64) H3_ABL_CASE(71) H3_ABL_CASE(87)
             default: break;
         }
 #undef H3_ABL_CASE
