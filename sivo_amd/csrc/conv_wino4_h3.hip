@@ -324,7 +324,6 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         return (uint32_t)t;
     };
     uint32_t st_wait = 0, st_k0 = 0, st_k1 = 0;
-    half8 FA[2][2][2], FB[2][TB][2];            // fragments [k-step][block][plane] (kernel scope for ABL & 16; per-iteration temporaries otherwise)
     auto iteration1 = [&](const int s, VSet &r) __attribute__((always_inline)) {
         // all but the NV + NU operations of the previous iteration have landed: U'(s), and V'(s + 1) in r; this wave's V'(s) pieces are written
         const uint32_t t0 = stamp();
@@ -338,18 +337,16 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         ub_cur = ub_cur == 2 ? 0 : ub_cur + 1;
         ub_next2 = ub_next2 == 2 ? 0 : ub_next2 + 1;
         constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};            // smallest terms first: (lo, hi) (hi, lo) (hi, hi)
+        half8 A[2][2], B[TB][2];
         {
-            auto &A = FA[0]; auto &B = FB[0];
-            if (!(ABL & 16) || s == 0) {
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) A[c][pl] = *reinterpret_cast<const half8 *>(us + a_off + c * 4096 + pl * 2048);
+                for (int pl = 0; pl < 2; ++pl) A[c][pl] = *reinterpret_cast<const half8 *>(us + a_off + c * 4096 + pl * 2048);
 #pragma unroll
-                for (int t = 0; t < TB; ++t)
+            for (int t = 0; t < TB; ++t)
 #pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) B[t][pl] = *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048);
-            }
+                for (int pl = 0; pl < 2; ++pl) B[t][pl] = *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048);
             write_v((s + 1) & 1, r);                 // V'(s + 1): registers -> LDS, under the latency of the fragment reads
             __builtin_amdgcn_sched_barrier(0);
             int slot = 0;
@@ -377,8 +374,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         advance(cu);
         const uint32_t t2 = stamp();
         {
-            auto &A = FA[1]; auto &B = FB[1];
-            if (!(ABL & 16) || s == 0) {
+            if (!(ABL & 16)) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll

@@ -19,8 +19,8 @@ SHAPES = [("conv4_2  512->512 44x128", 512, 512, 4224), ("conv5_2  512->512 22x6
 VARIANTS = [("as built", {}), ("phased form (round 5)", {"SIVO_H3_FORM": "0"}), ("no V loads", {"SIVO_H3_ABL": "1"}), ("no U DMA", {"SIVO_H3_ABL": "2"}),
             ("no loads at all", {"SIVO_H3_ABL": "3"}), ("no M stores", {"SIVO_H3_ABL": "4"}), ("MFMA + LDS only", {"SIVO_H3_ABL": "7"}),
             ("no MFMA", {"SIVO_H3_ABL": "8"}), ("no MFMA, no stores", {"SIVO_H3_ABL": "12"}),
-            ("MFMA only (no LDS reads)", {"SIVO_H3_ABL": "23"}), ("MFMA + LDS, no barrier", {"SIVO_H3_ABL": "39"}), ("MFMA only, no barrier", {"SIVO_H3_ABL": "55"}),
-            ("stamped: as built", {"SIVO_H3_ABL": "64"}), ("stamped: MFMA + LDS only", {"SIVO_H3_ABL": "71"}), ("stamped: MFMA only", {"SIVO_H3_ABL": "87"})]
+            ("MFMA, half the LDS reads", {"SIVO_H3_ABL": "23"}), ("MFMA + LDS, no barrier", {"SIVO_H3_ABL": "39"}), ("MFMA, half the reads, no barrier", {"SIVO_H3_ABL": "55"}),
+            ("stamped: as built", {"SIVO_H3_ABL": "64"}), ("stamped: MFMA + LDS only", {"SIVO_H3_ABL": "71"}), ("stamped: MFMA, half the reads", {"SIVO_H3_ABL": "87"})]
 rng = np.random.default_rng(0)
 for name, Cc, Kp, P in SHAPES:
     Pp = (P + 127) // 128 * 128
@@ -29,6 +29,10 @@ for name, Cc, Kp, P in SHAPES:
     M = np.empty((36, Kp, Pp), np.float32)
     flop = 2.0 * 36 * Cc * Kp * P * 3          # executed fp16 products
     for vname, env in VARIANTS:
+        if os.environ.get("H3_PROBE_ONLY") and os.environ["H3_PROBE_ONLY"] not in vname:
+            continue
+        if os.environ.get("H3_PROBE_SKIP") and os.environ["H3_PROBE_SKIP"] in vname:
+            continue
         if "SIVO_H3_TILE" in env:
             continue                              # (static in the launcher: run the script again with SIVO_H3_TILE=2 for that column)
         for k in ("SIVO_H3_ABL", "SIVO_H3_FORM"):
