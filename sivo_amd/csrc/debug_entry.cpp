@@ -55,19 +55,6 @@ extern "C" int sivo_debug_h3_gemm(int C, int Kp, int P, const float *V, const fl
     });
 }
 
-#ifdef SIVO_DIAG
-namespace sivo { uint32_t *h3_stamps(); }
-// diagnostic build: the cycle sums of the stamped GEMM ablations (SIVO_H3_ABL & 64, conv_wino4_h3.hip) since the last call
-extern "C" int sivo_debug_h3_stamps(uint32_t out[8]) {
-    return guarded([&] {
-        SIVO_HIP(hipDeviceSynchronize());
-        SIVO_HIP(hipMemcpy(out, sivo::h3_stamps(), 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        SIVO_HIP(hipMemset(sivo::h3_stamps(), 0, 8 * sizeof(uint32_t)));
-        return SIVO_OK;
-    });
-}
-#endif
-
 // Diagnostic / test: the direct f16x3 3x3 convolution (conv3_h3.hip) alone.  d_in / d_mask / d_out are device pointers
 // (d_mask null: d_in is (N, Cin, H, W); else d_in is the pooled tensor (N, Cin, H/2, W/2) and d_mask its window codes), the
 // weights (Caffe layout) and the per-channel affine are host arrays.

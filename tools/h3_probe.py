@@ -12,15 +12,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = C.CDLL(os.path.join(ROOT, "sivo_amd", "libsivo_hip_diag.so"))
 lib.sivo_debug_h3_gemm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
 lib.sivo_last_error.restype = C.c_char_p
-lib.sivo_debug_h3_stamps.argtypes = [C.c_void_p]
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 SHAPES = [("conv4_2  512->512 44x128", 512, 512, 4224), ("conv5_2  512->512 22x64", 512, 512, 1152),
           ("conv3_3D 256->256 88x256", 256, 256, 16896), ("conv4_1D 512->256 44x128", 512, 256, 4224)]
 VARIANTS = [("as built", {}), ("phased form (round 5)", {"SIVO_H3_FORM": "0"}), ("no V loads", {"SIVO_H3_ABL": "1"}), ("no U DMA", {"SIVO_H3_ABL": "2"}),
             ("no loads at all", {"SIVO_H3_ABL": "3"}), ("no M stores", {"SIVO_H3_ABL": "4"}), ("MFMA + LDS only", {"SIVO_H3_ABL": "7"}),
             ("no MFMA", {"SIVO_H3_ABL": "8"}), ("no MFMA, no stores", {"SIVO_H3_ABL": "12"}),
-            ("MFMA, half the LDS reads", {"SIVO_H3_ABL": "23"}), ("MFMA + LDS, no barrier", {"SIVO_H3_ABL": "39"}), ("MFMA, half the reads, no barrier", {"SIVO_H3_ABL": "55"}),
-            ("stamped: as built", {"SIVO_H3_ABL": "64"}), ("stamped: MFMA + LDS only", {"SIVO_H3_ABL": "71"}), ("stamped: MFMA, half the reads", {"SIVO_H3_ABL": "87"})]
+            ("MFMA, half the LDS reads", {"SIVO_H3_ABL": "23"}), ("MFMA + LDS, no barrier", {"SIVO_H3_ABL": "39"}), ("MFMA, half the reads, no barrier", {"SIVO_H3_ABL": "55"})]
 rng = np.random.default_rng(0)
 for name, Cc, Kp, P in SHAPES:
     Pp = (P + 127) // 128 * 128
@@ -43,11 +41,3 @@ for name, Cc, Kp, P in SHAPES:
         if rc:
             print(name, vname, "error", lib.sivo_last_error().decode()); continue
         print(f"{name:26s} {vname:28s} {ms.value:8.4f} ms   {flop / ms.value / 1e9:8.1f} TFLOP/s executed", flush=True)
-        if int(env.get("SIVO_H3_ABL", "0")) & 64:
-            w = (C.c_uint32 * 8)()
-            lib.sivo_debug_h3_stamps(w)
-            waves, stages = max(w[5], 1), max(w[6], 1)
-            per = lambda v: 16.0 * v / stages          # cycles per stage of a wave
-            clock = 16.0 * w[3] / max(w[4], 1) * 0.1      # shader cycles per 10 ns tick -> GHz
-            print(f"        per stage and wave: wait + barrier {per(w[0]):7.0f}, k-step 0 (+ memory side) {per(w[1]):7.0f}, k-step 1 {per(w[2]):7.0f}, all {per(w[3]):7.0f} cycles "
-                  f"(48 MFMAs of a wave = 1536 cycles of its SIMD's pipe, two waves share it); shader clock {clock:.2f} GHz; {waves} waves, {stages // waves} stages each", flush=True)
