@@ -38,7 +38,6 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
-#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -98,13 +97,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     constexpr int U0 = 2 * VBYTES;                               // LDS: V' buffers 0, 1 then U' buffers 0, 1, 2
     constexpr int NQ = BM == 256 ? 2 : 1;                        // channel octets each lane brings in per stage
     constexpr int NU = BN / 64;                                  // 1 KiB U pieces each wave copies per stage (4 or 2)
-    // FORM 1, 256-tile items: V' comes in as FOUR 16-byte loads per lane and stage (4 channels x 4 consecutive tiles) instead of sixteen
-    // 4-byte ones — the vector-memory path spends its address cycles per instruction, not per byte (tools/h3_probe.py: the memory side alone
-    // took as long as the MFMAs) — and the MFMA operands are swapped (D = tiles x couts), so that a lane holds four consecutive tiles of one
-    // cout in four registers and M leaves in 16-byte stores as well (32 instead of 128 per wave and item).
-    constexpr bool SWAP = FORM == 1;
-    constexpr bool V4 = FORM == 1 && BM == 256;
-    constexpr int NV = V4 ? 4 : NQ * 8;                          // V' load instructions per lane and stage
+    constexpr int NV = NQ * 8;                                   // V' loads per lane and stage
     static_assert(BM == 256 || BM == 128, "tile");
     static_assert(BN == 256 || BN == 128, "tile");
     static_assert(TB == 4 || TB == 2, "wave tile");
@@ -189,47 +182,6 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         }
     };
 
-    // ---- V' staging, V4: lane = (channel quad cq of 8, tile quad g of 64): four buffer_load_dwordx4, one per channel of the quad, each
-    // bringing tiles 4 g .. 4 g + 3.  Tile 4 g + i of a 32-tile block sits at fragment slot (g & 7) + 8 i of the block (a 16-lane group
-    // of a ds_write_b64 then covers 8 consecutive slots x both half-octets: conflict-free); with the operands swapped, MFMA row
-    // (r & 3) + 8 (r >> 2) + 4 lh is that slot, i.e. tile 4 (r & 3) + 16 lh + (r >> 2): registers b, b + 4, b + 8, b + 12 hold four consecutive tiles.
-    typedef u32x4 V4Set[4];
-    const int v4_cq = 2 * (tid >> 7) + (tid & 1), v4_g = 8 * ((tid >> 4) & 7) + ((tid >> 1) & 7);
-    const uint32_t v4_lane_off = (uint32_t)(((int64_t)(4 * v4_cq) * a.Pp + 4 * v4_g) * 4);
-    const uint32_t v4_lds_off = (uint32_t)((v4_g >> 3) * 4096 + (v4_cq >> 1) * 512 + (v4_g & 7) * 16 + (v4_cq & 1) * 8);
-    auto load_v4_one = [&](const Cursor &c, V4Set &r, const int j) __attribute__((always_inline)) {
-        const uint64_t base = (uint64_t)(uintptr_t)(a.V + (int64_t)c.xi * a.C * a.Pp);
-        const i32x4 rs = {(int)(uint32_t)base, (int)(uint32_t)((base >> 32) & 0xffffu), (int)v_slab_bytes, 0x00020000};
-        const uint32_t vo = v4_lane_off + (uint32_t)c.pt * (BM * 4);
-        const uint32_t so = (uint32_t)((int64_t)(c.chunk * H3_KC + j) * a.Pp * 4);
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(r[j]) : "v"(vo), "s"(rs), "s"(so) : "memory");
-    };
-    auto landed4 = [&](V4Set &r) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(r[j]));
-    };
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    auto write_v4 = [&](int buf, const V4Set &r) __attribute__((always_inline)) {
-        unsigned char *dst = lds_h3 + buf * VBYTES + v4_lds_off;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32x2 hi = {__builtin_amdgcn_perm(r[1][i], r[0][i], 0x05040100u), __builtin_amdgcn_perm(r[3][i], r[2][i], 0x05040100u)};
-            const u32x2 lo = {__builtin_amdgcn_perm(r[1][i], r[0][i], 0x07060302u), __builtin_amdgcn_perm(r[3][i], r[2][i], 0x07060302u)};
-            *reinterpret_cast<u32x2 *>(dst + i * 128) = hi;
-            *reinterpret_cast<u32x2 *>(dst + i * 128 + 2048) = lo;
-        }
-    };
-    // the register set of a stage and its three operations, by form
-    using Set = std::conditional_t<V4, V4Set, VSet>;
-    auto load_set = [&](const Cursor &c, Set &r) __attribute__((always_inline)) {
-        if constexpr (V4) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) load_v4_one(c, r, j);
-        } else load_v(c, r);
-    };
-    auto landed_set = [&](Set &r) __attribute__((always_inline)) { if constexpr (V4) landed4(r); else landed(r); };
-    auto write_set = [&](int buf, const Set &r) __attribute__((always_inline)) { if constexpr (V4) write_v4(buf, r); else write_v(buf, r); };
-
     // ---- U' staging: piece g = wave * NU + j of the stage: cout block g >> 2, quarter g & 3 ------------------------------
     const uint32_t lds_base = lds_addr_uniform(lds_h3);
     uint32_t u_voff[NU];
@@ -258,30 +210,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     clear_acc();
     const uint32_t a_off = (uint32_t)(wc * 2 * 4096 + lane * 16), b_off = (uint32_t)(wt * TB * 4096 + lane * 16);
     // accumulator register r of block (c, t) is M[cout 32 (2 wc + c) + 8 (r >> 2) + 4 lh + (r & 3)][tile 32 (TB wt + t) + ln]
-    // SWAP: register r of block (c, t) is M[cout 32 (2 wc + c) + ln][tile 32 (TB wt + t) + slot_tile((r & 3) + 8 (r >> 2) + 4 lh)]
-    auto store_item_swapped = [&](int xi, int pt, int kt) __attribute__((always_inline)) {
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.M + (int64_t)xi * a.Kp * a.Pp, 0, (int)((int64_t)a.Kp * a.Pp * 4), 0x00020000);
-        const uint32_t vo = (uint32_t)(((int64_t)ln * a.Pp + (V4 ? 16 : 4) * lh) * 4);
-#pragma unroll
-        for (int t = 0; t < TB; ++t) {
-            const int p0 = pt * BM + (wt * TB + t) * 32;
-            if (p0 < a.Pp && (!(ABL & 4) || acc[0][0][0] == 12345.678f)) {
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int64_t k0 = kt * BN + (2 * wc + c) * 32;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        // V4: registers q, q + 4, q + 8, q + 12 are tiles 16 lh + 4 q + 0 .. 3; else registers 4 q .. 4 q + 3 are tiles 8 q + 4 lh + 0 .. 3
-                        const u32x4 v = V4 ? u32x4{__float_as_uint(acc[c][t][q]), __float_as_uint(acc[c][t][q + 4]), __float_as_uint(acc[c][t][q + 8]), __float_as_uint(acc[c][t][q + 12])}
-                                           : u32x4{__float_as_uint(acc[c][t][4 * q]), __float_as_uint(acc[c][t][4 * q + 1]), __float_as_uint(acc[c][t][4 * q + 2]), __float_as_uint(acc[c][t][4 * q + 3])};
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rs, vo, (uint32_t)((k0 * a.Pp + p0 + (V4 ? 4 : 8) * q) * 4), 0);
-                    }
-                }
-            }
-        }
-        clear_acc();
-    };
-    auto store_item_plain = [&](int xi, int pt, int kt) __attribute__((always_inline)) {
+    auto store_item = [&](int xi, int pt, int kt) __attribute__((always_inline)) {
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.M + (int64_t)xi * a.Kp * a.Pp, 0, (int)((int64_t)a.Kp * a.Pp * 4), 0x00020000);
         const uint32_t vo = (uint32_t)(((int64_t)(4 * lh) * a.Pp + ln) * 4);
 #pragma unroll
@@ -298,9 +227,6 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
             }
         }
         clear_acc();
-    };
-    auto store_item = [&](int xi, int pt, int kt) __attribute__((always_inline)) {
-        if constexpr (SWAP) store_item_swapped(xi, pt, kt); else store_item_plain(xi, pt, kt);
     };
 
     // one load / one DMA piece at a time (FORM 1 spreads them over the MFMAs of k-step 0)
@@ -319,22 +245,21 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     Cursor cc, cu, cv;          // compute; U' DMA (two stages ahead); V' loads (three stages ahead)
     locate(cc);
     cu = cc; cv = cc;
-    Set vA, vB;                 // even iterations: vB holds V'(s + 1) and is refilled with V'(s + 3); odd iterations: vA
+    VSet vA, vB;                // even iterations: vB holds V'(s + 1) and is refilled with V'(s + 3); odd iterations: vA
     // prologue: V'(0) -> LDS; V'(1) in vB, V'(2) in flight into vA; U'(0), U'(1) in flight
-    load_set(cv, vA); advance(cv);
+    load_v(cv, vA); advance(cv);
     dma_u(cu, 0); advance(cu);
-    if (1 < total) { load_set(cv, vB); advance(cv); dma_u(cu, 1); advance(cu); }
-    else load_set(cv, vB);      // (total == 1: a set that is written to LDS below must hold loaded registers, whatever they are)
+    if (1 < total) { load_v(cv, vB); advance(cv); dma_u(cu, 1); advance(cu); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    landed_set(vA); landed_set(vB);
-    write_set(0, vA);
-    if (2 < total) { load_set(cv, vA); advance(cv); }
+    landed(vA); landed(vB);
+    write_v(0, vA);
+    if (2 < total) { load_v(cv, vA); advance(cv); }
     int prev_ops = 2 < total ? NV : 0;              // vector-memory operations this wave issued behind the last full wait
     bool pend = false;                              // an item ended with the previous stage: its M stores are due
     int pxi = 0, ppt = 0, pkt = 0;
 
     int ub_cur = 0, ub_next2 = 2;                   // U' buffers: of stage s, and the one the DMA of stage s + 2 fills (s % 3, (s + 2) % 3)
-    auto iteration = [&](const int s, Set &r) __attribute__((always_inline)) {
+    auto iteration = [&](const int s, VSet &r) __attribute__((always_inline)) {
         // Everything but what the previous iteration issued has landed: U'(s) (DMA of iteration s - 2) and V'(s + 1) (loads of
         // iteration s - 2, in r).  This wave's V'(s) pieces are written (lgkmcnt).  Behind the barrier nobody reads V' buffer
         // (s + 1) & 1 or U' buffer (s + 2) % 3 (stage s - 1) any more.
@@ -343,11 +268,11 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         else if (prev_ops == NU) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NU) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         prev_ops = 0;
-        landed_set(r);
+        landed(r);
         if (pend) { store_item(pxi, ppt, pkt); pend = false; }        // (older than this iteration's loads: a whole stage to drain)
-        if (s + 1 < total) write_set((s + 1) & 1, r);
+        if (s + 1 < total) write_v((s + 1) & 1, r);
         if (s + 3 < total) {
-            if (!(ABL & 1)) { load_set(cv, r); prev_ops += NV; }
+            if (!(ABL & 1)) { load_v(cv, r); prev_ops += NV; }
             advance(cv);
         }
         if (s + 2 < total) {
@@ -392,19 +317,18 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         }
     };
     // FORM 1: see the comment above the kernel
-    auto iteration1 = [&](const int s, Set &r) __attribute__((always_inline)) {
+    auto iteration1 = [&](const int s, VSet &r) __attribute__((always_inline)) {
         // all but the NV + NU operations of the previous iteration have landed: U'(s), and V'(s + 1) in r; this wave's V'(s) pieces are written
-        if (ABL & 32) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NV + NU) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NV + NU) : "memory");
-        landed_set(r);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NV + NU) : "memory");
+        landed(r);
         if (pend) { store_item(pxi, ppt, pkt); pend = false; }
         const unsigned char *vs = lds_h3 + (s & 1) * VBYTES, *us = lds_h3 + U0 + ub_cur * UBYTES;
         const int ub_fill = ub_next2;
         ub_cur = ub_cur == 2 ? 0 : ub_cur + 1;
         ub_next2 = ub_next2 == 2 ? 0 : ub_next2 + 1;
         constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};            // smallest terms first: (lo, hi) (hi, lo) (hi, hi)
-        half8 A[2][2], B[TB][2];
         {
+            half8 A[2][2], B[TB][2];
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -413,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
             for (int t = 0; t < TB; ++t)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) B[t][pl] = *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048);
-            write_set((s + 1) & 1, r);               // V'(s + 1): registers -> LDS, under the latency of the fragment reads
+            write_v((s + 1) & 1, r);                 // V'(s + 1): registers -> LDS, under the latency of the fragment reads
             __builtin_amdgcn_sched_barrier(0);
             int slot = 0;
 #pragma unroll
@@ -423,37 +347,31 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
 #pragma unroll
                     for (int t = 0; t < TB; ++t) {
                         if (ABL & 8) acc[c][t][term] += (float)A[c][PA[term]][0] + (float)B[t][PB[term]][1];
-                        else acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(B[t][PB[term]], A[c][PA[term]], acc[c][t], 0, 0, 0);      // (D = tiles x couts)
+                        else acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][PA[term]], B[t][PB[term]], acc[c][t], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
-                        // fillers behind MFMA number `slot` of the k-step: first the loads of V'(s + 3) (one 16-byte or two 4-byte loads per slot),
-                        // then the NU DMA pieces of U'(s + 2)
-                        constexpr int LSLOTS = V4 ? NV : NV / 2;
-                        if (slot < LSLOTS) {
-                            if (!(ABL & 1)) {
-                                if constexpr (V4) load_v4_one(cv, r, slot);
-                                else { load_v_one(cv, r, (2 * slot) / 8, (2 * slot) % 8); load_v_one(cv, r, (2 * slot + 1) / 8, (2 * slot + 1) % 8); }
-                            }
-                        } else if (slot < LSLOTS + NU) {
-                            if (!(ABL & 2)) dma_u_one(cu, ub_fill, slot - LSLOTS);
+                        // fillers behind MFMA number `slot` of the k-step: first the NV loads of V'(s + 3), two per slot, then the NU DMA pieces of U'(s + 2)
+                        if (slot < NV / 2) {
+                            if (!(ABL & 1)) { load_v_one(cv, r, (2 * slot) / 8, (2 * slot) % 8); load_v_one(cv, r, (2 * slot + 1) / 8, (2 * slot + 1) % 8); }
+                        } else if (slot < NV / 2 + NU) {
+                            if (!(ABL & 2)) dma_u_one(cu, ub_fill, slot - NV / 2);
                         }
-                        if (slot < LSLOTS + NU) __builtin_amdgcn_sched_barrier(0);
+                        if (slot < NV / 2 + NU) __builtin_amdgcn_sched_barrier(0);
                         ++slot;
                     }
-            static_assert((V4 ? NV : NV / 2) + NU <= 6 * TB, "more fillers than MFMAs in a k-step");
+            static_assert(NV / 2 + NU <= 6 * TB, "more fillers than MFMAs in a k-step");
         }
         advance(cv);
         advance(cu);
         {
-            if (!(ABL & 16)) {
+            half8 A[2][2], B[TB][2];
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) A[c][pl] = *reinterpret_cast<const half8 *>(us + a_off + c * 4096 + pl * 2048 + 1024);
+                for (int pl = 0; pl < 2; ++pl) A[c][pl] = *reinterpret_cast<const half8 *>(us + a_off + c * 4096 + pl * 2048 + 1024);
 #pragma unroll
-                for (int t = 0; t < TB; ++t)
+            for (int t = 0; t < TB; ++t)
 #pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) B[t][pl] = *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048 + 1024);
-            }
+                for (int pl = 0; pl < 2; ++pl) B[t][pl] = *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048 + 1024);
 #pragma unroll
             for (int term = 0; term < 3; ++term)
 #pragma unroll
@@ -461,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
 #pragma unroll
                     for (int t = 0; t < TB; ++t) {
                         if (ABL & 8) acc[c][t][term] += (float)A[c][PA[term]][0] + (float)B[t][PB[term]][1];
-                        else acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(B[t][PB[term]], A[c][PA[term]], acc[c][t], 0, 0, 0);
+                        else acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][PA[term]], B[t][PB[term]], acc[c][t], 0, 0, 0);
                     }
         }
         if (++cc.chunk == nst) {
@@ -584,7 +502,6 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
         return;
         switch (std::atoi(ab)) {
             H3_ABL_CASE(1) H3_ABL_CASE(2) H3_ABL_CASE(3) H3_ABL_CASE(4) H3_ABL_CASE(7) H3_ABL_CASE(8) H3_ABL_CASE(12)
-            H3_ABL_CASE(23) H3_ABL_CASE(39) H3_ABL_CASE(55)
             default: break;
         }
 #undef H3_ABL_CASE

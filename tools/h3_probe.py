@@ -17,8 +17,7 @@ SHAPES = [("conv4_2  512->512 44x128", 512, 512, 4224), ("conv5_2  512->512 22x6
           ("conv3_3D 256->256 88x256", 256, 256, 16896), ("conv4_1D 512->256 44x128", 512, 256, 4224)]
 VARIANTS = [("as built", {}), ("phased form (round 5)", {"SIVO_H3_FORM": "0"}), ("no V loads", {"SIVO_H3_ABL": "1"}), ("no U DMA", {"SIVO_H3_ABL": "2"}),
             ("no loads at all", {"SIVO_H3_ABL": "3"}), ("no M stores", {"SIVO_H3_ABL": "4"}), ("MFMA + LDS only", {"SIVO_H3_ABL": "7"}),
-            ("no MFMA", {"SIVO_H3_ABL": "8"}), ("no MFMA, no stores", {"SIVO_H3_ABL": "12"}),
-            ("MFMA, half the LDS reads", {"SIVO_H3_ABL": "23"}), ("MFMA + LDS, no barrier", {"SIVO_H3_ABL": "39"}), ("MFMA, half the reads, no barrier", {"SIVO_H3_ABL": "55"})]
+            ("no MFMA", {"SIVO_H3_ABL": "8"}), ("no MFMA, no stores", {"SIVO_H3_ABL": "12"})]
 rng = np.random.default_rng(0)
 for name, Cc, Kp, P in SHAPES:
     Pp = (P + 127) // 128 * 128
