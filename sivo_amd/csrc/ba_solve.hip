@@ -595,7 +595,61 @@ struct BaDev {
     // reduced system
     double *S, *xs;
     double *scal;               // [0] chi  [1] scale  [2] maxdiag  [3] ok(0/1)
+    // Levenberg-Marquardt state and the two estimate buffers it alternates between (round 6: the trial decision is taken on the device)
+    struct BaLm *lm;
+    double *poses[2], *points[2];
+    const int *abort;           // pinned host word: non-zero = the caller's stop flag went up (checked where the host loop checked *stop)
 };
+
+// The Levenberg-Marquardt loop of g2o::SparseOptimizer::optimize / OptimizationAlgorithmLevenberg::solve (the reference's
+// Optimizer.cc:757-821 stands on it) as device state.  Until round 5 the host took the decision of every trial: a blocking 56-byte read
+// per trial, 15 per LocalBundleAdjustment, each with its ~50 us of launch gap and a scheduling jitter that made sigma 2.5 ms on a 3 ms call.
+// Now the host enqueues `steps` (linearise-if-due + one trial each) without looking, every kernel starts by reading this state, and the
+// LAST workgroup of the trial's edge kernel takes the decision (the same arithmetic in the same order as the host loop it replaces):
+//   step:  [need_lin: errors + Jacobians, H / b blocks, chi2 of the linearisation point; first: lambda = 1e-5 max |diag H|]
+//          -> Y, Schur complement, dense solve -> trial estimates -> their errors, chi2 -> decide()
+// A step after `done` is seven empty launches.  The host reads the state once per batch of steps.
+struct BaLm {
+    double lambda, ni, current, rho;
+    int cur;                    // poses[cur] / points[cur] hold the current estimate, [cur ^ 1] the trial
+    int need_lin;               // the next step linearises (first step of an iteration)
+    int have_current;           // `current` holds the chi2 of this iteration's linearisation point or of an accepted trial
+    int first;                  // first iteration of an optimize() call: computeLambdaInit
+    int it, it_limit;           // iterations completed / allowed in this call
+    int qmax;                   // trials of the running iteration
+    int done;
+    int trials;                 // trials of this call
+    int pad;
+};
+__device__ __forceinline__ bool ba_lm_idle(const BaDev &d) { return d.lm->done != 0; }
+__device__ __forceinline__ bool ba_lm_skip_lin(const BaDev &d) { return d.lm->done != 0 || d.lm->need_lin == 0; }
+// one thread, behind the sums of a trial (r0 = chi2 of the trial, r4 = the points' share of computeScale)
+__device__ __forceinline__ void ba_lm_decide(const BaDev &d, double r0, double r4, int landmarks) {
+    BaLm &m = *d.lm;
+    if (!m.have_current) { m.current = d.scal[6]; m.have_current = 1; }
+    const bool ok = d.scal[3] != 0.0;
+    const double temp = ok ? r0 : DBL_MAX;
+    const double scale = ok ? d.scal[1] + (landmarks ? r4 : 0.0) : 0.0;
+    const double rho = (m.current - temp) / (scale + 1e-3);
+    if (rho > 0 && isfinite(temp)) {
+        const double t = 2 * rho - 1;
+        double alpha = 1. - t * t * t;                  // (as pose_optimize_kernel)
+        alpha = fmin(alpha, 2. / 3.);
+        m.lambda *= fmax(1. / 3., alpha);
+        m.ni = 2; m.current = temp;
+        m.cur ^= 1;
+    } else {
+        m.lambda *= m.ni; m.ni *= 2;
+    }
+    m.rho = rho;
+    ++m.qmax; ++m.trials;
+    const bool stop = d.abort && __atomic_load_n(d.abort, __ATOMIC_RELAXED) != 0;
+    if (rho < 0 && m.qmax < 10 && !stop) { m.need_lin = 0; return; }          // another trial of the same iteration
+    const bool brk = m.qmax == 10 || rho == 0;
+    ++m.it;
+    if (brk || stop || m.it >= m.it_limit) { m.done = 1; return; }
+    m.need_lin = 1; m.qmax = 0; m.have_current = 0;
+}
 
 // errors (+ Jacobians, W) of the active edges at (poses, points)
 // JAC = false (a trial estimate) with `partial`: the sums the host reads after a trial are formed here instead of by a launch
@@ -603,8 +657,11 @@ struct BaDev {
 // (atomic counter) adds the partials in block order (scal[0]) and, with_points, the per-point shares of computeScale
 // (sc_pt, written by the update kernel before this launch: scal[4]).  Fixed order of additions, whichever block is last.
 template <bool JAC>
-__global__ __launch_bounds__(BA_T) void ba_edge_kernel(BaDev d, const double *poses, const double *points, double *partial = nullptr,
-                                                      unsigned *counter = nullptr, int with_points = 0) {
+__global__ __launch_bounds__(BA_T) void ba_edge_kernel(BaDev d, double *partial = nullptr, unsigned *counter = nullptr, int with_points = 0) {
+    if (JAC ? ba_lm_skip_lin(d) : ba_lm_idle(d)) return;
+    // JAC: the current estimate; else the trial
+    const int buf = JAC ? d.lm->cur : d.lm->cur ^ 1;
+    const double *poses = d.poses[buf], *points = d.points[buf];
     const int64_t e = (int64_t)blockIdx.x * BA_T + threadIdx.x;
     if (!JAC && partial) {
         __shared__ double s_red[BA_T / 64], s_out[1];
@@ -638,7 +695,9 @@ __global__ __launch_bounds__(BA_T) void ba_edge_kernel(BaDev d, const double *po
         double p[1] = {0.0};
         for (unsigned i = threadIdx.x; i < gridDim.x; i += BA_T) p[0] += __builtin_nontemporal_load(partial + i);
         block_sum<1, BA_T>(p, s_red, s_out);
-        if (threadIdx.x == 0) { d.scal[0] = s_out[0]; *counter = 0u; }
+        const double chi = s_out[0];
+        double sc4 = 0.0;
+        if (threadIdx.x == 0) { d.scal[0] = chi; *counter = 0u; }
         if (with_points) {
             double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
             int i = threadIdx.x;
@@ -646,10 +705,10 @@ __global__ __launch_bounds__(BA_T) void ba_edge_kernel(BaDev d, const double *po
             for (; i < d.nX; i += BA_T) q0 += d.sc_pt[i];
             double q[1] = {(q0 + q1) + (q2 + q3)};
             block_sum<1, BA_T>(q, s_red, s_out);
-            if (threadIdx.x == 0) d.scal[4] = s_out[0];
+            sc4 = s_out[0];
+            if (threadIdx.x == 0) d.scal[4] = sc4;
         }
-        // (Tried in round 3 and removed: the seven scalars written straight into pinned host memory and a stream wait instead
-        // of the hipMemcpy below — no faster per trial, and the pinned allocation costs a BA call 0.2 ms.)
+        if (threadIdx.x == 0) ba_lm_decide(d, chi, sc4, with_points);
         return;
     }
     if (e >= d.nE) return;
@@ -766,6 +825,7 @@ __device__ __forceinline__ void ba_pose_body(const BaDev &d, int s) {
 // points' Hll / bl, the next nF blocks the free poses' Hpp / bp, the last block chi2 of the linearisation point (scal[6]).
 // (Three launches before: 9 + 21 + 25 us back to back on a 36 k-edge problem, each mostly latency.)
 __global__ __launch_bounds__(BA_BUILD_T) void ba_build_kernel(BaDev d, int point_blocks) {
+    if (ba_lm_skip_lin(d)) return;
     const int b = blockIdx.x;
     if (b < point_blocks) { ba_point_body(d, b); return; }
     if (b < point_blocks + d.nF) { ba_pose_body(d, b - point_blocks); return; }
@@ -782,6 +842,7 @@ __global__ __launch_bounds__(BA_BUILD_T) void ba_build_kernel(BaDev d, int point
 
 // scal[2] = max |diag| over Hpp and Hll (computeLambdaInit)
 __global__ __launch_bounds__(1024) void ba_maxdiag_kernel(BaDev d, int with_points) {
+    if (ba_lm_idle(d) || !d.lm->first) return;
     __shared__ double s_m[1024];
     double m = 0;
     for (int i = threadIdx.x; i < 6 * d.nF; i += 1024) m = fmax(m, fabs(d.Hpp[36 * (i / 6) + 7 * (i % 6)]));
@@ -793,7 +854,10 @@ __global__ __launch_bounds__(1024) void ba_maxdiag_kernel(BaDev d, int with_poin
         if (threadIdx.x < s) s_m[threadIdx.x] = fmax(s_m[threadIdx.x], s_m[threadIdx.x + s]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) d.scal[2] = s_m[0];
+    if (threadIdx.x == 0) {
+        d.scal[2] = s_m[0];
+        d.lm->lambda = 1e-5 * s_m[0]; d.lm->ni = 2; d.lm->first = 0;          // computeLambdaInit
+    }
 }
 
 // (Hll_q + lambda I)^-1 — formed where it is used (every edge of the point, and the point's update) instead of by a launch of
@@ -811,7 +875,9 @@ __device__ __forceinline__ void ba_point_inverse(const BaDev &d, int q, double l
 }
 
 // Y_e = W_e Hll^-1 for every active edge that touches a free keyframe (one thread per edge)
-__global__ __launch_bounds__(BA_T) void ba_edge_y_kernel(BaDev d, double lambda) {
+__global__ __launch_bounds__(BA_T) void ba_edge_y_kernel(BaDev d) {
+    if (ba_lm_idle(d)) return;
+    const double lambda = d.lm->lambda;
     const int64_t e = (int64_t)blockIdx.x * BA_T + threadIdx.x;
     if (e >= d.nE || d.level[e]) return;
     const SivoEdge ed = d.edges[e];
@@ -830,7 +896,9 @@ __global__ __launch_bounds__(BA_T) void ba_edge_y_kernel(BaDev d, double lambda)
 // (1024 threads per block — 3 points per thread instead of 12 — was measured in round 3: the whole call went from 3.4 to 3.9 ms;
 // the 42-value block reduction over 16 waves costs more than the shorter chains of dependent loads save)
 constexpr int BA_SCHUR_T = 512;       // a pair of keyframes shares up to nX points and every thread walks a chain of dependent loads per point: 6 points per thread (42 f64 accumulators: 1024 threads would spill)
-__global__ __launch_bounds__(BA_SCHUR_T) void ba_schur_kernel(BaDev d, double lambda) {
+__global__ __launch_bounds__(BA_SCHUR_T) void ba_schur_kernel(BaDev d) {
+    if (ba_lm_idle(d)) return;
+    const double lambda = d.lm->lambda;
     __shared__ double s_red[(BA_SCHUR_T / 64) * 64], s_out[42];
     // block index -> (i, j) of the upper triangle
     int i = 0, rem = blockIdx.x;
@@ -895,6 +963,7 @@ __global__ __launch_bounds__(BA_SCHUR_T) void ba_schur_kernel(BaDev d, double la
 // (n <= 126) takes ba_dense_solve_lds_kernel below.
 constexpr int BA_SOLVE_T = 256;        // (1024 threads: 89 us instead of 63 — every wave repeats the diagonal block's Cholesky, four waves per SIMD take turns at it)
 __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_kernel(BaDev d) {
+    if (ba_lm_idle(d)) return;
     __shared__ int s_ok;
     __shared__ double s_x[6];
     const int nb = d.nF, n = 6 * nb, tid = threadIdx.x;
@@ -998,19 +1067,49 @@ __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_kernel(BaDev d) {
 //     inverse).
 // 3 barriers per keyframe in all instead of 7.  LDS: (n + 1)^2 + 21 nF doubles <= 133 KB.
 __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_lds_kernel(BaDev d) {
-    extern __shared__ double s_mat[];          // rows 0 .. n - 1: the matrix (lower triangle); row n: the right-hand side
+    if (ba_lm_idle(d)) return;
+    extern __shared__ double s_mat[];          // rows 0 .. n - 1: the factor L (lower triangle, column block by column block); row n: y
     __shared__ double s_li[21 * 21];           // inverse of each diagonal block's Cholesky factor, packed lower triangle
     const int nb = d.nF, n = 6 * nb, tid = threadIdx.x;
-    // row stride n + 1 doubles (odd): the trailing update reads element (k, j0 + c) of 16 consecutive rows k at once, and with a
-    // stride of n = 6 nF doubles those fall on 4 bank pairs (48 k mod 64), a 4-way conflict on the kernel's dominant access
-    const int ld = n + 1;
-    for (int i = tid >> 4; i < n; i += BA_SOLVE_T / 16)
-        for (int k = tid & 15; k <= i; k += 16) s_mat[i * ld + k] = d.S[(int64_t)i * n + k];
-    for (int i = tid; i < n; i += BA_SOLVE_T) s_mat[n * ld + i] = d.xs[i];
-    __syncthreads();
+    const int ld = n + 1;                      // odd row stride: the rows of a panel fall on different banks
+    // Round 6: the TRAILING MATRIX LIVES IN REGISTERS.  Thread t owns one 6 x 6 block (I, K), K <= I, of the lower triangle — or the six
+    // right-hand-side values under column block K (I = nb) — for the whole factorisation: nb (nb + 1) / 2 + nb <= 252 blocks for the <= 21
+    // keyframes this kernel takes.  LDS holds only what is exchanged: the diagonal block of the step (published by its owner), and the
+    // finished panels = L itself, which the backward substitution reads afterwards.  Per step and thread the update is 72 LDS reads
+    // and no LDS write (the round-5 form kept the matrix in LDS: 7 reads + 1 write per ELEMENT, 288 per block); every sum has the
+    // same terms in the same order as before, so the solution is bit-identical.
+    int I = 0, K = tid;
+    while (I <= nb && K >= (I < nb ? I + 1 : nb)) { K -= (I < nb ? I + 1 : nb); ++I; }
+    const bool active = I <= nb, rhs = I == nb;
+    double B[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) B[a][b] = 0.0;
+    if (active) {
+        if (rhs) {
+#pragma unroll
+            for (int b = 0; b < 6; ++b) B[0][b] = d.xs[6 * K + b];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) B[a][b] = d.S[(int64_t)(6 * I + a) * n + 6 * K + b];
+        }
+    }
+    auto publish_diag = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) s_mat[(6 * I + a) * ld + 6 * K + b] = B[a][b];
+    };
+    if (active && I == 0 && K == 0) publish_diag();
+    // LDS rows of this thread's block rows (the right-hand side is row n; its unused rows 1 .. 5 alias row n and are never stored)
+    const int row0 = rhs ? n : 6 * I;
     bool ok = true;
-    for (int jb = 0; jb < nb && ok; ++jb) {
+    for (int jb = 0; jb < nb; ++jb) {
         const int j0 = 6 * jb;
+        __syncthreads();                       // the diagonal block of this step is in LDS
         double l[6][6], li[6][6];
 #pragma unroll
         for (int i = 0; i < 6; ++i)
@@ -1052,36 +1151,48 @@ __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_lds_kernel(BaDev d)
 #pragma unroll
                 for (int j = 0; j <= i; ++j) s_li[21 * jb + k++] = li[i][j];
         }
-        // panel: L_ij = S_ij L_jj^-T for the rows below the block, and for the right-hand side (row n): y_j = L_jj^-1 b_j
-        for (int i = j0 + 6 + tid; i <= n; i += BA_SOLVE_T) {
-            double *row = s_mat + i * ld + j0;
-            double sv[6];
+        // panel: L_ij = S_ij L_jj^-T for the blocks below the diagonal, and for the right-hand side: y_j = L_jj^-1 b_j — finished, to LDS
+        if (active && K == jb && I > jb) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) sv[c] = row[c];
+            for (int a = 0; a < 6; ++a) {
+                if (a == 0 || !rhs) {
+                    double *row = s_mat + (row0 + a) * ld + j0;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                double r = 0;
+                    for (int c = 0; c < 6; ++c) {
+                        double r = 0;
 #pragma unroll
-                for (int k = 0; k <= c; ++k) r += sv[k] * li[c][k];
-                row[c] = r;
+                        for (int k = 0; k <= c; ++k) r += B[a][k] * li[c][k];
+                        row[c] = r;
+                    }
+                }
             }
         }
         __syncthreads();
-        // trailing update, rows j0 + 6 .. n (the right-hand side included), columns j0 + 6 .. min(row, n - 1)
-        for (int i = j0 + 6 + (tid >> 4); i <= n; i += BA_SOLVE_T / 16) {
-            double ri[6];
+        // trailing update of this thread's block: S_IK -= L_I,jb L_K,jb'
+        if (active && K > jb) {
+            double lk[6][6];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) ri[c] = s_mat[i * ld + j0 + c];
-            const int kend = i < n ? i : n - 1;
-            for (int k = j0 + 6 + (tid & 15); k <= kend; k += 16) {
-                double v = 0;
+            for (int b = 0; b < 6; ++b)
 #pragma unroll
-                for (int c = 0; c < 6; ++c) v += ri[c] * s_mat[k * ld + j0 + c];
-                s_mat[i * ld + k] -= v;
+                for (int c = 0; c < 6; ++c) lk[b][c] = s_mat[(6 * K + b) * ld + j0 + c];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                double ri[6];
+                const int r = rhs ? n : row0 + a;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) ri[c] = s_mat[r * ld + j0 + c];
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    double v = 0;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) v += ri[c] * lk[b][c];
+                    B[a][b] -= v;
+                }
             }
+            if (I == jb + 1 && K == jb + 1) publish_diag();
         }
-        __syncthreads();
     }
+    __syncthreads();
     if (ok) {
         double *y = s_mat + n * ld;
         for (int jb = nb - 1; jb >= 0; --jb) {         // L' x = y, one keyframe per step
@@ -1181,14 +1292,18 @@ __device__ __forceinline__ void ba_pose_update_body(const BaDev &d, double lambd
 }
 
 // the trial estimates in one launch: block 0 the poses, the others the points
-__global__ __launch_bounds__(BA_T) void ba_update_kernel(BaDev d, double lambda, const double *poses, double *poses_trial, const double *points,
-                                                        double *points_trial) {
-    if (blockIdx.x == 0) ba_pose_update_body(d, lambda, poses, poses_trial);
-    else ba_point_update_body(d, (int)blockIdx.x - 1, lambda, points, points_trial);
+__global__ __launch_bounds__(BA_T) void ba_update_kernel(BaDev d) {
+    if (ba_lm_idle(d)) return;
+    const double lambda = d.lm->lambda;
+    const int cur = d.lm->cur;
+    if (blockIdx.x == 0) ba_pose_update_body(d, lambda, d.poses[cur], d.poses[cur ^ 1]);
+    else ba_point_update_body(d, (int)blockIdx.x - 1, lambda, d.points[cur], d.points[cur ^ 1]);
 }
 
 // pose-only variant of the reduced system (no landmarks in the state): S = blockdiag(Hpp + lambda I), xs = bp
-__global__ void ba_pose_only_system_kernel(BaDev d, double lambda) {
+__global__ void ba_pose_only_system_kernel(BaDev d) {
+    if (ba_lm_idle(d)) return;
+    const double lambda = d.lm->lambda;
     const int n6 = 6 * d.nF;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n6 * n6; idx += gridDim.x * blockDim.x) {
         const int r = idx / n6, c = idx % n6;
@@ -1260,6 +1375,22 @@ static bool dense_solve_lds_ok() {
     return state[dev] == 1;
 }
 
+// What the stop flag of a solver call needs, once per calling thread (a pinned allocation costs 0.2 ms: not per call): a pinned word the
+// device reads where the host loop read *stop, and an event to wait on while the host polls the caller's flag.
+struct BaStopCtx {
+    int *word = nullptr;
+    hipEvent_t ev = nullptr;
+    ~BaStopCtx() {
+        if (word) (void)hipHostFree(word);
+        if (ev) (void)hipEventDestroy(ev);
+    }
+    void ensure() {
+        if (!word) { SIVO_HIP(hipHostMalloc((void **)&word, 64, hipHostMallocDefault)); *word = 0; }
+        if (!ev) SIVO_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+};
+static thread_local BaStopCtx t_stop;
+
 class BaSolver {
  public:
     BaSolver(const double *poses, const uint8_t *fixed, int nP, const double *points, int nX, bool points_fixed,
@@ -1315,6 +1446,7 @@ class BaSolver {
         S_.alloc((size_t)36 * nF_ * nF_ * 8); xs_.zero((size_t)nF_ * 48);
         scal_.zero(8 * 8);
         partial_.zero((size_t)cdiv64(std::max<int64_t>(nE, 1), BA_T) * 8); counter_.zero(8);
+        lm_.zero(sizeof(BaLm));
         hpp_last_.assign((size_t)std::max(nF_, 1) * 36, 0.0);
         d_.edges = edges_.as<SivoEdge>(); d_.nE = nE; d_.slot = slot_.as<int32_t>();
         d_.level = level_.as<uint8_t>(); d_.robust = robust_.as<uint8_t>();
@@ -1327,6 +1459,9 @@ class BaSolver {
         d_.Hll = Hll_.as<double>(); d_.bl = bl_.as<double>(); d_.xl = xl_.as<double>();
         d_.sc_pt = sc_pt_.as<double>(); d_.Hpp = Hpp_.as<double>(); d_.bp = bp_.as<double>();
         d_.S = S_.as<double>(); d_.xs = xs_.as<double>(); d_.scal = scal_.as<double>();
+        d_.lm = lm_.as<BaLm>();
+        for (int k = 0; k < 2; ++k) { d_.poses[k] = poses_[k].as<double>(); d_.points[k] = points_[k].as<double>(); }
+        d_.abort = nullptr;
         slot_host_ = slot;
     }
 
@@ -1336,84 +1471,70 @@ class BaSolver {
     }
     void get_level(uint8_t *level) const { if (nE_) SIVO_HIP(hipMemcpy(level, level_.p, (size_t)nE_, hipMemcpyDeviceToHost)); }
 
-    // g2o::SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg
+    // g2o::SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg.  The loop itself runs on the device (BaLm): the
+    // host enqueues one step per remaining iteration, reads the state once, and enqueues more only when a trial was rejected.
     int optimize(int iterations, const volatile uint8_t *stop, int *trials) {
+        if (iterations <= 0 || (stop && *stop)) return 0;
         const unsigned gE = (unsigned)cdiv64(std::max<int64_t>(nE_, 1), BA_T), gX4 = (unsigned)cdiv(std::max(nX_, 1) * BA_PL, BA_T);
         const bool landmarks = !points_fixed_ && nX_ > 0;
-        double lambda = 0, ni = 2;
-        int it = 0;
-        bool linearized = false;
-        for (; it < iterations; ++it) {
-            if (stop && *stop) break;
-            const double *P = poses_[cur_].as<double>(), *X = points_[cur_].as<double>();
-            if (nE_) hipLaunchKernelGGL(ba_edge_kernel<true>, dim3(gE), dim3(BA_T), 0, 0, d_, P, X);
-            // Hll / bl of the points, Hpp / bp of the free poses, chi2 at the current estimate (scal[6])
-            const unsigned gXb = (unsigned)cdiv(std::max(nX_, 1) * BA_PL, BA_BUILD_T);
-            hipLaunchKernelGGL(ba_build_kernel, dim3((landmarks ? gXb : 0u) + (unsigned)nF_ + 1u), dim3(BA_BUILD_T), 0, 0, d_, landmarks ? (int)gXb : 0);
-            linearized = true;
-            // The host needs lambda before the first trial only in the first iteration (computeLambdaInit: 1e-5 max |diag H|);
-            // afterwards the chi2 of the linearisation point is read together with the trial's result: ONE host read per trial
-            // instead of two per iteration plus a 288-byte-per-keyframe copy of H_pp (now fetched once, behind the loop).
-            if (it == 0) {
-                hipLaunchKernelGGL(ba_maxdiag_kernel, dim3(1), dim3(1024), 0, 0, d_, landmarks ? 1 : 0);
-                SIVO_HIP(hipGetLastError());
-                double sc[4];
-                SIVO_HIP(hipMemcpy(sc, d_.scal, sizeof sc, hipMemcpyDeviceToHost));
-                lambda = 1e-5 * sc[2]; ni = 2;
-            }
-            double current = 0;
-            bool have_current = false;
-            double rho = 0;
-            int qmax = 0;
-            do {
-                double *Pt = poses_[cur_ ^ 1].as<double>(), *Xt = points_[cur_ ^ 1].as<double>();
-                if (nF_) {
-                    if (landmarks) {
-                        if (nE_) hipLaunchKernelGGL(ba_edge_y_kernel, dim3(gE), dim3(BA_T), 0, 0, d_, lambda);
-                        hipLaunchKernelGGL(ba_schur_kernel, dim3((unsigned)(nF_ * (nF_ + 1) / 2)), dim3(BA_SCHUR_T), 0, 0, d_, lambda);
-                    } else {
-                        hipLaunchKernelGGL(ba_pose_only_system_kernel, dim3(64), dim3(256), 0, 0, d_, lambda);
-                    }
-                    if (6 * nF_ <= 126 && dense_solve_lds_ok()) {
-                        hipLaunchKernelGGL(ba_dense_solve_lds_kernel, dim3(1), dim3(BA_SOLVE_T), (size_t)(6 * nF_ + 1) * (6 * nF_ + 1) * 8, 0, d_);
-                    } else {
-                        hipLaunchKernelGGL(ba_dense_solve_kernel, dim3(1), dim3(BA_SOLVE_T), 0, 0, d_);
-                    }
-                } else {
-                    const double one = 1.0;
-                    SIVO_HIP(hipMemcpy(d_.scal + 3, &one, 8, hipMemcpyHostToDevice));
-                }
-                hipLaunchKernelGGL(ba_update_kernel, dim3(1u + (landmarks ? gX4 : 0u)), dim3(BA_T), 0, 0, d_, lambda, P, Pt, X, Xt);
-                if (!landmarks && nX_) SIVO_HIP(hipMemcpyAsync(Xt, X, (size_t)nX_ * 24, hipMemcpyDeviceToDevice, 0));
-                if (nE_) hipLaunchKernelGGL(ba_edge_kernel<false>, dim3(gE), dim3(BA_T), 0, 0, d_, (const double *)Pt, (const double *)Xt, partial_.as<double>(),
-                                            counter_.as<unsigned>(), landmarks ? 1 : 0);        // + the sums the host reads: scal[0], scal[4]
-                else hipLaunchKernelGGL(ba_sum_kernel, dim3(landmarks ? 2 : 1), dim3(1024), 0, 0, d_.rchi, nE_, d_.scal, (const double *)d_.sc_pt, (int64_t)nX_, d_.scal + 4);
-                SIVO_HIP(hipGetLastError());
-                double r[7];
-                SIVO_HIP(hipMemcpy(r, d_.scal, sizeof r, hipMemcpyDeviceToHost));
-                if (!have_current) { current = r[6]; have_current = true; }
-                const bool ok = r[3] != 0.0;
-                double temp = ok ? r[0] : DBL_MAX;
-                const double scale = ok ? r[1] + (landmarks ? r[4] : 0.0) : 0.0;
-                rho = (current - temp) / (scale + 1e-3);
-                if (rho > 0 && std::isfinite(temp)) {
-                    double alpha = 1. - std::pow(2 * rho - 1, 3);
-                    alpha = std::min(alpha, 2. / 3.);
-                    lambda *= std::max(1. / 3., alpha);
-                    ni = 2; current = temp;
-                    cur_ ^= 1;
-                    P = poses_[cur_].as<double>(); X = points_[cur_].as<double>();
-                } else {
-                    lambda *= ni; ni *= 2;
-                }
-                ++qmax;
-                if (trials) ++*trials;
-            } while (rho < 0 && qmax < 10 && !(stop && *stop));
-            if (qmax == 10 || rho == 0) { ++it; break; }
+        const unsigned gXb = (unsigned)cdiv(std::max(nX_, 1) * BA_PL, BA_BUILD_T);
+        if (stop) {
+            t_stop.ensure();
+            abort_host_ = t_stop.word;
+            *abort_host_ = 0;
+            d_.abort = abort_host_;
+        } else {
+            d_.abort = nullptr;
         }
+        BaLm lm{};
+        lm.ni = 2; lm.cur = cur_; lm.need_lin = 1; lm.first = 1; lm.it_limit = iterations;
+        SIVO_HIP(hipMemcpyAsync(d_.lm, &lm, sizeof lm, hipMemcpyHostToDevice, 0));          // (pageable source: the copy is staged before the call returns)
+        if (!nF_) { const double one = 1.0; SIVO_HIP(hipMemcpyAsync(d_.scal + 3, &one, 8, hipMemcpyHostToDevice, 0)); }      // nothing to solve: "ok"
+        const bool lds_solve = 6 * nF_ <= 126 && dense_solve_lds_ok();
+        auto step = [&](bool first_of_call) {
+            // linearise at the current estimate (skipped by the kernels themselves while trials of the same iteration go on): errors,
+            // Jacobians, W; Hll / bl of the points, Hpp / bp of the free poses, chi2 of the linearisation point (scal[6])
+            hipLaunchKernelGGL(ba_edge_kernel<true>, dim3(gE), dim3(BA_T), 0, 0, d_, (double *)nullptr, (unsigned *)nullptr, 0);
+            hipLaunchKernelGGL(ba_build_kernel, dim3((landmarks ? gXb : 0u) + (unsigned)nF_ + 1u), dim3(BA_BUILD_T), 0, 0, d_, landmarks ? (int)gXb : 0);
+            if (first_of_call) hipLaunchKernelGGL(ba_maxdiag_kernel, dim3(1), dim3(1024), 0, 0, d_, landmarks ? 1 : 0);
+            // one trial
+            if (nF_) {
+                if (landmarks) {
+                    hipLaunchKernelGGL(ba_edge_y_kernel, dim3(gE), dim3(BA_T), 0, 0, d_);
+                    hipLaunchKernelGGL(ba_schur_kernel, dim3((unsigned)(nF_ * (nF_ + 1) / 2)), dim3(BA_SCHUR_T), 0, 0, d_);
+                } else {
+                    hipLaunchKernelGGL(ba_pose_only_system_kernel, dim3(64), dim3(256), 0, 0, d_);
+                }
+                if (lds_solve) hipLaunchKernelGGL(ba_dense_solve_lds_kernel, dim3(1), dim3(BA_SOLVE_T), (size_t)(6 * nF_ + 1) * (6 * nF_ + 1) * 8, 0, d_);
+                else hipLaunchKernelGGL(ba_dense_solve_kernel, dim3(1), dim3(BA_SOLVE_T), 0, 0, d_);
+            }
+            // (without landmarks in the state the points never move: both point buffers hold the caller's values from the upload on)
+            hipLaunchKernelGGL(ba_update_kernel, dim3(1u + (landmarks ? gX4 : 0u)), dim3(BA_T), 0, 0, d_);
+            // the trial's errors and chi2; its last workgroup forms the sums and takes the decision (ba_lm_decide)
+            hipLaunchKernelGGL(ba_edge_kernel<false>, dim3(gE), dim3(BA_T), 0, 0, d_, partial_.as<double>(), counter_.as<unsigned>(), landmarks ? 1 : 0);
+        };
+        bool first = true;
+        int steps_total = 0;
+        for (;;) {
+            const int batch = std::max(1, iterations - lm.it);
+            for (int b = 0; b < batch; ++b) { step(first); first = false; }
+            steps_total += batch;
+            SIVO_HIP(hipGetLastError());
+            if (stop) {
+                // the caller's flag is host memory the device cannot see: poll it while the batch runs and pass it on through the pinned word
+                hipEvent_t ev = t_stop.ev;
+                SIVO_HIP(hipEventRecord(ev, 0));
+                while (hipEventQuery(ev) == hipErrorNotReady)
+                    if (*stop) *abort_host_ = 1;
+            }
+            SIVO_HIP(hipMemcpy(&lm, d_.lm, sizeof lm, hipMemcpyDeviceToHost));
+            if (lm.done || steps_total > 10 * iterations + 1) break;
+        }
+        cur_ = lm.cur;
+        if (trials) *trials += lm.trials;
         // H_pp of the last linearisation (computeMarginals inverts its block, Optimizer.cc:482-487, 900-907)
-        if (linearized && nF_) SIVO_HIP(hipMemcpy(hpp_last_.data(), d_.Hpp, (size_t)nF_ * 288, hipMemcpyDeviceToHost));
-        return it;
+        if (nF_) SIVO_HIP(hipMemcpy(hpp_last_.data(), d_.Hpp, (size_t)nF_ * 288, hipMemcpyDeviceToHost));
+        return lm.it;
     }
 
     // chi2 / depth classification at the current estimates using the error vectors g2o would hold
@@ -1444,7 +1565,8 @@ class BaSolver {
     bool points_fixed_;
     int cur_ = 0;
     Buf slot_, pt_off_, pt_edges_, ps_off_, ps_edges_, table_, edges_, level_, robust_, poses_[2], points_[2];
-    Buf err_, Jp_, Jx_, wo_, rchi_, W_, Y_, Hll_, bl_, xl_, sc_pt_, Hpp_, bp_, S_, xs_, scal_, partial_, counter_;
+    Buf err_, Jp_, Jx_, wo_, rchi_, W_, Y_, Hll_, bl_, xl_, sc_pt_, Hpp_, bp_, S_, xs_, scal_, partial_, counter_, lm_;
+    int *abort_host_ = nullptr;            // (the calling thread's pinned word, BaStopCtx)
     std::vector<double> hpp_last_;
     std::vector<int32_t> slot_host_;
     BaDev d_{};

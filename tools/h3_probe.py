@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Where the time of the f16x3 GEMM goes: the production kernel and its compile-time ablations (libsivo_hip_diag.so, `make -C
 sivo_amd/csrc diag`; SIVO_H3_ABL bits: 1 no V' loads, 2 no U' DMA, 4 no M stores, 8 no MFMAs) on the GEMM shapes of
-SegNet-Standard T = 12.  GPU box only.  Usage: python tools/h3_probe.py [iters]"""
+SegNet-Standard T = 12.  GPU box only.  Usage: python tools/h3_probe.py [iters]
+H3_PROBE_SHAPE / H3_PROBE_ONLY / H3_PROBE_SKIP select shapes / variants by substring; H3_PROBE_ZEROS=1 runs on all-zero operands
+(tools/power_probe.py wraps this script to read board power and shader clock per variant)."""
 import ctypes as C
 import os
 import sys
@@ -20,9 +22,13 @@ VARIANTS = [("as built", {}), ("phased form (round 5)", {"SIVO_H3_FORM": "0"}), 
             ("no MFMA", {"SIVO_H3_ABL": "8"}), ("no MFMA, no stores", {"SIVO_H3_ABL": "12"})]
 rng = np.random.default_rng(0)
 for name, Cc, Kp, P in SHAPES:
+    if os.environ.get("H3_PROBE_SHAPE") and os.environ["H3_PROBE_SHAPE"] not in name:
+        continue
     Pp = (P + 127) // 128 * 128
     V = rng.standard_normal((36, Cc, Pp), dtype=np.float32)
     U = (rng.standard_normal((36, Cc, Kp), dtype=np.float32) * 0.05).astype(np.float32)
+    if os.environ.get("H3_PROBE_ZEROS"):       # all-zero operands: the same instructions with no toggling in the matrix cores (power probe)
+        V[:] = 0; U[:] = 0
     M = np.empty((36, Kp, Pp), np.float32)
     flop = 2.0 * 36 * Cc * Kp * P * 3          # executed fp16 products
     for vname, env in VARIANTS:
