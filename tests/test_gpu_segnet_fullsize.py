@@ -346,3 +346,51 @@ def test_f4x4_margin_robustness_sweep(oracle, tag, mutate, image, kitti_like_bgr
     assert err < LOGIT_TOL * max(1.0, mag / 30.0)
     if mutate:
         _cache.pop(("standard", T, None, tag))
+
+
+def test_trained_like_weights_through_a_caffemodel_file(oracle, kitti_like_bgr, tmp_path):
+    """Real trained weights never passed through the path (the reference's .caffemodel files are LFS pointers).  This is the closest
+    stand-in: tests/trained_like.py — VGG16's per-layer weight magnitudes, heavy-tailed filters of very different norm, dead filters,
+    BN gains over two decades on the layer's ACTUAL statistics, ~90 % of the activations zero behind the ReLUs — written as a binary
+    .caffemodel of the reference's size (117.8 MB) and loaded with the .prototxt through sivo_segnet_create_from_files, as
+    BayesianSegNet's constructor does (bayesian_segnet.cpp:62-64).  SegNet-Standard, full geometry, T = 2, switches teacher-forced;
+    prints the accuracy guard's table, the f16x3 scales and the used part of the 1e-3 logit budget."""
+    from trained_like import trained_like_weights
+    from sivo_amd.segnet import BayesianSegNetParams
+    T = 2
+    text = _text("standard", T)
+    net = oproto.parse(text)
+    frame = np.ascontiguousarray(kitti_like_bgr[:H, :W])
+    w = trained_like_weights(net, frame)
+    proto, model = tmp_path / "trained_like.prototxt", tmp_path / "trained_like.caffemodel"
+    proto.write_text(text)
+    model.write_bytes(wts.to_caffemodel(net["layers"], w))
+    assert abs(model.stat().st_size - 117.8e6) < 0.3e6                      # the size of the reference's bayesian_segnet_kitti.caffemodel
+    sn = BayesianSegNet(BayesianSegNetParams(str(proto), str(model)), T=T)
+    rep = sn.guard_report()
+    mode, overflowed, scales = sn.gemm_status()
+    print(f"[trained-like] guard: predicted {rep['predicted']:.3e} of budget {rep['budget']:.3e}, plans built {rep['builds']}, gemm mode {mode}")
+    for r in rep["layers"]:
+        print(f"[trained-like]   {r['layer']:12s} {r['kernel']:16s} rel_err {r['rel_err']:.2e} rms {r['rel_rms']:.2e} ref_max {r['ref_max']:.3g} level {r['level']}")
+    for name, vmax, vs, us in scales:
+        print(f"[trained-like]   scale {name:12s} |V|max {vmax:.4g} vscale 2^{int(np.log2(vs))} uscale 2^{int(np.log2(us))}")
+    for image, seed in (("kitti", 11), ("synthetic", 3)):
+        img = _images(kitti_like_bgr)[image]
+        lg, masks, cls, conf, ent = _device_run(sn, net, img, seed)
+        assert not sn.take_overflow()
+        flips = {}
+        res = oracle.segment(net, w, img, seed, logits_name="conv1_1_D", force_masks=masks, flips=flips, shared_prefix=True)
+        for name, (count, gap, mag) in flips.items():
+            assert gap <= NEAR_TIE * max(mag, 1.0), (name, count, gap, mag)
+        mag = float(np.abs(res["logits"]).max())
+        err = float(np.abs(lg - res["logits"]).max())
+        top2 = np.sort(res["logits"], axis=1)[:, -2:]
+        margin = float(np.median(top2[:, 1] - top2[:, 0]))
+        print(f"[trained-like {image}] max|logit| {mag:.2f}, max|dlogit| {err:.3e} = {err / (LOGIT_TOL * max(1.0, mag / 30.0)):.2f} of the budget, "
+              f"median top-1 margin {margin:.3f}, switches forced {sum(c for c, _, _ in flips.values())}, "
+              f"class map differs on {(cls != res['classes']).mean():.2e}, entropy max diff {np.abs(ent - res['entropy']).max():.2e}")
+        assert np.isfinite(lg).all()
+        assert err < LOGIT_TOL * max(1.0, mag / 30.0)
+        assert (cls != res["classes"]).mean() < 3e-3
+    assert sn.gemm_status()[0] == 2                                        # the matrix-core layers stayed on f16x3
+    torch.cuda.empty_cache()

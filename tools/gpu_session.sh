@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: the steps named on the command line, in order, every log under gpurun_out/<tag>/.
-#   bash tools/gpu_session.sh <tag> step...      steps: gemm segnet bench benchvar e2e fullsize alltests
+#   bash tools/gpu_session.sh <tag> step...      steps: gemm segnet bench benchvar e2e fullsize ba power alltests
 set -u
 TAG=$1; shift
 export TMPDIR=/tmp
@@ -44,6 +44,24 @@ try:
 except Exception as e: print("  no line:", e)
 PY
 ;;
+    ba) timeout 900 python -m pytest tests/test_gpu_ba_solve.py tests/test_pin_optimizer.py tests/test_gpu_match_ba.py tests/test_cpp_api.py -m gpu -q > $O/ba_tests.log 2>&1; echo "ba tests rc=$?"; tail -4 $O/ba_tests.log
+        timeout 300 python tests/tools/ba_bench.py > $O/ba_bench.json 2> $O/ba_bench.err; cut -c1-900 $O/ba_bench.json
+        timeout 300 python bench.py --configs ba --no-cpu-baseline --no-orb --steps 3 --warmup 1 > $O/bench_ba.json 2> $O/bench_ba.err; python - <<PY
+import json
+try:
+    d=json.load(open("$O/bench_ba.json"))
+    for c in d.get("configs", []): print("  ", {k: v for k, v in c.items() if k not in ("name", "note", "parity", "roofline")})
+except Exception as e: print("  no line:", e)
+PY
+;;
+    power)   # board power / shader clock under the f16x3 GEMM and its ablations (is the kernel power-limited?)
+        for v in "as built" "MFMA + LDS only" "no MFMA" "no M stores"; do
+          H3_PROBE_SHAPE=conv4_2 H3_PROBE_ONLY="$v" POWER_PROBE_SMI_AT=9 timeout 200 python tools/power_probe.py -- python tools/h3_probe.py 20000 2>&1 | grep -v "^$" | cut -c1-1500
+        done > $O/power.log 2>&1
+        H3_PROBE_ZEROS=1 H3_PROBE_SHAPE=conv4_2 H3_PROBE_ONLY="as built" POWER_PROBE_SMI_AT=99 timeout 200 python tools/power_probe.py -- python tools/h3_probe.py 20000 2>&1 | cut -c1-600 >> $O/power.log
+        H3_PROBE_ZEROS=1 H3_PROBE_SHAPE=conv4_2 H3_PROBE_ONLY="MFMA + LDS only" POWER_PROBE_SMI_AT=99 timeout 200 python tools/power_probe.py -- python tools/h3_probe.py 20000 2>&1 | cut -c1-600 >> $O/power.log
+        POWER_PROBE_SMI_AT=99 timeout 200 python tools/power_probe.py -- python bench.py --steps 600 --warmup 3 --no-cpu-baseline --configs none 2>/dev/null | cut -c1-600 >> $O/power.log
+        cat $O/power.log;;
     alltests) timeout 1800 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; echo "alltests rc=$?"; tail -5 $O/gpu_tests.log;;
   esac
 done
