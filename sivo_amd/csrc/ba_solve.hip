@@ -587,8 +587,8 @@ struct BaDev {
     const int64_t *pt_off; const int32_t *pt_edges;     // by point
     const int64_t *ps_off; const int32_t *ps_edges;     // by free pose
     const int32_t *table;                               // [nF][nX] edge id or -1
-    // per edge
-    double *err, *Jp, *Jx, *wo, *rchi, *W, *Y;
+    // per edge, one set per estimate buffer (set k belongs to poses[k] / points[k]); kernels pick theirs with ba_set()
+    struct BaEdgeSet { double *err, *Jp, *Jx, *wo, *rchi, *W; } sets[2];
     // per point / pose
     double *Hll, *bl, *xl, *sc_pt;
     double *Hpp, *bp;
@@ -619,8 +619,20 @@ struct BaLm {
     int qmax;                   // trials of the running iteration
     int done;
     int trials;                 // trials of this call
-    int pad;
+    int last_set;               // the per-edge set written last (g2o's edges hold the errors of the last computeActiveErrors())
+    int pad[2];
 };
+// the per-edge arrays of estimate buffer k (k is wave-uniform: six scalar selects; indexing the kernel argument with a run-time k made
+// hipcc copy the whole 400-byte struct to scratch and every kernel twice as slow)
+using BaEdgeSet = BaDev::BaEdgeSet;
+__device__ __forceinline__ BaEdgeSet ba_set(const BaDev &d, int k) {
+    BaEdgeSet s;
+    s.err = k ? d.sets[1].err : d.sets[0].err; s.Jp = k ? d.sets[1].Jp : d.sets[0].Jp; s.Jx = k ? d.sets[1].Jx : d.sets[0].Jx;
+    s.wo = k ? d.sets[1].wo : d.sets[0].wo; s.rchi = k ? d.sets[1].rchi : d.sets[0].rchi; s.W = k ? d.sets[1].W : d.sets[0].W;
+    return s;
+}
+__device__ __forceinline__ double *ba_poses(const BaDev &d, int k) { return k ? d.poses[1] : d.poses[0]; }
+__device__ __forceinline__ double *ba_points(const BaDev &d, int k) { return k ? d.points[1] : d.points[0]; }
 __device__ __forceinline__ bool ba_lm_idle(const BaDev &d) { return d.lm->done != 0; }
 __device__ __forceinline__ bool ba_lm_skip_lin(const BaDev &d) { return d.lm->done != 0 || d.lm->need_lin == 0; }
 // one thread, behind the sums of a trial (r0 = chi2 of the trial, r4 = the points' share of computeScale)
@@ -637,7 +649,7 @@ __device__ __forceinline__ void ba_lm_decide(const BaDev &d, double r0, double r
         alpha = fmin(alpha, 2. / 3.);
         m.lambda *= fmax(1. / 3., alpha);
         m.ni = 2; m.current = temp;
-        m.cur ^= 1;
+        m.cur ^= 1;                                     // (the trial kernel left errors, Jacobians and W of the new estimate in its set)
     } else {
         m.lambda *= m.ni; m.ni *= 2;
     }
@@ -656,87 +668,84 @@ __device__ __forceinline__ void ba_lm_decide(const BaDev &d, double r0, double r
 // of their own — every block leaves the sum of its edges' robustified chi2 in partial[block]; the block that finishes last
 // (atomic counter) adds the partials in block order (scal[0]) and, with_points, the per-point shares of computeScale
 // (sc_pt, written by the update kernel before this launch: scal[4]).  Fixed order of additions, whichever block is last.
-template <bool JAC>
+// Errors, Jacobians and W of every active edge at an estimate, into the per-edge set of that estimate's buffer.
+// LIN = true: the current estimate — launched ONCE per optimize() call (the flags may have changed since the last one).  LIN = false:
+// a trial estimate — Jacobians and W are formed here as well (+1.5 us on 36 k edges), so that an accepted trial needs no second pass over
+// the edges (until round 5 the next iteration began by evaluating every edge again at the very same estimate).  The set of the current
+// estimate is therefore valid from the first step of a call on: trials write the other set, an accepted trial's set becomes the current one.
+template <bool LIN>
 __global__ __launch_bounds__(BA_T) void ba_edge_kernel(BaDev d, double *partial = nullptr, unsigned *counter = nullptr, int with_points = 0) {
-    if (JAC ? ba_lm_skip_lin(d) : ba_lm_idle(d)) return;
-    // JAC: the current estimate; else the trial
-    const int buf = JAC ? d.lm->cur : d.lm->cur ^ 1;
-    const double *poses = d.poses[buf], *points = d.points[buf];
+    if (ba_lm_idle(d)) return;
+    const int buf = __builtin_amdgcn_readfirstlane(LIN ? d.lm->cur : d.lm->cur ^ 1);
+    const BaEdgeSet es = ba_set(d, buf);
+    const double *poses = ba_poses(d, buf), *points = ba_points(d, buf);
     const int64_t e = (int64_t)blockIdx.x * BA_T + threadIdx.x;
-    if (!JAC && partial) {
-        __shared__ double s_red[BA_T / 64], s_out[1];
-        __shared__ int s_last;
-        double v[1] = {0.0};
-        if (e < d.nE) {
-            if (d.level[e]) {
-                d.rchi[e] = 0.0;
-            } else {
-                const SivoEdge ed = d.edges[e];
-                double er[3], jp[18], jx[9];
-                bool dok;
-                edge_eval<false>(poses + 12 * (int64_t)ed.pose, points + 3 * (int64_t)ed.point, ed, d.K, er, jp, jx, dok);
-                d.err[3 * e] = er[0]; d.err[3 * e + 1] = er[1]; d.err[3 * e + 2] = er[2];
-                const double c2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * ed.inv_sigma2;
-                double r = c2, w = 1.0;
-                if (d.robust[e]) huber(c2, ed.stereo ? d.delta_stereo : d.delta_mono, r, w);
-                d.rchi[e] = r;
-                v[0] = r;
+    double v[1] = {0.0};
+    if (e < d.nE) {
+        if (d.level[e]) {
+            es.rchi[e] = 0.0;
+        } else {
+            const SivoEdge ed = d.edges[e];
+            double er[3], jp[18], jx[9];
+            bool dok;
+            edge_eval<true>(poses + 12 * (int64_t)ed.pose, points + 3 * (int64_t)ed.point, ed, d.K, er, jp, jx, dok);
+            es.err[3 * e] = er[0]; es.err[3 * e + 1] = er[1]; es.err[3 * e + 2] = er[2];
+            const double c2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * ed.inv_sigma2;
+            double r = c2, w = 1.0;
+            if (d.robust[e]) huber(c2, ed.stereo ? d.delta_stereo : d.delta_mono, r, w);
+            es.rchi[e] = r;
+            v[0] = r;
+            const double wo = w * ed.inv_sigma2;
+            es.wo[e] = wo;
+#pragma unroll
+            for (int i = 0; i < 18; ++i) es.Jp[18 * e + i] = jp[i];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) es.Jx[9 * e + i] = jx[i];
+            if (d.slot[ed.pose] >= 0) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        es.W[18 * e + 3 * a + b] = wo * (jp[a] * jx[b] + jp[6 + a] * jx[3 + b] + jp[12 + a] * jx[6 + b]);
             }
         }
-        block_sum<1, BA_T>(v, s_red, s_out);
-        if (threadIdx.x == 0) {
-            partial[blockIdx.x] = s_out[0];
-            __threadfence();
-            s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
-        }
-        __syncthreads();
-        if (!s_last) return;
-        __threadfence();
-        double p[1] = {0.0};
-        for (unsigned i = threadIdx.x; i < gridDim.x; i += BA_T) p[0] += __builtin_nontemporal_load(partial + i);
-        block_sum<1, BA_T>(p, s_red, s_out);
-        const double chi = s_out[0];
-        double sc4 = 0.0;
-        if (threadIdx.x == 0) { d.scal[0] = chi; *counter = 0u; }
-        if (with_points) {
-            double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-            int i = threadIdx.x;
-            for (; i + 3 * BA_T < d.nX; i += 4 * BA_T) { q0 += d.sc_pt[i]; q1 += d.sc_pt[i + BA_T]; q2 += d.sc_pt[i + 2 * BA_T]; q3 += d.sc_pt[i + 3 * BA_T]; }
-            for (; i < d.nX; i += BA_T) q0 += d.sc_pt[i];
-            double q[1] = {(q0 + q1) + (q2 + q3)};
-            block_sum<1, BA_T>(q, s_red, s_out);
-            sc4 = s_out[0];
-            if (threadIdx.x == 0) d.scal[4] = sc4;
-        }
-        if (threadIdx.x == 0) ba_lm_decide(d, chi, sc4, with_points);
+    }
+    if (LIN) {
+        if (e == 0) d.lm->last_set = buf;
         return;
     }
-    if (e >= d.nE) return;
-    if (d.level[e]) { d.rchi[e] = 0.0; return; }
-    const SivoEdge ed = d.edges[e];
-    double er[3], jp[18], jx[9];
-    bool dok;
-    edge_eval<JAC>(poses + 12 * (int64_t)ed.pose, points + 3 * (int64_t)ed.point, ed, d.K, er, jp, jx, dok);
-    d.err[3 * e] = er[0]; d.err[3 * e + 1] = er[1]; d.err[3 * e + 2] = er[2];
-    const double c2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * ed.inv_sigma2;
-    double r = c2, w = 1.0;
-    if (d.robust[e]) huber(c2, ed.stereo ? d.delta_stereo : d.delta_mono, r, w);
-    d.rchi[e] = r;
-    if (JAC) {
-        const double wo = w * ed.inv_sigma2;
-        d.wo[e] = wo;
-#pragma unroll
-        for (int i = 0; i < 18; ++i) d.Jp[18 * e + i] = jp[i];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) d.Jx[9 * e + i] = jx[i];
-        if (d.slot[ed.pose] >= 0) {
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b)
-                    d.W[18 * e + 3 * a + b] = wo * (jp[a] * jx[b] + jp[6 + a] * jx[3 + b] + jp[12 + a] * jx[6 + b]);
-        }
+    // The sums the decision needs are formed here instead of by a launch of their own — every block leaves the sum of its edges'
+    // robustified chi2 in partial[block]; the block that finishes last (atomic counter) adds the partials in block order (scal[0]) and,
+    // with_points, the per-point shares of computeScale (sc_pt, written by the update kernel before this launch: scal[4]).  Fixed order
+    // of additions, whichever block is last.
+    __shared__ double s_red[BA_T / 64], s_out[1];
+    __shared__ int s_last;
+    block_sum<1, BA_T>(v, s_red, s_out);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = s_out[0];
+        __threadfence();
+        s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
     }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    double p[1] = {0.0};
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += BA_T) p[0] += __builtin_nontemporal_load(partial + i);
+    block_sum<1, BA_T>(p, s_red, s_out);
+    const double chi = s_out[0];
+    double sc4 = 0.0;
+    if (threadIdx.x == 0) { d.scal[0] = chi; *counter = 0u; }
+    if (with_points) {
+        double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+        int i = threadIdx.x;
+        for (; i + 3 * BA_T < d.nX; i += 4 * BA_T) { q0 += d.sc_pt[i]; q1 += d.sc_pt[i + BA_T]; q2 += d.sc_pt[i + 2 * BA_T]; q3 += d.sc_pt[i + 3 * BA_T]; }
+        for (; i < d.nX; i += BA_T) q0 += d.sc_pt[i];
+        double q[1] = {(q0 + q1) + (q2 + q3)};
+        block_sum<1, BA_T>(q, s_red, s_out);
+        sc4 = s_out[0];
+        if (threadIdx.x == 0) d.scal[4] = sc4;
+    }
+    if (threadIdx.x == 0) { d.lm->last_set = buf; ba_lm_decide(d, chi, sc4, with_points); }
 }
 
 // out[0] = sum(in[0..n)) in a fixed order; one workgroup per sum (blockIdx.x = 1: the second sum, when given).  Four independent
@@ -767,7 +776,7 @@ __device__ __forceinline__ void ba_lanes_sum(double (&v)[K]) {
         v[k] += __shfl_xor(v[k], 2, 64);
     }
 }
-__device__ __forceinline__ void ba_point_body(const BaDev &d, int block) {
+__device__ __forceinline__ void ba_point_body(const BaDev &d, const BaEdgeSet &es, int block) {
     const int t = block * BA_BUILD_T + threadIdx.x, sub = t & (BA_PL - 1);
     const int q = t / BA_PL < d.nX ? t / BA_PL : d.nX - 1;          // (surplus lanes repeat the last point and do not store: every lane takes part in the butterfly)
     const bool mine = t / BA_PL < d.nX && sub == 0;
@@ -775,8 +784,8 @@ __device__ __forceinline__ void ba_point_body(const BaDev &d, int block) {
     for (int64_t i = d.pt_off[q] + sub; i < d.pt_off[q + 1]; i += BA_PL) {
         const int e = d.pt_edges[i];
         if (d.level[e]) continue;
-        const double wo = d.wo[e];
-        const double *jx = d.Jx + 9 * (int64_t)e, *er = d.err + 3 * (int64_t)e;
+        const double wo = es.wo[e];
+        const double *jx = es.Jx + 9 * (int64_t)e, *er = es.err + 3 * (int64_t)e;
         int k = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a)
@@ -794,7 +803,7 @@ __device__ __forceinline__ void ba_point_body(const BaDev &d, int block) {
 }
 
 // Hpp, bp of one free pose per workgroup
-__device__ __forceinline__ void ba_pose_body(const BaDev &d, int s) {
+__device__ __forceinline__ void ba_pose_body(const BaDev &d, const BaEdgeSet &es, int s) {
     __shared__ double s_red[(BA_BUILD_T / 64) * 32], s_out[27];
     double acc[27];
 #pragma unroll
@@ -802,8 +811,8 @@ __device__ __forceinline__ void ba_pose_body(const BaDev &d, int s) {
     for (int64_t i = d.ps_off[s] + threadIdx.x; i < d.ps_off[s + 1]; i += BA_BUILD_T) {
         const int e = d.ps_edges[i];
         if (d.level[e]) continue;
-        const double wo = d.wo[e];
-        const double *jp = d.Jp + 18 * (int64_t)e, *er = d.err + 3 * (int64_t)e;
+        const double wo = es.wo[e];
+        const double *jp = es.Jp + 18 * (int64_t)e, *er = es.err + 3 * (int64_t)e;
         int k = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
@@ -826,15 +835,16 @@ __device__ __forceinline__ void ba_pose_body(const BaDev &d, int s) {
 // (Three launches before: 9 + 21 + 25 us back to back on a 36 k-edge problem, each mostly latency.)
 __global__ __launch_bounds__(BA_BUILD_T) void ba_build_kernel(BaDev d, int point_blocks) {
     if (ba_lm_skip_lin(d)) return;
+    const BaEdgeSet es = ba_set(d, __builtin_amdgcn_readfirstlane(d.lm->cur));
     const int b = blockIdx.x;
-    if (b < point_blocks) { ba_point_body(d, b); return; }
-    if (b < point_blocks + d.nF) { ba_pose_body(d, b - point_blocks); return; }
+    if (b < point_blocks) { ba_point_body(d, es, b); return; }
+    if (b < point_blocks + d.nF) { ba_pose_body(d, es, b - point_blocks); return; }
     constexpr int T_ = BA_BUILD_T;
     __shared__ double s_red[T_ / 64], s_out[1];
     double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
     int64_t i = threadIdx.x;
-    for (; i + 3 * T_ < d.nE; i += 4 * T_) { p0 += d.rchi[i]; p1 += d.rchi[i + T_]; p2 += d.rchi[i + 2 * T_]; p3 += d.rchi[i + 3 * T_]; }
-    for (; i < d.nE; i += T_) p0 += d.rchi[i];
+    for (; i + 3 * T_ < d.nE; i += 4 * T_) { p0 += es.rchi[i]; p1 += es.rchi[i + T_]; p2 += es.rchi[i + 2 * T_]; p3 += es.rchi[i + 3 * T_]; }
+    for (; i < d.nE; i += T_) p0 += es.rchi[i];
     double v[1] = {(p0 + p1) + (p2 + p3)};
     block_sum<1, T_>(v, s_red, s_out);
     if (threadIdx.x == 0) d.scal[6] = s_out[0];
@@ -874,30 +884,16 @@ __device__ __forceinline__ void ba_point_inverse(const BaDev &d, int q, double l
     Ai[6] = c2 * id; Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id; Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
 }
 
-// Y_e = W_e Hll^-1 for every active edge that touches a free keyframe (one thread per edge)
-__global__ __launch_bounds__(BA_T) void ba_edge_y_kernel(BaDev d) {
-    if (ba_lm_idle(d)) return;
-    const double lambda = d.lm->lambda;
-    const int64_t e = (int64_t)blockIdx.x * BA_T + threadIdx.x;
-    if (e >= d.nE || d.level[e]) return;
-    const SivoEdge ed = d.edges[e];
-    if (d.slot[ed.pose] < 0) return;
-    const double *W = d.W + 18 * e;
-    double A9[9];
-    ba_point_inverse(d, ed.point, lambda, A9);
-    double *Y = d.Y + 18 * e;
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) Y[3 * a + b] = W[3 * a] * A9[b] + W[3 * a + 1] * A9[3 + b] + W[3 * a + 2] * A9[6 + b];
-}
-
 // S block (i, j), i <= j:  [i == j] (Hpp_i + lambda I)  -  sum_q Y_{e(i,q)} W_{e(j,q)}' ; rhs_i = bp_i - sum_q Y_{e(i,q)} bl_q
 // (1024 threads per block — 3 points per thread instead of 12 — was measured in round 3: the whole call went from 3.4 to 3.9 ms;
 // the 42-value block reduction over 16 waves costs more than the shorter chains of dependent loads save)
 constexpr int BA_SCHUR_T = 512;       // a pair of keyframes shares up to nX points and every thread walks a chain of dependent loads per point: 6 points per thread (42 f64 accumulators: 1024 threads would spill)
+// (Round 6: Y_e = W_e (Hll_q + lambda I)^-1 is formed here, where it is used — 9 more loads that do not depend on the table chain, ~100 flops —
+// instead of by a launch of its own over the edges that wrote 144 bytes per edge for this kernel to read back; the same expression, so the
+// same doubles.)
 __global__ __launch_bounds__(BA_SCHUR_T) void ba_schur_kernel(BaDev d) {
     if (ba_lm_idle(d)) return;
+    const double *Wc = ba_set(d, __builtin_amdgcn_readfirstlane(d.lm->cur)).W;
     const double lambda = d.lm->lambda;
     __shared__ double s_red[(BA_SCHUR_T / 64) * 64], s_out[42];
     // block index -> (i, j) of the upper triangle
@@ -930,14 +926,23 @@ __global__ __launch_bounds__(BA_SCHUR_T) void ba_schur_kernel(BaDev d) {
         for (int u = 0; u < SCH_U; ++u) {
             if (!on1[u]) continue;
             const int q = q0 + u * BA_SCHUR_T;
-            const double *Y = d.Y + 18 * (int64_t)e1[u];
+            double Y[18];
+            {
+                const double *W1 = Wc + 18 * (int64_t)e1[u];
+                double A9[9];
+                ba_point_inverse(d, q, lambda, A9);
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) Y[3 * a + b] = W1[3 * a] * A9[b] + W1[3 * a + 1] * A9[3 + b] + W1[3 * a + 2] * A9[6 + b];
+            }
             if (i == j) {
                 const double *bl = d.bl + 3 * (int64_t)q;
 #pragma unroll
                 for (int a = 0; a < 6; ++a) acc[36 + a] += Y[3 * a] * bl[0] + Y[3 * a + 1] * bl[1] + Y[3 * a + 2] * bl[2];
             }
             if (!on2[u]) continue;
-            const double *W = d.W + 18 * (int64_t)e2[u];
+            const double *W = Wc + 18 * (int64_t)e2[u];
 #pragma unroll
             for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -1067,49 +1072,24 @@ __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_kernel(BaDev d) {
 //     inverse).
 // 3 barriers per keyframe in all instead of 7.  LDS: (n + 1)^2 + 21 nF doubles <= 133 KB.
 __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_lds_kernel(BaDev d) {
+    // (Round 6, tried and removed: the trailing matrix in REGISTERS, one 6 x 6 block per thread for the whole factorisation — 72 LDS
+    // reads and no write per block and step instead of 8 LDS operations per element.  72 us instead of 61: a thread then updates its
+    // whole block in EVERY step, 20 x 36 elements in series, where this form spreads the shrinking trailing matrix evenly over the
+    // 256 threads — 195 elements per thread in all.  profiles/r06_h_kernel_stats_ba.csv.)
     if (ba_lm_idle(d)) return;
-    extern __shared__ double s_mat[];          // rows 0 .. n - 1: the factor L (lower triangle, column block by column block); row n: y
+    extern __shared__ double s_mat[];          // rows 0 .. n - 1: the matrix (lower triangle); row n: the right-hand side
     __shared__ double s_li[21 * 21];           // inverse of each diagonal block's Cholesky factor, packed lower triangle
     const int nb = d.nF, n = 6 * nb, tid = threadIdx.x;
-    const int ld = n + 1;                      // odd row stride: the rows of a panel fall on different banks
-    // Round 6: the TRAILING MATRIX LIVES IN REGISTERS.  Thread t owns one 6 x 6 block (I, K), K <= I, of the lower triangle — or the six
-    // right-hand-side values under column block K (I = nb) — for the whole factorisation: nb (nb + 1) / 2 + nb <= 252 blocks for the <= 21
-    // keyframes this kernel takes.  LDS holds only what is exchanged: the diagonal block of the step (published by its owner), and the
-    // finished panels = L itself, which the backward substitution reads afterwards.  Per step and thread the update is 72 LDS reads
-    // and no LDS write (the round-5 form kept the matrix in LDS: 7 reads + 1 write per ELEMENT, 288 per block); every sum has the
-    // same terms in the same order as before, so the solution is bit-identical.
-    int I = 0, K = tid;
-    while (I <= nb && K >= (I < nb ? I + 1 : nb)) { K -= (I < nb ? I + 1 : nb); ++I; }
-    const bool active = I <= nb, rhs = I == nb;
-    double B[6][6];
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int b = 0; b < 6; ++b) B[a][b] = 0.0;
-    if (active) {
-        if (rhs) {
-#pragma unroll
-            for (int b = 0; b < 6; ++b) B[0][b] = d.xs[6 * K + b];
-        } else {
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int b = 0; b < 6; ++b) B[a][b] = d.S[(int64_t)(6 * I + a) * n + 6 * K + b];
-        }
-    }
-    auto publish_diag = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = 0; b <= a; ++b) s_mat[(6 * I + a) * ld + 6 * K + b] = B[a][b];
-    };
-    if (active && I == 0 && K == 0) publish_diag();
-    // LDS rows of this thread's block rows (the right-hand side is row n; its unused rows 1 .. 5 alias row n and are never stored)
-    const int row0 = rhs ? n : 6 * I;
+    // row stride n + 1 doubles (odd): the trailing update reads element (k, j0 + c) of 16 consecutive rows k at once, and with a
+    // stride of n = 6 nF doubles those fall on 4 bank pairs (48 k mod 64), a 4-way conflict on the kernel's dominant access
+    const int ld = n + 1;
+    for (int i = tid >> 4; i < n; i += BA_SOLVE_T / 16)
+        for (int k = tid & 15; k <= i; k += 16) s_mat[i * ld + k] = d.S[(int64_t)i * n + k];
+    for (int i = tid; i < n; i += BA_SOLVE_T) s_mat[n * ld + i] = d.xs[i];
+    __syncthreads();
     bool ok = true;
-    for (int jb = 0; jb < nb; ++jb) {
+    for (int jb = 0; jb < nb && ok; ++jb) {
         const int j0 = 6 * jb;
-        __syncthreads();                       // the diagonal block of this step is in LDS
         double l[6][6], li[6][6];
 #pragma unroll
         for (int i = 0; i < 6; ++i)
@@ -1151,48 +1131,36 @@ __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_lds_kernel(BaDev d)
 #pragma unroll
                 for (int j = 0; j <= i; ++j) s_li[21 * jb + k++] = li[i][j];
         }
-        // panel: L_ij = S_ij L_jj^-T for the blocks below the diagonal, and for the right-hand side: y_j = L_jj^-1 b_j — finished, to LDS
-        if (active && K == jb && I > jb) {
+        // panel: L_ij = S_ij L_jj^-T for the rows below the block, and for the right-hand side (row n): y_j = L_jj^-1 b_j
+        for (int i = j0 + 6 + tid; i <= n; i += BA_SOLVE_T) {
+            double *row = s_mat + i * ld + j0;
+            double sv[6];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                if (a == 0 || !rhs) {
-                    double *row = s_mat + (row0 + a) * ld + j0;
+            for (int c = 0; c < 6; ++c) sv[c] = row[c];
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        double r = 0;
+            for (int c = 0; c < 6; ++c) {
+                double r = 0;
 #pragma unroll
-                        for (int k = 0; k <= c; ++k) r += B[a][k] * li[c][k];
-                        row[c] = r;
-                    }
-                }
+                for (int k = 0; k <= c; ++k) r += sv[k] * li[c][k];
+                row[c] = r;
             }
         }
         __syncthreads();
-        // trailing update of this thread's block: S_IK -= L_I,jb L_K,jb'
-        if (active && K > jb) {
-            double lk[6][6];
+        // trailing update, rows j0 + 6 .. n (the right-hand side included), columns j0 + 6 .. min(row, n - 1)
+        for (int i = j0 + 6 + (tid >> 4); i <= n; i += BA_SOLVE_T / 16) {
+            double ri[6];
 #pragma unroll
-            for (int b = 0; b < 6; ++b)
+            for (int c = 0; c < 6; ++c) ri[c] = s_mat[i * ld + j0 + c];
+            const int kend = i < n ? i : n - 1;
+            for (int k = j0 + 6 + (tid & 15); k <= kend; k += 16) {
+                double v = 0;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) lk[b][c] = s_mat[(6 * K + b) * ld + j0 + c];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                double ri[6];
-                const int r = rhs ? n : row0 + a;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) ri[c] = s_mat[r * ld + j0 + c];
-#pragma unroll
-                for (int b = 0; b < 6; ++b) {
-                    double v = 0;
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) v += ri[c] * lk[b][c];
-                    B[a][b] -= v;
-                }
+                for (int c = 0; c < 6; ++c) v += ri[c] * s_mat[k * ld + j0 + c];
+                s_mat[i * ld + k] -= v;
             }
-            if (I == jb + 1 && K == jb + 1) publish_diag();
         }
+        __syncthreads();
     }
-    __syncthreads();
     if (ok) {
         double *y = s_mat + n * ld;
         for (int jb = nb - 1; jb >= 0; --jb) {         // L' x = y, one keyframe per step
@@ -1231,7 +1199,7 @@ __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_lds_kernel(BaDev d)
 }
 
 // dx_l = Hll^-1 (bl - sum_e W_e' dx_p), points_trial = points + dx_l, per-point share of computeScale
-__device__ __forceinline__ void ba_point_update_body(const BaDev &d, int block, double lambda, const double *points, double *points_trial) {
+__device__ __forceinline__ void ba_point_update_body(const BaDev &d, const double *Wc, int block, double lambda, const double *points, double *points_trial) {
     const int t = block * BA_T + threadIdx.x, sub = t & (BA_PL - 1);
     const int q = t / BA_PL < d.nX ? t / BA_PL : d.nX - 1;
     const bool mine = t / BA_PL < d.nX && sub == 0;
@@ -1244,7 +1212,7 @@ __device__ __forceinline__ void ba_point_update_body(const BaDev &d, int block, 
             if (d.level[e]) continue;
             const int s = d.slot[d.edges[e].pose];
             if (s < 0) continue;
-            const double *W = d.W + 18 * (int64_t)e, *xp = d.xs + 6 * s;
+            const double *W = Wc + 18 * (int64_t)e, *xp = d.xs + 6 * s;
 #pragma unroll
             for (int b = 0; b < 3; ++b)
 #pragma unroll
@@ -1294,10 +1262,10 @@ __device__ __forceinline__ void ba_pose_update_body(const BaDev &d, double lambd
 // the trial estimates in one launch: block 0 the poses, the others the points
 __global__ __launch_bounds__(BA_T) void ba_update_kernel(BaDev d) {
     if (ba_lm_idle(d)) return;
+    const int cur = __builtin_amdgcn_readfirstlane(d.lm->cur);
     const double lambda = d.lm->lambda;
-    const int cur = d.lm->cur;
-    if (blockIdx.x == 0) ba_pose_update_body(d, lambda, d.poses[cur], d.poses[cur ^ 1]);
-    else ba_point_update_body(d, (int)blockIdx.x - 1, lambda, d.points[cur], d.points[cur ^ 1]);
+    if (blockIdx.x == 0) ba_pose_update_body(d, lambda, ba_poses(d, cur), ba_poses(d, cur ^ 1));
+    else ba_point_update_body(d, ba_set(d, cur).W, (int)blockIdx.x - 1, lambda, ba_points(d, cur), ba_points(d, cur ^ 1));
 }
 
 // pose-only variant of the reduced system (no landmarks in the state): S = blockdiag(Hpp + lambda I), xs = bp
@@ -1319,7 +1287,7 @@ __global__ __launch_bounds__(BA_T) void ba_classify_kernel(BaDev d, const double
     const int64_t e = (int64_t)blockIdx.x * BA_T + threadIdx.x;
     if (e >= d.nE) return;
     const SivoEdge ed = d.edges[e];
-    const double *er = d.err + 3 * e;
+    const double *er = (d.lm->last_set ? d.sets[1].err : d.sets[0].err) + 3 * e;          // the errors of the last evaluation, as g2o's edges hold them
     const double c2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * ed.inv_sigma2;
     const double *R = poses + 12 * (int64_t)ed.pose, *X = points + 3 * (int64_t)ed.point;
     const double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + R[11];
@@ -1352,6 +1320,24 @@ struct BaArena {
     }
 };
 static thread_local BaArena t_arena;
+// Per-thread, grow-only pinned staging buffer for a solver's one upload (a pinned allocation costs ~0.2 ms: never per call).  Its content
+// is in flight until the call's first blocking read (the LM state after the first batch of steps), which every call makes before it returns.
+struct BaStage {
+    char *p = nullptr;
+    size_t cap = 0;
+    ~BaStage() { if (p) (void)hipHostFree(p); }
+    char *reserve(size_t bytes) {
+        if (bytes > cap) {
+            if (p) SIVO_HIP(hipHostFree(p));
+            p = nullptr; cap = 0;
+            const size_t want = std::max(bytes * 2, (size_t)8 << 20);
+            SIVO_HIP(hipHostMalloc((void **)&p, want, hipHostMallocDefault));
+            cap = want;
+        }
+        return p;
+    }
+};
+static thread_local BaStage t_stage;
 
 struct Buf {
     void *p = nullptr;
@@ -1430,23 +1416,42 @@ class BaSolver {
                 }
             }
         }
-        slot_.upload(slot.data(), slot.size() * 4);
-        pt_off_.upload(pt_off.data(), pt_off.size() * 8); pt_edges_.upload(pt_edges.data(), pt_edges.size() * 4);
-        ps_off_.upload(ps_off.data(), ps_off.size() * 8); ps_edges_.upload(ps_edges.data(), ps_edges.size() * 4);
-        table_.upload(table.data(), table.size() * 4);
-        edges_.upload(edges, (size_t)nE * sizeof(SivoEdge));
-        level_.zero((size_t)nE); robust_.alloc((size_t)nE);
-        SIVO_HIP(hipMemset(robust_.p, 1, (size_t)std::max<int64_t>(nE, 1)));
-        for (int k = 0; k < 2; ++k) { poses_[k].upload(poses, (size_t)nP * 96); points_[k].upload(points, (size_t)nX * 24); }
-        err_.zero((size_t)nE * 24); Jp_.alloc((size_t)nE * 144); Jx_.alloc((size_t)nE * 72); wo_.alloc((size_t)nE * 8);
-        rchi_.zero((size_t)nE * 8); W_.alloc((size_t)nE * 144); Y_.alloc((size_t)nE * 144);
+        // ONE staged copy and ONE memset for the whole problem (round 6): the eleven uploads and thirteen memsets this constructor made until
+        // round 5 were 24 blocking calls of ~15 us each — a tenth of the LocalBundleAdjustment call.  The host arrays are packed into the
+        // calling thread's pinned staging buffer and go over in one asynchronous copy; everything that starts at zero is one region.
+        {
+            struct Seg { Buf *b; const void *src; size_t bytes; };
+            const Seg up[] = {{&slot_, slot.data(), slot.size() * 4}, {&pt_off_, pt_off.data(), pt_off.size() * 8}, {&pt_edges_, pt_edges.data(), pt_edges.size() * 4},
+                              {&ps_off_, ps_off.data(), ps_off.size() * 8}, {&ps_edges_, ps_edges.data(), ps_edges.size() * 4}, {&table_, table.data(), table.size() * 4},
+                              {&edges_, edges, (size_t)nE * sizeof(SivoEdge)}, {&poses_[0], poses, (size_t)nP * 96}, {&poses_[1], poses, (size_t)nP * 96},
+                              {&points_[0], points, (size_t)nX * 24}, {&points_[1], points, (size_t)nX * 24}};
+            auto pad = [](size_t n) { return (std::max<size_t>(n, 8) + 255) / 256 * 256; };
+            size_t total = 0;
+            for (const Seg &g : up) total += pad(g.bytes);
+            char *dev = (char *)t_arena.take(total), *host = t_stage.reserve(total);
+            size_t off = 0;
+            for (const Seg &g : up) {
+                if (g.bytes) std::memcpy(host + off, g.src, g.bytes);
+                g.b->p = dev + off;
+                off += pad(g.bytes);
+            }
+            SIVO_HIP(hipMemcpyAsync(dev, host, total, hipMemcpyHostToDevice, 0));
+            struct Z { Buf *b; size_t bytes; };
+            const Z zs[] = {{&level_, (size_t)nE}, {&err_[0], (size_t)nE * 24}, {&err_[1], (size_t)nE * 24}, {&rchi_[0], (size_t)nE * 8}, {&rchi_[1], (size_t)nE * 8},
+                            {&sc_pt_, (size_t)nX * 8}, {&Hpp_, (size_t)nF_ * 288}, {&bp_, (size_t)nF_ * 48}, {&xs_, (size_t)nF_ * 48}, {&scal_, 8 * 8},
+                            {&partial_, (size_t)cdiv64(std::max<int64_t>(nE, 1), BA_T) * 8}, {&counter_, 8}, {&lm_, sizeof(BaLm)}};
+            size_t ztotal = 0;
+            for (const Z &z : zs) ztotal += pad(z.bytes);
+            char *zdev = (char *)t_arena.take(ztotal);
+            off = 0;
+            for (const Z &z : zs) { z.b->p = zdev + off; off += pad(z.bytes); }
+            SIVO_HIP(hipMemsetAsync(zdev, 0, ztotal, 0));
+        }
+        robust_.alloc((size_t)nE);
+        SIVO_HIP(hipMemsetAsync(robust_.p, 1, (size_t)std::max<int64_t>(nE, 1), 0));
+        for (int k = 0; k < 2; ++k) { Jp_[k].alloc((size_t)nE * 144); Jx_[k].alloc((size_t)nE * 72); wo_[k].alloc((size_t)nE * 8); W_[k].alloc((size_t)nE * 144); }
         Hll_.alloc((size_t)nX * 72); bl_.alloc((size_t)nX * 24); xl_.alloc((size_t)nX * 24);
-        sc_pt_.zero((size_t)nX * 8);
-        Hpp_.zero((size_t)nF_ * 288); bp_.zero((size_t)nF_ * 48);
-        S_.alloc((size_t)36 * nF_ * nF_ * 8); xs_.zero((size_t)nF_ * 48);
-        scal_.zero(8 * 8);
-        partial_.zero((size_t)cdiv64(std::max<int64_t>(nE, 1), BA_T) * 8); counter_.zero(8);
-        lm_.zero(sizeof(BaLm));
+        S_.alloc((size_t)36 * nF_ * nF_ * 8);
         hpp_last_.assign((size_t)std::max(nF_, 1) * 36, 0.0);
         d_.edges = edges_.as<SivoEdge>(); d_.nE = nE; d_.slot = slot_.as<int32_t>();
         d_.level = level_.as<uint8_t>(); d_.robust = robust_.as<uint8_t>();
@@ -1454,8 +1459,10 @@ class BaSolver {
         d_.K = Intr{intr[0], intr[1], intr[2], intr[3], intr[4]}; d_.delta_mono = dm; d_.delta_stereo = ds;
         d_.pt_off = pt_off_.as<int64_t>(); d_.pt_edges = pt_edges_.as<int32_t>();
         d_.ps_off = ps_off_.as<int64_t>(); d_.ps_edges = ps_edges_.as<int32_t>(); d_.table = table_.as<int32_t>();
-        d_.err = err_.as<double>(); d_.Jp = Jp_.as<double>(); d_.Jx = Jx_.as<double>(); d_.wo = wo_.as<double>();
-        d_.rchi = rchi_.as<double>(); d_.W = W_.as<double>(); d_.Y = Y_.as<double>();
+        for (int k = 0; k < 2; ++k) {
+            d_.sets[k].err = err_[k].as<double>(); d_.sets[k].Jp = Jp_[k].as<double>(); d_.sets[k].Jx = Jx_[k].as<double>();
+            d_.sets[k].wo = wo_[k].as<double>(); d_.sets[k].rchi = rchi_[k].as<double>(); d_.sets[k].W = W_[k].as<double>();
+        }
         d_.Hll = Hll_.as<double>(); d_.bl = bl_.as<double>(); d_.xl = xl_.as<double>();
         d_.sc_pt = sc_pt_.as<double>(); d_.Hpp = Hpp_.as<double>(); d_.bp = bp_.as<double>();
         d_.S = S_.as<double>(); d_.xs = xs_.as<double>(); d_.scal = scal_.as<double>();
@@ -1487,20 +1494,20 @@ class BaSolver {
             d_.abort = nullptr;
         }
         BaLm lm{};
-        lm.ni = 2; lm.cur = cur_; lm.need_lin = 1; lm.first = 1; lm.it_limit = iterations;
+        lm.ni = 2; lm.cur = cur_; lm.need_lin = 1; lm.first = 1; lm.it_limit = iterations; lm.last_set = last_set_;
         SIVO_HIP(hipMemcpyAsync(d_.lm, &lm, sizeof lm, hipMemcpyHostToDevice, 0));          // (pageable source: the copy is staged before the call returns)
         if (!nF_) { const double one = 1.0; SIVO_HIP(hipMemcpyAsync(d_.scal + 3, &one, 8, hipMemcpyHostToDevice, 0)); }      // nothing to solve: "ok"
         const bool lds_solve = 6 * nF_ <= 126 && dense_solve_lds_ok();
         auto step = [&](bool first_of_call) {
-            // linearise at the current estimate (skipped by the kernels themselves while trials of the same iteration go on): errors,
-            // Jacobians, W; Hll / bl of the points, Hpp / bp of the free poses, chi2 of the linearisation point (scal[6])
-            hipLaunchKernelGGL(ba_edge_kernel<true>, dim3(gE), dim3(BA_T), 0, 0, d_, (double *)nullptr, (unsigned *)nullptr, 0);
+            // linearise at the current estimate: errors, Jacobians, W (first step of a call only: afterwards the accepted trial left them);
+            // Hll / bl of the points, Hpp / bp of the free poses, chi2 of the linearisation point (scal[6]) — skipped by the kernel itself
+            // while trials of the same iteration go on
+            if (first_of_call) hipLaunchKernelGGL(ba_edge_kernel<true>, dim3(gE), dim3(BA_T), 0, 0, d_, (double *)nullptr, (unsigned *)nullptr, 0);
             hipLaunchKernelGGL(ba_build_kernel, dim3((landmarks ? gXb : 0u) + (unsigned)nF_ + 1u), dim3(BA_BUILD_T), 0, 0, d_, landmarks ? (int)gXb : 0);
             if (first_of_call) hipLaunchKernelGGL(ba_maxdiag_kernel, dim3(1), dim3(1024), 0, 0, d_, landmarks ? 1 : 0);
             // one trial
             if (nF_) {
                 if (landmarks) {
-                    hipLaunchKernelGGL(ba_edge_y_kernel, dim3(gE), dim3(BA_T), 0, 0, d_);
                     hipLaunchKernelGGL(ba_schur_kernel, dim3((unsigned)(nF_ * (nF_ + 1) / 2)), dim3(BA_SCHUR_T), 0, 0, d_);
                 } else {
                     hipLaunchKernelGGL(ba_pose_only_system_kernel, dim3(64), dim3(256), 0, 0, d_);
@@ -1530,10 +1537,8 @@ class BaSolver {
             SIVO_HIP(hipMemcpy(&lm, d_.lm, sizeof lm, hipMemcpyDeviceToHost));
             if (lm.done || steps_total > 10 * iterations + 1) break;
         }
-        cur_ = lm.cur;
+        cur_ = lm.cur; last_set_ = lm.last_set;
         if (trials) *trials += lm.trials;
-        // H_pp of the last linearisation (computeMarginals inverts its block, Optimizer.cc:482-487, 900-907)
-        if (nF_) SIVO_HIP(hipMemcpy(hpp_last_.data(), d_.Hpp, (size_t)nF_ * 288, hipMemcpyDeviceToHost));
         return lm.it;
     }
 
@@ -1541,21 +1546,26 @@ class BaSolver {
     void classify(uint8_t *outlier_host, bool to_level, bool drop_kernels) {
         if (!nE_) return;
         Buf out;
-        out.alloc((size_t)nE_);
+        if (to_level && !outlier_host) out.p = level_.p;          // (the kernel does not read the flags it replaces)
+        else out.alloc((size_t)nE_);
         hipLaunchKernelGGL(ba_classify_kernel, dim3((unsigned)cdiv64(nE_, BA_T)), dim3(BA_T), 0, 0, d_,
                            (const double *)poses_[cur_].p, (const double *)points_[cur_].p, out.as<uint8_t>());
         SIVO_HIP(hipGetLastError());
-        if (to_level) SIVO_HIP(hipMemcpy(level_.p, out.p, (size_t)nE_, hipMemcpyDeviceToDevice));
-        if (drop_kernels) SIVO_HIP(hipMemset(robust_.p, 0, (size_t)nE_));
+        if (to_level && out.p != level_.p) SIVO_HIP(hipMemcpyAsync(level_.p, out.p, (size_t)nE_, hipMemcpyDeviceToDevice, 0));
+        if (drop_kernels) SIVO_HIP(hipMemsetAsync(robust_.p, 0, (size_t)nE_, 0));
         if (outlier_host) SIVO_HIP(hipMemcpy(outlier_host, out.p, (size_t)nE_, hipMemcpyDeviceToHost));
     }
 
     void download(double *poses, double *points, double *err) const {
         if (poses && nP_) SIVO_HIP(hipMemcpy(poses, poses_[cur_].p, (size_t)nP_ * 96, hipMemcpyDeviceToHost));
         if (points && nX_ && !points_fixed_) SIVO_HIP(hipMemcpy(points, points_[cur_].p, (size_t)nX_ * 24, hipMemcpyDeviceToHost));
-        if (err && nE_) SIVO_HIP(hipMemcpy(err, err_.p, (size_t)nE_ * 24, hipMemcpyDeviceToHost));
+        if (err && nE_) SIVO_HIP(hipMemcpy(err, err_[last_set_].p, (size_t)nE_ * 24, hipMemcpyDeviceToHost));
     }
-    const std::vector<double> &hpp_last() const { return hpp_last_; }
+    // H_pp of the last linearisation (computeMarginals inverts its block, Optimizer.cc:482-487, 900-907); fetched when asked for
+    const std::vector<double> &hpp_last() {
+        if (nF_) SIVO_HIP(hipMemcpy(hpp_last_.data(), d_.Hpp, (size_t)nF_ * 288, hipMemcpyDeviceToHost));
+        return hpp_last_;
+    }
     int free_slot(int pose) const { return pose >= 0 && pose < nP_ ? slot_host_[pose] : -1; }
     int n_free() const { return nF_; }
 
@@ -1565,7 +1575,8 @@ class BaSolver {
     bool points_fixed_;
     int cur_ = 0;
     Buf slot_, pt_off_, pt_edges_, ps_off_, ps_edges_, table_, edges_, level_, robust_, poses_[2], points_[2];
-    Buf err_, Jp_, Jx_, wo_, rchi_, W_, Y_, Hll_, bl_, xl_, sc_pt_, Hpp_, bp_, S_, xs_, scal_, partial_, counter_, lm_;
+    Buf err_[2], Jp_[2], Jx_[2], wo_[2], rchi_[2], W_[2], Hll_, bl_, xl_, sc_pt_, Hpp_, bp_, S_, xs_, scal_, partial_, counter_, lm_;
+    int last_set_ = 0;
     int *abort_host_ = nullptr;            // (the calling thread's pinned word, BaStopCtx)
     std::vector<double> hpp_last_;
     std::vector<int32_t> slot_host_;

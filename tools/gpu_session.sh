@@ -46,6 +46,9 @@ PY
 ;;
     ba) timeout 900 python -m pytest tests/test_gpu_ba_solve.py tests/test_pin_optimizer.py tests/test_gpu_match_ba.py tests/test_cpp_api.py -m gpu -q > $O/ba_tests.log 2>&1; echo "ba tests rc=$?"; tail -4 $O/ba_tests.log
         timeout 300 python tests/tools/ba_bench.py > $O/ba_bench.json 2> $O/ba_bench.err; cut -c1-900 $O/ba_bench.json
+        timeout 120 python tools/ba_probe.py 30 2>/dev/null | tee $O/ba_probe.log
+        rm -rf /tmp/prof_ba; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ba -o ba -- python $R/tools/ba_probe.py 10 > /dev/null 2>&1)
+        f=$(find /tmp/prof_ba -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_ba.csv && head -14 $O/kernel_stats_ba.csv | cut -c1-170
         timeout 300 python bench.py --configs ba --no-cpu-baseline --no-orb --steps 3 --warmup 1 > $O/bench_ba.json 2> $O/bench_ba.err; python - <<PY
 import json
 try:
