@@ -292,11 +292,10 @@ def membound_block(prof, fp, d_left, H, W, T, classes):
         fp.ex_l.profile(False)
         n = max(keys, 1.0)
         small = "working set 0.3-2 MB: launch / latency bound by construction (0.04-0.3 us at 8 TB/s)"
-        row("sivo::copy_level0_kernel + 7 x resize_kernel (pyramid)", 1e3 * ms["pyramid"], 2 * area[0] + sum(area[:-1]) + sum(area[1:]), small)
-        row("sivo::blur_kernel + border_kernel (all levels)", 1e3 * ms["blur"], 2 * pyr + (padded - pyr), small)
-        row("sivo::fast_cells_kernel + scan + compact (FAST-9/16, all levels)", 1e3 * ms["fast"], pyr + 3 * 4 * 20000, small)
-        row("sivo::angle_kernel (IC_Angle)", 1e3 * ms["angle"], n * (749 + 4), small)
-        row("sivo::descriptor_kernel (rBRIEF)", 1e3 * ms["descriptor"], n * (512 + 32), small)
+        row("sivo::pyramid_kernel (all 8 levels, one launch)", 1e3 * ms["pyramid"], 2 * area[0] + sum(area[:-1]) + sum(area[1:]), small)
+        row("sivo::blur_border_kernel (all levels)", 1e3 * ms["blur"], 2 * pyr + (padded - pyr), small)
+        row("sivo::fast_cells_kernel (FAST-9/16 + scan + ordered emission, all levels)", 1e3 * ms["fast"], pyr + 2 * 4 * 20000, small)
+        row("sivo::orient_describe_kernel (IC_Angle + rBRIEF)", 1e3 * ms["angle"], n * (749 + 512 + 36), small)
     rng = np.random.default_rng(0)
     A = torch.from_numpy(rng.integers(0, 256, (2000, 32), dtype=np.uint8)).cuda()
     B = torch.from_numpy(rng.integers(0, 256, (2000, 32), dtype=np.uint8)).cuda()

@@ -1152,6 +1152,9 @@ __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_lds_kernel(BaDev d)
 #pragma unroll
             for (int c = 0; c < 6; ++c) ri[c] = s_mat[i * ld + j0 + c];
             const int kend = i < n ? i : n - 1;
+            // (Round 6, tried and removed: four elements per pass with every operand read before anything is written — the panel columns (read) and
+            // the trailing columns (written) never overlap, which hipcc cannot know.  65.8 us instead of 59.8: with one wave per SIMD the 24 + 4
+            // reads in flight cost more registers and address arithmetic than the serialisation they remove; profiles/r06_k_kernel_stats_ba_unrolled_trailing.csv.)
             for (int k = j0 + 6 + (tid & 15); k <= kend; k += 16) {
                 double v = 0;
 #pragma unroll

@@ -13,11 +13,17 @@
 // polynomial with explicitly unfused float ops) — see oracle/orb_oracle.c for the
 // same definitions on the CPU.
 //
-// Per image:  pyramid (1 copy + 7 resize launches, level l needs l-1) -> border (1) ->
-// FAST per 30-px cell incl. the iniTh/minTh fallback and per-cell NMS (1) -> scan +
-// ordered compaction (2) -> D2H candidates -> host quadtree (orb_host.cpp)
-//            blur of all levels (1 launch, overlaps the host quadtree)
-// -> H2D kept keypoints -> IC angle (1) -> rBRIEF (1) -> D2H.
+// Per image (round 6: FOUR launches and three copies; fifteen launches and five copies before):
+//   pyramid_kernel       every level in one launch: a workgroup that owns a tile of level l recomputes the footprint of that tile on
+//                        levels 1 .. l - 1 in LDS (level l needs l - 1: the chain is a few thousand pixels deep per tile, the launches it
+//                        replaces were eight dependent dispatches of 3 us of work each)
+//   blur_border_kernel   Gaussian blur of all levels + the reflect-101 borders (second stream, overlaps FAST and the host quadtree)
+//   fast_cells_kernel    FAST per 30-px cell incl. the iniTh / minTh fallback and per-cell NMS, the exclusive scan of the cell counts
+//                        (every workgroup adds up the published counts of the cells before it) and the ordered emission
+//   -> ONE D2H (cell offsets + candidates) -> host quadtree (orb_host.cpp) -> H2D kept keypoints ->
+//   orient_describe_kernel  IC angle + rBRIEF of a keypoint in one wave -> ONE D2H (angle | descriptor records).
+// Geometries whose pyramid footprint does not fit the staging buffers (more levels / larger scale steps than ORB-SLAM uses) take the
+// level-by-level launches (copy_level0_kernel + resize_kernel).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <stdint.h>
@@ -79,18 +85,92 @@ __global__ void resize_kernel(const uint8_t *src, int sstep, int sw, uint8_t *ds
     dst[(int64_t)dy * dstep + dx] = (uint8_t)v;
 }
 
+// Every level in one launch.  Tile t of level l: the host has walked the resize tables down from the tile to level 1 (the source
+// footprint of a pixel range is the range of its first and last pixels' taps: the maps are monotone) and left the footprint of every
+// level in the tile's record; the workgroup brings the table slices of those footprints into LDS, then produces the footprint on level 1
+// from the source image, on level 2 from that, ... and finally its tile from the footprint on level l - 1 — each pixel by
+// resize_kernel's arithmetic from the same inputs, so every level is bit-identical to the level-by-level launches.  Only the first
+// stage reads pixels from memory; tiles of the deepest levels (the longest chains) come first in the list.
+struct PyrTile { short level, pad_; short r[MAX_LEVELS][4]; };      // r[j] = x0, x1 (exclusive), y0, y1 of the footprint on level j, j = 1 .. level
+struct PyrTables { const XTab *xt[MAX_LEVELS]; const YTab *yt[MAX_LEVELS]; };
+constexpr int PYR_TW = 64, PYR_TH = 16, PYR_LDS = 16 * 1024;      // output tile; bytes of each of the two staging buffers
+constexpr int PYR_XT = 2048, PYR_YT = 768;                         // table entries a workgroup holds (all its levels together)
+constexpr int PYR_T = 512;
+__global__ __launch_bounds__(PYR_T) void pyramid_kernel(const uint8_t *src, int sstep, uint8_t *pyr, LevelTable T, PyrTables tabs,
+                                                       const PyrTile *tiles) {
+    __shared__ uint8_t s_buf[2][PYR_LDS];
+    __shared__ XTab s_xt[PYR_XT];
+    __shared__ YTab s_yt[PYR_YT];
+    __shared__ PyrTile s_t;
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    for (int i = tid; i < (int)(sizeof(PyrTile) / 4); i += PYR_T) reinterpret_cast<int *>(&s_t)[i] = reinterpret_cast<const int *>(tiles + blockIdx.x)[i];
+    __syncthreads();
+    const int l = s_t.level;
+    const LevelInfo L = T.lv[l];
+    uint8_t *dst = pyr + L.off + (int64_t)EDGE_THRESHOLD * L.step + EDGE_THRESHOLD;
+    if (l == 0) {
+        const int x0 = s_t.r[0][0], x1 = s_t.r[0][1], y0 = s_t.r[0][2], y1 = s_t.r[0][3];
+        for (int y = y0 + ty; y < y1; y += PYR_T / 64)
+            for (int x = x0 + tx; x < x1; x += 64) dst[(int64_t)y * L.step + x] = src[(int64_t)y * sstep + x];
+        return;
+    }
+    // table slices of every stage (one round trip to memory for all of them)
+    {
+        int xo = 0, yo = 0;
+        for (int j = 1; j <= l; ++j) {
+            const int rx0 = s_t.r[j][0], rw = s_t.r[j][1] - rx0, ry0 = s_t.r[j][2], rh = s_t.r[j][3] - ry0;
+            for (int i = tid; i < rw; i += PYR_T) s_xt[xo + i] = tabs.xt[j][rx0 + i];
+            for (int i = tid; i < rh; i += PYR_T) s_yt[yo + i] = tabs.yt[j][ry0 + i];
+            xo += rw; yo += rh;
+        }
+    }
+    __syncthreads();
+    int xo = 0, yo = 0;
+    for (int j = 1; j <= l; ++j) {
+        const int rx0 = s_t.r[j][0], rw = s_t.r[j][1] - rx0, ry0 = s_t.r[j][2], rh = s_t.r[j][3] - ry0;
+        const int px0 = j > 1 ? s_t.r[j - 1][0] : 0, pw = j > 1 ? s_t.r[j - 1][1] - px0 : 0, py0 = j > 1 ? s_t.r[j - 1][2] : 0;
+        const uint8_t *prev = s_buf[(j - 1) & 1];
+        uint8_t *out = s_buf[j & 1];
+        const int sw = T.lv[j - 1].cols;
+        for (int iy = ty; iy < rh; iy += PYR_T / 64) {
+            const YTab Y = s_yt[yo + iy];
+#pragma unroll 4
+            for (int ix = tx; ix < rw; ix += 64) {
+                const XTab X = s_xt[xo + ix];
+                const int sx1 = X.sx + 1 < sw ? X.sx + 1 : X.sx;
+                int p00, p01, p10, p11;
+                if (j == 1) {
+                    const uint8_t *S0 = src + (int64_t)Y.sy0 * sstep, *S1 = src + (int64_t)Y.sy1 * sstep;
+                    p00 = S0[X.sx]; p01 = S0[sx1]; p10 = S1[X.sx]; p11 = S1[sx1];
+                } else {
+                    const uint8_t *S0 = prev + (Y.sy0 - py0) * pw - px0, *S1 = prev + (Y.sy1 - py0) * pw - px0;
+                    p00 = S0[X.sx]; p01 = S0[sx1]; p10 = S1[X.sx]; p11 = S1[sx1];
+                }
+                const int r0 = p00 * X.a0 + p01 * X.a1;
+                const int r1 = p10 * X.a0 + p11 * X.a1;
+                int v = (((Y.b0 * (r0 >> 4)) >> 16) + ((Y.b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                if (j == l) dst[(int64_t)(ry0 + iy) * L.step + rx0 + ix] = (uint8_t)v;
+                else out[iy * rw + ix] = (uint8_t)v;
+            }
+        }
+        xo += rw; yo += rh;
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ int reflect101(int p, int len) {
     while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
     return p;
 }
 
-// copyMakeBorder(BORDER_REFLECT_101) of every level in one launch (blockIdx.y = level).
-__global__ void border_kernel(uint8_t *pyr, LevelTable T) {
-    const LevelInfo L = T.lv[blockIdx.y];
+// copyMakeBorder(BORDER_REFLECT_101) of one level, `nblocks` workgroups sharing it (part of blur_border_kernel).
+constexpr int BORDER_BLOCKS = 64;
+__device__ __forceinline__ void border_body(uint8_t *pyr, const LevelInfo &L, int block, int nblocks) {
     const int PW = L.cols + 2 * EDGE_THRESHOLD, PH = L.rows + 2 * EDGE_THRESHOLD;
     uint8_t *base = pyr + L.off;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)PW * PH;
-         i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)block * blockDim.x + threadIdx.x; i < (int64_t)PW * PH;
+         i += (int64_t)nblocks * blockDim.x) {
         const int px = (int)(i % PW), py = (int)(i / PW);
         const int x = px - EDGE_THRESHOLD, y = py - EDGE_THRESHOLD;
         if (x >= 0 && x < L.cols && y >= 0 && y < L.rows) continue;
@@ -137,13 +217,23 @@ __device__ __forceinline__ bool nms_keep(const uint8_t *s, int sw, int th) {
 
 // One wave per 30-px cell (ORBextractor.cc:775-819): scores of the cell's tested region in
 // LDS, per-cell 3x3 NMS at iniTh, fall back to minTh when that leaves nothing, raster-order
-// emission through ballot/popcount.  Slot word = x | y << 12 | score << 24 with (x, y)
+// emission through ballot/popcount.  Word = x | y << 12 | score << 24 with (x, y)
 // relative to the FAST border (level coordinate - 16), as vToDistributeKeys holds them.
-__global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *pyr, LevelTable T, const CellInfo *cells,
-                                                       int ini_th, int min_th, uint32_t *slots, int cap,
-                                                       int *counts) {
+// Round 6: the exclusive scan over the cells and the ordered compaction happen HERE (they were two more launches and a
+// ncells x cap slot array): a cell publishes ONE word, status[c] = epoch of this extraction << 12 | its count, waits until every cell
+// before it has published — workgroups are dispatched in index order, so those are resident or finished — adds their counts
+// (integers: any order) and emits its corners straight to dense[offset ...].  offsets[c] goes to the host with the candidates.
+// One word per cell, read and written with relaxed device-scope atomics: nothing else has to be ordered, no fence, no cache
+// invalidation per poll (the first form — count and flag in two arrays, an acquire load per predecessor — took 118 us instead of 42).
+// A wait is bounded: if it runs out (it never should), the cell raises *err and the host fails the extraction loudly.
+constexpr int FAST_SPIN_LIMIT = 1 << 22;
+constexpr int FAST_EPOCH_MASK = (1 << 20) - 1;
+__global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *pyr, LevelTable T, const CellInfo *cells, int ncells,
+                                                       int ini_th, int min_th, int cap, uint32_t *status, uint32_t epoch,
+                                                       int *offsets, uint32_t *dense, int *err) {
     __shared__ uint8_t s_score[(CELL_MAX + 2) * (CELL_MAX + 2)];
-    const CellInfo C = cells[blockIdx.x];
+    const int cell = blockIdx.x;
+    const CellInfo C = cells[cell];
     const LevelInfo L = T.lv[C.level];
     const int lane = threadIdx.x;
     const uint8_t *img = pyr + L.off + (int64_t)EDGE_THRESHOLD * L.step + EDGE_THRESHOLD;
@@ -163,8 +253,40 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *pyr, Leve
         const bool keep = i < npx && nms_keep(s_score + (i / C.w + 1) * sw + i % C.w + 1, sw, th);
         total += __popcll(__ballot(keep));
     }
-    if (total == 0) th = min_th;   // vKeysCell.empty() -> FAST(minThFAST)
-    uint32_t *out = slots + (int64_t)blockIdx.x * cap;
+    if (total == 0) {              // vKeysCell.empty() -> FAST(minThFAST)
+        th = min_th;
+        for (int i0 = 0; i0 < npx; i0 += 64) {
+            const int i = i0 + lane;
+            const bool keep = i < npx && nms_keep(s_score + (i / C.w + 1) * sw + i % C.w + 1, sw, th);
+            total += __popcll(__ballot(keep));
+        }
+    }
+    const int count = total < cap ? total : cap;
+    // publish, then the sum of the counts before this cell
+    if (lane == 0) __hip_atomic_store(status + cell, (epoch << 12) | (uint32_t)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int offset = 0;
+    for (int b = 0; b < cell; b += 64) {
+        const int i = b + lane;
+        int v = 0;
+        if (i < cell) {
+            int spins = 0;
+            uint32_t w = __hip_atomic_load(status + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((w >> 12) != epoch) {
+                if (++spins > FAST_SPIN_LIMIT) { atomicExch(err, 1); break; }
+                __builtin_amdgcn_s_sleep(1);
+                w = __hip_atomic_load(status + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            v = (int)(w & 0xfffu);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        offset += v;
+    }
+    if (lane == 0) {
+        offsets[cell] = offset;
+        if (cell == ncells - 1) offsets[ncells] = offset + count;
+    }
+    uint32_t *out = dense + offset;
     int base = 0;
     for (int i0 = 0; i0 < npx; i0 += 64) {
         const int i = i0 + lane;
@@ -179,46 +301,19 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *pyr, Leve
         }
         base += __popcll(m);
     }
-    if (lane == 0) counts[blockIdx.x] = base < cap ? base : cap;
-}
-
-// Exclusive scan of the per-cell counts (single workgroup; cells are few thousand at most).
-__global__ __launch_bounds__(256) void scan_counts_kernel(const int *counts, int n, int *offsets, int *total) {
-    __shared__ int s[256];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int b = 0; b < n; b += 256) {
-        const int i = b + threadIdx.x;
-        const int v = i < n ? counts[i] : 0;
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            const int t = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
-            __syncthreads();
-            s[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < n) offsets[i] = carry + s[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 255) carry += s[255];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { offsets[n] = carry; *total = carry; }
-}
-
-__global__ __launch_bounds__(64) void compact_kernel(const uint32_t *slots, int cap, const int *counts,
-                                                    const int *offsets, uint32_t *dense) {
-    const int c = blockIdx.x, n = counts[c], o = offsets[c];
-    for (int k = threadIdx.x; k < n; k += 64) dense[o + k] = slots[(int64_t)c * cap + k];
 }
 
 // ---------------------------------------------------------------- Gaussian blur
 // GaussianBlur(7x7, sigma 2, REFLECT_101) on 8U: 8-bit fixed-point kernel (sum 257), row
 // pass in int, column pass (sum + 2^15) >> 16.  32x32 output tile per workgroup, all levels
-// in one launch (blockIdx.y = level).
-__global__ __launch_bounds__(256) void blur_kernel(const uint8_t *pyr, uint8_t *blur, LevelTable T, int k0, int k1,
-                                                  int k2, int k3) {
+// in one launch (blockIdx.y = level); rows nlevels .. 2 nlevels - 1 of the grid write the reflect-101 borders of the
+// pyramid levels (BORDER_BLOCKS workgroups each; the blur reflects for itself and reads interiors only, so the two do not meet).
+__global__ __launch_bounds__(256) void blur_border_kernel(uint8_t *pyr, uint8_t *blur, LevelTable T, int k0, int k1,
+                                                         int k2, int k3) {
+    if ((int)blockIdx.y >= T.n) {
+        if ((int)blockIdx.x < BORDER_BLOCKS) border_body(pyr, T.lv[blockIdx.y - T.n], blockIdx.x, BORDER_BLOCKS);
+        return;
+    }
     const LevelInfo L = T.lv[blockIdx.y];
     const int tiles_x = (L.cols + 31) / 32, tiles_y = (L.rows + 31) / 32;
     if ((int)blockIdx.x >= tiles_x * tiles_y) return;
@@ -273,43 +368,41 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-// IC_Angle (ORBextractor.cc:75-100): one wave per keypoint, lane = patch row v in [-15,15];
-// integer moments are order independent, so the wave reduction is exact.
-__global__ __launch_bounds__(256) void angle_kernel(const uint8_t *pyr, LevelTable T, const DevKp *kps, int n,
-                                                   float *angles) {
+// IC_Angle (ORBextractor.cc:75-100) and computeOrbDescriptor (ORBextractor.cc:104-150) of a keypoint in ONE wave (two launches
+// and two result copies until round 5).  Angle: lane = patch row v in [-15,15]; integer moments are order independent, so the wave
+// reduction is exact.  Descriptor, on the blurred level image: lane l evaluates tests 4l..4l+3 (a nibble); lanes pair up into
+// bytes.  Result record per keypoint: [angle f32 | 32 descriptor bytes] — one D2H copy for both.
+constexpr int KP_REC = 36;
+__global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *pyr, const uint8_t *blur, LevelTable T, const DevKp *kps,
+                                                             int n, uint8_t *rec) {
     const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= n) return;
     const DevKp kp = kps[k];
     const LevelInfo L = T.lv[kp.level];
-    const uint8_t *center = pyr + L.off + (int64_t)(EDGE_THRESHOLD + __float2int_rn(kp.y)) * L.step + EDGE_THRESHOLD +
-                            __float2int_rn(kp.x);
-    int m10 = 0, m01 = 0;
-    if (lane < 2 * HALF_PATCH + 1) {
-        const int v = lane - HALF_PATCH;
-        const int d = c_umax[v < 0 ? -v : v];
-        const uint8_t *row = center + (int64_t)v * L.step;
-        int s = 0;
-        for (int u = -d; u <= d; ++u) { const int val = row[u]; m10 += u * val; s += val; }
-        m01 = v * s;
-    }
+    const int kx = __float2int_rn(kp.x), ky = __float2int_rn(kp.y);
+    float deg;
+    {
+        const uint8_t *center = pyr + L.off + (int64_t)(EDGE_THRESHOLD + ky) * L.step + EDGE_THRESHOLD + kx;
+        int m10 = 0, m01 = 0;
+        if (lane < 2 * HALF_PATCH + 1) {
+            const int v = lane - HALF_PATCH;
+            const int d = c_umax[v < 0 ? -v : v];
+            const uint8_t *row = center + (int64_t)v * L.step;
+            int s = 0;
+            for (int u = -d; u <= d; ++u) { const int val = row[u]; m10 += u * val; s += val; }
+            m01 = v * s;
+        }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
-    if (lane == 0) angles[k] = fast_atan2_deg((float)m01, (float)m10);
-}
-
-// computeOrbDescriptor (ORBextractor.cc:104-150) on the blurred level image: one wave per
-// keypoint, lane l evaluates tests 4l..4l+3 (a nibble); lanes pair up into bytes.
-__global__ __launch_bounds__(256) void descriptor_kernel(const uint8_t *blur, LevelTable T, const DevKp *kps,
-                                                        const float *angles, int n, uint8_t *desc) {
-    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= n) return;
-    const DevKp kp = kps[k];
-    const LevelInfo L = T.lv[kp.level];
+        for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+        deg = fast_atan2_deg((float)m01, (float)m10);          // (every lane holds the sums: the same value in every lane)
+    }
+    uint8_t *r = rec + (int64_t)k * KP_REC;
+    if (lane == 0) *reinterpret_cast<float *>(r) = deg;
     const float factorPI = (float)(3.141592653589793238462643383279502884 / 180.f);
-    const float angle = __fmul_rn(angles[k], factorPI);
+    const float angle = __fmul_rn(deg, factorPI);
     const float a = (float)cos((double)angle), b = (float)sin((double)angle);
     const int step = L.cols;
-    const uint8_t *center = blur + L.blur_off + (int64_t)__float2int_rn(kp.y) * step + __float2int_rn(kp.x);
+    const uint8_t *center = blur + L.blur_off + (int64_t)ky * step + kx;
     int nib = 0;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -323,7 +416,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const uint8_t *blur, Le
         nib |= (t0 < t1) << t;
     }
     const int hi = __shfl_down(nib, 1);
-    if ((lane & 1) == 0) desc[(int64_t)k * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+    if ((lane & 1) == 0) r[4 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
 }
 
 // ---------------------------------------------------------------- stereo SAD (Frame.cc:543-583)
@@ -386,19 +479,27 @@ struct sivo_orb {
     XTab *d_xt[MAX_LEVELS] = {};
     YTab *d_yt[MAX_LEVELS] = {};
     CellInfo *d_cells = nullptr;
-    uint32_t *d_slots = nullptr, *d_dense = nullptr;
-    int *d_counts = nullptr, *d_offsets = nullptr, *d_total = nullptr;
-    int *h_counts = nullptr;          // pinned: ncells + 1 (total at the end)
-    uint32_t *h_dense = nullptr;      // pinned
-    size_t dense_cap = 0;
+    // FAST results, one region so that ONE copy brings them to the host: [offsets: ncells + 1, padded to off_words][dense candidates]
+    int *d_fast = nullptr, *h_fast = nullptr;      // (h_fast pinned)
+    size_t off_words = 0, dense_cap = 0;
+    uint32_t *d_status = nullptr;     // per cell: epoch << 12 | count (fast_cells_kernel)
+    int *d_err = nullptr;
+    uint32_t epoch = 0;
+    static constexpr size_t DENSE_FIRST = 24 * 1024;       // candidates the first copy brings along (a 352 x 1024 frame has 10 - 20 k); more: a second copy
+    // the pyramid in one launch (pyramid_kernel) when the footprints fit its staging buffers
+    std::vector<XTab> h_xt[MAX_LEVELS];
+    std::vector<YTab> h_yt[MAX_LEVELS];
+    PyrTile *d_tiles = nullptr;
+    int ntiles = 0;
+    bool fused_pyramid = false;
+    PyrTables pyr_tabs{};
     DevKp *d_kps = nullptr, *h_kps = nullptr;
-    float *d_angles = nullptr, *h_angles = nullptr;
-    uint8_t *d_desc = nullptr, *h_desc = nullptr;
+    uint8_t *d_rec = nullptr, *h_rec = nullptr;     // [angle | descriptor] records (KP_REC bytes per keypoint)
     int kp_cap = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
     // profiling (sivo_orb_profile): HIP events around the kernel groups of one extraction, on the stream each runs on
-    static constexpr int NPROF = 5;             // pyramid (copy + 7 resizes), blur + border, FAST cells + scan + compact, angle, descriptor
+    static constexpr int NPROF = 5;             // pyramid, blur + border, FAST cells (+ scan + emission), angle + descriptor, (unused since round 6: 0)
     bool prof = false;
     hipEvent_t pe0[NPROF] = {nullptr, nullptr, nullptr, nullptr, nullptr}, pe1[NPROF] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool pe_used[NPROF] = {false, false, false, false, false};
@@ -410,6 +511,18 @@ struct sivo_orb {
     // synchronisation — on the per-frame path once it has reached its working size)
     void *d_match = nullptr;
     size_t match_cap = 0;
+    // its pinned twin: the call's inputs are packed here and go over in ONE copy (four until round 5), its first results come back in one
+    uint8_t *h_match = nullptr;
+    size_t h_match_cap = 0;
+    uint8_t *match_stage(size_t bytes) {
+        if (bytes > h_match_cap) {
+            if (h_match) (void)hipHostFree(h_match);
+            h_match = nullptr;
+            h_match_cap = bytes + bytes / 2;
+            SIVO_HIP(hipHostMalloc((void **)&h_match, h_match_cap, hipHostMallocDefault));
+        }
+        return h_match;
+    }
     void *match_arena(size_t bytes) {
         if (bytes > match_cap) {
             if (d_match) (void)hipFree(d_match);
@@ -421,29 +534,26 @@ struct sivo_orb {
     }
 
     void free_geometry() {
-        for (void *p : {(void *)d_pyr, (void *)d_blur, (void *)d_src, (void *)d_cells, (void *)d_slots, (void *)d_dense,
-                        (void *)d_counts, (void *)d_offsets, (void *)d_total})
+        for (void *p : {(void *)d_pyr, (void *)d_blur, (void *)d_src, (void *)d_cells, (void *)d_fast, (void *)d_status, (void *)d_tiles})
             if (p) (void)hipFree(p);
         for (int l = 0; l < MAX_LEVELS; ++l) {
             if (d_xt[l]) (void)hipFree(d_xt[l]);
             if (d_yt[l]) (void)hipFree(d_yt[l]);
             d_xt[l] = nullptr; d_yt[l] = nullptr;
         }
-        if (h_counts) (void)hipHostFree(h_counts);
-        if (h_dense) (void)hipHostFree(h_dense);
-        d_pyr = d_blur = d_src = nullptr; d_cells = nullptr; d_slots = d_dense = nullptr;
-        d_counts = d_offsets = d_total = nullptr; h_counts = nullptr; h_dense = nullptr;
+        if (h_fast) (void)hipHostFree(h_fast);
+        d_pyr = d_blur = d_src = nullptr; d_cells = nullptr; d_fast = nullptr; h_fast = nullptr;
+        d_status = nullptr; d_err = nullptr; d_tiles = nullptr; ntiles = 0; fused_pyramid = false;
         src_bytes = 0;
     }
     ~sivo_orb() {
         free_geometry();
         if (d_match) (void)hipFree(d_match);
+        if (h_match) (void)hipHostFree(h_match);
         if (d_kps) (void)hipFree(d_kps);
-        if (d_angles) (void)hipFree(d_angles);
-        if (d_desc) (void)hipFree(d_desc);
+        if (d_rec) (void)hipFree(d_rec);
         if (h_kps) (void)hipHostFree(h_kps);
-        if (h_angles) (void)hipHostFree(h_angles);
-        if (h_desc) (void)hipHostFree(h_desc);
+        if (h_rec) (void)hipHostFree(h_rec);
         for (int i = 0; i < NPROF; ++i) {
             if (pe0[i]) (void)hipEventDestroy(pe0[i]);
             if (pe1[i]) (void)hipEventDestroy(pe1[i]);
@@ -526,8 +636,9 @@ void setup_geometry(sivo_orb &o, int rows, int cols) {
     for (int l = 1; l < o.nlevels; ++l) {
         const LevelInfo &S = o.table.lv[l - 1], &D = o.table.lv[l];
         const double scale_x = 1. / ((double)D.cols / S.cols), scale_y = 1. / ((double)D.rows / S.rows);
-        std::vector<XTab> xt(D.cols);
-        std::vector<YTab> yt(D.rows);
+        std::vector<XTab> &xt = o.h_xt[l];
+        std::vector<YTab> &yt = o.h_yt[l];
+        xt.assign(D.cols, XTab{}); yt.assign(D.rows, YTab{});
         for (int dx = 0; dx < D.cols; ++dx) {
             float fx = (float)((dx + 0.5) * scale_x - 0.5);
             int sx = cv_floor(fx);
@@ -547,6 +658,39 @@ void setup_geometry(sivo_orb &o, int rows, int cols) {
         o.d_yt[l] = dev_alloc<YTab>(yt.size());
         SIVO_HIP(hipMemcpy(o.d_xt[l], xt.data(), xt.size() * sizeof(XTab), hipMemcpyHostToDevice));
         SIVO_HIP(hipMemcpy(o.d_yt[l], yt.data(), yt.size() * sizeof(YTab), hipMemcpyHostToDevice));
+        o.pyr_tabs.xt[l] = o.d_xt[l]; o.pyr_tabs.yt[l] = o.d_yt[l];
+    }
+    // tiles of pyramid_kernel with the footprint of every level below them (the walk down the tables), deepest levels first, and whether
+    // every footprint and its table slices fit the kernel's LDS
+    {
+        std::vector<PyrTile> tiles;
+        bool fits = true;
+        for (int l = o.nlevels - 1; l >= 0; --l) {
+            const LevelInfo &L = o.table.lv[l];
+            for (int y0 = 0; y0 < L.rows; y0 += PYR_TH)
+                for (int x0 = 0; x0 < L.cols; x0 += PYR_TW) {
+                    PyrTile t{};
+                    t.level = (short)l;
+                    int a0 = x0, a1 = std::min(x0 + PYR_TW, L.cols), b0 = y0, b1 = std::min(y0 + PYR_TH, L.rows);
+                    t.r[l][0] = (short)a0; t.r[l][1] = (short)a1; t.r[l][2] = (short)b0; t.r[l][3] = (short)b1;
+                    int xsum = a1 - a0, ysum = b1 - b0;
+                    for (int j = l; j > 1; --j) {
+                        const int sw = o.table.lv[j - 1].cols;
+                        const int na0 = o.h_xt[j][a0].sx, hi = o.h_xt[j][a1 - 1].sx + 1;
+                        const int nb0 = o.h_yt[j][b0].sy0, nb1 = o.h_yt[j][b1 - 1].sy1 + 1;
+                        a0 = na0; a1 = (hi < sw ? hi : sw - 1) + 1; b0 = nb0; b1 = nb1;
+                        t.r[j - 1][0] = (short)a0; t.r[j - 1][1] = (short)a1; t.r[j - 1][2] = (short)b0; t.r[j - 1][3] = (short)b1;
+                        if ((int64_t)(a1 - a0) * (b1 - b0) > PYR_LDS) fits = false;
+                        xsum += a1 - a0; ysum += b1 - b0;
+                    }
+                    if (xsum > PYR_XT || ysum > PYR_YT) fits = false;
+                    tiles.push_back(t);
+                }
+        }
+        o.fused_pyramid = fits;
+        o.ntiles = (int)tiles.size();
+        o.d_tiles = dev_alloc<PyrTile>(tiles.size());
+        SIVO_HIP(hipMemcpy(o.d_tiles, tiles.data(), tiles.size() * sizeof(PyrTile), hipMemcpyHostToDevice));
     }
     // FAST cells (ORBextractor.cc:752-819)
     o.cells.clear();
@@ -587,25 +731,26 @@ void setup_geometry(sivo_orb &o, int rows, int cols) {
     const size_t nc = o.cells.size();
     o.d_cells = dev_alloc<CellInfo>(nc);
     if (nc) SIVO_HIP(hipMemcpy(o.d_cells, o.cells.data(), nc * sizeof(CellInfo), hipMemcpyHostToDevice));
-    o.d_slots = dev_alloc<uint32_t>(nc * cap);
-    o.dense_cap = nc * cap;
-    o.d_dense = dev_alloc<uint32_t>(o.dense_cap);
-    o.d_counts = dev_alloc<int>(nc + 1);
-    o.d_offsets = dev_alloc<int>(nc + 1);
-    o.d_total = dev_alloc<int>(1);
-    SIVO_HIP(hipHostMalloc((void **)&o.h_counts, (nc + 2) * sizeof(int), hipHostMallocDefault));
-    SIVO_HIP(hipHostMalloc((void **)&o.h_dense, std::max<size_t>(o.dense_cap, 1) * sizeof(uint32_t), hipHostMallocDefault));
+    o.dense_cap = std::max<size_t>(nc * cap, 1);
+    o.off_words = (nc + 2 + 63) / 64 * 64;          // nc + 1 offsets, then the error word of the scan
+    o.d_fast = dev_alloc<int>(o.off_words + o.dense_cap);
+    SIVO_HIP(hipMemset(o.d_fast, 0, (o.off_words + o.dense_cap) * sizeof(int)));
+    if (cap >= 4096) throw std::runtime_error("FAST cell capacity beyond the 12 bits of its status word");
+    o.d_status = dev_alloc<uint32_t>(nc + 1);
+    o.d_err = o.d_fast + nc + 1;                    // (inside the region the host copies: zero from the memset above)
+    SIVO_HIP(hipMemset(o.d_status, 0, (nc + 1) * sizeof(uint32_t)));
+    o.epoch = 0;
+    SIVO_HIP(hipHostMalloc((void **)&o.h_fast, (o.off_words + o.dense_cap) * sizeof(int), hipHostMallocDefault));
     o.have_pyramid = false;
 }
 
 void ensure_kp_capacity(sivo_orb &o, int n) {
     if (n <= o.kp_cap) return;
-    if (o.d_kps) { (void)hipFree(o.d_kps); (void)hipFree(o.d_angles); (void)hipFree(o.d_desc); (void)hipHostFree(o.h_kps); (void)hipHostFree(o.h_angles); (void)hipHostFree(o.h_desc); }
+    if (o.d_kps) { (void)hipFree(o.d_kps); (void)hipFree(o.d_rec); (void)hipHostFree(o.h_kps); (void)hipHostFree(o.h_rec); }
     const int cap = std::max(n, 4096);
-    o.d_kps = dev_alloc<DevKp>(cap); o.d_angles = dev_alloc<float>(cap); o.d_desc = dev_alloc<uint8_t>((size_t)cap * 32);
+    o.d_kps = dev_alloc<DevKp>(cap); o.d_rec = dev_alloc<uint8_t>((size_t)cap * KP_REC);
     SIVO_HIP(hipHostMalloc((void **)&o.h_kps, cap * sizeof(DevKp), hipHostMallocDefault));
-    SIVO_HIP(hipHostMalloc((void **)&o.h_angles, cap * sizeof(float), hipHostMallocDefault));
-    SIVO_HIP(hipHostMalloc((void **)&o.h_desc, (size_t)cap * 32, hipHostMallocDefault));
+    SIVO_HIP(hipHostMalloc((void **)&o.h_rec, (size_t)cap * KP_REC, hipHostMallocDefault));
     o.kp_cap = cap;
 }
 
@@ -627,7 +772,9 @@ int extract(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, Siv
     };
     // ---- pyramid
     mark(0, false, st);
-    {
+    if (o.fused_pyramid) {
+        hipLaunchKernelGGL(pyramid_kernel, dim3(o.ntiles), dim3(PYR_T), 0, st, d_src, step, o.d_pyr, T, o.pyr_tabs, o.d_tiles);
+    } else {        // footprints beyond the staging buffers (more levels / larger scale steps than ORB-SLAM's): level by level
         const LevelInfo &L0 = T.lv[0];
         uint8_t *dst = o.d_pyr + L0.off + (size_t)EDGE_THRESHOLD * L0.step + EDGE_THRESHOLD;
         hipLaunchKernelGGL(copy_level0_kernel, dim3(cdiv(cols, 256), rows), dim3(256), 0, st, d_src, step, dst, L0.step, rows, cols);
@@ -641,33 +788,38 @@ int extract(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, Siv
     }
     mark(0, true, st);
     SIVO_HIP(hipEventRecord(o.ev_pyr, st));
-    // ---- blur on the second stream (needs interiors only), overlapping FAST + the host quadtree
+    // ---- blur + borders on the second stream (they need interiors only), overlapping FAST + the host quadtree
     SIVO_HIP(hipStreamWaitEvent(o.stream2, o.ev_pyr, 0));
     {
-        int max_tiles = 0;
+        int max_tiles = BORDER_BLOCKS;
         for (int l = 0; l < o.nlevels; ++l) max_tiles = std::max(max_tiles, cdiv(T.lv[l].cols, 32) * cdiv(T.lv[l].rows, 32));
         mark(1, false, o.stream2);
-        hipLaunchKernelGGL(blur_kernel, dim3(max_tiles, o.nlevels), dim3(256), 0, o.stream2, o.d_pyr, o.d_blur, T, o.gk[0], o.gk[1],
+        hipLaunchKernelGGL(blur_border_kernel, dim3(max_tiles, 2 * o.nlevels), dim3(256), 0, o.stream2, o.d_pyr, o.d_blur, T, o.gk[0], o.gk[1],
                            o.gk[2], o.gk[3]);
-        hipLaunchKernelGGL(border_kernel, dim3(64, o.nlevels), dim3(256), 0, o.stream2, o.d_pyr, T);
         mark(1, true, o.stream2);
         SIVO_HIP(hipEventRecord(o.ev_blur, o.stream2));
     }
-    // ---- FAST cells -> ordered candidate list
+    // ---- FAST cells -> ordered candidate list, one copy: [cell offsets | the first DENSE_FIRST candidates]
     const int nc = (int)o.cells.size();
     int total = 0;
+    int *h_off = o.h_fast;
+    const uint32_t *h_dense = reinterpret_cast<const uint32_t *>(o.h_fast + o.off_words);
     if (nc) {
         mark(2, false, st);
-        hipLaunchKernelGGL(fast_cells_kernel, dim3(nc), dim3(64), 0, st, o.d_pyr, T, o.d_cells, o.ini_th, o.min_th, o.d_slots,
-                           o.cap, o.d_counts);
-        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(256), 0, st, o.d_counts, nc, o.d_offsets, o.d_total);
-        hipLaunchKernelGGL(compact_kernel, dim3(nc), dim3(64), 0, st, o.d_slots, o.cap, o.d_counts, o.d_offsets, o.d_dense);
+        o.epoch = (o.epoch % FAST_EPOCH_MASK) + 1;          // 1 .. 2^20 - 1: never the zero the status words start with
+        hipLaunchKernelGGL(fast_cells_kernel, dim3(nc), dim3(64), 0, st, o.d_pyr, T, o.d_cells, nc, o.ini_th, o.min_th, o.cap, o.d_status,
+                           o.epoch, o.d_fast, reinterpret_cast<uint32_t *>(o.d_fast + o.off_words), o.d_err);
         mark(2, true, st);
-        SIVO_HIP(hipMemcpyAsync(o.h_counts, o.d_offsets, (size_t)(nc + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+        const size_t first = std::min(o.dense_cap, sivo_orb::DENSE_FIRST);
+        h_off[nc] = -1;
+        SIVO_HIP(hipMemcpyAsync(o.h_fast, o.d_fast, (o.off_words + first) * sizeof(int), hipMemcpyDeviceToHost, st));
         SIVO_HIP(hipStreamSynchronize(st));
-        total = o.h_counts[nc];
-        if (total) {
-            SIVO_HIP(hipMemcpyAsync(o.h_dense, o.d_dense, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        total = h_off[nc];
+        if (total < 0 || (size_t)total > o.dense_cap || h_off[nc + 1] != 0)
+            return fail(SIVO_ERR_RUNTIME, "FAST candidate scan did not complete (total %d, error word %d)", total, h_off[nc + 1]);
+        if ((size_t)total > first) {
+            SIVO_HIP(hipMemcpyAsync(o.h_fast + o.off_words + first, o.d_fast + o.off_words + first, ((size_t)total - first) * sizeof(int),
+                                    hipMemcpyDeviceToHost, st));
             SIVO_HIP(hipStreamSynchronize(st));
         }
     }
@@ -679,11 +831,11 @@ int extract(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, Siv
     for (int l = 0; l < o.nlevels; ++l) {
         const int c0 = o.level_cell_begin[l], c1 = o.level_cell_begin[l + 1];
         if (c0 == c1) continue;
-        const int b = o.h_counts[c0], e = o.h_counts[c1];
+        const int b = h_off[c0], e = h_off[c1];
         std::vector<SivoKeyPoint> &cand = o.last_candidates[l];
         cand.resize(e - b);
         for (int i = b; i < e; ++i) {
-            const uint32_t w = o.h_dense[i];
+            const uint32_t w = h_dense[i];
             SivoKeyPoint &k = cand[i - b];
             k.x = (float)(w & 0xfff); k.y = (float)((w >> 12) & 0xfff);
             k.size = 7.f; k.angle = -1.f; k.response = (float)(w >> 24); k.octave = 0; k.class_id = -1;
@@ -708,15 +860,11 @@ int extract(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, Siv
     ensure_kp_capacity(o, n);
     for (int i = 0; i < n; ++i) o.h_kps[i] = DevKp{all[i].x, all[i].y, all[i].octave};
     SIVO_HIP(hipMemcpyAsync(o.d_kps, o.h_kps, (size_t)n * sizeof(DevKp), hipMemcpyHostToDevice, st));
-    mark(3, false, st);
-    hipLaunchKernelGGL(angle_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, o.d_pyr, T, o.d_kps, n, o.d_angles);
-    mark(3, true, st);
     SIVO_HIP(hipStreamWaitEvent(st, o.ev_blur, 0));
-    mark(4, false, st);
-    hipLaunchKernelGGL(descriptor_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, o.d_blur, T, o.d_kps, o.d_angles, n, o.d_desc);
-    mark(4, true, st);
-    SIVO_HIP(hipMemcpyAsync(o.h_angles, o.d_angles, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
-    SIVO_HIP(hipMemcpyAsync(o.h_desc, o.d_desc, (size_t)n * 32, hipMemcpyDeviceToHost, st));
+    mark(3, false, st);
+    hipLaunchKernelGGL(orient_describe_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, o.d_pyr, o.d_blur, T, o.d_kps, n, o.d_rec);
+    mark(3, true, st);
+    SIVO_HIP(hipMemcpyAsync(o.h_rec, o.d_rec, (size_t)n * KP_REC, hipMemcpyDeviceToHost, st));
     SIVO_HIP(hipStreamSynchronize(st));
     SIVO_HIP(hipGetLastError());
     if (o.prof) {
@@ -733,11 +881,12 @@ int extract(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, Siv
     // ---- assemble (ORBextractor.cc:1068-1081): pt *= scale for level > 0
     for (int i = 0; i < n; ++i) {
         SivoKeyPoint k = all[i];
-        k.angle = o.h_angles[i];
+        std::memcpy(&k.angle, o.h_rec + (size_t)i * KP_REC, 4);
         if (k.octave != 0) { const float s = o.scale[k.octave]; k.x *= s; k.y *= s; }
         keypoints[i] = k;
     }
-    if (descriptors) std::memcpy(descriptors, o.h_desc, (size_t)n * 32);
+    if (descriptors)
+        for (int i = 0; i < n; ++i) std::memcpy(descriptors + (size_t)i * 32, o.h_rec + (size_t)i * KP_REC + 4, 32);
     return SIVO_OK;
 }
 
@@ -961,16 +1110,18 @@ extern "C" int sivo_stereo_match_begin(sivo_orb_t left, sivo_orb_t right, const 
                      o_sd = o_bd + al((size_t)nL * 4), o_jobs = o_sd + al((size_t)nL * 4),
                      o_dists = o_jobs + al((size_t)nL * sizeof(SadJob)), total = o_dists + al((size_t)nL * 11 * 4);
         uint8_t *base = (uint8_t *)left->match_arena(total);
-        SIVO_HIP(hipMemcpyAsync(base + o_dl, descL, (size_t)nL * 32, hipMemcpyHostToDevice, st));
-        SIVO_HIP(hipMemcpyAsync(base + o_dr, descR, (size_t)nR * 32, hipMemcpyHostToDevice, st));
-        SIVO_HIP(hipMemcpyAsync(base + o_off, off.data(), (size_t)(nL + 1) * 4, hipMemcpyHostToDevice, st));
-        if (!idx.empty()) SIVO_HIP(hipMemcpyAsync(base + o_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, st));
-        std::vector<int> bi(nL), bd(nL), sd(nL);
+        // inputs [descL | descR | off | idx] in one staged copy; the pinned buffer also receives [best index | best distance] (o_bi .. o_sd)
+        uint8_t *hs = left->match_stage(o_sd);
+        std::memcpy(hs + o_dl, descL, (size_t)nL * 32);
+        std::memcpy(hs + o_dr, descR, (size_t)nR * 32);
+        std::memcpy(hs + o_off, off.data(), (size_t)(nL + 1) * 4);
+        if (!idx.empty()) std::memcpy(hs + o_idx, idx.data(), idx.size() * 4);
+        SIVO_HIP(hipMemcpyAsync(base, hs, o_idx + idx.size() * 4, hipMemcpyHostToDevice, st));
+        const int *bi = reinterpret_cast<const int *>(hs + o_bi), *bd = reinterpret_cast<const int *>(hs + o_bd);
         int rc = sivo_hamming_argmin2_dev(base + o_dl, nL, base + o_dr, (const int32_t *)(base + o_off), (const int32_t *)(base + o_idx),
                                           (int32_t *)(base + o_bi), (int32_t *)(base + o_bd), (int32_t *)(base + o_sd), nullptr, st);
         if (rc) return rc;
-        SIVO_HIP(hipMemcpyAsync(bi.data(), base + o_bi, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
-        SIVO_HIP(hipMemcpyAsync(bd.data(), base + o_bd, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
+        SIVO_HIP(hipMemcpyAsync(hs + o_bi, base + o_bi, (o_bd - o_bi) + (size_t)nL * 4, hipMemcpyDeviceToHost, st));
         SIVO_HIP(hipStreamSynchronize(st));
         // SAD jobs (:538-565)
         std::vector<SadJob> jobs;

@@ -75,7 +75,8 @@ class ORBextractor:
         check(self._L.sivo_orb_profile(self._h, int(bool(enable))))
 
     def profile_read(self):
-        """{group: mean ms per extraction}, extractions, mean keypoints — groups: pyramid, blur, fast, angle, descriptor."""
+        """{group: mean ms per extraction}, extractions, mean keypoints — groups: pyramid, blur (+ borders), fast (+ scan + emission), angle (IC angle + rBRIEF in
+        one kernel since round 6), descriptor (0: kept for the layout of the C entry point)."""
         ms = (C.c_double * 5)(); n = C.c_int32(0); k = C.c_double(0)
         check(self._L.sivo_orb_profile_read(self._h, ms, C.byref(n), C.byref(k)))
         return dict(zip(("pyramid", "blur", "fast", "angle", "descriptor"), list(ms))), n.value, k.value

@@ -72,7 +72,7 @@ def test_no_kernel_of_the_product_has_packed_fp32_instructions(tmp_path):
     bodies = {k: v for k, v in kernels.items() if len(v) > 8}
     assert len(bodies) >= 100, len(bodies)                                    # (the whole library was disassembled, not one translation unit)
     for must in ("wino4_bridge_kernel", "wino4_input_kernel", "wino4_output_kernel", "wino4_gemm_h3_kernel", "conv3_h3_kernel", "conv_cls_h3_kernel",
-                 "conv7_h3_kernel", "fast_cells_kernel", "descriptor_kernel", "entropy_gate_kernel", "maxpool2"):
+                 "conv7_h3_kernel", "fast_cells_kernel", "pyramid_kernel", "orient_describe_kernel", "entropy_gate_kernel", "maxpool2"):
         assert any(must in k for k in bodies), f"{must}: not found in the code object"
     bridge = {k: v for k, v in bodies.items() if "wino4_bridge_kernel" in k}
     assert len(bridge) == 2 and all(len(v) > 500 for v in bridge.values()), {k: len(v) for k, v in bridge.items()}      # <PACK = false>, <PACK = true>: real bodies

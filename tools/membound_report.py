@@ -8,14 +8,10 @@ padded = sum((w + 38) * (h + 38) for w, h in LV)
 pyr = sum(area)
 NKP = 2000
 BYTES = {
-    "resize_kernel": (sum(area[:-1]) + sum(area[1:])) / 7.0,          # mean over the 7 calls: read level l-1, write level l
-    "copy_level0_kernel": 2 * area[0],
-    "border_kernel": padded - pyr + pyr * 0.1,                          # writes the 19-px frames, reads the edge pixels
-    "fast_cells_kernel": pyr + 4 * 20000,                               # every level once + candidate slots
-    "scan_counts_kernel": 2 * 4 * 733, "compact_kernel": 2 * 4 * 20000,
-    "blur_kernel": 2 * pyr,
-    "angle_kernel": NKP * 749 + NKP * 4,                                # disc r = 15 per keypoint
-    "descriptor_kernel": NKP * 512 + NKP * 32,
+    "pyramid_kernel": 2 * area[0] + sum(area[:-1]) + sum(area[1:]),     # the source once, every level written once and read once by the next
+    "blur_border_kernel": 2 * pyr + padded - pyr + pyr * 0.1,           # blur: every level in and out; borders: the 19-px frames
+    "fast_cells_kernel": pyr + 2 * 4 * 20000,                           # every level once + the candidates (+ the cell counts)
+    "orient_describe_kernel": NKP * (749 + 512 + 36),                   # disc r = 15 + 512 test pixels per keypoint, 36-byte record
     "stereo_sad_kernel": 600 * (11 * 11 + 11 * 21),                     # ~600 matched keypoints, 11x11 window + 21-wide strip
     "hamming_matrix_kernel": 32 * 4000 + 4 * 2000 * 2000,
     "hamming_argmin2_kernel": 32 * 4000 + 3 * 4 * 2000,                 # brute force: every B row per query from L2
