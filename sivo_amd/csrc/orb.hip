@@ -95,7 +95,7 @@ struct PyrTile { short level, pad_; short r[MAX_LEVELS][4]; };      // r[j] = x0
 struct PyrTables { const XTab *xt[MAX_LEVELS]; const YTab *yt[MAX_LEVELS]; };
 constexpr int PYR_TW = 64, PYR_TH = 16, PYR_LDS = 16 * 1024;      // output tile; bytes of each of the two staging buffers
 constexpr int PYR_XT = 2048, PYR_YT = 768;                         // table entries a workgroup holds (all its levels together)
-constexpr int PYR_T = 512;
+constexpr int PYR_T = 1024;
 __global__ __launch_bounds__(PYR_T) void pyramid_kernel(const uint8_t *src, int sstep, uint8_t *pyr, LevelTable T, PyrTables tabs,
                                                        const PyrTile *tiles) {
     __shared__ uint8_t s_buf[2][PYR_LDS];
@@ -667,11 +667,14 @@ void setup_geometry(sivo_orb &o, int rows, int cols) {
         bool fits = true;
         for (int l = o.nlevels - 1; l >= 0; --l) {
             const LevelInfo &L = o.table.lv[l];
+            // tile width by depth: levels 0 and 1 read the source image directly (no footprint to stage: wide tiles, few workgroups); deep
+            // levels take narrow tiles (their footprint on level 1 — the one stage that reads memory — grows with 1.2^l)
+            const int tw = l <= 1 ? 4 * PYR_TW : (l == 2 ? 2 * PYR_TW : (l >= 5 ? PYR_TW / 2 : PYR_TW));
             for (int y0 = 0; y0 < L.rows; y0 += PYR_TH)
-                for (int x0 = 0; x0 < L.cols; x0 += PYR_TW) {
+                for (int x0 = 0; x0 < L.cols; x0 += tw) {
                     PyrTile t{};
                     t.level = (short)l;
-                    int a0 = x0, a1 = std::min(x0 + PYR_TW, L.cols), b0 = y0, b1 = std::min(y0 + PYR_TH, L.rows);
+                    int a0 = x0, a1 = std::min(x0 + tw, L.cols), b0 = y0, b1 = std::min(y0 + PYR_TH, L.rows);
                     t.r[l][0] = (short)a0; t.r[l][1] = (short)a1; t.r[l][2] = (short)b0; t.r[l][3] = (short)b1;
                     int xsum = a1 - a0, ysum = b1 - b0;
                     for (int j = l; j > 1; --j) {
