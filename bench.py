@@ -207,7 +207,9 @@ def mfma_roofline(prof_timed, prof_detail, n_timed_frames, n_detail, ms_per_fram
     kernel against the dense peak of the instruction type it issues; executed_tflops / executed_frac = the matrix-core
     products it really issues (Winograd multiplies 1/4 of the direct products, the split arithmetic 3 or 6 per fp32 product)."""
     by_kernel = aggregate(prof_detail)
+    prof_timed, prof_lanes = prof_timed if isinstance(prof_timed, tuple) else (prof_timed, [])
     timed = aggregate(prof_timed) if prof_timed else {}
+    lanes = aggregate(prof_lanes) if prof_lanes else {}
     mfma = {k: v for k, v in timed.items() if v["flops"] > 0 and v["ms"] > 0 and kernel_class(k)}
     frames = n_timed_frames
     if not mfma:
@@ -234,7 +236,19 @@ def mfma_roofline(prof_timed, prof_detail, n_timed_frames, n_detail, ms_per_fram
     stack_fl = sum(v["flops"] for k, v in by_kernel.items() if kernel_class(k))
     chain = chain_fl / (chain_ms * 1e-3) / 1e12 if chain_ms > 0 else None
     stack = stack_fl / (stack_ms * 1e-3) / 1e12 if stack_ms > 0 else None
-    return {"bound": "mfma", "kernel": "sivo::" + dom_name, "instruction": what,
+    # the same kernel in the frames that kept their lanes (the timed configuration): its launches carry half the samples each and
+    # share the chip with the other lane's kernels; time = sum over the lanes
+    two = {}
+    tl = lanes.get(dom_name)
+    if tl and tl["ms"] > 0 and tl["flops"] > 0:
+        alg2 = tl["flops"] / (tl["ms"] * 1e-3) / 1e12
+        n2 = tl["flops"] / (dom["flops"] / max(frames, 1))           # frames' worth of this kernel's work behind the two-lane rows
+        two = {"frac_two_lane": round(alg2 / peak, 4), "executed_frac_two_lane": round(alg2 * ratio / peak, 4), "achieved_two_lane": round(alg2, 2),
+               "avg_launch_ms_two_lane": tl["ms"] / max(tl["launches"], 1), "launches_per_frame_two_lane": round(tl["launches"] / max(n2, 1e-9), 2),
+               "ms_per_frame_two_lane": round(tl["ms"] / max(n2, 1e-9), 3), "ms_per_frame_one_lane": round(dom["ms"] / max(frames, 1), 3),
+               "two_lane_note": "the dominant kernel in the timed frames that keep their two sample groups on two streams (every "
+                                "frame but the profiled one-lane ones runs like this): HIP events per lane, times summed over the lanes"}
+    return {"bound": "mfma", "kernel": "sivo::" + dom_name, "instruction": what, **two,
             "chain_tflops": round(chain, 2) if chain else None, "chain_frac": round(chain / BF16_MFMA_PEAK_TFLOPS, 4) if chain else None,
             "chain_ms_per_frame": round(chain_ms / n_detail, 3),
             "conv_stack_tflops": round(stack, 2) if stack else None, "conv_stack_frac": round(stack / BF16_MFMA_PEAK_TFLOPS, 4) if stack else None,
@@ -318,23 +332,38 @@ def membound_block(prof, fp, d_left, H, W, T, classes):
 
 
 def time_segnet(sn, frame, steps, warmup, barrier, profile_every=8, events=True, flush=lambda: None):
-    """Warm up, time `steps` calls of frame(seed) between barriers, return (elapsed s, MFMA-kernel rows of the timed region,
-    all-kernel rows of min(steps, 10) further untimed single-lane frames)."""
+    """Warm up, time `steps` calls of frame(seed) between barriers, return (elapsed s, MFMA-kernel rows of the timed region — a pair:
+    the frames profiled in one lane, the frames profiled with their lanes kept —, all-kernel rows of min(steps, 10) further untimed
+    single-lane frames).  Inside the timed region frame i carries events when i % profile_every is 0 (issued in ONE lane: a launch has
+    the GPU to itself) or profile_every / 2 (lanes kept: the kernel's time while it shares the chip with the other sample group)."""
     for i in range(warmup):
         frame(1000 + i)
     flush()
     barrier()
+    one_lane, two_lane = [], []
+    half = profile_every // 2
     t0 = time.perf_counter()
     for i in range(steps):
-        if events and i % profile_every == 0:
-            sn.profile(True, mfma_only=True, reset=(i == 0))
-        elif events and i % profile_every == 1:
-            sn.profile(False)
+        ph = i % profile_every
+        if events and ph == 0:
+            sn.profile(True, mfma_only=True, reset=True)
+        elif events and ph == 1:
+            one_lane += sn.profile_read(); sn.profile(False)
+        elif events and ph == half:
+            sn.profile(True, mfma_only=True, reset=True, keep_lanes=True)
+        elif events and ph == half + 1:
+            two_lane += sn.profile_read(); sn.profile(False)
         frame(2000 + i)
     flush()                      # (frames still in flight are completed inside the timed region)
     barrier()
     elapsed = time.perf_counter() - t0
-    prof_timed = sn.profile_read() if events else []
+    if events and steps % profile_every == 1:
+        one_lane += sn.profile_read()
+    elif events and steps % profile_every == half + 1:
+        two_lane += sn.profile_read()
+    if events:
+        sn.profile(False)
+    prof_timed = (one_lane, two_lane)
     n_detail = min(steps, 10)
     sn.profile(True, reset=True)
     for i in range(n_detail):
@@ -547,7 +576,9 @@ def main():
     # every left key run beside it, the semantic filter + median cull wait for the class map
     from sivo_amd.frame import StereoFramePipeline
     orb_delay = float(os.environ.get("SIVO_BENCH_ORB_DELAY_MS", "0")) * 1e-3       # experiment: start ORB this long after the network
-    fp = StereoFramePipeline(device=local, start_delay_s=orb_delay) if do_orb else None
+    # SIVO_BENCH_ORB_MODE=0..3: sivo_orb_set_launch_mode of the frame's two extractors (A/B of the one-launch forms beside the network)
+    orb_mode = os.environ.get("SIVO_BENCH_ORB_MODE")
+    fp = StereoFramePipeline(device=local, start_delay_s=orb_delay, orb_launch_mode=None if orb_mode is None else int(orb_mode)) if do_orb else None
     tail_probe = [] if os.environ.get("SIVO_BENCH_TAIL_PROBE") else None         # experiment: host time of the cull behind the class map
 
     rank_events = []         # N > 1: (start, band done, gather done, forward done, all-reduce done) of every frame on this rank's stream

@@ -229,7 +229,9 @@ typedef struct {
 } SivoOpProfile;
 /* enable: 0 off; 1 on; 2 on + reset the accumulators; 3 like 2 but only the MFMA kernels are bracketed (convolution
  * kernels and the F(4x4,3x3) GEMM): a handful of events per forward, for timing inside a throughput run; 4 like 3
- * without the reset (to profile a subset of the frames of a run). */
+ * without the reset (to profile a subset of the frames of a run); 5 / 6 like 3 / 4, but the profiled forward KEEPS its sample groups
+ * on their streams (modes 1 - 4 run it in one lane, one launch per layer, so that a launch has the GPU to itself): events per lane,
+ * ms_total is the sum over the lanes — the kernel's time while it shares the chip with the other lane. */
 int sivo_segnet_profile(sivo_segnet_t h, int enable);
 int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int capacity, int *n_out);
 
@@ -296,6 +298,14 @@ int sivo_orb_destroy(sivo_orb_t h);
  * 4.0 - 4.5.0; variant 1 18 34 48 56 48 34 18 — OpenCV >= 3.4.13 / >= 4.5.1 (error-diffused taps, sum 256).  Pick the one the
  * reference build you compare against was linked with; descriptors are bit-exact per variant (INTEGRATION.md "OpenCV contract"). */
 int sivo_orb_set_gaussian(sivo_orb_t h, int variant);
+/* How an extraction is issued (round 6).  mode bits, each "this group of kernels in ONE launch": 0 ComputePyramid (ORBextractor.cc:1085-1122: a
+ * workgroup recomputes the footprint of its tile on the levels above it in LDS, instead of one copy + nlevels - 1 dependent resizes), 1 FAST +
+ * the scan of the cell counts + the ordered emission (ORBextractor.cc:775-819: a cell waits for the cells before it, instead of three
+ * launches), 2 GaussianBlur + the reflect-101 borders, 3 IC_Angle + computeOrbDescriptor (one wave per keypoint).  Default 15: four launches
+ * and NO copy per image (the kernels read the kept keys from, and write candidates and [angle | descriptor] records to, pinned host memory);
+ * 0 = the fifteen launches of rounds 1 - 5.  Inside a frame whose network keeps every CU busy 14 is 0.6 % faster than 15 (the level-by-level
+ * resize kernels need no LDS); results are bit-identical in every mode (tests/test_gpu_orb.py). */
+int sivo_orb_set_launch_mode(sivo_orb_t h, int mode);
 /* GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
  * GetInverseScaleSigmaSquares + mnFeaturesPerLevel; arrays of nlevels. */
 int sivo_orb_tables(sivo_orb_t h, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,

@@ -101,6 +101,7 @@ SIGNATURES = {
     "sivo_orb_create": [_i, _f, _i, _i, _i, _i, C.POINTER(_vp)],
     "sivo_orb_destroy": [_vp],
     "sivo_orb_set_gaussian": [_vp, _i],
+    "sivo_orb_set_launch_mode": [_vp, _i],
     "sivo_orb_tables": [_vp, _vp, _vp, _vp, _vp, _vp],
     "sivo_orb_extract": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _pi32],
     "sivo_orb_extract_dev": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _pi32, _vp],

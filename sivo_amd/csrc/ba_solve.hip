@@ -1374,7 +1374,7 @@ struct BaStopCtx {
         if (ev) (void)hipEventDestroy(ev);
     }
     void ensure() {
-        if (!word) { SIVO_HIP(hipHostMalloc((void **)&word, 64, hipHostMallocDefault)); *word = 0; }
+        if (!word) { SIVO_HIP(hipHostMalloc((void **)&word, 64, hipHostMallocCoherent | hipHostMallocMapped)); *word = 0; }      // (fine-grained: the device must not cache it)
         if (!ev) SIVO_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
 };

@@ -33,6 +33,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *pyr, Leve
             int spins = 0;
             uint32_t w = __hip_atomic_load(status + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             while ((w >> 12) != epoch) {
-                if (++spins > FAST_SPIN_LIMIT) { atomicExch(err, 1); break; }
+                if (++spins > FAST_SPIN_LIMIT) { *reinterpret_cast<volatile int *>(err) = 1; break; }
                 __builtin_amdgcn_s_sleep(1);
                 w = __hip_atomic_load(status + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -301,6 +302,85 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *pyr, Leve
         }
         base += __popcll(m);
     }
+}
+
+// The three-launch form (launch mode bit 1 clear): per-cell slots, a scan of the counts, a compaction — no workgroup waits for another,
+// which is what matters beside the network (see sivo_orb_set_launch_mode).  One wave per 30-px cell (ORBextractor.cc:775-819): scores of the cell's tested region in
+// LDS, per-cell 3x3 NMS at iniTh, fall back to minTh when that leaves nothing, raster-order
+// emission through ballot/popcount.  Slot word = x | y << 12 | score << 24 with (x, y)
+// relative to the FAST border (level coordinate - 16), as vToDistributeKeys holds them.
+__global__ __launch_bounds__(64) void fast_cells_slots_kernel(const uint8_t *pyr, LevelTable T, const CellInfo *cells,
+                                                       int ini_th, int min_th, uint32_t *slots, int cap,
+                                                       int *counts) {
+    __shared__ uint8_t s_score[(CELL_MAX + 2) * (CELL_MAX + 2)];
+    const CellInfo C = cells[blockIdx.x];
+    const LevelInfo L = T.lv[C.level];
+    const int lane = threadIdx.x;
+    const uint8_t *img = pyr + L.off + (int64_t)EDGE_THRESHOLD * L.step + EDGE_THRESHOLD;
+    const int sw = C.w + 2, npx = C.w * C.h;
+    for (int i = lane; i < sw * (C.h + 2); i += 64) s_score[i] = 0;
+    __syncthreads();
+    const int lowest = min(ini_th, min_th);
+    for (int i = lane; i < npx; i += 64) {
+        const int ix = i % C.w, iy = i / C.w;
+        const int sc = fast_score(img + (int64_t)(C.y0 + iy) * L.step + C.x0 + ix, L.step);
+        s_score[(iy + 1) * sw + ix + 1] = (uint8_t)(sc >= lowest ? sc : 0);
+    }
+    __syncthreads();
+    int th = ini_th, total = 0;
+    for (int i0 = 0; i0 < npx; i0 += 64) {
+        const int i = i0 + lane;
+        const bool keep = i < npx && nms_keep(s_score + (i / C.w + 1) * sw + i % C.w + 1, sw, th);
+        total += __popcll(__ballot(keep));
+    }
+    if (total == 0) th = min_th;   // vKeysCell.empty() -> FAST(minThFAST)
+    uint32_t *out = slots + (int64_t)blockIdx.x * cap;
+    int base = 0;
+    for (int i0 = 0; i0 < npx; i0 += 64) {
+        const int i = i0 + lane;
+        const int ix = i % C.w, iy = i / C.w;
+        const bool keep = i < npx && nms_keep(s_score + (iy + 1) * sw + ix + 1, sw, th);
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            const int k = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (k < cap)
+                out[k] = (uint32_t)(C.x0 + ix - 16) | ((uint32_t)(C.y0 + iy - 16) << 12) |
+                         ((uint32_t)s_score[(iy + 1) * sw + ix + 1] << 24);
+        }
+        base += __popcll(m);
+    }
+    if (lane == 0) counts[blockIdx.x] = base < cap ? base : cap;
+}
+
+// Exclusive scan of the per-cell counts (single workgroup; cells are few thousand at most).
+__global__ __launch_bounds__(256) void scan_counts_kernel(const int *counts, int n, int *offsets, int *mirror) {
+    __shared__ int s[256];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int b = 0; b < n; b += 256) {
+        const int i = b + threadIdx.x;
+        const int v = i < n ? counts[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int t = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) { offsets[i] = carry + s[threadIdx.x] - v; mirror[i] = carry + s[threadIdx.x] - v; }
+        __syncthreads();
+        if (threadIdx.x == 255) carry += s[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { offsets[n] = carry; mirror[n] = carry; }          // (mirror: the host's copy of the offsets, total last)
+}
+
+__global__ __launch_bounds__(64) void compact_kernel(const uint32_t *slots, int cap, const int *counts,
+                                                    const int *offsets, uint32_t *dense) {
+    const int c = blockIdx.x, n = counts[c], o = offsets[c];
+    for (int k = threadIdx.x; k < n; k += 64) dense[o + k] = slots[(int64_t)c * cap + k];
 }
 
 // ---------------------------------------------------------------- Gaussian blur
@@ -415,8 +495,112 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *pyr
         const int t0 = center[r0 * step + c0], t1 = center[r1 * step + c1];
         nib |= (t0 < t1) << t;
     }
+    // four bytes per store: the record lives in the host's memory (one PCIe write of 36 bytes per keypoint, not 32 single bytes)
     const int hi = __shfl_down(nib, 1);
-    if ((lane & 1) == 0) r[4 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+    const uint32_t byte = (uint32_t)(nib | (hi << 4)) & 0xffu;                // (valid on even lanes: byte lane / 2 of the descriptor)
+    const uint32_t w = byte | (__shfl_down(byte, 2) << 8) | (__shfl_down(byte, 4) << 16) | (__shfl_down(byte, 6) << 24);
+    if ((lane & 7) == 0) reinterpret_cast<uint32_t *>(r + 4)[lane >> 3] = w;
+}
+
+// ---- the separate forms (launch mode bits 2 / 3 clear): A/B against the merged kernels above
+// copyMakeBorder(BORDER_REFLECT_101) of every level in one launch (blockIdx.y = level).
+__global__ void border_kernel(uint8_t *pyr, LevelTable T) {
+    const LevelInfo L = T.lv[blockIdx.y];
+    const int PW = L.cols + 2 * EDGE_THRESHOLD, PH = L.rows + 2 * EDGE_THRESHOLD;
+    uint8_t *base = pyr + L.off;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)PW * PH;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int px = (int)(i % PW), py = (int)(i / PW);
+        const int x = px - EDGE_THRESHOLD, y = py - EDGE_THRESHOLD;
+        if (x >= 0 && x < L.cols && y >= 0 && y < L.rows) continue;
+        const int sx = reflect101(x, L.cols), sy = reflect101(y, L.rows);
+        base[(int64_t)py * L.step + px] = base[(int64_t)(sy + EDGE_THRESHOLD) * L.step + sx + EDGE_THRESHOLD];
+    }
+}
+
+// (blur alone)
+__global__ __launch_bounds__(256) void blur_kernel(const uint8_t *pyr, uint8_t *blur, LevelTable T, int k0, int k1,
+                                                  int k2, int k3) {
+    const LevelInfo L = T.lv[blockIdx.y];
+    const int tiles_x = (L.cols + 31) / 32, tiles_y = (L.rows + 31) / 32;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int x0 = (blockIdx.x % tiles_x) * 32, y0 = (blockIdx.x / tiles_x) * 32;
+    __shared__ uint8_t s_in[38][40];
+    __shared__ int s_row[38][33];
+    const uint8_t *img = pyr + L.off + (int64_t)EDGE_THRESHOLD * L.step + EDGE_THRESHOLD;
+    for (int i = threadIdx.x; i < 38 * 38; i += 256) {
+        const int px = i % 38, py = i / 38;
+        const int gx = reflect101(min(x0 + px - 3, L.cols + 2), L.cols), gy = reflect101(min(y0 + py - 3, L.rows + 2), L.rows);
+        s_in[py][px] = img[(int64_t)gy * L.step + gx];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 38 * 32; i += 256) {
+        const int x = i % 32, y = i / 32;
+        const uint8_t *r = &s_in[y][x];
+        s_row[y][x] = k0 * (r[0] + r[6]) + k1 * (r[1] + r[5]) + k2 * (r[2] + r[4]) + k3 * r[3];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+        const int x = i % 32, y = i / 32;
+        if (x0 + x >= L.cols || y0 + y >= L.rows) continue;
+        const int s = k0 * (s_row[y][x] + s_row[y + 6][x]) + k1 * (s_row[y + 1][x] + s_row[y + 5][x]) +
+                      k2 * (s_row[y + 2][x] + s_row[y + 4][x]) + k3 * s_row[y + 3][x];
+        const int v = (s + (1 << 15)) >> 16;
+        blur[L.blur_off + (int64_t)(y0 + y) * L.cols + x0 + x] = (uint8_t)(v > 255 ? 255 : v);
+    }
+}
+
+// IC_Angle (ORBextractor.cc:75-100): one wave per keypoint, lane = patch row v in [-15,15];
+// integer moments are order independent, so the wave reduction is exact.
+__global__ __launch_bounds__(256) void angle_kernel(const uint8_t *pyr, LevelTable T, const DevKp *kps, int n,
+                                                   float *angles) {
+    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n) return;
+    const DevKp kp = kps[k];
+    const LevelInfo L = T.lv[kp.level];
+    const uint8_t *center = pyr + L.off + (int64_t)(EDGE_THRESHOLD + __float2int_rn(kp.y)) * L.step + EDGE_THRESHOLD +
+                            __float2int_rn(kp.x);
+    int m10 = 0, m01 = 0;
+    if (lane < 2 * HALF_PATCH + 1) {
+        const int v = lane - HALF_PATCH;
+        const int d = c_umax[v < 0 ? -v : v];
+        const uint8_t *row = center + (int64_t)v * L.step;
+        int s = 0;
+        for (int u = -d; u <= d; ++u) { const int val = row[u]; m10 += u * val; s += val; }
+        m01 = v * s;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    if (lane == 0) angles[k] = fast_atan2_deg((float)m01, (float)m10);
+}
+
+// computeOrbDescriptor (ORBextractor.cc:104-150) on the blurred level image: one wave per
+// keypoint, lane l evaluates tests 4l..4l+3 (a nibble); lanes pair up into bytes.
+__global__ __launch_bounds__(256) void descriptor_kernel(const uint8_t *blur, LevelTable T, const DevKp *kps,
+                                                        const float *angles, int n, uint8_t *desc) {
+    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n) return;
+    const DevKp kp = kps[k];
+    const LevelInfo L = T.lv[kp.level];
+    const float factorPI = (float)(3.141592653589793238462643383279502884 / 180.f);
+    const float angle = __fmul_rn(angles[k], factorPI);
+    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    const int step = L.cols;
+    const uint8_t *center = blur + L.blur_off + (int64_t)__float2int_rn(kp.y) * step + __float2int_rn(kp.x);
+    int nib = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int8_t *p = c_pattern + 4 * (4 * lane + t);
+        const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = center[r0 * step + c0], t1 = center[r1 * step + c1];
+        nib |= (t0 < t1) << t;
+    }
+    const int hi = __shfl_down(nib, 1);
+    if ((lane & 1) == 0) desc[(int64_t)k * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
 }
 
 // ---------------------------------------------------------------- stereo SAD (Frame.cc:543-583)
@@ -460,7 +644,15 @@ __global__ __launch_bounds__(256) void stereo_sad_kernel(const uint8_t *pyrL, Le
 // ================================================================== host side
 using namespace sivo;
 
+// Host memory that kernels read and write directly (zero-copy): COHERENT (fine-grained) pinned memory — the device does not cache it, a
+// kernel's stores are in the host's memory when its stream has been synchronised with and the host's stores are what the next kernel
+// reads.  (With hipHostMallocDefault one extraction in ~10 read cell offsets of which some were the previous frame's: round 6.)
+constexpr unsigned ORB_PINNED = hipHostMallocCoherent | hipHostMallocMapped;
+
 struct sivo_orb {
+    // One image at a time: an extraction, and a stereo matching that reads this extractor's pyramid, hold this lock (a second thread
+    // entering the same handle waits instead of interleaving with the first one's buffers).
+    std::mutex mu;
     int device = 0;
     int nfeatures, nlevels, ini_th, min_th;
     double scale_factor;
@@ -479,22 +671,33 @@ struct sivo_orb {
     XTab *d_xt[MAX_LEVELS] = {};
     YTab *d_yt[MAX_LEVELS] = {};
     CellInfo *d_cells = nullptr;
-    // FAST results, one region so that ONE copy brings them to the host: [offsets: ncells + 1, padded to off_words][dense candidates]
-    int *d_fast = nullptr, *h_fast = nullptr;      // (h_fast pinned)
+    // FAST results: [offsets: ncells + 1 | error word, padded to off_words][dense candidates] in PINNED HOST memory that the kernels write
+    // directly (zero-copy, ~70 KB per image): beside a network that keeps every CU busy a copy is one more dependent operation that
+    // has to wait for a CU (blit kernel) or an engine, and the extraction is a chain of such waits (profiles/r06_ab_serial.log)
+    int *h_fast = nullptr, *d_fast = nullptr;      // (d_fast: the device's address of h_fast)
     size_t off_words = 0, dense_cap = 0;
     uint32_t *d_status = nullptr;     // per cell: epoch << 12 | count (fast_cells_kernel)
     int *d_err = nullptr;
     uint32_t epoch = 0;
-    static constexpr size_t DENSE_FIRST = 24 * 1024;       // candidates the first copy brings along (a 352 x 1024 frame has 10 - 20 k); more: a second copy
     // the pyramid in one launch (pyramid_kernel) when the footprints fit its staging buffers
     std::vector<XTab> h_xt[MAX_LEVELS];
     std::vector<YTab> h_yt[MAX_LEVELS];
     PyrTile *d_tiles = nullptr;
     int ntiles = 0;
-    bool fused_pyramid = false;
+    bool fused_pyramid = false;     // the footprints fit the kernel's LDS
+    // sivo_orb_set_launch_mode: bit 0 the pyramid in one launch, bit 1 FAST + scan + emission in one launch, bit 2 blur + borders in one
+    // launch, bit 3 IC angle + rBRIEF in one launch.  Default 15: four launches per image.  Measured inside the frame of bench.py (the
+    // network keeps every CU busy; 8 runs each on one box, profiles/r06_orb_launch_modes.log): 15 -> 144.2 frames/s, 14 (pyramid level
+    // by level: its resize kernels need no LDS and slip in beside the network's whole-LDS workgroups) -> 145.1, 0 (the round-5 kernels) ->
+    // 146 / 145; round 5's code with its 12 copies per stereo pair -> 143.8.  Alone on the GPU 15 is the fastest (1.0 ms per stereo pair).
+    int launch_mode = 15;
+    uint32_t *d_slots = nullptr;    // three-launch FAST: ncells x cap candidate slots
+    int *d_counts = nullptr, *d_offsets = nullptr;
     PyrTables pyr_tabs{};
-    DevKp *d_kps = nullptr, *h_kps = nullptr;
-    uint8_t *d_rec = nullptr, *h_rec = nullptr;     // [angle | descriptor] records (KP_REC bytes per keypoint)
+    DevKp *h_kps = nullptr, *d_kps = nullptr;       // pinned; d_* = the device's address of the same memory: the kernel reads the kept keys
+    uint8_t *h_rec = nullptr, *d_rec = nullptr;     // from the host's memory and writes the [angle | descriptor] records (KP_REC bytes per keypoint) there
+    float *d_angles = nullptr;                      // separate angle / descriptor kernels (launch mode bit 3 clear)
+    uint8_t *d_desc = nullptr;
     int kp_cap = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
@@ -519,7 +722,7 @@ struct sivo_orb {
             if (h_match) (void)hipHostFree(h_match);
             h_match = nullptr;
             h_match_cap = bytes + bytes / 2;
-            SIVO_HIP(hipHostMalloc((void **)&h_match, h_match_cap, hipHostMallocDefault));
+            SIVO_HIP(hipHostMalloc((void **)&h_match, h_match_cap, ORB_PINNED));
         }
         return h_match;
     }
@@ -534,7 +737,7 @@ struct sivo_orb {
     }
 
     void free_geometry() {
-        for (void *p : {(void *)d_pyr, (void *)d_blur, (void *)d_src, (void *)d_cells, (void *)d_fast, (void *)d_status, (void *)d_tiles})
+        for (void *p : {(void *)d_pyr, (void *)d_blur, (void *)d_src, (void *)d_cells, (void *)d_status, (void *)d_tiles, (void *)d_slots, (void *)d_counts, (void *)d_offsets})
             if (p) (void)hipFree(p);
         for (int l = 0; l < MAX_LEVELS; ++l) {
             if (d_xt[l]) (void)hipFree(d_xt[l]);
@@ -543,15 +746,16 @@ struct sivo_orb {
         }
         if (h_fast) (void)hipHostFree(h_fast);
         d_pyr = d_blur = d_src = nullptr; d_cells = nullptr; d_fast = nullptr; h_fast = nullptr;
-        d_status = nullptr; d_err = nullptr; d_tiles = nullptr; ntiles = 0; fused_pyramid = false;
+        d_status = nullptr; d_err = nullptr; d_tiles = nullptr; d_slots = nullptr; d_counts = nullptr; d_offsets = nullptr; ntiles = 0; fused_pyramid = false;
         src_bytes = 0;
     }
     ~sivo_orb() {
         free_geometry();
         if (d_match) (void)hipFree(d_match);
         if (h_match) (void)hipHostFree(h_match);
-        if (d_kps) (void)hipFree(d_kps);
-        if (d_rec) (void)hipFree(d_rec);
+
+        if (d_angles) (void)hipFree(d_angles);
+        if (d_desc) (void)hipFree(d_desc);
         if (h_kps) (void)hipHostFree(h_kps);
         if (h_rec) (void)hipHostFree(h_rec);
         for (int i = 0; i < NPROF; ++i) {
@@ -736,30 +940,36 @@ void setup_geometry(sivo_orb &o, int rows, int cols) {
     if (nc) SIVO_HIP(hipMemcpy(o.d_cells, o.cells.data(), nc * sizeof(CellInfo), hipMemcpyHostToDevice));
     o.dense_cap = std::max<size_t>(nc * cap, 1);
     o.off_words = (nc + 2 + 63) / 64 * 64;          // nc + 1 offsets, then the error word of the scan
-    o.d_fast = dev_alloc<int>(o.off_words + o.dense_cap);
-    SIVO_HIP(hipMemset(o.d_fast, 0, (o.off_words + o.dense_cap) * sizeof(int)));
+    SIVO_HIP(hipHostMalloc((void **)&o.h_fast, (o.off_words + o.dense_cap) * sizeof(int), ORB_PINNED));
+    std::memset(o.h_fast, 0, (o.off_words + o.dense_cap) * sizeof(int));
+    SIVO_HIP(hipHostGetDevicePointer((void **)&o.d_fast, o.h_fast, 0));
     if (cap >= 4096) throw std::runtime_error("FAST cell capacity beyond the 12 bits of its status word");
     o.d_status = dev_alloc<uint32_t>(nc + 1);
+    o.d_slots = dev_alloc<uint32_t>(std::max<size_t>(nc * cap, 1));
+    o.d_counts = dev_alloc<int>(nc + 1);
+    o.d_offsets = dev_alloc<int>(nc + 1);
     o.d_err = o.d_fast + nc + 1;                    // (inside the region the host copies: zero from the memset above)
     SIVO_HIP(hipMemset(o.d_status, 0, (nc + 1) * sizeof(uint32_t)));
     o.epoch = 0;
-    SIVO_HIP(hipHostMalloc((void **)&o.h_fast, (o.off_words + o.dense_cap) * sizeof(int), hipHostMallocDefault));
     o.have_pyramid = false;
 }
 
 void ensure_kp_capacity(sivo_orb &o, int n) {
     if (n <= o.kp_cap) return;
-    if (o.d_kps) { (void)hipFree(o.d_kps); (void)hipFree(o.d_rec); (void)hipHostFree(o.h_kps); (void)hipHostFree(o.h_rec); }
+    if (o.h_kps) { (void)hipHostFree(o.h_kps); (void)hipHostFree(o.h_rec); }
     const int cap = std::max(n, 4096);
-    o.d_kps = dev_alloc<DevKp>(cap); o.d_rec = dev_alloc<uint8_t>((size_t)cap * KP_REC);
-    SIVO_HIP(hipHostMalloc((void **)&o.h_kps, cap * sizeof(DevKp), hipHostMallocDefault));
-    SIVO_HIP(hipHostMalloc((void **)&o.h_rec, (size_t)cap * KP_REC, hipHostMallocDefault));
+    if (o.d_angles) { (void)hipFree(o.d_angles); (void)hipFree(o.d_desc); }
+    o.d_angles = dev_alloc<float>(cap); o.d_desc = dev_alloc<uint8_t>((size_t)cap * 32);
+    SIVO_HIP(hipHostMalloc((void **)&o.h_kps, cap * sizeof(DevKp), ORB_PINNED));
+    SIVO_HIP(hipHostMalloc((void **)&o.h_rec, (size_t)cap * KP_REC, ORB_PINNED));
+    SIVO_HIP(hipHostGetDevicePointer((void **)&o.d_kps, o.h_kps, 0));
+    SIVO_HIP(hipHostGetDevicePointer((void **)&o.d_rec, o.h_rec, 0));
     o.kp_cap = cap;
 }
 
 // The whole operator(): d_src is a device image (rows x cols, stride step).
-int extract(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, SivoKeyPoint *keypoints,
-            uint8_t *descriptors, int capacity, int *n_out, hipStream_t user_stream) {
+int extract_locked(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, SivoKeyPoint *keypoints,
+                   uint8_t *descriptors, int capacity, int *n_out, hipStream_t user_stream) {
     setup_geometry(o, rows, cols);
     hipStream_t st = o.stream;
     if (user_stream) {   // order after the producer of d_src
@@ -775,7 +985,7 @@ int extract(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, Siv
     };
     // ---- pyramid
     mark(0, false, st);
-    if (o.fused_pyramid) {
+    if (o.fused_pyramid && (o.launch_mode & 1)) {
         hipLaunchKernelGGL(pyramid_kernel, dim3(o.ntiles), dim3(PYR_T), 0, st, d_src, step, o.d_pyr, T, o.pyr_tabs, o.d_tiles);
     } else {        // footprints beyond the staging buffers (more levels / larger scale steps than ORB-SLAM's): level by level
         const LevelInfo &L0 = T.lv[0];
@@ -797,34 +1007,38 @@ int extract(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, Siv
         int max_tiles = BORDER_BLOCKS;
         for (int l = 0; l < o.nlevels; ++l) max_tiles = std::max(max_tiles, cdiv(T.lv[l].cols, 32) * cdiv(T.lv[l].rows, 32));
         mark(1, false, o.stream2);
-        hipLaunchKernelGGL(blur_border_kernel, dim3(max_tiles, 2 * o.nlevels), dim3(256), 0, o.stream2, o.d_pyr, o.d_blur, T, o.gk[0], o.gk[1],
-                           o.gk[2], o.gk[3]);
+        if (o.launch_mode & 4) {
+            hipLaunchKernelGGL(blur_border_kernel, dim3(max_tiles, 2 * o.nlevels), dim3(256), 0, o.stream2, o.d_pyr, o.d_blur, T, o.gk[0], o.gk[1],
+                               o.gk[2], o.gk[3]);
+        } else {
+            hipLaunchKernelGGL(blur_kernel, dim3(max_tiles, o.nlevels), dim3(256), 0, o.stream2, o.d_pyr, o.d_blur, T, o.gk[0], o.gk[1], o.gk[2], o.gk[3]);
+            hipLaunchKernelGGL(border_kernel, dim3(64, o.nlevels), dim3(256), 0, o.stream2, o.d_pyr, T);
+        }
         mark(1, true, o.stream2);
         SIVO_HIP(hipEventRecord(o.ev_blur, o.stream2));
     }
-    // ---- FAST cells -> ordered candidate list, one copy: [cell offsets | the first DENSE_FIRST candidates]
+    // ---- FAST cells -> ordered candidate list, written by the kernels into the host's (pinned) memory: [cell offsets | candidates]
     const int nc = (int)o.cells.size();
     int total = 0;
     int *h_off = o.h_fast;
     const uint32_t *h_dense = reinterpret_cast<const uint32_t *>(o.h_fast + o.off_words);
     if (nc) {
-        mark(2, false, st);
-        o.epoch = (o.epoch % FAST_EPOCH_MASK) + 1;          // 1 .. 2^20 - 1: never the zero the status words start with
-        hipLaunchKernelGGL(fast_cells_kernel, dim3(nc), dim3(64), 0, st, o.d_pyr, T, o.d_cells, nc, o.ini_th, o.min_th, o.cap, o.d_status,
-                           o.epoch, o.d_fast, reinterpret_cast<uint32_t *>(o.d_fast + o.off_words), o.d_err);
-        mark(2, true, st);
-        const size_t first = std::min(o.dense_cap, sivo_orb::DENSE_FIRST);
         h_off[nc] = -1;
-        SIVO_HIP(hipMemcpyAsync(o.h_fast, o.d_fast, (o.off_words + first) * sizeof(int), hipMemcpyDeviceToHost, st));
-        SIVO_HIP(hipStreamSynchronize(st));
+        mark(2, false, st);
+        if (o.launch_mode & 2) {
+            o.epoch = (o.epoch % FAST_EPOCH_MASK) + 1;          // 1 .. 2^20 - 1: never the zero the status words start with
+            hipLaunchKernelGGL(fast_cells_kernel, dim3(nc), dim3(64), 0, st, o.d_pyr, T, o.d_cells, nc, o.ini_th, o.min_th, o.cap, o.d_status,
+                               o.epoch, o.d_fast, reinterpret_cast<uint32_t *>(o.d_fast + o.off_words), o.d_err);
+        } else {
+            hipLaunchKernelGGL(fast_cells_slots_kernel, dim3(nc), dim3(64), 0, st, o.d_pyr, T, o.d_cells, o.ini_th, o.min_th, o.d_slots, o.cap, o.d_counts);
+            hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(256), 0, st, o.d_counts, nc, o.d_offsets, o.d_fast);
+            hipLaunchKernelGGL(compact_kernel, dim3(nc), dim3(64), 0, st, o.d_slots, o.cap, o.d_counts, o.d_offsets, reinterpret_cast<uint32_t *>(o.d_fast + o.off_words));
+        }
+        mark(2, true, st);
+        SIVO_HIP(hipStreamSynchronize(st));                 // the kernels wrote offsets and candidates into h_fast themselves
         total = h_off[nc];
         if (total < 0 || (size_t)total > o.dense_cap || h_off[nc + 1] != 0)
             return fail(SIVO_ERR_RUNTIME, "FAST candidate scan did not complete (total %d, error word %d)", total, h_off[nc + 1]);
-        if ((size_t)total > first) {
-            SIVO_HIP(hipMemcpyAsync(o.h_fast + o.off_words + first, o.d_fast + o.off_words + first, ((size_t)total - first) * sizeof(int),
-                                    hipMemcpyDeviceToHost, st));
-            SIVO_HIP(hipStreamSynchronize(st));
-        }
     }
     o.have_pyramid = true;
     // ---- host: quadtree per level (ORBextractor.cc:821-841)
@@ -835,6 +1049,15 @@ int extract(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, Siv
         const int c0 = o.level_cell_begin[l], c1 = o.level_cell_begin[l + 1];
         if (c0 == c1) continue;
         const int b = h_off[c0], e = h_off[c1];
+        if (b < 0 || e < b || e > total) {
+            // (diagnosis of an inconsistent offset table: what the device holds against what the host sees)
+            std::vector<int> dev(nc + 1, -7);
+            if (!(o.launch_mode & 2)) (void)hipMemcpy(dev.data(), o.d_offsets, (size_t)(nc + 1) * sizeof(int), hipMemcpyDeviceToHost);
+            int bad = 0, first_bad = -1;
+            for (int i = 0; i <= nc; ++i) if (dev[i] != h_off[i]) { if (first_bad < 0) first_bad = i; ++bad; }
+            return fail(SIVO_ERR_RUNTIME, "FAST offsets inconsistent: level %d cells [%d, %d) offsets %d .. %d, total %d, ncells %d; host != device at %d entries (first %d: host %d device %d)",
+                        l, c0, c1, b, e, total, nc, bad, first_bad, first_bad >= 0 ? h_off[first_bad] : 0, first_bad >= 0 ? dev[first_bad] : 0);
+        }
         std::vector<SivoKeyPoint> &cand = o.last_candidates[l];
         cand.resize(e - b);
         for (int i = b; i < e; ++i) {
@@ -862,13 +1085,27 @@ int extract(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, Siv
     // ---- device: orientation + descriptors
     ensure_kp_capacity(o, n);
     for (int i = 0; i < n; ++i) o.h_kps[i] = DevKp{all[i].x, all[i].y, all[i].octave};
-    SIVO_HIP(hipMemcpyAsync(o.d_kps, o.h_kps, (size_t)n * sizeof(DevKp), hipMemcpyHostToDevice, st));
-    SIVO_HIP(hipStreamWaitEvent(st, o.ev_blur, 0));
-    mark(3, false, st);
-    hipLaunchKernelGGL(orient_describe_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, o.d_pyr, o.d_blur, T, o.d_kps, n, o.d_rec);
-    mark(3, true, st);
-    SIVO_HIP(hipMemcpyAsync(o.h_rec, o.d_rec, (size_t)n * KP_REC, hipMemcpyDeviceToHost, st));
-    SIVO_HIP(hipStreamSynchronize(st));
+    if (o.launch_mode & 8) {
+        SIVO_HIP(hipStreamWaitEvent(st, o.ev_blur, 0));
+        mark(3, false, st);
+        hipLaunchKernelGGL(orient_describe_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, o.d_pyr, o.d_blur, T, o.d_kps, n, o.d_rec);
+        mark(3, true, st);
+        SIVO_HIP(hipStreamSynchronize(st));
+    } else {
+        mark(3, false, st);
+        hipLaunchKernelGGL(angle_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, o.d_pyr, T, o.d_kps, n, o.d_angles);
+        mark(3, true, st);
+        SIVO_HIP(hipStreamWaitEvent(st, o.ev_blur, 0));
+        mark(4, false, st);
+        hipLaunchKernelGGL(descriptor_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, o.d_blur, T, o.d_kps, o.d_angles, n, o.d_desc);
+        mark(4, true, st);
+        // (into the record layout the assembly below reads: angles behind the first n records' worth of descriptors is not possible in one
+        // copy — two copies, as until round 5)
+        SIVO_HIP(hipMemcpyAsync(o.h_rec, o.d_angles, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        SIVO_HIP(hipMemcpyAsync(o.h_rec + (size_t)o.kp_cap * 4, o.d_desc, (size_t)n * 32, hipMemcpyDeviceToHost, st));
+        SIVO_HIP(hipStreamSynchronize(st));
+    }
+    const bool recs = (o.launch_mode & 8) != 0;
     SIVO_HIP(hipGetLastError());
     if (o.prof) {
         SIVO_HIP(hipStreamSynchronize(o.stream2));
@@ -884,12 +1121,13 @@ int extract(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, Siv
     // ---- assemble (ORBextractor.cc:1068-1081): pt *= scale for level > 0
     for (int i = 0; i < n; ++i) {
         SivoKeyPoint k = all[i];
-        std::memcpy(&k.angle, o.h_rec + (size_t)i * KP_REC, 4);
+        std::memcpy(&k.angle, recs ? o.h_rec + (size_t)i * KP_REC : o.h_rec + (size_t)i * 4, 4);
         if (k.octave != 0) { const float s = o.scale[k.octave]; k.x *= s; k.y *= s; }
         keypoints[i] = k;
     }
     if (descriptors)
-        for (int i = 0; i < n; ++i) std::memcpy(descriptors + (size_t)i * 32, o.h_rec + (size_t)i * KP_REC + 4, 32);
+        for (int i = 0; i < n; ++i)
+            std::memcpy(descriptors + (size_t)i * 32, recs ? o.h_rec + (size_t)i * KP_REC + 4 : o.h_rec + (size_t)o.kp_cap * 4 + (size_t)i * 32, 32);
     return SIVO_OK;
 }
 
@@ -900,6 +1138,15 @@ int extract(sivo_orb &o, const uint8_t *d_src, int rows, int cols, int step, Siv
 // (OpenCV 3.2 - 3.4.12 and 4.0 - 4.5.0; the default), 1 = getGaussianKernelFixedPoint_ED of OpenCV >= 3.4.13 / >= 4.5.1: the
 // rounding error carried from tap to tap, the centre takes the rest of 256: 18 34 48 56 48 34 18.  Same arithmetic either way
 // (blur_kernel); oracle: orb_oracle.c orc_gaussian7_taps.
+extern "C" int sivo_orb_set_launch_mode(sivo_orb_t h, int mode) {
+    return guarded([&] {
+        if (!h) throw std::invalid_argument("null handle");
+        if (mode < 0 || mode > 15) throw std::invalid_argument("launch mode: bits 0 - 3 (pyramid, FAST, blur + borders, angle + descriptor in one launch each)");
+        h->launch_mode = mode;
+        return SIVO_OK;
+    });
+}
+
 extern "C" int sivo_orb_set_gaussian(sivo_orb_t h, int variant) {
     return guarded([&] {
         if (!h) throw std::invalid_argument("null handle");
@@ -988,7 +1235,8 @@ extern "C" int sivo_orb_extract_dev(sivo_orb_t h, const uint8_t *d_gray, int row
         if (!d_gray || rows <= 0 || cols <= 0) return SIVO_OK;   // _image.empty(): return silently (:1023-1024)
         if (step < cols || !keypoints) throw std::invalid_argument("bad step / null keypoints");
         DeviceGuard dg(h->device);
-        return extract(*h, d_gray, rows, cols, step, keypoints, descriptors, capacity, n_out, (hipStream_t)stream);
+        std::lock_guard<std::mutex> one_image(h->mu);
+        return extract_locked(*h, d_gray, rows, cols, step, keypoints, descriptors, capacity, n_out, (hipStream_t)stream);
     });
 }
 
@@ -1000,6 +1248,7 @@ extern "C" int sivo_orb_extract(sivo_orb_t h, const uint8_t *gray, int rows, int
         if (!gray || rows <= 0 || cols <= 0) return SIVO_OK;
         if (step < cols || !keypoints) throw std::invalid_argument("bad step / null keypoints");
         DeviceGuard dg(h->device);
+        std::lock_guard<std::mutex> one_image(h->mu);
         const size_t need = (size_t)rows * cols;
         if (h->src_bytes < need || h->rows != rows || h->cols != cols) {
             setup_geometry(*h, rows, cols);
@@ -1008,7 +1257,7 @@ extern "C" int sivo_orb_extract(sivo_orb_t h, const uint8_t *gray, int rows, int
             h->src_bytes = need;
         }
         SIVO_HIP(hipMemcpy2DAsync(h->d_src, cols, gray, step, cols, rows, hipMemcpyHostToDevice, h->stream));
-        return extract(*h, h->d_src, rows, cols, cols, keypoints, descriptors, capacity, n_out, nullptr);
+        return extract_locked(*h, h->d_src, rows, cols, cols, keypoints, descriptors, capacity, n_out, nullptr);
     });
 }
 
@@ -1073,6 +1322,8 @@ extern "C" int sivo_stereo_match_begin(sivo_orb_t left, sivo_orb_t right, const 
     return guarded([&] {
         if (!left || !right || nL < 0 || nR < 0 || (nL && (!kpL || !descL || !u_right || !depth)) || (nR && (!kpR || !descR)))
             throw std::invalid_argument("bad argument");
+        std::unique_lock<std::mutex> lock_l(left->mu, std::defer_lock), lock_r(right->mu, std::defer_lock);
+        if (left == right) lock_l.lock(); else std::lock(lock_l, lock_r);
         if (!left->have_pyramid || !right->have_pyramid) throw std::invalid_argument("both extractors must hold a pyramid");
         if (left->nlevels != right->nlevels || left->rows != right->rows || left->cols != right->cols)
             throw std::invalid_argument("left/right extractors differ in geometry");
@@ -1113,8 +1364,10 @@ extern "C" int sivo_stereo_match_begin(sivo_orb_t left, sivo_orb_t right, const 
                      o_sd = o_bd + al((size_t)nL * 4), o_jobs = o_sd + al((size_t)nL * 4),
                      o_dists = o_jobs + al((size_t)nL * sizeof(SadJob)), total = o_dists + al((size_t)nL * 11 * 4);
         uint8_t *base = (uint8_t *)left->match_arena(total);
-        // inputs [descL | descR | off | idx] in one staged copy; the pinned buffer also receives [best index | best distance] (o_bi .. o_sd)
-        uint8_t *hs = left->match_stage(o_sd);
+        // inputs [descL | descR | off | idx] in ONE staged copy (they are read many times: device memory); the results — best index / best
+        // distance, later the SAD distances — are written by the kernels into the pinned twin directly, and the SAD jobs are read from it
+        uint8_t *hs = left->match_stage(total), *hs_dev = nullptr;
+        SIVO_HIP(hipHostGetDevicePointer((void **)&hs_dev, hs, 0));
         std::memcpy(hs + o_dl, descL, (size_t)nL * 32);
         std::memcpy(hs + o_dr, descR, (size_t)nR * 32);
         std::memcpy(hs + o_off, off.data(), (size_t)(nL + 1) * 4);
@@ -1122,9 +1375,8 @@ extern "C" int sivo_stereo_match_begin(sivo_orb_t left, sivo_orb_t right, const 
         SIVO_HIP(hipMemcpyAsync(base, hs, o_idx + idx.size() * 4, hipMemcpyHostToDevice, st));
         const int *bi = reinterpret_cast<const int *>(hs + o_bi), *bd = reinterpret_cast<const int *>(hs + o_bd);
         int rc = sivo_hamming_argmin2_dev(base + o_dl, nL, base + o_dr, (const int32_t *)(base + o_off), (const int32_t *)(base + o_idx),
-                                          (int32_t *)(base + o_bi), (int32_t *)(base + o_bd), (int32_t *)(base + o_sd), nullptr, st);
+                                          (int32_t *)(hs_dev + o_bi), (int32_t *)(hs_dev + o_bd), (int32_t *)(base + o_sd), nullptr, st);
         if (rc) return rc;
-        SIVO_HIP(hipMemcpyAsync(hs + o_bi, base + o_bi, (o_bd - o_bi) + (size_t)nL * 4, hipMemcpyDeviceToHost, st));
         SIVO_HIP(hipStreamSynchronize(st));
         // SAD jobs (:538-565)
         std::vector<SadJob> jobs;
@@ -1142,17 +1394,16 @@ extern "C" int sivo_stereo_match_begin(sivo_orb_t left, sivo_orb_t right, const 
             jobs.push_back(SadJob{lvl, (int)svL, (int)suL, (int)suR0});
             jobL.push_back(iL);
         }
-        std::vector<int> dists(jobs.size() * 11);
+        const int *dists = reinterpret_cast<const int *>(hs + o_dists);
         if (!jobs.empty()) {
-            SadJob *dj = (SadJob *)(base + o_jobs);
-            int *dd = (int *)(base + o_dists);
-            SIVO_HIP(hipMemcpyAsync(dj, jobs.data(), jobs.size() * sizeof(SadJob), hipMemcpyHostToDevice, st));
+            std::memcpy(hs + o_jobs, jobs.data(), jobs.size() * sizeof(SadJob));      // (each job is read once by its wave: from the host's memory)
+            SadJob *dj = (SadJob *)(hs_dev + o_jobs);
+            int *dd = (int *)(hs_dev + o_dists);
             SIVO_HIP(hipStreamSynchronize(left->stream2));       // the pyramids of both extractors are complete
             SIVO_HIP(hipStreamSynchronize(right->stream));
             SIVO_HIP(hipStreamSynchronize(right->stream2));
             hipLaunchKernelGGL(stereo_sad_kernel, dim3(cdiv((int)jobs.size(), 4)), dim3(256), 0, st, left->d_pyr, left->table,
                                right->d_pyr, right->table, dj, (int)jobs.size(), dd);
-            SIVO_HIP(hipMemcpyAsync(dists.data(), dd, dists.size() * sizeof(int), hipMemcpyDeviceToHost, st));
             SIVO_HIP(hipStreamSynchronize(st));
         }
         // decision logic (:567-628)

@@ -11,22 +11,29 @@ namespace sivo {
 void harvest(sivo_segnet &S) {
     if (!S.pending) return;
     for (Op &op : S.ops) {
-        if (!op.timed_last) continue;
-        op.timed_last = false;
-        float ms = 0.f;
-        if (!op.w4_gemm_only_last) {
-            SIVO_HIP(hipEventSynchronize(op.ev1));
-            SIVO_HIP(hipEventElapsedTime(&ms, op.ev0, op.ev1));
-            op.ms_total += ms;
-        }
-        op.launches += 1;
-        for (int g = 0; g < op.w4_groups_last; ++g)
-            for (int k = op.w4_gemm_only_last ? 1 : 0; k < (op.w4_gemm_only_last ? 2 : 3); ++k) {
-                SIVO_HIP(hipEventSynchronize(op.w4_ev[4 * g + k + 1]));
-                SIVO_HIP(hipEventElapsedTime(&ms, op.w4_ev[4 * g + k], op.w4_ev[4 * g + k + 1]));
-                op.w4_ms[k] += ms;
+        if (!op.timed_mask) continue;
+        int n = 0;
+        for (int l = 0; l < Op::PROF_LANES; ++l) {
+            if (!(op.timed_mask & (1u << l))) continue;
+            float ms = 0.f;
+            if (!op.w4_gemm_only_last) {
+                SIVO_HIP(hipEventSynchronize(op.ev1[l]));
+                SIVO_HIP(hipEventElapsedTime(&ms, op.ev0[l], op.ev1[l]));
+                op.ms_total += ms;
             }
-        op.w4_launches += op.w4_groups_last;
+            for (int g = 0; g < op.w4_groups_last[l]; ++g)
+                for (int k = op.w4_gemm_only_last ? 1 : 0; k < (op.w4_gemm_only_last ? 2 : 3); ++k) {
+                    SIVO_HIP(hipEventSynchronize(op.w4_ev[l][4 * g + k + 1]));
+                    SIVO_HIP(hipEventElapsedTime(&ms, op.w4_ev[l][4 * g + k], op.w4_ev[l][4 * g + k + 1]));
+                    op.w4_ms[k] += ms;
+                }
+            op.w4_launches += op.w4_groups_last[l];
+            op.kernel_launches += 1;
+            n += op.lane_n[l];
+        }
+        op.last_n = n;               // samples of the forward pass (all lanes)
+        op.launches += 1;
+        op.timed_mask = 0;
     }
     S.pending = false;
 }
@@ -47,10 +54,10 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
         const int N = bo.shared ? 1 : n;
         const bool timed = S.profile && (!S.profile_mfma_only || op.kind == OP_CONV);
         const bool bracket = timed && !(S.profile_mfma_only && op.wino4);      // an F(4x4) layer then only times its GEMM
-        if (timed) { op.timed_last = true; op.w4_gemm_only_last = S.profile_mfma_only && op.wino4; op.last_n = N; }
+        if (timed) { op.timed_mask |= 1u << lane; op.w4_gemm_only_last = S.profile_mfma_only && op.wino4; op.lane_n[lane] = N; }
         if (bracket) {
-            if (!op.ev0) { SIVO_HIP(hipEventCreate(&op.ev0)); SIVO_HIP(hipEventCreate(&op.ev1)); }
-            SIVO_HIP(hipEventRecord(op.ev0, st));
+            if (!op.ev0[lane]) { SIVO_HIP(hipEventCreate(&op.ev0[lane])); SIVO_HIP(hipEventCreate(&op.ev1[lane])); }
+            SIVO_HIP(hipEventRecord(op.ev0[lane], st));
         }
         switch (op.kind) {
             case OP_CONV: {
@@ -122,15 +129,15 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                 } else if (op.wino4) {
                     hipEvent_t *sub = nullptr;
                     if (S.profile) {
-                        op.w4_groups_last = cdiv(N, op.wino4_group);
-                        while ((int)op.w4_ev.size() < 4 * op.w4_groups_last) {
+                        op.w4_groups_last[lane] = cdiv(N, op.wino4_group);
+                        while ((int)op.w4_ev[lane].size() < 4 * op.w4_groups_last[lane]) {
                             hipEvent_t e;
                             SIVO_HIP(hipEventCreate(&e));
-                            op.w4_ev.push_back(e);
+                            op.w4_ev[lane].push_back(e);
                         }
-                        sub = op.w4_ev.data();
+                        sub = op.w4_ev[lane].data();
                     } else {
-                        op.w4_groups_last = 0;
+                        op.w4_groups_last[lane] = 0;
                     }
                     Wino4Plan plan{};
                     const bool planned = op.wino4_group >= N && S.wino4_slot_floats;
@@ -202,7 +209,7 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                            op.beta, st);
                 break;
         }
-        if (bracket) SIVO_HIP(hipEventRecord(op.ev1, st));
+        if (bracket) SIVO_HIP(hipEventRecord(op.ev1[lane], st));
         const bool debug_sync = S.opt.debug_sync != 0;      // debugging aid: serialise every op of every lane
         if (debug_sync) SIVO_HIP(hipDeviceSynchronize());
     }
@@ -239,7 +246,7 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
     // with the f16x3 kernels, profiles/r05_lanes_sweep.log; T = 48: 40.9 / 40.5 / 40.1 for 2 / 3 / 4; round 1's fp32 kernels preferred 3): how many
     // sample groups run side by side; profiling keeps one launch per op, and lanes of fewer than 2 samples gain nothing
     int lanes = S.d_wino4_ws ? S.ws_lanes : 2;
-    if (S.profile) lanes = 1;
+    if (S.profile && !S.profile_keep_lanes) lanes = 1;
     while (lanes > 1 && n < 2 * lanes) --lanes;
     // The op at the fork (pool3 with its fused dropout in SegNet-Standard) produces per-sample values but also writes a
     // SHARED blob, the pooling switches every sample's decoder reads.  It runs once for all samples on the caller's
@@ -294,13 +301,13 @@ void forward(sivo_segnet &S, const uint8_t *d_bgr, int n, int sample0, uint64_t 
         if (S.calibrating && op.c3 && S.d_h3_vmax)       // the classifier's largest |input| (calibration runs the fp32 chain)
             launch_absmax((const float *)bi.d, (int64_t)n * bi.chw(), S.d_h3_vmax + S.ops.size() + S.cls_op, st);
         if (S.profile) {
-            op.timed_last = true; op.w4_gemm_only_last = false; op.w4_groups_last = 0; op.last_n = n;
-            if (!op.ev0) { SIVO_HIP(hipEventCreate(&op.ev0)); SIVO_HIP(hipEventCreate(&op.ev1)); }
-            SIVO_HIP(hipEventRecord(op.ev0, st));
+            op.timed_mask = 1u; op.w4_gemm_only_last = false; op.w4_groups_last[0] = 0; op.lane_n[0] = n;
+            if (!op.ev0[0]) { SIVO_HIP(hipEventCreate(&op.ev0[0])); SIVO_HIP(hipEventCreate(&op.ev1[0])); }
+            SIVO_HIP(hipEventRecord(op.ev0[0], st));
         }
         if (S.cls_pk_now) launch_conv_cls_h3(a, st);
         else launch_conv_cls_mc(a, st);
-        if (S.profile) SIVO_HIP(hipEventRecord(op.ev1, st));
+        if (S.profile) SIVO_HIP(hipEventRecord(op.ev1[0], st));
     } else {
         if (S.cls_op >= 0) S.ops[S.cls_op].mc_fused_last = false;
         if (d_prob_sum || d_prob || S.d_sum64)
@@ -725,10 +732,11 @@ extern "C" int sivo_segnet_profile(sivo_segnet_t h, int enable) {
         DeviceGuard dg(h->device);
         if (h->profile) harvest(*h);
         h->profile = enable != 0;
-        h->profile_mfma_only = enable == 3 || enable == 4;
-        if (enable == 2 || enable == 3)   // reset the accumulators
+        h->profile_mfma_only = enable >= 3 && enable <= 6;
+        h->profile_keep_lanes = enable == 5 || enable == 6;
+        if (enable == 2 || enable == 3 || enable == 5)   // reset the accumulators
             for (Op &op : h->ops) {
-                op.ms_total = 0.0; op.launches = 0; op.w4_launches = 0;
+                op.ms_total = 0.0; op.launches = 0; op.w4_launches = 0; op.kernel_launches = 0;
                 op.w4_ms[0] = op.w4_ms[1] = op.w4_ms[2] = 0.0;
             }
         return SIVO_OK;
@@ -785,7 +793,7 @@ extern "C" int sivo_segnet_profile_read(sivo_segnet_t h, SivoOpProfile *out, int
             p.bytes_per_sample = op.bytes;
             p.ms_total = op.ms_total;
             p.launches = op.launches;
-            p.kernel_launches = op.launches;
+            p.kernel_launches = op.kernel_launches;
         }
         return SIVO_OK;
     });

@@ -92,10 +92,12 @@ struct Op {
                                // in d_wd3, d3_uscale / d3_vscale / d3_vmax as for a direct f16x3 layer.  The bf16x6 form stays resident (fallback)
     bool wino4 = false;        // conv_wino4.hip: F(4x4,3x3) as input transform + batched GEMM + output transform
     int wino4_group = 1;       // samples per V/M workspace pass
-    std::vector<hipEvent_t> w4_ev;                 // profiling: 4 events per group of the last launch
+    static constexpr int PROF_LANES = 4;           // (= sivo_segnet::MAX_LANES) profiling state is kept per lane: a profiled frame may keep its lanes
+    std::vector<hipEvent_t> w4_ev[PROF_LANES];     // profiling: 4 events per group of the lane's last launch
     double w4_ms[3] = {0.0, 0.0, 0.0};             // input transform, GEMM, output transform
-    int w4_groups_last = 0, w4_launches = 0;
-    bool timed_last = false, w4_gemm_only_last = false;
+    int w4_groups_last[PROF_LANES] = {0, 0, 0, 0}, w4_launches = 0;
+    unsigned timed_mask = 0;                       // lanes whose last launch of this op was bracketed
+    bool w4_gemm_only_last = false;
     bool skip = false;             // Upsample fused into the following F(4x4,3x3) convolution
     bool w4_bridge = false;        // output transform fused with the next F(4x4) layer's input transform (no HBM round trip)
     bool w4_bridged_in = false;    // this layer's transformed input is written by its predecessor's bridge
@@ -113,9 +115,9 @@ struct Op {
     double flops = 0.0;
     // profiling (sivo_segnet_profile): HIP events bracket the launch on the launch stream
     std::string name, kernel;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0[PROF_LANES] = {nullptr, nullptr, nullptr, nullptr}, ev1[PROF_LANES] = {nullptr, nullptr, nullptr, nullptr};
     double ms_total = 0.0, bytes = 0.0;
-    int launches = 0, last_n = 0;
+    int launches = 0, kernel_launches = 0, last_n = 0, lane_n[PROF_LANES] = {0, 0, 0, 0};
 };
 
 
@@ -152,6 +154,7 @@ struct sivo_segnet {
     double flops_shared = 0.0, flops_sample = 0.0;
     bool profile = false, pending = false;
     bool profile_mfma_only = false;   // bracket only the MFMA kernels (convolutions / the F(4x4) GEMM): fewer events in a timed run
+    bool profile_keep_lanes = false;  // a profiled forward keeps its sample groups on their streams (events per lane; times are summed over the lanes)
     std::vector<void *> owned;
     // two-lane execution of the per-sample part: the MC samples are split in two halves that run on two streams, so the
     // tail of one lane's kernel (CUs running out of workgroups) and its launch bubbles are filled by the other lane
@@ -186,8 +189,11 @@ struct sivo_segnet {
         if (multi) sivo::segnet_multi_destroy(multi);
         for (auto &kv : bands) sivo::free_bands(kv.second);
         for (sivo::Op &op : ops) {
-            if (op.ev0) (void)hipEventDestroy(op.ev0);
-            if (op.ev1) (void)hipEventDestroy(op.ev1);
+            for (int l = 0; l < sivo::Op::PROF_LANES; ++l) {
+                if (op.ev0[l]) (void)hipEventDestroy(op.ev0[l]);
+                if (op.ev1[l]) (void)hipEventDestroy(op.ev1[l]);
+                for (hipEvent_t e : op.w4_ev[l]) (void)hipEventDestroy(e);
+            }
         }
         for (void *p : owned) (void)hipFree(p);
         if (h3_flag && owns_flag) (void)hipHostFree(const_cast<uint32_t *>(h3_flag));

@@ -15,18 +15,24 @@ TERRAIN = 8                      # bayesian_segnet.hpp:67-83: classes <= TERRAIN
 
 class StereoFramePipeline:
     def __init__(self, device=0, bf=386.1448, b=386.1448 / 718.856, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7,
-                 start_delay_s=0.0):
-        self.ex_l = orb.ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th, device=device)
-        self.ex_r = orb.ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th, device=device)
+                 start_delay_s=0.0, orb_launch_mode=None):
+        self.ex_l = orb.ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th, device=device, launch_mode=orb_launch_mode)
+        self.ex_r = orb.ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th, device=device, launch_mode=orb_launch_mode)
         self.bf, self.b = bf, b
         # Frame.cc:126-129 starts two threads per frame; here three long-lived workers (starting three Python threads per frame
         # cost 0.5 ms before the network was even enqueued: tools/frame_timeline.py)
         self.pool = ThreadPoolExecutor(max_workers=3)
         self.start_delay_s = start_delay_s
+        self._last = []              # the ORB work of the previous frame (futures)
 
     def start_orb(self, d_left, d_right):
         """ExtractORB left / right + the candidate search, Hamming matching and SAD refinement of every left key; returns the
         pending state for finish()."""
+        # One extractor holds ONE image: the previous frame's extractions and its matching (which reads both pyramids) must be over before
+        # the next image goes into the same two extractors.  With two frames in flight they normally ended a frame ago; when the GPU is
+        # so busy that they have not (round 6: one bench run in ten died of two extractions inside one extractor), this waits.
+        for f in self._last:
+            f.result()
         res = {}
 
         def run(k, ex, im):
@@ -41,7 +47,9 @@ class StereoFramePipeline:
             fl.result(); fr.result()
             (kl, dl), (kr, dr) = res["l"], res["r"]
             res["m"] = orb.stereo_match_begin(self.ex_l, self.ex_r, kl, dl, kr, dr, self.bf, self.b)
-        return res, [self.pool.submit(match)]
+        fm = self.pool.submit(match)
+        self._last = [fl, fr, fm]
+        return res, [fm]
 
     def finish(self, pending, classes_host):
         """SelectSemanticKeys (Frame.cc:177-203: class <= TERRAIN at the truncated key position) and the median cull of

@@ -19,15 +19,18 @@ def _p(a):
 class ORBextractor:
     """ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)."""
 
-    def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th_fast=20, min_th_fast=7, device=0, gaussian="rounded"):
+    def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th_fast=20, min_th_fast=7, device=0, gaussian="rounded", launch_mode=None):
         """gaussian: the OpenCV GaussianBlur 8U taps the reference build was linked with (sivo_orb_set_gaussian): "rounded" =
-        OpenCV 3.2 - 3.4.12 / 4.0 - 4.5.0 (default), "ed" = OpenCV >= 3.4.13 / >= 4.5.1."""
+        OpenCV 3.2 - 3.4.12 / 4.0 - 4.5.0 (default), "ed" = OpenCV >= 3.4.13 / >= 4.5.1.  launch_mode (sivo_orb_set_launch_mode): bits 0 - 3 = the pyramid /
+        FAST + scan + emission / blur + borders / angle + descriptor in one launch each; None = the library's default (15: four launches per image)."""
         h = C.c_void_p()
         self._L = lib()          # the library this object lives in (product, or the diagnostic build inside `with _lib.use("diag")`)
         check(self._L.sivo_orb_create(nfeatures, C.c_float(scale_factor), nlevels, ini_th_fast, min_th_fast, device, C.byref(h)))
         self._h = h
         if gaussian != "rounded":
             check(self._L.sivo_orb_set_gaussian(h, {"rounded": 0, "ed": 1}[gaussian]))
+        if launch_mode is not None:
+            check(self._L.sivo_orb_set_launch_mode(h, int(launch_mode)))
         self.nfeatures, self.nlevels, self._scale_factor = nfeatures, nlevels, scale_factor
         arrs = [np.empty(nlevels, np.float32) for _ in range(4)] + [np.empty(nlevels, np.int32)]
         check(self._L.sivo_orb_tables(h, *[_p(a) for a in arrs]))

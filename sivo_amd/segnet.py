@@ -190,10 +190,11 @@ class BayesianSegNet:
                                         conf.ctypes.data_as(C.c_void_p), ent.ctypes.data_as(C.c_void_p)))
         return classes, conf, ent
 
-    def profile(self, enable=True, reset=False, mfma_only=False):
+    def profile(self, enable=True, reset=False, mfma_only=False, keep_lanes=False):
         """Bracket every kernel of the forward with HIP events on its launch stream (mfma_only: just the convolution
-        kernels / the F(4x4,3x3) GEMM — a handful of events per forward, for use inside a timed run)."""
-        mode = (3 if reset else 4) if (enable and mfma_only) else 2 if (enable and reset) else int(bool(enable))
+        kernels / the F(4x4,3x3) GEMM — a handful of events per forward, for use inside a timed run; keep_lanes (with mfma_only): the
+        profiled forward keeps its sample groups on their streams, times are summed over the lanes)."""
+        mode = ((5 if reset else 6) if keep_lanes else (3 if reset else 4)) if (enable and mfma_only) else 2 if (enable and reset) else int(bool(enable))
         check(self._L.sivo_segnet_profile(self._h, mode))
 
     def profile_read(self):

@@ -39,6 +39,28 @@ def test_orb_synthetic_bit_exact(oracle):
     _compare(oracle, synthetic_frame(1234))
 
 
+@pytest.mark.parametrize("mode", [1, 2, 4, 8, 14, 15])
+def test_orb_launch_modes_are_bit_identical(oracle, kitti_like_bgr, mode):
+    """sivo_orb_set_launch_mode: the pyramid in one launch (bit 0: footprints recomputed in LDS), FAST + scan + emission in one launch
+    (bit 1: a cell waits for the cells before it), blur + borders (bit 2), angle + descriptor (bit 3) against the oracle on two frames and
+    a geometry with few levels, and every level, candidate list, key and descriptor against mode 0 (the fifteen launches of rounds 1 - 5)
+    on the same extractor parameters."""
+    for gray, kw in ((oracle.bgr2gray(kitti_like_bgr), {}), (synthetic_frame(9), {}), (synthetic_frame(5, 97, 131), dict(nfeatures=50, nlevels=3, scale_factor=1.5))):
+        ex_o = oracle.OrbExtractor(**kw)
+        names = {"nfeatures": "nfeatures", "scale_factor": "scale_factor", "nlevels": "nlevels"}
+        a = orb.ORBextractor(launch_mode=0, **{names[k]: v for k, v in kw.items()})
+        b = orb.ORBextractor(launch_mode=mode, **{names[k]: v for k, v in kw.items()})
+        kp_o, d_o = ex_o(gray)
+        (kp_a, d_a), (kp_b, d_b) = a(gray), b(gray)
+        for _ in range(3):                      # (the one-launch FAST keeps an epoch across calls)
+            kp_b2, d_b2 = b(gray)
+            assert kp_b2.tobytes() == kp_b.tobytes() and np.array_equal(d_b2, d_b)
+        for l in range(ex_o.nlevels):
+            assert np.array_equal(b.image_pyramid(l, with_border=True), a.image_pyramid(l, with_border=True)), f"pyramid level {l}"
+            assert b.candidates(l).tobytes() == a.candidates(l).tobytes() == ex_o.candidates(l).tobytes(), f"FAST candidates level {l}"
+        assert kp_a.tobytes() == kp_b.tobytes() == kp_o.tobytes() and np.array_equal(d_a, d_b) and np.array_equal(d_a, d_o)
+
+
 def test_orb_gaussian_taps_of_newer_opencv_bit_exact(oracle, kitti_like_bgr):
     """sivo_orb_set_gaussian(1): the descriptor image blurred with the error-diffused taps of OpenCV >= 3.4.13 / >= 4.5.1 (18 34 48 56 ...):
     bit-exact against the oracle's restatement of that variant, same keypoints as the default variant, other descriptors."""

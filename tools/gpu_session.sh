@@ -58,10 +58,12 @@ except Exception as e: print("  no line:", e)
 PY
 ;;
     orb) timeout 900 python -m pytest tests/test_gpu_orb.py tests/test_pin_orb.py tests/test_pin_frame.py tests/test_gpu_frame_e2e.py tests/test_codeobj.py tests/test_cpp_api.py -m gpu -q > $O/orb_tests.log 2>&1; echo "orb tests rc=$?"; tail -4 $O/orb_tests.log
-        timeout 200 python tools/orb_probe.py 50 2>/dev/null | tee $O/orb_probe.log
-        rm -rf /tmp/prof_orb; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d /tmp/prof_orb -o orb -- python $R/tools/orb_probe.py 20 > /dev/null 2>&1)
-        f=$(find /tmp/prof_orb -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_orb.csv && cat $O/kernel_stats_orb.csv | cut -c1-150
-        f=$(find /tmp/prof_orb -name "*memory_copy_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/memory_copy_stats_orb.csv && cat $O/memory_copy_stats_orb.csv | cut -c1-150
+        for m in 0 15; do timeout 200 python tools/orb_probe.py 50 $m 2>/dev/null; done | tee $O/orb_probe.log
+        for m in 0 15; do
+          rm -rf /tmp/prof_orb; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_orb -o orb -- python $R/tools/orb_probe.py 20 $m > /dev/null 2>&1)
+          f=$(find /tmp/prof_orb -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_orb_mode$m.csv && cat $O/kernel_stats_orb_mode$m.csv | cut -c1-150
+        done
+        bash tools/ab_orb_modes.sh 2>&1 | tee $O/orb_launch_modes.log
 ;;
     power)   # board power / shader clock under the f16x3 GEMM and its ablations (is the kernel power-limited?)
         for v in "as built" "MFMA + LDS only" "no MFMA" "no M stores"; do

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """ORB stereo extraction + stereo match ALONE (no network beside it): wall time per stereo pair, sequential and with the two images
 extracted on two host threads (as the frame pipeline of bench.py does).  Run under `rocprofv3 --kernel-trace --stats` for the number of
-kernel launches and copies per pair (tools/gpu_session.sh step `orb`).  Usage: python tools/orb_probe.py [pairs]"""
+kernel launches and copies per pair (tools/gpu_session.sh step `orb`).  Usage: python tools/orb_probe.py [pairs [launch mode]]"""
 import os
 import sys
 import threading
@@ -16,8 +16,10 @@ from conftest import synthetic_stereo  # noqa: E402
 from sivo_amd import orb  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+MODE = int(sys.argv[2]) if len(sys.argv) > 2 else None          # sivo_orb_set_launch_mode (None: the library's default)
 L, R = synthetic_stereo(21, disparity=8)
-ex_l, ex_r = orb.ORBextractor(), orb.ORBextractor()
+ex_l, ex_r = orb.ORBextractor(launch_mode=MODE), orb.ORBextractor(launch_mode=MODE)
+print("launch mode", MODE)
 dL, dR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
 BF, B = 386.1448, 386.1448 / 718.856
 
