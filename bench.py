@@ -1004,6 +1004,11 @@ def main():
             P0 = poses.copy(); P0[2:, 9:] += rng.normal(0, 0.02, (len(poses) - 2, 3))
             X0 = pts + rng.normal(0, 0.05, pts.shape)
             optimizer.local_ba(P0, fixed, X0, edges, intr, cov_pose=19)
+            # (the configurations above leave garbage behind — handles of 20 GB, event lists —: a cyclic collection inside one of the 30 calls
+            # was the 17 - 20 ms outlier of rounds 5 / 6, profiles/r06_m_bench_line.json; alone, `--configs ba`, sigma is 0.02 ms.  calls_ms lists every call.)
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
             ts = []
             for _ in range(30):
                 t0 = time.perf_counter(); g = optimizer.local_ba(P0, fixed, X0, edges, intr, cov_pose=19); ts.append(time.perf_counter() - t0)
@@ -1013,7 +1018,8 @@ def main():
             extra.append({"name": "BASELINE configs[4]: local BA, 20 keyframes x 3000 map points (whole Optimizer::LocalBundleAdjustment solve on the GPU: "
                                   "per-edge residuals / Jacobians, Schur complement, LM, marginal covariance)",
                           "metric": "ms per LocalBundleAdjustment call (mean of 30)", "value": round(t_call * 1e3, 3), "min_ms": round(min(ts) * 1e3, 3),
-                          "median_ms": round(float(np.median(ts)) * 1e3, 3), "std_ms": round(float(np.std(ts)) * 1e3, 3), "calls": len(ts), "edges": int(nE), "lm_iterations": g["iterations"],
+                          "median_ms": round(float(np.median(ts)) * 1e3, 3), "std_ms": round(float(np.std(ts)) * 1e3, 3), "calls": len(ts),
+                          "calls_ms": [round(t * 1e3, 2) for t in ts], "edges": int(nE), "lm_iterations": g["iterations"],
                           "ms_per_lm_iteration": round(t_call * 1e3 / it, 3),
                           "roofline": {"bound": "hbm", "achieved": round(alg_bytes / t_call / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(alg_bytes / t_call / 1e9 / HBM_PEAK_GBS, 5),

@@ -89,10 +89,10 @@ class FirstUse {
     bool always_ = false;      // device index unknown: run the block every time, unlocked
 };
 
-// Environment switches.  The product library reads EIGHT: SIVO_LANES, SIVO_GEMM, SIVO_D3, SIVO_D3_PK, SIVO_CONV7,
-// SIVO_WINO4_MB, SIVO_ORB_PRIO, SIVO_DEBUG_SYNC.  Every other one selects between kernel forms for A/B measurements, bit-identity tests
-// and fault injection (SIVO_H3_BOOST, SIVO_MULTI_EMULATE ...): those exist only in libsivo_hip_diag.so (`make diag`: every source
-// compiled with -DSIVO_DIAG) — in the product build the macro is a null pointer and the name is not even in the binary.
+// Environment switches.  The product library reads NONE (handles take SivoSegnetOptions / setters).  The switches that
+// select between kernel forms for A/B measurements, bit-identity tests and fault injection (SIVO_H3_BOOST, SIVO_MULTI_EMULATE ...) exist
+// only in libsivo_hip_diag.so (`make diag`: every source compiled with -DSIVO_DIAG) — in the product build the macro is a null pointer
+// and the name is not even in the binary.
 #ifdef SIVO_DIAG
 #define SIVO_DIAG_ENV(name) std::getenv(name)
 #else
