@@ -88,7 +88,12 @@ __device__ __forceinline__ void h3_dma16(const void *sbase, uint32_t voff, uint3
 // registers -> LDS under the reads' latency -> MFMA, two loads, MFMA, two loads ... MFMA, DMA ...; the loads and DMA are issued
 // unconditionally (the cursors clamp at the last item: the last three stages fetch bytes nobody consumes) so that the hot path has no
 // branch around a filler and the wait at the top is always vmcnt(NV + NU).  Same MFMAs in the same order per accumulator: M bit-identical.
-template <int BM, int BN, int ABL = 0, int FORM = 1>
+// FORM 2 (round 6, second half; the product's): FORM 1 with the V' loads of a 256-tile item as EIGHT 8-byte loads per lane and stage
+// instead of sixteen 4-byte ones — lane = (tile pair m of 16, channel octet o of 4) of its wave's 32-tile block: one load per channel of the
+// octet brings tiles 2m, 2m + 1; the same 16 v_perm and 4 ds_write_b128 (two adjacent fragment pieces per plane).  The fragment order, the
+// MFMAs and their order are FORM 1's: M bit-identical.  (The V' register path costs four times the U' LDS-DMA for the same bytes,
+// half the instructions on it.)  128-tile items keep FORM 1's loads.
+template <int BM, int BN, int ABL = 0, int FORM = 2>
 __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_h3[];
     constexpr int WC = BN / 64, WT = 8 / WC;                     // wave grid: couts (64 per wave) x tiles
@@ -97,7 +102,8 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     constexpr int U0 = 2 * VBYTES;                               // LDS: V' buffers 0, 1 then U' buffers 0, 1, 2
     constexpr int NQ = BM == 256 ? 2 : 1;                        // channel octets each lane brings in per stage
     constexpr int NU = BN / 64;                                  // 1 KiB U pieces each wave copies per stage (4 or 2)
-    constexpr int NV = NQ * 8;                                   // V' loads per lane and stage
+    constexpr bool V2 = FORM == 2 && BM == 256;                  // 8-byte V' loads (two tiles per lane)
+    constexpr int NV = V2 ? 8 : NQ * 8;                          // V' load instructions per lane and stage
     static_assert(BM == 256 || BM == 128, "tile");
     static_assert(BN == 256 || BN == 128, "tile");
     static_assert(TB == 4 || TB == 2, "wave tile");
@@ -182,6 +188,49 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         }
     };
 
+    // ---- V' staging, V2: lane = (tile pair v2_m, octet v2_o) of tile block `wave`; register e of the set = channel e of the octet, .x / .y = tiles 2m / 2m + 1
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef u32x2 V2Set[8];
+    const int v2_m = lane & 15, v2_o = lane >> 4;
+    const uint32_t v2_lane_off = (uint32_t)(((int64_t)(8 * v2_o) * a.Pp + wave * 32 + 2 * v2_m) * 4);
+    const uint32_t v2_lds_off = (uint32_t)(wave * 4096 + v2_o * 512 + 2 * v2_m * 16);
+    auto load_v2_one = [&](const Cursor &c, V2Set &r, const int e) __attribute__((always_inline)) {
+        const uint64_t base = (uint64_t)(uintptr_t)(a.V + (int64_t)c.xi * a.C * a.Pp);
+        const i32x4 rs = {(int)(uint32_t)base, (int)(uint32_t)((base >> 32) & 0xffffu), (int)v_slab_bytes, 0x00020000};
+        const uint32_t vo = v2_lane_off + (uint32_t)c.pt * (BM * 4);
+        const uint32_t so = (uint32_t)((int64_t)(c.chunk * H3_KC + e) * a.Pp * 4);
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=&v"(r[e]) : "v"(vo), "s"(rs), "s"(so) : "memory");
+    };
+    auto landed2 = [&](V2Set &r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(r[e]));
+    };
+    auto write_v2 = [&](int buf, const V2Set &r) __attribute__((always_inline)) {
+        unsigned char *dst = lds_h3 + buf * VBYTES + v2_lds_off;
+        u32x4 hi0, lo0, hi1, lo1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            hi0[j] = __builtin_amdgcn_perm(r[2 * j + 1].x, r[2 * j].x, 0x05040100u);
+            lo0[j] = __builtin_amdgcn_perm(r[2 * j + 1].x, r[2 * j].x, 0x07060302u);
+            hi1[j] = __builtin_amdgcn_perm(r[2 * j + 1].y, r[2 * j].y, 0x05040100u);
+            lo1[j] = __builtin_amdgcn_perm(r[2 * j + 1].y, r[2 * j].y, 0x07060302u);
+        }
+        *reinterpret_cast<u32x4 *>(dst) = hi0;
+        *reinterpret_cast<u32x4 *>(dst + 16) = hi1;
+        *reinterpret_cast<u32x4 *>(dst + 2048) = lo0;
+        *reinterpret_cast<u32x4 *>(dst + 2048 + 16) = lo1;
+    };
+    // the register set of a stage and its operations, by form
+    using Set = std::conditional_t<V2, V2Set, VSet>;
+    auto load_set = [&](const Cursor &c, Set &r) __attribute__((always_inline)) {
+        if constexpr (V2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) load_v2_one(c, r, e);
+        } else load_v(c, r);
+    };
+    auto landed_set = [&](Set &r) __attribute__((always_inline)) { if constexpr (V2) landed2(r); else landed(r); };
+    auto write_set = [&](int buf, const Set &r) __attribute__((always_inline)) { if constexpr (V2) write_v2(buf, r); else write_v(buf, r); };
+
     // ---- U' staging: piece g = wave * NU + j of the stage: cout block g >> 2, quarter g & 3 ------------------------------
     const uint32_t lds_base = lds_addr_uniform(lds_h3);
     uint32_t u_voff[NU];
@@ -245,21 +294,21 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     Cursor cc, cu, cv;          // compute; U' DMA (two stages ahead); V' loads (three stages ahead)
     locate(cc);
     cu = cc; cv = cc;
-    VSet vA, vB;                // even iterations: vB holds V'(s + 1) and is refilled with V'(s + 3); odd iterations: vA
+    Set vA, vB;                 // even iterations: vB holds V'(s + 1) and is refilled with V'(s + 3); odd iterations: vA
     // prologue: V'(0) -> LDS; V'(1) in vB, V'(2) in flight into vA; U'(0), U'(1) in flight
-    load_v(cv, vA); advance(cv);
+    load_set(cv, vA); advance(cv);
     dma_u(cu, 0); advance(cu);
-    if (1 < total) { load_v(cv, vB); advance(cv); dma_u(cu, 1); advance(cu); }
+    if (1 < total) { load_set(cv, vB); advance(cv); dma_u(cu, 1); advance(cu); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    landed(vA); landed(vB);
-    write_v(0, vA);
-    if (2 < total) { load_v(cv, vA); advance(cv); }
+    landed_set(vA); landed_set(vB);
+    write_set(0, vA);
+    if (2 < total) { load_set(cv, vA); advance(cv); }
     int prev_ops = 2 < total ? NV : 0;              // vector-memory operations this wave issued behind the last full wait
     bool pend = false;                              // an item ended with the previous stage: its M stores are due
     int pxi = 0, ppt = 0, pkt = 0;
 
     int ub_cur = 0, ub_next2 = 2;                   // U' buffers: of stage s, and the one the DMA of stage s + 2 fills (s % 3, (s + 2) % 3)
-    auto iteration = [&](const int s, VSet &r) __attribute__((always_inline)) {
+    auto iteration = [&](const int s, Set &r) __attribute__((always_inline)) {
         // Everything but what the previous iteration issued has landed: U'(s) (DMA of iteration s - 2) and V'(s + 1) (loads of
         // iteration s - 2, in r).  This wave's V'(s) pieces are written (lgkmcnt).  Behind the barrier nobody reads V' buffer
         // (s + 1) & 1 or U' buffer (s + 2) % 3 (stage s - 1) any more.
@@ -268,11 +317,11 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         else if (prev_ops == NU) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NU) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         prev_ops = 0;
-        landed(r);
+        landed_set(r);
         if (pend) { store_item(pxi, ppt, pkt); pend = false; }        // (older than this iteration's loads: a whole stage to drain)
-        if (s + 1 < total) write_v((s + 1) & 1, r);
+        if (s + 1 < total) write_set((s + 1) & 1, r);
         if (s + 3 < total) {
-            if (!(ABL & 1)) { load_v(cv, r); prev_ops += NV; }
+            if (!(ABL & 1)) { load_set(cv, r); prev_ops += NV; }
             advance(cv);
         }
         if (s + 2 < total) {
@@ -317,10 +366,10 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         }
     };
     // FORM 1: see the comment above the kernel
-    auto iteration1 = [&](const int s, VSet &r) __attribute__((always_inline)) {
+    auto iteration1 = [&](const int s, Set &r) __attribute__((always_inline)) {
         // all but the NV + NU operations of the previous iteration have landed: U'(s), and V'(s + 1) in r; this wave's V'(s) pieces are written
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NV + NU) : "memory");
-        landed(r);
+        landed_set(r);
         if (pend) { store_item(pxi, ppt, pkt); pend = false; }
         const unsigned char *vs = lds_h3 + (s & 1) * VBYTES, *us = lds_h3 + U0 + ub_cur * UBYTES;
         const int ub_fill = ub_next2;
@@ -337,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
             for (int t = 0; t < TB; ++t)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) B[t][pl] = *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048);
-            write_v((s + 1) & 1, r);                 // V'(s + 1): registers -> LDS, under the latency of the fragment reads
+            write_set((s + 1) & 1, r);               // V'(s + 1): registers -> LDS, under the latency of the fragment reads
             __builtin_amdgcn_sched_barrier(0);
             int slot = 0;
 #pragma unroll
@@ -349,16 +398,21 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
                         if (ABL & 8) acc[c][t][term] += (float)A[c][PA[term]][0] + (float)B[t][PB[term]][1];
                         else acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][PA[term]], B[t][PB[term]], acc[c][t], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
-                        // fillers behind MFMA number `slot` of the k-step: first the NV loads of V'(s + 3), two per slot, then the NU DMA pieces of U'(s + 2)
-                        if (slot < NV / 2) {
-                            if (!(ABL & 1)) { load_v_one(cv, r, (2 * slot) / 8, (2 * slot) % 8); load_v_one(cv, r, (2 * slot + 1) / 8, (2 * slot + 1) % 8); }
-                        } else if (slot < NV / 2 + NU) {
-                            if (!(ABL & 2)) dma_u_one(cu, ub_fill, slot - NV / 2);
+                        // fillers behind MFMA number `slot` of the k-step: first the loads of V'(s + 3) (one 8-byte or two 4-byte loads per slot), then
+                        // the NU DMA pieces of U'(s + 2)
+                        constexpr int LSLOTS = V2 ? NV : NV / 2;
+                        if (slot < LSLOTS) {
+                            if (!(ABL & 1)) {
+                                if constexpr (V2) load_v2_one(cv, r, slot);
+                                else { load_v_one(cv, r, (2 * slot) / 8, (2 * slot) % 8); load_v_one(cv, r, (2 * slot + 1) / 8, (2 * slot + 1) % 8); }
+                            }
+                        } else if (slot < LSLOTS + NU) {
+                            if (!(ABL & 2)) dma_u_one(cu, ub_fill, slot - LSLOTS);
                         }
-                        if (slot < NV / 2 + NU) __builtin_amdgcn_sched_barrier(0);
+                        if (slot < LSLOTS + NU) __builtin_amdgcn_sched_barrier(0);
                         ++slot;
                     }
-            static_assert(NV / 2 + NU <= 6 * TB, "more fillers than MFMAs in a k-step");
+            static_assert((V2 ? NV : NV / 2) + NU <= 6 * TB, "more fillers than MFMAs in a k-step");
         }
         advance(cv);
         advance(cu);
@@ -388,7 +442,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
             if (++cc.k < my_items) locate(cc);
         }
     };
-    if (FORM == 1) {
+    if (FORM >= 1) {
         for (int s = 0; s < total; s += 2) {
             iteration1(s, vB);
             if (s + 1 < total) iteration1(s + 1, vA);
@@ -509,6 +563,14 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
 #endif
     lds_claim_note(LDS_CLAIM_GEMM_H3, lds);
 #ifdef SIVO_DIAG
+    if (const char *f = SIVO_DIAG_ENV("SIVO_H3_FORM"); f && std::atoi(f) == 1) {          // diagnostic build: FORM 1 (4-byte V' loads), for A/B
+        static int attr1[64] = {0};
+        if (FirstUse once(attr1); once)
+            for (const void *fn : {(const void *)wino4_gemm_h3_kernel<256, 256, 0, 1>, (const void *)wino4_gemm_h3_kernel<256, 128, 0, 1>})
+                SIVO_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (t.bm == 256 && t.bn == 256) { hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, 0, 1>), grid, dim3(512), lds, s, a); return; }
+        if (t.bm == 256 && t.bn == 128) { hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 128, 0, 1>), grid, dim3(512), lds, s, a); return; }
+    }
     if (const char *f = SIVO_DIAG_ENV("SIVO_H3_FORM"); f && std::atoi(f) == 0) {          // diagnostic build: the phased form of round 3 - 5, for A/B
         static int attr0[64] = {0};
         if (FirstUse once(attr0); once)

@@ -393,4 +393,33 @@ def test_trained_like_weights_through_a_caffemodel_file(oracle, kitti_like_bgr, 
         assert err < LOGIT_TOL * max(1.0, mag / 30.0)
         assert (cls != res["classes"]).mean() < 3e-3
     assert sn.gemm_status()[0] == 2                                        # the matrix-core layers stayed on f16x3
+
+    # What the guard's verdict costs and what it buys on this family: the same files through the diagnostic build with the guard off (the plan
+    # as first made: every wide layer on F(4x4)) — its error against the oracle, and the forward time of both plans (T = 2, mean of 5).
+    def ms_per_forward(net_handle):
+        d_img = torch.from_numpy(frame).cuda()
+        net_handle.forward(d_img, 5); torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for i in range(5):
+            net_handle.forward(d_img, 6 + i)
+        ev1.record(); torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / 5
+    from sivo_amd import _lib
+    t_guarded = ms_per_forward(sn)
+    os.environ["SIVO_GUARD"] = "0"
+    try:
+        with _lib.use("diag"):
+            sn0 = BayesianSegNet(BayesianSegNetParams(str(proto), str(model)), T=T)
+            lg0, masks0, *_ = _device_run(sn0, net, frame, 11)
+            t_plain = ms_per_forward(sn0)
+    finally:
+        os.environ.pop("SIVO_GUARD", None)
+    res0 = oracle.segment(net, w, frame, 11, logits_name="conv1_1_D", force_masks=masks0, shared_prefix=True)
+    err0 = float(np.abs(lg0 - res0["logits"]).max())
+    mag0 = float(np.abs(res0["logits"]).max())
+    print(f"[trained-like] plan as first made (guard off, diagnostic build): max|dlogit| {err0:.3e} = {err0 / (LOGIT_TOL * max(1.0, mag0 / 30.0)):.2f} of the budget, "
+          f"{t_plain:.2f} ms per T = 2 forward; guarded plan (the product's): {t_guarded:.2f} ms — the guard moved "
+          f"{sum(1 for r in rep['layers'] if r['level'] > 0)} of {len(rep['layers'])} guarded layers off F(4x4)")
+    del sn0
     torch.cuda.empty_cache()
