@@ -1333,23 +1333,38 @@ extern "C" int sivo_stereo_match_begin(sivo_orb_t left, sivo_orb_t right, const 
         DeviceGuard dg(left->device);
         const int TH_HIGH = 100, TH_LOW = 50, thOrbDist = (TH_HIGH + TH_LOW) / 2;
         const int nRows = left->table.lv[0].rows;
-        // row table (:454-477); the reference indexes rows unchecked — clamped here
-        std::vector<std::vector<int>> rowIdx(nRows);
-        for (int iR = 0; iR < nR; ++iR) {
+        // row table (:454-477); the reference indexes rows unchecked — clamped here.  Flat (count, then fill in key order: the order a
+        // vector per row would hold) in per-thread storage: 352 small vectors per call were a fifth of the call's host time.
+        static thread_local std::vector<int> row_off, row_idx, row_at;
+        row_off.assign((size_t)nRows + 1, 0);
+        auto span = [&](int iR, int &minr, int &maxr) {
             const float r = 2.0f * left->scale[kpR[iR].octave];
-            const int maxr = (int)std::ceil(kpR[iR].y + r), minr = (int)std::floor(kpR[iR].y - r);
-            for (int yi = minr; yi <= maxr; ++yi)
-                if (yi >= 0 && yi < nRows) rowIdx[yi].push_back(iR);
+            maxr = std::min((int)std::ceil(kpR[iR].y + r), nRows - 1); minr = std::max((int)std::floor(kpR[iR].y - r), 0);
+        };
+        for (int iR = 0; iR < nR; ++iR) {
+            int minr, maxr;
+            span(iR, minr, maxr);
+            for (int yi = minr; yi <= maxr; ++yi) ++row_off[yi + 1];
+        }
+        for (int y = 0; y < nRows; ++y) row_off[y + 1] += row_off[y];
+        row_idx.resize((size_t)row_off[nRows]);
+        row_at.assign(row_off.begin(), row_off.end() - 1);
+        for (int iR = 0; iR < nR; ++iR) {
+            int minr, maxr;
+            span(iR, minr, maxr);
+            for (int yi = minr; yi <= maxr; ++yi) row_idx[row_at[yi]++] = iR;
         }
         const float minZ = b, minD = 0, maxD = bf / minZ;
-        std::vector<int> off(nL + 1, 0), idx;
+        static thread_local std::vector<int> off, idx;
+        off.assign((size_t)nL + 1, 0); idx.clear();
         for (int iL = 0; iL < nL; ++iL) {
             off[iL] = (int)idx.size();
             const int row = (int)kpL[iL].y;
             if (row < 0 || row >= nRows) continue;
             const float uL = kpL[iL].x, minU = uL - maxD, maxU = uL - minD;
-            if (rowIdx[row].empty() || maxU < 0) continue;
-            for (int iR : rowIdx[row]) {
+            if (row_off[row] == row_off[row + 1] || maxU < 0) continue;
+            for (int j = row_off[row]; j < row_off[row + 1]; ++j) {
+                const int iR = row_idx[j];
                 if (kpR[iR].octave < kpL[iL].octave - 1 || kpR[iR].octave > kpL[iL].octave + 1) continue;
                 if (kpR[iR].x >= minU && kpR[iR].x <= maxU) idx.push_back(iR);
             }

@@ -24,23 +24,33 @@
 namespace sivo {
 namespace {
 
+// (Round 6: the candidates of a cell are a RANGE of one pooled index array — a split counts the four quadrants, takes four consecutive ranges
+// at the end of the pool and scatters the parent's indices into them in order — instead of a std::vector per cell with its own heap block:
+// thousands of small allocations per level were most of the quadtree's time, and the quadtree is half of a stand-alone extraction.  The
+// arena and the pool are kept per thread between calls.)
 struct Cell {
     int x0, y0, x1, y1;
-    std::vector<int> keys;   // indices into the candidate array, in arrival order
+    int kb = 0, ke = 0;      // candidates: pool[kb .. ke), indices into the candidate array, in arrival order
     bool leaf = false;       // holds exactly one candidate: never split again
     int prev = -1, next = -1;
     bool linked = false;
+    int size() const { return ke - kb; }
 };
 
 struct Arena {
     std::vector<Cell> cells;
+    std::vector<int> pool;
     int head = -1, tail = -1, count = 0;
 
-    int make(int x0, int y0, int x1, int y1, size_t reserve) {
+    void reset(size_t n) {
+        cells.clear(); pool.clear();
+        head = tail = -1; count = 0;
+        if (cells.capacity() < 4 * (n + 8)) cells.reserve(4 * (n + 8));
+    }
+    int make(int x0, int y0, int x1, int y1) {
         cells.emplace_back();
         Cell &c = cells.back();
         c.x0 = x0; c.y0 = y0; c.x1 = x1; c.y1 = y1;
-        c.keys.reserve(reserve);
         return (int)cells.size() - 1;   // the id doubles as the creation sequence number
     }
     void push_back(int id) {
@@ -61,7 +71,6 @@ struct Arena {
         if (c.prev >= 0) cells[c.prev].next = c.next; else head = c.next;
         if (c.next >= 0) cells[c.next].prev = c.prev; else tail = c.prev;
         c.linked = false; --count;
-        std::vector<int>().swap(c.keys);
         return nx;
     }
 };
@@ -72,22 +81,33 @@ struct Arena {
 void split(Arena &A, int id, const SivoKeyPoint *kp, std::vector<std::pair<int, int>> &grown, int *n_expand) {
     const int x0 = A.cells[id].x0, y0 = A.cells[id].y0, x1 = A.cells[id].x1, y1 = A.cells[id].y1;
     const int hx = (int)std::ceil((float)(x1 - x0) / 2), hy = (int)std::ceil((float)(y1 - y0) / 2);
-    const size_t res = A.cells[id].keys.size();
-    const int q[4] = {A.make(x0, y0, x0 + hx, y0 + hy, res), A.make(x0 + hx, y0, x1, y0 + hy, res),
-                      A.make(x0, y0 + hy, x0 + hx, y1, res), A.make(x0 + hx, y0 + hy, x1, y1, res)};
-    const int mx = x0 + hx, my = y0 + hy;
-    for (int k : A.cells[id].keys) {
-        const bool west = kp[k].x < (float)mx, north = kp[k].y < (float)my;
-        A.cells[q[west ? (north ? 0 : 2) : (north ? 1 : 3)]].keys.push_back(k);
+    const int pb = A.cells[id].kb, pe = A.cells[id].ke;
+    const int q[4] = {A.make(x0, y0, x0 + hx, y0 + hy), A.make(x0 + hx, y0, x1, y0 + hy),
+                      A.make(x0, y0 + hy, x0 + hx, y1), A.make(x0 + hx, y0 + hy, x1, y1)};
+    const float mx = (float)(x0 + hx), my = (float)(y0 + hy);
+    int cnt[4] = {0, 0, 0, 0};
+    for (int i = pb; i < pe; ++i) {
+        const int k = A.pool[i];
+        const bool west = kp[k].x < mx, north = kp[k].y < my;
+        ++cnt[west ? (north ? 0 : 2) : (north ? 1 : 3)];
+    }
+    int at[4];
+    const int base = (int)A.pool.size();
+    A.pool.resize((size_t)base + (pe - pb));
+    for (int i = 0, o = base; i < 4; ++i) { at[i] = o; A.cells[q[i]].kb = o; o += cnt[i]; A.cells[q[i]].ke = o; }
+    for (int i = pb; i < pe; ++i) {
+        const int k = A.pool[i];
+        const bool west = kp[k].x < mx, north = kp[k].y < my;
+        A.pool[at[west ? (north ? 0 : 2) : (north ? 1 : 3)]++] = k;
     }
     for (int i = 0; i < 4; ++i) {
         Cell &c = A.cells[q[i]];
-        if (c.keys.empty()) continue;
-        if (c.keys.size() == 1) c.leaf = true;
+        if (c.size() == 0) continue;
+        if (c.size() == 1) c.leaf = true;
         A.push_front(q[i]);
-        if (c.keys.size() > 1) {
+        if (c.size() > 1) {
             if (n_expand) ++*n_expand;
-            grown.emplace_back((int)c.keys.size(), q[i]);
+            grown.emplace_back(c.size(), q[i]);
         }
     }
 }
@@ -98,20 +118,27 @@ int distribute_quadtree(const SivoKeyPoint *kp, int n, int min_x, int max_x, int
                         std::vector<SivoKeyPoint> &out) {
     out.clear();
     if (n <= 0) return 0;
-    Arena A;
-    A.cells.reserve((size_t)4 * (n + 8));
+    static thread_local Arena arena;
+    Arena &A = arena;
+    A.reset((size_t)n);
     const int n_ini = (int)std::round((float)(max_x - min_x) / (max_y - min_y));
     const float h_x = (float)(max_x - min_x) / n_ini;
     std::vector<int> roots(n_ini > 0 ? n_ini : 0);
     for (int i = 0; i < n_ini; ++i) {
-        roots[i] = A.make((int)(h_x * (float)i), 0, (int)(h_x * (float)(i + 1)), max_y - min_y, n);
+        roots[i] = A.make((int)(h_x * (float)i), 0, (int)(h_x * (float)(i + 1)), max_y - min_y);
         A.push_back(roots[i]);
     }
-    for (int k = 0; k < n; ++k) A.cells[roots[(int)(kp[k].x / h_x)]].keys.push_back(k);
+    {   // the roots' candidates: count, then scatter in arrival order
+        std::vector<int> cnt(roots.size(), 0), at(roots.size(), 0);
+        for (int k = 0; k < n; ++k) ++cnt[(int)(kp[k].x / h_x)];
+        A.pool.resize((size_t)n);
+        for (size_t i = 0, o = 0; i < roots.size(); ++i) { at[i] = (int)o; A.cells[roots[i]].kb = (int)o; o += cnt[i]; A.cells[roots[i]].ke = (int)o; }
+        for (int k = 0; k < n; ++k) A.pool[at[(int)(kp[k].x / h_x)]++] = k;
+    }
     for (int it = A.head; it >= 0;) {
         Cell &c = A.cells[it];
-        if (c.keys.size() == 1) { c.leaf = true; it = c.next; }
-        else if (c.keys.empty()) it = A.unlink(it);
+        if (c.size() == 1) { c.leaf = true; it = c.next; }
+        else if (c.size() == 0) it = A.unlink(it);
         else it = c.next;
     }
 
@@ -146,10 +173,10 @@ int distribute_quadtree(const SivoKeyPoint *kp, int n, int min_x, int max_x, int
     // keep the strongest candidate of every cell (first one wins ties), in list order
     out.reserve(A.count);
     for (int it = A.head; it >= 0; it = A.cells[it].next) {
-        const std::vector<int> &ks = A.cells[it].keys;
-        int best = ks[0];
-        for (size_t k = 1; k < ks.size(); ++k)
-            if (kp[ks[k]].response > kp[best].response) best = ks[k];
+        const Cell &c = A.cells[it];
+        int best = A.pool[c.kb];
+        for (int k = c.kb + 1; k < c.ke; ++k)
+            if (kp[A.pool[k]].response > kp[best].response) best = A.pool[k];
         out.push_back(kp[best]);
     }
     return (int)out.size();
