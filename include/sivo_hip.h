@@ -319,6 +319,11 @@ int sivo_orb_extract(sivo_orb_t h, const uint8_t *gray, int rows, int cols, int 
 int sivo_orb_extract_dev(sivo_orb_t h, const uint8_t *d_gray, int rows, int cols, int step,
                          SivoKeyPoint *keypoints, uint8_t *descriptors, int capacity, int *n_out,
                          void *stream);
+/* Both images of a stereo frame at once: Frame::Frame starts two ExtractORB threads and joins them (Frame.cc:126-131).  The right
+ * extractor runs on a thread of the library's while the left one runs on the caller's; results as two sivo_orb_extract_dev calls. */
+int sivo_orb_extract_pair_dev(sivo_orb_t left, sivo_orb_t right, const uint8_t *d_left, const uint8_t *d_right, int rows, int cols,
+                              int step_left, int step_right, SivoKeyPoint *kp_left, uint8_t *desc_left, int capacity_left, int *n_left,
+                              SivoKeyPoint *kp_right, uint8_t *desc_right, int capacity_right, int *n_right, void *stream);
 /* Profiling of the extractor's kernels: enable != 0 brackets the kernel groups of every following extraction with HIP
  * events on the streams they run on and clears the accumulators.  sivo_orb_profile_read: mean ms per extraction of
  * ms5 = {pyramid (copy + resizes), blur + border, FAST cells + scan + compact, IC-angle, rBRIEF descriptors}, the number

@@ -105,6 +105,7 @@ SIGNATURES = {
     "sivo_orb_tables": [_vp, _vp, _vp, _vp, _vp, _vp],
     "sivo_orb_extract": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _pi32],
     "sivo_orb_extract_dev": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _pi32, _vp],
+    "sivo_orb_extract_pair_dev": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _pi32, _vp, _vp, _i, _pi32, _vp],
     "sivo_orb_profile": [_vp, _i],
     "sivo_orb_profile_read": [_vp, C.POINTER(_d), _pi32, C.POINTER(_d)],
     "sivo_orb_level": [_vp, _i, _vp, _sz, _pi32, _pi32],

@@ -32,6 +32,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -1237,6 +1238,27 @@ extern "C" int sivo_orb_extract_dev(sivo_orb_t h, const uint8_t *d_gray, int row
         DeviceGuard dg(h->device);
         std::lock_guard<std::mutex> one_image(h->mu);
         return extract_locked(*h, d_gray, rows, cols, step, keypoints, descriptors, capacity, n_out, (hipStream_t)stream);
+    });
+}
+
+extern "C" int sivo_orb_extract_pair_dev(sivo_orb_t left, sivo_orb_t right, const uint8_t *d_left, const uint8_t *d_right, int rows, int cols,
+                                         int step_left, int step_right, SivoKeyPoint *kp_left, uint8_t *desc_left, int capacity_left,
+                                         int *n_left, SivoKeyPoint *kp_right, uint8_t *desc_right, int capacity_right, int *n_right,
+                                         void *stream) {
+    return guarded([&] {
+        if (!left || !right || left == right || !n_left || !n_right) throw std::invalid_argument("two different extractors and both counts are needed");
+        // threadRight (Frame.cc:127): the right image on a thread of its own; its error text travels back with its return code
+        std::string right_error;
+        auto fr = std::async(std::launch::async, [&] {
+            const int rc = sivo_orb_extract_dev(right, d_right, rows, cols, step_right, kp_right, desc_right, capacity_right, n_right, stream);
+            if (rc) right_error = sivo_last_error();
+            return rc;
+        });
+        const int rc_l = sivo_orb_extract_dev(left, d_left, rows, cols, step_left, kp_left, desc_left, capacity_left, n_left, stream);
+        const int rc_r = fr.get();
+        if (rc_l) return rc_l;                      // (its message is this thread's last error already)
+        if (rc_r) return fail(rc_r, "right image: %s", right_error.c_str());
+        return SIVO_OK;
     });
 }
 

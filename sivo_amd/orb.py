@@ -110,6 +110,22 @@ def distribute_octtree(keys, min_x, max_x, min_y, max_y, n_features):
     return out[:n.value].copy()
 
 
+def extract_pair(left, right, image_left, image_right):
+    """Both images of a stereo frame (cuda uint8 tensors of one shape) through two extractors at once, as Frame::Frame's two ExtractORB
+    threads (Frame.cc:126-131; sivo_orb_extract_pair_dev).  Returns ((keys, descriptors) left, (keys, descriptors) right)."""
+    import torch
+    for im in (image_left, image_right):
+        assert im.is_cuda and im.dtype == torch.uint8 and im.dim() == 2 and im.stride(1) == 1
+    assert image_left.shape == image_right.shape
+    capl, capr = left.nfeatures * 2 + 64, right.nfeatures * 2 + 64
+    kl = np.zeros(capl, KP_DTYPE); dl = np.zeros((capl, 32), np.uint8); nl = C.c_int32(0)
+    kr = np.zeros(capr, KP_DTYPE); dr = np.zeros((capr, 32), np.uint8); nr = C.c_int32(0)
+    check(left._L.sivo_orb_extract_pair_dev(left._h, right._h, image_left.data_ptr(), image_right.data_ptr(), image_left.shape[0], image_left.shape[1],
+                                          image_left.stride(0), image_right.stride(0), _p(kl), _p(dl), capl, C.byref(nl), _p(kr), _p(dr), capr, C.byref(nr),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return (kl[:nl.value].copy(), dl[:nl.value].copy()), (kr[:nr.value].copy(), dr[:nr.value].copy())
+
+
 def stereo_match(left, right, kpL, descL, kpR, descR, bf, b):
     """Frame::ComputeStereoMatches over two extractors' resident pyramids."""
     kpL = np.ascontiguousarray(kpL, KP_DTYPE); kpR = np.ascontiguousarray(kpR, KP_DTYPE)

@@ -71,6 +71,19 @@ def test_orb_gaussian_taps_of_newer_opencv_bit_exact(oracle, kitti_like_bgr):
     _compare(oracle, synthetic_frame(5, 97, 131), nfeatures=50, nlevels=3, scale_factor=1.5, gaussian="ed")
 
 
+def test_extract_pair_equals_two_extractions():
+    """sivo_orb_extract_pair_dev (the two ExtractORB threads of Frame::Frame, Frame.cc:126-131): the same keys and descriptors as two calls."""
+    left, right = synthetic_stereo(21, disparity=8)
+    dl, dr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    a, b = orb.ORBextractor(), orb.ORBextractor()
+    for _ in range(3):
+        (kl, el), (kr, er) = orb.extract_pair(a, b, dl, dr)
+        kl1, el1 = a(dl); kr1, er1 = b(dr)
+        assert kl.tobytes() == kl1.tobytes() and np.array_equal(el, el1) and kr.tobytes() == kr1.tobytes() and np.array_equal(er, er1)
+    with pytest.raises(Exception):
+        orb.extract_pair(a, a, dl, dr)           # one extractor holds one image
+
+
 def test_orb_device_resident_input(oracle):
     gray = synthetic_frame(77)
     ex = orb.ORBextractor()

@@ -42,7 +42,13 @@ def pair_threaded():
     return len(kl), len(kr)
 
 
-for name, fn in (("sequential", pair_sequential), ("two host threads", pair_threaded)):
+def pair_library():
+    (kl, dl), (kr, dr) = orb.extract_pair(ex_l, ex_r, dL, dR)
+    orb.stereo_match(ex_l, ex_r, kl, dl, kr, dr, BF, B)
+    return len(kl), len(kr)
+
+
+for name, fn in (("sequential", pair_sequential), ("two host threads", pair_threaded), ("sivo_orb_extract_pair_dev", pair_library)):
     for _ in range(5):
         n = fn()
     torch.cuda.synchronize()
