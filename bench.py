@@ -1003,12 +1003,15 @@ def main():
             fixed = np.zeros(len(poses), np.uint8); fixed[:2] = 1
             P0 = poses.copy(); P0[2:, 9:] += rng.normal(0, 0.02, (len(poses) - 2, 3))
             X0 = pts + rng.normal(0, 0.05, pts.shape)
-            optimizer.local_ba(P0, fixed, X0, edges, intr, cov_pose=19)
-            # (the configurations above leave garbage behind — handles of 20 GB, event lists —: a cyclic collection inside one of the 30 calls
-            # was the 17 - 20 ms outlier of rounds 5 / 6, profiles/r06_m_bench_line.json; alone, `--configs ba`, sigma is 0.02 ms.  calls_ms lists every call.)
+            # (the configurations above leave garbage behind — handles of 20 GB, event lists.  Collected BEFORE the warm-up call, not between it and
+            # the timed calls: the collection takes long enough for the idle GPU to drop its clocks, and the first call behind it then took
+            # 17 - 20 ms — the "outlier" of rounds 5 / 6, always call 0 of the 30 (profiles/r06_*_bench_line.json); `--configs ba` alone never
+            # showed it.  calls_ms lists every call.)
             import gc
             gc.collect()
             torch.cuda.synchronize()
+            for _ in range(2):
+                optimizer.local_ba(P0, fixed, X0, edges, intr, cov_pose=19)
             ts = []
             for _ in range(30):
                 t0 = time.perf_counter(); g = optimizer.local_ba(P0, fixed, X0, edges, intr, cov_pose=19); ts.append(time.perf_counter() - t0)
