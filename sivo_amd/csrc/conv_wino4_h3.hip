@@ -92,7 +92,8 @@ __device__ __forceinline__ void h3_dma16(const void *sbase, uint32_t voff, uint3
 // instead of sixteen 4-byte ones — lane = (tile pair m of 16, channel octet o of 4) of its wave's 32-tile block: one load per channel of the
 // octet brings tiles 2m, 2m + 1; the same 16 v_perm and 4 ds_write_b128 (two adjacent fragment pieces per plane).  The fragment order, the
 // MFMAs and their order are FORM 1's: M bit-identical.  (The V' register path costs four times the U' LDS-DMA for the same bytes,
-// half the instructions on it.)  128-tile items keep FORM 1's loads.
+// half the instructions on it — worth 0 - 2 %, so the instruction count is not what makes it expensive.)  128-tile and
+// 256 x 128 items keep FORM 1's loads.
 template <int BM, int BN, int ABL = 0, int FORM = 2>
 __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_h3[];
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     constexpr int U0 = 2 * VBYTES;                               // LDS: V' buffers 0, 1 then U' buffers 0, 1, 2
     constexpr int NQ = BM == 256 ? 2 : 1;                        // channel octets each lane brings in per stage
     constexpr int NU = BN / 64;                                  // 1 KiB U pieces each wave copies per stage (4 or 2)
-    constexpr bool V2 = FORM == 2 && BM == 256;                  // 8-byte V' loads (two tiles per lane)
+    constexpr bool V2 = FORM == 2 && BM == 256 && BN == 256;     // 8-byte V' loads (two tiles per lane); 256 x 128 items measured 1 % slower with them
     constexpr int NV = V2 ? 8 : NQ * 8;                          // V' load instructions per lane and stage
     static_assert(BM == 256 || BM == 128, "tile");
     static_assert(BN == 256 || BN == 128, "tile");
