@@ -51,6 +51,7 @@
 #include "common.hpp"
 #include "h3_split.hpp"
 #include "segnet_kernels.hpp"
+#include "wino4_transforms.hpp"
 
 namespace sivo {
 
@@ -101,17 +102,7 @@ __device__ __forceinline__ void wino4_report(const Wino4Args &a, bool bad, float
     }
 }
 
-// 1-D input transform B^T d (points 0, +-1, +-2, inf)
-__device__ __forceinline__ void wino4_bt(const float d0, const float d1, const float d2, const float d3, const float d4,
-                                         const float d5, float *t) {
-    const float a = d4 - 4.f * d2, b = d3 - 4.f * d1, c = d4 - d2, e = 2.f * (d3 - d1);
-    t[0] = 4.f * d0 - 5.f * d2 + d4;
-    t[1] = a + b;
-    t[2] = a - b;
-    t[3] = c + e;
-    t[4] = c - e;
-    t[5] = 4.f * d1 - 5.f * d3 + d5;
-}
+// (the 1-D transforms B^T d, A^T m and the weight matrix G: wino4_transforms.hpp)
 
 constexpr int W4_TIN = 256;
 
@@ -545,16 +536,6 @@ __global__ __launch_bounds__(512, 1) void wino4_gemm_x6p_kernel(Wino4Args a, con
     }
 }
 
-// 1-D output transform A^T m
-__device__ __forceinline__ void wino4_at(const float m0, const float m1, const float m2, const float m3, const float m4,
-                                         const float m5, float *s) {
-    const float p12 = m1 + m2, q12 = m1 - m2, p34 = m3 + m4, q34 = m3 - m4;
-    s[0] = m0 + p12 + p34;
-    s[1] = q12 + 2.f * q34;
-    s[2] = p12 + 4.f * p34;
-    s[3] = q12 + 8.f * q34 + m5;
-}
-
 // grid: (ceil(P / 256), K)
 // POOL: instead of the 4x4 outputs the kernel writes the 2x2 pooled values (first strict maximum in scan order, as
 // maxpool2_kernel / Caffe), their window codes and the pooling layer's dropout — the convolution output is not stored.
@@ -766,8 +747,7 @@ int wino4_cout_pad(int cout) { return (cout + G_BN - 1) / G_BN * G_BN; }
 
 // Caffe (Cout,Cin,3,3) -> U [36][Cin][Kp] = G g G^T, evaluated in double and rounded once
 void wino4_pack_weights(const float *W, int cin, int cout, std::vector<float> &out, int *cout_pad) {
-    static const double G[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+    const auto &G = WINO4_G;
     const int Kp = wino4_cout_pad(cout);
     *cout_pad = Kp;
     out.assign((size_t)36 * cin * Kp, 0.f);

@@ -398,7 +398,9 @@ def test_trained_like_weights_through_a_caffemodel_file(oracle, kitti_like_bgr, 
     # as first made: every wide layer on F(4x4)) — its error against the oracle, and the forward time of both plans (T = 2, mean of 5).
     def ms_per_forward(net_handle):
         d_img = torch.from_numpy(frame).cuda()
-        net_handle.forward(d_img, 5); torch.cuda.synchronize()
+        for i in range(4):                       # (the oracle ran on the CPU meanwhile: the idle GPU has dropped its clocks)
+            net_handle.forward(d_img, 1 + i)
+        torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for i in range(5):
