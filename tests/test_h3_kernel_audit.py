@@ -30,6 +30,8 @@ def test_h3_gemm_machine_code_keeps_the_hand_counted_pipeline():
     assert len(kernels) == 3, [k for k, _ in kernels]
     for name, body in kernels:
         loads = set(re.findall(r"buffer_load_dword (v\d+),", body))
+        for a, b in re.findall(r"buffer_load_dwordx2 v\[(\d+):(\d+)\],", body):          # FORM 2 (256 x 256 items): 8-byte loads, two tiles per lane
+            loads |= {"v%d" % i for i in range(int(a), int(b) + 1)}
         assert len(loads) in (16, 32), (name, len(loads))          # one or two octets per lane, two register sets
         for m in re.finditer(r"v_mov_b32_e32 v\d+, (v\d+)\b", body):
             assert m.group(1) not in loads, (name, m.group(0))
