@@ -27,7 +27,6 @@
 #include "common.hpp"
 #include "lds_dma.hpp"
 #include "segnet_kernels.hpp"
-#include "wino4_transforms.hpp"
 
 namespace sivo {
 
@@ -57,12 +56,24 @@ constexpr int F_SLAB = 36 * 4 * 64;           // floats per weight slab (36 KiB)
 constexpr int F_BUF = F_PATCH + F_SLAB;
 constexpr int F_RS = 17;                      // epilogue exchange: [mt][i][tile*4 + j'][cout16 + pad]
 
-// (the 1-D transforms and G: wino4_transforms.hpp, shared with the three-kernel path)
-__device__ __forceinline__ void w4f_bt(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5, float *t) {
-    wino4_bt(d0, d1, d2, d3, d4, d5, t);
+// (Lavin's interpolation points 0, +-1, +-2, inf; the three-kernel path moved to 0, +-1, 1/2, -2 in round 6, wino4_transforms.hpp)
+__device__ __forceinline__ void w4f_bt(const float d0, const float d1, const float d2, const float d3, const float d4,
+                                       const float d5, float *t) {
+    const float a = d4 - 4.f * d2, b = d3 - 4.f * d1, c = d4 - d2, e = 2.f * (d3 - d1);
+    t[0] = 4.f * d0 - 5.f * d2 + d4;
+    t[1] = a + b;
+    t[2] = a - b;
+    t[3] = c + e;
+    t[4] = c - e;
+    t[5] = 4.f * d1 - 5.f * d3 + d5;
 }
-__device__ __forceinline__ void w4f_at(const float m0, const float m1, const float m2, const float m3, const float m4, const float m5, float *s) {
-    wino4_at(m0, m1, m2, m3, m4, m5, s);
+__device__ __forceinline__ void w4f_at(const float m0, const float m1, const float m2, const float m3, const float m4,
+                                       const float m5, float *s) {
+    const float p12 = m1 + m2, q12 = m1 - m2, p34 = m3 + m4, q34 = m3 - m4;
+    s[0] = m0 + p12 + p34;
+    s[1] = q12 + 2.f * q34;
+    s[2] = p12 + 4.f * p34;
+    s[3] = q12 + 8.f * q34 + m5;
 }
 
 // ABL (tools/conv_probe.py only; 0 in production): 1 no patch staging after the prologue, 2 no weight DMA after the prologue,
@@ -710,7 +721,8 @@ int wino4f_slab_floats() { return F_SLAB; }
 
 // Caffe (Cout,Cin,3,3) -> [ceil(Cin/4)][Cout/64][36][4 ch][16 = cout%16][4 = (cout%64)/16], U = G g G^T in double
 void wino4f_pack_weights(const float *W, int cin, int cout, std::vector<float> &out, int *cout_pad) {
-    const auto &G = WINO4_G;
+    static const double G[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
     const int ntiles = cout / 64, nchunks = (cin + 3) / 4;
     *cout_pad = cout;
     out.assign((size_t)nchunks * ntiles * F_SLAB, 0.f);

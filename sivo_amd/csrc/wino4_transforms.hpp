@@ -1,5 +1,7 @@
-// wino4_transforms.hpp — the three matrices of Winograd F(4x4,3x3), shared by the three-kernel path (conv_wino4.hip) and the fused fp32
-// kernel (conv_wino4f.hip):   Y = A^T [ (G g G^T) .* (B^T d B) ] A.
+// wino4_transforms.hpp — the three matrices of Winograd F(4x4,3x3) of the three-kernel path (conv_wino4.hip: input / bridge / output
+// transforms and the weight transform of every GEMM arithmetic):   Y = A^T [ (G g G^T) .* (B^T d B) ] A.
+// (The fused fp32 kernel of the narrow layers, conv_wino4f.hip — a fallback that runs when f16x3 is off or paused — keeps Lavin's points
+// with its own transforms and weights: its first-dimension transform is built around at most four non-zeros per row of B^T.)
 //
 // Interpolation points 0, 1, -1, 1/2, -2, infinity (round 6).  Rounds 1 - 5 used Lavin's 0, +-1, +-2: its B^T and A^T carry 4, 5 and 8,
 // and in fp32 the cancellation behind those coefficients is most of what F(4x4) loses against a direct convolution.  With one point of
