@@ -345,24 +345,31 @@ def time_segnet(sn, frame, steps, warmup, barrier, profile_every=8, events=True,
     t0 = time.perf_counter()
     for i in range(steps):
         ph = i % profile_every
+        # (switching the events off does not wait for them; they are read one frame later, when the profiled frame has long completed and the
+        # next one is already enqueued: reading them right away drained the two-frame pipeline five times in twenty frames, 2.5 % of the line)
         if events and ph == 0:
             sn.profile(True, mfma_only=True, reset=True)
         elif events and ph == 1:
-            one_lane += sn.profile_read(); sn.profile(False)
+            sn.profile(False)
+        elif events and ph == 2:
+            one_lane += sn.profile_read()
         elif events and ph == half:
             sn.profile(True, mfma_only=True, reset=True, keep_lanes=True)
         elif events and ph == half + 1:
-            two_lane += sn.profile_read(); sn.profile(False)
+            sn.profile(False)
+        elif events and ph == half + 2:
+            two_lane += sn.profile_read()
         frame(2000 + i)
     flush()                      # (frames still in flight are completed inside the timed region)
     barrier()
     elapsed = time.perf_counter() - t0
-    if events and steps % profile_every == 1:
-        one_lane += sn.profile_read()
-    elif events and steps % profile_every == half + 1:
-        two_lane += sn.profile_read()
     if events:
         sn.profile(False)
+        last = (steps - 1) % profile_every           # a profiled frame whose rows were not read inside the loop
+        if last in (0, 1):
+            one_lane += sn.profile_read()
+        elif last in (half, half + 1):
+            two_lane += sn.profile_read()
     prof_timed = (one_lane, two_lane)
     n_detail = min(steps, 10)
     sn.profile(True, reset=True)
@@ -891,9 +898,9 @@ def main():
         def segnet_config(name, kind, t, steps, parity, tag):
             _, _, net = build_net(kind, t)
             m = new_maps()
-            el, pt_, pd_, nd = time_segnet(net, lambda seed: net.segment_into(d_bgr, seed, m), steps, 2, barrier, 4, events)
+            el, pt_, pd_, nd = time_segnet(net, lambda seed: net.segment_into(d_bgr, seed, m), steps, 2, barrier, 8, events)
             ms = 1e3 * el / steps
-            r = mfma_roofline(pt_, pd_, len(range(0, steps, 4)), nd, ms, "as the main roofline; SegNet only (no ORB)", tag)
+            r = mfma_roofline(pt_, pd_, len(range(0, steps, 8)), nd, ms, "as the main roofline; SegNet only (no ORB)", tag)
             alg = (net.flops_shared + t * net.flops_per_sample) / 1e9
             del net
             torch.cuda.empty_cache()

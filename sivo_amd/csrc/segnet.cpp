@@ -730,7 +730,9 @@ extern "C" int sivo_segnet_profile(sivo_segnet_t h, int enable) {
     return guarded([&] {
         if (!h) throw std::invalid_argument("null handle");
         DeviceGuard dg(h->device);
-        if (h->profile) harvest(*h);
+        // switching profiling OFF does not wait for the events of the last profiled forward (a caller inside a throughput loop would
+        // drain its pipeline): they are harvested by the next sivo_segnet_profile_read, or before profiling is switched on again
+        if (enable != 0 && h->pending) harvest(*h);
         h->profile = enable != 0;
         h->profile_mfma_only = enable >= 3 && enable <= 6;
         h->profile_keep_lanes = enable == 5 || enable == 6;
