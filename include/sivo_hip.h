@@ -227,7 +227,8 @@ typedef struct {
                               * kernels once per sample group and reports them as three rows) */
     int32_t pad_;
 } SivoOpProfile;
-/* enable: 0 off; 1 on; 2 on + reset the accumulators; 3 like 2 but only the MFMA kernels are bracketed (convolution
+/* enable: 0 off (does not wait for the events of the last profiled forward: they are harvested by the next sivo_segnet_profile_read or
+ * before profiling is switched on again); 1 on; 2 on + reset the accumulators; 3 like 2 but only the MFMA kernels are bracketed (convolution
  * kernels and the F(4x4,3x3) GEMM): a handful of events per forward, for timing inside a throughput run; 4 like 3
  * without the reset (to profile a subset of the frames of a run); 5 / 6 like 3 / 4, but the profiled forward KEEPS its sample groups
  * on their streams (modes 1 - 4 run it in one lane, one launch per layer, so that a launch has the GPU to itself): events per lane,
