@@ -28,6 +28,7 @@ void harvest(sivo_segnet &S) {
                     op.w4_ms[k] += ms;
                 }
             op.w4_launches += op.w4_groups_last[l];
+            op.w4_groups_last[l] = 0;
             op.kernel_launches += 1;
             n += op.lane_n[l];
         }
@@ -136,9 +137,7 @@ void run_ops(sivo_segnet &S, size_t first, size_t last, int n0, int n, int sampl
                             op.w4_ev[lane].push_back(e);
                         }
                         sub = op.w4_ev[lane].data();
-                    } else {
-                        op.w4_groups_last[lane] = 0;
-                    }
+                    }       // (not profiling: the counts of an earlier profiled forward stay until they are harvested)
                     Wino4Plan plan{};
                     const bool planned = op.wino4_group >= N && S.wino4_slot_floats;
                     if (planned) {
