@@ -702,3 +702,32 @@ def test_fork_dropout_in_the_input_transform_is_bit_identical():
         a, b = fused.blob("pool3"), plain.blob("pool3")
         assert a.shape == b.shape == (T, 256, H // 8, W // 8)
         assert np.array_equal(a[:n], b[:n]) and (a[:n] == 0).mean() > 0.3
+
+
+def test_profiling_events_survive_unprofiled_forwards_and_lanes(kitti_like_bgr):
+    """sivo_segnet_profile as bench.py uses it inside its timed loop (round 6): a forward is profiled (MFMA kernels only — in one lane, or with
+    its sample groups kept on their streams), profiling is switched off WITHOUT waiting, further forwards run, and only then the rows are
+    read.  The rows must be the profiled forward's: every F(4x4) layer's GEMM and every direct convolution, one kernel launch per layer in
+    one lane and one per layer and lane with the lanes kept, the same FLOPs either way.  (The deferred read had once dropped the GEMM rows:
+    the counts of a profiled forward were cleared by the next unprofiled one.)"""
+    T, H, W = 4, 64, 128
+    text = netspec.standard_prototxt(T, H, W)
+    net = oproto.parse(text)
+    sn = BayesianSegNet(prototxt=text, weights=wts.pack(net["layers"], wts.synth_weights(net["layers"], 42)), T=T)
+    d_img = torch.from_numpy(np.ascontiguousarray(kitti_like_bgr[:H, :W])).cuda()
+    out = {}
+    for keep in (False, True):
+        sn.profile(True, mfma_only=True, reset=True, keep_lanes=keep)
+        sn.forward(d_img, 1)                      # the profiled forward
+        sn.profile(False)                         # (does not wait)
+        for s in (2, 3):
+            sn.forward(d_img, s)                  # unprofiled forwards behind it
+        rows = [r for r in sn.profile_read() if r["launches"]]
+        torch.cuda.synchronize()
+        gemm = [r for r in rows if r["kernel"].startswith("wino4_gemm")]
+        direct = [r for r in rows if r["kernel"].startswith("conv3_h3")]
+        assert len(gemm) == 15 and len(direct) >= 6, sorted({r["kernel"] for r in rows})
+        assert all(r["launches"] == 1 and r["ms_total"] > 0 for r in gemm + direct)
+        out[keep] = (sum(r["kernel_launches"] for r in gemm), sum(r["flops_per_sample"] * r["samples"] for r in gemm))
+    assert out[False][0] == 15 and out[True][0] == 30           # one launch per layer / one per layer and lane (two lanes of two samples)
+    assert out[False][1] == out[True][1]
