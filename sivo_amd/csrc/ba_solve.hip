@@ -966,7 +966,7 @@ __global__ __launch_bounds__(BA_SCHUR_T) void ba_schur_kernel(BaDev d) {
 // matrix: 3 barriers per keyframe instead of 3 per column), as are the two triangular solves.  This is the form for systems
 // that do not fit in LDS (more than 21 free keyframes: a global bundle adjustment); it works in global memory.  A local BA
 // (n <= 126) takes ba_dense_solve_lds_kernel below.
-constexpr int BA_SOLVE_T = 256;        // (1024 threads: 89 us instead of 63 — every wave repeats the diagonal block's Cholesky, four waves per SIMD take turns at it)
+constexpr int BA_SOLVE_T = 512;        // (256 threads: 59.7 us, 512: 57.1, 1024: 89 — every wave repeats the diagonal block's Cholesky and the waves of a SIMD take turns at it)
 __global__ __launch_bounds__(BA_SOLVE_T) void ba_dense_solve_kernel(BaDev d) {
     if (ba_lm_idle(d)) return;
     __shared__ int s_ok;
