@@ -80,7 +80,11 @@ __device__ __forceinline__ void h3_dma16(const void *sbase, uint32_t voff, uint3
 // statically (the stage loop is unrolled by two).  The M stores of an item are issued at the top of the NEXT iteration,
 // ahead of its loads, so that they have a whole stage to drain and never stand between a wait and the loads it leaves in flight.
 // ABL (diagnostic builds only, -DSIVO_DIAG -> libsivo_hip_diag.so, tools/h3_probe.py; results are wrong by construction):
-// 1 no V' loads after the prologue, 2 no U' DMA after the prologue, 4 no M stores, 8 no MFMAs.
+// 1 no V' loads after the prologue, 2 no U' DMA after the prologue, 4 no M stores, 8 no MFMAs, 16 V' by LDS-DMA: what the kernel would
+// cost if the transform kernels wrote V' as the LDS image of its stages ([position][32-tile block][stage][plane][octet][tile][8] fp16,
+// as U' is) — the wave of a tile block copies four 1 KiB pieces per stage into V' buffer (s + 1) & 1 right behind the barrier of stage s
+// (two V' buffers: one stage of cover), no V' registers, no v_perm, no ds_write; the same bytes of the same slab in another order.
+// 32 start skew: workgroup w of an XCD sleeps (w & 3) quarter items (~ nst / 4 stage times) before its first stage.
 // FORM 1 (round 6, the product's): the memory side of a stage is issued INSIDE its multiply phase.  In the phased form (FORM 0, kept for
 // A/B in the diagnostic build) every wave did, behind the barrier, registers -> LDS (16 v_perm, 4 ds_write_b128), 16 buffer loads, 4 LDS-DMA
 // (each with its M0 save / restore) and only then its first fragment reads — all eight waves at once, so the matrix cores of the CU stood
@@ -124,6 +128,9 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     if (lo_it + wg >= hi_it) return;
     const int my_items = (hi_it - lo_it - wg + per_xcd - 1) / per_xcd;
     const int total = my_items * nst;
+    if constexpr ((ABL & 32) != 0) {          // start skew: the workgroups of an XCD in four phases a quarter item apart (are the M stores expensive because all CUs issue them at once?)
+        for (int i = 0; i < (wg & 3) * nst / 4; ++i) __builtin_amdgcn_s_sleep(110);
+    }
 
     struct Cursor {          // a stage = (item, chunk); everything here is wave-uniform
         int k = 0, chunk = 0, xi = 0, pt = 0, kt = 0;
@@ -292,11 +299,24 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         h3_dma16(sb, u_voff[j], lds_base + U0 + ubuf * UBYTES + (wave * NU + j) * 1024);
     };
 
+    constexpr bool VD = (ABL & 16) != 0;
+    auto dma_v_one = [&](const Cursor &c, int vbuf, const int j) __attribute__((always_inline)) {
+        const int nblk = a.Pp >> 5, blk = c.pt * (BM / 32) + (BM == 256 ? wave : wave >> 1);
+        const unsigned char *sb = reinterpret_cast<const unsigned char *>(a.V) + (int64_t)c.xi * a.C * a.Pp * 4 + ((int64_t)(blk < nblk ? blk : nblk - 1) * nst + c.chunk) * 4096;
+        h3_dma16(sb, (uint32_t)(j * 1024 + lane * 16), lds_base + vbuf * VBYTES + (BM == 256 ? wave : wave >> 1) * 4096 + j * 1024);
+    };
     Cursor cc, cu, cv;          // compute; U' DMA (two stages ahead); V' loads (three stages ahead)
     locate(cc);
     cu = cc; cv = cc;
     Set vA, vB;                 // even iterations: vB holds V'(s + 1) and is refilled with V'(s + 3); odd iterations: vA
     // prologue: V'(0) -> LDS; V'(1) in vB, V'(2) in flight into vA; U'(0), U'(1) in flight
+    if constexpr (VD) {
+        for (int j = 0; j < 4; ++j) dma_v_one(cv, 0, j);
+        advance(cv);
+        dma_u(cu, 0); advance(cu);
+        if (1 < total) { dma_u(cu, 1); advance(cu); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
     load_set(cv, vA); advance(cv);
     dma_u(cu, 0); advance(cu);
     if (1 < total) { load_set(cv, vB); advance(cv); dma_u(cu, 1); advance(cu); }
@@ -304,6 +324,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     landed_set(vA); landed_set(vB);
     write_set(0, vA);
     if (2 < total) { load_set(cv, vA); advance(cv); }
+    }
     int prev_ops = 2 < total ? NV : 0;              // vector-memory operations this wave issued behind the last full wait
     bool pend = false;                              // an item ended with the previous stage: its M stores are due
     int pxi = 0, ppt = 0, pkt = 0;
@@ -369,8 +390,9 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     // FORM 1: see the comment above the kernel
     auto iteration1 = [&](const int s, Set &r) __attribute__((always_inline)) {
         // all but the NV + NU operations of the previous iteration have landed: U'(s), and V'(s + 1) in r; this wave's V'(s) pieces are written
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NV + NU) : "memory");
-        landed_set(r);
+        if constexpr (VD) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NU) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NV + NU) : "memory");
+        if constexpr (!VD) landed_set(r);
         if (pend) { store_item(pxi, ppt, pkt); pend = false; }
         const unsigned char *vs = lds_h3 + (s & 1) * VBYTES, *us = lds_h3 + U0 + ub_cur * UBYTES;
         const int ub_fill = ub_next2;
@@ -387,7 +409,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
             for (int t = 0; t < TB; ++t)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) B[t][pl] = *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048);
-            write_set((s + 1) & 1, r);               // V'(s + 1): registers -> LDS, under the latency of the fragment reads
+            if constexpr (!VD) write_set((s + 1) & 1, r);               // V'(s + 1): registers -> LDS, under the latency of the fragment reads
             __builtin_amdgcn_sched_barrier(0);
             int slot = 0;
 #pragma unroll
@@ -401,9 +423,11 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
                         __builtin_amdgcn_sched_barrier(0);
                         // fillers behind MFMA number `slot` of the k-step: first the loads of V'(s + 3) (one 8-byte or two 4-byte loads per slot), then
                         // the NU DMA pieces of U'(s + 2)
-                        constexpr int LSLOTS = V2 ? NV : NV / 2;
+                        constexpr int LSLOTS = VD ? 4 : V2 ? NV : NV / 2;
                         if (slot < LSLOTS) {
-                            if (!(ABL & 1)) {
+                            if constexpr (VD) {
+                                dma_v_one(cv, (s + 1) & 1, slot);
+                            } else if (!(ABL & 1)) {
                                 if constexpr (V2) load_v2_one(cv, r, slot);
                                 else { load_v_one(cv, r, (2 * slot) / 8, (2 * slot) % 8); load_v_one(cv, r, (2 * slot + 1) / 8, (2 * slot + 1) % 8); }
                             }
@@ -413,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
                         if (slot < LSLOTS + NU) __builtin_amdgcn_sched_barrier(0);
                         ++slot;
                     }
-            static_assert((V2 ? NV : NV / 2) + NU <= 6 * TB, "more fillers than MFMAs in a k-step");
+            static_assert((VD ? 4 : V2 ? NV : NV / 2) + NU <= 6 * TB, "more fillers than MFMAs in a k-step");
         }
         advance(cv);
         advance(cu);
@@ -556,7 +580,7 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
         hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, n>), grid, dim3(512), (size_t)160 * 1024, s, a);                         \
         return;
         switch (std::atoi(ab)) {
-            H3_ABL_CASE(1) H3_ABL_CASE(2) H3_ABL_CASE(3) H3_ABL_CASE(4) H3_ABL_CASE(7) H3_ABL_CASE(8) H3_ABL_CASE(12)
+            H3_ABL_CASE(1) H3_ABL_CASE(2) H3_ABL_CASE(3) H3_ABL_CASE(4) H3_ABL_CASE(7) H3_ABL_CASE(8) H3_ABL_CASE(12) H3_ABL_CASE(16) H3_ABL_CASE(24) H3_ABL_CASE(32) H3_ABL_CASE(36)
             default: break;
         }
 #undef H3_ABL_CASE

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the time of the f16x3 GEMM goes: the production kernel and its compile-time ablations (libsivo_hip_diag.so, `make -C
-sivo_amd/csrc diag`; SIVO_H3_ABL bits: 1 no V' loads, 2 no U' DMA, 4 no M stores, 8 no MFMAs) on the GEMM shapes of
+sivo_amd/csrc diag`; SIVO_H3_ABL bits: 1 no V' loads, 2 no U' DMA, 4 no M stores, 8 no MFMAs, 16 V' by LDS-DMA from a fragment-order slab — timing only) on the GEMM shapes of
 SegNet-Standard T = 12.  GPU box only.  Usage: python tools/h3_probe.py [iters]
 H3_PROBE_SHAPE / H3_PROBE_ONLY / H3_PROBE_SKIP select shapes / variants by substring; H3_PROBE_ZEROS=1 runs on all-zero operands
 (tools/power_probe.py wraps this script to read board power and shader clock per variant)."""
@@ -19,7 +19,9 @@ SHAPES = [("conv4_2  512->512 44x128", 512, 512, 4224), ("conv5_2  512->512 22x6
           ("conv3_3D 256->256 88x256", 256, 256, 16896), ("conv4_1D 512->256 44x128", 512, 256, 4224)]
 VARIANTS = [("as built", {}), ("FORM 1 (4-byte V' loads)", {"SIVO_H3_FORM": "1"}), ("phased form (round 5)", {"SIVO_H3_FORM": "0"}), ("no V loads", {"SIVO_H3_ABL": "1"}), ("no U DMA", {"SIVO_H3_ABL": "2"}),
             ("no loads at all", {"SIVO_H3_ABL": "3"}), ("no M stores", {"SIVO_H3_ABL": "4"}), ("MFMA + LDS only", {"SIVO_H3_ABL": "7"}),
-            ("no MFMA", {"SIVO_H3_ABL": "8"}), ("no MFMA, no stores", {"SIVO_H3_ABL": "12"})]
+            ("no MFMA", {"SIVO_H3_ABL": "8"}), ("no MFMA, no stores", {"SIVO_H3_ABL": "12"}),
+            ("V' by LDS-DMA (timing only)", {"SIVO_H3_ABL": "16"}), ("V' by LDS-DMA, no MFMA", {"SIVO_H3_ABL": "24"}),
+            ("start skew (4 phases)", {"SIVO_H3_ABL": "32"}), ("start skew, no M stores", {"SIVO_H3_ABL": "36"})]
 rng = np.random.default_rng(0)
 for name, Cc, Kp, P in SHAPES:
     if os.environ.get("H3_PROBE_SHAPE") and os.environ["H3_PROBE_SHAPE"] not in name:
