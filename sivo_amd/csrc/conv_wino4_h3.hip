@@ -85,6 +85,7 @@ __device__ __forceinline__ void h3_dma16(const void *sbase, uint32_t voff, uint3
 // as U' is) — the wave of a tile block copies four 1 KiB pieces per stage into V' buffer (s + 1) & 1 right behind the barrier of stage s
 // (two V' buffers: one stage of cover), no V' registers, no v_perm, no ds_write; the same bytes of the same slab in another order.
 // 32 start skew: workgroup w of an XCD sleeps (w & 3) quarter items (~ nst / 4 stage times) before its first stage.
+// 64 M stores with the non-temporal hint, 128 V' loads with it (results stay right under these two).
 // FORM 1 (round 6, the product's): the memory side of a stage is issued INSIDE its multiply phase.  In the phased form (FORM 0, kept for
 // A/B in the diagnostic build) every wave did, behind the barrier, registers -> LDS (16 v_perm, 4 ds_write_b128), 16 buffer loads, 4 LDS-DMA
 // (each with its M0 save / restore) and only then its first fragment reads — all eight waves at once, so the matrix cores of the CU stood
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         const i32x4 rs = {(int)(uint32_t)base, (int)(uint32_t)((base >> 32) & 0xffffu), (int)v_slab_bytes, 0x00020000};
         const uint32_t vo = v2_lane_off + (uint32_t)c.pt * (BM * 4);
         const uint32_t so = (uint32_t)((int64_t)(c.chunk * H3_KC + e) * a.Pp * 4);
-        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=&v"(r[e]) : "v"(vo), "s"(rs), "s"(so) : "memory");
+        if constexpr ((ABL & 128) != 0) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen nt" : "=&v"(r[e]) : "v"(vo), "s"(rs), "s"(so) : "memory");
+        else asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=&v"(r[e]) : "v"(vo), "s"(rs), "s"(so) : "memory");
     };
     auto landed2 = [&](V2Set &r) __attribute__((always_inline)) {
 #pragma unroll
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int k = kt * BN + (2 * wc + c) * 32 + 8 * (r >> 2) + (r & 3);
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[c][t][r]), rs, vo, (uint32_t)(((int64_t)k * a.Pp + p0) * 4), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[c][t][r]), rs, vo, (uint32_t)(((int64_t)k * a.Pp + p0) * 4), (ABL & 64) ? 2 : 0);
                     }
             }
         }
@@ -580,7 +582,7 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
         hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, n>), grid, dim3(512), (size_t)160 * 1024, s, a);                         \
         return;
         switch (std::atoi(ab)) {
-            H3_ABL_CASE(1) H3_ABL_CASE(2) H3_ABL_CASE(3) H3_ABL_CASE(4) H3_ABL_CASE(7) H3_ABL_CASE(8) H3_ABL_CASE(12) H3_ABL_CASE(16) H3_ABL_CASE(24) H3_ABL_CASE(32) H3_ABL_CASE(36)
+            H3_ABL_CASE(1) H3_ABL_CASE(2) H3_ABL_CASE(3) H3_ABL_CASE(4) H3_ABL_CASE(7) H3_ABL_CASE(8) H3_ABL_CASE(12) H3_ABL_CASE(16) H3_ABL_CASE(24) H3_ABL_CASE(32) H3_ABL_CASE(36) H3_ABL_CASE(64) H3_ABL_CASE(128) H3_ABL_CASE(192)
             default: break;
         }
 #undef H3_ABL_CASE

@@ -21,7 +21,8 @@ VARIANTS = [("as built", {}), ("FORM 1 (4-byte V' loads)", {"SIVO_H3_FORM": "1"}
             ("no loads at all", {"SIVO_H3_ABL": "3"}), ("no M stores", {"SIVO_H3_ABL": "4"}), ("MFMA + LDS only", {"SIVO_H3_ABL": "7"}),
             ("no MFMA", {"SIVO_H3_ABL": "8"}), ("no MFMA, no stores", {"SIVO_H3_ABL": "12"}),
             ("V' by LDS-DMA (timing only)", {"SIVO_H3_ABL": "16"}), ("V' by LDS-DMA, no MFMA", {"SIVO_H3_ABL": "24"}),
-            ("start skew (4 phases)", {"SIVO_H3_ABL": "32"}), ("start skew, no M stores", {"SIVO_H3_ABL": "36"})]
+            ("start skew (4 phases)", {"SIVO_H3_ABL": "32"}), ("start skew, no M stores", {"SIVO_H3_ABL": "36"}),
+            ("M stores nt", {"SIVO_H3_ABL": "64"}), ("V' loads nt", {"SIVO_H3_ABL": "128"}), ("M stores + V' loads nt", {"SIVO_H3_ABL": "192"})]
 rng = np.random.default_rng(0)
 for name, Cc, Kp, P in SHAPES:
     if os.environ.get("H3_PROBE_SHAPE") and os.environ["H3_PROBE_SHAPE"] not in name:
