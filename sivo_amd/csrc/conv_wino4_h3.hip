@@ -99,7 +99,7 @@ __device__ __forceinline__ void h3_dma16(const void *sbase, uint32_t voff, uint3
 // MFMAs and their order are FORM 1's: M bit-identical.  (The V' register path costs four times the U' LDS-DMA for the same bytes,
 // half the instructions on it — worth 0 - 2 %, so the instruction count is not what makes it expensive.)  128-tile and
 // 256 x 128 items keep FORM 1's loads.
-template <int BM, int BN, int ABL = 0, int FORM = 2>
+template <int BM, int BN, int ABL = 0, int FORM = 3>
 __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_h3[];
     constexpr int WC = BN / 64, WT = 8 / WC;                     // wave grid: couts (64 per wave) x tiles
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     constexpr int U0 = 2 * VBYTES;                               // LDS: V' buffers 0, 1 then U' buffers 0, 1, 2
     constexpr int NQ = BM == 256 ? 2 : 1;                        // channel octets each lane brings in per stage
     constexpr int NU = BN / 64;                                  // 1 KiB U pieces each wave copies per stage (4 or 2)
-    constexpr bool V2 = FORM == 2 && BM == 256 && BN == 256;     // 8-byte V' loads (two tiles per lane); 256 x 128 items measured 1 % slower with them
+    constexpr bool V2 = FORM >= 2 && BM == 256 && BN == 256;     // 8-byte V' loads (two tiles per lane); 256 x 128 items measured 1 % slower with them
     constexpr int NV = V2 ? 8 : NQ * 8;                          // V' load instructions per lane and stage
     static_assert(BM == 256 || BM == 128, "tile");
     static_assert(BN == 256 || BN == 128, "tile");
@@ -469,7 +469,134 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
             if (++cc.k < my_items) locate(cc);
         }
     };
-    if (FORM >= 1) {
+    // FORM 3: the fragment reads as a rotating software pipeline over the SAME 48 fragment registers.  PMC on FORM 2 (tools/h3_pmc.sh,
+    // profiles/r06_h3_pmc_conv4_2*.txt; the cycle picture is the same on all-zero operands, where the clock is not throttled): the matrix
+    // cores are busy 0.49 of the cycles as built and only 0.65 with NO memory side at all — all eight waves pass the barrier together, issue
+    // the twelve fragment reads of k-step 0 together (96 KiB through a 128 B / cycle LDS: ~770 cycles in which no MFMA can issue), and the
+    // compiler, short of registers, re-reads three fragments of k-step 1 right in front of their use (`ds_read ... s_waitcnt lgkmcnt(0) ...
+    // v_mfma` twice per stage).  The three products of a k-step use (A lo, B hi), (A hi, B lo), (A hi, B hi): A lo dies after the first
+    // eight MFMAs, B lo after the second eight — so the next k-step's fragments can be read into registers as they die:
+    //     k0.t0 [read A lo']  k0.t1 [read B hi']  k0.t2 [read A hi', B lo']  k1.t0  k1.t1  [BARRIER of stage s + 1; read A lo'', B hi'' of its k-step 0]  k1.t2
+    // every read is issued at least eight MFMAs (~260 cycles) ahead of its first use, the stage barrier moves one term forward (the
+    // fragments k1.t2 multiplies are in registers by then; all LDS reads of stage s are complete), and the M stores of an item stay
+    // behind its last MFMA.  Same MFMAs in the same order per accumulator: M bit-identical to FORM 0 / 1 / 2.
+    half8 fAl[2], fBh[TB];          // (A lo, B hi) of k-step 0 of the stage about to be multiplied: loop-carried
+    auto rdA = [&](const unsigned char *us, int c, int pl, int kk) __attribute__((always_inline)) {
+        return *reinterpret_cast<const half8 *>(us + a_off + c * 4096 + pl * 2048 + kk * 1024);
+    };
+    auto rdB = [&](const unsigned char *vs, int t, int pl, int kk) __attribute__((always_inline)) {
+        return *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048 + kk * 1024);
+    };
+    auto mma = [&](f32x16 &d, const half8 &x, const half8 &y, const int term) __attribute__((always_inline)) {
+        if (ABL & 8) d[term] += (float)x[0] + (float)y[1];
+        else d = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, d, 0, 0, 0);
+    };
+    auto iteration3 = [&](const int s, Set &r) __attribute__((always_inline)) {
+        // entry: the barrier of stage s is behind us (U'(s) landed, everybody's V'(s) pieces written, V'(s + 1) landed in r), fAl / fBh issued
+        landed_set(r);
+        if (pend) { store_item(pxi, ppt, pkt); pend = false; }
+        const unsigned char *vs = lds_h3 + (s & 1) * VBYTES, *us = lds_h3 + U0 + ub_cur * UBYTES;
+        const int ub_fill = ub_next2;
+        ub_cur = ub_cur == 2 ? 0 : ub_cur + 1;
+        ub_next2 = ub_next2 == 2 ? 0 : ub_next2 + 1;
+        half8 Ah0[2], Bl0[TB], Al1[2], Bh1[TB], Ah1[2], Bl1[TB];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) Ah0[c] = rdA(us, c, 0, 0);
+#pragma unroll
+        for (int t = 0; t < TB; ++t) Bl0[t] = rdB(vs, t, 1, 0);
+        write_set((s + 1) & 1, r);               // V'(s + 1): registers -> LDS
+        __builtin_amdgcn_sched_barrier(0);
+        int slot = 0;
+        constexpr int LSLOTS = VD ? 4 : V2 ? NV : NV / 2;
+        static_assert(LSLOTS + NU <= 6 * TB, "more fillers than MFMAs in a k-step");
+        auto filler = [&]() __attribute__((always_inline)) {
+            // behind MFMA number `slot` of k-step 0: the loads of V'(s + 3) (one 8-byte or two 4-byte loads per slot), then the NU DMA pieces of U'(s + 2)
+            if (slot < LSLOTS) {
+                if constexpr (VD) {
+                    dma_v_one(cv, (s + 1) & 1, slot);
+                } else if (!(ABL & 1)) {
+                    if constexpr (V2) load_v2_one(cv, r, slot);
+                    else { load_v_one(cv, r, (2 * slot) / 8, (2 * slot) % 8); load_v_one(cv, r, (2 * slot + 1) / 8, (2 * slot + 1) % 8); }
+                }
+            } else if (slot < LSLOTS + NU) {
+                if (!(ABL & 2)) dma_u_one(cu, ub_fill, slot - LSLOTS);
+            }
+            if (slot < LSLOTS + NU) __builtin_amdgcn_sched_barrier(0);
+            ++slot;
+        };
+        // k-step 0, term 0: (A lo, B hi)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < TB; ++t) { mma(acc[c][t], fAl[c], fBh[t], 0); __builtin_amdgcn_sched_barrier(0); filler(); }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) Al1[c] = rdA(us, c, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // term 1: (A hi, B lo)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < TB; ++t) { mma(acc[c][t], Ah0[c], Bl0[t], 1); __builtin_amdgcn_sched_barrier(0); filler(); }
+#pragma unroll
+        for (int t = 0; t < TB; ++t) Bh1[t] = rdB(vs, t, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // term 2: (A hi, B hi)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < TB; ++t) { mma(acc[c][t], Ah0[c], fBh[t], 2); __builtin_amdgcn_sched_barrier(0); filler(); }
+        advance(cv);
+        advance(cu);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) Ah1[c] = rdA(us, c, 0, 1);
+#pragma unroll
+        for (int t = 0; t < TB; ++t) Bl1[t] = rdB(vs, t, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-step 1, terms 0 and 1
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < TB; ++t) { mma(acc[c][t], Al1[c], Bh1[t], 0); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < TB; ++t) { mma(acc[c][t], Ah1[c], Bl1[t], 1); __builtin_amdgcn_sched_barrier(0); }
+        // the barrier of stage s + 1 (after the last stage: of nothing — the reads fetch bytes nobody multiplies): all but this iteration's
+        // NV + NU operations have landed; this wave's V'(s + 1) pieces are written and its reads of stage s complete (lgkmcnt)
+        if constexpr (VD) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NU) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NV + NU) : "memory");
+        {
+            const unsigned char *vs1 = lds_h3 + ((s + 1) & 1) * VBYTES, *us1 = lds_h3 + U0 + ub_cur * UBYTES;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) fAl[c] = rdA(us1, c, 1, 0);
+#pragma unroll
+            for (int t = 0; t < TB; ++t) fBh[t] = rdB(vs1, t, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // term 2 of k-step 1
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < TB; ++t) { mma(acc[c][t], Ah1[c], Bh1[t], 2); __builtin_amdgcn_sched_barrier(0); }
+        if (++cc.chunk == nst) {
+            pend = true; pxi = cc.xi; ppt = cc.pt; pkt = cc.kt;
+            cc.chunk = 0;
+            if (++cc.k < my_items) locate(cc);
+        }
+    };
+    if (FORM >= 3) {
+        // the barrier of stage 0 and the first reads
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NV + NU) : "memory");
+#pragma unroll
+        for (int c = 0; c < 2; ++c) fAl[c] = rdA(lds_h3 + U0, c, 1, 0);
+#pragma unroll
+        for (int t = 0; t < TB; ++t) fBh[t] = rdB(lds_h3, t, 0, 0);
+        for (int s = 0; s < total; s += 2) {
+            iteration3(s, vB);
+            if (s + 1 < total) iteration3(s + 1, vA);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (FORM >= 1) {
         for (int s = 0; s < total; s += 2) {
             iteration1(s, vB);
             if (s + 1 < total) iteration1(s + 1, vA);
@@ -597,6 +724,16 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
                 SIVO_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (t.bm == 256 && t.bn == 256) { hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, 0, 1>), grid, dim3(512), lds, s, a); return; }
         if (t.bm == 256 && t.bn == 128) { hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 128, 0, 1>), grid, dim3(512), lds, s, a); return; }
+    }
+    if (const char *f = SIVO_DIAG_ENV("SIVO_H3_FORM"); f && std::atoi(f) == 2) {          // diagnostic build: FORM 2 (the fragment reads where the compiler puts them), for A/B
+        static int attr2[64] = {0};
+        if (FirstUse once(attr2); once)
+            for (const void *fn : {(const void *)wino4_gemm_h3_kernel<256, 256, 0, 2>, (const void *)wino4_gemm_h3_kernel<128, 256, 0, 2>, (const void *)wino4_gemm_h3_kernel<256, 128, 0, 2>})
+                SIVO_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (t.bm == 256 && t.bn == 256) hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, 0, 2>), grid, dim3(512), lds, s, a);
+        else if (t.bm == 128 && t.bn == 256) hipLaunchKernelGGL((wino4_gemm_h3_kernel<128, 256, 0, 2>), grid, dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 128, 0, 2>), grid, dim3(512), lds, s, a);
+        return;
     }
     if (const char *f = SIVO_DIAG_ENV("SIVO_H3_FORM"); f && std::atoi(f) == 0) {          // diagnostic build: the phased form of round 3 - 5, for A/B
         static int attr0[64] = {0};

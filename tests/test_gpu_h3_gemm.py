@@ -60,19 +60,20 @@ def test_h3_gemm_small_values_keep_their_precision():
         assert err[:, 128:].max() < 2.0 ** -20 * vmax * np.abs(U[xi]).sum(axis=0).max() * 2.0 ** -8
 
 
-@pytest.mark.parametrize("C,Kp,P", [(64, 256, 2816), (128, 128, 2100), (512, 512, 4224)], ids=["256x256", "256x128", "conv4_2"])
+@pytest.mark.parametrize("C,Kp,P", [(64, 256, 2816), (128, 128, 2100), (512, 512, 4224), (256, 512, 1100)], ids=["256x256", "256x128", "conv4_2", "128x256"])
 def test_the_three_stage_loop_forms_are_bit_identical(C, Kp, P, monkeypatch):
-    """FORM 2 (the product's: 8-byte V' loads, two tiles per lane), FORM 1 (4-byte loads, memory side inside the multiply phase) and FORM 0
-    (the phased loop of rounds 3 - 5) issue the same MFMAs in the same order per accumulator: M word for word, on the 256-tile items the
-    new loads exist for (tile counts that are not multiples of 256: the last item is ragged).  FORM 0 / 1 live in the diagnostic build."""
+    """FORM 3 (the product's: the fragment reads as a rotating pipeline, the stage barrier one term early), FORM 2 (8-byte V' loads, two tiles
+    per lane), FORM 1 (4-byte loads, memory side inside the multiply phase) and FORM 0 (the phased loop of rounds 3 - 5) issue the same
+    MFMAs in the same order per accumulator: M word for word, also on ragged last items and on the 128-tile / 128-cout kernels.  FORM 0 - 2
+    live in the diagnostic build."""
     from sivo_amd import _lib
     rng = np.random.default_rng(C + Kp + P)
     Pp = (P + 127) // 128 * 128
     V = (rng.standard_normal((36, C, Pp)) * np.exp(rng.uniform(-2, 2, (36, C, 1)))).astype(np.float32)
     V[:, :, P:] = 0
     U = (rng.standard_normal((36, C, Kp)) * 0.03).astype(np.float32)
-    ref, _ = h3_gemm(V, U, P)                           # the product library: FORM 2
-    for form in ("2", "1", "0"):
+    ref, _ = h3_gemm(V, U, P)                           # the product library: FORM 3
+    for form in ("3", "2", "1", "0"):
         monkeypatch.setenv("SIVO_H3_FORM", form)
         with _lib.use("diag"):
             M, _ = h3_gemm(V, U, P)

@@ -17,7 +17,7 @@ lib.sivo_last_error.restype = C.c_char_p
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 SHAPES = [("conv4_2  512->512 44x128", 512, 512, 4224), ("conv5_2  512->512 22x64", 512, 512, 1152),
           ("conv3_3D 256->256 88x256", 256, 256, 16896), ("conv4_1D 512->256 44x128", 512, 256, 4224)]
-VARIANTS = [("as built", {}), ("FORM 1 (4-byte V' loads)", {"SIVO_H3_FORM": "1"}), ("phased form (round 5)", {"SIVO_H3_FORM": "0"}), ("no V loads", {"SIVO_H3_ABL": "1"}), ("no U DMA", {"SIVO_H3_ABL": "2"}),
+VARIANTS = [("as built", {}), ("FORM 2 (fragment reads left to the compiler)", {"SIVO_H3_FORM": "2"}), ("FORM 1 (4-byte V' loads)", {"SIVO_H3_FORM": "1"}), ("phased form (round 5)", {"SIVO_H3_FORM": "0"}), ("no V loads", {"SIVO_H3_ABL": "1"}), ("no U DMA", {"SIVO_H3_ABL": "2"}),
             ("no loads at all", {"SIVO_H3_ABL": "3"}), ("no M stores", {"SIVO_H3_ABL": "4"}), ("MFMA + LDS only", {"SIVO_H3_ABL": "7"}),
             ("no MFMA", {"SIVO_H3_ABL": "8"}), ("no MFMA, no stores", {"SIVO_H3_ABL": "12"}),
             ("V' by LDS-DMA (timing only)", {"SIVO_H3_ABL": "16"}), ("V' by LDS-DMA, no MFMA", {"SIVO_H3_ABL": "24"}),
@@ -48,4 +48,4 @@ for name, Cc, Kp, P in SHAPES:
         rc = lib.sivo_debug_h3_gemm(Cc, Kp, P, V.ctypes.data, U.ctypes.data, C.c_float(16.0), M.ctypes.data, iters, C.byref(ms))
         if rc:
             print(name, vname, "error", lib.sivo_last_error().decode()); continue
-        print(f"{name:26s} {vname:28s} {ms.value:8.4f} ms   {flop / ms.value / 1e9:8.1f} TFLOP/s executed", flush=True)
+        print(f"{name:26s} {vname:44s} {ms.value:8.4f} ms   {flop / ms.value / 1e9:8.1f} TFLOP/s executed", flush=True)
