@@ -86,6 +86,7 @@ __device__ __forceinline__ void h3_dma16(const void *sbase, uint32_t voff, uint3
 // (two V' buffers: one stage of cover), no V' registers, no v_perm, no ds_write; the same bytes of the same slab in another order.
 // 32 start skew: workgroup w of an XCD sleeps (w & 3) quarter items (~ nst / 4 stage times) before its first stage.
 // 64 M stores with the non-temporal hint, 128 V' loads with it (results stay right under these two).
+// 512 no stage barrier (FORM 3), 1024 no fragment reads after the first two (FORM 3): with 7 they split the MFMA + LDS time into its parts.
 // FORM 1 (round 6, the product's): the memory side of a stage is issued INSIDE its multiply phase.  In the phased form (FORM 0, kept for
 // A/B in the diagnostic build) every wave did, behind the barrier, registers -> LDS (16 v_perm, 4 ds_write_b128), 16 buffer loads, 4 LDS-DMA
 // (each with its M0 save / restore) and only then its first fragment reads — all eight waves at once, so the matrix cores of the CU stood
@@ -229,6 +230,27 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         *reinterpret_cast<u32x4 *>(dst + 16) = hi1;
         *reinterpret_cast<u32x4 *>(dst + 2048) = lo0;
         *reinterpret_cast<u32x4 *>(dst + 2048 + 16) = lo1;
+    };
+    // one ds_write_b128 of a set at a time (FORM 3 deals them over MFMA shadows): NPARTS pieces
+    constexpr int NPARTS = V2 ? 4 : 2 * NQ;
+    auto write_part = [&](int buf, const auto &r, const int j) __attribute__((always_inline)) {
+        if constexpr (V2) {
+            unsigned char *dst = lds_h3 + buf * VBYTES + v2_lds_off + (j >> 1) * 2048 + (j & 1) * 16;
+            u32x4 w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t x1 = (j & 1) ? r[2 * i + 1].y : r[2 * i + 1].x, x0 = (j & 1) ? r[2 * i].y : r[2 * i].x;
+                w[i] = __builtin_amdgcn_perm(x1, x0, (j >> 1) ? 0x07060302u : 0x05040100u);
+            }
+            *reinterpret_cast<u32x4 *>(dst) = w;
+        } else {
+            const int q = j >> 1;
+            unsigned char *dst = lds_h3 + buf * VBYTES + v_lds_off + q * 1024 + (j & 1) * 2048;
+            u32x4 w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = __builtin_amdgcn_perm(r[q][2 * i + 1], r[q][2 * i], (j & 1) ? 0x07060302u : 0x05040100u);
+            *reinterpret_cast<u32x4 *>(dst) = w;
+        }
     };
     // the register set of a stage and its operations, by form
     using Set = std::conditional_t<V2, V2Set, VSet>;
@@ -481,11 +503,15 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     // fragments k1.t2 multiplies are in registers by then; all LDS reads of stage s are complete), and the M stores of an item stay
     // behind its last MFMA.  Same MFMAs in the same order per accumulator: M bit-identical to FORM 0 / 1 / 2.
     half8 fAl[2], fBh[TB];          // (A lo, B hi) of k-step 0 of the stage about to be multiplied: loop-carried
+    half8 frozen[2];                 // ABL 1024: two fragments read once
+    if constexpr ((ABL & 1024) != 0) { frozen[0] = *reinterpret_cast<const half8 *>(lds_h3 + a_off); frozen[1] = *reinterpret_cast<const half8 *>(lds_h3 + b_off); }
     auto rdA = [&](const unsigned char *us, int c, int pl, int kk) __attribute__((always_inline)) {
-        return *reinterpret_cast<const half8 *>(us + a_off + c * 4096 + pl * 2048 + kk * 1024);
+        if constexpr ((ABL & 1024) != 0) { half8 x = frozen[0]; asm volatile("" : "+v"(x)); return x; }
+        else return *reinterpret_cast<const half8 *>(us + a_off + c * 4096 + pl * 2048 + kk * 1024);
     };
     auto rdB = [&](const unsigned char *vs, int t, int pl, int kk) __attribute__((always_inline)) {
-        return *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048 + kk * 1024);
+        if constexpr ((ABL & 1024) != 0) { half8 x = frozen[1]; asm volatile("" : "+v"(x)); return x; }
+        else return *reinterpret_cast<const half8 *>(vs + b_off + t * 4096 + pl * 2048 + kk * 1024);
     };
     auto mma = [&](f32x16 &d, const half8 &x, const half8 &y, const int term) __attribute__((always_inline)) {
         if (ABL & 8) d[term] += (float)x[0] + (float)y[1];
@@ -504,24 +530,30 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         for (int c = 0; c < 2; ++c) Ah0[c] = rdA(us, c, 0, 0);
 #pragma unroll
         for (int t = 0; t < TB; ++t) Bl0[t] = rdB(vs, t, 1, 0);
-        write_set((s + 1) & 1, r);               // V'(s + 1): registers -> LDS
         __builtin_amdgcn_sched_barrier(0);
         int slot = 0;
+        constexpr int PPS = TB == 4 ? 1 : 2;                           // write pieces per slot
+        constexpr int WSLOTS = VD ? 0 : NPARTS / PPS;                  // V'(s + 1): registers -> LDS, a ds_write_b128 (+ its four v_perm) per piece
         constexpr int LSLOTS = VD ? 4 : V2 ? NV : NV / 2;
-        static_assert(LSLOTS + NU <= 6 * TB, "more fillers than MFMAs in a k-step");
+        static_assert(WSLOTS + LSLOTS + NU <= 6 * TB, "more fillers than MFMAs in a k-step");
         auto filler = [&]() __attribute__((always_inline)) {
-            // behind MFMA number `slot` of k-step 0: the loads of V'(s + 3) (one 8-byte or two 4-byte loads per slot), then the NU DMA pieces of U'(s + 2)
-            if (slot < LSLOTS) {
+            // behind MFMA number `slot` of k-step 0: first the pieces of V'(s + 1) out of r, then the loads of V'(s + 3) INTO r (one 8-byte or two
+            // 4-byte loads per slot), then the NU DMA pieces of U'(s + 2)
+            if (slot < WSLOTS) {
+#pragma unroll
+                for (int j = 0; j < PPS; ++j) write_part((s + 1) & 1, r, slot * PPS + j);
+            } else if (slot < WSLOTS + LSLOTS) {
+                const int ls = slot - WSLOTS;
                 if constexpr (VD) {
-                    dma_v_one(cv, (s + 1) & 1, slot);
+                    dma_v_one(cv, (s + 1) & 1, ls);
                 } else if (!(ABL & 1)) {
-                    if constexpr (V2) load_v2_one(cv, r, slot);
-                    else { load_v_one(cv, r, (2 * slot) / 8, (2 * slot) % 8); load_v_one(cv, r, (2 * slot + 1) / 8, (2 * slot + 1) % 8); }
+                    if constexpr (V2) load_v2_one(cv, r, ls);
+                    else { load_v_one(cv, r, (2 * ls) / 8, (2 * ls) % 8); load_v_one(cv, r, (2 * ls + 1) / 8, (2 * ls + 1) % 8); }
                 }
-            } else if (slot < LSLOTS + NU) {
-                if (!(ABL & 2)) dma_u_one(cu, ub_fill, slot - LSLOTS);
+            } else if (slot < WSLOTS + LSLOTS + NU) {
+                if (!(ABL & 2)) dma_u_one(cu, ub_fill, slot - WSLOTS - LSLOTS);
             }
-            if (slot < LSLOTS + NU) __builtin_amdgcn_sched_barrier(0);
+            if (slot < WSLOTS + LSLOTS + NU) __builtin_amdgcn_sched_barrier(0);
             ++slot;
         };
         // k-step 0, term 0: (A lo, B hi)
@@ -545,8 +577,6 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int t = 0; t < TB; ++t) { mma(acc[c][t], Ah0[c], fBh[t], 2); __builtin_amdgcn_sched_barrier(0); filler(); }
-        advance(cv);
-        advance(cu);
 #pragma unroll
         for (int c = 0; c < 2; ++c) Ah1[c] = rdA(us, c, 0, 1);
 #pragma unroll
@@ -556,7 +586,14 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int t = 0; t < TB; ++t) { mma(acc[c][t], Al1[c], Bh1[t], 0); __builtin_amdgcn_sched_barrier(0); }
+            for (int t = 0; t < TB; ++t) {
+                mma(acc[c][t], Al1[c], Bh1[t], 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // the scalar bookkeeping of the stage in the shadow of an MFMA each (both waves of a SIMD run this code at the same time: outside
+                // a shadow the matrix pipe would stand idle for it)
+                if (c == 0 && t == 0) { advance(cv); __builtin_amdgcn_sched_barrier(0); }
+                if (c == 1 && t == 0) { advance(cu); __builtin_amdgcn_sched_barrier(0); }
+            }
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -564,6 +601,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         // the barrier of stage s + 1 (after the last stage: of nothing — the reads fetch bytes nobody multiplies): all but this iteration's
         // NV + NU operations have landed; this wave's V'(s + 1) pieces are written and its reads of stage s complete (lgkmcnt)
         if constexpr (VD) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NU) : "memory");
+        else if constexpr ((ABL & 512) != 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NV + NU) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NV + NU) : "memory");
         {
             const unsigned char *vs1 = lds_h3 + ((s + 1) & 1) * VBYTES, *us1 = lds_h3 + U0 + ub_cur * UBYTES;
@@ -577,12 +615,18 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int t = 0; t < TB; ++t) { mma(acc[c][t], Ah1[c], Bh1[t], 2); __builtin_amdgcn_sched_barrier(0); }
-        if (++cc.chunk == nst) {
-            pend = true; pxi = cc.xi; ppt = cc.pt; pkt = cc.kt;
-            cc.chunk = 0;
-            if (++cc.k < my_items) locate(cc);
-        }
+            for (int t = 0; t < TB; ++t) {
+                mma(acc[c][t], Ah1[c], Bh1[t], 2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c == 0 && t == 0) {
+                    if (++cc.chunk == nst) {
+                        pend = true; pxi = cc.xi; ppt = cc.pt; pkt = cc.kt;
+                        cc.chunk = 0;
+                        if (++cc.k < my_items) locate(cc);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
     };
     if (FORM >= 3) {
         // the barrier of stage 0 and the first reads
@@ -709,7 +753,7 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
         hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, n>), grid, dim3(512), (size_t)160 * 1024, s, a);                         \
         return;
         switch (std::atoi(ab)) {
-            H3_ABL_CASE(1) H3_ABL_CASE(2) H3_ABL_CASE(3) H3_ABL_CASE(4) H3_ABL_CASE(7) H3_ABL_CASE(8) H3_ABL_CASE(12) H3_ABL_CASE(16) H3_ABL_CASE(24) H3_ABL_CASE(32) H3_ABL_CASE(36) H3_ABL_CASE(64) H3_ABL_CASE(128) H3_ABL_CASE(192)
+            H3_ABL_CASE(1) H3_ABL_CASE(2) H3_ABL_CASE(3) H3_ABL_CASE(4) H3_ABL_CASE(7) H3_ABL_CASE(8) H3_ABL_CASE(12) H3_ABL_CASE(16) H3_ABL_CASE(24) H3_ABL_CASE(32) H3_ABL_CASE(36) H3_ABL_CASE(64) H3_ABL_CASE(128) H3_ABL_CASE(192) H3_ABL_CASE(519) H3_ABL_CASE(1031) H3_ABL_CASE(1543)
             default: break;
         }
 #undef H3_ABL_CASE

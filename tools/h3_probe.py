@@ -2,7 +2,7 @@
 """Where the time of the f16x3 GEMM goes: the production kernel and its compile-time ablations (libsivo_hip_diag.so, `make -C
 sivo_amd/csrc diag`; SIVO_H3_ABL bits: 1 no V' loads, 2 no U' DMA, 4 no M stores, 8 no MFMAs, 16 V' by LDS-DMA from a fragment-order slab — timing only) on the GEMM shapes of
 SegNet-Standard T = 12.  GPU box only.  Usage: python tools/h3_probe.py [iters]
-H3_PROBE_SHAPE / H3_PROBE_ONLY / H3_PROBE_SKIP select shapes / variants by substring; H3_PROBE_ZEROS=1 runs on all-zero operands
+H3_PROBE_SHAPE / H3_PROBE_ONLY (comma-separated) / H3_PROBE_SKIP select shapes / variants by substring; H3_PROBE_ZEROS=1 runs on all-zero operands
 (tools/power_probe.py wraps this script to read board power and shader clock per variant)."""
 import ctypes as C
 import os
@@ -22,7 +22,7 @@ VARIANTS = [("as built", {}), ("FORM 2 (fragment reads left to the compiler)", {
             ("no MFMA", {"SIVO_H3_ABL": "8"}), ("no MFMA, no stores", {"SIVO_H3_ABL": "12"}),
             ("V' by LDS-DMA (timing only)", {"SIVO_H3_ABL": "16"}), ("V' by LDS-DMA, no MFMA", {"SIVO_H3_ABL": "24"}),
             ("start skew (4 phases)", {"SIVO_H3_ABL": "32"}), ("start skew, no M stores", {"SIVO_H3_ABL": "36"}),
-            ("M stores nt", {"SIVO_H3_ABL": "64"}), ("V' loads nt", {"SIVO_H3_ABL": "128"}), ("M stores + V' loads nt", {"SIVO_H3_ABL": "192"})]
+            ("MFMA + LDS, no barrier", {"SIVO_H3_ABL": "519"}), ("MFMA + barrier, no fragment reads", {"SIVO_H3_ABL": "1031"}), ("MFMA alone", {"SIVO_H3_ABL": "1543"}), ("M stores nt", {"SIVO_H3_ABL": "64"}), ("V' loads nt", {"SIVO_H3_ABL": "128"}), ("M stores + V' loads nt", {"SIVO_H3_ABL": "192"})]
 rng = np.random.default_rng(0)
 for name, Cc, Kp, P in SHAPES:
     if os.environ.get("H3_PROBE_SHAPE") and os.environ["H3_PROBE_SHAPE"] not in name:
@@ -35,7 +35,7 @@ for name, Cc, Kp, P in SHAPES:
     M = np.empty((36, Kp, Pp), np.float32)
     flop = 2.0 * 36 * Cc * Kp * P * 3          # executed fp16 products
     for vname, env in VARIANTS:
-        if os.environ.get("H3_PROBE_ONLY") and os.environ["H3_PROBE_ONLY"] not in vname:
+        if os.environ.get("H3_PROBE_ONLY") and not any(k in vname for k in os.environ["H3_PROBE_ONLY"].split(",")):
             continue
         if os.environ.get("H3_PROBE_SKIP") and os.environ["H3_PROBE_SKIP"] in vname:
             continue
