@@ -285,7 +285,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     };
     clear_acc();
     const uint32_t b_off = (uint32_t)((lh * D_NPX + (2 * rp) * D_PW + ch * 32 + ln) * 16), a_off = (uint32_t)(lane * 16);
-    half8 A[2][2][2], B[2][2][2];       // [tap parity][block / row][plane]
+    // [fragment set][block / row][plane]; sets 0 / 1 = the tap's parity; set 2 (packed forms): tap 0 of a stage, read under the LAST tap of the
+    // stage before it (which sits in set 0) — see the packed iterations
+    half8 A[3][2][2], B[3][2][2];
     auto fetch = [&](int buf, int t, int par) __attribute__((always_inline)) {
         const unsigned char *ps = lds_d + buf * PB + b_off, *us = lds_d + U0 + buf * D_UBYTES + a_off;
         const int ky = t / 3, kx = t - 3 * ky;
@@ -596,13 +598,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             constexpr bool MORE = decltype(more_tag)::value;
             // everything this wave issued in the previous iteration has had a whole multiply to complete: patch and weights of
             // stage s (DMA), the stores of an output stage.  Behind the barrier nobody reads the buffers of stage s - 1 any more.
-            const uint32_t t0 = stamp();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const uint32_t t1 = stamp();
-            if (ep_due && wave < 2) reinterpret_cast<float *>(lds_d + EP0)[ep_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
-            ep_due = false;
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const uint32_t t2 = stamp();
+            // Entry: the barrier of stage s is behind us and tap 0's fragments are on their way into set 2 — both happened in front of the LAST tap
+            // of stage s - 1 (the prologue for s = 0): all eight waves used to pass the barrier together, issue tap 0's eight reads together
+            // (64 KiB through a 128 B / cycle LDS) and wait for them with idle matrix cores, once per stage (PMC, zero operands: conv1_2_D
+            // 519 us with nothing but MFMAs and fragment reads, 423 us of MFMA cycles; the same finding as conv_wino4_h3.hip FORM 3).
+            const uint32_t t0 = stamp(), t1 = t0, t2 = t0;
             if (pend) { store_item(pn, pty, ptx, pg, ppar); pend = false; }
             const uint32_t t3 = stamp();
             const int nb = (s + 1) & 1;
@@ -610,13 +610,22 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 ep_due = true; ep_par = cu.k & 1;
                 if (wave < 2) epv = ep_src[cu.g * 64 + lane];
             }
-            fetch(s & 1, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int slot = 0; slot < 36; ++slot) {
                 const int t = slot >> 2, q = slot & 3;
                 if (q == 0 && t + 1 < 9) fetch(s & 1, t + 1, (t + 1) & 1);
-                mfma3(t & 1, q);
+                if (MORE && slot == 32) {
+                    // the barrier of stage s + 1: everything this wave issued in this iteration has had eight taps to complete (patch and weights
+                    // of stage s + 1, the stores of an output stage); all reads of stage s are issued (tap 8's went out under tap 7) and complete
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (ep_due && wave < 2) reinterpret_cast<float *>(lds_d + EP0)[ep_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
+                    ep_due = false;
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    fetch(nb, 0, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mfma3(t == 0 ? 2 : (t & 1), q);
                 if (MORE) {
                     if (slot < 5) { if (!(ABL & 2)) dma_piece_at(sbw, nb, slot); }
                     else if (slot < 11) { if (!(ABL & 1)) dma_patch(sbp, nb, slot - 5); }
@@ -630,6 +639,12 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             if (MORE) run_advance(cu);
             end_of_stage();
         };
+        // the barrier of stage 0 and its tap 0 (what every iteration does for its successor in front of its last tap)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ep_due && wave < 2) reinterpret_cast<float *>(lds_d + EP0)[ep_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
+        ep_due = false;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        fetch(0, 0, 2);
         for (int s = 0; s + 1 < total; ++s) iteration(s, std::true_type{});
         iteration(total - 1, std::false_type{});
     } else {
@@ -721,13 +736,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         // stages ahead) bought SGPR spills here and nothing else — a pooled stage is 3 loads per lane, not 24.
         auto iteration = [&](const int s, auto more_tag) __attribute__((always_inline)) {
             constexpr bool MORE = decltype(more_tag)::value;
-            const uint32_t t0 = stamp();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const uint32_t t1 = stamp();
-            if (ep_due && wave < 2) reinterpret_cast<float *>(lds_d + EP0)[ep_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
-            ep_due = false;
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const uint32_t t2 = stamp();
+            // Entry: the barrier of stage s is behind us and tap 0's fragments are on their way into set 2 — both happened in front of the LAST tap
+            // of stage s - 1 (the prologue for s = 0): all eight waves used to pass the barrier together, issue tap 0's eight reads together
+            // (64 KiB through a 128 B / cycle LDS) and wait for them with idle matrix cores, once per stage (PMC, zero operands: conv1_2_D
+            // 519 us with nothing but MFMAs and fragment reads, 423 us of MFMA cycles; the same finding as conv_wino4_h3.hip FORM 3).
+            const uint32_t t0 = stamp(), t1 = t0, t2 = t0;
             if (pend) { store_item(pn, pty, ptx, pg, ppar); pend = false; }
             const uint32_t t3 = stamp();
             const int nb = (s + 1) & 1;
@@ -735,13 +748,22 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 ep_due = true; ep_par = cu.k & 1;
                 if (wave < 2) epv = ep_src[cu.g * 64 + lane];
             }
-            fetch(s & 1, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int slot = 0; slot < 36; ++slot) {
                 const int t = slot >> 2, q = slot & 3;
                 if (q == 0 && t + 1 < 9) fetch(s & 1, t + 1, (t + 1) & 1);
-                mfma3(t & 1, q);
+                if (MORE && slot == 32) {
+                    // the barrier of stage s + 1: everything this wave issued in this iteration has had eight taps to complete (patch and weights
+                    // of stage s + 1, the stores of an output stage); all reads of stage s are issued (tap 8's went out under tap 7) and complete
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (ep_due && wave < 2) reinterpret_cast<float *>(lds_d + EP0)[ep_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
+                    ep_due = false;
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    fetch(nb, 0, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mfma3(t == 0 ? 2 : (t & 1), q);
                 if (MORE) {
                     if (slot < 5) { if (!(ABL & 2)) dma_piece_at(sbw, nb, slot); }
                     else if (slot < 8) { if (!(ABL & 1)) load_q(slot - 5, qs); }
@@ -757,6 +779,12 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             if (MORE) run_advance(cu);
             end_of_stage();
         };
+        // the barrier of stage 0 and its tap 0 (what every iteration does for its successor in front of its last tap)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ep_due && wave < 2) reinterpret_cast<float *>(lds_d + EP0)[ep_par * 128 + tid] = wave == 0 ? epv * mscale : epv;
+        ep_due = false;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        fetch(0, 0, 2);
         for (int s = 0; s + 1 < total; ++s) iteration(s, std::true_type{});
         iteration(total - 1, std::false_type{});
     }

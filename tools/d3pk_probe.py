@@ -26,16 +26,20 @@ VARIANTS = [("as built", None), ("no patch DMA / pooled loads", 1), ("no weight 
 rng = np.random.default_rng(0)
 for name, N, Cin, Cout, H, W, unpool, pk_out in SHAPES:
     h, w = (H // 2, W // 2) if unpool else (H, W)
+    if os.environ.get("SIVO_PROBE_SHAPE") and os.environ["SIVO_PROBE_SHAPE"] not in name:
+        continue
     x = (torch.randn((N, Cin, h, w), device="cuda").clamp_min(0) * 3).contiguous()
     mask = torch.randint(0, 4, (N, Cin, h, w), device="cuda", dtype=torch.uint8) if unpool else None
     out = torch.empty((N, Cout, H, W), device="cuda")
     wt = (rng.standard_normal((Cout, Cin, 3, 3)) * (2.0 / (9 * Cin)) ** 0.5).astype(np.float32)
+    if os.environ.get("SIVO_PROBE_ZEROS"):          # all-zero operands: the same instructions, no clock throttling (tools/h3_pmc.sh)
+        x.zero_(); wt[:] = 0
     one = np.ones(Cout, np.float32)
     flop = 2.0 * 9 * Cin * Cout * H * W * N * 3
     for vname, abl in VARIANTS:
         if abl == 16 and not unpool:
             continue
-        if os.environ.get("SIVO_PROBE_ONLY") and os.environ["SIVO_PROBE_ONLY"] != vname:
+        if os.environ.get("SIVO_PROBE_ONLY") and not any(k == vname for k in os.environ["SIVO_PROBE_ONLY"].split(",")):
             continue
         os.environ.pop("SIVO_D3_ABL", None)
         os.environ.pop("SIVO_D3_STAMPS", None)
