@@ -310,6 +310,32 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         clear_acc();
     };
 
+    // ABL 4096 (timing only, M wrong): what an item would cost if it left in 8 TB 16-byte stores of WHOLE lines (a lane quad transposed so
+    // that a lane holds four consecutive tiles of one cout: 8 lanes = a 128-byte run, 8 rows per instruction) that the counter can leave in
+    // flight until the second barrier behind them.  The registers go out as they are, to the addresses such a form would write.
+    auto store_item_x4 = [&](int xi, int pt, int kt) __attribute__((always_inline)) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.M + (int64_t)xi * a.Kp * a.Pp, 0, (int)((int64_t)a.Kp * a.Pp * 4), 0x00020000);
+        const uint32_t vo = (uint32_t)(((int64_t)(4 * lh + (ln >> 3)) * a.Pp + 4 * (ln & 7)) * 4);
+        int issued = 0;
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            const int p0 = pt * BM + (wt * TB + t) * 32;
+            if (p0 < a.Pp) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int k0 = kt * BN + (2 * wc + c) * 32 + 8 * q;
+                        const u32x4 w = {__float_as_uint(acc[c][t][4 * q]), __float_as_uint(acc[c][t][4 * q + 1]), __float_as_uint(acc[c][t][4 * q + 2]), __float_as_uint(acc[c][t][4 * q + 3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(w, rs, vo, (uint32_t)(((int64_t)k0 * a.Pp + p0) * 4), 0);
+                    }
+                issued += 8;
+            }
+        }
+        clear_acc();
+        return issued;
+    };
+
     // one load / one DMA piece at a time (FORM 1 spreads them over the MFMAs of k-step 0)
     auto load_v_one = [&](const Cursor &c, VSet &r, const int q, const int e) __attribute__((always_inline)) {
         const uint64_t base = (uint64_t)(uintptr_t)(a.V + (int64_t)c.xi * a.C * a.Pp);
@@ -520,7 +546,12 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
     auto iteration3 = [&](const int s, Set &r) __attribute__((always_inline)) {
         // entry: the barrier of stage s is behind us (U'(s) landed, everybody's V'(s) pieces written, V'(s + 1) landed in r), fAl / fBh issued
         landed_set(r);
-        if (pend) { store_item(pxi, ppt, pkt); pend = false; }
+        int x4_full = 0;
+        if (pend) {
+            if constexpr ((ABL & 4096) != 0) x4_full = store_item_x4(pxi, ppt, pkt) == 8 * TB ? 1 : 0;
+            else store_item(pxi, ppt, pkt);
+            pend = false;
+        }
         const unsigned char *vs = lds_h3 + (s & 1) * VBYTES, *us = lds_h3 + U0 + ub_cur * UBYTES;
         const int ub_fill = ub_next2;
         ub_cur = ub_cur == 2 ? 0 : ub_cur + 1;
@@ -602,6 +633,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_h3_kernel(H3Args a) {
         // NV + NU operations have landed; this wave's V'(s + 1) pieces are written and its reads of stage s complete (lgkmcnt)
         if constexpr (VD) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NU) : "memory");
         else if constexpr ((ABL & 512) != 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NV + NU) : "memory");
+        else if ((ABL & 4096) && x4_full) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NV + NU + 8 * TB) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NV + NU) : "memory");
         {
             const unsigned char *vs1 = lds_h3 + ((s + 1) & 1) * VBYTES, *us1 = lds_h3 + U0 + ub_cur * UBYTES;
@@ -753,7 +785,7 @@ void launch_wino4_gemm_h3(const uint32_t *V, const void *U, float *M, int C, int
         hipLaunchKernelGGL((wino4_gemm_h3_kernel<256, 256, n>), grid, dim3(512), (size_t)160 * 1024, s, a);                         \
         return;
         switch (std::atoi(ab)) {
-            H3_ABL_CASE(1) H3_ABL_CASE(2) H3_ABL_CASE(3) H3_ABL_CASE(4) H3_ABL_CASE(7) H3_ABL_CASE(8) H3_ABL_CASE(12) H3_ABL_CASE(16) H3_ABL_CASE(24) H3_ABL_CASE(32) H3_ABL_CASE(36) H3_ABL_CASE(64) H3_ABL_CASE(128) H3_ABL_CASE(192) H3_ABL_CASE(519) H3_ABL_CASE(1031) H3_ABL_CASE(1543)
+            H3_ABL_CASE(1) H3_ABL_CASE(2) H3_ABL_CASE(3) H3_ABL_CASE(4) H3_ABL_CASE(7) H3_ABL_CASE(8) H3_ABL_CASE(12) H3_ABL_CASE(16) H3_ABL_CASE(24) H3_ABL_CASE(32) H3_ABL_CASE(36) H3_ABL_CASE(64) H3_ABL_CASE(128) H3_ABL_CASE(192) H3_ABL_CASE(4096) H3_ABL_CASE(519) H3_ABL_CASE(1031) H3_ABL_CASE(1543)
             default: break;
         }
 #undef H3_ABL_CASE

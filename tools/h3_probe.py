@@ -22,7 +22,7 @@ VARIANTS = [("as built", {}), ("FORM 2 (fragment reads left to the compiler)", {
             ("no MFMA", {"SIVO_H3_ABL": "8"}), ("no MFMA, no stores", {"SIVO_H3_ABL": "12"}),
             ("V' by LDS-DMA (timing only)", {"SIVO_H3_ABL": "16"}), ("V' by LDS-DMA, no MFMA", {"SIVO_H3_ABL": "24"}),
             ("start skew (4 phases)", {"SIVO_H3_ABL": "32"}), ("start skew, no M stores", {"SIVO_H3_ABL": "36"}),
-            ("MFMA + LDS, no barrier", {"SIVO_H3_ABL": "519"}), ("MFMA + barrier, no fragment reads", {"SIVO_H3_ABL": "1031"}), ("MFMA alone", {"SIVO_H3_ABL": "1543"}), ("M stores nt", {"SIVO_H3_ABL": "64"}), ("V' loads nt", {"SIVO_H3_ABL": "128"}), ("M stores + V' loads nt", {"SIVO_H3_ABL": "192"})]
+            ("MFMA + LDS, no barrier", {"SIVO_H3_ABL": "519"}), ("MFMA + barrier, no fragment reads", {"SIVO_H3_ABL": "1031"}), ("MFMA alone", {"SIVO_H3_ABL": "1543"}), ("whole-line 16-byte M stores, counted wait (timing only)", {"SIVO_H3_ABL": "4096"}), ("M stores nt", {"SIVO_H3_ABL": "64"}), ("V' loads nt", {"SIVO_H3_ABL": "128"}), ("M stores + V' loads nt", {"SIVO_H3_ABL": "192"})]
 rng = np.random.default_rng(0)
 for name, Cc, Kp, P in SHAPES:
     if os.environ.get("H3_PROBE_SHAPE") and os.environ["H3_PROBE_SHAPE"] not in name:
